@@ -1,0 +1,141 @@
+"""ctypes binding of ``libfc_hip.so`` (C ABI in ``include/fc_hip.h``) and its in-tree build.
+
+The product path has no CPU fallback: if the library is missing or no MI355X is visible,
+:class:`FcError` is raised — nothing silently degrades to numpy.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+CSRC = Path(__file__).resolve().parent / "csrc"
+LIB_PATH = CSRC / "libfc_hip.so"
+SOURCES = [CSRC / "fc_hip.hip", CSRC / "fc_kernels.hip.h", CSRC.parent.parent / "include" / "fc_hip.h"]
+
+FC_OK = 0
+FC_ERR_INVALID, FC_ERR_HIP, FC_ERR_DIVERGED, FC_ERR_NOT_CONVERGED, FC_ERR_NOT_READY = -1, -2, -3, -4, -5
+SLOT_BDF1, SLOT_BDF2, SLOT_MASS, SLOT_SCRATCH = 0, 1, 2, 3
+METHOD_REFINE, METHOD_BICGSTAB, METHOD_GMRES = 0, 1, 2
+
+
+class FcError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libfc_hip error {code}: {msg}")
+        self.code = code
+
+
+class FcDiverged(FcError):
+    pass
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile ``libfc_hip.so`` for gfx950 in-tree with hipcc (cross-compiles without a GPU)."""
+    if LIB_PATH.exists() and not force:
+        newest = max(p.stat().st_mtime for p in SOURCES)
+        if LIB_PATH.stat().st_mtime >= newest:
+            return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        raise FcError(FC_ERR_HIP, "hipcc not found; cannot build libfc_hip.so")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", str(LIB_PATH), str(SOURCES[0])]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise FcError(FC_ERR_HIP, f"hipcc failed:\n{res.stdout}\n{res.stderr}")
+    return LIB_PATH
+
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_lp = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_H = C.c_void_p
+
+#: name → argtypes; every entry point of include/fc_hip.h (restype is int unless noted)
+SIGNATURES: dict[str, list] = {
+    "fc_device_count": [C.POINTER(C.c_int)],
+    "fc_create": [C.POINTER(_H), C.c_int, C.c_int32, C.c_int32, C.c_int32, _dp, _ip, _ip],
+    "fc_destroy": [_H],
+    "fc_get_sizes": [_H, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
+    "fc_get_pattern": [_H, _ip, _ip],
+    "fc_assemble_matrix": [_H, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_double, C.c_double],
+    "fc_get_matrix_values": [_H, C.c_int, _dp],
+    "fc_set_matrix_values": [_H, C.c_int, _dp],
+    "fc_spmv": [_H, C.c_int, _dp, _dp],
+    "fc_bench_spmv": [_H, C.c_int, C.c_int, C.POINTER(C.c_double)],
+    "fc_set_bc": [_H, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p],
+    "fc_set_force": [_H, C.c_int32, C.c_void_p],
+    "fc_set_sensors": [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
+    "fc_set_time_scheme": [_H, C.c_double, C.c_int],
+    "fc_apply_bc": [_H, C.c_int],
+    "fc_set_permutation": [_H, _ip],
+    "fc_solver_setup": [_H, C.c_int, _ip, _ip, _dp, C.c_int32, _lp, _ip, _ip, _ip, _lp, _ip, _dp],
+    "fc_set_solver_options": [_H, C.c_int, C.c_int, C.c_double, C.c_int],
+    "fc_set_state": [_H, _dp, _dp, C.c_void_p],
+    "fc_get_state": [_H, C.c_void_p, C.c_void_p, C.c_void_p],
+    "fc_get_solution": [_H, _dp],
+    "fc_step": [_H, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_void_p],
+    "fc_run": [_H, C.c_int, C.c_int32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int],
+    "fc_assemble_rhs": [_H, C.c_int, C.c_void_p, _dp],
+    "fc_solve": [_H, C.c_int, _dp, _dp, C.c_void_p],
+    "fc_energy": [_H, _dp, C.POINTER(C.c_double)],
+    "fc_measure": [_H, _dp, C.c_void_p],
+    "fc_profile_steps": [_H, C.c_int, C.c_int32, C.c_void_p, _dp, C.POINTER(C.c_int32)],
+    "fc_bench_sweeps": [_H, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int32)],
+    "fc_algorithmic_bytes": [_H, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)],
+}
+
+_lib = None
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    """dlopen the library (building it first if the sources are newer) and set prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_missing and os.environ.get("FC_NO_BUILD", "0") != "1":
+        try:
+            build()
+        except FcError:
+            if not LIB_PATH.exists():
+                raise
+    if not LIB_PATH.exists():
+        raise FcError(FC_ERR_HIP, f"{LIB_PATH} is missing: the HIP extension is required (no CPU fallback)")
+    lib = C.CDLL(str(LIB_PATH))
+    lib.fc_last_error.restype = C.c_char_p
+    lib.fc_last_error.argtypes = []
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int) -> None:
+    if code == FC_OK:
+        return
+    msg = (load().fc_last_error() or b"").decode(errors="replace")
+    if code == FC_ERR_DIVERGED:
+        raise FcDiverged(code, msg)
+    raise FcError(code, msg)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    code = load().fc_device_count(C.byref(n))
+    return n.value if code == FC_OK else 0
+
+
+def ptr(a: np.ndarray | None):
+    """void* of a contiguous array (None → NULL)."""
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+__all__ = ["FcError", "FcDiverged", "build", "load", "check", "device_count", "ptr", "SIGNATURES", "LIB_PATH"]

@@ -1,0 +1,1071 @@
+// libfc_hip.so — host side of the C ABI declared in include/fc_hip.h.
+//
+// One fc_ctx per solver: owns the device copy of the discretisation (SoA cell tables, CSR pattern,
+// inverted scatter indices), the matrix slots, the per-order solver data (permuted system matrix +
+// nested-dissection selected-inverse factors) and all work vectors.  All work is enqueued on one
+// HIP stream per handle; the only host synchronisation in the per-step path is the final copy of
+// (y, dE, info) to pinned memory.
+#include "../../include/fc_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "fc_kernels.hip.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      return fail(FC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + \
+                                  ":" + std::to_string(__LINE__) + ")");                     \
+  } while (0)
+
+#define FCCHK(expr)          \
+  do {                       \
+    int _s = (expr);         \
+    if (_s != FC_OK) return _s; \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) return FC_OK;
+    HIPCHK(hipMalloc((void**)&p, count * sizeof(T)));
+    return FC_OK;
+  }
+  int upload(const T* src, size_t count, hipStream_t s) {
+    if (count != n || (!p && count)) FCCHK(alloc(count));
+    if (count) HIPCHK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+    return FC_OK;
+  }
+  int upload(const std::vector<T>& v, hipStream_t s) { return upload(v.data(), v.size(), s); }
+  int zero(hipStream_t s) {
+    if (n) HIPCHK(hipMemsetAsync(p, 0, n * sizeof(T), s));
+    return FC_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  ~DevBuf() { release(); }
+};
+
+struct Stage {
+  int64_t rp_begin;  // offset into f_rowptr
+  int row0;          // first destination row (permuted numbering)
+  int nrows;
+  int kind;  // 0 up, 1 down
+  int lanes;
+  double bytes;  // algorithmic bytes of this launch
+};
+
+struct OrderSys {
+  bool have_lift = false, ready = false;
+  DevBuf<double> lift;    // [n_act][N] original numbering
+  DevBuf<double> lift_p;  // [n_act][N] permuted
+  DevBuf<int> Ap_rowptr, Ap_col;
+  DevBuf<double> Ap_val;
+  int64_t Ap_nnz = 0;
+  DevBuf<int64_t> f_rowptr;
+  DevBuf<int> f_col;
+  DevBuf<double> f_val;
+  std::vector<Stage> stages;
+  double sweep_bytes = 0.0;
+};
+
+constexpr int kPinDoubles = 4096;
+
+}  // namespace
+
+struct fc_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int nv = 0, ne = 0, nc = 0, nn = 0, N = 0;
+  int64_t nnz = 0;
+  // discretisation
+  DevBuf<int> cn;       // [6][nc]
+  DevBuf<double> geom;  // [5][nc]
+  std::vector<int> h_rowptr, h_col;
+  DevBuf<int> rowptr, col;
+  DevBuf<int> mptr, midx;  // matrix scatter (per CSR slot)
+  std::vector<int> h_gptr, h_gidx;  // vector scatter per W row (original numbering)
+  DevBuf<int> gptr_p, gidx_p;       // permuted row order
+  DevBuf<double> em, ev;
+  DevBuf<double> vals[FC_NUM_SLOTS];
+  bool slot_ok[FC_NUM_SLOTS] = {false, false, false, false};
+  // BC / force / sensors
+  int n_bc = 0, n_act = 0, n_sens = 0;
+  std::vector<int> h_bc_dofs;
+  std::vector<double> h_bcprof;
+  DevBuf<unsigned char> isbc;
+  DevBuf<int> bcslot_p;
+  DevBuf<double> bcprof, fprof;
+  bool have_force = false;
+  DevBuf<int> s_rowptr, s_idx;
+  DevBuf<double> s_w;
+  // time scheme
+  double dt = 0.0;
+  int nonlinear = 1;
+  // permutation
+  bool have_perm = false;
+  std::vector<int> h_perm;
+  DevBuf<int> perm;
+  OrderSys sys[2];
+  // solver options
+  int method = FC_METHOD_REFINE, max_iter = 1, check_residual = 1;
+  double rtol = 1e-10;
+  // state + work
+  DevBuf<double> u_n, u_nn, p_n, up;
+  DevBuf<double> b, buf, xsol, tmpN, tmpN2;  // buf = [y | x] (2N)
+  DevBuf<double> partial, scal;               // reductions; scal: [0]=E [1]=r2 [2]=b2
+  DevBuf<double> uctrl, ydev, yseq, Eseq, useq;
+  DevBuf<int> flag;
+  double* pin = nullptr;  // pinned host staging
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int nblk_N = 0;
+};
+
+namespace {
+
+void tabulate(double* phi2, double* dphi2, double* phi1, double* qw) {
+  const double s15 = std::sqrt(15.0);
+  const double a1 = (6.0 - s15) / 21.0, a2 = (6.0 + s15) / 21.0;
+  const double w0 = 9.0 / 40.0, w1 = (155.0 - s15) / 1200.0, w2 = (155.0 + s15) / 1200.0;
+  double lam[7][3] = {{1.0 / 3, 1.0 / 3, 1.0 / 3}, {1 - 2 * a1, a1, a1}, {a1, 1 - 2 * a1, a1}, {a1, a1, 1 - 2 * a1},
+                      {1 - 2 * a2, a2, a2},        {a2, 1 - 2 * a2, a2}, {a2, a2, 1 - 2 * a2}};
+  const double w[7] = {w0, w1, w1, w1, w2, w2, w2};
+  const double dl[3][2] = {{-1, -1}, {1, 0}, {0, 1}};
+  const int ev[3][2] = {{1, 2}, {2, 0}, {0, 1}};
+  for (int q = 0; q < 7; ++q) {
+    qw[q] = w[q];
+    for (int i = 0; i < 3; ++i) {
+      phi1[q * 3 + i] = lam[q][i];
+      phi2[q * 6 + i] = lam[q][i] * (2 * lam[q][i] - 1);
+      for (int d = 0; d < 2; ++d) dphi2[(q * 6 + i) * 2 + d] = (4 * lam[q][i] - 1) * dl[i][d];
+    }
+    for (int k = 0; k < 3; ++k) {
+      const int i = ev[k][0], j = ev[k][1];
+      phi2[q * 6 + 3 + k] = 4 * lam[q][i] * lam[q][j];
+      for (int d = 0; d < 2; ++d) dphi2[(q * 6 + 3 + k) * 2 + d] = 4 * (lam[q][i] * dl[j][d] + lam[q][j] * dl[i][d]);
+    }
+  }
+}
+
+inline int nblocks(int64_t n, int per) { return (int)((n + per - 1) / per); }
+
+int pick_lanes(double mean_nnz) {
+  if (mean_nnz <= 6) return 4;
+  if (mean_nnz <= 20) return 8;
+  if (mean_nnz <= 48) return 16;
+  if (mean_nnz <= 160) return 32;
+  return 64;
+}
+
+template <int MODE>
+int launch_spmv(fc_ctx* h, int nrows, double mean, const int* rp, const int* col, const double* val, const double* x,
+                const double* b, double* y, double* xsave, double* partial) {
+  const int lanes = pick_lanes(mean);
+  const int rpb = 256 / lanes;
+  dim3 grid(nblocks(nrows, rpb)), block(256);
+  switch (lanes) {
+    case 4: hipLaunchKernelGGL((fc_spmv_csr<4, MODE>), grid, block, 0, h->stream, nrows, rp, col, val, x, b, y, xsave, partial); break;
+    case 8: hipLaunchKernelGGL((fc_spmv_csr<8, MODE>), grid, block, 0, h->stream, nrows, rp, col, val, x, b, y, xsave, partial); break;
+    case 16: hipLaunchKernelGGL((fc_spmv_csr<16, MODE>), grid, block, 0, h->stream, nrows, rp, col, val, x, b, y, xsave, partial); break;
+    case 32: hipLaunchKernelGGL((fc_spmv_csr<32, MODE>), grid, block, 0, h->stream, nrows, rp, col, val, x, b, y, xsave, partial); break;
+    default: hipLaunchKernelGGL((fc_spmv_csr<64, MODE>), grid, block, 0, h->stream, nrows, rp, col, val, x, b, y, xsave, partial); break;
+  }
+  HIPCHK(hipGetLastError());
+  return grid.x;
+}
+
+int launch_sweep(fc_ctx* h, const OrderSys& S, const Stage& st) {
+  const int rpb = 256 / st.lanes;
+  dim3 grid(nblocks(st.nrows, rpb)), block(256);
+  const int64_t* rp = S.f_rowptr.p + st.rp_begin;
+  double* buf = h->buf.p;
+  const int dest0 = st.kind == 0 ? st.row0 : h->N + st.row0;
+  const int acc = st.kind == 0 ? 1 : 0;
+  switch (st.lanes) {
+    case 4: hipLaunchKernelGGL((fc_nd_sweep<4>), grid, block, 0, h->stream, st.nrows, rp, S.f_col.p, S.f_val.p, buf, dest0, acc); break;
+    case 8: hipLaunchKernelGGL((fc_nd_sweep<8>), grid, block, 0, h->stream, st.nrows, rp, S.f_col.p, S.f_val.p, buf, dest0, acc); break;
+    case 16: hipLaunchKernelGGL((fc_nd_sweep<16>), grid, block, 0, h->stream, st.nrows, rp, S.f_col.p, S.f_val.p, buf, dest0, acc); break;
+    case 32: hipLaunchKernelGGL((fc_nd_sweep<32>), grid, block, 0, h->stream, st.nrows, rp, S.f_col.p, S.f_val.p, buf, dest0, acc); break;
+    default: hipLaunchKernelGGL((fc_nd_sweep<64>), grid, block, 0, h->stream, st.nrows, rp, S.f_col.p, S.f_val.p, buf, dest0, acc); break;
+  }
+  HIPCHK(hipGetLastError());
+  return FC_OK;
+}
+
+// x_p (in buf[N..2N)) = M^-1 rhs_p, rhs_p must already be in buf[0..N)
+int apply_factors(fc_ctx* h, const OrderSys& S) {
+  for (const Stage& st : S.stages)
+    if (st.nrows > 0) FCCHK(launch_sweep(h, S, st));
+  return FC_OK;
+}
+
+// permuted-ordering solve of A_p x = b_p (b_p in h->b).  Leaves x in h->xsol (+ final correction
+// in buf x-half when `defer_last` — the finish kernel then adds it).  Returns via *dx the vector to
+// add (or nullptr).  Relative residual^2 pieces go to scal[1] (|r|^2) and scal[2] (|b|^2).
+int solve_permuted(fc_ctx* h, OrderSys& S, const double** x_out, const double** dx_out) {
+  const int N = h->N;
+  const int g = nblocks(N, 256);
+  hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, h->buf.p);
+  FCCHK(apply_factors(h, S));
+  const double* x = h->buf.p + N;
+  const double* dx = nullptr;
+  const double mean = (double)S.Ap_nnz / std::max(1, N);
+  for (int it = 0; it < h->max_iter; ++it) {
+    // r = b - A x  -> buf y-half ; xsol = x (+dx folded before)
+    if (it > 0) {
+      hipLaunchKernelGGL(fc_axpy, dim3(g), dim3(256), 0, h->stream, N, 1.0, h->buf.p + N, h->xsol.p);
+      x = h->xsol.p;
+      const int nb = launch_spmv<1>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, x, h->b.p, h->buf.p, nullptr,
+                                    nullptr);
+      if (nb < 0) return nb;
+    } else {
+      const int nb = launch_spmv<1>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, x, h->b.p, h->buf.p, h->xsol.p,
+                                    h->check_residual ? h->partial.p : nullptr);
+      if (nb < 0) return nb;
+      if (h->check_residual)
+        hipLaunchKernelGGL(fc_reduce_final, dim3(2), dim3(256), 0, h->stream, nb, h->partial.p, 1.0, h->scal.p + 1);
+      x = h->xsol.p;
+    }
+    FCCHK(apply_factors(h, S));
+    dx = h->buf.p + N;
+  }
+  HIPCHK(hipGetLastError());
+  *x_out = x;
+  *dx_out = dx;
+  return FC_OK;
+}
+
+int refresh_permuted(fc_ctx* h) {
+  if (!h->have_perm) return FC_OK;
+  const int N = h->N;
+  // vector-scatter lists and BC slots in permuted row order
+  std::vector<int> gp(N + 1, 0), gi;
+  gi.reserve(h->h_gidx.size());
+  for (int i = 0; i < N; ++i) {
+    const int r = h->h_perm[i];
+    for (int k = h->h_gptr[r]; k < h->h_gptr[r + 1]; ++k) gi.push_back(h->h_gidx[k]);
+    gp[i + 1] = (int)gi.size();
+  }
+  FCCHK(h->gptr_p.upload(gp, h->stream));
+  FCCHK(h->gidx_p.upload(gi, h->stream));
+  std::vector<int> slot_of(N, -1), bs(N);
+  for (int k = 0; k < h->n_bc; ++k) slot_of[h->h_bc_dofs[k]] = k;
+  for (int i = 0; i < N; ++i) bs[i] = slot_of[h->h_perm[i]];
+  FCCHK(h->bcslot_p.upload(bs, h->stream));
+  for (int o = 0; o < 2; ++o) {
+    OrderSys& S = h->sys[o];
+    if (!S.have_lift) continue;
+    FCCHK(S.lift_p.alloc((size_t)std::max(1, h->n_act) * N));
+    for (int k = 0; k < h->n_act; ++k)
+      hipLaunchKernelGGL(fc_gather_perm, dim3(nblocks(N, 256)), dim3(256), 0, h->stream, N, h->perm.p,
+                         S.lift.p + (size_t)k * N, S.lift_p.p + (size_t)k * N);
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return FC_OK;
+}
+
+struct StepCoeffs {
+  double cm_n, cm_nn, cc_n, cc_nn;
+};
+StepCoeffs coeffs_for(const fc_ctx* h, int order_slot) {
+  const double nl = h->nonlinear ? 1.0 : 0.0;
+  if (order_slot == FC_SLOT_BDF1) return {1.0 / h->dt, 0.0, -nl, 0.0};
+  return {2.0 / h->dt, -0.5 / h->dt, -2.0 * nl, nl};
+}
+
+int check_step_ready(fc_ctx* h, int order_slot) {
+  if (!h) return fail(FC_ERR_INVALID, "null handle");
+  if (order_slot != FC_SLOT_BDF1 && order_slot != FC_SLOT_BDF2) return fail(FC_ERR_INVALID, "order_slot must be BDF1/BDF2");
+  if (h->dt <= 0) return fail(FC_ERR_NOT_READY, "fc_set_time_scheme not called");
+  if (!h->have_perm) return fail(FC_ERR_NOT_READY, "fc_set_permutation not called");
+  if (!h->sys[order_slot].have_lift) return fail(FC_ERR_NOT_READY, "fc_apply_bc not called for this order");
+  return FC_OK;
+}
+
+// enqueue RHS assembly for the current state into h->b (permuted numbering)
+int enqueue_rhs(fc_ctx* h, int order_slot, const double* d_uctrl) {
+  const StepCoeffs c = coeffs_for(h, order_slot);
+  OrderSys& S = h->sys[order_slot];
+  hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks(h->nc, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
+                     h->u_n.p, h->u_nn.p, h->have_force ? h->fprof.p : nullptr, h->have_force ? h->n_act : 0, d_uctrl,
+                     c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p);
+  hipLaunchKernelGGL(fc_rhs_gather, dim3(nblocks(h->N, 256)), dim3(256), 0, h->stream, h->N, h->gptr_p.p, h->gidx_p.p,
+                     h->ev.p, h->bcslot_p.p, h->bcprof.p, S.lift_p.p, h->n_act, d_uctrl, h->b.p);
+  HIPCHK(hipGetLastError());
+  return FC_OK;
+}
+
+int enqueue_energy(fc_ctx* h, const double* d_u, double* d_out) {
+  const int nrows = 2 * h->nn;
+  const int nb = nblocks(nrows, 32);
+  hipLaunchKernelGGL(fc_energy_partial, dim3(nb), dim3(256), 0, h->stream, nrows, h->rowptr.p, h->col.p,
+                     h->vals[FC_SLOT_MASS].p, d_u, h->partial.p);
+  hipLaunchKernelGGL(fc_reduce_final, dim3(1), dim3(256), 0, h->stream, nb, h->partial.p, 0.5, d_out);
+  HIPCHK(hipGetLastError());
+  return FC_OK;
+}
+
+// enqueue one full step; y -> d_y, E -> d_E
+int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, double* d_E, int compute_energy) {
+  OrderSys& S = h->sys[order_slot];
+  if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this order");
+  FCCHK(enqueue_rhs(h, order_slot, d_uctrl));
+  const double *x = nullptr, *dx = nullptr;
+  FCCHK(solve_permuted(h, S, &x, &dx));
+  hipLaunchKernelGGL(fc_finish, dim3(nblocks(h->N, 256)), dim3(256), 0, h->stream, h->N, 2 * h->nn, h->perm.p, x, dx,
+                     h->up.p, h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p);
+  if (h->n_sens > 0)
+    hipLaunchKernelGGL(fc_sensors, dim3(h->n_sens), dim3(64), 0, h->stream, h->n_sens, h->s_rowptr.p, h->s_idx.p,
+                       h->s_w.p, h->up.p, d_y);
+  if (compute_energy) {
+    if (!h->slot_ok[FC_SLOT_MASS]) return fail(FC_ERR_NOT_READY, "FC_SLOT_MASS not assembled");
+    FCCHK(enqueue_energy(h, h->up.p, d_E));
+  }
+  HIPCHK(hipGetLastError());
+  return FC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fc_last_error(void) { return g_err.c_str(); }
+
+int fc_device_count(int* count) {
+  if (!count) return fail(FC_ERR_INVALID, "null count");
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(FC_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  return FC_OK;
+}
+
+int fc_create(fc_handle* out, int device, int32_t nv, int32_t ne, int32_t nc, const double* coords, const int32_t* cells,
+              const int32_t* cell_edges) {
+  if (!out || !coords || !cells || !cell_edges || nv <= 0 || ne <= 0 || nc <= 0)
+    return fail(FC_ERR_INVALID, "fc_create: bad arguments");
+  if ((int64_t)nc * 225 > std::numeric_limits<int>::max())
+    return fail(FC_ERR_INVALID, "fc_create: mesh too large for int32 element-matrix indexing");
+  *out = nullptr;
+  HIPCHK(hipSetDevice(device));
+  fc_ctx* h = new fc_ctx();
+  h->device = device;
+  h->nv = nv;
+  h->ne = ne;
+  h->nc = nc;
+  h->nn = nv + ne;
+  h->N = 2 * h->nn + nv;
+  const int nn = h->nn, N = h->N;
+  auto bail = [&](int code) {
+    fc_destroy(h);
+    return code;
+  };
+#define TRY(expr)                     \
+  do {                                \
+    int _s = (expr);                  \
+    if (_s != FC_OK) return bail(_s); \
+  } while (0)
+#define TRYHIP(expr)                                                                               \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) return bail(fail(FC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); \
+  } while (0)
+  TRYHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  TRYHIP(hipEventCreate(&h->ev0));
+  TRYHIP(hipEventCreate(&h->ev1));
+  TRYHIP(hipHostMalloc((void**)&h->pin, kPinDoubles * sizeof(double), hipHostMallocDefault));
+  // element tables -> constant memory
+  double phi2[42], dphi2[84], phi1[21], qw[7];
+  tabulate(phi2, dphi2, phi1, qw);
+  TRYHIP(hipMemcpyToSymbol(HIP_SYMBOL(c_phi2), phi2, sizeof(phi2)));
+  TRYHIP(hipMemcpyToSymbol(HIP_SYMBOL(c_dphi2), dphi2, sizeof(dphi2)));
+  TRYHIP(hipMemcpyToSymbol(HIP_SYMBOL(c_phi1), phi1, sizeof(phi1)));
+  TRYHIP(hipMemcpyToSymbol(HIP_SYMBOL(c_qw), qw, sizeof(qw)));
+  // SoA cell tables and geometry
+  std::vector<int> cn((size_t)6 * nc);
+  std::vector<double> geom((size_t)5 * nc);
+  std::vector<int> cd((size_t)nc * 15);
+  for (int c = 0; c < nc; ++c) {
+    int v[3], e[3];
+    for (int k = 0; k < 3; ++k) {
+      v[k] = cells[3 * c + k];
+      e[k] = cell_edges[3 * c + k];
+      if (v[k] < 0 || v[k] >= nv || e[k] < 0 || e[k] >= ne) {
+        return bail(fail(FC_ERR_INVALID, "fc_create: cell index out of range"));
+      }
+      cn[(size_t)k * nc + c] = v[k];
+      cn[(size_t)(3 + k) * nc + c] = nv + e[k];
+    }
+    const double x0 = coords[2 * v[0]], y0 = coords[2 * v[0] + 1];
+    const double a = coords[2 * v[1]] - x0, b = coords[2 * v[2]] - x0;       // J = [[a b],[c d]]
+    const double cc = coords[2 * v[1] + 1] - y0, d = coords[2 * v[2] + 1] - y0;
+    const double det = a * d - b * cc;
+    if (!(det > 0.0)) return bail(fail(FC_ERR_INVALID, "fc_create: cells must be counter-clockwise and non-degenerate"));
+    geom[c] = d / det;                    // Jinv[0][0]
+    geom[(size_t)nc + c] = -b / det;      // Jinv[0][1]
+    geom[(size_t)2 * nc + c] = -cc / det; // Jinv[1][0]
+    geom[(size_t)3 * nc + c] = a / det;   // Jinv[1][1]
+    geom[(size_t)4 * nc + c] = det;
+    for (int k = 0; k < 6; ++k) {
+      const int node = cn[(size_t)k * nc + c];
+      cd[(size_t)c * 15 + k] = node;
+      cd[(size_t)c * 15 + 6 + k] = nn + node;
+    }
+    for (int k = 0; k < 3; ++k) cd[(size_t)c * 15 + 12 + k] = 2 * nn + v[k];
+  }
+  TRY(h->cn.upload(cn, h->stream));
+  TRY(h->geom.upload(geom, h->stream));
+  // CSR pattern (no pressure-pressure coupling)
+  {
+    std::vector<uint64_t> keys;
+    keys.reserve((size_t)nc * 216);
+    for (int c = 0; c < nc; ++c)
+      for (int i = 0; i < 15; ++i)
+        for (int j = 0; j < 15; ++j) {
+          if (i >= 12 && j >= 12) continue;
+          keys.push_back(((uint64_t)cd[(size_t)c * 15 + i] << 32) | (uint32_t)cd[(size_t)c * 15 + j]);
+        }
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    if (keys.size() > (size_t)std::numeric_limits<int>::max())
+      return bail(fail(FC_ERR_INVALID, "fc_create: pattern exceeds int32 nnz"));
+    h->nnz = (int64_t)keys.size();
+    h->h_rowptr.assign(N + 1, 0);
+    h->h_col.resize(keys.size());
+    for (size_t k = 0; k < keys.size(); ++k) {
+      h->h_rowptr[(keys[k] >> 32) + 1]++;
+      h->h_col[k] = (int)(keys[k] & 0xFFFFFFFFu);
+    }
+    for (int r = 0; r < N; ++r) h->h_rowptr[r + 1] += h->h_rowptr[r];
+  }
+  TRY(h->rowptr.upload(h->h_rowptr, h->stream));
+  TRY(h->col.upload(h->h_col, h->stream));
+  // inverted index of matrix contributions: slot -> list of em entries
+  {
+    std::vector<int> cnt(h->nnz + 1, 0);
+    std::vector<int> slot_of((size_t)nc * 225, -1);
+    for (int c = 0; c < nc; ++c)
+      for (int i = 0; i < 15; ++i) {
+        const int r = cd[(size_t)c * 15 + i];
+        const int* b0 = h->h_col.data() + h->h_rowptr[r];
+        const int* b1 = h->h_col.data() + h->h_rowptr[r + 1];
+        for (int j = 0; j < 15; ++j) {
+          if (i >= 12 && j >= 12) continue;
+          const int cc2 = cd[(size_t)c * 15 + j];
+          const int s = (int)(std::lower_bound(b0, b1, cc2) - h->h_col.data());
+          slot_of[(size_t)c * 225 + i * 15 + j] = s;
+          cnt[s + 1]++;
+        }
+      }
+    for (int64_t s = 0; s < h->nnz; ++s) cnt[s + 1] += cnt[s];
+    std::vector<int> midx(cnt[h->nnz]);
+    std::vector<int> fill(cnt.begin(), cnt.end() - 1);
+    for (int c = 0; c < nc; ++c)  // cell-major order => fixed summation order per slot
+      for (int ij = 0; ij < 225; ++ij) {
+        const int s = slot_of[(size_t)c * 225 + ij];
+        if (s >= 0) midx[fill[s]++] = ij * nc + c;
+      }
+    TRY(h->mptr.upload(cnt, h->stream));
+    TRY(h->midx.upload(midx, h->stream));
+  }
+  // inverted index of vector contributions: W row -> list of ev entries (velocity rows only)
+  {
+    h->h_gptr.assign(N + 1, 0);
+    for (int c = 0; c < nc; ++c)
+      for (int k = 0; k < 12; ++k) h->h_gptr[cd[(size_t)c * 15 + k] + 1]++;
+    for (int r = 0; r < N; ++r) h->h_gptr[r + 1] += h->h_gptr[r];
+    h->h_gidx.resize(h->h_gptr[N]);
+    std::vector<int> fill(h->h_gptr.begin(), h->h_gptr.end() - 1);
+    for (int c = 0; c < nc; ++c)
+      for (int k = 0; k < 12; ++k) h->h_gidx[fill[cd[(size_t)c * 15 + k]]++] = k * nc + c;
+  }
+  TRY(h->em.alloc((size_t)225 * nc));
+  TRY(h->ev.alloc((size_t)12 * nc));
+  for (int s = 0; s < FC_NUM_SLOTS; ++s) TRY(h->vals[s].alloc((size_t)h->nnz));
+  TRY(h->u_n.alloc(2 * (size_t)nn));
+  TRY(h->u_nn.alloc(2 * (size_t)nn));
+  TRY(h->p_n.alloc(nv));
+  TRY(h->up.alloc(N));
+  TRY(h->b.alloc(N));
+  TRY(h->buf.alloc(2 * (size_t)N));
+  TRY(h->xsol.alloc(N));
+  TRY(h->tmpN.alloc(N));
+  TRY(h->tmpN2.alloc(N));
+  h->nblk_N = nblocks(N, 4) + 16;  // upper bound on blocks of any row-wise reduction
+  TRY(h->partial.alloc(2 * (size_t)h->nblk_N));
+  TRY(h->scal.alloc(8));
+  TRY(h->flag.alloc(1));
+  TRY(h->isbc.alloc(N));
+  TRY(h->u_n.zero(h->stream));
+  TRY(h->u_nn.zero(h->stream));
+  TRY(h->p_n.zero(h->stream));
+  TRY(h->up.zero(h->stream));
+  TRY(h->scal.zero(h->stream));
+  TRY(h->flag.zero(h->stream));
+  TRY(h->isbc.zero(h->stream));
+  TRY(h->uctrl.alloc(64));
+  TRY(h->uctrl.zero(h->stream));
+  TRY(h->ydev.alloc(64));
+  TRYHIP(hipStreamSynchronize(h->stream));
+#undef TRY
+#undef TRYHIP
+  *out = h;
+  return FC_OK;
+}
+
+int fc_destroy(fc_handle h) {
+  if (!h) return FC_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->pin) (void)hipHostFree(h->pin);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  hipStream_t s = h->stream;
+  delete h;
+  if (s) (void)hipStreamDestroy(s);
+  return FC_OK;
+}
+
+int fc_get_sizes(fc_handle h, int64_t* N, int64_t* nnz, int64_t* nn) {
+  if (!h) return fail(FC_ERR_INVALID, "null handle");
+  if (N) *N = h->N;
+  if (nnz) *nnz = h->nnz;
+  if (nn) *nn = h->nn;
+  return FC_OK;
+}
+
+int fc_get_pattern(fc_handle h, int32_t* rowptr, int32_t* colidx) {
+  if (!h || !rowptr || !colidx) return fail(FC_ERR_INVALID, "fc_get_pattern: null argument");
+  std::memcpy(rowptr, h->h_rowptr.data(), (size_t)(h->N + 1) * sizeof(int));
+  std::memcpy(colidx, h->h_col.data(), (size_t)h->nnz * sizeof(int));
+  return FC_OK;
+}
+
+int fc_assemble_matrix(fc_handle h, int slot, double mass, double nu, const double* adv, double adv_scale,
+                       const double* lin, double lin_scale, double pressure, double divergence) {
+  if (!h || slot < 0 || slot >= FC_NUM_SLOTS) return fail(FC_ERR_INVALID, "fc_assemble_matrix: bad slot");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t nv2 = 2 * (size_t)h->nn;
+  double *d_adv = nullptr, *d_lin = nullptr;
+  if (adv) {
+    HIPCHK(hipMemcpyAsync(h->tmpN.p, adv, nv2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    d_adv = h->tmpN.p;
+  }
+  if (lin) {
+    HIPCHK(hipMemcpyAsync(h->tmpN2.p, lin, nv2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    d_lin = h->tmpN2.p;
+  }
+  hipLaunchKernelGGL(fc_mat_elem, dim3(nblocks(h->nc, 256), 6), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p,
+                     h->geom.p, mass, nu, d_adv, adv_scale, d_lin, lin_scale, pressure, divergence, h->em.p);
+  hipLaunchKernelGGL(fc_mat_gather, dim3(nblocks(h->nnz, 256)), dim3(256), 0, h->stream, h->nnz, h->mptr.p, h->midx.p,
+                     h->em.p, h->vals[slot].p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->slot_ok[slot] = true;
+  if (slot < 2) {
+    h->sys[slot].have_lift = false;
+    h->sys[slot].ready = false;
+  }
+  return FC_OK;
+}
+
+int fc_get_matrix_values(fc_handle h, int slot, double* vals) {
+  if (!h || slot < 0 || slot >= FC_NUM_SLOTS || !vals) return fail(FC_ERR_INVALID, "fc_get_matrix_values: bad argument");
+  if (!h->slot_ok[slot]) return fail(FC_ERR_NOT_READY, "slot not assembled");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(vals, h->vals[slot].p, (size_t)h->nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return FC_OK;
+}
+
+int fc_set_matrix_values(fc_handle h, int slot, const double* vals) {
+  if (!h || slot < 0 || slot >= FC_NUM_SLOTS || !vals) return fail(FC_ERR_INVALID, "fc_set_matrix_values: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(h->vals[slot].p, vals, (size_t)h->nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->slot_ok[slot] = true;
+  return FC_OK;
+}
+
+int fc_spmv(fc_handle h, int slot, const double* x, double* y) {
+  if (!h || slot < 0 || slot >= FC_NUM_SLOTS || !x || !y) return fail(FC_ERR_INVALID, "fc_spmv: bad argument");
+  if (!h->slot_ok[slot]) return fail(FC_ERR_NOT_READY, "slot not assembled");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(h->tmpN.p, x, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  const int nb = launch_spmv<0>(h, h->N, (double)h->nnz / h->N, h->rowptr.p, h->col.p, h->vals[slot].p, h->tmpN.p, nullptr,
+                                h->tmpN2.p, nullptr, nullptr);
+  if (nb < 0) return nb;
+  HIPCHK(hipMemcpyAsync(y, h->tmpN2.p, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return FC_OK;
+}
+
+int fc_bench_spmv(fc_handle h, int slot, int reps, double* ms_per_launch) {
+  if (!h || slot < 0 || slot >= FC_NUM_SLOTS || reps <= 0 || !ms_per_launch)
+    return fail(FC_ERR_INVALID, "fc_bench_spmv: bad argument");
+  if (!h->slot_ok[slot]) return fail(FC_ERR_NOT_READY, "slot not assembled");
+  HIPCHK(hipSetDevice(h->device));
+  for (int i = 0; i < 3; ++i) {
+    const int nb = launch_spmv<0>(h, h->N, (double)h->nnz / h->N, h->rowptr.p, h->col.p, h->vals[slot].p, h->up.p,
+                                  nullptr, h->tmpN2.p, nullptr, nullptr);
+    if (nb < 0) return nb;
+  }
+  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  for (int i = 0; i < reps; ++i) {
+    const int nb = launch_spmv<0>(h, h->N, (double)h->nnz / h->N, h->rowptr.p, h->col.p, h->vals[slot].p, h->up.p,
+                                  nullptr, h->tmpN2.p, nullptr, nullptr);
+    if (nb < 0) return nb;
+  }
+  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  HIPCHK(hipEventSynchronize(h->ev1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *ms_per_launch = (double)ms / reps;
+  return FC_OK;
+}
+
+int fc_set_bc(fc_handle h, int32_t n_bc, const int32_t* bc_dofs, int32_t n_act, const double* profiles) {
+  if (!h || n_bc < 0 || n_act < 0 || n_act > 64 || (n_bc > 0 && !bc_dofs) || (n_bc > 0 && n_act > 0 && !profiles))
+    return fail(FC_ERR_INVALID, "fc_set_bc: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  std::vector<unsigned char> isbc(h->N, 0);
+  for (int k = 0; k < n_bc; ++k) {
+    if (bc_dofs[k] < 0 || bc_dofs[k] >= 2 * h->nn) return fail(FC_ERR_INVALID, "fc_set_bc: dof is not a velocity dof");
+    if (isbc[bc_dofs[k]]) return fail(FC_ERR_INVALID, "fc_set_bc: duplicate dof");
+    isbc[bc_dofs[k]] = 1;
+  }
+  h->n_bc = n_bc;
+  h->n_act = n_act;
+  h->h_bc_dofs.assign(bc_dofs, bc_dofs + n_bc);
+  h->h_bcprof.assign(profiles, profiles + (size_t)n_bc * n_act);
+  FCCHK(h->isbc.upload(isbc.data(), isbc.size(), h->stream));
+  std::vector<double> prof(std::max<size_t>(1, (size_t)n_bc * n_act), 0.0);
+  if (n_bc * n_act) std::copy(profiles, profiles + (size_t)n_bc * n_act, prof.begin());
+  FCCHK(h->bcprof.upload(prof, h->stream));
+  for (int o = 0; o < 2; ++o) h->sys[o].have_lift = h->sys[o].ready = false;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->have_perm) FCCHK(refresh_permuted(h));
+  return FC_OK;
+}
+
+int fc_set_force(fc_handle h, int32_t n_act, const double* profiles) {
+  if (!h) return fail(FC_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (!profiles || n_act == 0) {
+    h->have_force = false;
+    return FC_OK;
+  }
+  if (n_act != h->n_act) return fail(FC_ERR_INVALID, "fc_set_force: n_act differs from fc_set_bc");
+  FCCHK(h->fprof.upload(profiles, (size_t)n_act * 2 * h->nn, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->have_force = true;
+  return FC_OK;
+}
+
+int fc_set_sensors(fc_handle h, int32_t n_sens, const int32_t* rowptr, const int32_t* idx, const double* w) {
+  if (!h || n_sens < 0 || n_sens > 64 || (n_sens > 0 && (!rowptr || !idx || !w)))
+    return fail(FC_ERR_INVALID, "fc_set_sensors: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  h->n_sens = n_sens;
+  if (n_sens == 0) return FC_OK;
+  const int nz = rowptr[n_sens];
+  for (int k = 0; k < nz; ++k)
+    if (idx[k] < 0 || idx[k] >= h->N) return fail(FC_ERR_INVALID, "fc_set_sensors: index out of range");
+  FCCHK(h->s_rowptr.upload(rowptr, n_sens + 1, h->stream));
+  FCCHK(h->s_idx.upload(idx, std::max(1, nz), h->stream));
+  FCCHK(h->s_w.upload(w, std::max(1, nz), h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return FC_OK;
+}
+
+int fc_set_time_scheme(fc_handle h, double dt, int nonlinear) {
+  if (!h || !(dt > 0.0)) return fail(FC_ERR_INVALID, "fc_set_time_scheme: dt must be positive");
+  h->dt = dt;
+  h->nonlinear = nonlinear ? 1 : 0;
+  return FC_OK;
+}
+
+int fc_apply_bc(fc_handle h, int slot) {
+  if (!h || slot < 0 || slot >= FC_NUM_SLOTS) return fail(FC_ERR_INVALID, "fc_apply_bc: bad slot");
+  if (!h->slot_ok[slot]) return fail(FC_ERR_NOT_READY, "slot not assembled");
+  HIPCHK(hipSetDevice(h->device));
+  const int N = h->N;
+  if (slot < 2) {
+    OrderSys& S = h->sys[slot];
+    FCCHK(S.lift.alloc((size_t)std::max(1, h->n_act) * N));
+    FCCHK(S.lift.zero(h->stream));
+    std::vector<double> g(N);
+    for (int k = 0; k < h->n_act; ++k) {
+      std::fill(g.begin(), g.end(), 0.0);
+      for (int i = 0; i < h->n_bc; ++i) g[h->h_bc_dofs[i]] = h->h_bcprof[(size_t)i * h->n_act + k];
+      HIPCHK(hipMemcpyAsync(h->tmpN.p, g.data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      const int nb = launch_spmv<0>(h, N, (double)h->nnz / N, h->rowptr.p, h->col.p, h->vals[slot].p, h->tmpN.p, nullptr,
+                                    S.lift.p + (size_t)k * N, nullptr, nullptr);
+      if (nb < 0) return nb;
+      HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    S.have_lift = true;
+    S.ready = false;
+  }
+  hipLaunchKernelGGL(fc_apply_bc_rows, dim3(nblocks(N, 256)), dim3(256), 0, h->stream, N, h->rowptr.p, h->col.p,
+                     h->isbc.p, h->vals[slot].p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->have_perm) FCCHK(refresh_permuted(h));
+  return FC_OK;
+}
+
+int fc_set_permutation(fc_handle h, const int32_t* perm) {
+  if (!h || !perm) return fail(FC_ERR_INVALID, "fc_set_permutation: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  std::vector<unsigned char> seen(h->N, 0);
+  for (int i = 0; i < h->N; ++i) {
+    if (perm[i] < 0 || perm[i] >= h->N || seen[perm[i]]) return fail(FC_ERR_INVALID, "fc_set_permutation: not a permutation");
+    seen[perm[i]] = 1;
+  }
+  h->h_perm.assign(perm, perm + h->N);
+  FCCHK(h->perm.upload(h->h_perm, h->stream));
+  h->have_perm = true;
+  for (int o = 0; o < 2; ++o) h->sys[o].ready = false;
+  return refresh_permuted(h);
+}
+
+int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32_t* Ap_col, const double* Ap_val,
+                    int32_t n_stages, const int64_t* stage_rowptr_begin, const int32_t* stage_row0,
+                    const int32_t* stage_nrows, const int32_t* stage_kind, const int64_t* f_rowptr, const int32_t* f_col,
+                    const double* f_val) {
+  if (!h || slot < 0 || slot > 1 || !Ap_rowptr || !Ap_col || !Ap_val || n_stages <= 0 || !stage_rowptr_begin ||
+      !stage_row0 || !stage_nrows || !stage_kind || !f_rowptr || !f_col || !f_val)
+    return fail(FC_ERR_INVALID, "fc_solver_setup: bad argument");
+  if (!h->have_perm) return fail(FC_ERR_NOT_READY, "fc_set_permutation not called");
+  HIPCHK(hipSetDevice(h->device));
+  const int N = h->N;
+  OrderSys& S = h->sys[slot];
+  S.ready = false;
+  S.Ap_nnz = Ap_rowptr[N];
+  for (int64_t k = 0; k < S.Ap_nnz; ++k)
+    if (Ap_col[k] < 0 || Ap_col[k] >= N) return fail(FC_ERR_INVALID, "fc_solver_setup: system column out of range");
+  FCCHK(S.Ap_rowptr.upload(Ap_rowptr, N + 1, h->stream));
+  FCCHK(S.Ap_col.upload(Ap_col, (size_t)S.Ap_nnz, h->stream));
+  FCCHK(S.Ap_val.upload(Ap_val, (size_t)S.Ap_nnz, h->stream));
+  int64_t total_rows = 0;
+  S.stages.clear();
+  S.sweep_bytes = 0.0;
+  for (int s = 0; s < n_stages; ++s) {
+    Stage st;
+    st.rp_begin = stage_rowptr_begin[s];
+    st.row0 = stage_row0[s];
+    st.nrows = stage_nrows[s];
+    st.kind = stage_kind[s];
+    if (st.nrows < 0 || st.row0 < 0 || st.row0 + st.nrows > N || (st.kind != 0 && st.kind != 1) ||
+        st.rp_begin != total_rows)
+      return fail(FC_ERR_INVALID, "fc_solver_setup: inconsistent stage table");
+    const int64_t nz = f_rowptr[total_rows + st.nrows] - f_rowptr[total_rows];
+    const int64_t lim = st.kind == 0 ? N : 2 * (int64_t)N;
+    for (int64_t k = f_rowptr[total_rows]; k < f_rowptr[total_rows + st.nrows]; ++k)
+      if (f_col[k] < 0 || f_col[k] >= lim) return fail(FC_ERR_INVALID, "fc_solver_setup: factor column out of range");
+    st.lanes = pick_lanes(st.nrows ? (double)nz / st.nrows : 0.0);
+    st.bytes = (double)nz * 12.0 + (double)st.nrows * (8.0 + 8.0 + (st.kind == 0 ? 8.0 : 0.0));
+    S.sweep_bytes += st.bytes;
+    S.stages.push_back(st);
+    total_rows += st.nrows;
+  }
+  const int64_t fnnz = f_rowptr[total_rows];
+  FCCHK(S.f_rowptr.upload(f_rowptr, (size_t)total_rows + 1, h->stream));
+  FCCHK(S.f_col.upload(f_col, (size_t)fnnz, h->stream));
+  FCCHK(S.f_val.upload(f_val, (size_t)fnnz, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  S.ready = true;
+  return FC_OK;
+}
+
+int fc_set_solver_options(fc_handle h, int method, int max_iter, double rtol, int check_residual) {
+  if (!h || max_iter < 0 || max_iter > 1000) return fail(FC_ERR_INVALID, "fc_set_solver_options: bad argument");
+  if (method != FC_METHOD_REFINE) return fail(FC_ERR_INVALID, "fc_set_solver_options: method not available in this build");
+  h->method = method;
+  h->max_iter = max_iter;
+  h->rtol = rtol;
+  h->check_residual = check_residual;
+  return FC_OK;
+}
+
+int fc_set_state(fc_handle h, const double* u_n, const double* u_nn, const double* p_n) {
+  if (!h || !u_n || !u_nn) return fail(FC_ERR_INVALID, "fc_set_state: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t nv2 = 2 * (size_t)h->nn;
+  HIPCHK(hipMemcpyAsync(h->u_n.p, u_n, nv2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->u_nn.p, u_nn, nv2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (p_n) HIPCHK(hipMemcpyAsync(h->p_n.p, p_n, (size_t)h->nv * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemsetAsync(h->flag.p, 0, sizeof(int), h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return FC_OK;
+}
+
+int fc_get_state(fc_handle h, double* u_n, double* u_nn, double* p_n) {
+  if (!h) return fail(FC_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t nv2 = 2 * (size_t)h->nn;
+  if (u_n) HIPCHK(hipMemcpyAsync(u_n, h->u_n.p, nv2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (u_nn) HIPCHK(hipMemcpyAsync(u_nn, h->u_nn.p, nv2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (p_n) HIPCHK(hipMemcpyAsync(p_n, h->p_n.p, (size_t)h->nv * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return FC_OK;
+}
+
+int fc_get_solution(fc_handle h, double* up) {
+  if (!h || !up) return fail(FC_ERR_INVALID, "fc_get_solution: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(up, h->up.p, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return FC_OK;
+}
+
+int fc_step(fc_handle h, int order_slot, const double* u_ctrl, double* y_out, double* dE_out, int compute_energy,
+            double* info_out) {
+  FCCHK(check_step_ready(h, order_slot));
+  if (h->n_act > 0 && !u_ctrl) return fail(FC_ERR_INVALID, "fc_step: u_ctrl is null");
+  HIPCHK(hipSetDevice(h->device));
+  double* pin = h->pin;
+  for (int k = 0; k < h->n_act; ++k) pin[k] = u_ctrl[k];
+  if (h->n_act) HIPCHK(hipMemcpyAsync(h->uctrl.p, pin, h->n_act * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  FCCHK(enqueue_step(h, order_slot, h->uctrl.p, h->ydev.p, h->scal.p, compute_energy));
+  double* out = pin + 64;  // [0..63] y, [64..71] scal, [72] flag
+  if (h->n_sens) HIPCHK(hipMemcpyAsync(out, h->ydev.p, h->n_sens * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(out + 64, h->scal.p, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(out + 72, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int s = 0; s < h->n_sens; ++s)
+    if (y_out) y_out[s] = out[s];
+  if (dE_out) *dE_out = compute_energy ? out[64] : std::numeric_limits<double>::quiet_NaN();
+  int flag = 0;
+  std::memcpy(&flag, out + 72, sizeof(int));
+  if (info_out) {
+    info_out[0] = h->max_iter;
+    info_out[1] = h->check_residual ? std::sqrt(out[65] / (out[66] > 0 ? out[66] : 1.0)) : std::numeric_limits<double>::quiet_NaN();
+    info_out[2] = h->check_residual ? std::sqrt(out[66]) : std::numeric_limits<double>::quiet_NaN();
+    info_out[3] = flag;
+  }
+  if (flag) return fail(FC_ERR_DIVERGED, "non-finite velocity after solve");
+  return FC_OK;
+}
+
+int fc_run(fc_handle h, int first_order_slot, int32_t n_steps, const double* u_ctrl, int u_ctrl_is_sequence,
+           double* y_seq, double* dE_seq, int compute_energy) {
+  FCCHK(check_step_ready(h, first_order_slot));
+  if (n_steps <= 0) return fail(FC_ERR_INVALID, "fc_run: n_steps must be positive");
+  if (h->n_act > 0 && !u_ctrl) return fail(FC_ERR_INVALID, "fc_run: u_ctrl is null");
+  HIPCHK(hipSetDevice(h->device));
+  const int na = std::max(1, h->n_act), ns = std::max(1, h->n_sens);
+  const size_t nu = u_ctrl_is_sequence ? (size_t)n_steps * na : (size_t)na;
+  std::vector<double> uh(nu, 0.0);
+  if (h->n_act) std::copy(u_ctrl, u_ctrl + (u_ctrl_is_sequence ? (size_t)n_steps * h->n_act : (size_t)h->n_act), uh.begin());
+  FCCHK(h->useq.upload(uh, h->stream));
+  FCCHK(h->yseq.alloc((size_t)n_steps * ns));
+  FCCHK(h->Eseq.alloc((size_t)n_steps));
+  int order = first_order_slot;
+  for (int s = 0; s < n_steps; ++s) {
+    const double* du = h->useq.p + (u_ctrl_is_sequence ? (size_t)s * h->n_act : 0);
+    FCCHK(enqueue_step(h, order, du, h->yseq.p + (size_t)s * ns, h->Eseq.p + s, compute_energy));
+    order = FC_SLOT_BDF2;
+  }
+  std::vector<double> yh((size_t)n_steps * ns), Eh(n_steps);
+  int flag = 0;
+  HIPCHK(hipMemcpyAsync(yh.data(), h->yseq.p, yh.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(Eh.data(), h->Eseq.p, Eh.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(&flag, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (y_seq)
+    for (int s = 0; s < n_steps; ++s)
+      for (int k = 0; k < h->n_sens; ++k) y_seq[(size_t)s * h->n_sens + k] = yh[(size_t)s * ns + k];
+  if (dE_seq)
+    for (int s = 0; s < n_steps; ++s) dE_seq[s] = compute_energy ? Eh[s] : std::numeric_limits<double>::quiet_NaN();
+  if (flag) return fail(FC_ERR_DIVERGED, "non-finite velocity after solve");
+  return FC_OK;
+}
+
+int fc_assemble_rhs(fc_handle h, int order_slot, const double* u_ctrl, double* b_out) {
+  FCCHK(check_step_ready(h, order_slot));
+  if (!b_out || (h->n_act > 0 && !u_ctrl)) return fail(FC_ERR_INVALID, "fc_assemble_rhs: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  if (h->n_act) HIPCHK(hipMemcpyAsync(h->uctrl.p, u_ctrl, h->n_act * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  FCCHK(enqueue_rhs(h, order_slot, h->uctrl.p));
+  hipLaunchKernelGGL(fc_scatter_perm, dim3(nblocks(h->N, 256)), dim3(256), 0, h->stream, h->N, h->perm.p, h->b.p,
+                     (const double*)nullptr, h->tmpN.p);
+  HIPCHK(hipMemcpyAsync(b_out, h->tmpN.p, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return FC_OK;
+}
+
+int fc_solve(fc_handle h, int slot, const double* b, double* x, double* info_out) {
+  if (!h || slot < 0 || slot > 1 || !b || !x) return fail(FC_ERR_INVALID, "fc_solve: bad argument");
+  OrderSys& S = h->sys[slot];
+  if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this slot");
+  HIPCHK(hipSetDevice(h->device));
+  const int N = h->N, g = nblocks(N, 256);
+  HIPCHK(hipMemcpyAsync(h->tmpN.p, b, (size_t)N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(fc_gather_perm, dim3(g), dim3(256), 0, h->stream, N, h->perm.p, h->tmpN.p, h->b.p);
+  const double *xs = nullptr, *dx = nullptr;
+  FCCHK(solve_permuted(h, S, &xs, &dx));
+  hipLaunchKernelGGL(fc_scatter_perm, dim3(g), dim3(256), 0, h->stream, N, h->perm.p, xs, dx, h->tmpN2.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(x, h->tmpN2.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(h->pin, h->scal.p, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (info_out) {
+    info_out[0] = h->max_iter;
+    info_out[1] = h->check_residual ? std::sqrt(h->pin[1] / (h->pin[2] > 0 ? h->pin[2] : 1.0)) : std::numeric_limits<double>::quiet_NaN();
+    info_out[2] = h->check_residual ? std::sqrt(h->pin[2]) : std::numeric_limits<double>::quiet_NaN();
+    info_out[3] = 0.0;
+  }
+  return FC_OK;
+}
+
+int fc_energy(fc_handle h, const double* u, double* E) {
+  if (!h || !u || !E) return fail(FC_ERR_INVALID, "fc_energy: null argument");
+  if (!h->slot_ok[FC_SLOT_MASS]) return fail(FC_ERR_NOT_READY, "FC_SLOT_MASS not assembled");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(h->tmpN.p, u, 2 * (size_t)h->nn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  FCCHK(enqueue_energy(h, h->tmpN.p, h->scal.p + 3));
+  HIPCHK(hipMemcpyAsync(h->pin, h->scal.p + 3, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *E = h->pin[0];
+  return FC_OK;
+}
+
+int fc_measure(fc_handle h, const double* up, double* y) {
+  if (!h || !up || (h->n_sens > 0 && !y)) return fail(FC_ERR_INVALID, "fc_measure: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  if (h->n_sens == 0) return FC_OK;
+  HIPCHK(hipMemcpyAsync(h->tmpN.p, up, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(fc_sensors, dim3(h->n_sens), dim3(64), 0, h->stream, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p,
+                     h->tmpN.p, h->ydev.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(h->pin, h->ydev.p, h->n_sens * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int s = 0; s < h->n_sens; ++s) y[s] = h->pin[s];
+  return FC_OK;
+}
+
+int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double* u_ctrl, double* ms,
+                     int32_t* sweep_launches) {
+  FCCHK(check_step_ready(h, order_slot));
+  if (n_steps <= 0 || !ms) return fail(FC_ERR_INVALID, "fc_profile_steps: bad argument");
+  OrderSys& S = h->sys[order_slot];
+  if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this order");
+  HIPCHK(hipSetDevice(h->device));
+  if (h->n_act) HIPCHK(hipMemcpyAsync(h->uctrl.p, u_ctrl, h->n_act * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  const int N = h->N, g = nblocks(N, 256);
+  const StepCoeffs c = coeffs_for(h, order_slot);
+  const double mean = (double)S.Ap_nnz / std::max(1, N);
+  double acc[5] = {0, 0, 0, 0, 0};
+  int launches = 0;
+  auto lap = [&](int phase) -> int {
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, h->ev0, h->ev1));
+    acc[phase] += t;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    return FC_OK;
+  };
+  for (int s = 0; s < n_steps; ++s) {
+    launches = 0;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks(h->nc, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
+                       h->u_n.p, h->u_nn.p, h->have_force ? h->fprof.p : nullptr, h->have_force ? h->n_act : 0,
+                       h->uctrl.p, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p);
+    FCCHK(lap(0));
+    hipLaunchKernelGGL(fc_rhs_gather, dim3(g), dim3(256), 0, h->stream, N, h->gptr_p.p, h->gidx_p.p, h->ev.p,
+                       h->bcslot_p.p, h->bcprof.p, S.lift_p.p, h->n_act, h->uctrl.p, h->b.p);
+    hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, h->buf.p);
+    FCCHK(lap(1));
+    FCCHK(apply_factors(h, S));
+    launches += (int)S.stages.size();
+    FCCHK(lap(2));
+    const double* x = h->buf.p + N;
+    const double* dx = nullptr;
+    for (int it = 0; it < h->max_iter; ++it) {
+      if (it > 0) hipLaunchKernelGGL(fc_axpy, dim3(g), dim3(256), 0, h->stream, N, 1.0, h->buf.p + N, h->xsol.p);
+      const int nb = launch_spmv<1>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, it > 0 ? h->xsol.p : x, h->b.p,
+                                    h->buf.p, it > 0 ? nullptr : h->xsol.p, nullptr);
+      if (nb < 0) return nb;
+      x = h->xsol.p;
+      FCCHK(lap(3));
+      FCCHK(apply_factors(h, S));
+      launches += (int)S.stages.size();
+      dx = h->buf.p + N;
+      FCCHK(lap(2));
+    }
+    hipLaunchKernelGGL(fc_finish, dim3(g), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, x, dx, h->up.p, h->u_n.p,
+                       h->u_nn.p, h->p_n.p, h->flag.p);
+    if (h->n_sens > 0)
+      hipLaunchKernelGGL(fc_sensors, dim3(h->n_sens), dim3(64), 0, h->stream, h->n_sens, h->s_rowptr.p, h->s_idx.p,
+                         h->s_w.p, h->up.p, h->ydev.p);
+    if (h->slot_ok[FC_SLOT_MASS]) FCCHK(enqueue_energy(h, h->up.p, h->scal.p));
+    FCCHK(lap(4));
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int p = 0; p < 5; ++p) ms[p] = acc[p] / n_steps;
+  if (sweep_launches) *sweep_launches = launches;
+  return FC_OK;
+}
+
+int fc_bench_sweeps(fc_handle h, int slot, int reps, double* ms_per_apply, int32_t* launches_per_apply) {
+  if (!h || slot < 0 || slot > 1 || reps <= 0 || !ms_per_apply) return fail(FC_ERR_INVALID, "fc_bench_sweeps: bad argument");
+  OrderSys& S = h->sys[slot];
+  if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this slot");
+  HIPCHK(hipSetDevice(h->device));
+  const int N = h->N, g = nblocks(N, 256);
+  // rhs = last assembled b (any finite data); re-copied each rep so values stay bounded
+  for (int i = 0; i < 2; ++i) {
+    hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, h->buf.p);
+    FCCHK(apply_factors(h, S));
+  }
+  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  for (int i = 0; i < reps; ++i) {
+    hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, h->buf.p);
+    FCCHK(apply_factors(h, S));
+  }
+  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  HIPCHK(hipEventSynchronize(h->ev1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *ms_per_apply = (double)ms / reps;
+  if (launches_per_apply) *launches_per_apply = (int32_t)S.stages.size();
+  return FC_OK;
+}
+
+int fc_algorithmic_bytes(fc_handle h, int slot, double* sweep_bytes, double* spmv_bytes) {
+  if (!h || slot < 0 || slot > 1) return fail(FC_ERR_INVALID, "fc_algorithmic_bytes: bad argument");
+  if (sweep_bytes) *sweep_bytes = h->sys[slot].sweep_bytes;
+  if (spmv_bytes) *spmv_bytes = (double)h->nnz * 12.0 + (double)h->N * 16.0 + (double)(h->N + 1) * 4.0;
+  return FC_OK;
+}
+
+}  // extern "C"

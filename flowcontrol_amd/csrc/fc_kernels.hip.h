@@ -1,0 +1,440 @@
+// Device kernels of libfc_hip.so (gfx950 / CDNA4, wave64).  Included by fc_hip.hip only.
+//
+// All arithmetic is fp64 (the reference computes in fp64 end to end).  Every kernel here is
+// bandwidth/latency bound: there is no dense contraction, so no MFMA; what matters
+// is coalesced SoA access (thread-per-cell element loops read/write [slot][cell] arrays),
+// deterministic gathers instead of atomics (bit-reproducible sums), and enough loads in flight
+// per lane in the CSR kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FC_NQ 7
+
+__constant__ double c_phi2[FC_NQ * 6];       // P2 basis at the 7 Radon points
+__constant__ double c_dphi2[FC_NQ * 6 * 2];  // reference gradients d/d(xi,eta)
+__constant__ double c_phi1[FC_NQ * 3];       // P1 basis
+__constant__ double c_qw[FC_NQ];             // weights (sum = 1; times |detJ|/2)
+
+// ---------------------------------------------------------------------------------------------
+// RHS element loop: the `rhs` of NSForms._order1/_order2 (reference nsforms.py:238-305)
+//   g = cm_n u_n + cm_nn u_nn + cc_n (u_n.grad)u_n + cc_nn (u_nn.grad)u_nn + f ;  L_e[a,j] = ∫ g_j φ_a
+// One thread per cell; element vectors go to ev[slot][cell] (slot = a + 6 j), summed per dof by
+// k_rhs_gather (wavefront-independent, deterministic).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fc_rhs_elem(int nc, int nn, const int* __restrict__ cn,
+                                                   const double* __restrict__ geom,
+                                                   const double* __restrict__ un,
+                                                   const double* __restrict__ unn,
+                                                   const double* __restrict__ fprof, int n_act,
+                                                   const double* __restrict__ uctrl, double cm_n,
+                                                   double cm_nn, double cc_n, double cc_nn,
+                                                   double* __restrict__ ev) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const double j00 = geom[c], j01 = geom[nc + c], j10 = geom[2 * nc + c], j11 = geom[3 * nc + c];
+  const double hdet = 0.5 * geom[4 * nc + c];
+  double ax[6], ay[6], bx[6], by[6], fx[6], fy[6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    const int n = cn[a * nc + c];
+    ax[a] = un[n];
+    ay[a] = un[nn + n];
+    bx[a] = unn[n];
+    by[a] = unn[nn + n];
+    double sx = 0.0, sy = 0.0;
+    for (int k = 0; k < n_act; ++k) {
+      const double uk = uctrl[k];
+      sx += uk * fprof[(size_t)k * 2 * nn + n];
+      sy += uk * fprof[(size_t)k * 2 * nn + nn + n];
+    }
+    fx[a] = sx;
+    fy[a] = sy;
+  }
+  double accx[6] = {0, 0, 0, 0, 0, 0}, accy[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int q = 0; q < FC_NQ; ++q) {
+    double ux = 0, uy = 0, uxi = 0, uet = 0, vxi = 0, vet = 0;  // field n: value, d/dxi, d/deta of (ux, uy)
+    double wx = 0, wy = 0, wxi = 0, wet = 0, zxi = 0, zet = 0;  // field nn
+    double gx = 0, gy = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const double ph = c_phi2[q * 6 + a], dx = c_dphi2[(q * 6 + a) * 2], de = c_dphi2[(q * 6 + a) * 2 + 1];
+      ux += ph * ax[a];
+      uy += ph * ay[a];
+      uxi += dx * ax[a];
+      uet += de * ax[a];
+      vxi += dx * ay[a];
+      vet += de * ay[a];
+      wx += ph * bx[a];
+      wy += ph * by[a];
+      wxi += dx * bx[a];
+      wet += de * bx[a];
+      zxi += dx * by[a];
+      zet += de * by[a];
+      gx += ph * fx[a];
+      gy += ph * fy[a];
+    }
+    // physical gradients: d/dx = d/dxi*j00 + d/deta*j10 ; d/dy = d/dxi*j01 + d/deta*j11
+    const double ux_x = uxi * j00 + uet * j10, ux_y = uxi * j01 + uet * j11;
+    const double uy_x = vxi * j00 + vet * j10, uy_y = vxi * j01 + vet * j11;
+    const double wx_x = wxi * j00 + wet * j10, wx_y = wxi * j01 + wet * j11;
+    const double wy_x = zxi * j00 + zet * j10, wy_y = zxi * j01 + zet * j11;
+    gx += cm_n * ux + cm_nn * wx + cc_n * (ux * ux_x + uy * ux_y) + cc_nn * (wx * wx_x + wy * wx_y);
+    gy += cm_n * uy + cm_nn * wy + cc_n * (ux * uy_x + uy * uy_y) + cc_nn * (wx * wy_x + wy * wy_y);
+    const double w = c_qw[q] * hdet;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const double wp = w * c_phi2[q * 6 + a];
+      accx[a] += wp * gx;
+      accy[a] += wp * gy;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    ev[(size_t)a * nc + c] = accx[a];
+    ev[(size_t)(6 + a) * nc + c] = accy[a];
+  }
+}
+
+// per (permuted) row: sum the element contributions, lift and impose the Dirichlet data.
+__global__ __launch_bounds__(256) void fc_rhs_gather(int N, const int* __restrict__ gptr,
+                                                     const int* __restrict__ gidx,
+                                                     const double* __restrict__ ev,
+                                                     const int* __restrict__ bcslot,
+                                                     const double* __restrict__ bcprof,
+                                                     const double* __restrict__ lift, int n_act,
+                                                     const double* __restrict__ uctrl,
+                                                     double* __restrict__ b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  double s = 0.0;
+  const int bs = bcslot[i];
+  if (bs >= 0) {
+    for (int k = 0; k < n_act; ++k) s += uctrl[k] * bcprof[(size_t)bs * n_act + k];
+  } else {
+    for (int k = gptr[i]; k < gptr[i + 1]; ++k) s += ev[gidx[k]];
+    for (int k = 0; k < n_act; ++k) s -= uctrl[k] * lift[(size_t)k * N + i];
+  }
+  b[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bilinear-form element loop (lhs of the transient forms, Picard operator, steady Jacobian).
+// One thread per (cell, test node a): rows a (ux) and 6+a (uy) of the 15x15 element matrix and
+// the matching divergence columns.  em[(i*15+j)][cell].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fc_mat_elem(int nc, int nn, const int* __restrict__ cn,
+                                                   const double* __restrict__ geom, double mass,
+                                                   double nu, const double* __restrict__ adv,
+                                                   double adv_scale, const double* __restrict__ lin,
+                                                   double lin_scale, double pressure, double divergence,
+                                                   double* __restrict__ em) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int a = blockIdx.y;  // wave-uniform test node
+  if (c >= nc) return;
+  const double j00 = geom[c], j01 = geom[nc + c], j10 = geom[2 * nc + c], j11 = geom[3 * nc + c];
+  const double hdet = 0.5 * geom[4 * nc + c];
+  double Ux[6], Uy[6], Lx[6], Ly[6];
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {
+    const int n = cn[b * nc + c];
+    Ux[b] = adv ? adv[n] : 0.0;
+    Uy[b] = adv ? adv[nn + n] : 0.0;
+    Lx[b] = lin ? lin[n] : 0.0;
+    Ly[b] = lin ? lin[nn + n] : 0.0;
+  }
+  double blk[6], l00[6], l01[6], l10[6], l11[6], P0[3], P1[3];
+#pragma unroll
+  for (int b = 0; b < 6; ++b) blk[b] = l00[b] = l01[b] = l10[b] = l11[b] = 0.0;
+  P0[0] = P0[1] = P0[2] = P1[0] = P1[1] = P1[2] = 0.0;
+#pragma unroll
+  for (int q = 0; q < FC_NQ; ++q) {
+    const double w = c_qw[q] * hdet;
+    double gbx[6], gby[6];
+    double uq = 0, vq = 0, lx_xi = 0, lx_et = 0, ly_xi = 0, ly_et = 0;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      const double ph = c_phi2[q * 6 + b], dx = c_dphi2[(q * 6 + b) * 2], de = c_dphi2[(q * 6 + b) * 2 + 1];
+      gbx[b] = dx * j00 + de * j10;
+      gby[b] = dx * j01 + de * j11;
+      uq += ph * Ux[b];
+      vq += ph * Uy[b];
+      lx_xi += dx * Lx[b];
+      lx_et += de * Lx[b];
+      ly_xi += dx * Ly[b];
+      ly_et += de * Ly[b];
+    }
+    // GU[k][j] = d_k U_j of the `lin` field
+    const double g00 = lx_xi * j00 + lx_et * j10;  // d_x Ux
+    const double g10 = lx_xi * j01 + lx_et * j11;  // d_y Ux
+    const double g01 = ly_xi * j00 + ly_et * j10;  // d_x Uy
+    const double g11 = ly_xi * j01 + ly_et * j11;  // d_y Uy
+    const double pa = c_phi2[q * 6 + a];
+    const double dxa = c_dphi2[(q * 6 + a) * 2], dea = c_dphi2[(q * 6 + a) * 2 + 1];
+    const double gax = dxa * j00 + dea * j10, gay = dxa * j01 + dea * j11;
+    const double wpa = w * pa;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      const double pb = c_phi2[q * 6 + b];
+      const double mab = wpa * pb;
+      blk[b] += mass * mab + nu * w * (gax * gbx[b] + gay * gby[b]) + adv_scale * wpa * (uq * gbx[b] + vq * gby[b]);
+      // (row comp j, col comp k): ∫ φa φb d_k U_j
+      l00[b] += lin_scale * mab * g00;  // j=0,k=0: d_x Ux
+      l01[b] += lin_scale * mab * g10;  // j=0,k=1: d_y Ux
+      l10[b] += lin_scale * mab * g01;  // j=1,k=0: d_x Uy
+      l11[b] += lin_scale * mab * g11;  // j=1,k=1: d_y Uy
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const double ps = w * c_phi1[q * 3 + m];
+      P0[m] += ps * gax;
+      P1[m] += ps * gay;
+    }
+  }
+  const size_t snc = (size_t)nc;
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {
+    em[(size_t)(a * 15 + b) * snc + c] = blk[b] + l00[b];
+    em[(size_t)(a * 15 + 6 + b) * snc + c] = l01[b];
+    em[(size_t)((6 + a) * 15 + b) * snc + c] = l10[b];
+    em[(size_t)((6 + a) * 15 + 6 + b) * snc + c] = blk[b] + l11[b];
+  }
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    em[(size_t)(a * 15 + 12 + m) * snc + c] = pressure * P0[m];
+    em[(size_t)((6 + a) * 15 + 12 + m) * snc + c] = pressure * P1[m];
+    em[(size_t)((12 + m) * 15 + a) * snc + c] = divergence * P0[m];
+    em[(size_t)((12 + m) * 15 + 6 + a) * snc + c] = divergence * P1[m];
+  }
+}
+
+// per CSR slot: sum element-matrix contributions (inverted index, deterministic order)
+__global__ __launch_bounds__(256) void fc_mat_gather(int64_t nnz, const int* __restrict__ mptr,
+                                                     const int* __restrict__ midx,
+                                                     const double* __restrict__ em,
+                                                     double* __restrict__ vals) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nnz) return;
+  double v = 0.0;
+  for (int k = mptr[s]; k < mptr[s + 1]; ++k) v += em[midx[k]];
+  vals[s] = v;
+}
+
+// SystemAssembler-style symmetric Dirichlet elimination on CSR values
+__global__ __launch_bounds__(256) void fc_apply_bc_rows(int N, const int* __restrict__ rowptr,
+                                                        const int* __restrict__ col,
+                                                        const unsigned char* __restrict__ isbc,
+                                                        double* __restrict__ vals) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= N) return;
+  const bool rb = isbc[r] != 0;
+  for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+    const int cidx = col[k];
+    if (rb)
+      vals[k] = (cidx == r) ? 1.0 : 0.0;
+    else if (isbc[cidx])
+      vals[k] = 0.0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// CSR SpMV, LANES lanes per row (wave64 sub-groups), fp64 values / int32 columns.
+//   MODE 0: y = A x         MODE 1: y = b - A x, xsave = x (optional), partial |y|^2 per block
+// Algorithmic bytes: nnz*12 + N*16 + (N+1)*4  (SURVEY §8d).
+// ---------------------------------------------------------------------------------------------
+template <int LANES, int MODE>
+__global__ __launch_bounds__(256) void fc_spmv_csr(int nrows, const int* __restrict__ rowptr,
+                                                   const int* __restrict__ col,
+                                                   const double* __restrict__ val,
+                                                   const double* __restrict__ x,
+                                                   const double* __restrict__ b,
+                                                   double* __restrict__ y, double* __restrict__ xsave,
+                                                   double* __restrict__ partial) {
+  constexpr int RPB = 256 / LANES;
+  const int lane = threadIdx.x % LANES;
+  const int row = blockIdx.x * RPB + threadIdx.x / LANES;
+  double s = 0.0;
+  if (row < nrows) {
+    const int k0 = rowptr[row], k1 = rowptr[row + 1];
+    double s0 = 0.0, s1 = 0.0;
+    int k = k0 + lane;
+    for (; k + LANES < k1; k += 2 * LANES) {
+      s0 += val[k] * x[col[k]];
+      s1 += val[k + LANES] * x[col[k + LANES]];
+    }
+    if (k < k1) s0 += val[k] * x[col[k]];
+    s = s0 + s1;
+  }
+#pragma unroll
+  for (int off = LANES / 2; off > 0; off >>= 1) s += __shfl_down(s, off, LANES);
+  double r2 = 0.0, b2 = 0.0;
+  if (row < nrows && lane == 0) {
+    if (MODE == 0) {
+      y[row] = s;
+    } else {
+      const double bb = b[row];
+      const double r = bb - s;
+      y[row] = r;
+      if (xsave) xsave[row] = x[row];
+      r2 = r * r;
+      b2 = bb * bb;
+    }
+  }
+  if (MODE == 1 && partial) {  // partial[0..grid) = sum r^2, partial[grid..2 grid) = sum b^2
+    __shared__ double red[256], redb[256];
+    red[threadIdx.x] = r2;
+    redb[threadIdx.x] = b2;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if (threadIdx.x < st) {
+        red[threadIdx.x] += red[threadIdx.x + st];
+        redb[threadIdx.x] += redb[threadIdx.x + st];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      partial[blockIdx.x] = red[0];
+      partial[gridDim.x + blockIdx.x] = redb[0];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Nested-dissection factor sweep: one level-wide sparse mat-vec.
+//   kind 0 (up):   buf[row0 + r] += sum_k val[k] * buf[col[k]]          (entries hold -L)
+//   kind 1 (down): buf[N + row0 + r] = sum_k val[k] * buf[col[k]]       (entries hold [D^-1 | -U])
+// Rows of one level only read entries of other levels (or, for `down`, the y half), so a level is
+// one launch with no intra-launch dependency.  int64 row offsets: factors can exceed 2^31 nnz.
+// ---------------------------------------------------------------------------------------------
+template <int LANES>
+__global__ __launch_bounds__(256) void fc_nd_sweep(int nrows, const int64_t* __restrict__ rowptr,
+                                                   const int* __restrict__ col,
+                                                   const double* __restrict__ val,
+                                                   double* __restrict__ buf, int dest0, int accumulate) {
+  constexpr int RPB = 256 / LANES;
+  const int lane = threadIdx.x % LANES;
+  const int row = blockIdx.x * RPB + threadIdx.x / LANES;
+  double s = 0.0;
+  if (row < nrows) {
+    const int64_t k0 = rowptr[row], k1 = rowptr[row + 1];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int64_t k = k0 + lane;
+    for (; k + 3 * LANES < k1; k += 4 * LANES) {
+      const double v0 = val[k], v1 = val[k + LANES], v2 = val[k + 2 * LANES], v3 = val[k + 3 * LANES];
+      const int c0 = col[k], c1 = col[k + LANES], c2 = col[k + 2 * LANES], c3 = col[k + 3 * LANES];
+      s0 += v0 * buf[c0];
+      s1 += v1 * buf[c1];
+      s2 += v2 * buf[c2];
+      s3 += v3 * buf[c3];
+    }
+    for (; k < k1; k += LANES) s0 += val[k] * buf[col[k]];
+    s = (s0 + s1) + (s2 + s3);
+  }
+#pragma unroll
+  for (int off = LANES / 2; off > 0; off >>= 1) s += __shfl_down(s, off, LANES);
+  if (row < nrows && lane == 0) {
+    const int d = dest0 + row;
+    buf[d] = accumulate ? buf[d] + s : s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small vector kernels
+// ---------------------------------------------------------------------------------------------
+__global__ void fc_copy(int n, const double* __restrict__ a, double* __restrict__ b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) b[i] = a[i];
+}
+__global__ void fc_axpy(int n, double alpha, const double* __restrict__ a, double* __restrict__ b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) b[i] += alpha * a[i];
+}
+__global__ void fc_gather_perm(int n, const int* __restrict__ perm, const double* __restrict__ src,
+                               double* __restrict__ dst) {  // dst[i] = src[perm[i]]
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[perm[i]];
+}
+__global__ void fc_scatter_perm(int n, const int* __restrict__ perm, const double* __restrict__ src,
+                                const double* __restrict__ add, double* __restrict__ dst) {  // dst[perm[i]] = src[i] (+ add[i])
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[perm[i]] = add ? src[i] + add[i] : src[i];
+}
+
+// x (permuted) [+ dx] -> up (W layout); shift u_nn <- u_n <- u, p_n <- p; non-finite flag
+// (reference flowsolver.py:730-731,746-751,816-819)
+__global__ __launch_bounds__(256) void fc_finish(int N, int nn2, const int* __restrict__ perm,
+                                                 const double* __restrict__ x,
+                                                 const double* __restrict__ dx, double* __restrict__ up,
+                                                 double* __restrict__ u_n, double* __restrict__ u_nn,
+                                                 double* __restrict__ p_n, int* __restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int r = perm[i];
+  const double v = dx ? x[i] + dx[i] : x[i];
+  up[r] = v;
+  if (r < nn2) {
+    u_nn[r] = u_n[r];
+    u_n[r] = v;
+    if (!isfinite(v)) atomicOr(flag, 1);
+  } else {
+    p_n[r - nn2] = v;
+  }
+}
+
+// one wave per sensor row: y_s = sum_k w[k] up[idx[k]]   (sensor.py:96-98,166-197)
+__global__ void fc_sensors(int n_sens, const int* __restrict__ rowptr, const int* __restrict__ idx,
+                           const double* __restrict__ w, const double* __restrict__ up,
+                           double* __restrict__ y) {
+  const int s = blockIdx.x;
+  if (s >= n_sens) return;
+  double acc = 0.0;
+  for (int k = rowptr[s] + threadIdx.x; k < rowptr[s + 1]; k += 64) acc += w[k] * up[idx[k]];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (threadIdx.x == 0) y[s] = acc;
+}
+
+// energy partials: sum over velocity rows r of u[r] * (M u)[r]; 8 lanes per row
+__global__ __launch_bounds__(256) void fc_energy_partial(int nrows, const int* __restrict__ rowptr,
+                                                         const int* __restrict__ col,
+                                                         const double* __restrict__ val,
+                                                         const double* __restrict__ u,
+                                                         double* __restrict__ partial) {
+  constexpr int LANES = 8, RPB = 32;
+  const int lane = threadIdx.x % LANES;
+  const int row = blockIdx.x * RPB + threadIdx.x / LANES;
+  double s = 0.0;
+  if (row < nrows) {
+    for (int k = rowptr[row] + lane; k < rowptr[row + 1]; k += LANES) {
+      const int cidx = col[k];
+      if (cidx < nrows) s += val[k] * u[cidx];
+    }
+    s *= u[row];
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// out[seg] = scale * sum(partial[seg*n .. seg*n + n)) in a fixed order (one block per segment)
+__global__ void fc_reduce_final(int n, const double* __restrict__ partial, double scale,
+                                double* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  partial += (size_t)blockIdx.x * n;
+  out += blockIdx.x;
+  for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = scale * red[0];
+}

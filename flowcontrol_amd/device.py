@@ -1,0 +1,243 @@
+"""Host-side driver of one ``fc_handle``: numpy in, numpy out, everything else on the MI355X.
+
+This is the only module that talks to ``libfc_hip.so``.  ``FlowSolver`` (the mirror of the
+reference's ``src/flowcontrol/flowsolver.py``) owns one :class:`DeviceSolver`.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+from . import ndsolver
+from ._lib import SLOT_BDF1, SLOT_BDF2, SLOT_MASS, SLOT_SCRATCH, check, ptr
+from .fem.spaces import TaylorHood
+
+
+def _f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class DeviceSolver:
+    def __init__(self, th: TaylorHood, device: int = 0):
+        self.lib = _lib.load()
+        if _lib.device_count() <= 0:
+            raise _lib.FcError(_lib.FC_ERR_HIP, "no HIP device visible: the MI355X path has no CPU fallback")
+        self.th = th
+        m = th.mesh
+        self._h = C.c_void_p()
+        check(
+            self.lib.fc_create(
+                C.byref(self._h), device, m.num_vertices, m.num_edges, m.num_cells, _f64(m.coords), _i32(m.cells), _i32(m.cell_edges)
+            )
+        )
+        N, nnz, nn = C.c_int64(), C.c_int64(), C.c_int64()
+        check(self.lib.fc_get_sizes(self._h, C.byref(N), C.byref(nnz), C.byref(nn)))
+        self.N, self.nnz, self.nn = N.value, nnz.value, nn.value
+        assert self.N == th.N and self.nn == th.nn
+        self.rowptr = np.empty(self.N + 1, dtype=np.int32)
+        self.colidx = np.empty(self.nnz, dtype=np.int32)
+        check(self.lib.fc_get_pattern(self._h, self.rowptr, self.colidx))
+        self.n_act = 0
+        self.n_sens = 0
+        self.tree: ndsolver.NDTree | None = None
+        self.factor_nnz: dict[int, int] = {}
+
+    # ── lifetime ─────────────────────────────────────────────────────────────
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.fc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ── matrices ─────────────────────────────────────────────────────────────
+    def assemble_matrix(self, slot, mass=0.0, nu=0.0, adv=None, lin=None, adv_scale=1.0, lin_scale=1.0, pressure=-1.0, divergence=-1.0):
+        adv = None if adv is None else _f64(adv)
+        lin = None if lin is None else _f64(lin)
+        check(self.lib.fc_assemble_matrix(self._h, slot, mass, nu, ptr(adv), adv_scale, ptr(lin), lin_scale, pressure, divergence))
+
+    def matrix(self, slot) -> sp.csr_matrix:
+        vals = np.empty(self.nnz)
+        check(self.lib.fc_get_matrix_values(self._h, slot, vals))
+        return sp.csr_matrix((vals, self.colidx.copy(), self.rowptr.copy()), shape=(self.N, self.N))
+
+    def set_matrix_values(self, slot, vals) -> None:
+        check(self.lib.fc_set_matrix_values(self._h, slot, _f64(vals)))
+
+    def spmv(self, slot, x) -> np.ndarray:
+        y = np.empty(self.N)
+        check(self.lib.fc_spmv(self._h, slot, _f64(x), y))
+        return y
+
+    def bench_spmv(self, slot, reps=1000) -> float:
+        ms = C.c_double()
+        check(self.lib.fc_bench_spmv(self._h, slot, reps, C.byref(ms)))
+        return ms.value
+
+    # ── problem data ─────────────────────────────────────────────────────────
+    def set_bc(self, bc_dofs, profiles) -> None:
+        bc_dofs = _i32(bc_dofs)
+        profiles = _f64(profiles).reshape(len(bc_dofs), -1) if len(bc_dofs) else np.zeros((0, np.shape(profiles)[-1] if np.ndim(profiles) > 1 else 0))
+        self.n_act = profiles.shape[1]
+        self.bc_dofs = bc_dofs
+        check(self.lib.fc_set_bc(self._h, len(bc_dofs), ptr(bc_dofs), self.n_act, ptr(np.ascontiguousarray(profiles))))
+
+    def set_force(self, profiles) -> None:
+        if profiles is None:
+            check(self.lib.fc_set_force(self._h, 0, None))
+            return
+        profiles = _f64(profiles).reshape(self.n_act, 2 * self.nn)
+        check(self.lib.fc_set_force(self._h, self.n_act, ptr(profiles)))
+
+    def set_sensors(self, rows: list[tuple[np.ndarray, np.ndarray]]) -> None:
+        self.n_sens = len(rows)
+        rp = np.zeros(len(rows) + 1, dtype=np.int32)
+        for i, (idx, _) in enumerate(rows):
+            rp[i + 1] = rp[i] + len(idx)
+        idx = _i32(np.concatenate([r[0] for r in rows])) if rows else np.zeros(0, np.int32)
+        w = _f64(np.concatenate([r[1] for r in rows])) if rows else np.zeros(0)
+        check(self.lib.fc_set_sensors(self._h, len(rows), ptr(rp), ptr(idx), ptr(w)))
+
+    def set_time_scheme(self, dt: float, nonlinear: bool = True) -> None:
+        check(self.lib.fc_set_time_scheme(self._h, float(dt), int(bool(nonlinear))))
+
+    def apply_bc(self, slot) -> None:
+        check(self.lib.fc_apply_bc(self._h, slot))
+
+    # ── solver setup (host analysis + factorisation, device upload) ──────────
+    def setup_solver(self, slot: int, depth: int | None = None, refine: int = 1, check_residual: bool = True) -> None:
+        """Factorise the (BC-eliminated) matrix of ``slot`` and hand the factors to the device."""
+        A = self.matrix(slot)
+        if self.tree is None:
+            th = self.th
+            if depth is None:
+                depth = max(2, int(np.ceil(np.log2(max(th.nc, 1) / 8.0))))
+            skip = np.zeros(self.N, dtype=bool)
+            skip[self.bc_dofs] = True
+            self.tree = ndsolver.build_tree(th.cell_dofs, th.mesh.cell_centroids(), self.N, depth, skip)
+            check(self.lib.fc_set_permutation(self._h, _i32(self.tree.perm)))
+        fac = ndsolver.factorize(A, self.tree)
+        t = self.tree
+        Ap = A[t.perm][:, t.perm].tocsr()
+        Ap.sort_indices()
+        mats, row0, kind = [], [], []
+        for i, k in enumerate(range(t.depth - 1, -1, -1)):
+            mats.append(fac.up[i])
+            row0.append(int(t.node_ptr[k][0]))
+            kind.append(0)
+        for k in range(0, t.depth + 1):
+            mats.append(fac.down[k])
+            row0.append(int(t.node_ptr[k][0]))
+            kind.append(1)
+        nrows = np.array([m.shape[0] for m in mats], dtype=np.int32)
+        begin = np.concatenate([[0], np.cumsum(nrows)[:-1]]).astype(np.int64)
+        f_rowptr = np.zeros(int(nrows.sum()) + 1, dtype=np.int64)
+        pos, off = 0, 0
+        cols, vals = [], []
+        for m in mats:
+            m.sort_indices()
+            f_rowptr[pos + 1 : pos + 1 + m.shape[0]] = off + m.indptr[1:].astype(np.int64)
+            pos += m.shape[0]
+            off += m.nnz
+            cols.append(m.indices.astype(np.int32))
+            vals.append(m.data)
+        f_col = _i32(np.concatenate(cols))
+        f_val = _f64(np.concatenate(vals))
+        check(
+            self.lib.fc_solver_setup(
+                self._h, slot, _i32(Ap.indptr), _i32(Ap.indices), _f64(Ap.data), len(mats), begin,
+                _i32(row0), nrows, _i32(kind), f_rowptr, f_col, f_val,
+            )
+        )
+        self.factor_nnz[slot] = int(f_val.size)
+        check(self.lib.fc_set_solver_options(self._h, _lib.METHOD_REFINE, int(refine), 1e-10, int(check_residual)))
+
+    # ── state ────────────────────────────────────────────────────────────────
+    def set_state(self, u_n, u_nn, p_n=None) -> None:
+        p = None if p_n is None else _f64(p_n)
+        check(self.lib.fc_set_state(self._h, _f64(u_n), _f64(u_nn), ptr(p)))
+
+    def get_state(self):
+        u_n, u_nn, p_n = np.empty(2 * self.nn), np.empty(2 * self.nn), np.empty(self.th.nv)
+        check(self.lib.fc_get_state(self._h, ptr(u_n), ptr(u_nn), ptr(p_n)))
+        return u_n, u_nn, p_n
+
+    def get_solution(self) -> np.ndarray:
+        up = np.empty(self.N)
+        check(self.lib.fc_get_solution(self._h, up))
+        return up
+
+    # ── hot path ─────────────────────────────────────────────────────────────
+    def step(self, order_slot: int, u_ctrl, compute_energy: bool = True):
+        u = _f64(np.atleast_1d(u_ctrl)) if self.n_act else None
+        y = np.empty(max(self.n_sens, 1))
+        info = np.empty(4)
+        dE = C.c_double()
+        check(self.lib.fc_step(self._h, order_slot, ptr(u), ptr(y), C.byref(dE), int(compute_energy), ptr(info)))
+        return y[: self.n_sens], dE.value, info
+
+    def run(self, first_order_slot: int, n_steps: int, u_ctrl, compute_energy: bool = True):
+        u = _f64(u_ctrl)
+        is_seq = int(u.ndim == 2)
+        y = np.empty((n_steps, max(self.n_sens, 1)))
+        yv = np.empty((n_steps, self.n_sens))
+        dE = np.empty(n_steps)
+        check(self.lib.fc_run(self._h, first_order_slot, n_steps, ptr(u), is_seq, ptr(yv), ptr(dE), int(compute_energy)))
+        del y
+        return yv, dE
+
+    # ── parity hooks ─────────────────────────────────────────────────────────
+    def assemble_rhs(self, order_slot: int, u_ctrl) -> np.ndarray:
+        u = _f64(np.atleast_1d(u_ctrl)) if self.n_act else None
+        b = np.empty(self.N)
+        check(self.lib.fc_assemble_rhs(self._h, order_slot, ptr(u), b))
+        return b
+
+    def solve(self, slot: int, b):
+        x = np.empty(self.N)
+        info = np.empty(4)
+        check(self.lib.fc_solve(self._h, slot, _f64(b), x, ptr(info)))
+        return x, info
+
+    def energy(self, u) -> float:
+        E = C.c_double()
+        check(self.lib.fc_energy(self._h, _f64(u), C.byref(E)))
+        return E.value
+
+    def measure(self, up) -> np.ndarray:
+        y = np.empty(max(self.n_sens, 1))
+        check(self.lib.fc_measure(self._h, _f64(up), ptr(y)))
+        return y[: self.n_sens]
+
+    # ── measurement ──────────────────────────────────────────────────────────
+    def profile_steps(self, order_slot: int, n_steps: int, u_ctrl):
+        u = _f64(np.atleast_1d(u_ctrl)) if self.n_act else None
+        ms = np.empty(5)
+        nl = C.c_int32()
+        check(self.lib.fc_profile_steps(self._h, order_slot, n_steps, ptr(u), ms, C.byref(nl)))
+        return ms, nl.value
+
+    def bench_sweeps(self, slot: int, reps: int = 200):
+        ms, nl = C.c_double(), C.c_int32()
+        check(self.lib.fc_bench_sweeps(self._h, slot, reps, C.byref(ms), C.byref(nl)))
+        return ms.value, nl.value
+
+    def algorithmic_bytes(self, slot: int):
+        a, b = C.c_double(), C.c_double()
+        check(self.lib.fc_algorithmic_bytes(self._h, slot, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+
+__all__ = ["DeviceSolver", "SLOT_BDF1", "SLOT_BDF2", "SLOT_MASS", "SLOT_SCRATCH"]

@@ -140,6 +140,14 @@ class Mesh:
         nv = coords.shape[0]
         if cells.min() < 0 or cells.max() >= nv:
             raise ValueError("cell vertex index out of range")
+        # orient counter-clockwise *before* renumbering so the numbering does not depend on
+        # the orientation the file happened to use
+        p = coords[cells]
+        det = (p[:, 1, 0] - p[:, 0, 0]) * (p[:, 2, 1] - p[:, 0, 1]) - (p[:, 2, 0] - p[:, 0, 0]) * (
+            p[:, 1, 1] - p[:, 0, 1]
+        )
+        cells = cells.copy()
+        cells[det < 0] = cells[det < 0][:, [0, 2, 1]]
         if reorder:
             ckey = _morton_key(coords[cells].mean(axis=1))
             corder = np.argsort(ckey, kind="stable")

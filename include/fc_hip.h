@@ -1,0 +1,161 @@
+/*
+ * fc_hip.h — C ABI of libfc_hip.so: the MI355X (gfx950) implementation of FlowControl's
+ * per-timestep hot path (FEM assembly of the semi-implicit Navier–Stokes forms + the linear
+ * solve that advances (v, p) by one Δt).
+ *
+ * The reference (williamjussiau/FlowControl) has no FFI of its own: its hot path is
+ * `FlowSolver.step` (src/flowcontrol/flowsolver.py:703-799) driving two third-party dolfin
+ * objects, `dolfin.SystemAssembler` (:693-696, :728) and `dolfin.LUSolver("mumps")`
+ * (:697, :729, :812-814).  Every entry point below names the reference interface it replaces.
+ * The binding a reference maintainer would add is the ctypes stub in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no torch / C++ types in any signature; caller owns all host buffers, the library
+ *     owns all device memory; one opaque handle per solver, one HIP stream per handle,
+ *     not re-entrant per handle.
+ *   - every function returns an int status: 0 = ok, <0 = error class (FC_ERR_*); nothing throws
+ *     across the boundary.  fc_last_error() returns a message for the calling thread.
+ *   - all floating point data is IEEE fp64 (the reference computes in fp64 throughout);
+ *     all index data is int32 unless stated.
+ *   - mixed-space vector layout "W": [ux(nn) | uy(nn) | p(nv)], nn = nv + ne P2 scalar nodes
+ *     (vertex v → v, edge e → nv + e); N = 2 nn + nv.
+ */
+#ifndef FC_HIP_H
+#define FC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fc_ctx* fc_handle;
+
+enum {
+  FC_OK = 0,
+  FC_ERR_INVALID = -1,     /* bad argument / call order */
+  FC_ERR_HIP = -2,         /* HIP runtime error (no device, OOM, launch failure) */
+  FC_ERR_DIVERGED = -3,    /* non-finite velocity after the solve (flowsolver.py:731,816-819) */
+  FC_ERR_NOT_CONVERGED = -4, /* Krylov / refinement did not reach the requested tolerance */
+  FC_ERR_NOT_READY = -5    /* a required setup call is missing */
+};
+
+/* matrix slots: independent value arrays on the shared Taylor–Hood CSR pattern */
+enum { FC_SLOT_BDF1 = 0, FC_SLOT_BDF2 = 1, FC_SLOT_MASS = 2, FC_SLOT_SCRATCH = 3, FC_NUM_SLOTS = 4 };
+
+/* Krylov / refinement method of fc_solve / fc_step */
+enum { FC_METHOD_REFINE = 0, FC_METHOD_BICGSTAB = 1, FC_METHOD_GMRES = 2 };
+
+const char* fc_last_error(void);
+int fc_device_count(int* count);
+
+/* ── construction: replaces FlowSolver._make_mesh / _make_function_spaces
+ *    (flowsolver.py:233-250) on the device side.  cells are CCW vertex triples,
+ *    cell_edges[c][k] is the edge opposite local vertex k. ------------------------------------ */
+int fc_create(fc_handle* out, int device, int32_t nv, int32_t ne, int32_t nc,
+              const double* coords /* [nv][2] */, const int32_t* cells /* [nc][3] */,
+              const int32_t* cell_edges /* [nc][3] */);
+int fc_destroy(fc_handle h);
+
+/* sizes of the mixed space and of the CSR pattern (full 15x15 element coupling minus the
+ * pressure-pressure block) */
+int fc_get_sizes(fc_handle h, int64_t* N, int64_t* nnz, int64_t* nn);
+int fc_get_pattern(fc_handle h, int32_t* rowptr /* [N+1] */, int32_t* colidx /* [nnz] */);
+
+/* ── bilinear-form assembly: replaces dolfin.SystemAssembler.assemble(A) (flowsolver.py:693-696),
+ *    dolfin.assemble(a) in SteadyStateSolver.picard (steadystate.py:137) and the Jacobian
+ *    assembly of OperatorGetter.get_A (operatorgetter.py:79-80).  Element loop on the device:
+ *      mass (u,v) + adv_scale ((adv.grad)u, v) + lin_scale ((u.grad)lin, v) + nu (grad u, grad v)
+ *      + pressure (p, div v) + divergence (q, div u)
+ *    adv / lin are host velocity fields [2 nn] or NULL.  No boundary conditions. ------------- */
+int fc_assemble_matrix(fc_handle h, int slot, double mass, double nu, const double* adv,
+                       double adv_scale, const double* lin, double lin_scale, double pressure,
+                       double divergence);
+int fc_get_matrix_values(fc_handle h, int slot, double* vals /* [nnz] */);
+int fc_set_matrix_values(fc_handle h, int slot, const double* vals /* [nnz] */);
+
+/* y = A_slot x on the device (original numbering); parity hook + SpMV roofline probe */
+int fc_spmv(fc_handle h, int slot, const double* x /* [N] */, double* y /* [N] */);
+/* time `reps` back-to-back launches of the CSR SpMV kernel with HIP events on the handle's
+ * stream; returns the mean milliseconds per launch */
+int fc_bench_spmv(fc_handle h, int slot, int reps, double* ms_per_launch);
+
+/* ── Dirichlet data: replaces the DirichletBC list handed to SystemAssembler
+ *    (flowsolver.py:693; case files' _make_bcs).  Every actuator expression is linear in u_ctrl
+ *    (actuator.py:190-199,241-251,269-276), so the value on BC dof i is
+ *    sum_k profiles[i][k] * u_ctrl[k]. -------------------------------------------------------- */
+int fc_set_bc(fc_handle h, int32_t n_bc, const int32_t* bc_dofs /* [n_bc] W indices */,
+              int32_t n_act, const double* profiles /* [n_bc][n_act] */);
+/* body force of FORCE-type actuators (actuator.py:297-313): nodal P2 values per unit u_ctrl */
+int fc_set_force(fc_handle h, int32_t n_act, const double* profiles /* [n_act][2 nn] or NULL */);
+/* sensors as sparse rows of the functional up -> y (sensor.py:96-98,166-197; utils/mpi.py:22-37) */
+int fc_set_sensors(fc_handle h, int32_t n_sens, const int32_t* rowptr /* [n_sens+1] */,
+                   const int32_t* idx, const double* w);
+/* time scheme constants (flowsolverparameters.py ParamTime.dt, ParamSolver.is_eq_nonlinear) */
+int fc_set_time_scheme(fc_handle h, double dt, int nonlinear);
+
+/* SystemAssembler's symmetric Dirichlet elimination on a slot: stores the lifting vectors
+ * A[:, D] * profile_k for `order_slot`, then zeroes BC rows and columns and puts 1 on the
+ * diagonal. */
+int fc_apply_bc(fc_handle h, int slot);
+
+/* ── solver setup: replaces LUSolver.set_operator(A) + the factorisation MUMPS performs at the
+ *    first solve (flowsolver.py:697,729).  The host side (flowcontrol_amd/ndsolver.py) supplies
+ *    the nested-dissection permutation and the level-wise selected-inverse factors. ---------- */
+int fc_set_permutation(fc_handle h, const int32_t* perm /* [N] new -> old */);
+int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32_t* Ap_col,
+                    const double* Ap_val, /* permuted system matrix (N rows) */
+                    int32_t n_stages, const int64_t* stage_rowptr_begin /* [n_stages] */,
+                    const int32_t* stage_row0 /* [n_stages] first destination row */,
+                    const int32_t* stage_nrows /* [n_stages] */,
+                    const int32_t* stage_kind /* [n_stages] 0 = up (y += ..), 1 = down (x = ..) */,
+                    const int64_t* f_rowptr /* [total_rows + 1] */, const int32_t* f_col,
+                    const double* f_val);
+int fc_set_solver_options(fc_handle h, int method, int max_iter, double rtol, int check_residual);
+
+/* ── state: FlowFieldCollection u_n, u_nn, p_n (flowfield.py:67-105; flowsolver.py:487-491) ─ */
+int fc_set_state(fc_handle h, const double* u_n /* [2 nn] */, const double* u_nn /* [2 nn] */,
+                 const double* p_n /* [nv] */);
+int fc_get_state(fc_handle h, double* u_n, double* u_nn, double* p_n);
+int fc_get_solution(fc_handle h, double* up /* [N] last solve, W layout */);
+
+/* ── THE per-step crossing: replaces assemblers[order].assemble(rhs); solvers[order].solve(...);
+ *    split; _solver_diverged; field shift; make_measurement; compute_perturbation_energy
+ *    (flowsolver.py:724-779).  order_slot is FC_SLOT_BDF1 or FC_SLOT_BDF2.
+ *    y_out[n_sens], dE_out (1/2 |u|^2_L2, NaN if compute_energy == 0), info_out[4] =
+ *    {iterations, relative residual of the first refinement residual, |b|, flags}. ------------- */
+int fc_step(fc_handle h, int order_slot, const double* u_ctrl /* [n_act] */, double* y_out,
+            double* dE_out, int compute_energy, double* info_out);
+/* n_steps open-loop steps without host synchronisation in between (u_ctrl constant or a
+ * sequence [n_steps][n_act]); y_seq [n_steps][n_sens], dE_seq [n_steps] (may be NULL). */
+int fc_run(fc_handle h, int first_order_slot, int32_t n_steps, const double* u_ctrl,
+           int u_ctrl_is_sequence, double* y_seq, double* dE_seq, int compute_energy);
+
+/* ── parity hooks (tests) ------------------------------------------------------------------- */
+/* RHS of `order_slot` for the current state and u_ctrl, in W layout, BCs lifted and imposed:
+ * what SystemAssembler.assemble(rhs) returns (flowsolver.py:728) */
+int fc_assemble_rhs(fc_handle h, int order_slot, const double* u_ctrl, double* b_out /* [N] */);
+/* x = A_bc^{-1} b with the device solver of `slot` */
+int fc_solve(fc_handle h, int slot, const double* b /* [N] */, double* x /* [N] */,
+             double* info_out /* [4] */);
+/* 1/2 u^T M u for a host velocity field (flowsolver.py:827-829); needs FC_SLOT_MASS assembled */
+int fc_energy(fc_handle h, const double* u /* [2 nn] */, double* E);
+int fc_measure(fc_handle h, const double* up /* [N] */, double* y /* [n_sens] */);
+
+/* ── measurement: HIP-event timing of the phases of fc_step on the handle's stream.
+ *    phase ids: 0 rhs element loop, 1 rhs gather+BC, 2 factor sweeps (all launches of one
+ *    apply), 3 residual SpMV, 4 finish (scatter/shift/sensors/energy).
+ *    ms[5] = mean ms per step of each phase over `n_steps` profiled steps; sweep_launches =
+ *    number of sweep-kernel launches per step. */
+int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double* u_ctrl,
+                     double* ms /* [5] */, int32_t* sweep_launches);
+/* time `reps` back-to-back factor applies (all sweep launches of one M^-1 application) with HIP
+ * events on the handle's stream; mean milliseconds per apply and launches per apply */
+int fc_bench_sweeps(fc_handle h, int slot, int reps, double* ms_per_apply, int32_t* launches_per_apply);
+/* algorithmic bytes of one factor apply (sum over sweep launches) and of one CSR SpMV */
+int fc_algorithmic_bytes(fc_handle h, int slot, double* sweep_bytes, double* spmv_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FC_HIP_H */

@@ -1,0 +1,148 @@
+"""GPU parity of the individual HIP kernels against the CPU oracle (through the C ABI).
+
+Tolerances: everything is fp64; the device sums in a different (but fixed) order than numpy, so
+vectors agree to a few ulps relative to their norm — 1e-12 relative is asserted.
+"""
+import numpy as np
+import pytest
+
+from flowcontrol_amd.fem.mesh import Mesh, read_xdmf_mesh
+from flowcontrol_amd.fem.spaces import TaylorHood
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-12
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _smooth_velocity(th, k=1.0):
+    x = th.node_coords
+    return np.r_[1.0 + 0.3 * np.sin(k * x[:, 0]) * np.cos(0.7 * k * x[:, 1]), 0.2 * np.cos(0.5 * k * x[:, 0] + 0.1) * np.sin(k * x[:, 1])]
+
+
+@pytest.fixture(scope="module", params=["square8", "O1"])
+def setup(request, golden_dir):
+    from flowcontrol_amd.device import DeviceSolver
+    from oracle import ns_oracle as O
+
+    if request.param == "square8":
+        mesh = Mesh.unit_square(8, 8)
+    else:
+        mesh = read_xdmf_mesh(golden_dir / "meshes" / "O1.npz")
+    th = TaylorHood(mesh)
+    dev = DeviceSolver(th)
+    d = O.Disc.from_taylor_hood(th)
+    yield th, dev, d, O
+    dev.close()
+
+
+def test_pattern_matches_oracle(setup):
+    th, dev, d, O = setup
+    A = O.assemble_matrix(d, mass=1.0, nu=1.0, adv=_smooth_velocity(th), lin=_smooth_velocity(th))
+    import scipy.sparse as sp
+
+    P = sp.csr_matrix((np.ones(dev.nnz), dev.colidx, dev.rowptr), shape=(dev.N, dev.N))
+    # every oracle nonzero lies inside the device pattern
+    A.eliminate_zeros()
+    assert (abs(A) > 0).multiply(P).nnz == (abs(A) > 0).nnz
+
+
+@pytest.mark.parametrize("case", ["bdf2", "picard", "jacobian", "mass"])
+def test_matrix_assembly(setup, case):
+    th, dev, d, O = setup
+    from flowcontrol_amd.device import SLOT_SCRATCH
+
+    U = _smooth_velocity(th)
+    kw = dict(
+        bdf2=dict(mass=300.0, nu=0.01, adv=U, lin=U),
+        picard=dict(mass=0.0, nu=0.01, adv=U, lin=None),
+        jacobian=dict(mass=0.0, nu=0.02, adv=U, lin=0.5 * U),
+        mass=dict(mass=1.0, nu=0.0, adv=None, lin=None, pressure=0.0, divergence=0.0),
+    )[case]
+    dev.assemble_matrix(SLOT_SCRATCH, **kw)
+    A_dev = dev.matrix(SLOT_SCRATCH)
+    A_ref = O.assemble_matrix(d, **kw)
+    diff = (A_dev - A_ref).tocoo()
+    assert np.abs(diff.data).max() <= RTOL * np.abs(A_ref.data).max()
+
+
+def test_spmv(setup):
+    th, dev, d, O = setup
+    from flowcontrol_amd.device import SLOT_SCRATCH
+
+    U = _smooth_velocity(th)
+    dev.assemble_matrix(SLOT_SCRATCH, mass=300.0, nu=0.01, adv=U, lin=U)
+    A = dev.matrix(SLOT_SCRATCH)
+    x = np.random.default_rng(0).standard_normal(dev.N)
+    assert _rel(dev.spmv(SLOT_SCRATCH, x), A @ x) < RTOL
+
+
+def _bc_setup(th):
+    """Dirichlet on every boundary facet except the x = xmax side (outflow keeps the pressure
+    level unique); two 'actuators' with smooth profiles on them."""
+    m = th.mesh
+    be = m.boundary_edges()
+    be = be[m.edge_midpoints()[be, 0] < m.coords[:, 0].max() - 1e-9]
+    nodes = np.unique(np.r_[m.edges[be].reshape(-1), th.nv + be])
+    dofs = np.r_[nodes, nodes + th.nn]
+    x = th.node_coords[nodes]
+    p0 = np.r_[np.sin(x[:, 0] + 2 * x[:, 1]), 0 * x[:, 0]]
+    p1 = np.r_[0 * x[:, 0], np.cos(3 * x[:, 0] - x[:, 1])]
+    order = np.argsort(dofs)
+    return dofs[order], np.stack([p0, p1], axis=1)[order]
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_rhs_solve_step(setup, order):
+    th, dev, d, O = setup
+    from flowcontrol_amd.device import SLOT_BDF1, SLOT_BDF2, SLOT_MASS
+
+    dt, Re = 0.005, 100.0
+    U0 = _smooth_velocity(th)
+    dofs, prof = _bc_setup(th)
+    dev.set_bc(dofs, prof)
+    dev.set_time_scheme(dt, True)
+    ts = O.TimeStepper(d, Re, dt, U0, dofs, prof, orders=(order,))
+    slot = SLOT_BDF1 if order == 1 else SLOT_BDF2
+    alpha = (1.0 if order == 1 else 1.5) / dt
+    dev.assemble_matrix(slot, mass=alpha, nu=1.0 / Re, adv=U0, lin=U0)
+    dev.apply_bc(slot)
+    A_bc = dev.matrix(slot)
+    dA = (A_bc - ts.A_bc[order]).tocoo()
+    assert np.abs(dA.data).max() <= RTOL * np.abs(ts.A_bc[order].data).max()
+    dev.assemble_matrix(SLOT_MASS, mass=1.0, nu=0.0, pressure=0.0, divergence=0.0)
+    dev.setup_solver(slot, refine=1)
+    rng = np.random.default_rng(order)
+    u_n = 0.1 * _smooth_velocity(th, 2.0) + 0.01 * rng.standard_normal(2 * th.nn)
+    u_nn = 0.1 * _smooth_velocity(th, 1.5)
+    dev.set_state(u_n, u_nn, np.zeros(th.nv))
+    uc = np.array([0.3, -0.2])
+    # RHS (element loop + gather + lifting)
+    b_dev = dev.assemble_rhs(slot, uc)
+    b_ref = ts.rhs(order, u_n, u_nn, uc)
+    assert _rel(b_dev, b_ref) < RTOL
+    # solve
+    x_dev, info = dev.solve(slot, b_ref)
+    x_ref = ts.solve(order, b_ref)
+    assert _rel(x_dev, x_ref) < 1e-10
+    assert np.linalg.norm(ts.A_bc[order] @ x_dev - b_ref) / np.linalg.norm(b_ref) < 1e-12
+    # full step: shift, sensors, energy
+    rows = [th.point_eval_row(p, c) for p, c in [((0.31, 0.42), 1), ((0.5, 0.5), 0), ((0.77, 0.13), 2)]] if th.nc < 1000 else [
+        th.point_eval_row(p, 1) for p in [(3.0, 0.0), (3.1, 1.0), (3.1, -1.0)]
+    ]
+    dev.set_sensors(rows)
+    y, dE, info = dev.step(slot, uc)
+    up_ref = ts.step(order, u_n, u_nn, uc)
+    up_dev = dev.get_solution()
+    assert _rel(up_dev, up_ref) < 1e-10
+    y_ref = np.array([w @ up_ref[i] for i, w in rows])
+    assert np.allclose(y, y_ref, rtol=1e-9, atol=1e-12)
+    M = O.velocity_mass(d)
+    u_new = up_ref[: 2 * th.nn]
+    assert np.isclose(dE, 0.5 * u_new @ (M @ u_new), rtol=1e-10)
+    g_un, g_unn, g_pn = dev.get_state()
+    assert _rel(g_un, u_new) < 1e-10 and np.array_equal(g_unn, u_n)
+    assert info[1] < 1e-9  # relative residual before refinement
