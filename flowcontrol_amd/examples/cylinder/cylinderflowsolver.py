@@ -1,0 +1,119 @@
+"""Flow past a cylinder (Re = 100): the case file of BASELINE configs 1/2/4.
+
+Counterpart of the reference's ``src/examples/cylinder/cylinderflowsolver.py``: same six
+boundaries (inlet, outlet, walls, cylinder body, two actuator slots at the poles), same five
+Dirichlet conditions in the same order, same ``make_default`` parameters.  The C++ predicate
+strings of the reference (``cylinderflowsolver.py:35-83``) are written as vectorised numpy
+predicates with identical comparisons and tolerances.
+"""
+
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+import pandas
+
+from ... import flowsolver
+from ...fem.boundary import DOLFIN_EPS, Constant, DirichletBC, SubDomain, between, near
+from ...flowfield import BoundaryConditions
+
+#: mesh fixture shipped with this repository (converted from the reference's O1.xdmf data file)
+DEFAULT_MESH = Path(__file__).resolve().parents[3] / "tests" / "golden" / "meshes" / "O1.npz"
+
+
+class CylinderFlowSolver(flowsolver.FlowSolver):
+    """Flow past a cylinder. Proposed Re=100."""
+
+    def _make_boundaries(self):
+        TOL = DOLFIN_EPS
+        xinfa = self.params_mesh.user_data["xinfa"]
+        xinf = self.params_mesh.user_data["xinf"]
+        yinf = self.params_mesh.user_data["yinf"]
+        radius = self.params_flow.user_data["D"] / 2
+        ldelta = self.params_control.actuator_list[0].width
+
+        def close_to_cylinder(x):
+            return between(x[:, 0], -radius, radius) & between(x[:, 1], -radius, radius)
+
+        inlet = SubDomain(lambda x, ob: ob & near(x[:, 0], xinfa, TOL), "inlet")
+        outlet = SubDomain(lambda x, ob: ob & near(x[:, 0], xinf, TOL), "outlet")
+        walls = SubDomain(lambda x, ob: ob & (near(x[:, 1], -yinf, TOL) | near(x[:, 1], yinf, TOL)), "walls")
+        cylinder = SubDomain(
+            lambda x, ob: ob & close_to_cylinder(x) & (between(x[:, 0], -radius, -ldelta) | between(x[:, 0], ldelta, radius)),
+            "cylinder",
+        )
+        actuator_up = SubDomain(
+            lambda x, ob: ob & close_to_cylinder(x) & between(x[:, 0], -ldelta, ldelta, tol=0.01) & between(x[:, 1], 0.0, radius),
+            "actuator_up",
+        )
+        actuator_lo = SubDomain(
+            lambda x, ob: ob & close_to_cylinder(x) & between(x[:, 0], -ldelta, ldelta, tol=0.01) & between(x[:, 1], -radius, 0.0),
+            "actuator_lo",
+        )
+        return pandas.DataFrame(
+            index=["inlet", "outlet", "walls", "cylinder", "actuator_up", "actuator_lo"],
+            data={"subdomain": [inlet, outlet, walls, cylinder, actuator_up, actuator_lo]},
+        )
+
+    def _make_bcs(self):
+        """Zero on inlet / walls (v only) / cylinder body; actuator expressions on the two slots."""
+        W = self.W
+        acts = self.params_control.actuator_list
+        bcu_inlet = DirichletBC(W.sub(0), Constant((0, 0)), self.get_subdomain("inlet"))
+        bcu_walls = DirichletBC(W.sub(0).sub(1), Constant(0), self.get_subdomain("walls"))
+        bcu_cylinder = DirichletBC(W.sub(0), Constant((0, 0)), self.get_subdomain("cylinder"))
+        bcu_actuation_up = DirichletBC(W.sub(0), acts[0].expression, self.get_subdomain("actuator_up"))
+        bcu_actuation_lo = DirichletBC(W.sub(0), acts[1].expression, self.get_subdomain("actuator_lo"))
+        return BoundaryConditions(bcu=[bcu_inlet, bcu_walls, bcu_cylinder, bcu_actuation_up, bcu_actuation_lo], bcp=[])
+
+    @classmethod
+    def make_default(
+        cls,
+        Re: float = 100,
+        path_out=None,
+        num_steps: int = 10,
+        save_every: int = 0,
+        Tstart: float = 0.0,
+        verbose: int = 0,
+        meshpath: str | Path | None = None,
+    ) -> "CylinderFlowSolver":
+        """Standard parameters of the reference (``cylinderflowsolver.py:128-186``): Re=100, dt=0.005,
+        2 parabolic BC actuators of 10° at the poles, 3 V-probes at (3,0), (3.1,±1)."""
+        from ... import flowsolverparameters as fsp
+        from ...actuator import ActuatorBCParabolicV
+        from ...sensor import SENSOR_TYPE, SensorPoint
+
+        if path_out is None:
+            path_out = Path.cwd() / "data_output"
+        params_flow = fsp.ParamFlow(Re=Re, uinf=1.0)
+        params_flow.user_data["D"] = 1.0
+        params_time = fsp.ParamTime(num_steps=num_steps, dt=0.005, Tstart=Tstart)
+        params_save = fsp.ParamSave(save_every=save_every, path_out=Path(path_out))
+        params_solver = fsp.ParamSolver(throw_error=True, is_eq_nonlinear=True, shift=0.0)
+        params_mesh = fsp.ParamMesh(meshpath=Path(meshpath or DEFAULT_MESH))
+        params_mesh.user_data.update({"xinf": 20, "xinfa": -10, "yinf": 10})
+        radius = params_flow.user_data["D"] / 2
+        width = ActuatorBCParabolicV.angular_size_deg_to_width(10, radius)
+        params_control = fsp.ParamControl(
+            sensor_list=[
+                SensorPoint(sensor_type=SENSOR_TYPE.V, position=np.array([3.0, 0.0])),
+                SensorPoint(sensor_type=SENSOR_TYPE.V, position=np.array([3.1, 1.0])),
+                SensorPoint(sensor_type=SENSOR_TYPE.V, position=np.array([3.1, -1.0])),
+            ],
+            actuator_list=[
+                ActuatorBCParabolicV(width=width, position_x=0.0, boundary_name="actuator_up"),
+                ActuatorBCParabolicV(width=width, position_x=0.0, boundary_name="actuator_lo"),
+            ],
+        )
+        params_ic = fsp.ParamIC()
+        return cls(
+            params_flow=params_flow,
+            params_time=params_time,
+            params_save=params_save,
+            params_solver=params_solver,
+            params_mesh=params_mesh,
+            params_control=params_control,
+            params_ic=params_ic,
+            verbose=verbose,
+        )

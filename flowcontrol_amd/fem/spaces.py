@@ -317,3 +317,23 @@ class TaylorHood:
 
 
 __all__ = ["Vector", "FunctionSpace", "Function", "TaylorHood"]
+
+
+def _th_device(self, device_index: int = 0):
+    """The MI355X handle bound to this discretisation (created on first use; no CPU fallback)."""
+    if getattr(self, "_device", None) is None:
+        from ..device import DeviceSolver
+
+        self._device = DeviceSolver(self, device_index)
+    return self._device
+
+
+def _th_release(self) -> None:
+    dev = getattr(self, "_device", None)
+    if dev is not None:
+        dev.close()
+    self._device = None
+
+
+TaylorHood.device = _th_device
+TaylorHood.release_device = _th_release

@@ -1,0 +1,56 @@
+"""Small helpers user scripts import from the reference's ``utils`` package
+(``utils/utils_flowsolver.py`` aggregator: ``flu.apply_fun``, ``flu.MpiUtils``, ``flu.summarize_timings``)."""
+
+from __future__ import annotations
+
+import logging
+import time
+from typing import Any, Callable
+
+import numpy as np
+
+logger = logging.getLogger(__name__)
+
+
+def apply_fun(u, fun: Callable[[np.ndarray], Any]) -> Any:
+    """Apply a numpy reduction to all DoF values of ``u`` (``utils/fem.py:20-28``)."""
+    return fun(u.vector().get_local())
+
+
+def get_rank() -> int:
+    try:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank()
+    except Exception:  # pragma: no cover
+        pass
+    return 0
+
+
+def mpi_broadcast(x):
+    """Identity on one rank; every rank of a multi-GPU run already holds identical ``y_meas``."""
+    return x
+
+
+def peval(f, x):
+    """Point evaluation (``utils/mpi.py:22-37``) — one process owns the whole host mirror."""
+    return f(x)
+
+
+class MpiUtils:
+    get_rank = staticmethod(get_rank)
+    peval = staticmethod(peval)
+    mpi_broadcast = staticmethod(mpi_broadcast)
+
+
+def summarize_timings(fs: Any, t0: float | None = None) -> None:
+    """Iteration-1/2/mean step times and time/iter/dof (``utils/fem.py:89-102``)."""
+    if fs.iter > 3:
+        ts = fs.timeseries
+        if t0 is not None:
+            logger.info("Total time is: %f", time.time() - t0)
+        logger.info("Iteration 1 time     --- %E", ts.loc[1, "runtime"])
+        logger.info("Iteration 2 time     --- %E", ts.loc[2, "runtime"])
+        logger.info("Mean iteration time  --- %E", np.mean(ts.loc[3:, "runtime"]))
+        logger.info("Time/iter/dof        --- %E", np.mean(ts.loc[3:, "runtime"]) / fs.W.dim())

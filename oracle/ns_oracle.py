@@ -266,12 +266,29 @@ def apply_bc_rows(A: sp.csr_matrix, b: np.ndarray | None, dofs: np.ndarray, vals
     return Abc, b
 
 
-def _lu(A):
+class _PermutedLU:
+    """SuperLU on P A Pᵀ with the caller's fill-reducing ordering (NATURAL column order)."""
+
+    def __init__(self, A, perm):
+        self.perm = np.asarray(perm)
+        self.lu = spla.splu(A[self.perm][:, self.perm].tocsc(), permc_spec="NATURAL", diag_pivot_thresh=0.01)
+
+    def solve(self, b):
+        x = np.empty_like(b)
+        x[self.perm] = self.lu.solve(b[self.perm])
+        return x
+
+
+def _lu(A, perm=None):
+    """Sparse LU (SuperLU).  ``perm``: optional fill-reducing symmetric ordering (e.g. nested
+    dissection); without it SuperLU's own MMD(AᵀA+A) ordering is used."""
+    if perm is not None:
+        return _PermutedLU(A, perm)
     return spla.splu(A.tocsc(), permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.1, options=dict(SymmetricMode=True))
 
 
 # ── steady state (setup) ──────────────────────────────────────────────────────────────────
-def picard(d: Disc, nu: float, up0: np.ndarray, bc_dofs, bc_vals, max_iter=10, tol=1e-8, f_nodal=None, log=None):
+def picard(d: Disc, nu: float, up0: np.ndarray, bc_dofs, bc_vals, max_iter=10, tol=1e-8, f_nodal=None, log=None, perm=None):
     """``SteadyStateSolver.picard`` (``steadystate.py:98-159``)."""
     up0 = up0.copy()
     bp = np.zeros(d.N) if f_nodal is None else _load(d, d.vel_at_q(f_nodal)[0])
@@ -279,7 +296,7 @@ def picard(d: Disc, nu: float, up0: np.ndarray, bc_dofs, bc_vals, max_iter=10, t
     for i in range(max_iter):
         A = assemble_matrix(d, nu=nu, adv=up0[: 2 * d.nn])
         Ab, b = apply_bc_rows(A, bp, bc_dofs, bc_vals)
-        up1 = _lu(Ab).solve(b)
+        up1 = _lu(Ab, perm).solve(b)
         rel = np.linalg.norm(up1 - up0) / (np.linalg.norm(up0) + 1e-14)
         up0 = up1.copy()
         if log:
@@ -289,7 +306,7 @@ def picard(d: Disc, nu: float, up0: np.ndarray, bc_dofs, bc_vals, max_iter=10, t
     return up1
 
 
-def newton(d: Disc, nu: float, up0: np.ndarray, bc_dofs, bc_vals, max_iter=25, f_nodal=None, rtol=1e-9, atol=1e-10, log=None):
+def newton(d: Disc, nu: float, up0: np.ndarray, bc_dofs, bc_vals, max_iter=25, f_nodal=None, rtol=1e-9, atol=1e-10, log=None, perm=None):
     """``SteadyStateSolver.newton`` → ``dolfin.solve(F == 0, UP0, bcs)`` (``steadystate.py:60-96``)
     with dolfin's NewtonSolver defaults (residual criterion, rel 1e-9 / abs 1e-10)."""
     up = up0.copy()
@@ -309,7 +326,7 @@ def newton(d: Disc, nu: float, up0: np.ndarray, bc_dofs, bc_vals, max_iter=25, f
         u = up[: 2 * d.nn]
         Jm = assemble_matrix(d, nu=nu, adv=u, lin=u)
         Jb, _ = apply_bc_rows(Jm, None, bc_dofs, bc_vals)
-        up = up - _lu(Jb).solve(F)
+        up = up - _lu(Jb, perm).solve(F)
     raise RuntimeError("Newton solver did not converge")
 
 
@@ -334,8 +351,9 @@ class TimeStepper:
     """
 
     def __init__(self, d: Disc, Re: float, dt: float, U0: np.ndarray, bc_dofs, bc_profiles,
-                 force_profiles=None, nonlinear=True, shift=0.0, orders=(1, 2)):
+                 force_profiles=None, nonlinear=True, shift=0.0, orders=(1, 2), perm=None):
         self.d, self.dt, self.nonlinear = d, dt, nonlinear
+        self.perm = perm
         self.bc_dofs = np.asarray(bc_dofs, dtype=np.int64)
         self.bc_profiles = np.asarray(bc_profiles, dtype=np.float64).reshape(len(self.bc_dofs), -1)
         self.force_profiles = force_profiles
@@ -361,7 +379,7 @@ class TimeStepper:
 
     def solve(self, order, b) -> np.ndarray:
         if self.lu[order] is None:
-            self.lu[order] = _lu(self.A_bc[order])
+            self.lu[order] = _lu(self.A_bc[order], self.perm)
         return self.lu[order].solve(b)
 
     def step(self, order, u_n, u_nn, u_ctrl) -> np.ndarray:

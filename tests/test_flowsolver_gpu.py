@@ -1,0 +1,129 @@
+"""End-to-end parity of the MI355X ``FlowSolver`` (public API, through the C ABI).
+
+Reads like the reference's ``tests/integration/test_cylinder.py``: same scenario, same constants,
+same tolerances; in addition every series is compared with the oracle's golden vectors at 1e-8
+relative (fp64 everywhere; the device solve is a different but LU-grade algorithm).
+"""
+import numpy as np
+import pytest
+
+from flowcontrol_amd import utils as flu
+from flowcontrol_amd.controller import Controller
+from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver
+from flowcontrol_amd.fem.spaces import Function
+from flowcontrol_amd.flowsolverparameters import ParamIC
+
+pytestmark = pytest.mark.gpu
+
+# reference tests/integration/test_cylinder.py:66-74
+_U0_MAX_REF = np.float64(1.1921615450014942)
+_U0_MEAN_REF = np.float64(0.336746427968607)
+_U_MAX_REF = np.float64(1.325070045534714)
+_U_MEAN_REF = np.float64(0.3376859329866094)
+_LAST_TIME_REF = np.float64(0.1)
+_LAST_Y_MEAS_1_REF = np.float64(0.011615482723602308)
+_LAST_Y_MEAS_2_REF = np.float64(0.003860524805395703)
+_LAST_Y_MEAS_3_REF = np.float64(0.0038461597025207803)
+_LAST_DE_REF = np.float64(0.09462807324653322)
+
+
+def _rel_l2(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(np.asarray(b))
+
+
+def _load_baseflow(fs, golden_dir):
+    up0 = np.load(golden_dir / "cylinder_O1.npz")["UP0"]
+    U0, P0 = Function(fs.W, up0).split()
+    fs._assign_steady_state(U0, P0)
+
+
+def test_cylinder_smoke(tmp_path_factory):
+    """Pipeline runs; velocity values are finite after 3 steps (reference test_cylinder_smoke)."""
+    fs = CylinderFlowSolver.make_default(Re=100, path_out=tmp_path_factory.mktemp("cylinder_smoke"), num_steps=3)
+    fs.compute_steady_state(method="picard", max_iter=3, tol=1e-7, u_ctrl=[0.0, 0.0])
+    fs.initialize_time_stepping(ic=None)
+    for _ in range(fs.params_time.num_steps):
+        fs.step(u_ctrl=[0.0, 0.0])
+    u_vals = fs.fields.u_.vector().get_local()
+    assert np.all(np.isfinite(u_vals)), "velocity field contains non-finite values"
+    fs.th.release_device()
+
+
+def test_cylinder_regression(tmp_path_factory, golden_dir):
+    """10-step closed-loop run + JSON-based restart must reproduce the reference values
+    (mirror of the reference's test_cylinder_regression)."""
+    path_out = tmp_path_factory.mktemp("cylinder_regression")
+    fs = CylinderFlowSolver.make_default(Re=100, path_out=path_out, num_steps=10, save_every=5)
+    fs.compute_steady_state(method="picard", max_iter=3, tol=1e-7, u_ctrl=[0.0, 0.0])
+    fs.compute_steady_state(method="newton", max_iter=25, u_ctrl=[0.0, 0.0], initial_guess=fs.fields.UP0)
+
+    u0_max = flu.apply_fun(fs.fields.U0, np.max)
+    u0_mean = flu.apply_fun(fs.fields.U0, np.mean)
+    assert np.isclose(u0_max, _U0_MAX_REF, rtol=1e-6), f"u0_max: {u0_max}"
+    assert np.isclose(u0_mean, _U0_MEAN_REF, rtol=1e-6), f"u0_mean: {u0_mean}"
+
+    fs.initialize_time_stepping(ic=None)
+    Kss = Controller.from_file(file=golden_dir / "controllers" / "Kopt_reduced13.mat", x0=None)
+    for _ in range(fs.params_time.num_steps):
+        y_meas = flu.MpiUtils.mpi_broadcast(fs.y_meas)
+        u_ctrl = Kss.step(y=-y_meas[0], dt=fs.params_time.dt)
+        fs.step(u_ctrl=[u_ctrl[0], u_ctrl[0]])
+    fs.write_timeseries()
+    g = np.load(golden_dir / "cylinder_O1.npz")
+    ts = fs.timeseries
+    assert _rel_l2(ts[["y_meas_1", "y_meas_2", "y_meas_3"]].to_numpy(), g["cl_y"][:11]) < 1e-8
+    assert _rel_l2(ts["dE"].to_numpy(), g["cl_dE"][:11]) < 1e-8
+    fs.th.release_device()
+
+    # restart from Tstart=0.05 using the JSON sidecar (no ParamRestart needed)
+    fs_restart = CylinderFlowSolver.make_default(Re=100, path_out=path_out, num_steps=10, save_every=5, Tstart=0.05)
+    fs_restart.load_steady_state()
+    fs_restart.initialize_time_stepping(Tstart=fs_restart.params_time.Tstart)
+    for _ in range(fs_restart.params_time.num_steps):
+        y_meas = flu.MpiUtils.mpi_broadcast(fs_restart.y_meas)
+        u_ctrl = Kss.step(y=-y_meas[0], dt=fs_restart.params_time.dt)
+        fs_restart.step(u_ctrl=np.repeat(u_ctrl, repeats=2, axis=0))
+    fs_restart.write_timeseries()
+
+    u_max = flu.apply_fun(fs_restart.fields.Usave, np.max)
+    u_mean = flu.apply_fun(fs_restart.fields.Usave, np.mean)
+    last = fs_restart.timeseries.iloc[-1]
+    assert np.isclose(u_max, _U_MAX_REF, rtol=1e-4), f"u_max: {u_max} != {_U_MAX_REF}"
+    assert np.isclose(u_mean, _U_MEAN_REF, rtol=1e-6), f"u_mean: {u_mean} != {_U_MEAN_REF}"
+    assert np.isclose(last["time"], _LAST_TIME_REF, rtol=1e-6), f"time: {last['time']}"
+    assert np.isclose(last["y_meas_1"], _LAST_Y_MEAS_1_REF, rtol=1e-4), f"y_meas_1: {last['y_meas_1']}"
+    assert np.isclose(last["y_meas_2"], _LAST_Y_MEAS_2_REF, rtol=1e-4), f"y_meas_2: {last['y_meas_2']}"
+    assert np.isclose(last["y_meas_3"], _LAST_Y_MEAS_3_REF, rtol=1e-4), f"y_meas_3: {last['y_meas_3']}"
+    assert np.isclose(last["dE"], _LAST_DE_REF, rtol=1e-4), f"dE: {last['dE']}"
+    # and far tighter against the oracle's series
+    tr = fs_restart.timeseries
+    assert _rel_l2(tr[["y_meas_1", "y_meas_2", "y_meas_3"]].to_numpy(), g["cl_y"][10:21]) < 1e-8
+    fs_restart.th.release_device()
+
+
+def test_cylinder_open_loop_200_steps_vs_oracle(tmp_path_factory, golden_dir):
+    """BASELINE config 2: 200 open-loop steps, IC of run_cylinder_example.py:55; sensor and energy
+    series within 1e-8 rel-L2 of the oracle (target stated by north_star: 1e-6)."""
+    fs = CylinderFlowSolver.make_default(Re=100, path_out=tmp_path_factory.mktemp("cyl_ol"), num_steps=200)
+    fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
+    _load_baseflow(fs, golden_dir)
+    fs.initialize_time_stepping(ic=None)
+    for _ in range(100):
+        fs.step(u_ctrl=[0.0, 0.0])
+    y_b, dE_b = fs.run(100, np.zeros(2))  # batched path continues the same trajectory
+    g = np.load(golden_dir / "cylinder_O1.npz")
+    ts = fs.timeseries
+    y = ts[["y_meas_1", "y_meas_2", "y_meas_3"]].to_numpy()
+    assert y.shape == (201, 3)
+    assert _rel_l2(y, g["ol_y"]) < 1e-8
+    assert _rel_l2(ts["dE"].to_numpy(), g["ol_dE"]) < 1e-8
+    assert fs.solve_info[1] < 1e-9
+    assert np.isclose(fs.t, 1.0)
+    fs.th.release_device()
+
+
+def test_missing_baseflow_and_bad_inputs(tmp_path_factory):
+    fs = CylinderFlowSolver.make_default(path_out=tmp_path_factory.mktemp("cyl_err"))
+    with pytest.raises(ValueError):
+        fs.set_actuators_u_ctrl([0.0])
+    fs.th.release_device()

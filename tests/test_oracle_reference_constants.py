@@ -1,0 +1,103 @@
+"""Pins the CPU oracle (and the committed golden vectors) to the reference's own known answers.
+
+The reference's only numerical known-answer tests of the hot path are its slow regression tests
+(SURVEY §8c); FEniCS cannot be imported here, so these constants are the parity anchor:
+  tests/integration/test_cylinder.py:66-74   (base flow, 10 closed-loop steps + restart → t = 0.1)
+  tests/integration/test_operatorgetter.py:23-26  (‖A‖_F of the steady Jacobian)
+Tolerances are the reference's own (rtol 1e-6 / 1e-4); the oracle actually agrees to ~1e-13.
+"""
+import tempfile
+
+import numpy as np
+import pytest
+import scipy.io as sio
+
+from flowcontrol_amd import ndsolver
+from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver
+from flowcontrol_amd.fem.boundary import combine_bcs
+from oracle import ns_oracle as O
+
+# reference tests/integration/test_cylinder.py:66-74
+U0_MAX_REF = 1.1921615450014942
+U0_MEAN_REF = 0.336746427968607
+U_MAX_REF = 1.325070045534714
+U_MEAN_REF = 0.3376859329866094
+LAST_Y_REF = (0.011615482723602308, 0.003860524805395703, 0.0038461597025207803)
+LAST_DE_REF = 0.09462807324653322
+# reference tests/integration/test_operatorgetter.py:23-26
+A_FROBENIUS_CYLINDER_REF = 55.37024024761875
+
+
+@pytest.fixture(scope="module")
+def case(golden_dir):
+    fs = CylinderFlowSolver.make_default(path_out=tempfile.mkdtemp())
+    d = O.Disc.from_taylor_hood(fs.th)
+    g = np.load(golden_dir / "cylinder_O1.npz")
+    return fs, d, g
+
+
+def test_golden_vectors_match_reference_constants(case):
+    _, _, g = case
+    nn2 = None
+    U0 = g["UP0"]
+    fs = case[0]
+    nn2 = 2 * fs.th.nn
+    assert np.isclose(U0[:nn2].max(), U0_MAX_REF, rtol=1e-6)
+    assert np.isclose(U0[:nn2].mean(), U0_MEAN_REF, rtol=1e-6)
+    assert np.allclose(g["cl_y"][-1], LAST_Y_REF, rtol=1e-4)
+    assert np.isclose(g["cl_dE"][-1], LAST_DE_REF, rtol=1e-4)
+    assert np.isclose(float(g["cl_umax"]), U_MAX_REF, rtol=1e-4)
+    assert np.isclose(float(g["cl_umean"]), U_MEAN_REF, rtol=1e-6)
+    # the oracle is in fact far closer than the reference's tolerances
+    assert abs(g["cl_dE"][-1] / LAST_DE_REF - 1) < 1e-11
+    assert abs(U0[:nn2].max() / U0_MAX_REF - 1) < 1e-11
+
+
+def test_base_flow_is_a_steady_solution_and_jacobian_norm(case):
+    fs, d, g = case
+    up = g["UP0"]
+    dofs, vals = combine_bcs(fs._make_BCs().bcu, fs.th.N)
+    assert np.allclose(up[dofs], vals, atol=1e-14)
+    F = O.steady_residual(d, 1.0 / fs.params_flow.Re, up)
+    F[dofs] = 0.0
+    assert np.linalg.norm(F) < 1e-10  # dolfin NewtonSolver absolute tolerance
+    pdofs, _ = combine_bcs(fs.bc.bcu, fs.th.N)
+    A = O.steady_jacobian_A(d, 1.0 / fs.params_flow.Re, up, pdofs)
+    assert np.isclose(np.sqrt((A.data**2).sum()), A_FROBENIUS_CYLINDER_REF, rtol=1e-6)
+
+
+def test_oracle_closed_loop_reproduces_reference(case, golden_dir):
+    """Re-run the regression scenario with the oracle: BDF1 → BDF2, actuation BC lifting, point
+    sensors, energy, ZOH controller; 20 steps ≡ the reference's 10 steps + restart + 10 steps."""
+    fs, d, g = case
+    th = fs.th
+    up0 = g["UP0"]
+    U0 = up0[: 2 * th.nn]
+    dofs, prof = fs._bc_tables()
+    skip = np.zeros(th.N, bool)
+    skip[dofs] = True
+    perm = ndsolver.build_tree(th.cell_dofs, th.mesh.cell_centroids(), th.N, 10, skip).perm
+    ts = O.TimeStepper(d, 100.0, 0.005, U0, dofs, prof, perm=perm)
+    M = O.velocity_mass(d)
+    rows = [s.row(fs) for s in fs.params_control.sensor_list]
+    K = sio.loadmat(golden_dir / "controllers" / "Kopt_reduced13.mat")
+    Ad, Bd, Cd, Dd = O.zoh_discretize(K["A"], K["B"], K["C"], K["D"], 0.005)
+    uic = O.div0_gaussian_nodal(th.node_coords, 0.0, 0.0, 1.0)  # default ParamIC()
+    u_n = np.r_[uic[:, 0], uic[:, 1]]
+    u_nn = u_n.copy()
+    y = np.array([w @ np.r_[u_n, up0[2 * th.nn :]][i] for i, w in rows])
+    x = np.zeros(Ad.shape[0])
+    order = 1
+    for _ in range(20):
+        yy = np.atleast_1d(-y[0])
+        uc = Cd @ x + Dd @ yy
+        x = Ad @ x + Bd @ yy
+        upn = ts.step(order, u_n, u_nn, [uc[0], uc[0]])
+        order = 2
+        u_nn, u_n = u_n, upn[: 2 * th.nn]
+        y = np.array([w @ upn[i] for i, w in rows])
+    assert np.allclose(y, LAST_Y_REF, rtol=1e-4)
+    assert np.isclose(0.5 * u_n @ (M @ u_n), LAST_DE_REF, rtol=1e-4)
+    assert np.isclose((u_n + U0).max(), U_MAX_REF, rtol=1e-4)
+    assert np.isclose((u_n + U0).mean(), U_MEAN_REF, rtol=1e-6)
+    assert np.allclose(y, g["cl_y"][-1], rtol=1e-9)
