@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""Headline benchmark: timesteps/s of ``FlowSolver.step`` on the cylinder Re=100 case (MI355X).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): shipped coarse mesh O1 (12 284 P2/P1 triangles, 56 203
+DoFs), Re=100, dt=0.005, BDF1→BDF2, IC ParamIC(xloc=2, yloc=0, radius=0.5, amplitude=1), open loop
+u_ctrl=[0,0], energy every step.  A "step" is one public ``FlowSolver.step()`` call: RHS element
+loop with BC lifting → LU-grade solve (ND selected-inverse sweeps + 1 refinement) → shift →
+sensors → energy, synchronised back to the host every step as the reference's loop is.
+
+One JSON line on rank 0 with the driver's keys plus
+  roofline      dominant kernel (fc_nd_sweep): algorithmic bytes per launch ÷ mean launch duration
+                measured with HIP events on the solver's stream during an instrumented replay of
+                the same K steps
+  cpu_baseline  the CPU oracle (numpy assembly + SuperLU factor-once/solve-many, 1 core) timed on
+                a bounded sample of the same workload
+  spmv          CSR SpMV probe on the assembled BDF2 matrix (cache resident) and on a
+                cavity_fine-sized matrix (> Infinity Cache), % of 8 TB/s
+N > 1 (torchrun, one rank per GPU): independent replicas of the workload, no data-path collective
+(row-partitioned multi-GPU is not wired up yet); value = total steps of all ranks ÷ max time.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+GOLDEN = ROOT / "tests" / "golden"
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_solver(device: int):
+    from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver
+    from flowcontrol_amd.fem.spaces import Function
+    from flowcontrol_amd.flowsolverparameters import ParamIC
+
+    fs = CylinderFlowSolver.make_default(Re=100, path_out=tempfile.mkdtemp(prefix="fc_bench_"), num_steps=0, save_every=0)
+    fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
+    fs.th.device(device)
+    up0 = np.load(GOLDEN / "cylinder_O1.npz")["UP0"]
+    U0, P0 = Function(fs.W, up0).split()
+    fs._assign_steady_state(U0, P0)
+    fs.initialize_time_stepping(ic=None)
+    return fs
+
+
+def cpu_baseline(fs, n_steps: int = 120, warm: int = 3) -> dict:
+    """Oracle leg: same mesh/dt/IC; element-loop RHS (numpy) + SuperLU triangular solves with the
+    nested-dissection ordering (the best CPU ordering found) + sensors + energy;
+    1 thread; mean over steps ≥ 3 so both factorisations are excluded (utils/fem.py:94-96)."""
+    from oracle import ns_oracle as O
+
+    th = fs.th
+    d = O.Disc.from_taylor_hood(th)
+    U0 = fs.fields.U0.vector().array()
+    dofs, prof = fs._bc_tables()
+    perm = th.device().tree.perm
+    ts = O.TimeStepper(d, fs.params_flow.Re, fs.params_time.dt, U0, dofs, prof, perm=perm)
+    M = O.velocity_mass(d)
+    rows = [s.row(fs) for s in fs.params_control.sensor_list]
+    u_n = fs.fields.ic.u.vector().array().copy()
+    u_nn = u_n.copy()
+    order, times = 1, []
+    y = None
+    for _ in range(n_steps + warm):
+        t0 = time.perf_counter()
+        up = ts.step(order, u_n, u_nn, np.zeros(2))
+        order = 2
+        u_nn, u_n = u_n, up[: 2 * th.nn]
+        y = np.array([w @ up[i] for i, w in rows])
+        dE = 0.5 * u_n @ (M @ u_n)
+        times.append(time.perf_counter() - t0)
+    mean = float(np.mean(times[warm:]))
+    return {
+        "value": 1.0 / mean,
+        "unit": "timesteps/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{n_steps} steps of the same workload after {warm} warm-up steps (factorisations excluded); "
+        f"{mean * 1e3:.1f} ms/step; host has {os.cpu_count()} logical cores",
+        "_y_last": y.tolist(),
+        "_dE_last": float(dE),
+    }
+
+
+def spmv_probe(fs, include_large: bool) -> dict:
+    from flowcontrol_amd._lib import SLOT_BDF2, SLOT_SCRATCH
+
+    dev = fs.th.device()
+    out = {}
+    ms = dev.bench_spmv(SLOT_BDF2, 1000)
+    byt = dev.nnz * 12 + dev.N * 16 + (dev.N + 1) * 4
+    out["O1_bdf2"] = {"nnz": dev.nnz, "N": dev.N, "bytes": byt, "us": ms * 1e3, "GB/s": byt / ms / 1e6,
+                      "pct_hbm_peak": 100 * byt / ms / 1e6 / HBM_PEAK_GBS, "note": "21 MB: L2/Infinity-Cache resident"}
+    if include_large:
+        from flowcontrol_amd.device import DeviceSolver
+        from flowcontrol_amd.fem.mesh import read_xdmf_mesh
+        from flowcontrol_amd.fem.spaces import TaylorHood
+
+        th = TaylorHood(read_xdmf_mesh(GOLDEN / "meshes" / "cavity_fine.npz"))
+        big = DeviceSolver(th, dev_index(fs))
+        U = np.r_[np.ones(th.nn), np.zeros(th.nn)]
+        big.assemble_matrix(SLOT_SCRATCH, mass=3750.0, nu=1.0 / 7500.0, adv=U, lin=U)
+        big.spmv(SLOT_SCRATCH, np.random.default_rng(0).standard_normal(big.N))
+        ms = big.bench_spmv(SLOT_SCRATCH, 200)
+        byt = big.nnz * 12 + big.N * 16 + (big.N + 1) * 4
+        out["cavity_fine_bdf2"] = {"nnz": big.nnz, "N": big.N, "bytes": byt, "us": ms * 1e3, "GB/s": byt / ms / 1e6,
+                                   "pct_hbm_peak": 100 * byt / ms / 1e6 / HBM_PEAK_GBS,
+                                   "note": "329 MB > 256 MiB Infinity Cache: HBM streaming; synthetic uniform base flow"}
+        big.close()
+    return out
+
+
+def dev_index(fs) -> int:
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large-spmv", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t_setup = time.time()
+    fs = build_solver(local)
+    u0 = np.zeros(2)
+    fs.step(u0)  # BDF1 step: assembles + factorises both systems (setup, untimed)
+    log(f"[rank {rank}] setup {time.time() - t_setup:.1f}s; N={fs.th.N}")
+    for _ in range(max(args.warmup - 1, 0)):
+        fs.step(u0)
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fs.step(u0)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    y_last = fs.y_meas.copy()
+
+    result = None
+    if rank == 0:
+        from flowcontrol_amd._lib import SLOT_BDF2
+
+        dev = fs.th.device()
+        # batched (no per-step host sync) throughput of the same kernels
+        tb = time.perf_counter()
+        fs.run(args.steps, u0)
+        t_batched = time.perf_counter() - tb
+        # instrumented replay: HIP-event pair around every sweep / SpMV launch on the solver stream
+        dev.set_timing(True)
+        for _ in range(args.steps):
+            fs.step(u0)
+        tim = dev.get_timing()
+        dev.set_timing(False)
+        sweep_bytes, spmv_bytes = dev.algorithmic_bytes(SLOT_BDF2)
+        n_stage = 2 * dev.tree.depth + 1
+        applies = tim["sweep_launches"] / max(n_stage, 1)
+        mean_launch_ms = tim["sweep_ms"] / max(tim["sweep_launches"], 1)
+        bytes_per_launch = sweep_bytes / n_stage
+        achieved = bytes_per_launch / mean_launch_ms / 1e6  # GB/s
+        traffic = None
+        tfile = ROOT / "profiles" / "traffic.json"
+        if tfile.exists():
+            try:
+                traffic = json.loads(tfile.read_text()).get("fc_nd_sweep_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {
+            "bound": "hbm", "kernel": "fc_nd_sweep", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "bytes_per_launch": bytes_per_launch, "launches_per_step": tim["sweep_launches"] / args.steps,
+            "mean_launch_us": mean_launch_ms * 1e3, "factor_nnz": dev.factor_nnz.get(SLOT_BDF2),
+            "applies_per_step": applies / args.steps,
+            "spmv_in_step": {"bytes": spmv_bytes, "mean_us": 1e3 * tim["spmv_ms"] / max(tim["spmv_launches"], 1),
+                             "GB/s": spmv_bytes / (tim["spmv_ms"] / max(tim["spmv_launches"], 1)) / 1e6},
+            "note": "factors (~200 MB) are re-read every step and largely stay in the 256 MiB Infinity Cache",
+        }
+        phases, nl = dev.profile_steps(SLOT_BDF2, 50, u0)
+        spmv = spmv_probe(fs, include_large=not args.no_large_spmv)
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(fs)
+            cpu.pop("_y_last"), cpu.pop("_dE_last")
+        value = world * args.steps / elapsed
+        result = {
+            "metric": "timesteps/s (cylinder Re=100, fixed mesh)",
+            "value": value,
+            "unit": "timesteps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "cylinder Re=100, mesh O1 (12284 cells, 56203 dofs), dt=0.005, BDF2, open loop, "
+                "IC div-free vortex (2,0) r=0.5, sensors+energy every step",
+                "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (no collective)",
+                "solver": f"ND selected-inverse depth {dev.tree.depth}, {fs.refine_steps} refinement",
+            },
+            "batched_steps_per_s": args.steps / t_batched,
+            "roofline": roofline,
+            "phase_ms_eager": {k: float(v) for k, v in zip(["rhs_elem", "rhs_gather", "sweeps", "residual_spmv", "finish"], phases)},
+            "spmv": spmv,
+            "cpu_baseline": cpu,
+            "speedup_vs_cpu_baseline": (value / cpu["value"]) if cpu else None,
+            "solve_rel_residual_pre_refine": float(fs.solve_info[1]),
+            "y_last": y_last.tolist(),
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -72,7 +72,7 @@ struct DevBuf {
 };
 
 struct Stage {
-  int64_t rp_begin;  // offset into f_rowptr
+  int64_t rp_begin;  // offset of the stage's first row in seg_ptr
   int row0;          // first destination row (permuted numbering)
   int nrows;
   int kind;  // 0 up, 1 down
@@ -87,9 +87,10 @@ struct OrderSys {
   DevBuf<int> Ap_rowptr, Ap_col;
   DevBuf<double> Ap_val;
   int64_t Ap_nnz = 0;
-  DevBuf<int64_t> f_rowptr;
-  DevBuf<int> f_col;
+  DevBuf<int64_t> seg_ptr, seg_val;  // per-row segment lists of all stages, concatenated
+  DevBuf<int> seg_col, seg_len, f_idx;
   DevBuf<double> f_val;
+  int64_t f_nnz = 0;
   std::vector<Stage> stages;
   double sweep_bytes = 0.0;
 };
@@ -132,6 +133,9 @@ struct fc_ctx {
   std::vector<int> h_perm;
   DevBuf<int> perm;
   OrderSys sys[2];
+  DevBuf<int> mp_rowptr, mp_col;  // velocity mass matrix in permuted numbering (energy)
+  DevBuf<double> mp_val;
+  bool have_mp = false;
   // solver options
   int method = FC_METHOD_REFINE, max_iter = 1, check_residual = 1;
   double rtol = 1e-10;
@@ -144,6 +148,13 @@ struct fc_ctx {
   double* pin = nullptr;  // pinned host staging
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int nblk_N = 0;
+  // per-launch HIP-event timing (fc_set_timing): pairs recorded around every sweep / SpMV launch
+  bool timing = false;
+  std::vector<hipEvent_t> tev;   // pool, 2 per launch
+  std::vector<int> tkind;        // 0 sweep, 1 spmv (per recorded pair)
+  size_t tused = 0;
+  double t_ms[2] = {0.0, 0.0};
+  int64_t t_cnt[2] = {0, 0};
 };
 
 namespace {
@@ -182,12 +193,47 @@ int pick_lanes(double mean_nnz) {
   return 64;
 }
 
+int time_begin(fc_ctx* h, int kind) {
+  if (!h->timing) return FC_OK;
+  if (h->tused + 2 > h->tev.size()) {
+    for (int i = 0; i < 64; ++i) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreate(&e));
+      h->tev.push_back(e);
+    }
+  }
+  h->tkind.push_back(kind);
+  HIPCHK(hipEventRecord(h->tev[h->tused], h->stream));
+  return FC_OK;
+}
+int time_end(fc_ctx* h) {
+  if (!h->timing) return FC_OK;
+  HIPCHK(hipEventRecord(h->tev[h->tused + 1], h->stream));
+  h->tused += 2;
+  return FC_OK;
+}
+// after a stream synchronisation: fold the recorded pairs into the accumulators
+int time_collect(fc_ctx* h) {
+  if (!h->timing) return FC_OK;
+  for (size_t i = 0; i < h->tused; i += 2) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->tev[i], h->tev[i + 1]));
+    const int k = h->tkind[i / 2];
+    h->t_ms[k] += ms;
+    h->t_cnt[k] += 1;
+  }
+  h->tused = 0;
+  h->tkind.clear();
+  return FC_OK;
+}
+
 template <int MODE>
 int launch_spmv(fc_ctx* h, int nrows, double mean, const int* rp, const int* col, const double* val, const double* x,
                 const double* b, double* y, double* xsave, double* partial) {
   const int lanes = pick_lanes(mean);
   const int rpb = 256 / lanes;
   dim3 grid(nblocks(nrows, rpb)), block(256);
+  FCCHK(time_begin(h, 1));
   switch (lanes) {
     case 4: hipLaunchKernelGGL((fc_spmv_csr<4, MODE>), grid, block, 0, h->stream, nrows, rp, col, val, x, b, y, xsave, partial); break;
     case 8: hipLaunchKernelGGL((fc_spmv_csr<8, MODE>), grid, block, 0, h->stream, nrows, rp, col, val, x, b, y, xsave, partial); break;
@@ -195,6 +241,7 @@ int launch_spmv(fc_ctx* h, int nrows, double mean, const int* rp, const int* col
     case 32: hipLaunchKernelGGL((fc_spmv_csr<32, MODE>), grid, block, 0, h->stream, nrows, rp, col, val, x, b, y, xsave, partial); break;
     default: hipLaunchKernelGGL((fc_spmv_csr<64, MODE>), grid, block, 0, h->stream, nrows, rp, col, val, x, b, y, xsave, partial); break;
   }
+  FCCHK(time_end(h));
   HIPCHK(hipGetLastError());
   return grid.x;
 }
@@ -202,17 +249,23 @@ int launch_spmv(fc_ctx* h, int nrows, double mean, const int* rp, const int* col
 int launch_sweep(fc_ctx* h, const OrderSys& S, const Stage& st) {
   const int rpb = 256 / st.lanes;
   dim3 grid(nblocks(st.nrows, rpb)), block(256);
-  const int64_t* rp = S.f_rowptr.p + st.rp_begin;
+  const int64_t* rp = S.seg_ptr.p + st.rp_begin;
   double* buf = h->buf.p;
   const int dest0 = st.kind == 0 ? st.row0 : h->N + st.row0;
   const int acc = st.kind == 0 ? 1 : 0;
+  FCCHK(time_begin(h, 0));
+#define FC_SWEEP(L)                                                                                              \
+  hipLaunchKernelGGL((fc_nd_sweep<L>), grid, block, 0, h->stream, st.nrows, rp, S.seg_val.p, S.seg_col.p, S.seg_len.p, \
+                     S.f_idx.p, S.f_val.p, buf, dest0, acc)
   switch (st.lanes) {
-    case 4: hipLaunchKernelGGL((fc_nd_sweep<4>), grid, block, 0, h->stream, st.nrows, rp, S.f_col.p, S.f_val.p, buf, dest0, acc); break;
-    case 8: hipLaunchKernelGGL((fc_nd_sweep<8>), grid, block, 0, h->stream, st.nrows, rp, S.f_col.p, S.f_val.p, buf, dest0, acc); break;
-    case 16: hipLaunchKernelGGL((fc_nd_sweep<16>), grid, block, 0, h->stream, st.nrows, rp, S.f_col.p, S.f_val.p, buf, dest0, acc); break;
-    case 32: hipLaunchKernelGGL((fc_nd_sweep<32>), grid, block, 0, h->stream, st.nrows, rp, S.f_col.p, S.f_val.p, buf, dest0, acc); break;
-    default: hipLaunchKernelGGL((fc_nd_sweep<64>), grid, block, 0, h->stream, st.nrows, rp, S.f_col.p, S.f_val.p, buf, dest0, acc); break;
+    case 4: FC_SWEEP(4); break;
+    case 8: FC_SWEEP(8); break;
+    case 16: FC_SWEEP(16); break;
+    case 32: FC_SWEEP(32); break;
+    default: FC_SWEEP(64); break;
   }
+#undef FC_SWEEP
+  FCCHK(time_end(h));
   HIPCHK(hipGetLastError());
   return FC_OK;
 }
@@ -224,33 +277,39 @@ int apply_factors(fc_ctx* h, const OrderSys& S) {
   return FC_OK;
 }
 
-// permuted-ordering solve of A_p x = b_p (b_p in h->b).  Leaves x in h->xsol (+ final correction
-// in buf x-half when `defer_last` — the finish kernel then adds it).  Returns via *dx the vector to
-// add (or nullptr).  Relative residual^2 pieces go to scal[1] (|r|^2) and scal[2] (|b|^2).
-int solve_permuted(fc_ctx* h, OrderSys& S, const double** x_out, const double** dx_out) {
+// permuted-ordering solve of A_p x = b_p.  On entry b_p is in h->b AND in the y-half of h->buf.
+// max_iter = number of iterative-refinement sweeps (0: factor apply only).  With check_residual the
+// first residual r0 = b - A x0 is always formed (one SpMV) and |r0|^2, |b|^2 partials are left in
+// h->partial (n_rpartial blocks) for fc_final.  Returns x (and an optional correction dx to add).
+int solve_permuted(fc_ctx* h, OrderSys& S, const double** x_out, const double** dx_out, int* n_rpartial) {
   const int N = h->N;
   const int g = nblocks(N, 256);
-  hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, h->buf.p);
   FCCHK(apply_factors(h, S));
   const double* x = h->buf.p + N;
   const double* dx = nullptr;
   const double mean = (double)S.Ap_nnz / std::max(1, N);
-  for (int it = 0; it < h->max_iter; ++it) {
-    // r = b - A x  -> buf y-half ; xsol = x (+dx folded before)
-    if (it > 0) {
-      hipLaunchKernelGGL(fc_axpy, dim3(g), dim3(256), 0, h->stream, N, 1.0, h->buf.p + N, h->xsol.p);
-      x = h->xsol.p;
-      const int nb = launch_spmv<1>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, x, h->b.p, h->buf.p, nullptr,
-                                    nullptr);
-      if (nb < 0) return nb;
-    } else {
+  *n_rpartial = 0;
+  const int iters = h->max_iter;
+  if (iters == 0 && h->check_residual) {
+    // monitor only: r0 -> tmpN (x stays in the x-half of buf)
+    const int nb = launch_spmv<1>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, x, h->b.p, h->tmpN.p, nullptr,
+                                  h->partial.p);
+    if (nb < 0) return nb;
+    *n_rpartial = nb;
+  }
+  for (int it = 0; it < iters; ++it) {
+    if (it == 0) {
       const int nb = launch_spmv<1>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, x, h->b.p, h->buf.p, h->xsol.p,
                                     h->check_residual ? h->partial.p : nullptr);
       if (nb < 0) return nb;
-      if (h->check_residual)
-        hipLaunchKernelGGL(fc_reduce_final, dim3(2), dim3(256), 0, h->stream, nb, h->partial.p, 1.0, h->scal.p + 1);
-      x = h->xsol.p;
+      if (h->check_residual) *n_rpartial = nb;
+    } else {
+      hipLaunchKernelGGL(fc_axpy, dim3(g), dim3(256), 0, h->stream, N, 1.0, h->buf.p + N, h->xsol.p);
+      const int nb = launch_spmv<1>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, h->xsol.p, h->b.p, h->buf.p,
+                                    nullptr, nullptr);
+      if (nb < 0) return nb;
     }
+    x = h->xsol.p;
     FCCHK(apply_factors(h, S));
     dx = h->buf.p + N;
   }
@@ -315,7 +374,7 @@ int enqueue_rhs(fc_ctx* h, int order_slot, const double* d_uctrl) {
                      h->u_n.p, h->u_nn.p, h->have_force ? h->fprof.p : nullptr, h->have_force ? h->n_act : 0, d_uctrl,
                      c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p);
   hipLaunchKernelGGL(fc_rhs_gather, dim3(nblocks(h->N, 256)), dim3(256), 0, h->stream, h->N, h->gptr_p.p, h->gidx_p.p,
-                     h->ev.p, h->bcslot_p.p, h->bcprof.p, S.lift_p.p, h->n_act, d_uctrl, h->b.p);
+                     h->ev.p, h->bcslot_p.p, h->bcprof.p, S.lift_p.p, h->n_act, d_uctrl, h->b.p, h->buf.p);
   HIPCHK(hipGetLastError());
   return FC_OK;
 }
@@ -330,22 +389,23 @@ int enqueue_energy(fc_ctx* h, const double* d_u, double* d_out) {
   return FC_OK;
 }
 
-// enqueue one full step; y -> d_y, E -> d_E
+// enqueue one full step; y -> d_y, E -> d_E; residual norms -> scal[1], scal[2]
 int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, double* d_E, int compute_energy) {
   OrderSys& S = h->sys[order_slot];
   if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this order");
+  if (compute_energy && !h->have_mp) return fail(FC_ERR_NOT_READY, "fc_set_energy_matrix not called");
   FCCHK(enqueue_rhs(h, order_slot, d_uctrl));
   const double *x = nullptr, *dx = nullptr;
-  FCCHK(solve_permuted(h, S, &x, &dx));
-  hipLaunchKernelGGL(fc_finish, dim3(nblocks(h->N, 256)), dim3(256), 0, h->stream, h->N, 2 * h->nn, h->perm.p, x, dx,
-                     h->up.p, h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p);
-  if (h->n_sens > 0)
-    hipLaunchKernelGGL(fc_sensors, dim3(h->n_sens), dim3(64), 0, h->stream, h->n_sens, h->s_rowptr.p, h->s_idx.p,
-                       h->s_w.p, h->up.p, d_y);
-  if (compute_energy) {
-    if (!h->slot_ok[FC_SLOT_MASS]) return fail(FC_ERR_NOT_READY, "FC_SLOT_MASS not assembled");
-    FCCHK(enqueue_energy(h, h->up.p, d_E));
-  }
+  int nrp = 0;
+  FCCHK(solve_permuted(h, S, &x, &dx, &nrp));
+  const int g = nblocks(h->N, 256);
+  double* e_partial = h->partial.p + 2 * (size_t)h->nblk_N;  // energy partials live after the residual ones
+  hipLaunchKernelGGL(fc_finish, dim3(g), dim3(256), 0, h->stream, h->N, 2 * h->nn, h->perm.p, x, dx, h->up.p, h->u_n.p,
+                     h->u_nn.p, h->p_n.p, h->flag.p, compute_energy ? h->mp_rowptr.p : nullptr, h->mp_col.p,
+                     h->mp_val.p, compute_energy ? e_partial : nullptr);
+  hipLaunchKernelGGL(fc_final, dim3(1 + h->n_sens), dim3(256), 0, h->stream, g, compute_energy ? e_partial : nullptr,
+                     d_E, nrp, nrp > 0 ? h->partial.p : nullptr, h->scal.p + 1, h->n_sens, h->s_rowptr.p, h->s_idx.p,
+                     h->s_w.p, h->up.p, d_y);
   HIPCHK(hipGetLastError());
   return FC_OK;
 }
@@ -518,7 +578,7 @@ int fc_create(fc_handle* out, int device, int32_t nv, int32_t ne, int32_t nc, co
   TRY(h->tmpN.alloc(N));
   TRY(h->tmpN2.alloc(N));
   h->nblk_N = nblocks(N, 4) + 16;  // upper bound on blocks of any row-wise reduction
-  TRY(h->partial.alloc(2 * (size_t)h->nblk_N));
+  TRY(h->partial.alloc(3 * (size_t)h->nblk_N));
   TRY(h->scal.alloc(8));
   TRY(h->flag.alloc(1));
   TRY(h->isbc.alloc(N));
@@ -546,6 +606,7 @@ int fc_destroy(fc_handle h) {
   if (h->pin) (void)hipHostFree(h->pin);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  for (hipEvent_t e : h->tev) (void)hipEventDestroy(e);
   hipStream_t s = h->stream;
   delete h;
   if (s) (void)hipStreamDestroy(s);
@@ -752,16 +813,19 @@ int fc_set_permutation(fc_handle h, const int32_t* perm) {
   h->h_perm.assign(perm, perm + h->N);
   FCCHK(h->perm.upload(h->h_perm, h->stream));
   h->have_perm = true;
+  h->have_mp = false;
   for (int o = 0; o < 2; ++o) h->sys[o].ready = false;
   return refresh_permuted(h);
 }
 
 int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32_t* Ap_col, const double* Ap_val,
-                    int32_t n_stages, const int64_t* stage_rowptr_begin, const int32_t* stage_row0,
-                    const int32_t* stage_nrows, const int32_t* stage_kind, const int64_t* f_rowptr, const int32_t* f_col,
-                    const double* f_val) {
-  if (!h || slot < 0 || slot > 1 || !Ap_rowptr || !Ap_col || !Ap_val || n_stages <= 0 || !stage_rowptr_begin ||
-      !stage_row0 || !stage_nrows || !stage_kind || !f_rowptr || !f_col || !f_val)
+                    int32_t n_stages, const int64_t* stage_begin, const int32_t* stage_row0,
+                    const int32_t* stage_nrows, const int32_t* stage_kind, const int64_t* seg_ptr, int64_t n_seg,
+                    const int64_t* seg_val, const int32_t* seg_col, const int32_t* seg_len, int64_t n_idx,
+                    const int32_t* idx, int64_t n_val, const double* vals) {
+  if (!h || slot < 0 || slot > 1 || !Ap_rowptr || !Ap_col || !Ap_val || n_stages <= 0 || !stage_begin || !stage_row0 ||
+      !stage_nrows || !stage_kind || !seg_ptr || !seg_val || !seg_col || !seg_len || !vals || n_seg < 0 || n_idx < 0 ||
+      n_val <= 0 || (n_idx > 0 && !idx))
     return fail(FC_ERR_INVALID, "fc_solver_setup: bad argument");
   if (!h->have_perm) return fail(FC_ERR_NOT_READY, "fc_set_permutation not called");
   HIPCHK(hipSetDevice(h->device));
@@ -771,37 +835,86 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
   S.Ap_nnz = Ap_rowptr[N];
   for (int64_t k = 0; k < S.Ap_nnz; ++k)
     if (Ap_col[k] < 0 || Ap_col[k] >= N) return fail(FC_ERR_INVALID, "fc_solver_setup: system column out of range");
-  FCCHK(S.Ap_rowptr.upload(Ap_rowptr, N + 1, h->stream));
-  FCCHK(S.Ap_col.upload(Ap_col, (size_t)S.Ap_nnz, h->stream));
-  FCCHK(S.Ap_val.upload(Ap_val, (size_t)S.Ap_nnz, h->stream));
+  // validate every segment against the buffers it will index (a bad table would fault the GPU)
+  for (int64_t q = 0; q < n_seg; ++q) {
+    const int64_t len = seg_len[q];
+    if (len < 0 || seg_val[q] < 0 || seg_val[q] + len > n_val) return fail(FC_ERR_INVALID, "fc_solver_setup: segment values out of range");
+    if (seg_col[q] >= 0) {
+      if ((int64_t)seg_col[q] + len > 2 * (int64_t)N) return fail(FC_ERR_INVALID, "fc_solver_setup: segment columns out of range");
+    } else {
+      const int64_t o = -((int64_t)seg_col[q] + 1);
+      if (o + len > n_idx) return fail(FC_ERR_INVALID, "fc_solver_setup: segment index list out of range");
+    }
+  }
+  for (int64_t k = 0; k < n_idx; ++k)
+    if (idx[k] < 0 || idx[k] >= 2 * N) return fail(FC_ERR_INVALID, "fc_solver_setup: shared index out of range");
   int64_t total_rows = 0;
   S.stages.clear();
   S.sweep_bytes = 0.0;
   for (int s = 0; s < n_stages; ++s) {
     Stage st;
-    st.rp_begin = stage_rowptr_begin[s];
+    st.rp_begin = stage_begin[s];
     st.row0 = stage_row0[s];
     st.nrows = stage_nrows[s];
     st.kind = stage_kind[s];
-    if (st.nrows < 0 || st.row0 < 0 || st.row0 + st.nrows > N || (st.kind != 0 && st.kind != 1) ||
-        st.rp_begin != total_rows)
+    if (st.nrows < 0 || st.row0 < 0 || st.row0 + st.nrows > N || (st.kind != 0 && st.kind != 1) || st.rp_begin != total_rows)
       return fail(FC_ERR_INVALID, "fc_solver_setup: inconsistent stage table");
-    const int64_t nz = f_rowptr[total_rows + st.nrows] - f_rowptr[total_rows];
-    const int64_t lim = st.kind == 0 ? N : 2 * (int64_t)N;
-    for (int64_t k = f_rowptr[total_rows]; k < f_rowptr[total_rows + st.nrows]; ++k)
-      if (f_col[k] < 0 || f_col[k] >= lim) return fail(FC_ERR_INVALID, "fc_solver_setup: factor column out of range");
-    st.lanes = pick_lanes(st.nrows ? (double)nz / st.nrows : 0.0);
-    st.bytes = (double)nz * 12.0 + (double)st.nrows * (8.0 + 8.0 + (st.kind == 0 ? 8.0 : 0.0));
+    const int64_t q0 = seg_ptr[total_rows], q1 = seg_ptr[total_rows + st.nrows];
+    if (q0 < 0 || q1 < q0 || q1 > n_seg) return fail(FC_ERR_INVALID, "fc_solver_setup: segment pointers out of range");
+    int64_t nz = 0, nz_idx = 0;
+    for (int64_t q = q0; q < q1; ++q) {
+      nz += seg_len[q];
+      if (seg_col[q] < 0) nz_idx += seg_len[q];
+      // an up stage must only read the y-half; a down stage reads y of its own level and x above
+      if (st.kind == 0 && (seg_col[q] < 0 || (int64_t)seg_col[q] + seg_len[q] > N))
+        return fail(FC_ERR_INVALID, "fc_solver_setup: up-sweep segment reads outside y");
+    }
+    const double mean_seg = (q1 > q0) ? (double)nz / (double)(q1 - q0) : 0.0;
+    const double mean_row = st.nrows ? (double)nz / st.nrows : 0.0;
+    // lanes per row: enough to cover a typical segment, but keep >= ~2 waves per SIMD of rows in flight
+    int lanes = mean_seg <= 6 ? 4 : mean_seg <= 12 ? 8 : mean_seg <= 24 ? 16 : mean_seg <= 48 ? 32 : 64;
+    if (mean_row > 2048 && lanes < 64) lanes = 64;
+    st.lanes = lanes;
+    // algorithmic bytes: values 8 B, x/y operand 8 B per value is served on-chip (vectors are < 1 MB),
+    // segment descriptors 16 B, shared index lists 4 B per indexed value (re-used by the rows of a node:
+    // counted once per row as an upper bound), row pointers 8 B, destination 8 B (+8 B read when accumulating)
+    st.bytes = 8.0 * (double)nz + 16.0 * (double)(q1 - q0) + 4.0 * (double)nz_idx +
+               (double)st.nrows * (8.0 + 8.0 + (st.kind == 0 ? 8.0 : 0.0));
     S.sweep_bytes += st.bytes;
     S.stages.push_back(st);
     total_rows += st.nrows;
   }
-  const int64_t fnnz = f_rowptr[total_rows];
-  FCCHK(S.f_rowptr.upload(f_rowptr, (size_t)total_rows + 1, h->stream));
-  FCCHK(S.f_col.upload(f_col, (size_t)fnnz, h->stream));
-  FCCHK(S.f_val.upload(f_val, (size_t)fnnz, h->stream));
+  S.f_nnz = n_val;
+  FCCHK(S.Ap_rowptr.upload(Ap_rowptr, N + 1, h->stream));
+  FCCHK(S.Ap_col.upload(Ap_col, (size_t)S.Ap_nnz, h->stream));
+  FCCHK(S.Ap_val.upload(Ap_val, (size_t)S.Ap_nnz, h->stream));
+  FCCHK(S.seg_ptr.upload(seg_ptr, (size_t)total_rows + 1, h->stream));
+  FCCHK(S.seg_val.upload(seg_val, (size_t)std::max<int64_t>(1, n_seg), h->stream));
+  FCCHK(S.seg_col.upload(seg_col, (size_t)std::max<int64_t>(1, n_seg), h->stream));
+  FCCHK(S.seg_len.upload(seg_len, (size_t)std::max<int64_t>(1, n_seg), h->stream));
+  if (n_idx > 0) FCCHK(S.f_idx.upload(idx, (size_t)n_idx, h->stream));
+  else FCCHK(S.f_idx.alloc(1));
+  FCCHK(S.f_val.upload(vals, (size_t)n_val, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   S.ready = true;
+  return FC_OK;
+}
+
+int fc_set_energy_matrix(fc_handle h, const int32_t* rowptr, const int32_t* col, const double* val) {
+  if (!h || !rowptr || !col || !val) return fail(FC_ERR_INVALID, "fc_set_energy_matrix: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  const int N = h->N;
+  const int nz = rowptr[N];
+  if (rowptr[0] != 0 || nz < 0) return fail(FC_ERR_INVALID, "fc_set_energy_matrix: bad row pointers");
+  for (int i = 0; i < N; ++i)
+    if (rowptr[i + 1] < rowptr[i]) return fail(FC_ERR_INVALID, "fc_set_energy_matrix: bad row pointers");
+  for (int k = 0; k < nz; ++k)
+    if (col[k] < 0 || col[k] >= N) return fail(FC_ERR_INVALID, "fc_set_energy_matrix: column out of range");
+  FCCHK(h->mp_rowptr.upload(rowptr, (size_t)N + 1, h->stream));
+  FCCHK(h->mp_col.upload(col, (size_t)std::max(1, nz), h->stream));
+  FCCHK(h->mp_val.upload(val, (size_t)std::max(1, nz), h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->have_mp = true;
   return FC_OK;
 }
 
@@ -860,6 +973,7 @@ int fc_step(fc_handle h, int order_slot, const double* u_ctrl, double* y_out, do
   HIPCHK(hipMemcpyAsync(out + 64, h->scal.p, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(out + 72, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  FCCHK(time_collect(h));
   for (int s = 0; s < h->n_sens; ++s)
     if (y_out) y_out[s] = out[s];
   if (dE_out) *dE_out = compute_energy ? out[64] : std::numeric_limits<double>::quiet_NaN();
@@ -900,6 +1014,7 @@ int fc_run(fc_handle h, int first_order_slot, int32_t n_steps, const double* u_c
   HIPCHK(hipMemcpyAsync(Eh.data(), h->Eseq.p, Eh.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(&flag, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  FCCHK(time_collect(h));
   if (y_seq)
     for (int s = 0; s < n_steps; ++s)
       for (int k = 0; k < h->n_sens; ++k) y_seq[(size_t)s * h->n_sens + k] = yh[(size_t)s * ns + k];
@@ -930,8 +1045,11 @@ int fc_solve(fc_handle h, int slot, const double* b, double* x, double* info_out
   const int N = h->N, g = nblocks(N, 256);
   HIPCHK(hipMemcpyAsync(h->tmpN.p, b, (size_t)N * sizeof(double), hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(fc_gather_perm, dim3(g), dim3(256), 0, h->stream, N, h->perm.p, h->tmpN.p, h->b.p);
+  hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, h->buf.p);
   const double *xs = nullptr, *dx = nullptr;
-  FCCHK(solve_permuted(h, S, &xs, &dx));
+  int nrp = 0;
+  FCCHK(solve_permuted(h, S, &xs, &dx, &nrp));
+  if (nrp > 0) hipLaunchKernelGGL(fc_reduce_final, dim3(2), dim3(256), 0, h->stream, nrp, h->partial.p, 1.0, h->scal.p + 1);
   hipLaunchKernelGGL(fc_scatter_perm, dim3(g), dim3(256), 0, h->stream, N, h->perm.p, xs, dx, h->tmpN2.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(x, h->tmpN2.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -978,6 +1096,7 @@ int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double*
   if (n_steps <= 0 || !ms) return fail(FC_ERR_INVALID, "fc_profile_steps: bad argument");
   OrderSys& S = h->sys[order_slot];
   if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this order");
+  if (!h->have_mp) return fail(FC_ERR_NOT_READY, "fc_set_energy_matrix not called");
   HIPCHK(hipSetDevice(h->device));
   if (h->n_act) HIPCHK(hipMemcpyAsync(h->uctrl.p, u_ctrl, h->n_act * sizeof(double), hipMemcpyHostToDevice, h->stream));
   const int N = h->N, g = nblocks(N, 256);
@@ -994,6 +1113,7 @@ int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double*
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     return FC_OK;
   };
+  double* e_partial = h->partial.p + 2 * (size_t)h->nblk_N;
   for (int s = 0; s < n_steps; ++s) {
     launches = 0;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
@@ -1002,19 +1122,25 @@ int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double*
                        h->uctrl.p, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p);
     FCCHK(lap(0));
     hipLaunchKernelGGL(fc_rhs_gather, dim3(g), dim3(256), 0, h->stream, N, h->gptr_p.p, h->gidx_p.p, h->ev.p,
-                       h->bcslot_p.p, h->bcprof.p, S.lift_p.p, h->n_act, h->uctrl.p, h->b.p);
-    hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, h->buf.p);
+                       h->bcslot_p.p, h->bcprof.p, S.lift_p.p, h->n_act, h->uctrl.p, h->b.p, h->buf.p);
     FCCHK(lap(1));
     FCCHK(apply_factors(h, S));
     launches += (int)S.stages.size();
     FCCHK(lap(2));
     const double* x = h->buf.p + N;
     const double* dx = nullptr;
+    int nrp = 0;
+    if (h->max_iter == 0 && h->check_residual) {
+      nrp = launch_spmv<1>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, x, h->b.p, h->tmpN.p, nullptr, h->partial.p);
+      if (nrp < 0) return nrp;
+      FCCHK(lap(3));
+    }
     for (int it = 0; it < h->max_iter; ++it) {
       if (it > 0) hipLaunchKernelGGL(fc_axpy, dim3(g), dim3(256), 0, h->stream, N, 1.0, h->buf.p + N, h->xsol.p);
       const int nb = launch_spmv<1>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, it > 0 ? h->xsol.p : x, h->b.p,
-                                    h->buf.p, it > 0 ? nullptr : h->xsol.p, nullptr);
+                                    h->buf.p, it > 0 ? nullptr : h->xsol.p, it == 0 && h->check_residual ? h->partial.p : nullptr);
       if (nb < 0) return nb;
+      if (it == 0 && h->check_residual) nrp = nb;
       x = h->xsol.p;
       FCCHK(lap(3));
       FCCHK(apply_factors(h, S));
@@ -1023,11 +1149,10 @@ int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double*
       FCCHK(lap(2));
     }
     hipLaunchKernelGGL(fc_finish, dim3(g), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, x, dx, h->up.p, h->u_n.p,
-                       h->u_nn.p, h->p_n.p, h->flag.p);
-    if (h->n_sens > 0)
-      hipLaunchKernelGGL(fc_sensors, dim3(h->n_sens), dim3(64), 0, h->stream, h->n_sens, h->s_rowptr.p, h->s_idx.p,
-                         h->s_w.p, h->up.p, h->ydev.p);
-    if (h->slot_ok[FC_SLOT_MASS]) FCCHK(enqueue_energy(h, h->up.p, h->scal.p));
+                       h->u_nn.p, h->p_n.p, h->flag.p, h->mp_rowptr.p, h->mp_col.p, h->mp_val.p, e_partial);
+    hipLaunchKernelGGL(fc_final, dim3(1 + h->n_sens), dim3(256), 0, h->stream, g, e_partial, h->scal.p, nrp,
+                       nrp > 0 ? h->partial.p : nullptr, h->scal.p + 1, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p,
+                       h->up.p, h->ydev.p);
     FCCHK(lap(4));
   }
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1061,10 +1186,33 @@ int fc_bench_sweeps(fc_handle h, int slot, int reps, double* ms_per_apply, int32
   return FC_OK;
 }
 
+int fc_set_timing(fc_handle h, int on) {
+  if (!h) return fail(FC_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->timing = on != 0;
+  h->tused = 0;
+  h->tkind.clear();
+  h->t_ms[0] = h->t_ms[1] = 0.0;
+  h->t_cnt[0] = h->t_cnt[1] = 0;
+  return FC_OK;
+}
+
+int fc_get_timing(fc_handle h, double* sweep_ms, int64_t* sweep_launches, double* spmv_ms, int64_t* spmv_launches) {
+  if (!h) return fail(FC_ERR_INVALID, "null handle");
+  if (sweep_ms) *sweep_ms = h->t_ms[0];
+  if (sweep_launches) *sweep_launches = h->t_cnt[0];
+  if (spmv_ms) *spmv_ms = h->t_ms[1];
+  if (spmv_launches) *spmv_launches = h->t_cnt[1];
+  return FC_OK;
+}
+
 int fc_algorithmic_bytes(fc_handle h, int slot, double* sweep_bytes, double* spmv_bytes) {
   if (!h || slot < 0 || slot > 1) return fail(FC_ERR_INVALID, "fc_algorithmic_bytes: bad argument");
   if (sweep_bytes) *sweep_bytes = h->sys[slot].sweep_bytes;
-  if (spmv_bytes) *spmv_bytes = (double)h->nnz * 12.0 + (double)h->N * 16.0 + (double)(h->N + 1) * 4.0;
+  // the in-step SpMV runs on the permuted system matrix (same nnz as the slot up to explicit zeros)
+  const double nz = h->sys[slot].Ap_nnz > 0 ? (double)h->sys[slot].Ap_nnz : (double)h->nnz;
+  if (spmv_bytes) *spmv_bytes = nz * 12.0 + (double)h->N * 16.0 + (double)(h->N + 1) * 4.0;
   return FC_OK;
 }
 

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void fc_rhs_gather(int N, const int* __restric
                                                      const double* __restrict__ bcprof,
                                                      const double* __restrict__ lift, int n_act,
                                                      const double* __restrict__ uctrl,
-                                                     double* __restrict__ b) {
+                                                     double* __restrict__ b, double* __restrict__ y) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   double s = 0.0;
@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256) void fc_rhs_gather(int N, const int* __restric
     for (int k = 0; k < n_act; ++k) s -= uctrl[k] * lift[(size_t)k * N + i];
   }
   b[i] = s;
+  y[i] = s;  // y-half of the solver work buffer: the first factor sweep starts from b
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -301,36 +302,56 @@ __global__ __launch_bounds__(256) void fc_spmv_csr(int nrows, const int* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// Nested-dissection factor sweep: one level-wide sparse mat-vec.
-//   kind 0 (up):   buf[row0 + r] += sum_k val[k] * buf[col[k]]          (entries hold -L)
-//   kind 1 (down): buf[N + row0 + r] = sum_k val[k] * buf[col[k]]       (entries hold [D^-1 | -U])
-// Rows of one level only read entries of other levels (or, for `down`, the y half), so a level is
-// one launch with no intra-launch dependency.  int64 row offsets: factors can exceed 2^31 nnz.
+// Nested-dissection factor sweep: one level-wide block mat-vec in "segment list" form.
+// Each factor row is a list of segments (val_off, col, len): len consecutive fp64 values times
+//   col >= 0 : buf[col .. col+len)             (contiguous slice: a pivot-block / L-block row)
+//   col <  0 : buf[idx[-(col+1) + j]]          (node-shared index list: a U-block row)
+//   kind 0 (up):   buf[dest0 + r] += sum        (segments hold -L rows; reads deeper levels of y)
+//   kind 1 (down): buf[dest0 + r]  = sum        ([D^-1 | -U] rows; reads y and shallower x)
+// Rows of one level never read what the same launch writes, so a level is one launch.
+// Values stream at 8 B/nnz; column information is O(1/len) bytes per value.
 // ---------------------------------------------------------------------------------------------
 template <int LANES>
-__global__ __launch_bounds__(256) void fc_nd_sweep(int nrows, const int64_t* __restrict__ rowptr,
-                                                   const int* __restrict__ col,
+__global__ __launch_bounds__(256) void fc_nd_sweep(int nrows, const int64_t* __restrict__ seg_ptr,
+                                                   const int64_t* __restrict__ seg_val,
+                                                   const int* __restrict__ seg_col,
+                                                   const int* __restrict__ seg_len,
+                                                   const int* __restrict__ idx,
                                                    const double* __restrict__ val,
                                                    double* __restrict__ buf, int dest0, int accumulate) {
   constexpr int RPB = 256 / LANES;
   const int lane = threadIdx.x % LANES;
   const int row = blockIdx.x * RPB + threadIdx.x / LANES;
-  double s = 0.0;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   if (row < nrows) {
-    const int64_t k0 = rowptr[row], k1 = rowptr[row + 1];
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int64_t k = k0 + lane;
-    for (; k + 3 * LANES < k1; k += 4 * LANES) {
-      const double v0 = val[k], v1 = val[k + LANES], v2 = val[k + 2 * LANES], v3 = val[k + 3 * LANES];
-      const int c0 = col[k], c1 = col[k + LANES], c2 = col[k + 2 * LANES], c3 = col[k + 3 * LANES];
-      s0 += v0 * buf[c0];
-      s1 += v1 * buf[c1];
-      s2 += v2 * buf[c2];
-      s3 += v3 * buf[c3];
+    const int64_t q0 = seg_ptr[row], q1 = seg_ptr[row + 1];
+    for (int64_t q = q0; q < q1; ++q) {
+      const double* __restrict__ v = val + seg_val[q];
+      const int c = seg_col[q];
+      const int len = seg_len[q];
+      int j = lane;
+      if (c >= 0) {
+        const double* __restrict__ x = buf + c;
+        for (; j + 3 * LANES < len; j += 4 * LANES) {
+          s0 += v[j] * x[j];
+          s1 += v[j + LANES] * x[j + LANES];
+          s2 += v[j + 2 * LANES] * x[j + 2 * LANES];
+          s3 += v[j + 3 * LANES] * x[j + 3 * LANES];
+        }
+        for (; j < len; j += LANES) s0 += v[j] * x[j];
+      } else {
+        const int* __restrict__ ix = idx + (-(c + 1));
+        for (; j + 3 * LANES < len; j += 4 * LANES) {
+          s0 += v[j] * buf[ix[j]];
+          s1 += v[j + LANES] * buf[ix[j + LANES]];
+          s2 += v[j + 2 * LANES] * buf[ix[j + 2 * LANES]];
+          s3 += v[j + 3 * LANES] * buf[ix[j + 3 * LANES]];
+        }
+        for (; j < len; j += LANES) s0 += v[j] * buf[ix[j]];
+      }
     }
-    for (; k < k1; k += LANES) s0 += val[k] * buf[col[k]];
-    s = (s0 + s1) + (s2 + s3);
   }
+  double s = (s0 + s1) + (s2 + s3);
 #pragma unroll
   for (int off = LANES / 2; off > 0; off >>= 1) s += __shfl_down(s, off, LANES);
   if (row < nrows && lane == 0) {
@@ -362,23 +383,101 @@ __global__ void fc_scatter_perm(int n, const int* __restrict__ perm, const doubl
 }
 
 // x (permuted) [+ dx] -> up (W layout); shift u_nn <- u_n <- u, p_n <- p; non-finite flag
-// (reference flowsolver.py:730-731,746-751,816-819)
+// (reference flowsolver.py:730-731,746-751,816-819).  Fused: per-row share of the perturbation
+// energy 1/2 u^T M u (flowsolver.py:827-829) with the velocity mass matrix in permuted numbering
+// (Mp rows of pressure dofs are empty) -> one partial per block, summed by fc_final.
 __global__ __launch_bounds__(256) void fc_finish(int N, int nn2, const int* __restrict__ perm,
                                                  const double* __restrict__ x,
                                                  const double* __restrict__ dx, double* __restrict__ up,
                                                  double* __restrict__ u_n, double* __restrict__ u_nn,
-                                                 double* __restrict__ p_n, int* __restrict__ flag) {
+                                                 double* __restrict__ p_n, int* __restrict__ flag,
+                                                 const int* __restrict__ m_rowptr,
+                                                 const int* __restrict__ m_col,
+                                                 const double* __restrict__ m_val,
+                                                 double* __restrict__ e_partial) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const int r = perm[i];
-  const double v = dx ? x[i] + dx[i] : x[i];
-  up[r] = v;
-  if (r < nn2) {
-    u_nn[r] = u_n[r];
-    u_n[r] = v;
-    if (!isfinite(v)) atomicOr(flag, 1);
+  double e = 0.0;
+  if (i < N) {
+    const int r = perm[i];
+    const double v = dx ? x[i] + dx[i] : x[i];
+    up[r] = v;
+    if (r < nn2) {
+      u_nn[r] = u_n[r];
+      u_n[r] = v;
+      if (!isfinite(v)) atomicOr(flag, 1);
+      if (m_rowptr) {
+        double s = 0.0;
+        for (int k = m_rowptr[i]; k < m_rowptr[i + 1]; ++k) {
+          const int j = m_col[k];
+          s += m_val[k] * (dx ? x[j] + dx[j] : x[j]);
+        }
+        e = v * s;
+      }
+    } else {
+      p_n[r - nn2] = v;
+    }
+  }
+  if (e_partial) {
+    __shared__ double red[256];
+    red[threadIdx.x] = e;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) e_partial[blockIdx.x] = red[0];
+  }
+}
+
+// tail of a step, one launch: block 0 folds the energy partials (-> E = 1/2 sum) and, if present,
+// the residual partials (sum r^2, sum b^2); block 1+s evaluates sensor row s
+// (y_s = sum_k w[k] up[idx[k]], sensor.py:96-98,166-197).  Fixed summation order => reproducible.
+__global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restrict__ e_partial,
+                                                double* __restrict__ E_out, int n_r,
+                                                const double* __restrict__ r_partial,
+                                                double* __restrict__ r_out, int n_sens,
+                                                const int* __restrict__ s_rowptr,
+                                                const int* __restrict__ s_idx,
+                                                const double* __restrict__ s_w,
+                                                const double* __restrict__ up, double* __restrict__ y) {
+  __shared__ double red[3][256];
+  const int t = threadIdx.x;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  if (blockIdx.x == 0) {
+    if (e_partial)
+      for (int i = t; i < n_e; i += 256) a0 += e_partial[i];
+    if (r_partial)
+      for (int i = t; i < n_r; i += 256) {
+        a1 += r_partial[i];
+        a2 += r_partial[n_r + i];
+      }
   } else {
-    p_n[r - nn2] = v;
+    const int s = blockIdx.x - 1;
+    if (s < n_sens)
+      for (int k = s_rowptr[s] + t; k < s_rowptr[s + 1]; k += 256) a0 += s_w[k] * up[s_idx[k]];
+  }
+  red[0][t] = a0;
+  red[1][t] = a1;
+  red[2][t] = a2;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (t < st) {
+      red[0][t] += red[0][t + st];
+      red[1][t] += red[1][t + st];
+      red[2][t] += red[2][t + st];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    if (blockIdx.x == 0) {
+      if (e_partial && E_out) E_out[0] = 0.5 * red[0][0];
+      if (r_partial && r_out) {
+        r_out[0] = red[1][0];
+        r_out[1] = red[2][0];
+      }
+    } else if (blockIdx.x - 1 < n_sens) {
+      y[blockIdx.x - 1] = red[0][0];
+    }
   }
 }
 

@@ -117,52 +117,53 @@ class DeviceSolver:
         check(self.lib.fc_apply_bc(self._h, slot))
 
     # ── solver setup (host analysis + factorisation, device upload) ──────────
-    def setup_solver(self, slot: int, depth: int | None = None, refine: int = 1, check_residual: bool = True) -> None:
-        """Factorise the (BC-eliminated) matrix of ``slot`` and hand the factors to the device."""
+    def setup_solver(self, slot: int, depth: int | None = None, refine: int = 0, check_residual: bool = True, merge: int = 2) -> None:
+        """Factorise the (BC-eliminated) matrix of ``slot`` and hand the factors to the device.
+
+        ``depth`` binary bisections (default: leaves of ≈ 12 cells), fused ``merge`` at a time into a
+        2**merge-ary elimination tree; ``refine`` iterative-refinement sweeps per solve (the fp64
+        selected inverse is accurate to round-off on its own, so 0 + residual monitoring is the default).
+        """
         A = self.matrix(slot)
         if self.tree is None:
             th = self.th
             if depth is None:
-                depth = max(2, int(np.ceil(np.log2(max(th.nc, 1) / 8.0))))
+                depth = max(merge, int(np.ceil(np.log2(max(th.nc, 1) / 12.0))))
             skip = np.zeros(self.N, dtype=bool)
             skip[self.bc_dofs] = True
-            self.tree = ndsolver.build_tree(th.cell_dofs, th.mesh.cell_centroids(), self.N, depth, skip)
+            self.tree = ndsolver.build_tree(th.cell_dofs, th.mesh.cell_centroids(), self.N, depth, skip, merge=merge)
             check(self.lib.fc_set_permutation(self._h, _i32(self.tree.perm)))
-        fac = ndsolver.factorize(A, self.tree)
+            self._upload_energy_matrix()
         t = self.tree
+        fac = ndsolver.factorize_blocks(A, t)
         Ap = A[t.perm][:, t.perm].tocsr()
         Ap.sort_indices()
-        mats, row0, kind = [], [], []
-        for i, k in enumerate(range(t.depth - 1, -1, -1)):
-            mats.append(fac.up[i])
-            row0.append(int(t.node_ptr[k][0]))
-            kind.append(0)
-        for k in range(0, t.depth + 1):
-            mats.append(fac.down[k])
-            row0.append(int(t.node_ptr[k][0]))
-            kind.append(1)
-        nrows = np.array([m.shape[0] for m in mats], dtype=np.int32)
-        begin = np.concatenate([[0], np.cumsum(nrows)[:-1]]).astype(np.int64)
-        f_rowptr = np.zeros(int(nrows.sum()) + 1, dtype=np.int64)
-        pos, off = 0, 0
-        cols, vals = [], []
-        for m in mats:
-            m.sort_indices()
-            f_rowptr[pos + 1 : pos + 1 + m.shape[0]] = off + m.indptr[1:].astype(np.int64)
-            pos += m.shape[0]
-            off += m.nnz
-            cols.append(m.indices.astype(np.int32))
-            vals.append(m.data)
-        f_col = _i32(np.concatenate(cols))
-        f_val = _f64(np.concatenate(vals))
+        idx = fac.idx if fac.idx.size else np.zeros(1, dtype=np.int32)
         check(
             self.lib.fc_solver_setup(
-                self._h, slot, _i32(Ap.indptr), _i32(Ap.indices), _f64(Ap.data), len(mats), begin,
-                _i32(row0), nrows, _i32(kind), f_rowptr, f_col, f_val,
+                self._h, slot, _i32(Ap.indptr), _i32(Ap.indices), _f64(Ap.data), len(fac.stage_kind), fac.stage_begin,
+                fac.stage_row0, fac.stage_nrows, fac.stage_kind, fac.seg_ptr, int(fac.seg_val.size), fac.seg_val,
+                fac.seg_col, fac.seg_len, int(fac.idx.size), _i32(idx), int(fac.vals.size), fac.vals,
             )
         )
-        self.factor_nnz[slot] = int(f_val.size)
+        self.factor_nnz[slot] = int(fac.nnz)
+        self.n_stages = len(fac.stage_kind)
+        self.set_solver_options(refine, check_residual)
+
+    def set_solver_options(self, refine: int = 0, check_residual: bool = True) -> None:
         check(self.lib.fc_set_solver_options(self._h, _lib.METHOD_REFINE, int(refine), 1e-10, int(check_residual)))
+
+    def _upload_energy_matrix(self) -> None:
+        """(u, v) mass matrix in the permuted numbering for the fused energy evaluation."""
+        self.assemble_matrix(SLOT_MASS, mass=1.0, nu=0.0, pressure=0.0, divergence=0.0)
+        M = self.matrix(SLOT_MASS)
+        nn2 = 2 * self.nn
+        M = sp.block_diag([M[:nn2, :nn2], sp.csr_matrix((self.N - nn2, self.N - nn2))]).tocsr()
+        M.eliminate_zeros()
+        p = self.tree.perm
+        Mp = M[p][:, p].tocsr()
+        Mp.sort_indices()
+        check(self.lib.fc_set_energy_matrix(self._h, _i32(Mp.indptr), _i32(Mp.indices), _f64(Mp.data)))
 
     # ── state ────────────────────────────────────────────────────────────────
     def set_state(self, u_n, u_nn, p_n=None) -> None:
@@ -233,6 +234,15 @@ class DeviceSolver:
         ms, nl = C.c_double(), C.c_int32()
         check(self.lib.fc_bench_sweeps(self._h, slot, reps, C.byref(ms), C.byref(nl)))
         return ms.value, nl.value
+
+    def set_timing(self, on: bool) -> None:
+        check(self.lib.fc_set_timing(self._h, int(bool(on))))
+
+    def get_timing(self) -> dict:
+        a, b = C.c_double(), C.c_double()
+        na, nb = C.c_int64(), C.c_int64()
+        check(self.lib.fc_get_timing(self._h, C.byref(a), C.byref(na), C.byref(b), C.byref(nb)))
+        return {"sweep_ms": a.value, "sweep_launches": na.value, "spmv_ms": b.value, "spmv_launches": nb.value}
 
     def algorithmic_bytes(self, slot: int):
         a, b = C.c_double(), C.c_double()

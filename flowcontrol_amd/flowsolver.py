@@ -73,9 +73,9 @@ class FlowSolver(ABC):
         self.params_ic = params_ic
         self.verbose = verbose
         #: device solver knobs (not in the reference): ND tree depth (None = automatic) and the
-        #: number of iterative-refinement sweeps per solve
+        #: number of iterative-refinement sweeps per solve (0 = factor apply + residual monitoring)
         self.nd_depth: int | None = None
-        self.refine_steps: int = 1
+        self.refine_steps: int = 0
         self._setup()
 
     # ── validation (reference :108-165) ──────────────────────────────────────

@@ -32,12 +32,13 @@ import scipy.sparse as sp
 
 @dataclass
 class NDTree:
-    depth: int  # leaves live at this depth; level k has 2**k nodes
+    depth: int  # leaves live at this depth; level k has 2**(k*arity_bits) nodes
     perm: np.ndarray  # new → old dof index
     iperm: np.ndarray  # old → new
     node_ptr: list[np.ndarray]  # per level k: (2**k + 1,) offsets into the *new* ordering
     level_ptr: np.ndarray  # (depth + 2,) new-index offsets of levels, deepest level FIRST
     bnd: list[list[np.ndarray]]  # per level k, per node: boundary dofs (new indices, sorted)
+    arity_bits: int = 1  # children per node = 2**arity_bits
 
 
 def _bisect_cells(cent: np.ndarray, depth: int) -> np.ndarray:
@@ -63,14 +64,20 @@ def _bisect_cells(cent: np.ndarray, depth: int) -> np.ndarray:
     return leaf
 
 
-def build_tree(cell_dofs: np.ndarray, centroids: np.ndarray, N: int, depth: int, skip: np.ndarray | None = None) -> NDTree:
+def build_tree(cell_dofs: np.ndarray, centroids: np.ndarray, N: int, depth: int, skip: np.ndarray | None = None, merge: int = 1) -> NDTree:
     """Element-based nested dissection.
 
     A dof is owned by the deepest tree node whose cell set contains every cell touching it
     (leaf ⇒ subdomain interior; internal node ⇒ separator).  ``skip`` marks dofs that are
     decoupled identity rows (Dirichlet) — they are parked in the leaves.
+
+    ``depth`` counts binary bisections.  ``merge = m`` fuses every m consecutive binary levels
+    into one level of a 2**m-ary tree (the separators of those levels become one pivot block):
+    fewer, fatter sweep stages on the device at the price of somewhat denser pivot inverses.
     """
     nc, nl = cell_dofs.shape
+    if depth % merge:
+        depth += merge - depth % merge
     leaf = _bisect_cells(centroids, depth)
     lo = np.full(N, np.iinfo(np.int64).max)
     hi = np.full(N, -1)
@@ -86,8 +93,13 @@ def build_tree(cell_dofs: np.ndarray, centroids: np.ndarray, N: int, depth: int,
     nbits = np.zeros(N, dtype=np.int64)
     nz = x > 0
     nbits[nz] = np.floor(np.log2(x[nz])).astype(np.int64) + 1
-    level = depth - nbits  # owner depth
+    level = depth - nbits  # owner depth in the binary tree
+    if merge > 1:
+        level = level // merge  # level of the 2**merge-ary tree (floor: separators join their coarser group)
+        nbits = depth - level * merge
+        depth = depth // merge
     prefix = lo >> nbits  # owner index within its level
+    arity_bits = merge
     # ordering: deepest level first, then node, then original index (locality)
     key = np.lexsort((np.arange(N), prefix, -level))
     perm = key.astype(np.int64)
@@ -97,7 +109,7 @@ def build_tree(cell_dofs: np.ndarray, centroids: np.ndarray, N: int, depth: int,
     level_ptr = np.zeros(depth + 2, dtype=np.int64)
     pos = 0
     for i, k in enumerate(range(depth, -1, -1)):
-        cnt = np.bincount(prefix[level == k], minlength=2**k)
+        cnt = np.bincount(prefix[level == k], minlength=2 ** (k * arity_bits))
         node_ptr[k] = pos + np.r_[0, np.cumsum(cnt)]
         pos += int(cnt.sum())
         level_ptr[i + 1] = pos
@@ -106,16 +118,16 @@ def build_tree(cell_dofs: np.ndarray, centroids: np.ndarray, N: int, depth: int,
     new_cell_dofs = iperm[cell_dofs.astype(np.int64)]
     lvl_new = level[perm]
     for k in range(depth, -1, -1):
-        sub = leaf >> (depth - k)
+        sub = leaf >> ((depth - k) * arity_bits)
         order = np.argsort(sub, kind="stable")
-        starts = np.searchsorted(sub[order], np.arange(2**k + 1))
+        starts = np.searchsorted(sub[order], np.arange(2 ** (k * arity_bits) + 1))
         out = []
-        for t in range(2**k):
+        for t in range(2 ** (k * arity_bits)):
             cells = order[starts[t] : starts[t + 1]]
             dd = np.unique(new_cell_dofs[cells].reshape(-1))
             out.append(dd[lvl_new[dd] < k])
         bnd[k] = out
-    return NDTree(depth, perm, iperm, node_ptr, level_ptr, bnd)
+    return NDTree(depth, perm, iperm, node_ptr, level_ptr, bnd, arity_bits)
 
 
 @dataclass
@@ -154,8 +166,9 @@ def factorize(A: sp.csr_matrix, tree: NDTree) -> NDFactors:
     Lr, Lc, Lv = [], [], []  # −L entries (row in B_t, col in I_t)
     Ur, Uc, Uv = [], [], []  # −U entries (row in I_t, col in B_t)
     Dr, Dc, Dv = [], [], []
+    ab = t.arity_bits
     for k in range(t.depth, -1, -1):
-        for n in range(2**k):
+        for n in range(2 ** (k * ab)):
             i0, i1 = int(t.node_ptr[k][n]), int(t.node_ptr[k][n + 1])
             ni = i1 - i0
             B = t.bnd[k][n]
@@ -165,7 +178,7 @@ def factorize(A: sp.csr_matrix, tree: NDTree) -> NDFactors:
                 if k < t.depth:
                     idx = B
                     F = np.zeros((nb, nb))
-                    for ch in (2 * n, 2 * n + 1):
+                    for ch in range(n << ab, (n + 1) << ab):
                         cb, cu = updates.pop((k + 1, ch))
                         if cb.size:
                             p = np.searchsorted(idx, cb)
@@ -200,7 +213,7 @@ def factorize(A: sp.csr_matrix, tree: NDTree) -> NDFactors:
                 cols = Ap[:, i0:i1].tocsc()[B].tocoo()  # A[B, I]
                 F[ni + cols.row, cols.col] += cols.data
             if k < t.depth:
-                for ch in (2 * n, 2 * n + 1):
+                for ch in range(n << ab, (n + 1) << ab):
                     cb, cu = updates.pop((k + 1, ch))
                     if cb.size:
                         p = np.searchsorted(idx, cb)
@@ -242,3 +255,222 @@ def factorize(A: sp.csr_matrix, tree: NDTree) -> NDFactors:
 
 
 __all__ = ["NDTree", "NDFactors", "build_tree", "factorize"]
+
+
+# ──────────────────────────────────────────────────────────────────────────────────────────
+# Block ("segment list") factors: what the device actually consumes.
+# ──────────────────────────────────────────────────────────────────────────────────────────
+@dataclass
+class BlockFactors:
+    """Selected-inverse factors as dense blocks + per-row segment lists.
+
+    Every factor row is a short list of *segments* ``(val_off, col, len)``: ``len`` consecutive
+    fp64 values at ``vals[val_off:]`` multiplied with either ``len`` consecutive entries of the
+    work buffer starting at ``col`` (``col >= 0``) or with the entries ``idx[-(col+1) + j]``
+    (``col < 0``; the index list is shared by all rows of a tree node).  Values therefore cost
+    8 B/nnz of HBM traffic and the column information a fraction of a byte, instead of CSR's
+    12 B/nnz.
+
+    Work buffer layout: ``buf = [y (N) | x (N)]``.
+      stage kind 0 (up,   level k = depth-1 … 0):  y[r] += Σ segments   (segments hold −L rows)
+      stage kind 1 (down, level k = 0 … depth):    x[r]  = Σ segments   ([D⁻¹ | −U] rows)
+    """
+
+    tree: NDTree
+    N: int
+    vals: np.ndarray  # float64
+    idx: np.ndarray  # int32 shared column lists (entries index into buf)
+    seg_val: np.ndarray  # int64 (nseg,)
+    seg_col: np.ndarray  # int32 (nseg,)
+    seg_len: np.ndarray  # int32 (nseg,)
+    seg_ptr: np.ndarray  # int64 (total_rows + 1,) rows of all stages concatenated
+    stage_row0: np.ndarray  # int32 first destination row of each stage (permuted numbering)
+    stage_nrows: np.ndarray  # int32
+    stage_kind: np.ndarray  # int32
+    stage_begin: np.ndarray  # int64 offset of the stage's first row in seg_ptr
+    nnz: int
+
+    def to_csr_stages(self):
+        """(up, down) lists of scipy CSR matrices — host reference used by the CPU tests."""
+        mats = []
+        for s in range(len(self.stage_kind)):
+            r0 = int(self.stage_begin[s])
+            nr = int(self.stage_nrows[s])
+            rows, cols, vals = [], [], []
+            for r in range(nr):
+                for q in range(int(self.seg_ptr[r0 + r]), int(self.seg_ptr[r0 + r + 1])):
+                    n = int(self.seg_len[q])
+                    c = int(self.seg_col[q])
+                    cc = np.arange(c, c + n) if c >= 0 else self.idx[-(c + 1) : -(c + 1) + n]
+                    rows.append(np.full(n, r))
+                    cols.append(cc)
+                    vals.append(self.vals[int(self.seg_val[q]) : int(self.seg_val[q]) + n])
+            if rows:
+                M = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nr, 2 * self.N))
+            else:
+                M = sp.csr_matrix((nr, 2 * self.N))
+            mats.append(M)
+        return mats
+
+    def solve(self, b: np.ndarray) -> np.ndarray:
+        """Host reference of the device apply (small meshes only: builds CSR stages)."""
+        t = self.tree
+        buf = np.concatenate([b[t.perm].astype(np.float64), np.zeros(self.N)])
+        for s, M in enumerate(self.to_csr_stages()):
+            r0, nr = int(self.stage_row0[s]), int(self.stage_nrows[s])
+            if self.stage_kind[s] == 0:
+                buf[r0 : r0 + nr] += M @ buf
+            else:
+                buf[self.N + r0 : self.N + r0 + nr] = M @ buf
+        x = np.empty(self.N)
+        x[t.perm] = buf[self.N :]
+        return x
+
+
+def factorize_blocks(A: sp.csr_matrix, tree: NDTree) -> BlockFactors:
+    """Numeric multifrontal factorisation with explicit pivot-block inverses → block factors."""
+    N = A.shape[0]
+    t = tree
+    ab = t.arity_bits
+    Ap = A[t.perm][:, t.perm].tocoo()
+    r_, c_, v_ = Ap.row.astype(np.int64), Ap.col.astype(np.int64), Ap.data
+    keep = v_ != 0.0
+    r_, c_, v_ = r_[keep], c_[keep], v_[keep]
+    # node id (global, in elimination order) of every permuted dof
+    starts = np.concatenate([t.node_ptr[k][:-1] for k in range(t.depth, -1, -1)])
+    node_level = np.concatenate([np.full(len(t.node_ptr[k]) - 1, k) for k in range(t.depth, -1, -1)])
+    node_index = np.concatenate([np.arange(len(t.node_ptr[k]) - 1) for k in range(t.depth, -1, -1)])
+    ends = np.concatenate([t.node_ptr[k][1:] for k in range(t.depth, -1, -1)])
+    order_nodes = np.argsort(starts, kind="stable")
+    sorted_starts = starts[order_nodes]
+    nonempty = ends[order_nodes] > sorted_starts
+    sn = sorted_starts[nonempty]
+    sid = order_nodes[nonempty]
+    owner_of_dof = sid[np.searchsorted(sn, np.arange(N), side="right") - 1]
+    own = owner_of_dof[np.minimum(r_, c_)]
+    eorder = np.argsort(own, kind="stable")
+    r_, c_, v_, own = r_[eorder], c_[eorder], v_[eorder], own[eorder]
+    ebeg = np.searchsorted(own, np.arange(len(starts) + 1))
+    gid = {(int(k), int(n)): g for g, (k, n) in enumerate(zip(node_level, node_index))}
+
+    vals_chunks: list[np.ndarray] = []
+    vpos = 0
+    idx_chunks: list[np.ndarray] = []
+    ipos = 0
+    up_rows, up_val, up_col, up_len = [], [], [], []
+    dn_val = np.zeros((N, 2), dtype=np.int64)
+    dn_col = np.zeros((N, 2), dtype=np.int32)
+    dn_len = np.zeros((N, 2), dtype=np.int32)
+    updates: dict[tuple[int, int], tuple[np.ndarray, np.ndarray]] = {}
+    nnz = 0
+    for k in range(t.depth, -1, -1):
+        for n in range(2 ** (k * ab)):
+            i0, i1 = int(t.node_ptr[k][n]), int(t.node_ptr[k][n + 1])
+            ni = i1 - i0
+            B = t.bnd[k][n]
+            nb = B.size
+            children = range(n << ab, (n + 1) << ab) if k < t.depth else ()
+            if ni == 0:
+                F = np.zeros((nb, nb))
+                for ch in children:
+                    cb, cu = updates.pop((k + 1, ch))
+                    if cb.size:
+                        p = np.searchsorted(B, cb)
+                        F[np.ix_(p, p)] += cu
+                updates[(k, n)] = (B, F)
+                continue
+            idxs = np.concatenate([np.arange(i0, i1), B])
+            nf = ni + nb
+            F = np.zeros((nf, nf))
+            g = gid[(k, n)]
+            er, ec, ev = r_[ebeg[g] : ebeg[g + 1]], c_[ebeg[g] : ebeg[g + 1]], v_[ebeg[g] : ebeg[g + 1]]
+            rin, cin = er < i1, ec < i1  # owner = node of min(r, c) ⇒ both ≥ i0
+            pr = np.where(rin, er - i0, ni + np.searchsorted(B, er))
+            pc = np.where(cin, ec - i0, ni + np.searchsorted(B, ec))
+            if nb:
+                bad = (~rin & (B[np.clip(pr - ni, 0, nb - 1)] != er)) | (~cin & (B[np.clip(pc - ni, 0, nb - 1)] != ec))
+            else:
+                bad = ~rin | ~cin
+            if np.any(bad):
+                raise RuntimeError("matrix entry outside the front: tree/boundary sets inconsistent")
+            np.add.at(F, (pr, pc), ev)
+            for ch in children:
+                cb, cu = updates.pop((k + 1, ch))
+                if cb.size:
+                    p = np.searchsorted(idxs, cb)
+                    F[np.ix_(p, p)] += cu
+            Dinv = np.linalg.inv(F[:ni, :ni])
+            rows = np.arange(i0, i1)
+            if nb:
+                F12, F21 = F[:ni, ni:], F[ni:, :ni]
+                Wt = F21 @ Dinv
+                Vt = Dinv @ F12
+                updates[(k, n)] = (B, F[ni:, ni:] - Wt @ F12)
+                DV = np.hstack([Dinv, -Vt])  # (ni, ni+nb) row-major: one contiguous row per dof
+                vals_chunks.append(DV.ravel())
+                dn_val[rows, 0] = vpos + np.arange(ni) * nf
+                dn_val[rows, 1] = vpos + np.arange(ni) * nf + ni
+                vpos += DV.size
+                idx_chunks.append((N + B).astype(np.int32))
+                dn_col[rows, 0], dn_len[rows, 0] = i0, ni
+                dn_col[rows, 1], dn_len[rows, 1] = -(ipos + 1), nb
+                ipos += nb
+                vals_chunks.append((-Wt).ravel())  # (nb, ni) row-major: row j feeds dof B[j]
+                up_rows.append(B)
+                up_val.append(vpos + np.arange(nb, dtype=np.int64) * ni)
+                up_col.append(np.full(nb, i0, dtype=np.int32))
+                up_len.append(np.full(nb, ni, dtype=np.int32))
+                vpos += Wt.size
+                nnz += ni * ni + 2 * ni * nb
+            else:
+                updates[(k, n)] = (B, np.zeros((0, 0)))
+                vals_chunks.append(Dinv.ravel())
+                dn_val[rows, 0] = vpos + np.arange(ni) * ni
+                vpos += Dinv.size
+                dn_col[rows, 0], dn_len[rows, 0] = i0, ni
+                nnz += ni * ni
+    vals = np.concatenate(vals_chunks) if vals_chunks else np.zeros(0)
+    idx = np.concatenate(idx_chunks) if idx_chunks else np.zeros(0, dtype=np.int32)
+    # up segments grouped by destination row (stable ⇒ fixed summation order: deeper nodes first)
+    if up_rows:
+        ur = np.concatenate(up_rows)
+        uo = np.argsort(ur, kind="stable")
+        ur = ur[uo]
+        uv, uc, ul = np.concatenate(up_val)[uo], np.concatenate(up_col)[uo], np.concatenate(up_len)[uo]
+    else:
+        ur = np.zeros(0, dtype=np.int64)
+        uv, uc, ul = np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int32)
+    up_cnt = np.bincount(ur, minlength=N)
+    up_start = np.concatenate([[0], np.cumsum(up_cnt)])
+    seg_val, seg_col, seg_len, seg_cnt = [], [], [], []
+    row0, nrows, kind = [], [], []
+    for k in range(t.depth - 1, -1, -1):  # up stages
+        r0, r1 = int(t.node_ptr[k][0]), int(t.node_ptr[k][-1])
+        a, b = int(up_start[r0]), int(up_start[r1])
+        seg_val.append(uv[a:b]), seg_col.append(uc[a:b]), seg_len.append(ul[a:b])
+        seg_cnt.append(up_cnt[r0:r1])
+        row0.append(r0), nrows.append(r1 - r0), kind.append(0)
+    for k in range(0, t.depth + 1):  # down stages
+        r0, r1 = int(t.node_ptr[k][0]), int(t.node_ptr[k][-1])
+        has2 = dn_len[r0:r1, 1] > 0
+        cnt = 1 + has2.astype(np.int64)
+        m = np.ones((r1 - r0, 2), dtype=bool)
+        m[:, 1] = has2
+        seg_val.append(dn_val[r0:r1][m]), seg_col.append(dn_col[r0:r1][m]), seg_len.append(dn_len[r0:r1][m])
+        seg_cnt.append(cnt)
+        row0.append(r0), nrows.append(r1 - r0), kind.append(1)
+    cnt_all = np.concatenate(seg_cnt) if seg_cnt else np.zeros(0, np.int64)
+    seg_ptr = np.concatenate([[0], np.cumsum(cnt_all)]).astype(np.int64)
+    nrows = np.array(nrows, dtype=np.int32)
+    begin = np.concatenate([[0], np.cumsum(nrows)[:-1]]).astype(np.int64)
+    return BlockFactors(
+        tree=t, N=N, vals=np.ascontiguousarray(vals), idx=np.ascontiguousarray(idx, dtype=np.int32),
+        seg_val=np.ascontiguousarray(np.concatenate(seg_val), dtype=np.int64),
+        seg_col=np.ascontiguousarray(np.concatenate(seg_col), dtype=np.int32),
+        seg_len=np.ascontiguousarray(np.concatenate(seg_len), dtype=np.int32),
+        seg_ptr=seg_ptr, stage_row0=np.array(row0, dtype=np.int32), stage_nrows=nrows,
+        stage_kind=np.array(kind, dtype=np.int32), stage_begin=begin, nnz=int(nnz),
+    )
+
+
+__all__ += ["BlockFactors", "factorize_blocks"]

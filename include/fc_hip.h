@@ -105,12 +105,19 @@ int fc_apply_bc(fc_handle h, int slot);
 int fc_set_permutation(fc_handle h, const int32_t* perm /* [N] new -> old */);
 int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32_t* Ap_col,
                     const double* Ap_val, /* permuted system matrix (N rows) */
-                    int32_t n_stages, const int64_t* stage_rowptr_begin /* [n_stages] */,
+                    int32_t n_stages, const int64_t* stage_begin /* [n_stages] first row in seg_ptr */,
                     const int32_t* stage_row0 /* [n_stages] first destination row */,
                     const int32_t* stage_nrows /* [n_stages] */,
                     const int32_t* stage_kind /* [n_stages] 0 = up (y += ..), 1 = down (x = ..) */,
-                    const int64_t* f_rowptr /* [total_rows + 1] */, const int32_t* f_col,
-                    const double* f_val);
+                    const int64_t* seg_ptr /* [total_rows + 1] */, int64_t n_seg,
+                    const int64_t* seg_val /* [n_seg] offset into vals */,
+                    const int32_t* seg_col /* [n_seg] >=0: first buffer index; <0: -(offset into idx)-1 */,
+                    const int32_t* seg_len /* [n_seg] */, int64_t n_idx, const int32_t* idx,
+                    int64_t n_val, const double* vals);
+/* velocity mass matrix (u,v) in the solver's permuted numbering, CSR with N rows (pressure rows
+ * empty): the matrix behind compute_perturbation_energy (flowsolver.py:827-829), used by the
+ * fused step tail */
+int fc_set_energy_matrix(fc_handle h, const int32_t* rowptr, const int32_t* col, const double* val);
 int fc_set_solver_options(fc_handle h, int method, int max_iter, double rtol, int check_residual);
 
 /* ── state: FlowFieldCollection u_n, u_nn, p_n (flowfield.py:67-105; flowsolver.py:487-491) ─ */
@@ -152,6 +159,12 @@ int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double*
 /* time `reps` back-to-back factor applies (all sweep launches of one M^-1 application) with HIP
  * events on the handle's stream; mean milliseconds per apply and launches per apply */
 int fc_bench_sweeps(fc_handle h, int slot, int reps, double* ms_per_apply, int32_t* launches_per_apply);
+/* per-launch HIP-event timing inside fc_step / fc_run: when on, every factor-sweep launch and
+ * every in-step CSR SpMV launch is bracketed by an event pair on the handle's stream; totals are
+ * accumulated after the step's synchronisation.  fc_set_timing resets the accumulators. */
+int fc_set_timing(fc_handle h, int on);
+int fc_get_timing(fc_handle h, double* sweep_ms, int64_t* sweep_launches, double* spmv_ms,
+                  int64_t* spmv_launches);
 /* algorithmic bytes of one factor apply (sum over sweep launches) and of one CSR SpMV */
 int fc_algorithmic_bytes(fc_handle h, int slot, double* sweep_bytes, double* spmv_bytes);
 
