@@ -76,7 +76,7 @@ struct Stage {
   int row0;          // first destination row (permuted numbering)
   int nrows;
   int kind;  // 0 up, 1 down
-  int lanes;
+  int lanes, sub;  // lanes per row, lanes per segment slot
   double bytes;  // algorithmic bytes of this launch
 };
 
@@ -87,8 +87,9 @@ struct OrderSys {
   DevBuf<int> Ap_rowptr, Ap_col;
   DevBuf<double> Ap_val;
   int64_t Ap_nnz = 0;
-  DevBuf<int64_t> seg_ptr, seg_val;  // per-row segment lists of all stages, concatenated
-  DevBuf<int> seg_col, seg_len, f_idx;
+  DevBuf<int64_t> seg_ptr;  // per-row segment lists of all stages, concatenated
+  DevBuf<FcSeg> seg;
+  DevBuf<int> f_idx;
   DevBuf<double> f_val;
   int64_t f_nnz = 0;
   std::vector<Stage> stages;
@@ -96,6 +97,9 @@ struct OrderSys {
 };
 
 constexpr int kPinDoubles = 4096;
+#ifndef FC_DOWN_DEPTH
+#define FC_DOWN_DEPTH 2  // down-sweep rows: lanes ~ mean segment length / this
+#endif
 
 }  // namespace
 
@@ -145,7 +149,8 @@ struct fc_ctx {
   DevBuf<double> partial, scal;               // reductions; scal: [0]=E [1]=r2 [2]=b2
   DevBuf<double> uctrl, ydev, yseq, Eseq, useq;
   DevBuf<int> flag;
-  double* pin = nullptr;  // pinned host staging
+  double* pin = nullptr;    // pinned, device-mapped host record: [0..63] u_ctrl in, [64..] outputs
+  double* pin_dev = nullptr;  // device address of the same memory
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int nblk_N = 0;
   // per-launch HIP-event timing (fc_set_timing): pairs recorded around every sweep / SpMV launch
@@ -254,15 +259,30 @@ int launch_sweep(fc_ctx* h, const OrderSys& S, const Stage& st) {
   const int dest0 = st.kind == 0 ? st.row0 : h->N + st.row0;
   const int acc = st.kind == 0 ? 1 : 0;
   FCCHK(time_begin(h, 0));
-#define FC_SWEEP(L)                                                                                              \
-  hipLaunchKernelGGL((fc_nd_sweep<L>), grid, block, 0, h->stream, st.nrows, rp, S.seg_val.p, S.seg_col.p, S.seg_len.p, \
-                     S.f_idx.p, S.f_val.p, buf, dest0, acc)
-  switch (st.lanes) {
-    case 4: FC_SWEEP(4); break;
-    case 8: FC_SWEEP(8); break;
-    case 16: FC_SWEEP(16); break;
-    case 32: FC_SWEEP(32); break;
-    default: FC_SWEEP(64); break;
+#define FC_SWEEP(L, SB)                                                                                          \
+  hipLaunchKernelGGL((fc_nd_sweep<L, SB>), grid, block, 0, h->stream, st.nrows, rp, S.seg.p, S.f_idx.p, S.f_val.p, buf, \
+                     dest0, acc)
+  const int key = st.lanes * 1000 + st.sub;
+  switch (key) {
+    case 8004: FC_SWEEP(8, 4); break;
+    case 8008: FC_SWEEP(8, 8); break;
+    case 16004: FC_SWEEP(16, 4); break;
+    case 16008: FC_SWEEP(16, 8); break;
+    case 16016: FC_SWEEP(16, 16); break;
+    case 32004: FC_SWEEP(32, 4); break;
+    case 32008: FC_SWEEP(32, 8); break;
+    case 32016: FC_SWEEP(32, 16); break;
+    case 32032: FC_SWEEP(32, 32); break;
+    case 64004: FC_SWEEP(64, 4); break;
+    case 64008: FC_SWEEP(64, 8); break;
+    case 64016: FC_SWEEP(64, 16); break;
+    case 64032: FC_SWEEP(64, 32); break;
+    case 64064: FC_SWEEP(64, 64); break;
+    case 256016: FC_SWEEP(256, 16); break;
+    case 256032: FC_SWEEP(256, 32); break;
+    case 256064: FC_SWEEP(256, 64); break;
+    case 256256: FC_SWEEP(256, 256); break;
+    default: return fail(FC_ERR_INVALID, "launch_sweep: unsupported (lanes, sub) combination");
   }
 #undef FC_SWEEP
   FCCHK(time_end(h));
@@ -370,7 +390,7 @@ int check_step_ready(fc_ctx* h, int order_slot) {
 int enqueue_rhs(fc_ctx* h, int order_slot, const double* d_uctrl) {
   const StepCoeffs c = coeffs_for(h, order_slot);
   OrderSys& S = h->sys[order_slot];
-  hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks(h->nc, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
+  hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks(h->nc, 64)), dim3(64), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
                      h->u_n.p, h->u_nn.p, h->have_force ? h->fprof.p : nullptr, h->have_force ? h->n_act : 0, d_uctrl,
                      c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p);
   hipLaunchKernelGGL(fc_rhs_gather, dim3(nblocks(h->N, 256)), dim3(256), 0, h->stream, h->N, h->gptr_p.p, h->gidx_p.p,
@@ -390,7 +410,8 @@ int enqueue_energy(fc_ctx* h, const double* d_u, double* d_out) {
 }
 
 // enqueue one full step; y -> d_y, E -> d_E; residual norms -> scal[1], scal[2]
-int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, double* d_E, int compute_energy) {
+int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, double* d_E, double* d_r,
+                 double* d_flag_out, int compute_energy) {
   OrderSys& S = h->sys[order_slot];
   if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this order");
   if (compute_energy && !h->have_mp) return fail(FC_ERR_NOT_READY, "fc_set_energy_matrix not called");
@@ -404,8 +425,8 @@ int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, 
                      h->u_nn.p, h->p_n.p, h->flag.p, compute_energy ? h->mp_rowptr.p : nullptr, h->mp_col.p,
                      h->mp_val.p, compute_energy ? e_partial : nullptr);
   hipLaunchKernelGGL(fc_final, dim3(1 + h->n_sens), dim3(256), 0, h->stream, g, compute_energy ? e_partial : nullptr,
-                     d_E, nrp, nrp > 0 ? h->partial.p : nullptr, h->scal.p + 1, h->n_sens, h->s_rowptr.p, h->s_idx.p,
-                     h->s_w.p, h->up.p, d_y);
+                     d_E, nrp, nrp > 0 ? h->partial.p : nullptr, d_r, h->n_sens, h->s_rowptr.p, h->s_idx.p,
+                     h->s_w.p, h->up.p, d_y, h->flag.p, d_flag_out);
   HIPCHK(hipGetLastError());
   return FC_OK;
 }
@@ -459,7 +480,9 @@ int fc_create(fc_handle* out, int device, int32_t nv, int32_t ne, int32_t nc, co
   TRYHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   TRYHIP(hipEventCreate(&h->ev0));
   TRYHIP(hipEventCreate(&h->ev1));
-  TRYHIP(hipHostMalloc((void**)&h->pin, kPinDoubles * sizeof(double), hipHostMallocDefault));
+  TRYHIP(hipHostMalloc((void**)&h->pin, kPinDoubles * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+  TRYHIP(hipHostGetDevicePointer((void**)&h->pin_dev, h->pin, 0));
+  std::memset(h->pin, 0, kPinDoubles * sizeof(double));
   // element tables -> constant memory
   double phi2[42], dphi2[84], phi1[21], qw[7];
   tabulate(phi2, dphi2, phi1, qw);
@@ -871,10 +894,36 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
     }
     const double mean_seg = (q1 > q0) ? (double)nz / (double)(q1 - q0) : 0.0;
     const double mean_row = st.nrows ? (double)nz / st.nrows : 0.0;
-    // lanes per row: enough to cover a typical segment, but keep >= ~2 waves per SIMD of rows in flight
-    int lanes = mean_seg <= 6 ? 4 : mean_seg <= 12 ? 8 : mean_seg <= 24 ? 16 : mean_seg <= 48 ? 32 : 64;
-    if (mean_row > 2048 && lanes < 64) lanes = 64;
+    // geometry of the launch (see fc_nd_sweep): SUB lanes cover one segment with a 4-deep issue,
+    // G = LANES / SUB segments of a row are in flight together
+    auto pow2_ceil = [](double v) { int p = 1; while (p < v) p <<= 1; return p; };
+    auto pow2_floor = [](double v) { int p = 1; while (2 * p <= v) p <<= 1; return p; };
+    const double segs_per_row = st.nrows ? (double)(q1 - q0) / st.nrows : 0.0;
+    int sub, lanes;
+    const bool few_long_rows = (int64_t)st.nrows < 4096 && mean_row >= 1024;
+    if (st.kind == 0) {
+      // up: every segment is a contiguous slice -> run G of them side by side
+      sub = std::min(64, std::max(4, pow2_ceil(mean_seg / 4.0)));
+      const int grp = std::min(16, std::max(1, pow2_floor(segs_per_row)));
+      lanes = sub * grp;
+      if (lanes > 64) {
+        if (few_long_rows) {
+          lanes = 256;  // a whole workgroup per row keeps >= ~4 waves on every SIMD near the root
+          sub = std::max(sub, 16);
+        } else {
+          lanes = 64;
+        }
+      }
+    } else {
+      // down: one contiguous (D^-1) and one indexed (-U) segment per row; running them side by
+      // side would diverge inside the wave, so all lanes of the row walk them one after the other
+      lanes = few_long_rows ? 256 : std::min(64, std::max(8, pow2_ceil(mean_seg / (double)FC_DOWN_DEPTH)));
+      sub = lanes;
+    }
+    if (lanes < 8) lanes = 8;
+    if (sub > lanes) sub = lanes;
     st.lanes = lanes;
+    st.sub = sub;
     // algorithmic bytes: values 8 B, x/y operand 8 B per value is served on-chip (vectors are < 1 MB),
     // segment descriptors 16 B, shared index lists 4 B per indexed value (re-used by the rows of a node:
     // counted once per row as an upper bound), row pointers 8 B, destination 8 B (+8 B read when accumulating)
@@ -889,9 +938,12 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
   FCCHK(S.Ap_col.upload(Ap_col, (size_t)S.Ap_nnz, h->stream));
   FCCHK(S.Ap_val.upload(Ap_val, (size_t)S.Ap_nnz, h->stream));
   FCCHK(S.seg_ptr.upload(seg_ptr, (size_t)total_rows + 1, h->stream));
-  FCCHK(S.seg_val.upload(seg_val, (size_t)std::max<int64_t>(1, n_seg), h->stream));
-  FCCHK(S.seg_col.upload(seg_col, (size_t)std::max<int64_t>(1, n_seg), h->stream));
-  FCCHK(S.seg_len.upload(seg_len, (size_t)std::max<int64_t>(1, n_seg), h->stream));
+  {
+    std::vector<FcSeg> packed((size_t)std::max<int64_t>(1, n_seg));
+    for (int64_t q = 0; q < n_seg; ++q) packed[q] = FcSeg{(long long)seg_val[q], seg_col[q], seg_len[q]};
+    FCCHK(S.seg.upload(packed, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
   if (n_idx > 0) FCCHK(S.f_idx.upload(idx, (size_t)n_idx, h->stream));
   else FCCHK(S.f_idx.alloc(1));
   FCCHK(S.f_val.upload(vals, (size_t)n_val, h->stream));
@@ -964,25 +1016,23 @@ int fc_step(fc_handle h, int order_slot, const double* u_ctrl, double* y_out, do
   FCCHK(check_step_ready(h, order_slot));
   if (h->n_act > 0 && !u_ctrl) return fail(FC_ERR_INVALID, "fc_step: u_ctrl is null");
   HIPCHK(hipSetDevice(h->device));
-  double* pin = h->pin;
+  // zero-copy record in pinned, device-mapped host memory: the kernels read u_ctrl from it and the
+  // last kernel of the step writes (y, dE, |r|^2, |b|^2, flag) into it — no memcpy on the stream.
+  volatile double* pin = h->pin;
   for (int k = 0; k < h->n_act; ++k) pin[k] = u_ctrl[k];
-  if (h->n_act) HIPCHK(hipMemcpyAsync(h->uctrl.p, pin, h->n_act * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  FCCHK(enqueue_step(h, order_slot, h->uctrl.p, h->ydev.p, h->scal.p, compute_energy));
-  double* out = pin + 64;  // [0..63] y, [64..71] scal, [72] flag
-  if (h->n_sens) HIPCHK(hipMemcpyAsync(out, h->ydev.p, h->n_sens * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(out + 64, h->scal.p, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(out + 72, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  double* dev = h->pin_dev;
+  FCCHK(enqueue_step(h, order_slot, dev, dev + 64, dev + 128, dev + 129, dev + 136, compute_energy));
   HIPCHK(hipStreamSynchronize(h->stream));
   FCCHK(time_collect(h));
   for (int s = 0; s < h->n_sens; ++s)
-    if (y_out) y_out[s] = out[s];
-  if (dE_out) *dE_out = compute_energy ? out[64] : std::numeric_limits<double>::quiet_NaN();
-  int flag = 0;
-  std::memcpy(&flag, out + 72, sizeof(int));
+    if (y_out) y_out[s] = pin[64 + s];
+  if (dE_out) *dE_out = compute_energy ? pin[128] : std::numeric_limits<double>::quiet_NaN();
+  const int flag = (int)pin[136];
   if (info_out) {
+    const double r2 = pin[129], b2 = pin[130];
     info_out[0] = h->max_iter;
-    info_out[1] = h->check_residual ? std::sqrt(out[65] / (out[66] > 0 ? out[66] : 1.0)) : std::numeric_limits<double>::quiet_NaN();
-    info_out[2] = h->check_residual ? std::sqrt(out[66]) : std::numeric_limits<double>::quiet_NaN();
+    info_out[1] = h->check_residual ? std::sqrt(r2 / (b2 > 0 ? b2 : 1.0)) : std::numeric_limits<double>::quiet_NaN();
+    info_out[2] = h->check_residual ? std::sqrt(b2) : std::numeric_limits<double>::quiet_NaN();
     info_out[3] = flag;
   }
   if (flag) return fail(FC_ERR_DIVERGED, "non-finite velocity after solve");
@@ -1005,7 +1055,7 @@ int fc_run(fc_handle h, int first_order_slot, int32_t n_steps, const double* u_c
   int order = first_order_slot;
   for (int s = 0; s < n_steps; ++s) {
     const double* du = h->useq.p + (u_ctrl_is_sequence ? (size_t)s * h->n_act : 0);
-    FCCHK(enqueue_step(h, order, du, h->yseq.p + (size_t)s * ns, h->Eseq.p + s, compute_energy));
+    FCCHK(enqueue_step(h, order, du, h->yseq.p + (size_t)s * ns, h->Eseq.p + s, h->scal.p + 1, nullptr, compute_energy));
     order = FC_SLOT_BDF2;
   }
   std::vector<double> yh((size_t)n_steps * ns), Eh(n_steps);
@@ -1152,7 +1202,7 @@ int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double*
                        h->u_nn.p, h->p_n.p, h->flag.p, h->mp_rowptr.p, h->mp_col.p, h->mp_val.p, e_partial);
     hipLaunchKernelGGL(fc_final, dim3(1 + h->n_sens), dim3(256), 0, h->stream, g, e_partial, h->scal.p, nrp,
                        nrp > 0 ? h->partial.p : nullptr, h->scal.p + 1, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p,
-                       h->up.p, h->ydev.p);
+                       h->up.p, h->ydev.p, h->flag.p, (double*)nullptr);
     FCCHK(lap(4));
   }
   HIPCHK(hipStreamSynchronize(h->stream));

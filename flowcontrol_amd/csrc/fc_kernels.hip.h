@@ -311,50 +311,92 @@ __global__ __launch_bounds__(256) void fc_spmv_csr(int nrows, const int* __restr
 // Rows of one level never read what the same launch writes, so a level is one launch.
 // Values stream at 8 B/nnz; column information is O(1/len) bytes per value.
 // ---------------------------------------------------------------------------------------------
-template <int LANES>
+struct __attribute__((aligned(16))) FcSeg {
+  long long val;  // offset of the first value
+  int col;        // >= 0: first buffer index; < 0: -(offset into idx) - 1
+  int len;
+};
+
+// LANES lanes cooperate on one row (8..64: sub-wave groups, RPB rows per 256-thread block; 256: the
+// whole workgroup on one row — few, very long rows near the root).  Inside a row group, sub-groups
+// of SUB lanes each take every (LANES/SUB)-th segment, so several segments of the row are in flight
+// at once: a row is a *chain* of short dense slices and one slice per memory round trip would leave
+// the launch latency-bound (bytes in flight = rows x slice length) far below the HBM rate.
+template <int LANES, int SUB>
 __global__ __launch_bounds__(256) void fc_nd_sweep(int nrows, const int64_t* __restrict__ seg_ptr,
-                                                   const int64_t* __restrict__ seg_val,
-                                                   const int* __restrict__ seg_col,
-                                                   const int* __restrict__ seg_len,
+                                                   const FcSeg* __restrict__ seg,
                                                    const int* __restrict__ idx,
                                                    const double* __restrict__ val,
                                                    double* __restrict__ buf, int dest0, int accumulate) {
   constexpr int RPB = 256 / LANES;
+  constexpr int SW = LANES < 64 ? LANES : 64;  // shuffle width (descriptor broadcast, reduction)
+  constexpr int G = LANES / SUB;               // segments processed concurrently per row
   const int lane = threadIdx.x % LANES;
+  const int sl = threadIdx.x % SW;             // lane inside the shuffle group
+  const int g = lane / SUB;                    // sub-group of this lane
+  const int l2 = lane % SUB;
   const int row = blockIdx.x * RPB + threadIdx.x / LANES;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  if (row < nrows) {
-    const int64_t q0 = seg_ptr[row], q1 = seg_ptr[row + 1];
-    for (int64_t q = q0; q < q1; ++q) {
-      const double* __restrict__ v = val + seg_val[q];
-      const int c = seg_col[q];
-      const int len = seg_len[q];
-      int j = lane;
+  // rows beyond nrows still take part in the shuffles below (q0 == q1: zero trips)
+  const int64_t q0 = row < nrows ? seg_ptr[row] : 0, q1 = row < nrows ? seg_ptr[row + 1] : 0;
+  for (int64_t qb = q0; qb < q1; qb += SW) {
+    // the lanes of a (sub-)wave fetch up to SW segment descriptors with one coalesced 16-B load
+    // each, then broadcast them: no dependent descriptor -> value load chain per segment
+    FcSeg mine = {0, 0, 0};
+    if (qb + sl < q1) mine = seg[qb + sl];
+    const int cnt = (int)((q1 - qb) < SW ? (q1 - qb) : SW);
+    // sub-group g of wave w (LANES = 256: four waves) takes segments g, g + G, ...
+    for (int sbase = 0; sbase < cnt; sbase += G) {
+      const int sidx = sbase + g;
+      const int src = sidx < cnt ? (sidx % SW) : 0;
+      const long long vo = __shfl(mine.val, src, SW);
+      const int c = __shfl(mine.col, src, SW);
+      int len = __shfl(mine.len, src, SW);
+      if (sidx >= cnt) len = 0;  // this sub-group has no segment in the last round
+      const double* __restrict__ v = val + vo;
       if (c >= 0) {
         const double* __restrict__ x = buf + c;
-        for (; j + 3 * LANES < len; j += 4 * LANES) {
-          s0 += v[j] * x[j];
-          s1 += v[j + LANES] * x[j + LANES];
-          s2 += v[j + 2 * LANES] * x[j + 2 * LANES];
-          s3 += v[j + 3 * LANES] * x[j + 3 * LANES];
+        // predicated 4-deep issue: all eight loads of a trip are in flight before the first FMA
+        for (int base = 0; base < len; base += 4 * SUB) {
+          const int j0 = base + l2, j1 = j0 + SUB, j2 = j1 + SUB, j3 = j2 + SUB;
+          const double v0 = j0 < len ? v[j0] : 0.0, v1 = j1 < len ? v[j1] : 0.0;
+          const double v2 = j2 < len ? v[j2] : 0.0, v3 = j3 < len ? v[j3] : 0.0;
+          const double x0 = j0 < len ? x[j0] : 0.0, x1 = j1 < len ? x[j1] : 0.0;
+          const double x2 = j2 < len ? x[j2] : 0.0, x3 = j3 < len ? x[j3] : 0.0;
+          s0 += v0 * x0;
+          s1 += v1 * x1;
+          s2 += v2 * x2;
+          s3 += v3 * x3;
         }
-        for (; j < len; j += LANES) s0 += v[j] * x[j];
       } else {
         const int* __restrict__ ix = idx + (-(c + 1));
-        for (; j + 3 * LANES < len; j += 4 * LANES) {
-          s0 += v[j] * buf[ix[j]];
-          s1 += v[j + LANES] * buf[ix[j + LANES]];
-          s2 += v[j + 2 * LANES] * buf[ix[j + 2 * LANES]];
-          s3 += v[j + 3 * LANES] * buf[ix[j + 3 * LANES]];
+        for (int base = 0; base < len; base += 4 * SUB) {
+          const int j0 = base + l2, j1 = j0 + SUB, j2 = j1 + SUB, j3 = j2 + SUB;
+          const int i0 = j0 < len ? ix[j0] : 0, i1 = j1 < len ? ix[j1] : 0;
+          const int i2 = j2 < len ? ix[j2] : 0, i3 = j3 < len ? ix[j3] : 0;
+          const double v0 = j0 < len ? v[j0] : 0.0, v1 = j1 < len ? v[j1] : 0.0;
+          const double v2 = j2 < len ? v[j2] : 0.0, v3 = j3 < len ? v[j3] : 0.0;
+          s0 += v0 * buf[i0];
+          s1 += v1 * buf[i1];
+          s2 += v2 * buf[i2];
+          s3 += v3 * buf[i3];
         }
-        for (; j < len; j += LANES) s0 += v[j] * buf[ix[j]];
       }
     }
   }
   double s = (s0 + s1) + (s2 + s3);
 #pragma unroll
-  for (int off = LANES / 2; off > 0; off >>= 1) s += __shfl_down(s, off, LANES);
-  if (row < nrows && lane == 0) {
+  for (int off = SW / 2; off > 0; off >>= 1) s += __shfl_down(s, off, SW);
+  if (LANES == 256) {
+    __shared__ double part[4];
+    if (sl == 0) part[threadIdx.x / 64] = s;
+    __syncthreads();
+    if (threadIdx.x == 0 && row < nrows) {
+      const double t = (part[0] + part[1]) + (part[2] + part[3]);
+      const int d = dest0 + row;
+      buf[d] = accumulate ? buf[d] + t : t;
+    }
+  } else if (row < nrows && lane == 0) {
     const int d = dest0 + row;
     buf[d] = accumulate ? buf[d] + s : s;
   }
@@ -439,7 +481,8 @@ __global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restric
                                                 const int* __restrict__ s_rowptr,
                                                 const int* __restrict__ s_idx,
                                                 const double* __restrict__ s_w,
-                                                const double* __restrict__ up, double* __restrict__ y) {
+                                                const double* __restrict__ up, double* __restrict__ y,
+                                                const int* __restrict__ flag, double* __restrict__ flag_out) {
   __shared__ double red[3][256];
   const int t = threadIdx.x;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
@@ -475,6 +518,7 @@ __global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restric
         r_out[0] = red[1][0];
         r_out[1] = red[2][0];
       }
+      if (flag_out) flag_out[0] = (double)flag[0];
     } else if (blockIdx.x - 1 < n_sens) {
       y[blockIdx.x - 1] = red[0][0];
     }
