@@ -1,0 +1,273 @@
+"""CPU tests of the host side: mesh/XDMF/HDF5 reading, Taylor–Hood tables, dolfin boundary
+semantics, sensors, actuators, controller, exporter, parameter validation, ND factorisation.
+Modelled on the reference's unit tests (tests/test_*.py) — same identities, our own objects."""
+import json
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import pytest
+import scipy.signal
+
+from flowcontrol_amd import ndsolver
+from flowcontrol_amd.actuator import ActuatorBCParabolicV, ActuatorBCRotation
+from flowcontrol_amd.controller import Controller
+from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver
+from flowcontrol_amd.fem import element as el
+from flowcontrol_amd.fem.boundary import DOLFIN_EPS, Constant, DirichletBC, SubDomain, between, combine_bcs, near
+from flowcontrol_amd.fem.mesh import Mesh, read_xdmf_mesh
+from flowcontrol_amd.fem.spaces import Function, TaylorHood
+from flowcontrol_amd.flowsolverparameters import ParamIC, ParamTime
+from flowcontrol_amd.sensor import SENSOR_TYPE, SensorHorizontalWallShear, SensorPoint
+from oracle import ns_oracle as O
+
+REF = Path("/root/reference/src/examples")
+
+
+# ── mesh / readers ───────────────────────────────────────────────────────────────────────────
+@pytest.mark.skipif(not REF.exists(), reason="reference data files are only mounted in the build container")
+@pytest.mark.parametrize("rel,name", [("cylinder/data_input/O1.xdmf", "O1"), ("cavity/data_input/cavity_fine.xdmf", "cavity_fine"),
+                                      ("pinball/data_input/mesh_middle_gmsh.xdmf", "mesh_middle_gmsh")])
+def test_xdmf_hdf5_reader_matches_fixture(rel, name, golden_dir):
+    """Chunked+deflate, int64/int32 topology and big-endian f8 geometry (cavity_fine) all decode."""
+    a = read_xdmf_mesh(REF / rel)
+    b = read_xdmf_mesh(golden_dir / "meshes" / f"{name}.npz")
+    assert np.array_equal(a.coords, b.coords) and np.array_equal(a.cells, b.cells)
+
+
+@pytest.mark.skipif(not REF.exists(), reason="reference data files are only mounted in the build container")
+def test_dolfin_layout_hdf5_contiguous():
+    m = read_xdmf_mesh(REF / "lidcavity/data_input/mesh64.xdmf")
+    assert m.num_cells > 0 and np.isclose(m.coords.min(), 0.0) and np.isclose(m.coords.max(), 1.0)
+
+
+def test_o1_sizes_match_survey(golden_dir):
+    m = read_xdmf_mesh(golden_dir / "meshes" / "O1.npz")
+    th = TaylorHood(m)
+    assert (m.num_vertices, m.num_cells, m.num_edges, len(m.boundary_edges())) == (6327, 12284, 18611, 370)
+    assert (2 * th.nn, th.nv, th.N) == (49876, 6327, 56203)
+    assert np.all(th.detJ > 0)
+    assert np.isclose(0.5 * th.detJ.sum(), 30 * 20 - np.pi * 0.25, rtol=1e-3)  # domain area minus the cylinder
+
+
+def test_numbering_is_orientation_and_order_independent():
+    m1 = Mesh.unit_square(5, 4)
+    perm = np.random.default_rng(0).permutation(m1.num_cells)
+    flipped = m1.cells[perm][:, [0, 2, 1]]
+    m2 = Mesh.from_arrays(m1.coords, flipped)
+    a = np.sort(np.sort(m1.coords[m1.cells].reshape(-1, 6), axis=1), axis=0)
+    b = np.sort(np.sort(m2.coords[m2.cells].reshape(-1, 6), axis=1), axis=0)
+    assert np.allclose(a, b)
+
+
+def test_refine_quadruples_cells():
+    m = Mesh.unit_square(3, 3)
+    r = m.refine()
+    assert r.num_cells == 4 * m.num_cells and r.num_vertices == m.num_vertices + m.num_edges
+    assert np.isclose(TaylorHood(r).detJ.sum(), TaylorHood(m).detJ.sum())
+
+
+# ── element tables ───────────────────────────────────────────────────────────────────────────
+def test_quadrature_is_exact_to_degree_5():
+    # ∫_T λ0^a λ1^b λ2^c = a! b! c! 2! / (a+b+c+2)!  (area 1/2 → weights sum to 1 times 1/2)
+    from math import factorial as f
+
+    for a in range(6):
+        for b in range(6 - a):
+            for c in range(6 - a - b):
+                exact = f(a) * f(b) * f(c) * 2.0 / f(a + b + c + 2)
+                got = (el.QUAD_W * el.QUAD_BARY[:, 0] ** a * el.QUAD_BARY[:, 1] ** b * el.QUAD_BARY[:, 2] ** c).sum()
+                assert np.isclose(got, exact, rtol=1e-13, atol=1e-16)
+
+
+def test_p2_basis_is_nodal_and_partition_of_unity():
+    assert np.allclose(el.p2_basis(el.P2_NODES_BARY), np.eye(6))
+    lam = np.random.default_rng(1).dirichlet(np.ones(3), 10)
+    assert np.allclose(el.p2_basis(lam).sum(axis=1), 1.0)
+    assert np.allclose(el.p2_grad_ref(lam).sum(axis=1), 0.0)
+
+
+# ── boundary semantics ───────────────────────────────────────────────────────────────────────
+def test_cylinder_boundary_counts_match_survey():
+    """inlet 20 facets/41 nodes, outlet 20/41, walls 60/122, cylinder 252/506, slots 9/19."""
+    fs = CylinderFlowSolver.make_default(path_out=tempfile.mkdtemp())
+    want = {"inlet": (20, 41), "outlet": (20, 41), "walls": (60, 122), "cylinder": (252, 506), "actuator_up": (9, 19), "actuator_lo": (9, 19)}
+    for name, (nf, nn) in want.items():
+        bc = DirichletBC(fs.W.sub(0), Constant((0, 0)), fs.get_subdomain(name))
+        assert (len(bc.facets), len(bc.nodes)) == (nf, nn), name
+    dofs, prof = fs._bc_tables()
+    assert len(dofs) == 1282 and prof.shape == (1282, 2)
+    # later BCs overwrite earlier ones on shared dofs: the slot end points carry the actuator profile (0 there)
+    assert np.all(prof[:, 0] * prof[:, 1] == 0)
+
+
+def test_facet_needs_vertices_and_midpoint_inside():
+    m = Mesh.unit_square(4, 4)
+    left_half = SubDomain(lambda x, ob: ob & near(x[:, 0], 0.0, DOLFIN_EPS) & (x[:, 1] <= 0.3))
+    marked = np.nonzero(left_half.mark_facets(m))[0]
+    assert len(marked) == 1  # only [0, 0.25]; the facet [0.25, 0.5] has a vertex outside
+    assert between(np.array([0.5]), 0.5, 1.0)[0] and not between(np.array([0.5 - 1e-3]), 0.5, 1.0)[0]
+
+
+def test_subspace_bc_constrains_one_component():
+    th = TaylorHood(Mesh.unit_square(3, 3))
+    top = SubDomain(lambda x, ob: ob & near(x[:, 1], 1.0, DOLFIN_EPS))
+    bc_v = DirichletBC(th.W.sub(0).sub(1), Constant(0), top)
+    bc_uv = DirichletBC(th.W.sub(0), Constant((1.0, 2.0)), top)
+    assert np.all((bc_v.dofs >= th.nn) & (bc_v.dofs < 2 * th.nn)) and len(bc_uv.dofs) == 2 * len(bc_v.dofs)
+    dofs, vals = combine_bcs([bc_uv, bc_v], th.N)
+    assert set(vals) == {0.0, 1.0}  # v overwritten by the later BC, u kept
+
+
+# ── sensors / actuators ──────────────────────────────────────────────────────────────────────
+def test_point_sensor_row_equals_eval():
+    fs = CylinderFlowSolver.make_default(path_out=tempfile.mkdtemp())
+    up = Function(fs.W, np.random.default_rng(0).standard_normal(fs.th.N))
+    for s in fs.params_control.sensor_list:
+        idx, w = s.row(fs)
+        assert np.isclose(w @ up.vector().array()[idx], s.eval(up), rtol=1e-12)
+    lin = Function(fs.W)
+    lin.interpolate(lambda x: np.stack([2 * x[:, 0], 3 * x[:, 1] - x[:, 0], x[:, 0] + x[:, 1]], axis=1))
+    assert np.allclose(lin((3.1, 1.0)), [6.2, -0.1, 4.1])
+    with pytest.raises(RuntimeError):
+        lin((100.0, 0.0))
+
+
+def test_wall_shear_sensor_is_exact_for_linear_shear():
+    class Dummy:
+        pass
+
+    th = TaylorHood(Mesh.unit_square(8, 8))
+    fs = Dummy()
+    fs.th = th
+    s = SensorHorizontalWallShear(sensor_type=SENSOR_TYPE.OTHER, x_sensor_left=0.25, x_sensor_right=0.75, y_sensor=0.0)
+    s.load(fs)
+    up = Function(th.W)
+    up.interpolate(lambda x: np.stack([3.0 * x[:, 1] + x[:, 1] ** 2, 0 * x[:, 0], 0 * x[:, 0]], axis=1))
+    assert len(s.ds) == 4  # whole facets inside [0.25, 0.75]
+    assert np.isclose(s.eval(up), 3.0 * 0.5, rtol=1e-12)  # ∂u_x/∂y = 3 + 2y = 3 on y = 0
+
+
+def test_actuator_profiles():
+    a = ActuatorBCParabolicV(width=0.2, position_x=1.0)
+    e = a._load_expression(None, None)
+    e.u_ctrl = 2.0
+    x = np.array([[1.0, 0.0], [1.1, 0.0], [1.2, 0.0], [0.7, 0.0]])
+    assert np.allclose(e(x), [[0, 2.0], [0, 1.5], [0, 0], [0, 0]])
+    assert np.isclose(ActuatorBCParabolicV.angular_size_deg_to_width(10, 0.5), 0.5 * np.sin(np.deg2rad(5)))
+    r = ActuatorBCRotation(diameter=1.0)._load_expression(None, None)
+    r.u_ctrl = 1.0
+    assert np.allclose(r(np.array([[0.5, 0.0], [0.0, 0.5]])), [[0, 0.5], [-0.5, 0]])
+
+
+# ── controller ───────────────────────────────────────────────────────────────────────────────
+def test_controller_zoh_matches_scipy_and_forced_response():
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((4, 4)) - 2 * np.eye(4)
+    B, C, D = rng.standard_normal((4, 2)), rng.standard_normal((3, 4)), rng.standard_normal((3, 2))
+    K = Controller(A, B, C, D)
+    dt = 0.01
+    Ad, Bd, Cd, Dd, _ = scipy.signal.cont2discrete((A, B, C, D), dt, method="zoh")
+    x = np.zeros(4)
+    for k in range(20):
+        y = np.array([np.sin(0.3 * k), np.cos(0.2 * k)])
+        u = K.step(y, dt)
+        assert np.allclose(u, Cd @ x + Dd @ y)
+        x = Ad @ x + Bd @ y
+    assert np.allclose(K.x, x)
+    K.reset()
+    assert np.all(K.x == 0)
+
+
+def test_controller_from_file_and_algebra(golden_dir):
+    K = Controller.from_file(golden_dir / "controllers" / "Kopt_reduced13.mat")
+    assert (K.nstates, K.ninputs, K.noutputs) == (13, 1, 1) and K.file is not None
+    assert np.max(np.linalg.eigvals(K.A).real) < 0
+    G = Controller(-np.eye(2), np.ones((2, 1)), np.ones((1, 2)), np.array([[2.0]]))
+    s = 0.3j
+    tf = lambda S: S.C @ np.linalg.solve(s * np.eye(S.nstates) - S.A, S.B) + S.D  # noqa: E731
+    assert np.allclose(tf(G + G), 2 * tf(G)) and np.allclose(tf(G * G), tf(G) @ tf(G))
+    assert np.allclose(tf(G.inv()), np.linalg.inv(tf(G)))
+    assert (G * G).x.shape == (4,)
+
+
+# ── exporter / parameters ────────────────────────────────────────────────────────────────────
+def test_exporter_schema_and_sidecar(tmp_path):
+    fs = CylinderFlowSolver.make_default(path_out=tmp_path, save_every=5, num_steps=10)
+    ex = fs.exporter
+    ex.log_ic(t=0.0, y_meas=[1.0, 2.0, 3.0], dE=0.5)
+    ex.log(u_ctrl=[0.1, 0.2], y_meas=[4.0, 5.0, 6.0], dE=0.6, t=0.005, runtime=1e-3)
+    df = ex.to_dataframe()
+    assert list(df.columns) == ["time", "dE", "runtime", "y_meas_1", "y_meas_2", "y_meas_3", "u_ctrl_1", "u_ctrl_2"]
+    assert np.isnan(df.loc[0, "u_ctrl_1"]) and df.loc[1, "u_ctrl_2"] == 0.2
+    ex.write_timeseries()
+    assert fs.paths.timeseries.name == "timeseries1D_restart0,000.csv" and fs.paths.timeseries.exists()
+    ex.write_metadata(restart_order=2)
+    meta = json.loads(fs.paths.metadata.read_text())
+    assert set(meta) == {"Tstart", "dt", "save_every", "checkpoints_written", "restart_order", "files"}
+    assert meta["files"]["U"] == "U_restart0,000.xdmf"
+
+
+def test_parameter_validation(tmp_path):
+    with pytest.raises(ValueError):
+        fs = CylinderFlowSolver.make_default(path_out=tmp_path)
+        fs._validate_params(fs.params_flow, ParamTime(num_steps=1, dt=-1.0, Tstart=0.0), fs.params_save, fs.params_solver, fs.params_mesh, fs.params_control, fs.params_ic)
+    with pytest.raises(FileNotFoundError):
+        CylinderFlowSolver.make_default(path_out=tmp_path, meshpath=tmp_path / "nope.xdmf")
+    assert ParamTime(num_steps=10, dt=0.5, Tstart=1.0).Tfinal == 5.0
+    assert ParamIC().amplitude == 1.0
+
+
+def test_default_ic_is_divergence_free():
+    """‖P1-projection of div u‖_L2 < 1e-2 for the interpolated Gaussian vortex on 32×32
+    (the reference's tests/test_physics.py:31-46, same mesh, centre and size)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    th = TaylorHood(Mesh.unit_square(32, 32))
+    d = O.Disc.from_taylor_hood(th)
+    u = O.div0_gaussian_nodal(th.node_coords, 0.5, 0.5, 0.1)
+    assert np.abs(u).max() > 0.1
+    _, grad = d.vel_at_q(np.r_[u[:, 0], u[:, 1]])
+    div = grad[:, :, 0, 0] + grad[:, :, 1, 1]
+    P1 = el.PHI1
+    Me = np.einsum("cq,qm,qn->cmn", d.w, P1, P1)
+    rows = np.repeat(d.cells, 3, axis=1).reshape(-1)
+    cols = np.tile(d.cells, (1, 3)).reshape(-1)
+    Mp = sp.coo_matrix((Me.reshape(-1), (rows, cols)), shape=(th.nv, th.nv)).tocsc()
+    rhs = np.zeros(th.nv)
+    np.add.at(rhs, d.cells.reshape(-1), np.einsum("cq,qm,cq->cm", d.w, P1, div).reshape(-1))
+    proj = spla.spsolve(Mp, rhs)
+    assert np.sqrt(proj @ (Mp @ proj)) < 1e-2
+
+
+# ── nested-dissection selected inverse (host numerics of the device solver) ─────────────────
+@pytest.mark.parametrize("depth,merge", [(3, 1), (4, 2), (6, 3)])
+def test_nd_block_factors_solve_saddle_point_system(depth, merge):
+    th = TaylorHood(Mesh.unit_square(10, 10))
+    d = O.Disc.from_taylor_hood(th)
+    x = th.node_coords
+    U = np.r_[1 + 0.3 * np.sin(x[:, 0]), 0.2 * np.cos(x[:, 1])]
+    m = th.mesh
+    be = m.boundary_edges()
+    be = be[m.edge_midpoints()[be, 0] < 1 - 1e-9]
+    nodes = np.unique(np.r_[m.edges[be].reshape(-1), th.nv + be])
+    dofs = np.sort(np.r_[nodes, nodes + th.nn])
+    A, _ = O.apply_bc_symmetric(O.assemble_matrix(d, mass=300.0, nu=0.01, adv=U, lin=U), None, dofs, np.zeros(len(dofs)))
+    skip = np.zeros(th.N, bool)
+    skip[dofs] = True
+    tree = ndsolver.build_tree(th.cell_dofs, m.cell_centroids(), th.N, depth, skip, merge=merge)
+    assert sorted(tree.perm) == list(range(th.N))
+    b = np.random.default_rng(0).standard_normal(th.N)
+    fb = ndsolver.factorize_blocks(A, tree)
+    xb = fb.solve(b)
+    assert np.linalg.norm(A @ xb - b) / np.linalg.norm(b) < 1e-12
+    fc = ndsolver.factorize(A, tree)
+    assert fc.nnz == fb.nnz and np.allclose(fc.solve(b), xb, rtol=1e-12, atol=1e-14)
+    # every stage only reads what earlier stages (or the other half of the buffer) produced
+    for s in range(len(fb.stage_kind)):
+        r0, nr = int(fb.stage_row0[s]), int(fb.stage_nrows[s])
+        q0, q1 = int(fb.seg_ptr[fb.stage_begin[s]]), int(fb.seg_ptr[fb.stage_begin[s] + nr])
+        cols = fb.seg_col[q0:q1]
+        if fb.stage_kind[s] == 0:
+            assert np.all(cols >= 0) and np.all(cols + fb.seg_len[q0:q1] <= r0)  # deeper levels come first
