@@ -161,9 +161,15 @@ class ActuatorForceGaussianV(Actuator):
         return expr
 
     def load_expression(self, flowsolver: "FlowSolver") -> ActuatorExpression:
+        """Build the (un-normalised) expression; η is fixed by :meth:`normalise` the first time the
+        solver needs the force (the norm is evaluated with the device mass matrix, and building a
+        FlowSolver must not require a GPU)."""
         expr = super().load_expression(flowsolver)
-        nodal = expr.profile(flowsolver.th.node_coords)
-        norm = flowsolver._velocity_l2_norm(np.r_[nodal[:, 0], nodal[:, 1]])
-        expr.eta = 1.0 / norm
+        expr.eta = 1.0
         expr.u_ctrl = 0.0
+        self._normalised = False
         return expr
+
+    def normalise(self, l2_norm_of_unit_profile: float) -> None:
+        self.expression.eta = 1.0 / l2_norm_of_unit_profile
+        self._normalised = True

@@ -7,6 +7,7 @@
 // (y, dE, info) to pinned memory.
 #include "../../include/fc_hip.h"
 
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -94,6 +95,7 @@ struct OrderSys {
   int64_t f_nnz = 0;
   std::vector<Stage> stages;
   double sweep_bytes = 0.0;
+  int ar_stage = -1, ar_row0 = 0, ar_n = 0;  // all-reduce buf[ar_row0 .. +ar_n) after this stage
 };
 
 constexpr int kPinDoubles = 4096;
@@ -153,6 +155,16 @@ struct fc_ctx {
   double* pin_dev = nullptr;  // device address of the same memory
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int nblk_N = 0;
+  // multi-GPU partition (fc_set_partition / fc_comm_init): this rank's cells and rows
+  bool partitioned = false, lead = true;
+  int ncl = 0;
+  std::vector<int> h_cell_list;
+  std::vector<unsigned char> h_rowkind;  // original numbering: 0 other rank, 1 owned, 2 shared root
+  DevBuf<int> cell_list;
+  DevBuf<unsigned char> rowkind_p;  // permuted numbering
+  void* comm = nullptr;             // ncclComm_t
+  int nranks = 1, rank = 0;
+  DevBuf<double> tail;  // [y(64) | E | r2 | b2 | .. | flag@72] partial sums of a step, all-reduced
   // per-launch HIP-event timing (fc_set_timing): pairs recorded around every sweep / SpMV launch
   bool timing = false;
   std::vector<hipEvent_t> tev;   // pool, 2 per launch
@@ -163,6 +175,51 @@ struct fc_ctx {
 };
 
 namespace {
+
+// RCCL is resolved at run time (dlopen): single-GPU use has no dependency on it, and inside a
+// torch process the copy torch already loaded is reused.
+struct FcNcclId {
+  char internal[128];
+};
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(FcNcclId*) = nullptr;
+  int (*CommInitRank)(void**, int, FcNcclId, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load() {
+  if (g_rccl.lib) return FC_OK;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  void* lib = nullptr;
+  for (const char* n : names) {
+    lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (lib) break;
+  }
+  if (!lib) return fail(FC_ERR_HIP, std::string("cannot load RCCL: ") + dlerror());
+  g_rccl.GetUniqueId = (int (*)(FcNcclId*))dlsym(lib, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (int (*)(void**, int, FcNcclId, int))dlsym(lib, "ncclCommInitRank");
+  g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclAllReduce");
+  g_rccl.CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+  g_rccl.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+    return fail(FC_ERR_HIP, "RCCL symbols missing");
+  g_rccl.lib = lib;
+  return FC_OK;
+}
+
+#define NCCLCHK(expr)                                                                             \
+  do {                                                                                            \
+    int _r = (expr);                                                                              \
+    if (_r != 0)                                                                                  \
+      return fail(FC_ERR_HIP, std::string(#expr) + ": " +                                         \
+                                  (g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "rccl error")); \
+  } while (0)
+
+constexpr int kNcclDouble = 8, kNcclSum = 0;
 
 void tabulate(double* phi2, double* dphi2, double* phi1, double* qw) {
   const double s15 = std::sqrt(15.0);
@@ -234,17 +291,17 @@ int time_collect(fc_ctx* h) {
 
 template <int MODE>
 int launch_spmv(fc_ctx* h, int nrows, double mean, const int* rp, const int* col, const double* val, const double* x,
-                const double* b, double* y, double* xsave, double* partial) {
+                const double* b, double* y, double* xsave, double* partial, const unsigned char* rowmask = nullptr) {
   const int lanes = pick_lanes(mean);
   const int rpb = 256 / lanes;
   dim3 grid(nblocks(nrows, rpb)), block(256);
   FCCHK(time_begin(h, 1));
   switch (lanes) {
-    case 4: hipLaunchKernelGGL((fc_spmv_csr<4, MODE>), grid, block, 0, h->stream, nrows, rp, col, val, x, b, y, xsave, partial); break;
-    case 8: hipLaunchKernelGGL((fc_spmv_csr<8, MODE>), grid, block, 0, h->stream, nrows, rp, col, val, x, b, y, xsave, partial); break;
-    case 16: hipLaunchKernelGGL((fc_spmv_csr<16, MODE>), grid, block, 0, h->stream, nrows, rp, col, val, x, b, y, xsave, partial); break;
-    case 32: hipLaunchKernelGGL((fc_spmv_csr<32, MODE>), grid, block, 0, h->stream, nrows, rp, col, val, x, b, y, xsave, partial); break;
-    default: hipLaunchKernelGGL((fc_spmv_csr<64, MODE>), grid, block, 0, h->stream, nrows, rp, col, val, x, b, y, xsave, partial); break;
+    case 4: hipLaunchKernelGGL((fc_spmv_csr<4, MODE>), grid, block, 0, h->stream, nrows, rp, col, val, x, b, y, xsave, partial, rowmask); break;
+    case 8: hipLaunchKernelGGL((fc_spmv_csr<8, MODE>), grid, block, 0, h->stream, nrows, rp, col, val, x, b, y, xsave, partial, rowmask); break;
+    case 16: hipLaunchKernelGGL((fc_spmv_csr<16, MODE>), grid, block, 0, h->stream, nrows, rp, col, val, x, b, y, xsave, partial, rowmask); break;
+    case 32: hipLaunchKernelGGL((fc_spmv_csr<32, MODE>), grid, block, 0, h->stream, nrows, rp, col, val, x, b, y, xsave, partial, rowmask); break;
+    default: hipLaunchKernelGGL((fc_spmv_csr<64, MODE>), grid, block, 0, h->stream, nrows, rp, col, val, x, b, y, xsave, partial, rowmask); break;
   }
   FCCHK(time_end(h));
   HIPCHK(hipGetLastError());
@@ -292,8 +349,16 @@ int launch_sweep(fc_ctx* h, const OrderSys& S, const Stage& st) {
 
 // x_p (in buf[N..2N)) = M^-1 rhs_p, rhs_p must already be in buf[0..N)
 int apply_factors(fc_ctx* h, const OrderSys& S) {
-  for (const Stage& st : S.stages)
+  for (size_t i = 0; i < S.stages.size(); ++i) {
+    const Stage& st = S.stages[i];
     if (st.nrows > 0) FCCHK(launch_sweep(h, S, st));
+    if ((int)i == S.ar_stage && h->comm && S.ar_n > 0) {
+      // multi-GPU: the root separator's right-hand side is the sum of every rank's element and
+      // sub-tree contributions — the one exchange step of a solve (RCCL all-reduce over xGMI)
+      double* p = h->buf.p + S.ar_row0;
+      NCCLCHK(g_rccl.AllReduce(p, p, (size_t)S.ar_n, kNcclDouble, kNcclSum, h->comm, h->stream));
+    }
+  }
   return FC_OK;
 }
 
@@ -310,10 +375,11 @@ int solve_permuted(fc_ctx* h, OrderSys& S, const double** x_out, const double** 
   const double mean = (double)S.Ap_nnz / std::max(1, N);
   *n_rpartial = 0;
   const int iters = h->max_iter;
+  if (h->partitioned && iters > 0) return fail(FC_ERR_INVALID, "iterative refinement is not available on a partitioned (multi-GPU) handle");
   if (iters == 0 && h->check_residual) {
-    // monitor only: r0 -> tmpN (x stays in the x-half of buf)
+    // monitor only: r0 -> tmpN (x stays in the x-half of buf); partitioned: owned rows only
     const int nb = launch_spmv<1>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, x, h->b.p, h->tmpN.p, nullptr,
-                                  h->partial.p);
+                                  h->partial.p, h->partitioned ? h->rowkind_p.p : nullptr);
     if (nb < 0) return nb;
     *n_rpartial = nb;
   }
@@ -356,6 +422,11 @@ int refresh_permuted(fc_ctx* h) {
   for (int k = 0; k < h->n_bc; ++k) slot_of[h->h_bc_dofs[k]] = k;
   for (int i = 0; i < N; ++i) bs[i] = slot_of[h->h_perm[i]];
   FCCHK(h->bcslot_p.upload(bs, h->stream));
+  if (h->partitioned) {
+    std::vector<unsigned char> rk(N);
+    for (int i = 0; i < N; ++i) rk[i] = h->h_rowkind[h->h_perm[i]];
+    FCCHK(h->rowkind_p.upload(rk.data(), rk.size(), h->stream));
+  }
   for (int o = 0; o < 2; ++o) {
     OrderSys& S = h->sys[o];
     if (!S.have_lift) continue;
@@ -390,11 +461,14 @@ int check_step_ready(fc_ctx* h, int order_slot) {
 int enqueue_rhs(fc_ctx* h, int order_slot, const double* d_uctrl) {
   const StepCoeffs c = coeffs_for(h, order_slot);
   OrderSys& S = h->sys[order_slot];
-  hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks(h->nc, 64)), dim3(64), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
-                     h->u_n.p, h->u_nn.p, h->have_force ? h->fprof.p : nullptr, h->have_force ? h->n_act : 0, d_uctrl,
-                     c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p);
+  const int ncl = h->partitioned ? h->ncl : h->nc;
+  if (ncl > 0)
+    hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks(ncl, 64)), dim3(64), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
+                       h->u_n.p, h->u_nn.p, h->have_force ? h->fprof.p : nullptr, h->have_force ? h->n_act : 0, d_uctrl,
+                       c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p, h->partitioned ? h->cell_list.p : nullptr, ncl);
   hipLaunchKernelGGL(fc_rhs_gather, dim3(nblocks(h->N, 256)), dim3(256), 0, h->stream, h->N, h->gptr_p.p, h->gidx_p.p,
-                     h->ev.p, h->bcslot_p.p, h->bcprof.p, S.lift_p.p, h->n_act, d_uctrl, h->b.p, h->buf.p);
+                     h->ev.p, h->bcslot_p.p, h->bcprof.p, S.lift_p.p, h->n_act, d_uctrl, h->b.p, h->buf.p,
+                     h->partitioned ? h->rowkind_p.p : nullptr, h->lead ? 1 : 0);
   HIPCHK(hipGetLastError());
   return FC_OK;
 }
@@ -414,19 +488,39 @@ int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, 
                  double* d_flag_out, int compute_energy) {
   OrderSys& S = h->sys[order_slot];
   if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this order");
-  if (compute_energy && !h->have_mp) return fail(FC_ERR_NOT_READY, "fc_set_energy_matrix not called");
+  if (compute_energy && !h->partitioned && !h->have_mp) return fail(FC_ERR_NOT_READY, "fc_set_energy_matrix not called");
   FCCHK(enqueue_rhs(h, order_slot, d_uctrl));
   const double *x = nullptr, *dx = nullptr;
   int nrp = 0;
   FCCHK(solve_permuted(h, S, &x, &dx, &nrp));
   const int g = nblocks(h->N, 256);
   double* e_partial = h->partial.p + 2 * (size_t)h->nblk_N;  // energy partials live after the residual ones
-  hipLaunchKernelGGL(fc_finish, dim3(g), dim3(256), 0, h->stream, h->N, 2 * h->nn, h->perm.p, x, dx, h->up.p, h->u_n.p,
-                     h->u_nn.p, h->p_n.p, h->flag.p, compute_energy ? h->mp_rowptr.p : nullptr, h->mp_col.p,
-                     h->mp_val.p, compute_energy ? e_partial : nullptr);
-  hipLaunchKernelGGL(fc_final, dim3(1 + h->n_sens), dim3(256), 0, h->stream, g, compute_energy ? e_partial : nullptr,
-                     d_E, nrp, nrp > 0 ? h->partial.p : nullptr, d_r, h->n_sens, h->s_rowptr.p, h->s_idx.p,
-                     h->s_w.p, h->up.p, d_y, h->flag.p, d_flag_out);
+  if (!h->partitioned) {
+    hipLaunchKernelGGL(fc_finish, dim3(g), dim3(256), 0, h->stream, h->N, 2 * h->nn, h->perm.p, x, dx, h->up.p, h->u_n.p,
+                       h->u_nn.p, h->p_n.p, h->flag.p, compute_energy ? h->mp_rowptr.p : nullptr, h->mp_col.p,
+                       h->mp_val.p, compute_energy ? e_partial : nullptr, (const unsigned char*)nullptr);
+    hipLaunchKernelGGL(fc_final, dim3(1 + h->n_sens), dim3(256), 0, h->stream, g, compute_energy ? e_partial : nullptr,
+                       d_E, nrp, nrp > 0 ? h->partial.p : nullptr, d_r, h->n_sens, h->s_rowptr.p, h->s_idx.p,
+                       h->s_w.p, h->up.p, d_y, h->flag.p, d_flag_out);
+  } else {
+    // partitioned: scatter owned + root rows, energy from this rank's cells, sensor rows restricted to
+    // owned dofs; the partial tail is summed over the ranks with one small all-reduce
+    hipLaunchKernelGGL(fc_finish, dim3(g), dim3(256), 0, h->stream, h->N, 2 * h->nn, h->perm.p, x, dx, h->up.p, h->u_n.p,
+                       h->u_nn.p, h->p_n.p, h->flag.p, (const int*)nullptr, (const int*)nullptr, (const double*)nullptr,
+                       (double*)nullptr, h->rowkind_p.p);
+    int ne = 0;
+    if (compute_energy && h->ncl > 0) {
+      ne = nblocks(h->ncl, 256);
+      hipLaunchKernelGGL(fc_energy_elem, dim3(ne), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p, h->u_n.p,
+                         h->cell_list.p, h->ncl, e_partial);
+    }
+    HIPCHK(hipMemsetAsync(h->tail.p, 0, 128 * sizeof(double), h->stream));
+    hipLaunchKernelGGL(fc_final, dim3(1 + h->n_sens), dim3(256), 0, h->stream, ne, ne > 0 ? e_partial : nullptr,
+                       h->tail.p + 64, nrp, nrp > 0 ? h->partial.p : nullptr, h->tail.p + 65, h->n_sens, h->s_rowptr.p,
+                       h->s_idx.p, h->s_w.p, h->up.p, h->tail.p, h->flag.p, h->tail.p + 72);
+    if (h->comm) NCCLCHK(g_rccl.AllReduce(h->tail.p, h->tail.p, 80, kNcclDouble, kNcclSum, h->comm, h->stream));
+    hipLaunchKernelGGL(fc_publish_tail, dim3(1), dim3(64), 0, h->stream, h->tail.p, d_y, h->n_sens, d_E, d_r, d_flag_out);
+  }
   HIPCHK(hipGetLastError());
   return FC_OK;
 }
@@ -615,6 +709,8 @@ int fc_create(fc_handle* out, int device, int32_t nv, int32_t ne, int32_t nc, co
   TRY(h->uctrl.alloc(64));
   TRY(h->uctrl.zero(h->stream));
   TRY(h->ydev.alloc(64));
+  TRY(h->tail.alloc(128));
+  TRY(h->tail.zero(h->stream));
   TRYHIP(hipStreamSynchronize(h->stream));
 #undef TRY
 #undef TRYHIP
@@ -626,6 +722,7 @@ int fc_destroy(fc_handle h) {
   if (!h) return FC_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
   if (h->pin) (void)hipHostFree(h->pin);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -845,7 +942,8 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
                     int32_t n_stages, const int64_t* stage_begin, const int32_t* stage_row0,
                     const int32_t* stage_nrows, const int32_t* stage_kind, const int64_t* seg_ptr, int64_t n_seg,
                     const int64_t* seg_val, const int32_t* seg_col, const int32_t* seg_len, int64_t n_idx,
-                    const int32_t* idx, int64_t n_val, const double* vals) {
+                    const int32_t* idx, int64_t n_val, const double* vals, int32_t ar_stage, int32_t ar_row0,
+                    int32_t ar_n) {
   if (!h || slot < 0 || slot > 1 || !Ap_rowptr || !Ap_col || !Ap_val || n_stages <= 0 || !stage_begin || !stage_row0 ||
       !stage_nrows || !stage_kind || !seg_ptr || !seg_val || !seg_col || !seg_len || !vals || n_seg < 0 || n_idx < 0 ||
       n_val <= 0 || (n_idx > 0 && !idx))
@@ -933,6 +1031,11 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
     S.stages.push_back(st);
     total_rows += st.nrows;
   }
+  if (ar_stage >= n_stages || ar_row0 < 0 || ar_n < 0 || (int64_t)ar_row0 + ar_n > N)
+    return fail(FC_ERR_INVALID, "fc_solver_setup: bad all-reduce range");
+  S.ar_stage = ar_stage;
+  S.ar_row0 = ar_row0;
+  S.ar_n = ar_n;
   S.f_nnz = n_val;
   FCCHK(S.Ap_rowptr.upload(Ap_rowptr, N + 1, h->stream));
   FCCHK(S.Ap_col.upload(Ap_col, (size_t)S.Ap_nnz, h->stream));
@@ -1147,6 +1250,7 @@ int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double*
   OrderSys& S = h->sys[order_slot];
   if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this order");
   if (!h->have_mp) return fail(FC_ERR_NOT_READY, "fc_set_energy_matrix not called");
+  if (h->partitioned) return fail(FC_ERR_INVALID, "fc_profile_steps: single-GPU handles only");
   HIPCHK(hipSetDevice(h->device));
   if (h->n_act) HIPCHK(hipMemcpyAsync(h->uctrl.p, u_ctrl, h->n_act * sizeof(double), hipMemcpyHostToDevice, h->stream));
   const int N = h->N, g = nblocks(N, 256);
@@ -1169,10 +1273,11 @@ int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double*
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks(h->nc, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
                        h->u_n.p, h->u_nn.p, h->have_force ? h->fprof.p : nullptr, h->have_force ? h->n_act : 0,
-                       h->uctrl.p, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p);
+                       h->uctrl.p, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p, (const int*)nullptr, h->nc);
     FCCHK(lap(0));
     hipLaunchKernelGGL(fc_rhs_gather, dim3(g), dim3(256), 0, h->stream, N, h->gptr_p.p, h->gidx_p.p, h->ev.p,
-                       h->bcslot_p.p, h->bcprof.p, S.lift_p.p, h->n_act, h->uctrl.p, h->b.p, h->buf.p);
+                       h->bcslot_p.p, h->bcprof.p, S.lift_p.p, h->n_act, h->uctrl.p, h->b.p, h->buf.p,
+                       (const unsigned char*)nullptr, 1);
     FCCHK(lap(1));
     FCCHK(apply_factors(h, S));
     launches += (int)S.stages.size();
@@ -1199,7 +1304,8 @@ int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double*
       FCCHK(lap(2));
     }
     hipLaunchKernelGGL(fc_finish, dim3(g), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, x, dx, h->up.p, h->u_n.p,
-                       h->u_nn.p, h->p_n.p, h->flag.p, h->mp_rowptr.p, h->mp_col.p, h->mp_val.p, e_partial);
+                       h->u_nn.p, h->p_n.p, h->flag.p, h->mp_rowptr.p, h->mp_col.p, h->mp_val.p, e_partial,
+                       (const unsigned char*)nullptr);
     hipLaunchKernelGGL(fc_final, dim3(1 + h->n_sens), dim3(256), 0, h->stream, g, e_partial, h->scal.p, nrp,
                        nrp > 0 ? h->partial.p : nullptr, h->scal.p + 1, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p,
                        h->up.p, h->ydev.p, h->flag.p, (double*)nullptr);
@@ -1233,6 +1339,74 @@ int fc_bench_sweeps(fc_handle h, int slot, int reps, double* ms_per_apply, int32
   HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   *ms_per_apply = (double)ms / reps;
   if (launches_per_apply) *launches_per_apply = (int32_t)S.stages.size();
+  return FC_OK;
+}
+
+int fc_set_partition(fc_handle h, int32_t n_local_cells, const int32_t* local_cells, const uint8_t* rowkind, int lead) {
+  if (!h || n_local_cells < 0 || (n_local_cells > 0 && !local_cells) || !rowkind)
+    return fail(FC_ERR_INVALID, "fc_set_partition: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  const int N = h->N, nc = h->nc;
+  std::vector<unsigned char> mine(nc, 0);
+  for (int k = 0; k < n_local_cells; ++k) {
+    if (local_cells[k] < 0 || local_cells[k] >= nc || mine[local_cells[k]]) return fail(FC_ERR_INVALID, "fc_set_partition: bad cell list");
+    mine[local_cells[k]] = 1;
+  }
+  for (int i = 0; i < N; ++i)
+    if (rowkind[i] > 2) return fail(FC_ERR_INVALID, "fc_set_partition: rowkind must be 0, 1 or 2");
+  h->h_cell_list.assign(local_cells, local_cells + n_local_cells);
+  h->h_rowkind.assign(rowkind, rowkind + N);
+  h->ncl = n_local_cells;
+  h->lead = lead != 0;
+  h->partitioned = true;
+  std::vector<int> cl(std::max(1, n_local_cells), 0);
+  std::copy(local_cells, local_cells + n_local_cells, cl.begin());
+  FCCHK(h->cell_list.upload(cl, h->stream));
+  // element -> row gather lists restricted to this rank's cells (same fixed order as the serial lists)
+  {
+    std::vector<int> cnh((size_t)6 * nc);
+    HIPCHK(hipMemcpyAsync(cnh.data(), h->cn.p, cnh.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<int> gp(N + 1, 0);
+    for (int c = 0; c < nc; ++c) {
+      if (!mine[c]) continue;
+      for (int k = 0; k < 12; ++k) gp[cnh[(size_t)(k % 6) * nc + c] + (k / 6) * h->nn + 1]++;
+    }
+    for (int r = 0; r < N; ++r) gp[r + 1] += gp[r];
+    std::vector<int> gi(gp[N]);
+    std::vector<int> fill(gp.begin(), gp.end() - 1);
+    for (int c = 0; c < nc; ++c) {
+      if (!mine[c]) continue;
+      for (int k = 0; k < 12; ++k) gi[fill[cnh[(size_t)(k % 6) * nc + c] + (k / 6) * h->nn]++] = k * nc + c;
+    }
+    h->h_gptr.swap(gp);
+    h->h_gidx.swap(gi);
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->have_perm) FCCHK(refresh_permuted(h));
+  return FC_OK;
+}
+
+int fc_comm_unique_id(char* out128) {
+  if (!out128) return fail(FC_ERR_INVALID, "fc_comm_unique_id: null argument");
+  FCCHK(rccl_load());
+  FcNcclId id;
+  NCCLCHK(g_rccl.GetUniqueId(&id));
+  std::memcpy(out128, id.internal, 128);
+  return FC_OK;
+}
+
+int fc_comm_init(fc_handle h, int nranks, int rank, const char* id128) {
+  if (!h || nranks < 1 || rank < 0 || rank >= nranks || !id128) return fail(FC_ERR_INVALID, "fc_comm_init: bad argument");
+  FCCHK(rccl_load());
+  HIPCHK(hipSetDevice(h->device));
+  FcNcclId id;
+  std::memcpy(id.internal, id128, 128);
+  void* comm = nullptr;
+  NCCLCHK(g_rccl.CommInitRank(&comm, nranks, id, rank));
+  h->comm = comm;
+  h->nranks = nranks;
+  h->rank = rank;
   return FC_OK;
 }
 

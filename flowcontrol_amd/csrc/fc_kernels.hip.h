@@ -29,9 +29,12 @@ __global__ __launch_bounds__(256) void fc_rhs_elem(int nc, int nn, const int* __
                                                    const double* __restrict__ fprof, int n_act,
                                                    const double* __restrict__ uctrl, double cm_n,
                                                    double cm_nn, double cc_n, double cc_nn,
-                                                   double* __restrict__ ev) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= nc) return;
+                                                   double* __restrict__ ev,
+                                                   const int* __restrict__ cell_list, int ncl) {
+  // cell_list != nullptr: this rank's share of the cells (multi-GPU partition), else all nc cells
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ncl) return;
+  const int c = cell_list ? cell_list[t] : t;
   const double j00 = geom[c], j01 = geom[nc + c], j10 = geom[2 * nc + c], j11 = geom[3 * nc + c];
   const double hdet = 0.5 * geom[4 * nc + c];
   double ax[6], ay[6], bx[6], by[6], fx[6], fy[6];
@@ -105,16 +108,25 @@ __global__ __launch_bounds__(256) void fc_rhs_gather(int N, const int* __restric
                                                      const double* __restrict__ bcprof,
                                                      const double* __restrict__ lift, int n_act,
                                                      const double* __restrict__ uctrl,
-                                                     double* __restrict__ b, double* __restrict__ y) {
+                                                     double* __restrict__ b, double* __restrict__ y,
+                                                     const unsigned char* __restrict__ rowkind, int lead) {
+  // rowkind (multi-GPU): 0 = another rank's row, 1 = owned, 2 = root separator shared by all ranks
+  // (every rank adds its cells' share; the BC value / lifting is added once, by the lead rank)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   double s = 0.0;
+  const int kind = rowkind ? rowkind[i] : 1;
+  const bool once = kind == 1 || (kind == 2 && lead);
   const int bs = bcslot[i];
-  if (bs >= 0) {
-    for (int k = 0; k < n_act; ++k) s += uctrl[k] * bcprof[(size_t)bs * n_act + k];
+  if (kind == 0) {
+    s = 0.0;
+  } else if (bs >= 0) {
+    if (once)
+      for (int k = 0; k < n_act; ++k) s += uctrl[k] * bcprof[(size_t)bs * n_act + k];
   } else {
     for (int k = gptr[i]; k < gptr[i + 1]; ++k) s += ev[gidx[k]];
-    for (int k = 0; k < n_act; ++k) s -= uctrl[k] * lift[(size_t)k * N + i];
+    if (once)
+      for (int k = 0; k < n_act; ++k) s -= uctrl[k] * lift[(size_t)k * N + i];
   }
   b[i] = s;
   y[i] = s;  // y-half of the solver work buffer: the first factor sweep starts from b
@@ -251,12 +263,15 @@ __global__ __launch_bounds__(256) void fc_spmv_csr(int nrows, const int* __restr
                                                    const double* __restrict__ x,
                                                    const double* __restrict__ b,
                                                    double* __restrict__ y, double* __restrict__ xsave,
-                                                   double* __restrict__ partial) {
+                                                   double* __restrict__ partial,
+                                                   const unsigned char* __restrict__ rowmask) {
+  // rowmask (multi-GPU residual monitor): only rows with mask == 1 (owned) are evaluated
   constexpr int RPB = 256 / LANES;
   const int lane = threadIdx.x % LANES;
   const int row = blockIdx.x * RPB + threadIdx.x / LANES;
   double s = 0.0;
-  if (row < nrows) {
+  const bool active = row < nrows && (!rowmask || rowmask[row] == 1);
+  if (active) {
     const int k0 = rowptr[row], k1 = rowptr[row + 1];
     double s0 = 0.0, s1 = 0.0;
     int k = k0 + lane;
@@ -270,7 +285,9 @@ __global__ __launch_bounds__(256) void fc_spmv_csr(int nrows, const int* __restr
 #pragma unroll
   for (int off = LANES / 2; off > 0; off >>= 1) s += __shfl_down(s, off, LANES);
   double r2 = 0.0, b2 = 0.0;
-  if (row < nrows && lane == 0) {
+  if (row < nrows && lane == 0 && !active) {
+    y[row] = 0.0;
+  } else if (row < nrows && lane == 0) {
     if (MODE == 0) {
       y[row] = s;
     } else {
@@ -436,10 +453,11 @@ __global__ __launch_bounds__(256) void fc_finish(int N, int nn2, const int* __re
                                                  const int* __restrict__ m_rowptr,
                                                  const int* __restrict__ m_col,
                                                  const double* __restrict__ m_val,
-                                                 double* __restrict__ e_partial) {
+                                                 double* __restrict__ e_partial,
+                                                 const unsigned char* __restrict__ rowkind) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double e = 0.0;
-  if (i < N) {
+  if (i < N && (!rowkind || rowkind[i] != 0)) {
     const int r = perm[i];
     const double v = dx ? x[i] + dx[i] : x[i];
     up[r] = v;
@@ -522,6 +540,61 @@ __global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restric
     } else if (blockIdx.x - 1 < n_sens) {
       y[blockIdx.x - 1] = red[0][0];
     }
+  }
+}
+
+// multi-GPU: energy share of this rank's cells, 1/2 ∫ |u|^2 (degree-4 integrand: exact with the 7-pt rule);
+// one partial per block
+__global__ __launch_bounds__(256) void fc_energy_elem(int nc, int nn, const int* __restrict__ cn,
+                                                      const double* __restrict__ geom,
+                                                      const double* __restrict__ u,
+                                                      const int* __restrict__ cell_list, int ncl,
+                                                      double* __restrict__ partial) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  double e = 0.0;
+  if (t < ncl) {
+    const int c = cell_list ? cell_list[t] : t;
+    const double hdet = 0.5 * geom[4 * (size_t)nc + c];
+    double ax[6], ay[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const int n = cn[(size_t)a * nc + c];
+      ax[a] = u[n];
+      ay[a] = u[nn + n];
+    }
+#pragma unroll
+    for (int q = 0; q < FC_NQ; ++q) {
+      double ux = 0.0, uy = 0.0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        ux += c_phi2[q * 6 + a] * ax[a];
+        uy += c_phi2[q * 6 + a] * ay[a];
+      }
+      e += c_qw[q] * hdet * (ux * ux + uy * uy);
+    }
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = e;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// multi-GPU: after the all-reduce of the step tail [y(64) | E | r2 | b2 | ... | flag@72] publish it
+__global__ void fc_publish_tail(const double* __restrict__ tail, double* __restrict__ y, int n_sens,
+                                double* __restrict__ E, double* __restrict__ r, double* __restrict__ flag_out) {
+  const int t = threadIdx.x;
+  if (t < n_sens && y) y[t] = tail[t];
+  if (t == 0) {
+    if (E) E[0] = tail[64];
+    if (r) {
+      r[0] = tail[65];
+      r[1] = tail[66];
+    }
+    if (flag_out) flag_out[0] = tail[72];
   }
 }
 

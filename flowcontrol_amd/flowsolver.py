@@ -205,8 +205,17 @@ class FlowSolver(ABC):
     def get_actuators_u_ctrl(self) -> list:
         return [a.expression.u_ctrl for a in self.params_control.actuator_list]
 
+    def _normalise_force_actuators(self) -> None:
+        """Give every FORCE actuator its unit-L2-norm scaling η (reference ``actuator.py:308-312``)."""
+        for a in self.params_control.actuator_list:
+            if a.actuator_type is ACTUATOR_TYPE.FORCE and not getattr(a, "_normalised", True):
+                a.expression.eta = 1.0
+                nodal = a.expression.profile(self.th.node_coords)
+                a.normalise(self._velocity_l2_norm(np.r_[nodal[:, 0], nodal[:, 1]]))
+
     def _gather_actuators_expressions(self):
         """Sum of FORCE-type expressions as a callable x → (n,2), or None when there is none."""
+        self._normalise_force_actuators()
         forces = [a.expression for a in self.params_control.actuator_list if a.actuator_type is ACTUATOR_TYPE.FORCE]
         if not forces:
             return None
@@ -249,6 +258,7 @@ class FlowSolver(ABC):
         acts = self.params_control.actuator_list
         if not any(a.actuator_type is ACTUATOR_TYPE.FORCE for a in acts):
             return None
+        self._normalise_force_actuators()
         out = np.zeros((len(acts), 2 * self.th.nn))
         for k, a in enumerate(acts):
             if a.actuator_type is ACTUATOR_TYPE.FORCE:

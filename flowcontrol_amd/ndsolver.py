@@ -32,13 +32,21 @@ import scipy.sparse as sp
 
 @dataclass
 class NDTree:
-    depth: int  # leaves live at this depth; level k has 2**(k*arity_bits) nodes
+    depth: int  # leaves live at this tree level; level k has 2**cum[k] nodes
     perm: np.ndarray  # new → old dof index
     iperm: np.ndarray  # old → new
     node_ptr: list[np.ndarray]  # per level k: (2**k + 1,) offsets into the *new* ordering
     level_ptr: np.ndarray  # (depth + 2,) new-index offsets of levels, deepest level FIRST
     bnd: list[list[np.ndarray]]  # per level k, per node: boundary dofs (new indices, sorted)
-    arity_bits: int = 1  # children per node = 2**arity_bits
+    cum: tuple = ()  # cum[k] = number of binary bisections above tree level k (cum[0] = 0)
+
+    def nnodes(self, k: int) -> int:
+        return 1 << self.cum[k]
+
+    def children(self, k: int, n: int) -> range:
+        """Node ids at level k+1 below node n of level k."""
+        b = self.cum[k + 1] - self.cum[k]
+        return range(n << b, (n + 1) << b)
 
 
 def _bisect_cells(cent: np.ndarray, depth: int) -> np.ndarray:
@@ -64,7 +72,8 @@ def _bisect_cells(cent: np.ndarray, depth: int) -> np.ndarray:
     return leaf
 
 
-def build_tree(cell_dofs: np.ndarray, centroids: np.ndarray, N: int, depth: int, skip: np.ndarray | None = None, merge: int = 1) -> NDTree:
+def build_tree(cell_dofs: np.ndarray, centroids: np.ndarray, N: int, depth: int, skip: np.ndarray | None = None,
+               merge: int = 1, top_bits: int = 0) -> NDTree:
     """Element-based nested dissection.
 
     A dof is owned by the deepest tree node whose cell set contains every cell touching it
@@ -74,11 +83,16 @@ def build_tree(cell_dofs: np.ndarray, centroids: np.ndarray, N: int, depth: int,
     ``depth`` counts binary bisections.  ``merge = m`` fuses every m consecutive binary levels
     into one level of a 2**m-ary tree (the separators of those levels become one pivot block):
     fewer, fatter sweep stages on the device at the price of somewhat denser pivot inverses.
+    ``top_bits = p`` makes the root 2**p-ary first (one sub-tree per GPU of a 2**p-rank run).
     """
     nc, nl = cell_dofs.shape
-    if depth % merge:
-        depth += merge - depth % merge
-    leaf = _bisect_cells(centroids, depth)
+    bits = [top_bits] if top_bits > 0 else []
+    while sum(bits) < depth:
+        bits.append(merge)
+    depth_bin = sum(bits)
+    cum = np.concatenate([[0], np.cumsum(bits)]).astype(np.int64)
+    K = len(bits)  # leaves at tree level K
+    leaf = _bisect_cells(centroids, depth_bin)
     lo = np.full(N, np.iinfo(np.int64).max)
     hi = np.full(N, -1)
     flat = cell_dofs.reshape(-1).astype(np.int64)
@@ -90,44 +104,45 @@ def build_tree(cell_dofs: np.ndarray, centroids: np.ndarray, N: int, depth: int,
     if skip is not None:
         hi = np.where(skip, lo, hi)
     x = lo ^ hi
-    nbits = np.zeros(N, dtype=np.int64)
+    nb_bin = np.zeros(N, dtype=np.int64)
     nz = x > 0
-    nbits[nz] = np.floor(np.log2(x[nz])).astype(np.int64) + 1
-    level = depth - nbits  # owner depth in the binary tree
-    if merge > 1:
-        level = level // merge  # level of the 2**merge-ary tree (floor: separators join their coarser group)
-        nbits = depth - level * merge
-        depth = depth // merge
+    nb_bin[nz] = np.floor(np.log2(x[nz])).astype(np.int64) + 1
+    beta = depth_bin - nb_bin  # owner depth in the binary tree
+    level = np.searchsorted(cum, beta, side="right") - 1  # tree level: separators join their coarser group
+    nbits = depth_bin - cum[level]
     prefix = lo >> nbits  # owner index within its level
-    arity_bits = merge
     # ordering: deepest level first, then node, then original index (locality)
     key = np.lexsort((np.arange(N), prefix, -level))
     perm = key.astype(np.int64)
     iperm = np.empty(N, dtype=np.int64)
     iperm[perm] = np.arange(N)
-    node_ptr: list[np.ndarray] = [None] * (depth + 1)
-    level_ptr = np.zeros(depth + 2, dtype=np.int64)
+    node_ptr: list[np.ndarray] = [None] * (K + 1)
+    level_ptr = np.zeros(K + 2, dtype=np.int64)
     pos = 0
-    for i, k in enumerate(range(depth, -1, -1)):
-        cnt = np.bincount(prefix[level == k], minlength=2 ** (k * arity_bits))
+    for i, k in enumerate(range(K, -1, -1)):
+        cnt = np.bincount(prefix[level == k], minlength=1 << int(cum[k]))
         node_ptr[k] = pos + np.r_[0, np.cumsum(cnt)]
         pos += int(cnt.sum())
         level_ptr[i + 1] = pos
     # boundary sets: dofs touching cells of subtree(t) that are owned by a proper ancestor
-    bnd: list[list[np.ndarray]] = [None] * (depth + 1)
+    bnd: list[list[np.ndarray]] = [None] * (K + 1)
     new_cell_dofs = iperm[cell_dofs.astype(np.int64)]
     lvl_new = level[perm]
-    for k in range(depth, -1, -1):
-        sub = leaf >> ((depth - k) * arity_bits)
+    for k in range(K, -1, -1):
+        sub = leaf >> int(depth_bin - cum[k])
         order = np.argsort(sub, kind="stable")
-        starts = np.searchsorted(sub[order], np.arange(2 ** (k * arity_bits) + 1))
+        nn_k = 1 << int(cum[k])
+        starts = np.searchsorted(sub[order], np.arange(nn_k + 1))
         out = []
-        for t in range(2 ** (k * arity_bits)):
+        for t in range(nn_k):
             cells = order[starts[t] : starts[t + 1]]
             dd = np.unique(new_cell_dofs[cells].reshape(-1))
             out.append(dd[lvl_new[dd] < k])
         bnd[k] = out
-    return NDTree(depth, perm, iperm, node_ptr, level_ptr, bnd, arity_bits)
+    tree = NDTree(K, perm, iperm, node_ptr, level_ptr, bnd, tuple(int(c) for c in cum))
+    tree.leaf_of_cell = leaf  # binary leaf index of every cell (partitioning of the element loops)
+    tree.depth_bin = depth_bin
+    return tree
 
 
 @dataclass
@@ -166,9 +181,8 @@ def factorize(A: sp.csr_matrix, tree: NDTree) -> NDFactors:
     Lr, Lc, Lv = [], [], []  # −L entries (row in B_t, col in I_t)
     Ur, Uc, Uv = [], [], []  # −U entries (row in I_t, col in B_t)
     Dr, Dc, Dv = [], [], []
-    ab = t.arity_bits
     for k in range(t.depth, -1, -1):
-        for n in range(2 ** (k * ab)):
+        for n in range(t.nnodes(k)):
             i0, i1 = int(t.node_ptr[k][n]), int(t.node_ptr[k][n + 1])
             ni = i1 - i0
             B = t.bnd[k][n]
@@ -178,7 +192,7 @@ def factorize(A: sp.csr_matrix, tree: NDTree) -> NDFactors:
                 if k < t.depth:
                     idx = B
                     F = np.zeros((nb, nb))
-                    for ch in range(n << ab, (n + 1) << ab):
+                    for ch in t.children(k, n):
                         cb, cu = updates.pop((k + 1, ch))
                         if cb.size:
                             p = np.searchsorted(idx, cb)
@@ -213,7 +227,7 @@ def factorize(A: sp.csr_matrix, tree: NDTree) -> NDFactors:
                 cols = Ap[:, i0:i1].tocsc()[B].tocoo()  # A[B, I]
                 F[ni + cols.row, cols.col] += cols.data
             if k < t.depth:
-                for ch in range(n << ab, (n + 1) << ab):
+                for ch in t.children(k, n):
                     cb, cu = updates.pop((k + 1, ch))
                     if cb.size:
                         p = np.searchsorted(idx, cb)
@@ -331,7 +345,6 @@ def factorize_blocks(A: sp.csr_matrix, tree: NDTree) -> BlockFactors:
     """Numeric multifrontal factorisation with explicit pivot-block inverses → block factors."""
     N = A.shape[0]
     t = tree
-    ab = t.arity_bits
     Ap = A[t.perm][:, t.perm].tocoo()
     r_, c_, v_ = Ap.row.astype(np.int64), Ap.col.astype(np.int64), Ap.data
     keep = v_ != 0.0
@@ -364,12 +377,12 @@ def factorize_blocks(A: sp.csr_matrix, tree: NDTree) -> BlockFactors:
     updates: dict[tuple[int, int], tuple[np.ndarray, np.ndarray]] = {}
     nnz = 0
     for k in range(t.depth, -1, -1):
-        for n in range(2 ** (k * ab)):
+        for n in range(t.nnodes(k)):
             i0, i1 = int(t.node_ptr[k][n]), int(t.node_ptr[k][n + 1])
             ni = i1 - i0
             B = t.bnd[k][n]
             nb = B.size
-            children = range(n << ab, (n + 1) << ab) if k < t.depth else ()
+            children = t.children(k, n) if k < t.depth else ()
             if ni == 0:
                 F = np.zeros((nb, nb))
                 for ch in children:

@@ -113,7 +113,10 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
                     const int64_t* seg_val /* [n_seg] offset into vals */,
                     const int32_t* seg_col /* [n_seg] >=0: first buffer index; <0: -(offset into idx)-1 */,
                     const int32_t* seg_len /* [n_seg] */, int64_t n_idx, const int32_t* idx,
-                    int64_t n_val, const double* vals);
+                    int64_t n_val, const double* vals,
+                    /* multi-GPU: after stage `ar_stage` (-1: none) the rows [ar_row0, ar_row0+ar_n) of the
+                     * work buffer are summed over the ranks (RCCL all-reduce) */
+                    int32_t ar_stage, int32_t ar_row0, int32_t ar_n);
 /* velocity mass matrix (u,v) in the solver's permuted numbering, CSR with N rows (pressure rows
  * empty): the matrix behind compute_perturbation_energy (flowsolver.py:827-829), used by the
  * fused step tail */
@@ -159,6 +162,17 @@ int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double*
 /* time `reps` back-to-back factor applies (all sweep launches of one M^-1 application) with HIP
  * events on the handle's stream; mean milliseconds per apply and launches per apply */
 int fc_bench_sweeps(fc_handle h, int slot, int reps, double* ms_per_apply, int32_t* launches_per_apply);
+/* ── multi-GPU (one process per GPU): replaces dolfin's MPI mesh partitioning
+ *    (flowsolver.py:236-238) and PETSc/MUMPS' internal MPI.  Each rank holds the whole (small)
+ *    discretisation but assembles only its cells and sweeps only its sub-tree of the elimination
+ *    tree; rowkind[N] (W numbering): 0 = other rank's dof, 1 = owned, 2 = root separator (replicated).
+ *    Exchange steps per step: one all-reduce of the root right-hand side inside the solve and one of
+ *    the 80-double step tail (sensor partials, energy, residual norms, divergence flag). */
+int fc_set_partition(fc_handle h, int32_t n_local_cells, const int32_t* local_cells,
+                     const uint8_t* rowkind /* [N] */, int lead);
+int fc_comm_unique_id(char* out128 /* ncclUniqueId bytes, made on rank 0 and broadcast by the host */);
+int fc_comm_init(fc_handle h, int nranks, int rank, const char* id128);
+
 /* per-launch HIP-event timing inside fc_step / fc_run: when on, every factor-sweep launch and
  * every in-step CSR SpMV launch is bracketed by an event pair on the handle's stream; totals are
  * accumulated after the step's synchronisation.  fc_set_timing resets the accumulators. */

@@ -127,3 +127,58 @@ def test_missing_baseflow_and_bad_inputs(tmp_path_factory):
     with pytest.raises(ValueError):
         fs.set_actuators_u_ctrl([0.0])
     fs.th.release_device()
+
+
+# ── open cavity (BASELINE config 3 ingredients) and pinball (config 5) ─────────────────────────────
+def _run_case_vs_fixture(fs, g, n_act, nsteps=10):
+    U0, P0 = Function(fs.W, g["UP0"]).split()
+    fs._assign_steady_state(U0, P0)
+    fs.initialize_time_stepping(ic=None)
+    for _ in range(nsteps):
+        fs.step(u_ctrl=[0.0] * n_act)
+    ts = fs.timeseries
+    ycols = [c for c in ts.columns if c.startswith("y_meas_")]
+    assert _rel_l2(ts[ycols].to_numpy(), g["y"]) < 1e-8
+    assert _rel_l2(ts["dE"].to_numpy(), g["dE"]) < 1e-8
+    return ts
+
+
+def test_cavity_regression_open_loop(tmp_path_factory, golden_dir):
+    """Mirror of the reference's test_cavity_regression time-stepping part (Re=7500, dt=4e-4, FORCE
+    actuator at u_ctrl=0, wall-shear + point sensors) from the golden base flow."""
+    from flowcontrol_amd.examples.cavity.cavityflowsolver import CavityFlowSolver
+
+    fs = CavityFlowSolver.make_default(Re=7500, path_out=tmp_path_factory.mktemp("cavity"), num_steps=10, save_every=5)
+    g = np.load(golden_dir / "cavity_coarse.npz")
+    ts = _run_case_vs_fixture(fs, g, 1)
+    last = ts.iloc[-1]
+    assert np.isclose(last["time"], 0.004, rtol=1e-6)
+    assert np.isclose(last["y_meas_1"], 6.0488687475121505, rtol=1e-4)
+    assert np.isclose(last["y_meas_2"], 0.024799707355708498, rtol=1e-4)
+    assert np.isclose(last["dE"], 0.005000924582291293, rtol=1e-4)
+    assert np.isclose(flu.apply_fun(fs.fields.Usave, np.mean), 0.3565670457803184, rtol=1e-6)
+    assert np.isclose(flu.apply_fun(fs.fields.Usave, np.max), 1.1897880864595587, rtol=1e-4)
+    # the FORCE actuator is unit-L2-norm (reference tests/test_actuator.py:155-161) and acts on the flow
+    act = fs.params_control.actuator_list[0]
+    v = act.expression.profile(fs.th.node_coords)
+    assert np.isclose(fs._velocity_l2_norm(np.r_[v[:, 0], v[:, 1]]), 1.0, rtol=1e-12)
+    y_before = fs.y_meas.copy()
+    fs.step(u_ctrl=[5.0])
+    assert np.all(np.isfinite(fs.y_meas)) and not np.allclose(fs.y_meas, y_before)
+    fs.th.release_device()
+
+
+def test_pinball_regression_open_loop(tmp_path_factory, golden_dir):
+    from flowcontrol_amd.actuator import CYLINDER_ACTUATION_MODE
+    from flowcontrol_amd.examples.pinball.pinballflowsolver import PinballFlowSolver
+
+    fs = PinballFlowSolver.make_default(Re=30, mode_actuation=CYLINDER_ACTUATION_MODE.SUCTION, path_out=tmp_path_factory.mktemp("pinball"),
+                                        num_steps=10, save_every=5)
+    g = np.load(golden_dir / "pinball_middle.npz")
+    ts = _run_case_vs_fixture(fs, g, 3)
+    last = ts.iloc[-1]
+    assert np.isclose(last["time"], 0.05, rtol=1e-6)
+    assert np.isclose(last["y_meas_1"], -0.0007241196930108308, rtol=1e-4)
+    assert np.isclose(last["dE"], 0.05722263472621765, rtol=1e-4)
+    assert np.isclose(flu.apply_fun(fs.fields.Usave, np.mean), 0.14938204178441114, rtol=1e-6)
+    fs.th.release_device()

@@ -101,3 +101,26 @@ def test_oracle_closed_loop_reproduces_reference(case, golden_dir):
     assert np.isclose((u_n + U0).max(), U_MAX_REF, rtol=1e-4)
     assert np.isclose((u_n + U0).mean(), U_MEAN_REF, rtol=1e-6)
     assert np.allclose(y, g["cl_y"][-1], rtol=1e-9)
+
+
+# ── cavity (Re=7500, FORCE actuator, wall-shear sensor) and pinball (Re=30, 3 BC actuators) ───────
+# reference tests/integration/test_cavity.py:47-54 and test_pinball.py:59-65
+CAVITY_REF = dict(u0_max=1.053181755992023, u0_mean=0.3497226515169121, u_max=1.1897880864595587, u_mean=0.3565670457803184,
+                  y=(6.0488687475121505, 0.024799707355708498), dE=0.005000924582291293)
+PINBALL_REF = dict(u0_max=1.463395784527965, u0_mean=0.1477130662080712, u_max=1.5168848768060617, u_mean=0.14938204178441114,
+                   y=(-0.0007241196930108308,), dE=0.05722263472621765)
+
+
+@pytest.mark.parametrize("name,ref,nvel", [("cavity_coarse", CAVITY_REF, 209052), ("pinball_middle", PINBALL_REF, 268296)])
+def test_cavity_and_pinball_golden_vectors_match_reference_constants(golden_dir, name, ref, nvel):
+    """The oracle's 10-step regression runs (generated by tests/golden/make_cavity_pinball_fixtures.py:
+    Picard → Newton base flow, default IC, u_ctrl = 0) against the reference's constants with the
+    reference's tolerances; all but the (loosely pinned, rtol 1e-4) Usave max agree to ~1e-13."""
+    g = np.load(golden_dir / f"{name}.npz")
+    U0 = g["UP0"][:nvel]
+    assert np.isclose(U0.max(), ref["u0_max"], rtol=1e-6) and abs(U0.max() / ref["u0_max"] - 1) < 1e-11
+    assert np.isclose(U0.mean(), ref["u0_mean"], rtol=1e-6) and abs(U0.mean() / ref["u0_mean"] - 1) < 1e-11
+    assert np.allclose(g["y"][-1][: len(ref["y"])], ref["y"], rtol=1e-4)
+    assert np.isclose(g["dE"][-1], ref["dE"], rtol=1e-4) and abs(g["dE"][-1] / ref["dE"] - 1) < 1e-11
+    assert np.isclose(float(g["umax"]), ref["u_max"], rtol=1e-4)
+    assert np.isclose(float(g["umean"]), ref["u_mean"], rtol=1e-6) and abs(float(g["umean"]) / ref["u_mean"] - 1) < 1e-11
