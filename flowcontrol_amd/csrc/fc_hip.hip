@@ -348,8 +348,9 @@ int launch_sweep(fc_ctx* h, const OrderSys& S, const Stage& st) {
 }
 
 // x_p (in buf[N..2N)) = M^-1 rhs_p, rhs_p must already be in buf[0..N)
-int apply_factors(fc_ctx* h, const OrderSys& S) {
-  for (size_t i = 0; i < S.stages.size(); ++i) {
+int apply_factors(fc_ctx* h, const OrderSys& S, int first = 0, int last = -1) {
+  if (last < 0) last = (int)S.stages.size() - 1;
+  for (size_t i = (size_t)first; i < S.stages.size() && (int)i <= last; ++i) {
     const Stage& st = S.stages[i];
     if (st.nrows > 0) FCCHK(launch_sweep(h, S, st));
     if ((int)i == S.ar_stage && h->comm && S.ar_n > 0) {
@@ -1139,6 +1140,64 @@ int fc_step(fc_handle h, int order_slot, const double* u_ctrl, double* y_out, do
     info_out[3] = flag;
   }
   if (flag) return fail(FC_ERR_DIVERGED, "non-finite velocity after solve");
+  return FC_OK;
+}
+
+int fc_step_phase(fc_handle h, int order_slot, int phase, const double* u_ctrl, int compute_energy, double* root_io,
+                  double* tail_io) {
+  // Host-staged exchange for a partitioned handle WITHOUT an RCCL communicator (debug / CPU-collective
+  // fallback of the *exchange only*; all arithmetic stays on the device):
+  //   phase 0: RHS element loop + up-sweeps through the root stage; root partial -> root_io[ar_n]
+  //   (caller sums root_io over the ranks)
+  //   phase 1: root_io -> device; remaining sweeps, residual monitor, finish, energy, sensors;
+  //            partial tail -> tail_io[80]   (caller sums tail_io over the ranks)
+  FCCHK(check_step_ready(h, order_slot));
+  if (!h->partitioned || h->comm) return fail(FC_ERR_INVALID, "fc_step_phase: needs a partitioned handle without RCCL communicator");
+  OrderSys& S = h->sys[order_slot];
+  if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this order");
+  if (S.ar_stage < 0 || !root_io) return fail(FC_ERR_INVALID, "fc_step_phase: no exchange stage configured");
+  if (h->max_iter > 0) return fail(FC_ERR_INVALID, "iterative refinement is not available on a partitioned handle");
+  HIPCHK(hipSetDevice(h->device));
+  const int N = h->N, g = nblocks(N, 256);
+  double* root = h->buf.p + S.ar_row0;
+  if (phase == 0) {
+    if (h->n_act > 0 && !u_ctrl) return fail(FC_ERR_INVALID, "fc_step_phase: u_ctrl is null");
+    volatile double* pin = h->pin;
+    for (int k = 0; k < h->n_act; ++k) pin[k] = u_ctrl[k];
+    FCCHK(enqueue_rhs(h, order_slot, h->pin_dev));
+    FCCHK(apply_factors(h, S, 0, S.ar_stage));
+    HIPCHK(hipMemcpyAsync(root_io, root, (size_t)S.ar_n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return FC_OK;
+  }
+  if (phase != 1 || !tail_io) return fail(FC_ERR_INVALID, "fc_step_phase: bad phase");
+  HIPCHK(hipMemcpyAsync(root, root_io, (size_t)S.ar_n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  FCCHK(apply_factors(h, S, S.ar_stage + 1, -1));
+  const double* x = h->buf.p + N;
+  int nrp = 0;
+  if (h->check_residual) {
+    const double mean = (double)S.Ap_nnz / std::max(1, N);
+    nrp = launch_spmv<1>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, x, h->b.p, h->tmpN.p, nullptr, h->partial.p,
+                         h->rowkind_p.p);
+    if (nrp < 0) return nrp;
+  }
+  double* e_partial = h->partial.p + 2 * (size_t)h->nblk_N;
+  hipLaunchKernelGGL(fc_finish, dim3(g), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, x, (const double*)nullptr, h->up.p,
+                     h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p, (const int*)nullptr, (const int*)nullptr,
+                     (const double*)nullptr, (double*)nullptr, h->rowkind_p.p);
+  int ne = 0;
+  if (compute_energy && h->ncl > 0) {
+    ne = nblocks(h->ncl, 256);
+    hipLaunchKernelGGL(fc_energy_elem, dim3(ne), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p, h->u_n.p,
+                       h->cell_list.p, h->ncl, e_partial);
+  }
+  HIPCHK(hipMemsetAsync(h->tail.p, 0, 128 * sizeof(double), h->stream));
+  hipLaunchKernelGGL(fc_final, dim3(1 + h->n_sens), dim3(256), 0, h->stream, ne, ne > 0 ? e_partial : nullptr, h->tail.p + 64,
+                     nrp, nrp > 0 ? h->partial.p : nullptr, h->tail.p + 65, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p,
+                     h->up.p, h->tail.p, h->flag.p, h->tail.p + 72);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(tail_io, h->tail.p, 80 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
   return FC_OK;
 }
 

@@ -49,6 +49,32 @@ class DeviceSolver:
         self.n_sens = 0
         self.tree: ndsolver.NDTree | None = None
         self.factor_nnz: dict[int, int] = {}
+        self.rank, self.world = 0, 1
+        self.part: ndsolver.RankPartition | None = None
+        self._sensor_rows: list | None = None
+        self.device_index = device
+
+    # ── multi-GPU ────────────────────────────────────────────────────────────
+    def join(self, rank: int, world: int, broadcast_bytes, host_allreduce=None) -> None:
+        """Make this handle rank ``rank`` of a ``world``-GPU run (one process per GPU).
+
+        ``broadcast_bytes(b | None) -> bytes`` ships the 128-byte RCCL unique id from rank 0 to every
+        rank (e.g. ``torch.distributed.broadcast_object_list``); the communicator then lives inside
+        the library and its all-reduces run on the solver's own HIP stream.
+        """
+        if world & (world - 1):
+            raise ValueError("world size must be a power of two (one elimination sub-tree per GPU)")
+        self.rank, self.world = int(rank), int(world)
+        self._host_allreduce = host_allreduce
+        if world == 1 or host_allreduce is not None:
+            # host-staged exchange (fc_step_phase): no RCCL communicator; ``host_allreduce(array)``
+            # sums a float64 array over the ranks in place
+            return
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            check(self.lib.fc_comm_unique_id(buf))
+        uid = broadcast_bytes(buf.raw if rank == 0 else None)
+        check(self.lib.fc_comm_init(self._h, world, rank, C.create_string_buffer(uid, 128)))
 
     # ── lifetime ─────────────────────────────────────────────────────────────
     def close(self) -> None:
@@ -102,6 +128,13 @@ class DeviceSolver:
         check(self.lib.fc_set_force(self._h, self.n_act, ptr(profiles)))
 
     def set_sensors(self, rows: list[tuple[np.ndarray, np.ndarray]]) -> None:
+        self._sensor_rows = rows
+        if self.part is not None:
+            # partitioned: every rank evaluates the part of each sensor row that lives on dofs it owns
+            # (root dofs: lead rank only); the partial readings are summed by the step's all-reduce
+            k = self.part.rowkind
+            keep = [(k[np.asarray(i)] == 1) | ((k[np.asarray(i)] == 2) & (self.rank == 0)) for i, _ in rows]
+            rows = [(np.asarray(i)[m], np.asarray(w)[m]) for (i, w), m in zip(rows, keep)]
         self.n_sens = len(rows)
         rp = np.zeros(len(rows) + 1, dtype=np.int32)
         for i, (idx, _) in enumerate(rows):
@@ -121,33 +154,47 @@ class DeviceSolver:
         """Factorise the (BC-eliminated) matrix of ``slot`` and hand the factors to the device.
 
         ``depth`` binary bisections (default: leaves of ≈ 12 cells), fused ``merge`` at a time into a
-        2**merge-ary elimination tree; ``refine`` iterative-refinement sweeps per solve (the fp64
-        selected inverse is accurate to round-off on its own, so 0 + residual monitoring is the default).
+        2**merge-ary elimination tree (on ``world`` GPUs the root is ``world``-ary first: one sub-tree
+        per rank); ``refine`` iterative-refinement sweeps per solve (the fp64 selected inverse is
+        accurate to round-off on its own, so 0 + residual monitoring is the default).
         """
         A = self.matrix(slot)
         if self.tree is None:
             th = self.th
+            top = int(np.log2(self.world)) if self.world > 1 else 0
             if depth is None:
-                depth = max(merge, int(np.ceil(np.log2(max(th.nc, 1) / 12.0))))
+                depth = max(merge + top, int(np.ceil(np.log2(max(th.nc, 1) / 12.0))))
             skip = np.zeros(self.N, dtype=bool)
             skip[self.bc_dofs] = True
-            self.tree = ndsolver.build_tree(th.cell_dofs, th.mesh.cell_centroids(), self.N, depth, skip, merge=merge)
+            self.tree = ndsolver.build_tree(th.cell_dofs, th.mesh.cell_centroids(), self.N, depth, skip, merge=merge, top_bits=top)
             check(self.lib.fc_set_permutation(self._h, _i32(self.tree.perm)))
             self._upload_energy_matrix()
         t = self.tree
         fac = ndsolver.factorize_blocks(A, t)
+        part = ndsolver.partition(fac, self.rank, self.world)
+        if self.world > 1 and self.part is None:
+            check(self.lib.fc_set_partition(self._h, int(part.local_cells.size), ptr(_i32(part.local_cells)),
+                                            ptr(np.ascontiguousarray(part.rowkind, dtype=np.uint8)), int(self.rank == 0)))
+            self.part = part
+            if self._sensor_rows is not None:
+                self.set_sensors(self._sensor_rows)
         Ap = A[t.perm][:, t.perm].tocsr()
         Ap.sort_indices()
         idx = fac.idx if fac.idx.size else np.zeros(1, dtype=np.int32)
+        seg_val = part.seg_val if part.seg_val.size else np.zeros(1, dtype=np.int64)
+        seg_col = part.seg_col if part.seg_col.size else np.zeros(1, dtype=np.int32)
+        seg_len = part.seg_len if part.seg_len.size else np.zeros(1, dtype=np.int32)
         check(
             self.lib.fc_solver_setup(
-                self._h, slot, _i32(Ap.indptr), _i32(Ap.indices), _f64(Ap.data), len(fac.stage_kind), fac.stage_begin,
-                fac.stage_row0, fac.stage_nrows, fac.stage_kind, fac.seg_ptr, int(fac.seg_val.size), fac.seg_val,
-                fac.seg_col, fac.seg_len, int(fac.idx.size), _i32(idx), int(fac.vals.size), fac.vals,
+                self._h, slot, _i32(Ap.indptr), _i32(Ap.indices), _f64(Ap.data), len(part.stage_kind), part.stage_begin,
+                part.stage_row0, part.stage_nrows, part.stage_kind, part.seg_ptr, int(part.seg_val.size), seg_val,
+                seg_col, seg_len, int(fac.idx.size), _i32(idx), int(fac.vals.size), fac.vals,
+                int(part.ar_stage), int(part.ar_row0), int(part.ar_n),
             )
         )
         self.factor_nnz[slot] = int(fac.nnz)
-        self.n_stages = len(fac.stage_kind)
+        self.local_factor_nnz = int(part.seg_len.sum())
+        self.n_stages = len(part.stage_kind)
         self.set_solver_options(refine, check_residual)
 
     def set_solver_options(self, refine: int = 0, check_residual: bool = True) -> None:
@@ -175,14 +222,35 @@ class DeviceSolver:
         check(self.lib.fc_get_state(self._h, ptr(u_n), ptr(u_nn), ptr(p_n)))
         return u_n, u_nn, p_n
 
+    def owned_mask(self) -> np.ndarray:
+        """W-layout mask of the dofs whose values this rank is responsible for when fields are merged."""
+        if self.part is None:
+            return np.ones(self.N, dtype=bool)
+        k = self.part.rowkind
+        return (k == 1) | ((k == 2) & (self.rank == 0))
+
     def get_solution(self) -> np.ndarray:
         up = np.empty(self.N)
         check(self.lib.fc_get_solution(self._h, up))
         return up
 
     # ── hot path ─────────────────────────────────────────────────────────────
+    def _step_host_staged(self, order_slot: int, u, compute_energy: bool):
+        root = np.empty(max(1, self.part.ar_n))
+        tail = np.empty(80)
+        check(self.lib.fc_step_phase(self._h, order_slot, 0, ptr(u), int(compute_energy), ptr(root), ptr(tail)))
+        self._host_allreduce(root)
+        check(self.lib.fc_step_phase(self._h, order_slot, 1, ptr(u), int(compute_energy), ptr(root), ptr(tail)))
+        self._host_allreduce(tail)
+        info = np.array([0.0, np.sqrt(tail[65] / tail[66]) if tail[66] > 0 else np.nan, np.sqrt(tail[66]), tail[72]])
+        if tail[72] > 0:
+            raise _lib.FcDiverged(_lib.FC_ERR_DIVERGED, "non-finite velocity after solve")
+        return tail[: self.n_sens].copy(), (float(tail[64]) if compute_energy else float("nan")), info
+
     def step(self, order_slot: int, u_ctrl, compute_energy: bool = True):
         u = _f64(np.atleast_1d(u_ctrl)) if self.n_act else None
+        if self.world > 1 and getattr(self, "_host_allreduce", None) is not None:
+            return self._step_host_staged(order_slot, u, compute_energy)
         y = np.empty(max(self.n_sens, 1))
         info = np.empty(4)
         dE = C.c_double()

@@ -451,6 +451,7 @@ class FlowSolver(ABC):
         if self.fields.U0 is None:
             raise RuntimeError("no base flow: call compute_steady_state() or load_steady_state() first")
         dev = self.th.device()
+        self._join_process_group(dev)
         U0 = self.fields.U0
         dofs, prof = self._bc_tables()
         dev.set_bc(dofs, prof)
@@ -469,6 +470,35 @@ class FlowSolver(ABC):
             self.solvers[order] = solver
         self._systems_ready = True
 
+    def _join_process_group(self, dev) -> None:
+        """One process per GPU: when ``torch.distributed`` is initialised with more than one rank the
+        solver partitions the elimination tree over the ranks (RCCL inside the library)."""
+        if getattr(self, "_joined", False):
+            return
+        self._joined = True
+        try:
+            import torch.distributed as dist
+        except Exception:  # pragma: no cover
+            return
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or not getattr(self, "distributed", True):
+            return
+
+        def bcast(b):
+            box = [b]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+
+        host_allreduce = None
+        if dist.get_backend() != "nccl":
+            # no RCCL process group (CPU collectives, or several ranks sharing one GPU): the two
+            # exchange steps of a time step are staged through the host; the arithmetic stays on the GPU
+            import torch
+
+            def host_allreduce(a: np.ndarray) -> None:
+                dist.all_reduce(torch.from_numpy(a))
+
+        dev.join(dist.get_rank(), dist.get_world_size(), bcast, host_allreduce)
+
     def _upload_state(self) -> None:
         f = self.fields
         self.th.device().set_state(f._store["u_n"].vector().array(), f._store["u_nn"].vector().array(), f._store["p_n"].vector().array())
@@ -478,6 +508,20 @@ class FlowSolver(ABC):
     def _download_fields(self) -> None:
         dev = self.th.device()
         u_n, u_nn, p_n = dev.get_state()
+        if dev.world > 1:
+            # every rank holds its own dofs (+ the replicated root): merge by masked sum
+            import torch
+            import torch.distributed as dist
+
+            m = dev.owned_mask()
+            nn2 = 2 * self.th.nn
+            flat = np.concatenate([np.where(m[:nn2], u_n, 0.0), np.where(m[:nn2], u_nn, 0.0), np.where(m[nn2:], p_n, 0.0)])
+            tns = torch.from_numpy(flat)
+            if dist.get_backend() == "nccl":
+                tns = tns.cuda()
+            dist.all_reduce(tns)
+            flat = tns.cpu().numpy()
+            u_n, u_nn, p_n = flat[:nn2], flat[nn2 : 2 * nn2], flat[2 * nn2 :]
         st = self.fields._store
         st["u_n"].vector().set_local(u_n)
         st["u_nn"].vector().set_local(u_nn)

@@ -102,7 +102,11 @@ def build_tree(cell_dofs: np.ndarray, centroids: np.ndarray, N: int, depth: int,
     if np.any(hi < 0):
         raise ValueError("dof without any cell")
     if skip is not None:
-        hi = np.where(skip, lo, hi)
+        # decoupled (Dirichlet) rows are parked in a leaf — unless cells of different top-level
+        # sub-trees (= different GPUs) touch them: those stay in the replicated root so that every
+        # rank that needs their value has it
+        same_top = (lo >> (depth_bin - top_bits)) == (hi >> (depth_bin - top_bits))
+        hi = np.where(skip & same_top, lo, hi)
     x = lo ^ hi
     nb_bin = np.zeros(N, dtype=np.int64)
     nz = x > 0
@@ -487,3 +491,138 @@ def factorize_blocks(A: sp.csr_matrix, tree: NDTree) -> BlockFactors:
 
 
 __all__ += ["BlockFactors", "factorize_blocks"]
+
+
+# ──────────────────────────────────────────────────────────────────────────────────────────
+# Multi-GPU partition: one sub-tree of the root per rank, the root separator replicated.
+# ──────────────────────────────────────────────────────────────────────────────────────────
+@dataclass
+class RankPartition:
+    """What rank ``rank`` of ``world`` executes (permuted numbering unless stated).
+
+    * rows of tree levels ≥ 1 that lie in the rank's sub-tree (contiguous ranges per level);
+    * the root level: every rank sweeps *its* columns of the root's L rows into a partial
+      right-hand side, an all-reduce sums the partials (the single exchange step of a solve), and
+      every rank then applies the root's D⁻¹ redundantly (it is small), so the solution on the root
+      separator is replicated and no halo exchange is needed afterwards.
+    """
+
+    rank: int
+    world: int
+    rank_of_dof: np.ndarray  # (N,) permuted numbering; -1 = root separator
+    rowkind: np.ndarray  # (N,) ORIGINAL numbering: 0 other rank, 1 owned, 2 root (replicated)
+    local_cells: np.ndarray  # cell ids assembled by this rank
+    seg_ptr: np.ndarray
+    seg_val: np.ndarray
+    seg_col: np.ndarray
+    seg_len: np.ndarray
+    stage_row0: np.ndarray
+    stage_nrows: np.ndarray
+    stage_kind: np.ndarray
+    stage_begin: np.ndarray
+    ar_stage: int
+    ar_row0: int
+    ar_n: int
+
+
+def partition(fac: BlockFactors, rank: int, world: int) -> RankPartition:
+    t = fac.tree
+    N = fac.N
+    p = int(np.log2(world))
+    if (1 << p) != world:
+        raise ValueError("world size must be a power of two")
+    if world > 1 and (len(t.cum) < 2 or t.cum[1] != p):
+        raise ValueError("tree was not built with top_bits = log2(world)")
+    rank_of = np.full(N, -1, dtype=np.int64)
+    if world == 1:
+        rank_of[:] = 0
+    else:
+        for k in range(1, t.depth + 1):
+            sh = t.cum[k] - p
+            for n in range(t.nnodes(k)):
+                rank_of[int(t.node_ptr[k][n]) : int(t.node_ptr[k][n + 1])] = n >> sh
+    rowkind = np.zeros(N, dtype=np.uint8)
+    kind_new = np.where(rank_of < 0, 2, np.where(rank_of == rank, 1, 0)).astype(np.uint8)
+    rowkind[t.perm] = kind_new
+    leaf = t.leaf_of_cell
+    local_cells = np.nonzero((leaf >> (t.depth_bin - p)) == rank)[0].astype(np.int32) if world > 1 else np.arange(leaf.size, dtype=np.int32)
+    seg_ptr = [np.zeros(1, dtype=np.int64)]
+    sv, sc, sl = [], [], []
+    row0, nrows, kinds = [], [], []
+    ar_stage = -1
+    nseg = 0
+    nstages = len(fac.stage_kind)
+    for s in range(nstages):
+        k = (t.depth - 1 - s) if s < t.depth else (s - t.depth)  # level of this stage
+        g0 = int(fac.stage_begin[s])
+        gr0, gn = int(fac.stage_row0[s]), int(fac.stage_nrows[s])
+        ptr = fac.seg_ptr[g0 : g0 + gn + 1]
+        if k >= 1 and world > 1:
+            sh = t.cum[k] - p
+            n0, n1 = rank << sh, (rank + 1) << sh
+            r0, r1 = int(t.node_ptr[k][n0]), int(t.node_ptr[k][n1])
+            a, b = r0 - gr0, r1 - gr0
+            q0, q1 = int(ptr[a]), int(ptr[b])
+            cnt = np.diff(ptr[a : b + 1])
+            sel = slice(q0, q1)
+            row0.append(r0), nrows.append(r1 - r0)
+            sv.append(fac.seg_val[sel]), sc.append(fac.seg_col[sel]), sl.append(fac.seg_len[sel])
+        elif k == 0 and world > 1 and fac.stage_kind[s] == 0:
+            # root up-sweep: keep only the segments that read this rank's part of y
+            q0, q1 = int(ptr[0]), int(ptr[-1])
+            cols = fac.seg_col[q0:q1]
+            keep = rank_of[cols] == rank
+            row_of_seg = np.repeat(np.arange(gn), np.diff(ptr))
+            cnt = np.bincount(row_of_seg[keep], minlength=gn)
+            row0.append(gr0), nrows.append(gn)
+            sv.append(fac.seg_val[q0:q1][keep]), sc.append(cols[keep]), sl.append(fac.seg_len[q0:q1][keep])
+            ar_stage = len(kinds)
+        else:
+            q0, q1 = int(ptr[0]), int(ptr[-1])
+            cnt = np.diff(ptr)
+            row0.append(gr0), nrows.append(gn)
+            sv.append(fac.seg_val[q0:q1]), sc.append(fac.seg_col[q0:q1]), sl.append(fac.seg_len[q0:q1])
+        kinds.append(int(fac.stage_kind[s]))
+        seg_ptr.append(nseg + np.cumsum(cnt))
+        nseg += int(cnt.sum())
+    nrows = np.array(nrows, dtype=np.int32)
+    root0, root1 = int(t.node_ptr[0][0]), int(t.node_ptr[0][-1])
+    return RankPartition(
+        rank=rank, world=world, rank_of_dof=rank_of, rowkind=rowkind, local_cells=local_cells,
+        seg_ptr=np.concatenate(seg_ptr).astype(np.int64),
+        seg_val=np.ascontiguousarray(np.concatenate(sv), dtype=np.int64),
+        seg_col=np.ascontiguousarray(np.concatenate(sc), dtype=np.int32),
+        seg_len=np.ascontiguousarray(np.concatenate(sl), dtype=np.int32),
+        stage_row0=np.array(row0, dtype=np.int32), stage_nrows=nrows, stage_kind=np.array(kinds, dtype=np.int32),
+        stage_begin=np.concatenate([[0], np.cumsum(nrows)[:-1]]).astype(np.int64),
+        ar_stage=ar_stage if world > 1 else -1, ar_row0=root0, ar_n=(root1 - root0) if world > 1 else 0,
+    )
+
+
+def solve_partitioned_reference(fac: BlockFactors, part: RankPartition, b_local_perm: np.ndarray, allreduce) -> np.ndarray:
+    """Host emulation of what one rank's device does (CPU tests with gloo): ``b_local_perm`` holds
+    this rank's share of the permuted right-hand side (owned rows + its partial of the root rows);
+    ``allreduce(array)`` sums an array over the ranks in place.  Returns the x-half of the buffer
+    (valid on owned and root rows)."""
+    N = fac.N
+    buf = np.concatenate([b_local_perm.astype(np.float64), np.zeros(N)])
+    for s in range(len(part.stage_kind)):
+        g0, nr, r0 = int(part.stage_begin[s]), int(part.stage_nrows[s]), int(part.stage_row0[s])
+        acc = np.zeros(nr)
+        for r in range(nr):
+            for q in range(int(part.seg_ptr[g0 + r]), int(part.seg_ptr[g0 + r + 1])):
+                n, c, vo = int(part.seg_len[q]), int(part.seg_col[q]), int(part.seg_val[q])
+                xs = buf[c : c + n] if c >= 0 else buf[fac.idx[-(c + 1) : -(c + 1) + n]]
+                acc[r] += fac.vals[vo : vo + n] @ xs
+        if part.stage_kind[s] == 0:
+            buf[r0 : r0 + nr] += acc
+        else:
+            buf[N + r0 : N + r0 + nr] = acc
+        if s == part.ar_stage and part.ar_n > 0:
+            seg = buf[part.ar_row0 : part.ar_row0 + part.ar_n].copy()
+            allreduce(seg)
+            buf[part.ar_row0 : part.ar_row0 + part.ar_n] = seg
+    return buf[N:]
+
+
+__all__ += ["RankPartition", "partition", "solve_partitioned_reference"]

@@ -172,6 +172,12 @@ int fc_set_partition(fc_handle h, int32_t n_local_cells, const int32_t* local_ce
                      const uint8_t* rowkind /* [N] */, int lead);
 int fc_comm_unique_id(char* out128 /* ncclUniqueId bytes, made on rank 0 and broadcast by the host */);
 int fc_comm_init(fc_handle h, int nranks, int rank, const char* id128);
+/* Host-staged exchange for a partitioned handle that has NO RCCL communicator (several ranks on one
+ * GPU, CPU-only collectives): the step is cut at its two exchange points and the caller sums
+ * root_io[ar_n] (after phase 0) and tail_io[80] (after phase 1) over the ranks.  All arithmetic stays
+ * on the device.  tail layout: y[0..63], E at 64, |r|^2 65, |b|^2 66, non-finite flag 72. */
+int fc_step_phase(fc_handle h, int order_slot, int phase, const double* u_ctrl, int compute_energy,
+                  double* root_io, double* tail_io);
 
 /* per-launch HIP-event timing inside fc_step / fc_run: when on, every factor-sweep launch and
  * every in-step CSR SpMV launch is bracketed by an event pair on the handle's stream; totals are
