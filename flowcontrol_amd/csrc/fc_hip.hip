@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -248,10 +249,15 @@ void tabulate(double* phi2, double* dphi2, double* phi1, double* qw) {
 inline int nblocks(int64_t n, int per) { return (int)((n + per - 1) / per); }
 
 int pick_lanes(double mean_nnz) {
-  if (mean_nnz <= 6) return 4;
-  if (mean_nnz <= 20) return 8;
-  if (mean_nnz <= 48) return 16;
-  if (mean_nnz <= 160) return 32;
+  if (const char* e = std::getenv("FC_SPMV_LANES")) {  // tuning aid
+    const int v = std::atoi(e);
+    if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) return v;
+  }
+  // the CSR kernel issues 4 predicated loads per lane and trip: lanes ~ row length / 4
+  if (mean_nnz <= 16) return 4;
+  if (mean_nnz <= 40) return 8;
+  if (mean_nnz <= 96) return 16;
+  if (mean_nnz <= 256) return 32;
   return 64;
 }
 
@@ -1016,7 +1022,9 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
     } else {
       // down: one contiguous (D^-1) and one indexed (-U) segment per row; running them side by
       // side would diverge inside the wave, so all lanes of the row walk them one after the other
-      lanes = few_long_rows ? 256 : std::min(64, std::max(8, pow2_ceil(mean_seg / (double)FC_DOWN_DEPTH)));
+      double dd = FC_DOWN_DEPTH;
+      if (const char* e = std::getenv("FC_DOWN_DEPTH")) dd = std::max(1.0, std::atof(e));  // tuning aid
+      lanes = few_long_rows ? 256 : std::min(64, std::max(8, pow2_ceil(mean_seg / dd)));
       sub = lanes;
     }
     if (lanes < 8) lanes = 8;

@@ -273,14 +273,21 @@ __global__ __launch_bounds__(256) void fc_spmv_csr(int nrows, const int* __restr
   const bool active = row < nrows && (!rowmask || rowmask[row] == 1);
   if (active) {
     const int k0 = rowptr[row], k1 = rowptr[row + 1];
-    double s0 = 0.0, s1 = 0.0;
-    int k = k0 + lane;
-    for (; k + LANES < k1; k += 2 * LANES) {
-      s0 += val[k] * x[col[k]];
-      s1 += val[k + LANES] * x[col[k + LANES]];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    // predicated 4-deep issue: the 8 streaming loads (values + columns) of a trip are in flight
+    // before the first gather of x; a 29-nnz Taylor-Hood row is one trip of 8 lanes
+    for (int base = k0; base < k1; base += 4 * LANES) {
+      const int j0 = base + lane, j1 = j0 + LANES, j2 = j1 + LANES, j3 = j2 + LANES;
+      const int c0 = j0 < k1 ? col[j0] : 0, c1 = j1 < k1 ? col[j1] : 0;
+      const int c2 = j2 < k1 ? col[j2] : 0, c3 = j3 < k1 ? col[j3] : 0;
+      const double v0 = j0 < k1 ? val[j0] : 0.0, v1 = j1 < k1 ? val[j1] : 0.0;
+      const double v2 = j2 < k1 ? val[j2] : 0.0, v3 = j3 < k1 ? val[j3] : 0.0;
+      s0 += v0 * x[c0];
+      s1 += v1 * x[c1];
+      s2 += v2 * x[c2];
+      s3 += v3 * x[c3];
     }
-    if (k < k1) s0 += val[k] * x[col[k]];
-    s = s0 + s1;
+    s = (s0 + s1) + (s2 + s3);
   }
 #pragma unroll
   for (int off = LANES / 2; off > 0; off >>= 1) s += __shfl_down(s, off, LANES);
