@@ -97,6 +97,10 @@ struct OrderSys {
   std::vector<Stage> stages;
   double sweep_bytes = 0.0;
   int ar_stage = -1, ar_row0 = 0, ar_n = 0;  // all-reduce buf[ar_row0 .. +ar_n) after this stage
+  // optional explicit operator of the rhs (Crank-Nicolson): rows permuted, columns index u_n (W layout)
+  DevBuf<int> c_rowptr, c_col;
+  DevBuf<double> c_val;
+  bool have_c = false;
 };
 
 constexpr int kPinDoubles = 4096;
@@ -465,17 +469,20 @@ int check_step_ready(fc_ctx* h, int order_slot) {
 }
 
 // enqueue RHS assembly for the current state into h->b (permuted numbering)
-int enqueue_rhs(fc_ctx* h, int order_slot, const double* d_uctrl) {
+int enqueue_rhs(fc_ctx* h, int order_slot, const double* d_uctrl, const double* d_uforce = nullptr) {
   const StepCoeffs c = coeffs_for(h, order_slot);
   OrderSys& S = h->sys[order_slot];
+  if (!d_uforce) d_uforce = d_uctrl;
+  if (S.have_c && h->partitioned) return fail(FC_ERR_INVALID, "an explicit rhs operator (Crank-Nicolson) is not available on a partitioned handle");
   const int ncl = h->partitioned ? h->ncl : h->nc;
   if (ncl > 0)
     hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks(ncl, 64)), dim3(64), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
-                       h->u_n.p, h->u_nn.p, h->have_force ? h->fprof.p : nullptr, h->have_force ? h->n_act : 0, d_uctrl,
+                       h->u_n.p, h->u_nn.p, h->have_force ? h->fprof.p : nullptr, h->have_force ? h->n_act : 0, d_uforce,
                        c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p, h->partitioned ? h->cell_list.p : nullptr, ncl);
   hipLaunchKernelGGL(fc_rhs_gather, dim3(nblocks(h->N, 256)), dim3(256), 0, h->stream, h->N, h->gptr_p.p, h->gidx_p.p,
                      h->ev.p, h->bcslot_p.p, h->bcprof.p, S.lift_p.p, h->n_act, d_uctrl, h->b.p, h->buf.p,
-                     h->partitioned ? h->rowkind_p.p : nullptr, h->lead ? 1 : 0);
+                     h->partitioned ? h->rowkind_p.p : nullptr, h->lead ? 1 : 0, S.have_c ? S.c_rowptr.p : nullptr,
+                     S.c_col.p, S.c_val.p, h->u_n.p);
   HIPCHK(hipGetLastError());
   return FC_OK;
 }
@@ -492,11 +499,11 @@ int enqueue_energy(fc_ctx* h, const double* d_u, double* d_out) {
 
 // enqueue one full step; y -> d_y, E -> d_E; residual norms -> scal[1], scal[2]
 int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, double* d_E, double* d_r,
-                 double* d_flag_out, int compute_energy) {
+                 double* d_flag_out, int compute_energy, const double* d_uforce = nullptr) {
   OrderSys& S = h->sys[order_slot];
   if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this order");
   if (compute_energy && !h->partitioned && !h->have_mp) return fail(FC_ERR_NOT_READY, "fc_set_energy_matrix not called");
-  FCCHK(enqueue_rhs(h, order_slot, d_uctrl));
+  FCCHK(enqueue_rhs(h, order_slot, d_uctrl, d_uforce));
   const double *x = nullptr, *dx = nullptr;
   int nrp = 0;
   FCCHK(solve_permuted(h, S, &x, &dx, &nrp));
@@ -1064,6 +1071,30 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
   return FC_OK;
 }
 
+int fc_set_rhs_operator(fc_handle h, int slot, const int32_t* rowptr, const int32_t* col, const double* val) {
+  if (!h || slot < 0 || slot > 1) return fail(FC_ERR_INVALID, "fc_set_rhs_operator: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  OrderSys& S = h->sys[slot];
+  if (!rowptr) {
+    S.have_c = false;
+    return FC_OK;
+  }
+  if (!col || !val) return fail(FC_ERR_INVALID, "fc_set_rhs_operator: null argument");
+  const int N = h->N;
+  const int nz = rowptr[N];
+  if (rowptr[0] != 0 || nz < 0) return fail(FC_ERR_INVALID, "fc_set_rhs_operator: bad row pointers");
+  for (int i = 0; i < N; ++i)
+    if (rowptr[i + 1] < rowptr[i]) return fail(FC_ERR_INVALID, "fc_set_rhs_operator: bad row pointers");
+  for (int k = 0; k < nz; ++k)
+    if (col[k] < 0 || col[k] >= 2 * h->nn) return fail(FC_ERR_INVALID, "fc_set_rhs_operator: column is not a velocity dof");
+  FCCHK(S.c_rowptr.upload(rowptr, (size_t)N + 1, h->stream));
+  FCCHK(S.c_col.upload(col, (size_t)std::max(1, nz), h->stream));
+  FCCHK(S.c_val.upload(val, (size_t)std::max(1, nz), h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  S.have_c = true;
+  return FC_OK;
+}
+
 int fc_set_energy_matrix(fc_handle h, const int32_t* rowptr, const int32_t* col, const double* val) {
   if (!h || !rowptr || !col || !val) return fail(FC_ERR_INVALID, "fc_set_energy_matrix: null argument");
   HIPCHK(hipSetDevice(h->device));
@@ -1123,17 +1154,21 @@ int fc_get_solution(fc_handle h, double* up) {
   return FC_OK;
 }
 
-int fc_step(fc_handle h, int order_slot, const double* u_ctrl, double* y_out, double* dE_out, int compute_energy,
-            double* info_out) {
+int fc_step(fc_handle h, int order_slot, const double* u_ctrl, const double* u_force, double* y_out, double* dE_out,
+            int compute_energy, double* info_out) {
   FCCHK(check_step_ready(h, order_slot));
   if (h->n_act > 0 && !u_ctrl) return fail(FC_ERR_INVALID, "fc_step: u_ctrl is null");
+  if (h->n_act > 32) return fail(FC_ERR_INVALID, "fc_step: at most 32 actuators");
   HIPCHK(hipSetDevice(h->device));
   // zero-copy record in pinned, device-mapped host memory: the kernels read u_ctrl from it and the
   // last kernel of the step writes (y, dE, |r|^2, |b|^2, flag) into it — no memcpy on the stream.
   volatile double* pin = h->pin;
-  for (int k = 0; k < h->n_act; ++k) pin[k] = u_ctrl[k];
+  for (int k = 0; k < h->n_act; ++k) {
+    pin[k] = u_ctrl[k];
+    pin[32 + k] = u_force ? u_force[k] : u_ctrl[k];  // body-force amplitudes (CN: mean of new and old)
+  }
   double* dev = h->pin_dev;
-  FCCHK(enqueue_step(h, order_slot, dev, dev + 64, dev + 128, dev + 129, dev + 136, compute_energy));
+  FCCHK(enqueue_step(h, order_slot, dev, dev + 64, dev + 128, dev + 129, dev + 136, compute_energy, dev + 32));
   HIPCHK(hipStreamSynchronize(h->stream));
   FCCHK(time_collect(h));
   for (int s = 0; s < h->n_sens; ++s)
@@ -1344,7 +1379,7 @@ int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double*
     FCCHK(lap(0));
     hipLaunchKernelGGL(fc_rhs_gather, dim3(g), dim3(256), 0, h->stream, N, h->gptr_p.p, h->gidx_p.p, h->ev.p,
                        h->bcslot_p.p, h->bcprof.p, S.lift_p.p, h->n_act, h->uctrl.p, h->b.p, h->buf.p,
-                       (const unsigned char*)nullptr, 1);
+                       (const unsigned char*)nullptr, 1, S.have_c ? S.c_rowptr.p : nullptr, S.c_col.p, S.c_val.p, h->u_n.p);
     FCCHK(lap(1));
     FCCHK(apply_factors(h, S));
     launches += (int)S.stages.size();

@@ -109,7 +109,11 @@ __global__ __launch_bounds__(256) void fc_rhs_gather(int N, const int* __restric
                                                      const double* __restrict__ lift, int n_act,
                                                      const double* __restrict__ uctrl,
                                                      double* __restrict__ b, double* __restrict__ y,
-                                                     const unsigned char* __restrict__ rowkind, int lead) {
+                                                     const unsigned char* __restrict__ rowkind, int lead,
+                                                     const int* __restrict__ c_rowptr,
+                                                     const int* __restrict__ c_col,
+                                                     const double* __restrict__ c_val,
+                                                     const double* __restrict__ un) {
   // rowkind (multi-GPU): 0 = another rank's row, 1 = owned, 2 = root separator shared by all ranks
   // (every rank adds its cells' share; the BC value / lifting is added once, by the lead rank)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -127,6 +131,9 @@ __global__ __launch_bounds__(256) void fc_rhs_gather(int N, const int* __restric
     for (int k = gptr[i]; k < gptr[i + 1]; ++k) s += ev[gidx[k]];
     if (once)
       for (int k = 0; k < n_act; ++k) s -= uctrl[k] * lift[(size_t)k * N + i];
+    // explicit half of the linear terms of Crank-Nicolson (nsforms.py:212-216): -(C u_n)[row]
+    if (c_rowptr)
+      for (int k = c_rowptr[i]; k < c_rowptr[i + 1]; ++k) s -= c_val[k] * un[c_col[k]];
   }
   b[i] = s;
   y[i] = s;  // y-half of the solver work buffer: the first factor sweep starts from b

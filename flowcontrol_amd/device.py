@@ -247,14 +247,25 @@ class DeviceSolver:
             raise _lib.FcDiverged(_lib.FC_ERR_DIVERGED, "non-finite velocity after solve")
         return tail[: self.n_sens].copy(), (float(tail[64]) if compute_energy else float("nan")), info
 
-    def step(self, order_slot: int, u_ctrl, compute_energy: bool = True):
+    def set_rhs_operator(self, slot: int, Cmat: sp.csr_matrix | None) -> None:
+        """b -= C u_n with C given in W numbering (N × 2nn); rows are permuted here."""
+        if Cmat is None:
+            check(self.lib.fc_set_rhs_operator(self._h, slot, None, None, None))
+            return
+        Cp = Cmat.tocsr()[self.tree.perm].tocsr()
+        Cp.eliminate_zeros()
+        Cp.sort_indices()
+        check(self.lib.fc_set_rhs_operator(self._h, slot, ptr(_i32(Cp.indptr)), ptr(_i32(Cp.indices)), ptr(_f64(Cp.data))))
+
+    def step(self, order_slot: int, u_ctrl, compute_energy: bool = True, u_force=None):
         u = _f64(np.atleast_1d(u_ctrl)) if self.n_act else None
+        uf = _f64(np.atleast_1d(u_force)) if (self.n_act and u_force is not None) else None
         if self.world > 1 and getattr(self, "_host_allreduce", None) is not None:
             return self._step_host_staged(order_slot, u, compute_energy)
         y = np.empty(max(self.n_sens, 1))
         info = np.empty(4)
         dE = C.c_double()
-        check(self.lib.fc_step(self._h, order_slot, ptr(u), ptr(y), C.byref(dE), int(compute_energy), ptr(info)))
+        check(self.lib.fc_step(self._h, order_slot, ptr(u), ptr(uf), ptr(y), C.byref(dE), int(compute_energy), ptr(info)))
         return y[: self.n_sens], dE.value, info
 
     def run(self, first_order_slot: int, n_steps: int, u_ctrl, compute_energy: bool = True):

@@ -361,9 +361,8 @@ class FlowSolver(ABC):
         self.exporter.log_ic(t=self.params_time.Tstart, y_meas=self.y_meas, dE=self._dE_host)
 
     def _initialize_with_ic(self, ic: Function | None = None):
-        if self.params_solver.time_scheme == "cn":
-            raise NotImplementedError("time_scheme='cn' is not available on the MI355X path yet")
-        self.order = 1
+        self.order = "cn" if self.params_solver.time_scheme == "cn" else 1
+        self._u_ctrl_prev = None
         self.iter = 0
         self.t = self.params_time.Tstart
         self.fields.ic = FlowField(up=Function(self.W) if ic is None else ic)
@@ -419,8 +418,7 @@ class FlowSolver(ABC):
     def _initialize_at_time(self, Tstart: float):
         meta, counter, base_dir = self._find_restart_source(Tstart)
         self.order = meta["restart_order"]
-        if self.order == "cn":
-            raise NotImplementedError("time_scheme='cn' is not available on the MI355X path yet")
+        self._u_ctrl_prev = None
         self.iter = 0
         self.t = Tstart
         U_path, Uprev_path, P_path = (base_dir / meta["files"][k] for k in ("U", "Uprev", "P"))
@@ -446,8 +444,6 @@ class FlowSolver(ABC):
     def _prepare_systems(self, u_n: Function | None = None, u_nn: Function | None = None) -> None:
         """Assemble both LHS operators on the device, eliminate Dirichlet dofs, factorise, and ship
         BC / force / sensor tables — the one-time work of reference ``:665-701``."""
-        if self.params_solver.time_scheme == "cn":
-            raise NotImplementedError("time_scheme='cn' is not available on the MI355X path yet")
         if self.fields.U0 is None:
             raise RuntimeError("no base flow: call compute_steady_state() or load_steady_state() first")
         dev = self.th.device()
@@ -460,14 +456,26 @@ class FlowSolver(ABC):
         dev.set_time_scheme(self.params_time.dt, self.params_solver.is_eq_nonlinear)
         self._ensure_mass()
         self.solvers: dict[int | str, Any] = {}
-        for order, slot in ((1, SLOT_BDF1), (2, SLOT_BDF2)):
-            F = self.forms.transient(order=order, U0=U0, u_n=u_n, u_nn=u_nn, f=None)
+        scheme = self.params_solver.time_scheme
+        orders = (("cn", SLOT_BDF1),) if scheme == "cn" else ((1, SLOT_BDF1), (2, SLOT_BDF2))
+        for order, slot in orders:
+            F = self.forms.transient(order=order, U0=U0, u_n=u_n, u_nn=u_nn, f=None, f_n=0.0)
             a = F.a
-            dev.assemble_matrix(slot, mass=a.mass, nu=a.nu, adv=a.adv, lin=a.lin, pressure=a.pressure, divergence=a.divergence)
+            dev.assemble_matrix(slot, mass=a.mass, nu=a.nu, adv=a.adv, lin=a.lin, adv_scale=a.adv_scale, lin_scale=a.lin_scale,
+                                pressure=a.pressure, divergence=a.divergence)
             dev.apply_bc(slot)
             solver = self._make_solver(order=order)
             solver.set_operator(slot)
             self.solvers[order] = solver
+            if F.explicit is not None:
+                from ._lib import SLOT_SCRATCH
+
+                c = F.explicit
+                dev.assemble_matrix(SLOT_SCRATCH, mass=c.mass, nu=c.nu, adv=c.adv, lin=c.lin, adv_scale=c.adv_scale,
+                                    lin_scale=c.lin_scale, pressure=c.pressure, divergence=c.divergence)
+                dev.set_rhs_operator(slot, dev.matrix(SLOT_SCRATCH)[:, : 2 * self.th.nn])
+            else:
+                dev.set_rhs_operator(slot, None)
         self._systems_ready = True
 
     def _join_process_group(self, dev) -> None:
@@ -544,8 +552,13 @@ class FlowSolver(ABC):
         self.set_actuators_u_ctrl(u_ctrl)
         next_iter = self.iter + 1
         want_energy = self._niter_multiple_of(next_iter, self.params_save.energy_every)
+        u_force = None
+        if self.order == "cn":
+            # Crank–Nicolson averages the body force: ½(f^{n+1} + f^n), f^0 = 0 (flowsolver.py:681-686,755-758)
+            prev = np.zeros_like(u_ctrl) if self._u_ctrl_prev is None else self._u_ctrl_prev
+            u_force = 0.5 * (u_ctrl + prev)
         try:
-            y, dE, info = self.th.device().step(SLOT_BDF1 if self.order == 1 else SLOT_BDF2, u_ctrl, compute_energy=want_energy)
+            y, dE, info = self.th.device().step(SLOT_BDF2 if self.order == 2 else SLOT_BDF1, u_ctrl, compute_energy=want_energy, u_force=u_force)
         except FcDiverged:
             logger.critical("Solver diverged (Inf detected)")
             if not self.params_solver.throw_error:
@@ -554,7 +567,9 @@ class FlowSolver(ABC):
         self.solve_info = info
         self.iter = next_iter
         self.t = self.params_time.Tstart + self.iter * self.params_time.dt
-        self.order = 2
+        self._u_ctrl_prev = u_ctrl.copy()
+        if self.params_solver.time_scheme != "cn":
+            self.order = 2
         self.fields._mark_stale()
         self.y_meas = y.copy()
         runtime = time.time() - t0
@@ -564,7 +579,7 @@ class FlowSolver(ABC):
         self.exporter.log(u_ctrl=u_ctrl, y_meas=self.y_meas, dE=dE if want_energy else np.nan, t=self.t, runtime=runtime)
         if at_checkpoint:
             self.exporter.export_xdmf(self.fields.u_n, self.fields.u_nn, self.fields.p_n, time=self.t, adjust_baseflow=1.0)
-            self.exporter.write_metadata(restart_order=2)
+            self.exporter.write_metadata(restart_order="cn" if self.params_solver.time_scheme == "cn" else 2)
             self.exporter.write_timeseries()
         return self.y_meas
 
@@ -578,6 +593,8 @@ class FlowSolver(ABC):
                 self._upload_state()
             self.first_step = False
         u = np.asarray(u_ctrl, dtype=np.float64)
+        if self.order == "cn":
+            raise NotImplementedError("FlowSolver.run (batched) supports the BDF scheme only; use step() with time_scheme='cn'")
         t0 = time.time()
         try:
             y, dE = self.th.device().run(SLOT_BDF1 if self.order == 1 else SLOT_BDF2, n_steps, u, compute_energy=bool(self.params_save.energy_every))

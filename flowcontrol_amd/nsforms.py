@@ -24,6 +24,8 @@ class BilinearCoefficients:
     lin: np.ndarray | None = None  # field whose gradient multiplies the trial function
     pressure: float = -1.0
     divergence: float = -1.0
+    adv_scale: float = 1.0
+    lin_scale: float = 1.0
 
 
 @dataclass
@@ -39,6 +41,7 @@ class TransientForm:
     order: int | str
     a: BilinearCoefficients
     L: LinearCoefficients
+    explicit: BilinearCoefficients | None = None  # operator C with rhs -= C u_n (Crank–Nicolson)
 
 
 class NSForms:
@@ -65,7 +68,11 @@ class NSForms:
         elif order == "cn":
             if f_n is None:
                 raise ValueError("f_n is required for Crank-Nicolson form")
-            raise NotImplementedError("Crank–Nicolson is not implemented on the MI355X path yet (BDF only)")
+            # θ = ½ on the linear terms, explicit (u_n·∇)u_n, implicit pressure (nsforms.py:191-236)
+            a = BilinearCoefficients(mass=1.0 / dt - self.shift, nu=0.5 * self.invRe, adv=U, lin=U, adv_scale=0.5, lin_scale=0.5)
+            L = LinearCoefficients(cm_n=1.0 / dt, cc_n=-nl)
+            C = BilinearCoefficients(mass=0.0, nu=0.5 * self.invRe, adv=U, lin=U, adv_scale=0.5, lin_scale=0.5, pressure=0.0, divergence=0.0)
+            return TransientForm(order, a, L, explicit=C)
         else:
             raise ValueError(f"order must be 1, 2, or 'cn', got {order}")
         return TransientForm(order, a, L)

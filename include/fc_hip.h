@@ -117,6 +117,10 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
                     /* multi-GPU: after stage `ar_stage` (-1: none) the rows [ar_row0, ar_row0+ar_n) of the
                      * work buffer are summed over the ranks (RCCL all-reduce) */
                     int32_t ar_stage, int32_t ar_row0, int32_t ar_n);
+/* optional explicit operator C of the right-hand side, b -= C u_n (rows in the solver's permuted
+ * numbering, columns = velocity dofs in W numbering): the explicit half of the linear terms of the
+ * Crank-Nicolson form (NSForms._cn, nsforms.py:191-236).  rowptr == NULL removes it. */
+int fc_set_rhs_operator(fc_handle h, int slot, const int32_t* rowptr, const int32_t* col, const double* val);
 /* velocity mass matrix (u,v) in the solver's permuted numbering, CSR with N rows (pressure rows
  * empty): the matrix behind compute_perturbation_energy (flowsolver.py:827-829), used by the
  * fused step tail */
@@ -134,8 +138,10 @@ int fc_get_solution(fc_handle h, double* up /* [N] last solve, W layout */);
  *    (flowsolver.py:724-779).  order_slot is FC_SLOT_BDF1 or FC_SLOT_BDF2.
  *    y_out[n_sens], dE_out (1/2 |u|^2_L2, NaN if compute_energy == 0), info_out[4] =
  *    {iterations, relative residual of the first refinement residual, |b|, flags}. ------------- */
-int fc_step(fc_handle h, int order_slot, const double* u_ctrl /* [n_act] */, double* y_out,
-            double* dE_out, int compute_energy, double* info_out);
+int fc_step(fc_handle h, int order_slot, const double* u_ctrl /* [n_act] */,
+            const double* u_force /* [n_act] body-force amplitudes, NULL = u_ctrl (CN passes the
+                                     mean of the new and the previous control, nsforms.py:224-226) */,
+            double* y_out, double* dE_out, int compute_energy, double* info_out);
 /* n_steps open-loop steps without host synchronisation in between (u_ctrl constant or a
  * sequence [n_steps][n_act]); y_seq [n_steps][n_sens], dE_seq [n_steps] (may be NULL). */
 int fc_run(fc_handle h, int first_order_slot, int32_t n_steps, const double* u_ctrl,

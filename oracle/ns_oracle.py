@@ -386,6 +386,46 @@ class TimeStepper:
         return self.solve(order, self.rhs(order, u_n, u_nn, u_ctrl))
 
 
+class TimeStepperCN:
+    """Crank–Nicolson variant (``NSForms._cn``, ``nsforms.py:191-236``; ``flowsolver.py:681-686,755-758``):
+    θ=½ on the linear terms, explicit perturbation advection, fully implicit pressure, body force
+    ½(f^{n+1} + f^n) with f^n the force of the previous step (zero before the first step)."""
+
+    def __init__(self, d: Disc, Re: float, dt: float, U0: np.ndarray, bc_dofs, bc_profiles, force_profiles=None,
+                 nonlinear=True, shift=0.0, perm=None):
+        self.d, self.dt, self.nonlinear, self.perm = d, dt, nonlinear, perm
+        self.bc_dofs = np.asarray(bc_dofs, dtype=np.int64)
+        self.bc_profiles = np.asarray(bc_profiles, dtype=np.float64).reshape(len(self.bc_dofs), -1)
+        self.force_profiles = force_profiles
+        nu = 1.0 / Re
+        self.A_full = assemble_matrix(d, mass=1.0 / dt - shift, nu=0.5 * nu, adv=U0, lin=U0, adv_scale=0.5, lin_scale=0.5)
+        self.C = assemble_matrix(d, mass=0.0, nu=0.5 * nu, adv=U0, lin=U0, adv_scale=0.5, lin_scale=0.5, pressure=0.0, divergence=0.0)
+        self.A_bc, _ = apply_bc_symmetric(self.A_full, None, self.bc_dofs, np.zeros(len(self.bc_dofs)))
+        self.lu = None
+        self.u_ctrl_prev = None
+
+    def rhs(self, u_n, u_ctrl, u_ctrl_prev=None) -> np.ndarray:
+        u_ctrl = np.atleast_1d(np.asarray(u_ctrl, dtype=np.float64))
+        f = None
+        if self.force_profiles is not None:
+            prev = np.zeros_like(u_ctrl) if u_ctrl_prev is None else np.atleast_1d(u_ctrl_prev)
+            f = self.force_profiles @ (0.5 * (u_ctrl + prev))
+        b = rhs_transient(self.d, 1, self.dt, u_n, None, f, self.nonlinear)
+        b = b - self.C @ np.r_[u_n, np.zeros(self.d.nv)]
+        g = np.zeros(self.d.N)
+        g[self.bc_dofs] = self.bc_profiles @ u_ctrl
+        b = b - self.A_full @ g
+        b[self.bc_dofs] = g[self.bc_dofs]
+        return b
+
+    def step(self, u_n, u_ctrl) -> np.ndarray:
+        if self.lu is None:
+            self.lu = _lu(self.A_bc, self.perm)
+        b = self.rhs(u_n, u_ctrl, self.u_ctrl_prev)
+        self.u_ctrl_prev = np.atleast_1d(np.asarray(u_ctrl, dtype=np.float64)).copy()
+        return self.lu.solve(b)
+
+
 def div0_gaussian_nodal(x: np.ndarray, xloc: float, yloc: float, size: float) -> np.ndarray:
     """``get_div0_u`` (``utils/physics.py:32-56``): ψ = 0.25·exp(−r²/(2 s²)),
     u = (∂ψ/∂y, −∂ψ/∂x) evaluated at the P2 nodes ``x`` (n,2) → (n,2)."""

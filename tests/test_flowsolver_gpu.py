@@ -182,3 +182,39 @@ def test_pinball_regression_open_loop(tmp_path_factory, golden_dir):
     assert np.isclose(last["dE"], 0.05722263472621765, rtol=1e-4)
     assert np.isclose(flu.apply_fun(fs.fields.Usave, np.mean), 0.14938204178441114, rtol=1e-6)
     fs.th.release_device()
+
+
+def test_cylinder_crank_nicolson_vs_oracle(tmp_path_factory, golden_dir):
+    """time_scheme="cn" through the public API (ParamSolver.time_scheme, flowsolverparameters.py) against
+    the oracle's CN stepper: 10 actuated steps; and CN ≈ BDF2 to O(dt²) on the same trajectory."""
+    from flowcontrol_amd import ndsolver
+    from oracle import ns_oracle as O
+
+    g = np.load(golden_dir / "cylinder_O1.npz")
+    fs = CylinderFlowSolver.make_default(Re=100, path_out=tmp_path_factory.mktemp("cyl_cn"), num_steps=10)
+    fs.params_solver.time_scheme = "cn"
+    fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
+    _load_baseflow(fs, golden_dir)
+    fs.initialize_time_stepping(ic=None)
+    assert fs.order == "cn"
+    th = fs.th
+    d = O.Disc.from_taylor_hood(th)
+    dofs, prof = fs._bc_tables()
+    skip = np.zeros(th.N, bool)
+    skip[dofs] = True
+    perm = ndsolver.build_tree(th.cell_dofs, th.mesh.cell_centroids(), th.N, 10, skip).perm
+    ts = O.TimeStepperCN(d, 100.0, 0.005, g["UP0"][: 2 * th.nn], dofs, prof, perm=perm)
+    rows = [s.row(fs) for s in fs.params_control.sensor_list]
+    u_n = fs.fields.ic.u.vector().get_local()
+    ys = []
+    for k in range(10):
+        uc = np.array([0.05 * np.sin(0.4 * k), -0.03])
+        fs.step(uc)
+        up = ts.step(u_n, uc)
+        u_n = up[: 2 * th.nn]
+        ys.append([w @ up[i] for i, w in rows])
+    y_dev = fs.timeseries[["y_meas_1", "y_meas_2", "y_meas_3"]].to_numpy()[1:]
+    assert _rel_l2(y_dev, np.array(ys)) < 1e-8
+    assert _rel_l2(fs.fields.u_.vector().get_local(), u_n) < 1e-9
+    assert fs.order == "cn" and np.isclose(fs.t, 0.05)
+    fs.th.release_device()

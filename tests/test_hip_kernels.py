@@ -146,3 +146,39 @@ def test_rhs_solve_step(setup, order):
     g_un, g_unn, g_pn = dev.get_state()
     assert _rel(g_un, u_new) < 1e-10 and np.array_equal(g_unn, u_n)
     assert info[1] < 1e-9  # relative residual before refinement
+
+
+def test_crank_nicolson_step(setup):
+    """CN = BDF1 element rhs − C u_n + ½(f^{n+1}+f^n), LHS with θ=½ on the linear terms
+    (reference NSForms._cn, nsforms.py:191-236) — device vs oracle, two consecutive steps."""
+    th, dev, d, O = setup
+    from flowcontrol_amd.device import SLOT_BDF1, SLOT_SCRATCH
+
+    dt, Re = 0.01, 50.0
+    U0 = _smooth_velocity(th)
+    dofs, prof = _bc_setup(th)
+    x = th.node_coords
+    fprof = np.stack([np.r_[np.exp(-((x[:, 0] - 0.4) ** 2 + (x[:, 1] - 0.5) ** 2) / 0.02), 0 * x[:, 0]],
+                      np.r_[0 * x[:, 0], np.sin(x[:, 0]) * np.cos(x[:, 1])]])  # (n_act=2, 2nn)
+    dev.set_bc(dofs, prof)
+    dev.set_force(fprof)
+    dev.set_time_scheme(dt, True)
+    dev.assemble_matrix(SLOT_BDF1, mass=1.0 / dt, nu=0.5 / Re, adv=U0, lin=U0, adv_scale=0.5, lin_scale=0.5)
+    dev.apply_bc(SLOT_BDF1)
+    dev.setup_solver(SLOT_BDF1)
+    dev.assemble_matrix(SLOT_SCRATCH, mass=0.0, nu=0.5 / Re, adv=U0, lin=U0, adv_scale=0.5, lin_scale=0.5, pressure=0.0, divergence=0.0)
+    dev.set_rhs_operator(SLOT_BDF1, dev.matrix(SLOT_SCRATCH)[:, : 2 * th.nn])
+    dev.set_sensors([])
+    ts = O.TimeStepperCN(d, Re, dt, U0, dofs, prof, force_profiles=fprof.T)
+    u_n = 0.1 * _smooth_velocity(th, 2.0)
+    dev.set_state(u_n, u_n, np.zeros(th.nv))
+    prev = None
+    for uc in (np.array([0.3, -0.2]), np.array([-0.1, 0.4])):
+        uf = 0.5 * (uc + (0 if prev is None else prev))
+        dev.step(SLOT_BDF1, uc, compute_energy=True, u_force=uf)
+        up_ref = ts.step(u_n, uc)
+        assert _rel(dev.get_solution(), up_ref) < 1e-10
+        u_n = up_ref[: 2 * th.nn]
+        prev = uc
+    dev.set_rhs_operator(SLOT_BDF1, None)
+    dev.set_force(None)
