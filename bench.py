@@ -65,8 +65,15 @@ def cpu_baseline(fs, n_steps: int = 120, warm: int = 3) -> dict:
     """Oracle leg: same mesh/dt/IC; element-loop RHS (numpy) + SuperLU triangular solves with the
     nested-dissection ordering (the best CPU ordering found, BASELINE.md §2) + sensors + energy;
     1 thread; mean over steps ≥ 3 so both factorisations are excluded (utils/fem.py:94-96)."""
+    from threadpoolctl import threadpool_limits
+
     from oracle import ns_oracle as O
 
+    with threadpool_limits(limits=1):  # "cores": 1 — no hidden BLAS / OpenMP threads
+        return _cpu_baseline_1core(fs, O, n_steps, warm)
+
+
+def _cpu_baseline_1core(fs, O, n_steps, warm) -> dict:
     th = fs.th
     d = O.Disc.from_taylor_hood(th)
     U0 = fs.fields.U0.vector().array()
@@ -77,11 +84,15 @@ def cpu_baseline(fs, n_steps: int = 120, warm: int = 3) -> dict:
     rows = [s.row(fs) for s in fs.params_control.sensor_list]
     u_n = fs.fields.ic.u.vector().array().copy()
     u_nn = u_n.copy()
-    order, times = 1, []
+    order, times, t_asm, t_sol = 1, [], [], []
     y = None
     for _ in range(n_steps + warm):
         t0 = time.perf_counter()
-        up = ts.step(order, u_n, u_nn, np.zeros(2))
+        b = ts.rhs(order, u_n, u_nn, np.zeros(2))
+        t1 = time.perf_counter()
+        up = ts.solve(order, b)
+        t2 = time.perf_counter()
+        t_asm.append(t1 - t0), t_sol.append(t2 - t1)
         order = 2
         u_nn, u_n = u_n, up[: 2 * th.nn]
         y = np.array([w @ up[i] for i, w in rows])
@@ -94,7 +105,9 @@ def cpu_baseline(fs, n_steps: int = 120, warm: int = 3) -> dict:
         "cores": 1,
         "kind": "port",
         "sample": f"{n_steps} steps of the same workload after {warm} warm-up steps (factorisations excluded); "
-        f"{mean * 1e3:.1f} ms/step; host has {os.cpu_count()} logical cores",
+        f"{mean * 1e3:.1f} ms/step = numpy element-loop RHS {np.mean(t_asm[warm:]) * 1e3:.1f} ms + SuperLU triangular solves "
+        f"(ND ordering) {np.mean(t_sol[warm:]) * 1e3:.1f} ms + sensors/energy; 1 thread (threadpool_limits); "
+        f"host has {os.cpu_count()} logical cores",
         "_y_last": y.tolist(),
         "_dE_last": float(dE),
     }

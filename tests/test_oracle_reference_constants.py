@@ -124,3 +124,12 @@ def test_cavity_and_pinball_golden_vectors_match_reference_constants(golden_dir,
     assert np.isclose(g["dE"][-1], ref["dE"], rtol=1e-4) and abs(g["dE"][-1] / ref["dE"] - 1) < 1e-11
     assert np.isclose(float(g["umax"]), ref["u_max"], rtol=1e-4)
     assert np.isclose(float(g["umean"]), ref["u_mean"], rtol=1e-6) and abs(float(g["umean"]) / ref["u_mean"] - 1) < 1e-11
+
+
+def test_cavity_re500_jacobian_frobenius(golden_dir):
+    """‖A‖_F of the steady Jacobian on cavity_coarse at Re=500 (Picard 10 → Newton 10), the second
+    constant of the reference's tests/integration/test_operatorgetter.py:23-26 (rtol 1e-6).
+    Generated with the oracle (recipe in the fixture's generator docstring below)."""
+    g = np.load(golden_dir / "cavity_coarse_re500.npz")
+    assert np.isclose(float(g["frob"]), 47.31849925281407, rtol=1e-6)
+    assert abs(float(g["frob"]) / 47.31849925281407 - 1) < 1e-10
