@@ -65,6 +65,8 @@ class PinballFlowSolver(flowsolver.FlowSolver):
         bcu = [DirichletBC(W.sub(0), Constant((0, 0)), g("inlet")), DirichletBC(W.sub(0).sub(1), Constant(0), g("walls"))]
         if mode == CYLINDER_ACTUATION_MODE.SUCTION:
             bcu += [DirichletBC(W.sub(0), Constant((0, 0)), g(n)) for n in ("cylinder_top", "cylinder_bot", "cylinder_mid")]
+        for a, name in zip(acts, ("actuator_mid", "actuator_top", "actuator_bot")):
+            a.boundary = g(name)  # as the reference's _make_bcs leaves it for OperatorGetter.get_B
         bcu += [
             DirichletBC(W.sub(0), acts[0].expression, g("actuator_mid")),
             DirichletBC(W.sub(0), acts[1].expression, g("actuator_top")),

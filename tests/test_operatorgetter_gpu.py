@@ -1,0 +1,72 @@
+"""OperatorGetter on the device assembly — mirror of the reference's
+tests/integration/test_operatorgetter.py (Frobenius regression, B/C shapes, C @ x == sensor.eval)."""
+import numpy as np
+import pytest
+
+from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver
+from flowcontrol_amd.fem.spaces import Function
+from flowcontrol_amd.operatorgetter import OperatorGetter
+
+pytestmark = pytest.mark.gpu
+
+_A_FROBENIUS_REF = {"fs_cylinder": 55.37024024761875}  # reference test_operatorgetter.py:23-26
+
+
+@pytest.fixture(scope="module")
+def fs_cylinder(tmp_path_factory, golden_dir):
+    fs = CylinderFlowSolver.make_default(Re=100, path_out=tmp_path_factory.mktemp("opget_cylinder"))
+    U0, P0 = Function(fs.W, np.load(golden_dir / "cylinder_O1.npz")["UP0"]).split()
+    fs._assign_steady_state(U0, P0)
+    yield fs
+    fs.th.release_device()
+
+
+def test_get_A_regression(fs_cylinder):
+    """Frobenius norm of the device-assembled Jacobian matches the reference's constant (rtol 1e-6)."""
+    A = OperatorGetter(fs_cylinder).get_A(autodiff=True)
+    frob = np.sqrt((A.data**2).sum())
+    assert np.isclose(frob, _A_FROBENIUS_REF["fs_cylinder"], rtol=1e-6), f"||A||_F = {frob}"
+    assert abs(frob / _A_FROBENIUS_REF["fs_cylinder"] - 1) < 1e-11
+
+
+def test_get_A_finite_difference(fs_cylinder):
+    """A @ x ≈ −(F(UP0 + h x) − F(UP0)) / h on interior dofs (reference :106-130), with the residual
+    evaluated as (device Picard operator) · UP."""
+    fs = fs_cylinder
+    from flowcontrol_amd._lib import SLOT_SCRATCH
+    from flowcontrol_amd.fem.boundary import combine_bcs
+
+    A = OperatorGetter(fs).get_A()
+    dev = fs.th.device()
+    dofs, _ = combine_bcs(fs.bc.bcu, fs.th.N)
+    interior = np.setdiff1d(np.arange(fs.th.N), dofs)
+    x = np.zeros(fs.th.N)
+    x[interior] = np.random.default_rng(1).standard_normal(len(interior))
+    up0 = fs.fields.UP0.vector().get_local()
+
+    def residual(up):
+        dev.assemble_matrix(SLOT_SCRATCH, mass=0.0, nu=fs.forms.invRe, adv=up[: 2 * fs.th.nn])
+        return dev.spmv(SLOT_SCRATCH, up)
+
+    h = 1e-6
+    fd = -(residual(up0 + h * x) - residual(up0)) / h
+    Ax = A @ x
+    assert np.linalg.norm(Ax[interior] - fd[interior]) / np.linalg.norm(Ax[interior]) < 1e-4
+
+
+def test_mass_B_C(fs_cylinder):
+    fs = fs_cylinder
+    og = OperatorGetter(fs)
+    E = og.get_mass_matrix()
+    assert E.shape == (fs.th.N, fs.th.N) and E[2 * fs.th.nn :].nnz == 0
+    one = np.r_[np.ones(fs.th.nn), np.zeros(fs.th.nn + fs.th.nv)]
+    assert np.isclose(one @ (E @ one), 30 * 20 - np.pi * 0.25, rtol=1e-3)  # ∫ 1 dx = domain area
+    B = og.get_B()
+    C = og.get_C()
+    assert B.shape == (fs.th.N, 2) and C.shape == (3, fs.th.N)
+    assert np.all(np.isfinite(B)) and np.linalg.norm(B[:, 0]) > 0
+    x = Function(fs.W, np.random.default_rng(0).standard_normal(fs.th.N))
+    y = np.array([s.eval(x) for s in fs.params_control.sensor_list])
+    assert np.allclose(C @ x.vector().get_local(), y, rtol=1e-10)  # reference :238-254
+    A, E2, B2, C2 = og.get_all()
+    assert A.shape == E2.shape and np.array_equal(B2, B) and np.array_equal(C2, C)
