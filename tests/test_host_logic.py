@@ -271,3 +271,49 @@ def test_nd_block_factors_solve_saddle_point_system(depth, merge):
         cols = fb.seg_col[q0:q1]
         if fb.stage_kind[s] == 0:
             assert np.all(cols >= 0) and np.all(cols + fb.seg_len[q0:q1] <= r0)  # deeper levels come first
+
+
+# ── dolfin look-alike: the reference's C++ predicate / expression strings evaluated with numpy ──
+def test_compiled_subdomains_reproduce_the_case_file_boundaries():
+    """The six cylinder boundaries built from the *strings* of the reference's case file
+    (cylinderflowsolver.py:35-83, via the utils/fem.py string helpers) mark exactly the facets that the
+    hand-written numpy predicates of flowcontrol_amd's case file mark."""
+    from flowcontrol_amd import dolfin_compat as dolfin
+
+    fs = CylinderFlowSolver.make_default(path_out=tempfile.mkdtemp())
+    near_cpp, between_cpp, and_cpp, or_cpp, ob = dolfin.near_cpp, dolfin.between_cpp, dolfin.and_cpp(), dolfin.or_cpp(), dolfin.on_boundary_cpp()
+    TOL = dolfin.DOLFIN_EPS
+    radius, ldelta = 0.5, fs.params_control.actuator_list[0].width
+    close = between_cpp("x[0]", "-radius", "radius") + and_cpp + between_cpp("x[1]", "-radius", "radius")
+    cyl_b = ob + and_cpp + close
+    cone_up = between_cpp("x[0]", "-ldelta", "ldelta", tol="0.01") + and_cpp + between_cpp("x[1]", "0", "radius")
+    cone_lo = between_cpp("x[0]", "-ldelta", "ldelta", tol="0.01") + and_cpp + between_cpp("x[1]", "-radius", "0")
+    subs = {
+        "inlet": dolfin.CompiledSubDomain(ob + and_cpp + near_cpp("x[0]", "xinfa", "MESH_TOL"), xinfa=-10, MESH_TOL=TOL),
+        "outlet": dolfin.CompiledSubDomain(ob + and_cpp + near_cpp("x[0]", "xinf", "MESH_TOL"), xinf=20, MESH_TOL=TOL),
+        "walls": dolfin.CompiledSubDomain(ob + and_cpp + "(" + near_cpp("x[1]", "-yinf", "MESH_TOL") + or_cpp + near_cpp("x[1]", "yinf", "MESH_TOL") + ")", yinf=10, MESH_TOL=TOL),
+        "cylinder": dolfin.CompiledSubDomain(cyl_b + and_cpp + "(" + between_cpp("x[0]", "-radius", "-ldelta") + or_cpp + between_cpp("x[0]", "ldelta", "radius") + ")", radius=radius, ldelta=ldelta),
+        "actuator_up": dolfin.CompiledSubDomain(cyl_b + and_cpp + cone_up, radius=radius, ldelta=ldelta),
+        "actuator_lo": dolfin.CompiledSubDomain(cyl_b + and_cpp + cone_lo, radius=radius, ldelta=ldelta),
+    }
+    for name, sd in subs.items():
+        assert np.array_equal(sd.mark_facets(fs.mesh), fs.get_subdomain(name).mark_facets(fs.mesh)), name
+
+
+def test_c_expression_strings_of_the_actuators():
+    from flowcontrol_amd import dolfin_compat as dolfin
+
+    # reference actuator.py:190-199 (parabolic slot) and :241-251 (rotation)
+    e = dolfin.Expression(["0", "(x[0]-x0>=L || x[0]-x0<=-L) ? 0 : u_ctrl * -1*(x[0]-x0+L)*(x[0]-x0-L) / (L*L)"], element=None, L=0.2, x0=1.0, u_ctrl=0.0)
+    a = ActuatorBCParabolicV(width=0.2, position_x=1.0)._load_expression(None, None)
+    x = np.random.default_rng(0).uniform(0.5, 1.5, (50, 2))
+    e.u_ctrl = a.u_ctrl = 1.7
+    assert np.allclose(e(x), a(x))
+    r = dolfin.Expression(["-sin(atan2(x[1]-y0,x[0]-x0))*u_ctrl*d/2", "cos(atan2(x[1]-y0,x[0]-x0))*u_ctrl*d/2"], element=None, y0=0.1, x0=-0.2, u_ctrl=0.0, d=1.0)
+    b = ActuatorBCRotation(position_x=-0.2, position_y=0.1, diameter=1.0)._load_expression(None, None)
+    r.u_ctrl = b.u_ctrl = -0.8
+    assert np.allclose(r(x), b(x))
+    f = dolfin.compile_c_expression("a > 1 && !(b <= 2) || -c * 2 + 1 == 3 ? pow(a, 2) : exp(0) / 4")
+    assert np.allclose(f({"a": np.array([2.0, 0.0, 0.0]), "b": np.array([3.0, 0.0, 0.0]), "c": np.array([0.0, -1.0, 0.0])}), [4.0, 0.0, 0.25])
+    with pytest.raises(ValueError):
+        dolfin.compile_c_expression("foo(1)")({})
