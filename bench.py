@@ -45,18 +45,47 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+REFINE = 0  # --refine K: BASELINE config 4 (O1 red-refined K times, cylinder midpoints projected to r = 0.5)
+
+
+def refined_mesh_file(levels: int) -> Path:
+    """Write the refined O1 mesh next to the temp outputs and return its path (.npz)."""
+    from flowcontrol_amd.fem.mesh import read_xdmf_mesh
+
+    m = read_xdmf_mesh(GOLDEN / "meshes" / "O1.npz", reorder=False)
+
+    def project(mid, is_boundary):
+        r = np.hypot(mid[:, 0], mid[:, 1])
+        on_cyl = is_boundary & (r < 0.6)
+        out = mid.copy()
+        out[on_cyl] *= (0.5 / r[on_cyl])[:, None]
+        return out
+
+    for _ in range(levels):
+        m = m.refine(project)
+    path = Path(tempfile.mkdtemp(prefix="fc_mesh_")) / f"O1_refined{levels}.npz"
+    np.savez(path, coords=m.coords, cells=m.cells)
+    return path
+
+
 def build_solver(device: int, distributed: bool = False):
     from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver
     from flowcontrol_amd.fem.spaces import Function
     from flowcontrol_amd.flowsolverparameters import ParamIC
 
-    fs = CylinderFlowSolver.make_default(Re=100, path_out=tempfile.mkdtemp(prefix="fc_bench_"), num_steps=0, save_every=0)
+    meshpath = refined_mesh_file(REFINE) if REFINE else None
+    fs = CylinderFlowSolver.make_default(Re=100, path_out=tempfile.mkdtemp(prefix="fc_bench_"), num_steps=0, save_every=0, meshpath=meshpath)
     fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
     fs.distributed = distributed
     fs.th.device(device)
-    up0 = np.load(GOLDEN / "cylinder_O1.npz")["UP0"]
-    U0, P0 = Function(fs.W, up0).split()
-    fs._assign_steady_state(U0, P0)
+    if REFINE:
+        # no golden base flow for the refined mesh: compute it as the reference's scripts do (setup, untimed)
+        fs.compute_steady_state(method="picard", max_iter=3, tol=1e-7, u_ctrl=[0.0, 0.0])
+        fs.compute_steady_state(method="newton", max_iter=25, u_ctrl=[0.0, 0.0], initial_guess=fs.fields.UP0)
+    else:
+        up0 = np.load(GOLDEN / "cylinder_O1.npz")["UP0"]
+        U0, P0 = Function(fs.W, up0).split()
+        fs._assign_steady_state(U0, P0)
     fs.initialize_time_stepping(ic=None)
     return fs
 
@@ -153,7 +182,10 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-spmv", action="store_true")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent replicas instead of the partitioned run")
+    ap.add_argument("--refine", type=int, default=0, help="red-refine the O1 mesh K times (BASELINE config 4: K=1); not the headline workload")
     args = ap.parse_args()
+    global REFINE
+    REFINE = args.refine
 
     import torch
     import torch.distributed as dist
@@ -290,8 +322,8 @@ def main() -> None:
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "cylinder Re=100, mesh O1 (12284 cells, 56203 dofs), dt=0.005, BDF2, open loop, "
-                "IC div-free vortex (2,0) r=0.5, sensors+energy every step",
+                "workload": f"cylinder Re=100, mesh O1{' red-refined x' + str(REFINE) if REFINE else ''} ({fs.th.nc} cells, {fs.th.N} dofs), "
+                "dt=0.005, BDF2, open loop, IC div-free vortex (2,0) r=0.5, sensors+energy every step",
                 "parallelism": "single GPU" if world == 1 else (
                     f"row-partitioned over {world} GPUs: one elimination sub-tree + its cells per rank, replicated root "
                     f"separator, 2 RCCL all-reduces per step" if partitioned

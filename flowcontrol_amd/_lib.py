@@ -15,7 +15,7 @@ from pathlib import Path
 import numpy as np
 
 CSRC = Path(__file__).resolve().parent / "csrc"
-LIB_PATH = CSRC / "libfc_hip.so"
+LIB_PATH = Path(os.environ["FC_LIB_PATH"]) if os.environ.get("FC_LIB_PATH") else CSRC / "libfc_hip.so"  # FC_LIB_PATH: tuning builds
 SOURCES = [CSRC / "fc_hip.hip", CSRC / "fc_kernels.hip.h", CSRC.parent.parent / "include" / "fc_hip.h"]
 
 FC_OK = 0
@@ -43,7 +43,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not Path(hipcc).exists():
         raise FcError(FC_ERR_HIP, "hipcc not found; cannot build libfc_hip.so")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", str(LIB_PATH), str(SOURCES[0])]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *os.environ.get("FC_HIPCC_FLAGS", "").split(),
+           "-o", str(LIB_PATH), str(SOURCES[0])]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
