@@ -78,6 +78,7 @@ SIGNATURES: dict[str, list] = {
     "fc_set_permutation": [_H, _ip],
     "fc_solver_setup": [_H, C.c_int, _ip, _ip, _dp, C.c_int32, _lp, _ip, _ip, _ip, _lp, C.c_int64, _lp, _ip, _ip, C.c_int64, _ip, C.c_int64, _dp, C.c_int32, C.c_int32, C.c_int32],
     "fc_set_energy_matrix": [_H, _ip, _ip, _dp],
+    "fc_solver_set_blocks": [_H, C.c_int, C.c_int32, _lp, _ip, _ip, C.c_int64, _lp, _ip, _ip, _ip, _ip, _ip, _ip, C.c_int64, C.c_int64],
     "fc_set_solver_options": [_H, C.c_int, C.c_int, C.c_double, C.c_int],
     "fc_set_state": [_H, _dp, _dp, C.c_void_p],
     "fc_get_state": [_H, C.c_void_p, C.c_void_p, C.c_void_p],

@@ -79,6 +79,8 @@ struct Stage {
   int nrows;
   int kind;  // 0 up, 1 down
   int lanes, sub;  // lanes per row, lanes per segment slot
+  int64_t blk_begin = 0;  // down stages: LDS-tiled block kernel (fc_nd_down_block) when blk_count > 0
+  int blk_count = 0, blk_lpr = 64;
   double bytes;  // algorithmic bytes of this launch
 };
 
@@ -91,6 +93,7 @@ struct OrderSys {
   int64_t Ap_nnz = 0;
   DevBuf<int64_t> seg_ptr;  // per-row segment lists of all stages, concatenated
   DevBuf<FcSeg> seg;
+  DevBuf<FcBlk> blk;
   DevBuf<int> f_idx;
   DevBuf<double> f_val;
   int64_t f_nnz = 0;
@@ -319,6 +322,19 @@ int launch_spmv(fc_ctx* h, int nrows, double mean, const int* rp, const int* col
 }
 
 int launch_sweep(fc_ctx* h, const OrderSys& S, const Stage& st) {
+  if (st.kind == 1 && st.blk_count > 0) {
+    FCCHK(time_begin(h, 0));
+    const FcBlk* bp = S.blk.p + st.blk_begin;
+    if (st.blk_lpr == 16)
+      hipLaunchKernelGGL((fc_nd_down_block<16>), dim3(st.blk_count), dim3(256), 0, h->stream, bp, S.f_idx.p, S.f_val.p, h->buf.p, h->N);
+    else if (st.blk_lpr == 32)
+      hipLaunchKernelGGL((fc_nd_down_block<32>), dim3(st.blk_count), dim3(256), 0, h->stream, bp, S.f_idx.p, S.f_val.p, h->buf.p, h->N);
+    else
+      hipLaunchKernelGGL((fc_nd_down_block<64>), dim3(st.blk_count), dim3(256), 0, h->stream, bp, S.f_idx.p, S.f_val.p, h->buf.p, h->N);
+    FCCHK(time_end(h));
+    HIPCHK(hipGetLastError());
+    return FC_OK;
+  }
   const int rpb = 256 / st.lanes;
   dim3 grid(nblocks(st.nrows, rpb)), block(256);
   const int64_t* rp = S.seg_ptr.p + st.rp_begin;
@@ -1068,6 +1084,53 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
   FCCHK(S.f_val.upload(vals, (size_t)n_val, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   S.ready = true;
+  return FC_OK;
+}
+
+int fc_solver_set_blocks(fc_handle h, int slot, int32_t n_stages, const int64_t* stage_blk_begin, const int32_t* stage_blk_count,
+                         const int32_t* stage_lpr, int64_t n_blk, const int64_t* blk_val, const int32_t* blk_row0,
+                         const int32_t* blk_nrows, const int32_t* blk_i0, const int32_t* blk_ni, const int32_t* blk_idx,
+                         const int32_t* blk_nb, int64_t n_idx, int64_t n_val) {
+  if (!h || slot < 0 || slot > 1 || !stage_blk_begin || !stage_blk_count || !stage_lpr || n_blk < 0 ||
+      (n_blk > 0 && (!blk_val || !blk_row0 || !blk_nrows || !blk_i0 || !blk_ni || !blk_idx || !blk_nb)))
+    return fail(FC_ERR_INVALID, "fc_solver_set_blocks: bad argument");
+  OrderSys& S = h->sys[slot];
+  if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup must be called first");
+  if (n_stages != (int)S.stages.size()) return fail(FC_ERR_INVALID, "fc_solver_set_blocks: stage count differs from fc_solver_setup");
+  if (n_val != S.f_nnz) return fail(FC_ERR_INVALID, "fc_solver_set_blocks: value count differs from fc_solver_setup");
+  HIPCHK(hipSetDevice(h->device));
+  const int N = h->N;
+  std::vector<FcBlk> packed((size_t)std::max<int64_t>(1, n_blk));
+  for (int64_t q = 0; q < n_blk; ++q) {
+    const int64_t wd = (int64_t)blk_ni[q] + blk_nb[q];
+    if (blk_nrows[q] <= 0 || blk_nrows[q] > 32 || blk_row0[q] < 0 || (int64_t)blk_row0[q] + blk_nrows[q] > N || blk_ni[q] < 0 ||
+        blk_nb[q] < 0 || blk_i0[q] < 0 || (int64_t)blk_i0[q] + blk_ni[q] > N || blk_idx[q] < 0 ||
+        (blk_nb[q] > 0 && (int64_t)blk_idx[q] + blk_nb[q] > n_idx) || blk_val[q] < 0 ||
+        blk_val[q] + (int64_t)blk_nrows[q] * wd > n_val)
+      return fail(FC_ERR_INVALID, "fc_solver_set_blocks: block descriptor out of range");
+    packed[q] = FcBlk{(long long)blk_val[q], blk_row0[q], blk_nrows[q], blk_i0[q], blk_ni[q], blk_idx[q], blk_nb[q]};
+  }
+  for (int s = 0; s < n_stages; ++s) {
+    Stage& st = S.stages[s];
+    if (stage_blk_count[s] < 0 || stage_blk_begin[s] < 0 || stage_blk_begin[s] + stage_blk_count[s] > n_blk)
+      return fail(FC_ERR_INVALID, "fc_solver_set_blocks: stage block range out of bounds");
+    if (stage_blk_count[s] > 0) {
+      if (st.kind != 1) return fail(FC_ERR_INVALID, "fc_solver_set_blocks: blocks are for down stages only");
+      if (stage_lpr[s] != 16 && stage_lpr[s] != 32 && stage_lpr[s] != 64) return fail(FC_ERR_INVALID, "fc_solver_set_blocks: lanes per row must be 16, 32 or 64");
+      // the blocks of a stage must tile exactly the stage's destination rows
+      int64_t rows = 0;
+      for (int64_t q = stage_blk_begin[s]; q < stage_blk_begin[s] + stage_blk_count[s]; ++q) {
+        if (blk_row0[q] < st.row0 || blk_row0[q] + blk_nrows[q] > st.row0 + st.nrows) return fail(FC_ERR_INVALID, "fc_solver_set_blocks: block outside its stage");
+        rows += blk_nrows[q];
+      }
+      if (rows != st.nrows) return fail(FC_ERR_INVALID, "fc_solver_set_blocks: blocks do not cover the stage rows");
+    }
+    st.blk_begin = stage_blk_begin[s];
+    st.blk_count = stage_blk_count[s];
+    st.blk_lpr = stage_lpr[s];
+  }
+  FCCHK(S.blk.upload(packed, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
   return FC_OK;
 }
 

@@ -434,6 +434,78 @@ __global__ __launch_bounds__(256) void fc_nd_sweep(int nrows, const int64_t* __r
 }
 
 // ---------------------------------------------------------------------------------------------
+// Down-sweep as batched dense block mat-vec with the operand staged in LDS.
+// All rows of a tree node share one operand vector  [ y[i0 .. i0+ni) | x[idx[0 .. nb)] ]  (pivot block
+// D^-1 and coupling block -U side by side, row-major, stride wd = ni + nb).  A workgroup takes up
+// to `nrows` rows of one node: the operand is gathered once per workgroup into LDS (coalesced /
+// index-list gather), after which the lanes only stream the fp64 values from HBM (8 B/nnz, 512 B per
+// wave instruction) and read the operand with conflict-free ds_read_b64 — the global-load queue is
+// left entirely to the value stream.  LPR lanes cooperate on a row (256/LPR rows in flight per
+// workgroup); fixed summation order, no atomics.
+// ---------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) FcBlk {
+  long long val;  // offset of the first row's values
+  int row0;       // first destination row (permuted numbering)
+  int nrows;
+  int i0, ni;     // pivot part: y[i0 .. i0+ni)
+  int idx, nb;    // coupling part: x[idx_list[idx .. idx+nb)]  (entries already offset by N)
+};
+
+#define FC_BLK_TILE 2048
+
+template <int LPR>
+__global__ __launch_bounds__(256) void fc_nd_down_block(const FcBlk* __restrict__ blk,
+                                                        const int* __restrict__ idxlist,
+                                                        const double* __restrict__ val,
+                                                        double* __restrict__ buf, int N) {
+  __shared__ double xs[FC_BLK_TILE];
+  constexpr int SLOTS = 256 / LPR;  // rows in flight per workgroup
+  constexpr int MAXR = 32;          // rows per workgroup (host guarantees nrows <= MAXR)
+  constexpr int RPS = (MAXR + SLOTS - 1) / SLOTS;
+  const FcBlk b = blk[blockIdx.x];
+  const int slot = threadIdx.x / LPR, l = threadIdx.x % LPR;
+  const int wd = b.ni + b.nb;
+  double acc[RPS];
+#pragma unroll
+  for (int k = 0; k < RPS; ++k) acc[k] = 0.0;
+  for (int t0 = 0; t0 < wd; t0 += FC_BLK_TILE) {
+    const int tl = wd - t0 < FC_BLK_TILE ? wd - t0 : FC_BLK_TILE;
+    for (int j = threadIdx.x; j < tl; j += 256) {
+      const int col = t0 + j;
+      xs[j] = col < b.ni ? buf[b.i0 + col] : buf[idxlist[b.idx + (col - b.ni)]];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RPS; ++k) {
+      const int r = slot + k * SLOTS;
+      if (r < b.nrows) {
+        const double* __restrict__ v = val + b.val + (long long)r * wd + t0;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (int base = 0; base < tl; base += 4 * LPR) {
+          const int j0 = base + l, j1 = j0 + LPR, j2 = j1 + LPR, j3 = j2 + LPR;
+          const double v0 = j0 < tl ? v[j0] : 0.0, v1 = j1 < tl ? v[j1] : 0.0;
+          const double v2 = j2 < tl ? v[j2] : 0.0, v3 = j3 < tl ? v[j3] : 0.0;
+          s0 += v0 * (j0 < tl ? xs[j0] : 0.0);
+          s1 += v1 * (j1 < tl ? xs[j1] : 0.0);
+          s2 += v2 * (j2 < tl ? xs[j2] : 0.0);
+          s3 += v3 * (j3 < tl ? xs[j3] : 0.0);
+        }
+        acc[k] += (s0 + s1) + (s2 + s3);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < RPS; ++k) {
+    double s = acc[k];
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_down(s, off, LPR);
+    const int r = slot + k * SLOTS;
+    if (l == 0 && r < b.nrows) buf[N + b.row0 + r] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // small vector kernels
 // ---------------------------------------------------------------------------------------------
 __global__ void fc_copy(int n, const double* __restrict__ a, double* __restrict__ b) {

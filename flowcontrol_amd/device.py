@@ -7,6 +7,7 @@ reference's ``src/flowcontrol/flowsolver.py``) owns one :class:`DeviceSolver`.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import scipy.sparse as sp
@@ -50,6 +51,7 @@ class DeviceSolver:
         self.tree: ndsolver.NDTree | None = None
         self.factor_nnz: dict[int, int] = {}
         self.rank, self.world = 0, 1
+        self.use_block_kernel = os.environ.get("FC_BLOCK_KERNEL", "1") != "0"  # LDS-tiled down-sweeps
         self.part: ndsolver.RankPartition | None = None
         self._sensor_rows: list | None = None
         self.device_index = device
@@ -192,6 +194,16 @@ class DeviceSolver:
                 int(part.ar_stage), int(part.ar_row0), int(part.ar_n),
             )
         )
+        if self.use_block_kernel:
+            bb, bc, bl, bval, brow0, bnr, bi0, bni, bidx, bnb = ndsolver.down_blocks(fac, self.rank, self.world)
+            z64, z32 = np.zeros(1, np.int64), np.zeros(1, np.int32)
+            pick = lambda a, z: a if a.size else z  # noqa: E731
+            check(
+                self.lib.fc_solver_set_blocks(
+                    self._h, slot, len(bb), bb, bc, bl, int(bval.size), pick(bval, z64), pick(brow0, z32), pick(bnr, z32),
+                    pick(bi0, z32), pick(bni, z32), pick(bidx, z32), pick(bnb, z32), int(fac.idx.size), int(fac.vals.size),
+                )
+            )
         self.factor_nnz[slot] = int(fac.nnz)
         self.local_factor_nnz = int(part.seg_len.sum())
         self.n_stages = len(part.stage_kind)

@@ -307,6 +307,9 @@ class BlockFactors:
     stage_kind: np.ndarray  # int32
     stage_begin: np.ndarray  # int64 offset of the stage's first row in seg_ptr
     nnz: int
+    # per tree node with rows (for the LDS-tiled down-sweep kernel): level, node id, first row, rows,
+    # boundary size, offset of its [D⁻¹ | −U] rows in ``vals`` (row stride ni+nb), offset of its index list
+    nodes: np.ndarray | None = None  # (n_nodes, 7) int64: level, n, i0, ni, nb, val_off, idx_off
 
     def to_csr_stages(self):
         """(up, down) lists of scipy CSR matrices — host reference used by the CPU tests."""
@@ -380,6 +383,7 @@ def factorize_blocks(A: sp.csr_matrix, tree: NDTree) -> BlockFactors:
     dn_len = np.zeros((N, 2), dtype=np.int32)
     updates: dict[tuple[int, int], tuple[np.ndarray, np.ndarray]] = {}
     nnz = 0
+    node_rows: list[tuple] = []
     for k in range(t.depth, -1, -1):
         for n in range(t.nnodes(k)):
             i0, i1 = int(t.node_ptr[k][n]), int(t.node_ptr[k][n + 1])
@@ -424,6 +428,7 @@ def factorize_blocks(A: sp.csr_matrix, tree: NDTree) -> BlockFactors:
                 Vt = Dinv @ F12
                 updates[(k, n)] = (B, F[ni:, ni:] - Wt @ F12)
                 DV = np.hstack([Dinv, -Vt])  # (ni, ni+nb) row-major: one contiguous row per dof
+                node_rows.append((k, n, i0, ni, nb, vpos, ipos))
                 vals_chunks.append(DV.ravel())
                 dn_val[rows, 0] = vpos + np.arange(ni) * nf
                 dn_val[rows, 1] = vpos + np.arange(ni) * nf + ni
@@ -441,6 +446,7 @@ def factorize_blocks(A: sp.csr_matrix, tree: NDTree) -> BlockFactors:
                 nnz += ni * ni + 2 * ni * nb
             else:
                 updates[(k, n)] = (B, np.zeros((0, 0)))
+                node_rows.append((k, n, i0, ni, 0, vpos, 0))
                 vals_chunks.append(Dinv.ravel())
                 dn_val[rows, 0] = vpos + np.arange(ni) * ni
                 vpos += Dinv.size
@@ -487,10 +493,63 @@ def factorize_blocks(A: sp.csr_matrix, tree: NDTree) -> BlockFactors:
         seg_len=np.ascontiguousarray(np.concatenate(seg_len), dtype=np.int32),
         seg_ptr=seg_ptr, stage_row0=np.array(row0, dtype=np.int32), stage_nrows=nrows,
         stage_kind=np.array(kind, dtype=np.int32), stage_begin=begin, nnz=int(nnz),
+        nodes=np.array(node_rows, dtype=np.int64).reshape(-1, 7),
     )
 
 
-__all__ += ["BlockFactors", "factorize_blocks"]
+def down_blocks(fac: BlockFactors, rank: int = 0, world: int = 1, max_rows: int = 32, target_blocks: int = 2048,
+                min_stage_values: float = 4.0e6):
+    """Workgroup tiles of the down-sweep stages for ``fc_solver_set_blocks``.
+
+    Returns per-stage arrays (begin, count, lanes-per-row) aligned with the stage list of
+    :func:`partition` (up stages get count 0) and the block arrays.  A block is ≤ ``max_rows``
+    consecutive rows of one tree node; rows per block shrink for stages with few rows so that a launch
+    still has ≳ ``target_blocks`` workgroups.  With ``world > 1`` only the rank's nodes (and the root)
+    are tiled.  Stages that stream fewer than ``min_stage_values`` values stay on the segment kernel:
+    they are launch-latency bound and the LDS staging round trip only adds to that (measured on the
+    56 k-dof cylinder mesh: −3 %; on the 223 k-dof refined mesh the tiled kernel is +16 %)."""
+    t = fac.tree
+    p = int(np.log2(world)) if world > 1 else 0
+    nodes = fac.nodes
+    nst = len(fac.stage_kind)
+    begin = np.zeros(nst, dtype=np.int64)
+    count = np.zeros(nst, dtype=np.int32)
+    lpr = np.full(nst, 64, dtype=np.int32)
+    cols: list[list[int]] = [[] for _ in range(7)]
+    nblk = 0
+    for s in range(nst):
+        if fac.stage_kind[s] != 1:
+            begin[s] = nblk
+            continue
+        k = s - t.depth
+        sel = nodes[nodes[:, 0] == k]
+        if world > 1 and k >= 1:
+            sh = t.cum[k] - p
+            sel = sel[(sel[:, 1] >> sh) == rank]
+        sel = sel[np.argsort(sel[:, 2])]
+        if float(((sel[:, 3] + sel[:, 4]) * sel[:, 3]).sum()) < min_stage_values:
+            begin[s] = nblk
+            continue
+        rows = int(sel[:, 3].sum())
+        rc = max_rows
+        while rc > 4 and rows // rc < target_blocks:
+            rc //= 2
+        wd_mean = float(((sel[:, 3] + sel[:, 4]) * sel[:, 3]).sum() / max(rows, 1))
+        lpr[s] = 16 if wd_mean <= 256 else (32 if wd_mean <= 1024 else 64)
+        begin[s] = nblk
+        for _, n, i0, ni, nb, voff, ioff in sel:
+            wd = ni + nb
+            for r0 in range(0, int(ni), rc):
+                nr = min(rc, int(ni) - r0)
+                for lst, v in zip(cols, (voff + r0 * wd, i0 + r0, nr, i0, ni, ioff, nb)):
+                    lst.append(int(v))
+                nblk += 1
+        count[s] = nblk - begin[s]
+    arr = lambda i, dt: np.ascontiguousarray(np.array(cols[i], dtype=dt))  # noqa: E731
+    return begin, count, lpr, arr(0, np.int64), arr(1, np.int32), arr(2, np.int32), arr(3, np.int32), arr(4, np.int32), arr(5, np.int32), arr(6, np.int32)
+
+
+__all__ += ["BlockFactors", "factorize_blocks", "down_blocks"]
 
 
 # ──────────────────────────────────────────────────────────────────────────────────────────

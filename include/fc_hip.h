@@ -117,6 +117,15 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
                     /* multi-GPU: after stage `ar_stage` (-1: none) the rows [ar_row0, ar_row0+ar_n) of the
                      * work buffer are summed over the ranks (RCCL all-reduce) */
                     int32_t ar_stage, int32_t ar_row0, int32_t ar_n);
+/* optional: hand the down-sweep stages to the LDS-tiled block kernel.  Every block is up to 32
+ * consecutive rows of ONE tree node, whose rows all read the same operand
+ * [ y[i0..i0+ni) | x[idx[idx_off..+nb)] ] and whose values lie row-major (stride ni+nb) at blk_val.
+ * stage_* arrays have one entry per stage of fc_solver_setup (count 0 = keep the segment kernel). */
+int fc_solver_set_blocks(fc_handle h, int slot, int32_t n_stages, const int64_t* stage_blk_begin,
+                         const int32_t* stage_blk_count, const int32_t* stage_lpr, int64_t n_blk,
+                         const int64_t* blk_val, const int32_t* blk_row0, const int32_t* blk_nrows,
+                         const int32_t* blk_i0, const int32_t* blk_ni, const int32_t* blk_idx,
+                         const int32_t* blk_nb, int64_t n_idx, int64_t n_val);
 /* optional explicit operator C of the right-hand side, b -= C u_n (rows in the solver's permuted
  * numbering, columns = velocity dofs in W numbering): the explicit half of the linear terms of the
  * Crank-Nicolson form (NSForms._cn, nsforms.py:191-236).  rowptr == NULL removes it. */

@@ -182,3 +182,34 @@ def test_crank_nicolson_step(setup):
         prev = uc
     dev.set_rhs_operator(SLOT_BDF1, None)
     dev.set_force(None)
+
+
+def test_block_and_segment_down_sweeps_agree(setup):
+    """The LDS-tiled block kernel (forced on for every down stage) and the segment kernel produce the
+    same solve to round-off."""
+    th, dev, d, O = setup
+    from flowcontrol_amd import ndsolver
+    from flowcontrol_amd.device import SLOT_BDF2
+
+    dt, Re = 0.005, 100.0
+    U0 = _smooth_velocity(th)
+    dofs, prof = _bc_setup(th)
+    dev.set_bc(dofs, prof)
+    dev.set_time_scheme(dt, True)
+    dev.assemble_matrix(SLOT_BDF2, mass=1.5 / dt, nu=1.0 / Re, adv=U0, lin=U0)
+    dev.apply_bc(SLOT_BDF2)
+    b = np.random.default_rng(3).standard_normal(dev.N)
+    orig = ndsolver.down_blocks
+    try:
+        dev.use_block_kernel = False
+        dev.setup_solver(SLOT_BDF2)
+        x_seg, _ = dev.solve(SLOT_BDF2, b)
+        dev.use_block_kernel = True
+        ndsolver.down_blocks = lambda fac, rank=0, world=1, **kw: orig(fac, rank, world, min_stage_values=0.0)
+        dev.setup_solver(SLOT_BDF2)
+        x_blk, info = dev.solve(SLOT_BDF2, b)
+    finally:
+        ndsolver.down_blocks = orig
+        dev.use_block_kernel = True
+    assert _rel(x_blk, x_seg) < 1e-12
+    assert info[1] < 1e-9
