@@ -161,6 +161,7 @@ struct fc_ctx {
   DevBuf<int> flag;
   double* pin = nullptr;    // pinned, device-mapped host record: [0..63] u_ctrl in, [64..] outputs
   double* pin_dev = nullptr;  // device address of the same memory
+  uint64_t seq = 0;           // step sequence number published by the last kernel of a step
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int nblk_N = 0;
   // multi-GPU partition (fc_set_partition / fc_comm_init): this rank's cells and rows
@@ -515,7 +516,8 @@ int enqueue_energy(fc_ctx* h, const double* d_u, double* d_out) {
 
 // enqueue one full step; y -> d_y, E -> d_E; residual norms -> scal[1], scal[2]
 int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, double* d_E, double* d_r,
-                 double* d_flag_out, int compute_energy, const double* d_uforce = nullptr) {
+                 double* d_flag_out, int compute_energy, const double* d_uforce = nullptr, double* d_seq = nullptr,
+                 double seq = 0.0) {
   OrderSys& S = h->sys[order_slot];
   if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this order");
   if (compute_energy && !h->partitioned && !h->have_mp) return fail(FC_ERR_NOT_READY, "fc_set_energy_matrix not called");
@@ -529,9 +531,9 @@ int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, 
     hipLaunchKernelGGL(fc_finish, dim3(g), dim3(256), 0, h->stream, h->N, 2 * h->nn, h->perm.p, x, dx, h->up.p, h->u_n.p,
                        h->u_nn.p, h->p_n.p, h->flag.p, compute_energy ? h->mp_rowptr.p : nullptr, h->mp_col.p,
                        h->mp_val.p, compute_energy ? e_partial : nullptr, (const unsigned char*)nullptr);
-    hipLaunchKernelGGL(fc_final, dim3(1 + h->n_sens), dim3(256), 0, h->stream, g, compute_energy ? e_partial : nullptr,
+    hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, g, compute_energy ? e_partial : nullptr,
                        d_E, nrp, nrp > 0 ? h->partial.p : nullptr, d_r, h->n_sens, h->s_rowptr.p, h->s_idx.p,
-                       h->s_w.p, h->up.p, d_y, h->flag.p, d_flag_out);
+                       h->s_w.p, h->up.p, d_y, h->flag.p, d_flag_out, d_seq, seq);
   } else {
     // partitioned: scatter owned + root rows, energy from this rank's cells, sensor rows restricted to
     // owned dofs; the partial tail is summed over the ranks with one small all-reduce
@@ -545,11 +547,12 @@ int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, 
                          h->cell_list.p, h->ncl, e_partial);
     }
     HIPCHK(hipMemsetAsync(h->tail.p, 0, 128 * sizeof(double), h->stream));
-    hipLaunchKernelGGL(fc_final, dim3(1 + h->n_sens), dim3(256), 0, h->stream, ne, ne > 0 ? e_partial : nullptr,
+    hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, ne, ne > 0 ? e_partial : nullptr,
                        h->tail.p + 64, nrp, nrp > 0 ? h->partial.p : nullptr, h->tail.p + 65, h->n_sens, h->s_rowptr.p,
-                       h->s_idx.p, h->s_w.p, h->up.p, h->tail.p, h->flag.p, h->tail.p + 72);
+                       h->s_idx.p, h->s_w.p, h->up.p, h->tail.p, h->flag.p, h->tail.p + 72, (double*)nullptr, 0.0);
     if (h->comm) NCCLCHK(g_rccl.AllReduce(h->tail.p, h->tail.p, 80, kNcclDouble, kNcclSum, h->comm, h->stream));
-    hipLaunchKernelGGL(fc_publish_tail, dim3(1), dim3(64), 0, h->stream, h->tail.p, d_y, h->n_sens, d_E, d_r, d_flag_out);
+    hipLaunchKernelGGL(fc_publish_tail, dim3(1), dim3(64), 0, h->stream, h->tail.p, d_y, h->n_sens, d_E, d_r, d_flag_out,
+                       d_seq, seq);
   }
   HIPCHK(hipGetLastError());
   return FC_OK;
@@ -1231,9 +1234,24 @@ int fc_step(fc_handle h, int order_slot, const double* u_ctrl, const double* u_f
     pin[32 + k] = u_force ? u_force[k] : u_ctrl[k];  // body-force amplitudes (CN: mean of new and old)
   }
   double* dev = h->pin_dev;
-  FCCHK(enqueue_step(h, order_slot, dev, dev + 64, dev + 128, dev + 129, dev + 136, compute_energy, dev + 32));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  FCCHK(time_collect(h));
+  const double seq = (double)(++h->seq);
+  FCCHK(enqueue_step(h, order_slot, dev, dev + 64, dev + 128, dev + 129, dev + 136, compute_energy, dev + 32, dev + 137, seq));
+  // the last kernel publishes `seq` behind a system-scope fence: poll the host-mapped word (bounded),
+  // then fall back to a stream synchronisation — which is also what reports a faulted kernel
+  bool seen = false;
+  if (!h->timing) {
+    for (long spin = 0; spin < 20000000L; ++spin) {
+      if (pin[137] == seq) {
+        seen = true;
+        break;
+      }
+      __builtin_ia32_pause();
+    }
+  }
+  if (!seen) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    FCCHK(time_collect(h));
+  }
   for (int s = 0; s < h->n_sens; ++s)
     if (y_out) y_out[s] = pin[64 + s];
   if (dE_out) *dE_out = compute_energy ? pin[128] : std::numeric_limits<double>::quiet_NaN();
@@ -1298,9 +1316,9 @@ int fc_step_phase(fc_handle h, int order_slot, int phase, const double* u_ctrl, 
                        h->cell_list.p, h->ncl, e_partial);
   }
   HIPCHK(hipMemsetAsync(h->tail.p, 0, 128 * sizeof(double), h->stream));
-  hipLaunchKernelGGL(fc_final, dim3(1 + h->n_sens), dim3(256), 0, h->stream, ne, ne > 0 ? e_partial : nullptr, h->tail.p + 64,
+  hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, ne, ne > 0 ? e_partial : nullptr, h->tail.p + 64,
                      nrp, nrp > 0 ? h->partial.p : nullptr, h->tail.p + 65, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p,
-                     h->up.p, h->tail.p, h->flag.p, h->tail.p + 72);
+                     h->up.p, h->tail.p, h->flag.p, h->tail.p + 72, (double*)nullptr, 0.0);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(tail_io, h->tail.p, 80 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1471,9 +1489,9 @@ int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double*
     hipLaunchKernelGGL(fc_finish, dim3(g), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, x, dx, h->up.p, h->u_n.p,
                        h->u_nn.p, h->p_n.p, h->flag.p, h->mp_rowptr.p, h->mp_col.p, h->mp_val.p, e_partial,
                        (const unsigned char*)nullptr);
-    hipLaunchKernelGGL(fc_final, dim3(1 + h->n_sens), dim3(256), 0, h->stream, g, e_partial, h->scal.p, nrp,
+    hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, g, e_partial, h->scal.p, nrp,
                        nrp > 0 ? h->partial.p : nullptr, h->scal.p + 1, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p,
-                       h->up.p, h->ydev.p, h->flag.p, (double*)nullptr);
+                       h->up.p, h->ydev.p, h->flag.p, (double*)nullptr, (double*)nullptr, 0.0);
     FCCHK(lap(4));
   }
   HIPCHK(hipStreamSynchronize(h->stream));

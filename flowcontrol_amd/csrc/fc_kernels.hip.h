@@ -575,9 +575,11 @@ __global__ __launch_bounds__(256) void fc_finish(int N, int nn2, const int* __re
   }
 }
 
-// tail of a step, one launch: block 0 folds the energy partials (-> E = 1/2 sum) and, if present,
-// the residual partials (sum r^2, sum b^2); block 1+s evaluates sensor row s
-// (y_s = sum_k w[k] up[idx[k]], sensor.py:96-98,166-197).  Fixed summation order => reproducible.
+// tail of a step, ONE workgroup: folds the energy partials (-> E = 1/2 sum) and, if present, the
+// residual partials (sum r^2, sum b^2), evaluates the sensor rows (y_s = sum_k w[k] up[idx[k]],
+// sensor.py:96-98,166-197) and publishes everything to the (host-mapped) record; the step sequence
+// number is written last, behind a system-scope fence, so the host can poll it instead of
+// synchronising the stream.  Fixed summation order => reproducible.
 __global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restrict__ e_partial,
                                                 double* __restrict__ E_out, int n_r,
                                                 const double* __restrict__ r_partial,
@@ -586,23 +588,18 @@ __global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restric
                                                 const int* __restrict__ s_idx,
                                                 const double* __restrict__ s_w,
                                                 const double* __restrict__ up, double* __restrict__ y,
-                                                const int* __restrict__ flag, double* __restrict__ flag_out) {
+                                                const int* __restrict__ flag, double* __restrict__ flag_out,
+                                                double* __restrict__ seq_out, double seq) {
   __shared__ double red[3][256];
   const int t = threadIdx.x;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-  if (blockIdx.x == 0) {
-    if (e_partial)
-      for (int i = t; i < n_e; i += 256) a0 += e_partial[i];
-    if (r_partial)
-      for (int i = t; i < n_r; i += 256) {
-        a1 += r_partial[i];
-        a2 += r_partial[n_r + i];
-      }
-  } else {
-    const int s = blockIdx.x - 1;
-    if (s < n_sens)
-      for (int k = s_rowptr[s] + t; k < s_rowptr[s + 1]; k += 256) a0 += s_w[k] * up[s_idx[k]];
-  }
+  if (e_partial)
+    for (int i = t; i < n_e; i += 256) a0 += e_partial[i];
+  if (r_partial)
+    for (int i = t; i < n_r; i += 256) {
+      a1 += r_partial[i];
+      a2 += r_partial[n_r + i];
+    }
   red[0][t] = a0;
   red[1][t] = a1;
   red[2][t] = a2;
@@ -616,15 +613,28 @@ __global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restric
     __syncthreads();
   }
   if (t == 0) {
-    if (blockIdx.x == 0) {
-      if (e_partial && E_out) E_out[0] = 0.5 * red[0][0];
-      if (r_partial && r_out) {
-        r_out[0] = red[1][0];
-        r_out[1] = red[2][0];
-      }
-      if (flag_out) flag_out[0] = (double)flag[0];
-    } else if (blockIdx.x - 1 < n_sens) {
-      y[blockIdx.x - 1] = red[0][0];
+    if (e_partial && E_out) E_out[0] = 0.5 * red[0][0];
+    if (r_partial && r_out) {
+      r_out[0] = red[1][0];
+      r_out[1] = red[2][0];
+    }
+    if (flag_out) flag_out[0] = (double)flag[0];
+  }
+  // sensors: one wave per row, waves take rows round-robin
+  const int wave = t >> 6, lane = t & 63;
+  for (int s = wave; s < n_sens; s += 4) {
+    double acc = 0.0;
+    for (int k = s_rowptr[s] + lane; k < s_rowptr[s + 1]; k += 64) acc += s_w[k] * up[s_idx[k]];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) y[s] = acc;
+  }
+  if (seq_out) {
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) {
+      __threadfence_system();
+      seq_out[0] = seq;
     }
   }
 }
@@ -671,7 +681,8 @@ __global__ __launch_bounds__(256) void fc_energy_elem(int nc, int nn, const int*
 
 // multi-GPU: after the all-reduce of the step tail [y(64) | E | r2 | b2 | ... | flag@72] publish it
 __global__ void fc_publish_tail(const double* __restrict__ tail, double* __restrict__ y, int n_sens,
-                                double* __restrict__ E, double* __restrict__ r, double* __restrict__ flag_out) {
+                                double* __restrict__ E, double* __restrict__ r, double* __restrict__ flag_out,
+                                double* __restrict__ seq_out, double seq) {
   const int t = threadIdx.x;
   if (t < n_sens && y) y[t] = tail[t];
   if (t == 0) {
@@ -681,6 +692,14 @@ __global__ void fc_publish_tail(const double* __restrict__ tail, double* __restr
       r[1] = tail[66];
     }
     if (flag_out) flag_out[0] = tail[72];
+  }
+  if (seq_out) {
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) {
+      __threadfence_system();
+      seq_out[0] = seq;
+    }
   }
 }
 
