@@ -68,7 +68,10 @@ class DeviceSolver:
             raise ValueError("world size must be a power of two (one elimination sub-tree per GPU)")
         self.rank, self.world = int(rank), int(world)
         self._host_allreduce = host_allreduce
-        if world == 1 or host_allreduce is not None:
+        # FC_FORCE_COMM=1 (test aid): build a 1-rank RCCL communicator and run the partitioned code
+        # path (cell list, row kinds, in-stream all-reduces) on a single GPU
+        self._force_comm = world == 1 and os.environ.get("FC_FORCE_COMM", "0") == "1"
+        if (world == 1 and not self._force_comm) or host_allreduce is not None:
             # host-staged exchange (fc_step_phase): no RCCL communicator; ``host_allreduce(array)``
             # sums a float64 array over the ranks in place
             return
@@ -174,7 +177,12 @@ class DeviceSolver:
         t = self.tree
         fac = ndsolver.factorize_blocks(A, t)
         part = ndsolver.partition(fac, self.rank, self.world)
-        if self.world > 1 and self.part is None:
+        if getattr(self, "_force_comm", False):
+            # single-rank communicator: everything is owned, the root rows are "shared" with nobody
+            root0, root1 = int(t.node_ptr[0][0]), int(t.node_ptr[0][-1])
+            part.rowkind[t.perm[root0:root1]] = 2
+            part.ar_stage, part.ar_row0, part.ar_n = t.depth - 1, root0, root1 - root0
+        if (self.world > 1 or getattr(self, "_force_comm", False)) and self.part is None:
             check(self.lib.fc_set_partition(self._h, int(part.local_cells.size), ptr(_i32(part.local_cells)),
                                             ptr(np.ascontiguousarray(part.rowkind, dtype=np.uint8)), int(self.rank == 0)))
             self.part = part

@@ -89,3 +89,36 @@ def test_partitioned_ranks_reproduce_the_serial_run(world):
         assert rel(out["u"], u_ref) < 1e-10
         assert out["resid"] < 1e-9
         assert abs(out["cells"] - 12284 // world) <= 1
+
+
+def test_rccl_plumbing_with_a_single_rank_communicator(monkeypatch):
+    """FC_FORCE_COMM=1: a 1-rank RCCL communicator (dlopen, ncclCommInitRank with the unique id passed by
+    value, in-place ncclAllReduce of doubles on the solver's stream, inside the solve and on the step
+    tail) drives the partitioned code path on one GPU; results must equal the plain single-GPU run."""
+    nsteps = 8
+    y_ref, dE_ref, u_ref = _serial(nsteps)
+    monkeypatch.setenv("FC_FORCE_COMM", "1")
+    from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver
+    from flowcontrol_amd.fem.spaces import Function
+    from flowcontrol_amd.flowsolverparameters import ParamIC
+
+    g = np.load(ROOT / "tests" / "golden" / "cylinder_O1.npz")
+    fs = CylinderFlowSolver.make_default(Re=100, path_out=tempfile.mkdtemp(), num_steps=nsteps)
+    fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
+    U0, P0 = Function(fs.W, g["UP0"]).split()
+    fs._assign_steady_state(U0, P0)
+    fs.initialize_time_stepping(ic=None)
+    dev = fs.th.device()
+    dev.join(0, 1, lambda b: b)
+    fs._joined = True
+    for k in range(nsteps):
+        fs.step([0.05 * np.sin(0.3 * k), -0.02])
+    assert dev.part is not None and dev.part.ar_n > 0
+    ts = fs.timeseries
+    rel = lambda a, b: np.linalg.norm(np.asarray(a) - b) / np.linalg.norm(b)  # noqa: E731
+    assert rel(ts[["y_meas_1", "y_meas_2", "y_meas_3"]].to_numpy(), y_ref[: nsteps + 1]) < 1e-10
+    assert rel(ts["dE"].to_numpy(), dE_ref[: nsteps + 1]) < 1e-10
+    assert rel(fs.fields.u_.vector().get_local(), u_ref) < 1e-10
+    y_b, dE_b = fs.run(4, np.zeros(2))  # batched path with in-stream collectives
+    assert np.all(np.isfinite(y_b)) and np.all(np.isfinite(dE_b))
+    fs.th.release_device()
