@@ -3,9 +3,9 @@
 Timeseries rows ``{time, dE, runtime, u_ctrl_i, y_meas_i}`` (1-based suffixes, the IC row has no
 ``u_ctrl``) → pandas DataFrame → CSV, exactly the reference's schema (``exporter.py:169-267``):
 parity is judged on this series.  Field checkpoints keep the reference's naming
-(``U_restart<T>`` …, JSON sidecar ``meta_restart<T>.json`` with the same keys,
-``exporter.py:234-262``) but store each frame as ``<name>.<counter>.npy`` next to the would-be
-XDMF file; an XDMF/HDF5 writer is listed under SURVEY §8f "next".
+(``U_restart<T>.xdmf`` + ``.h5`` …, series names ``U`` / ``U_n`` / ``P``, JSON sidecar
+``meta_restart<T>.json`` with the same keys, ``exporter.py:85-165,234-262``); the files are written by
+``flowcontrol_amd/io.py`` (ParaView-readable XDMF, own HDF5 payload layout).
 """
 
 from __future__ import annotations
@@ -23,20 +23,21 @@ from .flowfield import FlowFieldCollection, SimPaths
 logger = logging.getLogger(__name__)
 
 
-def frame_path(path: Path, counter: int) -> Path:
-    return Path(str(path) + f".{counter}.npy")
+def write_frame(path: Path, func: Function, counter: int, name: str = "f", time: float = 0.0) -> None:
+    """Frame ``counter`` of the checkpoint series at ``path`` (XDMF + HDF5, ``io.write_xdmf``)."""
+    from .io import write_xdmf
+
+    got = write_xdmf(path, func, name, time_step=time, append=counter > 0)
+    if got != counter:
+        raise RuntimeError(f"{path}: expected to write frame {counter}, series has {got}")
 
 
-def write_frame(path: Path, func: Function, counter: int) -> None:
-    path.parent.mkdir(parents=True, exist_ok=True)
-    np.save(frame_path(path, counter), func.vector().array())
+def read_frame(path: Path, func: Function, counter: int, name: str = "f") -> None:
+    from .io import read_xdmf
 
-
-def read_frame(path: Path, func: Function, counter: int) -> None:
-    fp = frame_path(Path(path), counter)
-    if not fp.exists():
-        raise FileNotFoundError(f"checkpoint frame {fp} not found")
-    func.vector().set_local(np.load(fp))
+    if not Path(path).with_suffix(".h5").exists():
+        raise FileNotFoundError(f"checkpoint {Path(path).with_suffix('.h5')} not found")
+    read_xdmf(path, func, name, counter)
 
 
 class FlowExporter:
@@ -72,8 +73,8 @@ class FlowExporter:
         if not append:
             self._frames = 0
         self._checkpoints_written += 1
-        for path, func in ((self.paths.U_restart, f.Usave), (self.paths.Uprev_restart, f.Usave_n), (self.paths.P_restart, f.Psave)):
-            write_frame(path, func, self._frames)
+        for path, func, nm in ((self.paths.U_restart, f.Usave, "U"), (self.paths.Uprev_restart, f.Usave_n, "U_n"), (self.paths.P_restart, f.Psave, "P")):
+            write_frame(path, func, self._frames, name=nm, time=time)
         self._frames += 1
 
     # ── timeseries ───────────────────────────────────────────────────────────

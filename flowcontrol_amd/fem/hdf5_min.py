@@ -286,3 +286,135 @@ __all__ = ["MinimalHDF5", "read_dataset", "HDF5Error"]
 
 # keep struct imported for callers that extend the reader
 _ = struct
+
+
+# ──────────────────────────────────────────────────────────────────────────────────────────
+# Minimal writer: the same on-disk structures the reader above understands (and that HDF5 1.8+
+# reads): superblock v0, old-style groups (v1 B-tree + local heap + one symbol node), v1 object
+# headers, contiguous uncompressed little-endian datasets of f8 / i8 / i4 / u1.
+# ──────────────────────────────────────────────────────────────────────────────────────────
+_INT_K = 16
+
+
+def _pad8(b: bytes) -> bytes:
+    return b + b"\x00" * (-len(b) % 8)
+
+
+def _dtype_message(dt: np.dtype) -> bytes:
+    dt = np.dtype(dt)
+    if dt.kind == "f" and dt.itemsize == 8:
+        head = bytes([0x11, 0x20, 0x3F, 0x00]) + struct.pack("<I", 8)
+        props = struct.pack("<HHBBBBI", 0, 64, 52, 11, 0, 52, 1023)
+        return head + props
+    if dt.kind in "iu" and dt.itemsize in (1, 4, 8):
+        head = bytes([0x10, 0x08 if dt.kind == "i" else 0x00, 0x00, 0x00]) + struct.pack("<I", dt.itemsize)
+        return head + struct.pack("<HH", 0, 8 * dt.itemsize)
+    raise HDF5Error(f"cannot write dtype {dt}")
+
+
+def _message(mtype: int, body: bytes) -> bytes:
+    body = _pad8(body)
+    return struct.pack("<HHB3x", mtype, len(body), 0) + body
+
+
+def _object_header(messages: list[bytes]) -> bytes:
+    blob = b"".join(messages)
+    return struct.pack("<BBHII4x", 1, 0, len(messages), 1, len(blob)) + blob
+
+
+class _Writer:
+    def __init__(self, leaf_k: int = 4):
+        self.buf = bytearray(96)  # superblock v0 with 8-byte offsets/lengths is 96 bytes
+        self.leaf_k = leaf_k  # symbols per group node = 2K; a file-level parameter stored in the superblock
+
+    def alloc(self, data: bytes) -> int:
+        self.buf += b"\x00" * (-len(self.buf) % 8)
+        addr = len(self.buf)
+        self.buf += data
+        return addr
+
+    def dataset(self, arr: np.ndarray) -> int:
+        arr = np.ascontiguousarray(arr)
+        if arr.dtype.byteorder == ">":
+            arr = arr.astype(arr.dtype.newbyteorder("<"))
+        raw = arr.tobytes()
+        daddr = self.alloc(raw) if raw else _UNDEF
+        space = struct.pack("<BBB5x", 1, arr.ndim, 0) + b"".join(struct.pack("<Q", d) for d in arr.shape)
+        layout = struct.pack("<BB", 3, 1) + struct.pack("<QQ", daddr, len(raw))
+        fill = struct.pack("<BBBB", 2, 2, 2, 0)  # fill value v2: late allocation, write-if-set, undefined
+        return self.alloc(_object_header([_message(0x0001, space), _message(0x0003, _dtype_message(arr.dtype)),
+                                          _message(0x0005, fill), _message(0x0008, layout)]))
+
+    def group(self, members: dict[str, int]) -> tuple[int, int, int]:
+        """members: name → object header address.  Returns (header, btree, heap) addresses."""
+        if len(members) > 2 * self.leaf_k:
+            raise HDF5Error("too many members in one group for the minimal writer")
+        names = sorted(members)
+        heap_data = bytearray(8)  # offset 0: empty string
+        offs = {}
+        for n in names:
+            offs[n] = len(heap_data)
+            heap_data += _pad8(n.encode() + b"\x00")
+        free_off = len(heap_data)
+        heap_data += struct.pack("<QQ", 1, 16)  # one free block: next = 1 (none), size = 16
+        data_addr = self.alloc(bytes(heap_data))
+        heap = self.alloc(b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap_data), free_off, data_addr))
+        snod = bytearray(b"SNOD" + struct.pack("<BBH", 1, 0, len(names)))
+        for n in names:
+            snod += struct.pack("<QQII16x", offs[n], members[n], 0, 0)
+        snod += b"\x00" * (8 + 2 * self.leaf_k * 40 - len(snod))
+        snod_addr = self.alloc(bytes(snod))
+        tree = bytearray(b"TREE" + struct.pack("<BBHQQ", 0, 0, 1 if names else 0, _UNDEF, _UNDEF))
+        tree += struct.pack("<QQQ", 0, snod_addr, offs[names[-1]] if names else 0)
+        tree += b"\x00" * (24 + (2 * _INT_K + 1) * 8 + 2 * _INT_K * 8 - len(tree))
+        btree = self.alloc(bytes(tree))
+        header = self.alloc(_object_header([_message(0x0011, struct.pack("<QQ", btree, heap))]))
+        return header, btree, heap
+
+    def finish(self, root: tuple[int, int, int]) -> bytes:
+        header, btree, heap = root
+        sb = _SIG + bytes([0, 0, 0, 0, 0, 8, 8, 0]) + struct.pack("<HHI", self.leaf_k, _INT_K, 0)
+        sb += struct.pack("<QQQQ", 0, _UNDEF, len(self.buf), _UNDEF)
+        sb += struct.pack("<QQII", 0, header, 1, 0) + struct.pack("<QQ", btree, heap)
+        assert len(sb) == 96
+        self.buf[:96] = sb
+        return bytes(self.buf)
+
+
+def write_hdf5(path: str | Path, tree: dict) -> None:
+    """Write nested ``{name: array | {…}}`` as groups / contiguous datasets."""
+    def widest(node: dict) -> int:
+        return max([len(node)] + [widest(v) for v in node.values() if isinstance(v, dict)])
+
+    w = _Writer(leaf_k=max(4, (widest(tree) + 1) // 2))
+
+    def emit(node: dict) -> tuple[int, int, int]:
+        members = {}
+        for name, val in node.items():
+            if "/" in name or not name:
+                raise HDF5Error(f"bad member name {name!r}")
+            members[name] = emit(val)[0] if isinstance(val, dict) else w.dataset(np.asarray(val))
+        return w.group(members)
+
+    data = w.finish(emit(tree))
+    Path(path).write_bytes(data)
+
+
+def read_hdf5_tree(path: str | Path) -> dict:
+    """Inverse of :func:`write_hdf5` for files made of old-style groups and simple datasets."""
+    f = MinimalHDF5(path)
+
+    def walk(prefix: str) -> dict:
+        out = {}
+        for k in f.keys(prefix or "/"):
+            p = f"{prefix}/{k}"
+            try:
+                out[k] = f.read(p)
+            except HDF5Error:
+                out[k] = walk(p)
+        return out
+
+    return walk("")
+
+
+__all__ += ["write_hdf5", "read_hdf5_tree"]

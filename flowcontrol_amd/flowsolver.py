@@ -293,8 +293,8 @@ class FlowSolver(ABC):
         self._mass_ready = False
         U0, P0 = UP0.split(deepcopy=True)
         if self.params_save.save_every:
-            write_frame(self.paths.U0, U0, 0)
-            write_frame(self.paths.P0, P0, 0)
+            write_frame(self.paths.U0, U0, 0, name="U0")
+            write_frame(self.paths.P0, P0, 0, name="P0")
             self.paths.steady_meta.parent.mkdir(parents=True, exist_ok=True)
             self.paths.steady_meta.write_text(json.dumps({"mesh_cells": self.mesh.num_cells}, indent=2))
         self._assign_steady_state(U0, P0)
@@ -303,8 +303,8 @@ class FlowSolver(ABC):
         paths = path_u_p or (self.paths.U0, self.paths.P0)
         self._check_steady_state_compatible(Path(paths[0]))
         U0, P0 = Function(self.V), Function(self.P)
-        read_frame(paths[0], U0, 0)
-        read_frame(paths[1], P0, 0)
+        read_frame(paths[0], U0, 0, name="U0")
+        read_frame(paths[1], P0, 0, name="P0")
         self._assign_steady_state(U0, P0)
 
     def _check_steady_state_compatible(self, u0_path: Path) -> None:
@@ -423,9 +423,9 @@ class FlowSolver(ABC):
         self.t = Tstart
         U_path, Uprev_path, P_path = (base_dir / meta["files"][k] for k in ("U", "Uprev", "P"))
         U_, U_nn, P_ = Function(self.V), Function(self.V), Function(self.P)
-        read_frame(U_path, U_, counter)
-        read_frame(Uprev_path, U_nn, counter)
-        read_frame(P_path, P_, counter)
+        read_frame(U_path, U_, counter, name="U")
+        read_frame(Uprev_path, U_nn, counter, name="U_n")
+        read_frame(P_path, P_, counter, name="P")
         U_n, P_n = U_.copy(deepcopy=True), P_.copy(deepcopy=True)
         if self.fields.U0 is None:
             raise RuntimeError("no base flow: call load_steady_state() before restarting")

@@ -317,3 +317,35 @@ def test_c_expression_strings_of_the_actuators():
     assert np.allclose(f({"a": np.array([2.0, 0.0, 0.0]), "b": np.array([3.0, 0.0, 0.0]), "c": np.array([0.0, -1.0, 0.0])}), [4.0, 0.0, 0.25])
     with pytest.raises(ValueError):
         dolfin.compile_c_expression("foo(1)")({})
+
+
+# ── HDF5 writer + XDMF checkpoints ───────────────────────────────────────────────────────────
+def test_hdf5_writer_round_trip_and_xdmf_checkpoints(tmp_path):
+    from flowcontrol_amd.fem.hdf5_min import MinimalHDF5, read_hdf5_tree, write_hdf5
+    from flowcontrol_amd.io import read_xdmf, write_xdmf
+
+    tree = {"Mesh": {"mesh": {"geometry": np.random.rand(7, 2), "topology": np.arange(12, dtype=np.int64).reshape(4, 3)}},
+            "many": {str(i): np.full(3, float(i)) for i in range(40)}, "flags": np.array([1, 0, 1], dtype=np.uint8),
+            "i4": np.arange(5, dtype=np.int32)}
+    write_hdf5(tmp_path / "t.h5", tree)
+    back = read_hdf5_tree(tmp_path / "t.h5")
+    assert np.array_equal(back["Mesh"]["mesh"]["geometry"], tree["Mesh"]["mesh"]["geometry"])
+    assert back["Mesh"]["mesh"]["topology"].dtype == np.int64 and back["i4"].dtype == np.int32 and back["flags"].dtype == np.uint8
+    assert len(back["many"]) == 40 and back["many"]["39"][0] == 39.0
+    assert MinimalHDF5(tmp_path / "t.h5").keys("/Mesh/mesh") == ["geometry", "topology"]
+
+    th = TaylorHood(Mesh.unit_square(4, 4))
+    u = Function(th.V, np.random.default_rng(0).standard_normal(2 * th.nn))
+    assert write_xdmf(tmp_path / "U_restart0,000.xdmf", u, "U", 0.0, append=False) == 0
+    u2 = Function(th.V, 2.0 * u.vector().array())
+    assert write_xdmf(tmp_path / "U_restart0,000.xdmf", u2, "U", 0.025, append=True) == 1
+    v = Function(th.V)
+    assert read_xdmf(tmp_path / "U_restart0,000.xdmf", v, "U", 1) == 0.025 and np.array_equal(v.vector().array(), u2.vector().array())
+    assert read_xdmf(tmp_path / "U_restart0,000.xdmf", v, "U", 0) == 0.0 and np.array_equal(v.vector().array(), u.vector().array())
+    with pytest.raises(FileNotFoundError):
+        read_xdmf(tmp_path / "U_restart0,000.xdmf", v, "U", 5)
+    with pytest.raises(ValueError):
+        read_xdmf(tmp_path / "U_restart0,000.xdmf", Function(th.P), "U", 0)
+    # the XDMF is a valid temporal collection whose mesh our own reader (and ParaView) can open
+    m = read_xdmf_mesh(tmp_path / "U_restart0,000.xdmf")
+    assert m.num_cells == th.nc and m.num_vertices == th.nv
