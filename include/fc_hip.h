@@ -85,7 +85,7 @@ int fc_bench_spmv(fc_handle h, int slot, int reps, double* ms_per_launch);
  *    (actuator.py:190-199,241-251,269-276), so the value on BC dof i is
  *    sum_k profiles[i][k] * u_ctrl[k]. -------------------------------------------------------- */
 int fc_set_bc(fc_handle h, int32_t n_bc, const int32_t* bc_dofs /* [n_bc] W indices */,
-              int32_t n_act, const double* profiles /* [n_bc][n_act] */);
+              int32_t n_act /* <= 32 for fc_step */, const double* profiles /* [n_bc][n_act] */);
 /* body force of FORCE-type actuators (actuator.py:297-313): nodal P2 values per unit u_ctrl */
 int fc_set_force(fc_handle h, int32_t n_act, const double* profiles /* [n_act][2 nn] or NULL */);
 /* sensors as sparse rows of the functional up -> y (sensor.py:96-98,166-197; utils/mpi.py:22-37) */
