@@ -218,3 +218,47 @@ def test_cylinder_crank_nicolson_vs_oracle(tmp_path_factory, golden_dir):
     assert _rel_l2(fs.fields.u_.vector().get_local(), u_n) < 1e-9
     assert fs.order == "cn" and np.isclose(fs.t, 0.05)
     fs.th.release_device()
+
+
+def test_cavity_closed_loop_force_actuation_vs_oracle(tmp_path_factory, golden_dir):
+    """BASELINE config 3 ingredients in one loop: open cavity Re=7500, Gaussian FORCE actuator driven by
+    an LTI Controller fed with the wall-shear sensor (no cavity controller ships with the reference: a
+    documented synthetic stable first-order low-pass, K(s) = 0.5 / (0.01 s + 1)), 6 steps; the device
+    trajectory must follow the oracle's with the same control sequence."""
+    from flowcontrol_amd import ndsolver
+    from flowcontrol_amd.examples.cavity.cavityflowsolver import CavityFlowSolver
+    from oracle import ns_oracle as O
+
+    g = np.load(golden_dir / "cavity_coarse.npz")
+    fs = CavityFlowSolver.make_default(Re=7500, path_out=tmp_path_factory.mktemp("cavity_cl"), num_steps=6)
+    U0, P0 = Function(fs.W, g["UP0"]).split()
+    fs._assign_steady_state(U0, P0)
+    fs.initialize_time_stepping(ic=None)
+    K = Controller(A=[[-100.0]], B=[[1.0]], C=[[50.0]], D=[[0.0]])
+    us = []
+    for _ in range(6):
+        u = K.step(y=fs.y_meas[0] - g["y"][0][0], dt=fs.params_time.dt)  # feedback on the shear fluctuation
+        us.append(float(u[0]))
+        fs.step(u_ctrl=[u[0]])
+    assert np.max(np.abs(us)) > 1e-6  # the loop is really closed
+    # oracle with the recorded control sequence
+    th = fs.th
+    d = O.Disc.from_taylor_hood(th)
+    dofs, prof = fs._bc_tables()
+    skip = np.zeros(th.N, bool)
+    skip[dofs] = True
+    perm = ndsolver.build_tree(th.cell_dofs, th.mesh.cell_centroids(), th.N, 13, skip).perm
+    ts = O.TimeStepper(d, 7500.0, fs.params_time.dt, g["UP0"][: 2 * th.nn], dofs, prof, force_profiles=fs._force_tables().T, perm=perm)
+    rows = [s.row(fs) for s in fs.params_control.sensor_list]
+    u_n = fs.fields.ic.u.vector().get_local()
+    u_nn = u_n.copy()
+    ys, order = [], 1
+    for k in range(6):
+        up = ts.step(order, u_n, u_nn, [us[k]])
+        order = 2
+        u_nn, u_n = u_n, up[: 2 * th.nn]
+        ys.append([w @ up[i] for i, w in rows])
+    y_dev = fs.timeseries[["y_meas_1", "y_meas_2"]].to_numpy()[1:]
+    assert _rel_l2(y_dev, np.array(ys)) < 1e-8
+    assert _rel_l2(fs.fields.u_.vector().get_local(), u_n) < 1e-8
+    fs.th.release_device()
