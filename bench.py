@@ -11,8 +11,8 @@ sensors → energy, synchronised back to the host every step as the reference's 
 
 One JSON line on rank 0 with the driver's keys plus
   roofline      dominant kernel (fc_nd_sweep): algorithmic bytes per launch ÷ mean launch duration
-                measured with HIP events on the solver's stream during an instrumented replay of
-                the same K steps
+                measured with HIP events on the solver's stream (one pair around the back-to-back
+                sweep launches of each apply) during an instrumented replay of the same K steps
   cpu_baseline  the CPU oracle (numpy assembly + SuperLU factor-once/solve-many, 1 core) timed on
                 a bounded sample of the same workload
   spmv          CSR SpMV probe on the assembled BDF2 matrix (cache resident) and on a

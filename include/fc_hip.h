@@ -194,9 +194,10 @@ int fc_comm_init(fc_handle h, int nranks, int rank, const char* id128);
 int fc_step_phase(fc_handle h, int order_slot, int phase, const double* u_ctrl, int compute_energy,
                   double* root_io, double* tail_io);
 
-/* per-launch HIP-event timing inside fc_step / fc_run: when on, every factor-sweep launch and
- * every in-step CSR SpMV launch is bracketed by an event pair on the handle's stream; totals are
- * accumulated after the step's synchronisation.  fc_set_timing resets the accumulators. */
+/* HIP-event timing inside fc_step / fc_run: when on, the back-to-back factor-sweep launches of
+ * every apply are bracketed by ONE event pair on the handle's stream (sweep_ms / sweep_launches =
+ * mean launch duration including the inter-launch gap) and every in-step CSR SpMV launch by its own
+ * pair; totals are accumulated after the step's synchronisation.  fc_set_timing resets them. */
 int fc_set_timing(fc_handle h, int on);
 int fc_get_timing(fc_handle h, double* sweep_ms, int64_t* sweep_launches, double* spmv_ms,
                   int64_t* spmv_launches);
