@@ -530,7 +530,7 @@ int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, 
   const double *x = nullptr, *dx = nullptr;
   int nrp = 0;
   FCCHK(solve_permuted(h, S, &x, &dx, &nrp));
-  const int g = nblocks(h->N, 256);
+  const int g = nblocks(h->N, 32);  // fc_finish: 8 lanes per row, 32 rows per workgroup
   double* e_partial = h->partial.p + 2 * (size_t)h->nblk_N;  // energy partials live after the residual ones
   if (!h->partitioned) {
     hipLaunchKernelGGL(fc_finish, dim3(g), dim3(256), 0, h->stream, h->N, 2 * h->nn, h->perm.p, x, dx, h->up.p, h->u_n.p,
@@ -1311,7 +1311,7 @@ int fc_step_phase(fc_handle h, int order_slot, int phase, const double* u_ctrl, 
     if (nrp < 0) return nrp;
   }
   double* e_partial = h->partial.p + 2 * (size_t)h->nblk_N;
-  hipLaunchKernelGGL(fc_finish, dim3(g), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, x, (const double*)nullptr, h->up.p,
+  hipLaunchKernelGGL(fc_finish, dim3(nblocks(N, 32)), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, x, (const double*)nullptr, h->up.p,
                      h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p, (const int*)nullptr, (const int*)nullptr,
                      (const double*)nullptr, (double*)nullptr, h->rowkind_p.p);
   int ne = 0;
@@ -1491,10 +1491,10 @@ int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double*
       dx = h->buf.p + N;
       FCCHK(lap(2));
     }
-    hipLaunchKernelGGL(fc_finish, dim3(g), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, x, dx, h->up.p, h->u_n.p,
+    hipLaunchKernelGGL(fc_finish, dim3(nblocks(N, 32)), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, x, dx, h->up.p, h->u_n.p,
                        h->u_nn.p, h->p_n.p, h->flag.p, h->mp_rowptr.p, h->mp_col.p, h->mp_val.p, e_partial,
                        (const unsigned char*)nullptr);
-    hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, g, e_partial, h->scal.p, nrp,
+    hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, nblocks(N, 32), e_partial, h->scal.p, nrp,
                        nrp > 0 ? h->partial.p : nullptr, h->scal.p + 1, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p,
                        h->up.p, h->ydev.p, h->flag.p, (double*)nullptr, (double*)nullptr, 0.0);
     FCCHK(lap(4));

@@ -541,25 +541,32 @@ __global__ __launch_bounds__(256) void fc_finish(int N, int nn2, const int* __re
                                                  const double* __restrict__ m_val,
                                                  double* __restrict__ e_partial,
                                                  const unsigned char* __restrict__ rowkind) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // 8 lanes per (permuted) row: they share the mass-matrix row of the energy term (coalesced 8 x 12 B
+  // per trip), lane 0 scatters / shifts the row's dof
+  constexpr int LANES = 8, RPB = 256 / LANES;
+  const int lane = threadIdx.x % LANES;
+  const int i = blockIdx.x * RPB + threadIdx.x / LANES;
   double e = 0.0;
   if (i < N && (!rowkind || rowkind[i] != 0)) {
     const int r = perm[i];
     const double v = dx ? x[i] + dx[i] : x[i];
-    up[r] = v;
     if (r < nn2) {
-      u_nn[r] = u_n[r];
-      u_n[r] = v;
-      if (!isfinite(v)) atomicOr(flag, 1);
       if (m_rowptr) {
         double s = 0.0;
-        for (int k = m_rowptr[i]; k < m_rowptr[i + 1]; ++k) {
+        for (int k = m_rowptr[i] + lane; k < m_rowptr[i + 1]; k += LANES) {
           const int j = m_col[k];
           s += m_val[k] * (dx ? x[j] + dx[j] : x[j]);
         }
         e = v * s;
       }
-    } else {
+      if (lane == 0) {
+        up[r] = v;
+        u_nn[r] = u_n[r];
+        u_n[r] = v;
+        if (!isfinite(v)) atomicOr(flag, 1);
+      }
+    } else if (lane == 0) {
+      up[r] = v;
       p_n[r - nn2] = v;
     }
   }
