@@ -519,6 +519,29 @@ int enqueue_energy(fc_ctx* h, const double* d_u, double* d_out) {
   return FC_OK;
 }
 
+// single-GPU step without refinement: residual monitor + state shift + energy are ONE launch (then fc_final)
+bool use_fused_tail(const fc_ctx* h) {
+  static const bool enabled = [] {
+    const char* e = std::getenv("FC_FUSED_TAIL");  // 0: residual SpMV and fc_finish as separate launches
+    return !(e && e[0] == '0');
+  }();
+  return enabled && !h->partitioned && h->max_iter == 0;
+}
+
+int launch_tail(fc_ctx* h, OrderSys& S, int compute_energy, double* d_y, double* d_E, double* d_r, double* d_flag_out,
+                double* d_seq, double seq) {
+  const bool res = h->check_residual != 0;
+  const int g = nblocks(h->N, 32);
+  hipLaunchKernelGGL(fc_tail, dim3(g), dim3(256), 0, h->stream, h->N, 2 * h->nn, h->perm.p, h->buf.p + h->N, h->b.p,
+                     res ? S.Ap_rowptr.p : nullptr, S.Ap_col.p, S.Ap_val.p, compute_energy ? h->mp_rowptr.p : nullptr,
+                     h->mp_col.p, h->mp_val.p, h->up.p, h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p, h->partial.p);
+  hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, g, compute_energy ? h->partial.p + 2 * (size_t)g : nullptr,
+                     d_E, res ? g : 0, res ? h->partial.p : nullptr, d_r, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p,
+                     h->up.p, d_y, h->flag.p, d_flag_out, d_seq, seq);
+  HIPCHK(hipGetLastError());
+  return FC_OK;
+}
+
 // enqueue one full step; y -> d_y, E -> d_E; residual norms -> scal[1], scal[2]
 int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, double* d_E, double* d_r,
                  double* d_flag_out, int compute_energy, const double* d_uforce = nullptr, double* d_seq = nullptr,
@@ -529,6 +552,10 @@ int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, 
   FCCHK(enqueue_rhs(h, order_slot, d_uctrl, d_uforce));
   const double *x = nullptr, *dx = nullptr;
   int nrp = 0;
+  if (use_fused_tail(h)) {
+    FCCHK(apply_factors(h, S));
+    return launch_tail(h, S, compute_energy, d_y, d_E, d_r, d_flag_out, d_seq, seq);
+  }
   FCCHK(solve_permuted(h, S, &x, &dx, &nrp));
   const int g = nblocks(h->N, 32);  // fc_finish: 8 lanes per row, 32 rows per workgroup
   double* e_partial = h->partial.p + 2 * (size_t)h->nblk_N;  // energy partials live after the residual ones
@@ -1473,6 +1500,11 @@ int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double*
     const double* x = h->buf.p + N;
     const double* dx = nullptr;
     int nrp = 0;
+    if (use_fused_tail(h)) {
+      FCCHK(launch_tail(h, S, 1, h->ydev.p, h->scal.p, h->scal.p + 1, nullptr, nullptr, 0.0));
+      FCCHK(lap(4));
+      continue;
+    }
     if (h->max_iter == 0 && h->check_residual) {
       nrp = launch_spmv<1>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, x, h->b.p, h->tmpN.p, nullptr, h->partial.p);
       if (nrp < 0) return nrp;
