@@ -80,7 +80,7 @@ struct Stage {
   int kind;  // 0 up, 1 down
   int lanes, sub;  // lanes per row, lanes per segment slot
   int64_t blk_begin = 0;  // down stages: LDS-tiled block kernel (fc_nd_down_block) when blk_count > 0
-  int blk_count = 0, blk_lpr = 64;
+  int blk_count = 0, blk_lpr = 64, blk_rps = 1;
   double bytes;  // algorithmic bytes of this launch
 };
 
@@ -328,12 +328,22 @@ int launch_spmv(fc_ctx* h, int nrows, double mean, const int* rp, const int* col
 int launch_sweep(fc_ctx* h, const OrderSys& S, const Stage& st) {
   if (st.kind == 1 && st.blk_count > 0) {
     const FcBlk* bp = S.blk.p + st.blk_begin;
-    if (st.blk_lpr == 16)
-      hipLaunchKernelGGL((fc_nd_down_block<16>), dim3(st.blk_count), dim3(256), 0, h->stream, bp, S.f_idx.p, S.f_val.p, h->buf.p, h->N);
-    else if (st.blk_lpr == 32)
-      hipLaunchKernelGGL((fc_nd_down_block<32>), dim3(st.blk_count), dim3(256), 0, h->stream, bp, S.f_idx.p, S.f_val.p, h->buf.p, h->N);
-    else
-      hipLaunchKernelGGL((fc_nd_down_block<64>), dim3(st.blk_count), dim3(256), 0, h->stream, bp, S.f_idx.p, S.f_val.p, h->buf.p, h->N);
+#define FC_BLOCK(L, R)                                                                                                   \
+  hipLaunchKernelGGL((fc_nd_down_block<L, R>), dim3(st.blk_count), dim3(256), 0, h->stream, bp, S.f_idx.p, S.f_val.p, \
+                     h->buf.p, h->N)
+    switch (st.blk_lpr * 100 + st.blk_rps) {
+      case 1601: FC_BLOCK(16, 1); break;
+      case 1602: FC_BLOCK(16, 2); break;
+      case 3201: FC_BLOCK(32, 1); break;
+      case 3202: FC_BLOCK(32, 2); break;
+      case 3204: FC_BLOCK(32, 4); break;
+      case 6401: FC_BLOCK(64, 1); break;
+      case 6402: FC_BLOCK(64, 2); break;
+      case 6404: FC_BLOCK(64, 4); break;
+      case 6408: FC_BLOCK(64, 8); break;
+      default: return fail(FC_ERR_INVALID, "launch_sweep: unsupported block geometry");
+    }
+#undef FC_BLOCK
     HIPCHK(hipGetLastError());
     return FC_OK;
   }
@@ -1163,6 +1173,13 @@ int fc_solver_set_blocks(fc_handle h, int slot, int32_t n_stages, const int64_t*
     st.blk_begin = stage_blk_begin[s];
     st.blk_count = stage_blk_count[s];
     st.blk_lpr = stage_lpr[s];
+    // rows per row slot: the smallest power of two that covers the stage's tallest block
+    int maxr = 1;
+    for (int64_t q = stage_blk_begin[s]; q < stage_blk_begin[s] + stage_blk_count[s]; ++q) maxr = std::max(maxr, (int)blk_nrows[q]);
+    const int slots = 256 / std::max(16, st.blk_lpr);
+    int rps = 1;
+    while (rps * slots < maxr) rps *= 2;
+    st.blk_rps = rps;
   }
   FCCHK(S.blk.upload(packed, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));

@@ -453,21 +453,34 @@ struct __attribute__((aligned(16))) FcBlk {
 
 #define FC_BLK_TILE 2048
 
-template <int LPR>
+// RPS = rows per row slot: a workgroup covers up to RPS * (256 / LPR) rows of its node.  The first
+// trip of every row's value stream (4 x LPR values) depends only on the block descriptor, so it is
+// issued BEFORE the operand gather: descriptor -> {values | index list -> operand} is a chain of
+// three memory round trips instead of five (descriptor, indices, operand, LDS, values).  On the
+// small nodes near the leaves (row width <= 4 x LPR) that first trip is the whole row.
+template <int LPR, int RPS>
 __global__ __launch_bounds__(256) void fc_nd_down_block(const FcBlk* __restrict__ blk,
                                                         const int* __restrict__ idxlist,
                                                         const double* __restrict__ val,
                                                         double* __restrict__ buf, int N) {
   __shared__ double xs[FC_BLK_TILE];
   constexpr int SLOTS = 256 / LPR;  // rows in flight per workgroup
-  constexpr int MAXR = 32;          // rows per workgroup (host guarantees nrows <= MAXR)
-  constexpr int RPS = (MAXR + SLOTS - 1) / SLOTS;
   const FcBlk b = blk[blockIdx.x];
   const int slot = threadIdx.x / LPR, l = threadIdx.x % LPR;
   const int wd = b.ni + b.nb;
-  double acc[RPS];
+  const int tl0 = wd < FC_BLK_TILE ? wd : FC_BLK_TILE;
+  double acc[RPS], pv[RPS][4];
 #pragma unroll
-  for (int k = 0; k < RPS; ++k) acc[k] = 0.0;
+  for (int k = 0; k < RPS; ++k) {
+    acc[k] = 0.0;
+    const int r = slot + k * SLOTS;
+    const double* __restrict__ v = val + b.val + (long long)r * wd;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = l + u * LPR;
+      pv[k][u] = (r < b.nrows && j < tl0) ? v[j] : 0.0;
+    }
+  }
   for (int t0 = 0; t0 < wd; t0 += FC_BLK_TILE) {
     const int tl = wd - t0 < FC_BLK_TILE ? wd - t0 : FC_BLK_TILE;
     for (int j = threadIdx.x; j < tl; j += 256) {
@@ -481,7 +494,16 @@ __global__ __launch_bounds__(256) void fc_nd_down_block(const FcBlk* __restrict_
       if (r < b.nrows) {
         const double* __restrict__ v = val + b.val + (long long)r * wd + t0;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        for (int base = 0; base < tl; base += 4 * LPR) {
+        int base = 0;
+        if (t0 == 0) {
+          const int j0 = l, j1 = j0 + LPR, j2 = j1 + LPR, j3 = j2 + LPR;
+          s0 = pv[k][0] * (j0 < tl ? xs[j0] : 0.0);
+          s1 = pv[k][1] * (j1 < tl ? xs[j1] : 0.0);
+          s2 = pv[k][2] * (j2 < tl ? xs[j2] : 0.0);
+          s3 = pv[k][3] * (j3 < tl ? xs[j3] : 0.0);
+          base = 4 * LPR;
+        }
+        for (; base < tl; base += 4 * LPR) {
           const int j0 = base + l, j1 = j0 + LPR, j2 = j1 + LPR, j3 = j2 + LPR;
           const double v0 = j0 < tl ? v[j0] : 0.0, v1 = j1 < tl ? v[j1] : 0.0;
           const double v2 = j2 < tl ? v[j2] : 0.0, v3 = j3 < tl ? v[j3] : 0.0;
@@ -493,7 +515,7 @@ __global__ __launch_bounds__(256) void fc_nd_down_block(const FcBlk* __restrict_
         acc[k] += (s0 + s1) + (s2 + s3);
       }
     }
-    __syncthreads();
+    if (t0 + FC_BLK_TILE < wd) __syncthreads();
   }
 #pragma unroll
   for (int k = 0; k < RPS; ++k) {

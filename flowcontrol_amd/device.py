@@ -203,7 +203,9 @@ class DeviceSolver:
             )
         )
         if self.use_block_kernel:
-            bb, bc, bl, bval, brow0, bnr, bi0, bni, bidx, bnb = ndsolver.down_blocks(fac, self.rank, self.world)
+            bb, bc, bl, bval, brow0, bnr, bi0, bni, bidx, bnb = ndsolver.down_blocks(
+                fac, self.rank, self.world, target_blocks=int(os.environ.get("FC_BLOCK_TARGET", "1024")),
+                min_blocks=int(os.environ.get("FC_BLOCK_MIN", "512")))
             z64, z32 = np.zeros(1, np.int64), np.zeros(1, np.int32)
             pick = lambda a, z: a if a.size else z  # noqa: E731
             check(

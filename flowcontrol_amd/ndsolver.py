@@ -497,17 +497,20 @@ def factorize_blocks(A: sp.csr_matrix, tree: NDTree) -> BlockFactors:
     )
 
 
-def down_blocks(fac: BlockFactors, rank: int = 0, world: int = 1, max_rows: int = 32, target_blocks: int = 2048,
-                min_stage_values: float = 4.0e6):
+def down_blocks(fac: BlockFactors, rank: int = 0, world: int = 1, max_rows: int = 32, target_blocks: int = 1024,
+                min_blocks: int = 512):
     """Workgroup tiles of the down-sweep stages for ``fc_solver_set_blocks``.
 
     Returns per-stage arrays (begin, count, lanes-per-row) aligned with the stage list of
     :func:`partition` (up stages get count 0) and the block arrays.  A block is ≤ ``max_rows``
-    consecutive rows of one tree node; rows per block shrink for stages with few rows so that a launch
-    still has ≳ ``target_blocks`` workgroups.  With ``world > 1`` only the rank's nodes (and the root)
-    are tiled.  Stages that stream fewer than ``min_stage_values`` values stay on the segment kernel:
-    they are launch-latency bound and the LDS staging round trip only adds to that (measured on the
-    56 k-dof cylinder mesh: −3 %; on the 223 k-dof refined mesh the tiled kernel is +16 %)."""
+    consecutive rows of one tree node; lanes per row follow the row width (4 × lanes ≥ width when
+    possible: the whole row is then one trip of loads) and rows per block shrink for stages with few
+    rows so that a launch still has ≳ ``target_blocks`` workgroups.  With ``world > 1`` only the
+    rank's nodes (and the root) are tiled.  A stage is tiled when that gives ≥ ``min_blocks``
+    workgroups even at the smallest tile; a stage of few, long rows (the root of a small mesh) stays
+    on the segment kernel, which puts a whole workgroup on each row (measured on the 56 k-dof
+    cylinder mesh, per-launch medians: leaves 10.1 → 7.0 µs, level 4: 8.6 → 6.6, level 3:
+    7.5 → 6.3, level 2: 8.4 → 6.9, level 1: 9.1 → 8.4, but root 5.6 → 7.1)."""
     t = fac.tree
     p = int(np.log2(world)) if world > 1 else 0
     nodes = fac.nodes
@@ -527,15 +530,17 @@ def down_blocks(fac: BlockFactors, rank: int = 0, world: int = 1, max_rows: int 
             sh = t.cum[k] - p
             sel = sel[(sel[:, 1] >> sh) == rank]
         sel = sel[np.argsort(sel[:, 2])]
-        if float(((sel[:, 3] + sel[:, 4]) * sel[:, 3]).sum()) < min_stage_values:
+        values = float(((sel[:, 3] + sel[:, 4]) * sel[:, 3]).sum())
+        rows = int(sel[:, 3].sum())
+        wd_mean = values / max(rows, 1)
+        lpr[s] = 16 if wd_mean <= 64 else (32 if wd_mean <= 128 else 64)
+        slots = 256 // int(lpr[s])
+        if rows // slots < min_blocks:
             begin[s] = nblk
             continue
-        rows = int(sel[:, 3].sum())
         rc = max_rows
-        while rc > 4 and rows // rc < target_blocks:
+        while rc > slots and rows // rc < target_blocks:
             rc //= 2
-        wd_mean = float(((sel[:, 3] + sel[:, 4]) * sel[:, 3]).sum() / max(rows, 1))
-        lpr[s] = 16 if wd_mean <= 256 else (32 if wd_mean <= 1024 else 64)
         begin[s] = nblk
         for _, n, i0, ni, nb, voff, ioff in sel:
             wd = ni + nb

@@ -200,16 +200,21 @@ def test_block_and_segment_down_sweeps_agree(setup):
     dev.apply_bc(SLOT_BDF2)
     b = np.random.default_rng(3).standard_normal(dev.N)
     orig = ndsolver.down_blocks
+    results = []
     try:
         dev.use_block_kernel = False
         dev.setup_solver(SLOT_BDF2)
         x_seg, _ = dev.solve(SLOT_BDF2, b)
         dev.use_block_kernel = True
-        ndsolver.down_blocks = lambda fac, rank=0, world=1, **kw: orig(fac, rank, world, min_stage_values=0.0)
-        dev.setup_solver(SLOT_BDF2)
-        x_blk, info = dev.solve(SLOT_BDF2, b)
+        # target_blocks 1 / 64 / huge: 32 / intermediate / fewest rows per workgroup, i.e. every
+        # (lanes per row, rows per slot) instantiation of the kernel
+        for target in (1, 64, 1 << 30):
+            ndsolver.down_blocks = lambda fac, rank=0, world=1, **kw: orig(fac, rank, world, target_blocks=target, min_blocks=1)  # noqa: B023
+            dev.setup_solver(SLOT_BDF2)
+            results.append(dev.solve(SLOT_BDF2, b))
     finally:
         ndsolver.down_blocks = orig
         dev.use_block_kernel = True
-    assert _rel(x_blk, x_seg) < 1e-12
-    assert info[1] < 1e-9
+    for x_blk, info in results:
+        assert _rel(x_blk, x_seg) < 1e-12
+        assert info[1] < 1e-9
