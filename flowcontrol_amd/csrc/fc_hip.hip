@@ -1097,6 +1097,23 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
     }
     if (lanes < 8) lanes = 8;
     if (sub > lanes) sub = lanes;
+    if (const char* e = std::getenv("FC_SWEEP_GEOM")) {  // tuning aid: "lanes:sub,lanes:sub,..." per stage, 0 = keep
+      int idx = 0, l = 0, sb = 0;
+      const char* p = e;
+      while (*p && idx <= s) {
+        l = std::atoi(p);
+        const char* c = std::strchr(p, ':');
+        sb = c ? std::atoi(c + 1) : 0;
+        if (idx == s && l > 0 && sb > 0) {
+          lanes = l;
+          sub = sb;
+        }
+        const char* nx = std::strchr(p, ',');
+        if (!nx) break;
+        p = nx + 1;
+        ++idx;
+      }
+    }
     st.lanes = lanes;
     st.sub = sub;
     // algorithmic bytes: values 8 B, x/y operand 8 B per value is served on-chip (vectors are < 1 MB),

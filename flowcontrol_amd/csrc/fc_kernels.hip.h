@@ -621,11 +621,37 @@ __global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restric
                                                 double* __restrict__ seq_out, double seq) {
   __shared__ double red[3][256];
   const int t = threadIdx.x;
+  // a single workgroup is pure latency: issue every load up front (8 partials per thread and array,
+  // predicated; the sensor rows' index/weight chain right behind them), reduce afterwards
+  constexpr int U = 8;
+  double pe[U], pr[U], pb[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int i = t + 256 * u;
+    pe[u] = (e_partial && i < n_e) ? e_partial[i] : 0.0;
+    pr[u] = (r_partial && i < n_r) ? r_partial[i] : 0.0;
+    pb[u] = (r_partial && i < n_r) ? r_partial[n_r + i] : 0.0;
+  }
+  // sensors: one wave per row, waves take rows round-robin
+  const int wave = t >> 6, lane = t & 63;
+  for (int s = wave; s < n_sens; s += 4) {
+    double acc = 0.0;
+    for (int k = s_rowptr[s] + lane; k < s_rowptr[s + 1]; k += 64) acc += s_w[k] * up[s_idx[k]];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) y[s] = acc;
+  }
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    a0 += pe[u];
+    a1 += pr[u];
+    a2 += pb[u];
+  }
   if (e_partial)
-    for (int i = t; i < n_e; i += 256) a0 += e_partial[i];
+    for (int i = t + 256 * U; i < n_e; i += 256) a0 += e_partial[i];
   if (r_partial)
-    for (int i = t; i < n_r; i += 256) {
+    for (int i = t + 256 * U; i < n_r; i += 256) {
       a1 += r_partial[i];
       a2 += r_partial[n_r + i];
     }
@@ -648,15 +674,6 @@ __global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restric
       r_out[1] = red[2][0];
     }
     if (flag_out) flag_out[0] = (double)flag[0];
-  }
-  // sensors: one wave per row, waves take rows round-robin
-  const int wave = t >> 6, lane = t & 63;
-  for (int s = wave; s < n_sens; s += 4) {
-    double acc = 0.0;
-    for (int k = s_rowptr[s] + lane; k < s_rowptr[s + 1]; k += 64) acc += s_w[k] * up[s_idx[k]];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if (lane == 0) y[s] = acc;
   }
   if (seq_out) {
     __threadfence_system();

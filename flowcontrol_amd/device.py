@@ -175,7 +175,7 @@ class DeviceSolver:
             check(self.lib.fc_set_permutation(self._h, _i32(self.tree.perm)))
             self._upload_energy_matrix()
         t = self.tree
-        fac = ndsolver.factorize_blocks(A, t)
+        fac = ndsolver.split_up_segments(ndsolver.factorize_blocks(A, t), int(os.environ.get("FC_UP_SPLIT", "0")))
         part = ndsolver.partition(fac, self.rank, self.world)
         if getattr(self, "_force_comm", False):
             # single-rank communicator: everything is owned, the root rows are "shared" with nobody

@@ -497,6 +497,35 @@ def factorize_blocks(A: sp.csr_matrix, tree: NDTree) -> BlockFactors:
     )
 
 
+def split_up_segments(fac: BlockFactors, maxlen: int) -> BlockFactors:
+    """Cut the up-sweep segments into pieces of ≤ ``maxlen`` values (same values, same order).
+
+    A sub-group of lanes covers ``maxlen`` values with one trip of loads; with every segment a single
+    trip, the sub-groups of a row run side by side and the row is one memory round trip deep instead
+    of one per (long) segment."""
+    if maxlen <= 0:
+        return fac
+    nseg = fac.seg_len.size
+    up = np.zeros(nseg, dtype=bool)
+    for s in range(len(fac.stage_kind)):
+        if fac.stage_kind[s] == 0:
+            b, nr = int(fac.stage_begin[s]), int(fac.stage_nrows[s])
+            up[int(fac.seg_ptr[b]) : int(fac.seg_ptr[b + nr])] = True
+    pieces = np.where(up, np.maximum(1, -(-fac.seg_len.astype(np.int64) // maxlen)), 1)
+    cp = np.concatenate([[0], np.cumsum(pieces)])
+    rep = np.repeat(np.arange(nseg), pieces)
+    within = np.arange(int(cp[-1])) - cp[:-1][rep]
+    off = within * maxlen
+    new_len = np.where(up[rep], np.minimum(maxlen, fac.seg_len[rep] - off), fac.seg_len[rep])
+    from dataclasses import replace
+
+    return replace(
+        fac, seg_val=np.ascontiguousarray(fac.seg_val[rep] + off, dtype=np.int64),
+        seg_col=np.ascontiguousarray(fac.seg_col[rep] + np.where(up[rep], off, 0), dtype=np.int32),
+        seg_len=np.ascontiguousarray(new_len, dtype=np.int32), seg_ptr=np.ascontiguousarray(cp[fac.seg_ptr], dtype=np.int64),
+    )
+
+
 def down_blocks(fac: BlockFactors, rank: int = 0, world: int = 1, max_rows: int = 32, target_blocks: int = 1024,
                 min_blocks: int = 512):
     """Workgroup tiles of the down-sweep stages for ``fc_solver_set_blocks``.
@@ -554,7 +583,7 @@ def down_blocks(fac: BlockFactors, rank: int = 0, world: int = 1, max_rows: int 
     return begin, count, lpr, arr(0, np.int64), arr(1, np.int32), arr(2, np.int32), arr(3, np.int32), arr(4, np.int32), arr(5, np.int32), arr(6, np.int32)
 
 
-__all__ += ["BlockFactors", "factorize_blocks", "down_blocks"]
+__all__ += ["BlockFactors", "factorize_blocks", "down_blocks", "split_up_segments"]
 
 
 # ──────────────────────────────────────────────────────────────────────────────────────────
