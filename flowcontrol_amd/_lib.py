@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import shutil
 import subprocess
 from pathlib import Path
@@ -78,6 +79,9 @@ SIGNATURES: dict[str, list] = {
     "fc_set_permutation": [_H, _ip],
     "fc_solver_setup": [_H, C.c_int, _ip, _ip, _dp, C.c_int32, _lp, _ip, _ip, _ip, _lp, C.c_int64, _lp, _ip, _ip, C.c_int64, _ip, C.c_int64, _dp, C.c_int32, C.c_int32, C.c_int32],
     "fc_set_energy_matrix": [_H, _ip, _ip, _dp],
+    "fc_factor_plan": [_H, C.c_int32, _lp, C.c_int32, _lp, C.c_int64, C.c_int64, _lp, _lp, _lp, _lp, C.c_int64, _ip, C.c_int64, _lp, C.c_int32],
+    "fc_refactor": [_H, C.c_int, C.c_void_p],
+    "fc_get_factor_values": [_H, C.c_int, C.c_int64, _dp],
     "fc_solver_set_blocks": [_H, C.c_int, C.c_int32, _lp, _ip, _ip, C.c_int64, _lp, _ip, _ip, _ip, _ip, _ip, _ip, C.c_int64, C.c_int64],
     "fc_set_solver_options": [_H, C.c_int, C.c_int, C.c_double, C.c_int],
     "fc_set_state": [_H, _dp, _dp, C.c_void_p],
@@ -104,6 +108,28 @@ SIGNATURES: dict[str, list] = {
 _lib = None
 
 
+def _preload_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm ships its own ``libamdhip64.so`` (soname
+    ``libamdhip64.so.7``, but its dependants ask for it by the un-versioned file name): if libfc_hip.so were
+    loaded first it would bind to /opt/rocm's copy and a later ``import torch`` would bring a second runtime
+    into the process — streams and buffers of one are garbage to libraries (RCCL, rocBLAS) bound to the
+    other.  Loading torch's copy first (when torch is installed) makes every later request resolve to it.
+    ``FC_SYSTEM_HIP=1`` skips this (torch-free deployments)."""
+    if os.environ.get("FC_SYSTEM_HIP", "0") == "1" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = Path(list(spec.submodule_search_locations)[0]) / "lib" / "libamdhip64.so"
+        if cand.exists():
+            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass  # fall back to the system runtime
+
+
 def load(build_if_missing: bool = True) -> C.CDLL:
     """dlopen the library (building it first if the sources are newer) and set prototypes."""
     global _lib
@@ -117,6 +143,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
                 raise
     if not LIB_PATH.exists():
         raise FcError(FC_ERR_HIP, f"{LIB_PATH} is missing: the HIP extension is required (no CPU fallback)")
+    _preload_hip_runtime()
     lib = C.CDLL(str(LIB_PATH))
     lib.fc_last_error.restype = C.c_char_p
     lib.fc_last_error.argtypes = []

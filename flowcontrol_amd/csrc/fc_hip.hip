@@ -9,6 +9,8 @@
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
 
 #include <algorithm>
 #include <cmath>
@@ -86,6 +88,7 @@ struct Stage {
 
 struct OrderSys {
   bool have_lift = false, ready = false;
+  bool structured = false;  // segment lists / stage table uploaded (fc_solver_setup); values may be stale
   DevBuf<double> lift;    // [n_act][N] original numbering
   DevBuf<double> lift_p;  // [n_act][N] permuted
   DevBuf<int> Ap_rowptr, Ap_col;
@@ -177,6 +180,21 @@ struct fc_ctx {
   // per-launch HIP-event timing (fc_set_timing): pairs recorded around every sweep / SpMV launch
   bool timing = false;
   std::vector<hipEvent_t> tev;   // pool, 2 per launch
+  // device-side numeric factorisation (fc_factor_plan / fc_refactor)
+  struct PlanNode {
+    int64_t front, voff;
+    int level, nf, ni, parent;
+  };
+  bool have_plan = false;
+  std::vector<PlanNode> pnodes;
+  std::vector<int64_t> plevel_ptr, pa_ptr;
+  std::vector<std::vector<std::pair<int64_t, int>>> pext_groups;  // per (level, slot): (first FcExt, count)
+  std::vector<std::vector<int>> pext_maxnb;
+  int pmax_slots = 1, pmax_ni = 0;
+  DevBuf<double> fronts;
+  DevBuf<int64_t> pa_src, pa_dst, pap_src;
+  DevBuf<FcExt> pext;
+  DevBuf<int> pext_p, pipiv;
   std::vector<int> tkind;        // 0 sweep, 1 spmv (per recorded pair)
   std::vector<int> tcount;       // kernel launches bracketed by the pair
   size_t tused = 0;
@@ -227,6 +245,65 @@ int rccl_load() {
     if (_r != 0)                                                                                  \
       return fail(FC_ERR_HIP, std::string(#expr) + ": " +                                         \
                                   (g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "rccl error")); \
+  } while (0)
+
+// rocBLAS / rocSOLVER (dense pivot-block inverses and front updates of fc_refactor) are resolved at run
+// time as well: the time-stepping path does not depend on them, and inside a torch process the
+// copies torch already loaded are reused.
+struct DenseLibs {
+  void* blas = nullptr;
+  void* solver = nullptr;
+  rocblas_handle handle = nullptr;
+  decltype(&rocblas_create_handle) create_handle = nullptr;
+  decltype(&rocblas_destroy_handle) destroy_handle = nullptr;
+  decltype(&rocblas_set_stream) set_stream = nullptr;
+  decltype(&rocblas_dgemm) dgemm = nullptr;
+  decltype(&rocsolver_dgetrf) dgetrf = nullptr;
+  decltype(&rocsolver_dgetri_outofplace) dgetri = nullptr;
+};
+DenseLibs g_dense;
+
+int dense_load() {
+  if (g_dense.handle) return FC_OK;
+  // take the copies that sit next to the HIP runtime this library is bound to (PyTorch ships its own
+  // set): a rocBLAS bound to another runtime would not understand our stream
+  std::string dir;
+  Dl_info di;
+  if (dladdr((void*)&hipStreamSynchronize, &di) && di.dli_fname) {
+    dir = di.dli_fname;
+    const size_t cut = dir.rfind('/');
+    dir = cut == std::string::npos ? std::string() : dir.substr(0, cut + 1);
+  }
+  const std::string blas_names[] = {dir + "librocblas.so", dir + "librocblas.so.5", "librocblas.so.5", "librocblas.so",
+                                    "/opt/rocm/lib/librocblas.so.5"};
+  const std::string solver_names[] = {dir + "librocsolver.so", dir + "librocsolver.so.0", "librocsolver.so.0", "librocsolver.so",
+                                      "/opt/rocm/lib/librocsolver.so.0"};
+  for (const std::string& n : blas_names)
+    if ((g_dense.blas = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL))) break;
+  if (!g_dense.blas) return fail(FC_ERR_HIP, std::string("cannot load rocBLAS: ") + dlerror());
+  for (const std::string& n : solver_names)
+    if ((g_dense.solver = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL))) break;
+  if (!g_dense.solver) return fail(FC_ERR_HIP, std::string("cannot load rocSOLVER: ") + dlerror());
+  g_dense.create_handle = (decltype(g_dense.create_handle))dlsym(g_dense.blas, "rocblas_create_handle");
+  g_dense.destroy_handle = (decltype(g_dense.destroy_handle))dlsym(g_dense.blas, "rocblas_destroy_handle");
+  g_dense.set_stream = (decltype(g_dense.set_stream))dlsym(g_dense.blas, "rocblas_set_stream");
+  g_dense.dgemm = (decltype(g_dense.dgemm))dlsym(g_dense.blas, "rocblas_dgemm");
+  g_dense.dgetrf = (decltype(g_dense.dgetrf))dlsym(g_dense.solver, "rocsolver_dgetrf");
+  g_dense.dgetri = (decltype(g_dense.dgetri))dlsym(g_dense.solver, "rocsolver_dgetri_outofplace");
+  if (!g_dense.create_handle || !g_dense.set_stream || !g_dense.dgemm || !g_dense.dgetrf || !g_dense.dgetri)
+    return fail(FC_ERR_HIP, "rocBLAS / rocSOLVER symbols missing");
+  rocblas_handle hd = nullptr;
+  const rocblas_status cs = g_dense.create_handle(&hd);
+  if (cs != rocblas_status_success) return fail(FC_ERR_HIP, "rocblas_create_handle failed with status " + std::to_string((int)cs));
+  g_dense.handle = hd;
+  return FC_OK;
+}
+
+#define ROCCHK(expr)                                                                             \
+  do {                                                                                           \
+    rocblas_status _r = (expr);                                                                  \
+    if (_r != rocblas_status_success)                                                            \
+      return fail(FC_ERR_HIP, std::string(#expr) + ": rocblas status " + std::to_string((int)_r)); \
   } while (0)
 
 constexpr int kNcclDouble = 8, kNcclSum = 0;
@@ -1009,7 +1086,7 @@ int fc_set_permutation(fc_handle h, const int32_t* perm) {
   FCCHK(h->perm.upload(h->h_perm, h->stream));
   h->have_perm = true;
   h->have_mp = false;
-  for (int o = 0; o < 2; ++o) h->sys[o].ready = false;
+  for (int o = 0; o < 2; ++o) h->sys[o].ready = h->sys[o].structured = false;
   return refresh_permuted(h);
 }
 
@@ -1146,6 +1223,7 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
   FCCHK(S.f_val.upload(vals, (size_t)n_val, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   S.ready = true;
+  S.structured = true;
   return FC_OK;
 }
 
@@ -1199,6 +1277,169 @@ int fc_solver_set_blocks(fc_handle h, int slot, int32_t n_stages, const int64_t*
     st.blk_rps = rps;
   }
   FCCHK(S.blk.upload(packed, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return FC_OK;
+}
+
+int fc_factor_plan(fc_handle h, int32_t n_nodes, const int64_t* nodes, int32_t n_levels, const int64_t* level_ptr,
+                   int64_t front_size, int64_t n_a, const int64_t* a_src, const int64_t* a_dst, const int64_t* a_ptr,
+                   const int64_t* ext_off, int64_t n_ext, const int32_t* ext_p, int64_t n_ap, const int64_t* ap_src,
+                   int32_t max_slots) {
+  if (!h || n_nodes <= 0 || !nodes || n_levels <= 0 || !level_ptr || front_size <= 0 || n_a < 0 || !a_src || !a_dst || !a_ptr ||
+      !ext_off || n_ext < 0 || !ext_p || n_ap <= 0 || !ap_src || max_slots < 1 || max_slots > 64)
+    return fail(FC_ERR_INVALID, "fc_factor_plan: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  if (level_ptr[0] != 0 || level_ptr[n_levels] != n_nodes || a_ptr[0] != 0 || a_ptr[n_levels] != n_a)
+    return fail(FC_ERR_INVALID, "fc_factor_plan: level pointers do not cover the nodes / entries");
+  h->have_plan = false;
+  h->pnodes.assign((size_t)n_nodes, {});
+  h->pmax_ni = 0;
+  for (int g = 0; g < n_nodes; ++g) {
+    const int64_t* r = nodes + (size_t)g * 7;  // level, front offset, nf, ni, value offset, parent, child slot
+    fc_ctx::PlanNode& nd = h->pnodes[g];
+    nd.level = (int)r[0];
+    nd.front = r[1];
+    nd.nf = (int)r[2];
+    nd.ni = (int)r[3];
+    nd.voff = r[4];
+    nd.parent = (int)r[5];
+    if (nd.nf < 0 || nd.ni < 0 || nd.ni > nd.nf || nd.front < 0 || nd.front + (int64_t)nd.nf * nd.nf > front_size ||
+        nd.parent >= n_nodes || (nd.parent >= 0 && nd.parent <= g) || r[6] < 0 || r[6] >= max_slots || (nd.ni > 0 && nd.voff < 0))
+      return fail(FC_ERR_INVALID, "fc_factor_plan: node table out of range");
+    h->pmax_ni = std::max(h->pmax_ni, nd.ni);
+  }
+  for (int64_t k = 0; k < n_a; ++k)
+    if (a_src[k] < 0 || a_src[k] >= h->nnz || a_dst[k] < 0 || a_dst[k] >= front_size)
+      return fail(FC_ERR_INVALID, "fc_factor_plan: matrix scatter map out of range");
+  for (int64_t k = 0; k < n_ap; ++k)
+    if (ap_src[k] < 0 || ap_src[k] >= h->nnz) return fail(FC_ERR_INVALID, "fc_factor_plan: permuted-matrix map out of range");
+  h->plevel_ptr.assign(level_ptr, level_ptr + n_levels + 1);
+  h->pa_ptr.assign(a_ptr, a_ptr + n_levels + 1);
+  h->pmax_slots = max_slots;
+  // extend-add descriptors grouped by (level of the children, child slot)
+  std::vector<FcExt> ext;
+  h->pext_groups.assign((size_t)n_levels, std::vector<std::pair<int64_t, int>>((size_t)max_slots, {0, 0}));
+  h->pext_maxnb.assign((size_t)n_levels, std::vector<int>((size_t)max_slots, 0));
+  for (int li = 0; li < n_levels; ++li) {
+    for (int sl = 0; sl < max_slots; ++sl) {
+      const int64_t first = (int64_t)ext.size();
+      int mx = 0;
+      for (int64_t g = level_ptr[li]; g < level_ptr[li + 1]; ++g) {
+        const fc_ctx::PlanNode& c = h->pnodes[(size_t)g];
+        if (ext_off[g] < 0 || nodes[(size_t)g * 7 + 6] != sl) continue;
+        const int nbc = c.nf - c.ni;
+        if (c.parent < 0 || nbc <= 0 || ext_off[g] + nbc > n_ext) return fail(FC_ERR_INVALID, "fc_factor_plan: bad extend-add entry");
+        const fc_ctx::PlanNode& par = h->pnodes[(size_t)c.parent];
+        if (par.level != c.level - 1) return fail(FC_ERR_INVALID, "fc_factor_plan: parent is not one level up");
+        for (int i = 0; i < nbc; ++i)
+          if (ext_p[ext_off[g] + i] < 0 || ext_p[ext_off[g] + i] >= par.nf) return fail(FC_ERR_INVALID, "fc_factor_plan: extend-add position out of range");
+        ext.push_back(FcExt{(long long)(c.front + (int64_t)c.ni * c.nf + c.ni), (long long)par.front, c.nf, par.nf, nbc, (int)ext_off[g]});
+        mx = std::max(mx, nbc);
+      }
+      h->pext_groups[li][sl] = {first, (int)((int64_t)ext.size() - first)};
+      h->pext_maxnb[li][sl] = mx;
+    }
+  }
+  if (ext.empty()) ext.push_back(FcExt{0, 0, 0, 0, 0, 0});
+  FCCHK(h->fronts.alloc((size_t)front_size));
+  FCCHK(h->pa_src.upload(a_src, (size_t)std::max<int64_t>(1, n_a), h->stream));
+  FCCHK(h->pa_dst.upload(a_dst, (size_t)std::max<int64_t>(1, n_a), h->stream));
+  FCCHK(h->pap_src.upload(ap_src, (size_t)n_ap, h->stream));
+  FCCHK(h->pext.upload(ext, h->stream));
+  FCCHK(h->pext_p.upload(ext_p, (size_t)std::max<int64_t>(1, n_ext), h->stream));
+  FCCHK(h->pipiv.alloc((size_t)h->pmax_ni + 8));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->have_plan = true;
+  return FC_OK;
+}
+
+int fc_refactor(fc_handle h, int slot, double* ms_out) {
+  if (!h || slot < 0 || slot > 1) return fail(FC_ERR_INVALID, "fc_refactor: bad argument");
+  if (!h->have_plan) return fail(FC_ERR_NOT_READY, "fc_factor_plan not called");
+  if (h->partitioned) return fail(FC_ERR_INVALID, "fc_refactor: single-GPU handles only");
+  OrderSys& S = h->sys[slot];
+  if (!S.structured) return fail(FC_ERR_NOT_READY, "fc_solver_setup (structure) must be called first");
+  if (!S.have_lift) return fail(FC_ERR_NOT_READY, "fc_apply_bc not called for this slot");
+  if ((int64_t)h->pap_src.n != S.Ap_nnz) return fail(FC_ERR_INVALID, "fc_refactor: plan and solver structure disagree (matrix)");
+  HIPCHK(hipSetDevice(h->device));
+  FCCHK(dense_load());
+  ROCCHK(g_dense.set_stream(g_dense.handle, h->stream));
+  for (const fc_ctx::PlanNode& nd : h->pnodes) {
+    const int nb = nd.nf - nd.ni;
+    if (nd.ni > 0 && nd.voff + (int64_t)nd.ni * nd.nf + (int64_t)nb * nd.ni > S.f_nnz)
+      return fail(FC_ERR_INVALID, "fc_refactor: plan and solver structure disagree (factor values)");
+  }
+  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  const double* av = h->vals[slot].p;
+  double* F = h->fronts.p;
+  double* fv = S.f_val.p;
+  // permuted copy of the matrix for the residual monitor
+  hipLaunchKernelGGL(fc_gather64, dim3(nblocks(S.Ap_nnz, 256)), dim3(256), 0, h->stream, S.Ap_nnz, h->pap_src.p, av, S.Ap_val.p);
+  HIPCHK(hipMemsetAsync(F, 0, h->fronts.n * sizeof(double), h->stream));
+  const int64_t n_a = h->pa_ptr.back();
+  if (n_a > 0)
+    hipLaunchKernelGGL(fc_front_scatter, dim3(nblocks(n_a, 256)), dim3(256), 0, h->stream, n_a, h->pa_src.p, h->pa_dst.p, av, F);
+  const int n_levels = (int)h->plevel_ptr.size() - 1;
+  int* ipiv = h->pipiv.p;
+  int* info = h->pipiv.p + h->pmax_ni;
+  const double one = 1.0, zero = 0.0, minus = -1.0;
+  for (int li = 0; li < n_levels; ++li) {
+    if (li > 0) {
+      // update blocks of the level below, one launch per child slot (deterministic, conflict-free)
+      for (int sl = 0; sl < h->pmax_slots; ++sl) {
+        const auto grp = h->pext_groups[li - 1][sl];
+        if (grp.second == 0) continue;
+        const int gx = (h->pext_maxnb[li - 1][sl] + FC_EXT_ROWS - 1) / FC_EXT_ROWS;
+        hipLaunchKernelGGL(fc_extend_add, dim3(gx, grp.second), dim3(256), 0, h->stream, h->pext.p + grp.first, h->pext_p.p, F);
+      }
+    }
+    for (int64_t g = h->plevel_ptr[li]; g < h->plevel_ptr[li + 1]; ++g) {
+      const fc_ctx::PlanNode& nd = h->pnodes[(size_t)g];
+      const int ni = nd.ni, nf = nd.nf, nb = nf - ni;
+      if (ni == 0) continue;
+      double* Fn = F + nd.front;  // row-major nf x nf: [F11 F12; F21 F22]
+      // D^-1 = F11^-1, written straight into the factor rows [D^-1 | -U] (stride nf).  The column-major
+      // view LAPACK sees is F11^T; (F11^T)^-1 stored column-major is F11^-1 stored row-major, which is what
+      // the sweeps read.  Out-of-place getri: the in-place rocsolver_dgetri of ROCm 7.0/7.2 returns wrong
+      // inverses for n = 255, 383, 511, 639, 1023, 1151, ... (n = 127 mod 128; scripts/micro/getri_check.py).
+      double* dv = fv + nd.voff;
+      ROCCHK(g_dense.dgetrf(g_dense.handle, ni, ni, Fn, nf, ipiv, info));
+      ROCCHK(g_dense.dgetri(g_dense.handle, ni, Fn, nf, ipiv, dv, nf, info));
+      if (nb > 0) {
+        double* F12 = Fn + ni;
+        double* F21 = Fn + (size_t)ni * nf;
+        double* F22 = F21 + ni;
+        double* mW = dv + (size_t)ni * nf;  // -L rows (nb x ni), stride ni
+        // row-major C = A B  <=>  column-major C' = B' A' (same memory): operands swapped below
+        // -U = -D^-1 F12   (ni x nb), written next to D^-1
+        ROCCHK(g_dense.dgemm(g_dense.handle, rocblas_operation_none, rocblas_operation_none, nb, ni, ni, &minus, F12, nf, dv, nf, &zero,
+                             dv + ni, nf));
+        // -L = -F21 D^-1   (nb x ni)
+        ROCCHK(g_dense.dgemm(g_dense.handle, rocblas_operation_none, rocblas_operation_none, ni, nb, ni, &minus, dv, nf, F21, nf, &zero,
+                             mW, ni));
+        // Schur complement handed to the parent: F22 += (-L) F12
+        if (nd.parent >= 0)
+          ROCCHK(g_dense.dgemm(g_dense.handle, rocblas_operation_none, rocblas_operation_none, nb, nb, ni, &one, F12, nf, mW, ni, &one,
+                               F22, nf));
+      }
+    }
+  }
+  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  HIPCHK(hipEventSynchronize(h->ev1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  if (ms_out) *ms_out = (double)ms;
+  S.ready = true;
+  return FC_OK;
+}
+
+int fc_get_factor_values(fc_handle h, int slot, int64_t n, double* out) {
+  if (!h || slot < 0 || slot > 1 || !out) return fail(FC_ERR_INVALID, "fc_get_factor_values: bad argument");
+  OrderSys& S = h->sys[slot];
+  if (!S.structured) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this slot");
+  if (n != S.f_nnz) return fail(FC_ERR_INVALID, "fc_get_factor_values: size differs from the uploaded factors");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(out, S.f_val.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return FC_OK;
 }

@@ -528,6 +528,43 @@ __global__ __launch_bounds__(256) void fc_nd_down_block(const FcBlk* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Device-side numeric factorisation (fc_refactor): index kernels around the dense library calls.
+// ---------------------------------------------------------------------------------------------
+// fronts[a_dst[k]] = vals[a_src[k]]: every matrix entry has exactly one slot in exactly one front
+__global__ void fc_front_scatter(int64_t n, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                                 const double* __restrict__ vals, double* __restrict__ fronts) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) fronts[dst[k]] = vals[src[k]];
+}
+__global__ void fc_gather64(int64_t n, const int64_t* __restrict__ src, const double* __restrict__ vals,
+                            double* __restrict__ out) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) out[k] = vals[src[k]];
+}
+// extend-add: parent[p[i], p[j]] += child update block [i, j].  One launch covers the c-th child of
+// every parent of a level, so no two workgroups of a launch touch the same parent entry.
+struct __attribute__((aligned(16))) FcExt {
+  long long src;  // child front: offset of its update block (row stride nfc)
+  long long dst;  // parent front offset (row stride nfp)
+  int nfc, nfp;
+  int nbc;   // order of the update block
+  int poff;  // offset of the child's position list
+};
+#define FC_EXT_ROWS 8
+__global__ __launch_bounds__(256) void fc_extend_add(const FcExt* __restrict__ ext, const int* __restrict__ p,
+                                                     double* __restrict__ fronts) {
+  const FcExt d = ext[blockIdx.y];
+  const int i0 = blockIdx.x * FC_EXT_ROWS;
+  if (i0 >= d.nbc) return;
+  const int* __restrict__ pp = p + d.poff;
+  for (int i = i0; i < i0 + FC_EXT_ROWS && i < d.nbc; ++i) {
+    const double* __restrict__ srow = fronts + d.src + (long long)i * d.nfc;
+    double* __restrict__ drow = fronts + d.dst + (long long)pp[i] * d.nfp;
+    for (int j = threadIdx.x; j < d.nbc; j += 256) drow[pp[j]] += srow[j];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // small vector kernels
 // ---------------------------------------------------------------------------------------------
 __global__ void fc_copy(int n, const double* __restrict__ a, double* __restrict__ b) {

@@ -54,6 +54,13 @@ class DeviceSolver:
         self.use_block_kernel = os.environ.get("FC_BLOCK_KERNEL", "1") != "0"  # LDS-tiled down-sweeps
         self.part: ndsolver.RankPartition | None = None
         self._sensor_rows: list | None = None
+        # numeric factorisation on the device (fc_refactor); FC_HOST_FACTOR=1 keeps the numpy multifrontal
+        self.device_factor = os.environ.get("FC_HOST_FACTOR", "0") != "1"
+        self._fac_struct: ndsolver.BlockFactors | None = None
+        self._plan: ndsolver.FactorPlan | None = None
+        self._structured: set[int] = set()
+        self.refactor_ms: dict[int, float] = {}
+        self._probe: np.ndarray | None = None
         self.device_index = device
 
     # ── multi-GPU ────────────────────────────────────────────────────────────
@@ -122,6 +129,10 @@ class DeviceSolver:
         bc_dofs = _i32(bc_dofs)
         profiles = _f64(profiles).reshape(len(bc_dofs), -1) if len(bc_dofs) else np.zeros((0, np.shape(profiles)[-1] if np.ndim(profiles) > 1 else 0))
         self.n_act = profiles.shape[1]
+        if self.tree is not None and not np.array_equal(np.sort(bc_dofs), np.sort(getattr(self, "bc_dofs", bc_dofs))):
+            # the elimination tree parks the Dirichlet dofs in the leaves: a different set needs a new tree
+            self.tree, self._fac_struct, self._plan = None, None, None
+            self._structured.clear()
         self.bc_dofs = bc_dofs
         check(self.lib.fc_set_bc(self._h, len(bc_dofs), ptr(bc_dofs), self.n_act, ptr(np.ascontiguousarray(profiles))))
 
@@ -155,15 +166,20 @@ class DeviceSolver:
         check(self.lib.fc_apply_bc(self._h, slot))
 
     # ── solver setup (host analysis + factorisation, device upload) ──────────
-    def setup_solver(self, slot: int, depth: int | None = None, refine: int = 0, check_residual: bool = True, merge: int = 2) -> None:
+    def setup_solver(self, slot: int, depth: int | None = None, refine: int = 0, check_residual: bool = True, merge: int = 2,
+                     restructure: bool = False) -> None:
         """Factorise the (BC-eliminated) matrix of ``slot`` and hand the factors to the device.
 
         ``depth`` binary bisections (default: leaves of ≈ 12 cells), fused ``merge`` at a time into a
         2**merge-ary elimination tree (on ``world`` GPUs the root is ``world``-ary first: one sub-tree
         per rank); ``refine`` iterative-refinement sweeps per solve (the fp64 selected inverse is
         accurate to round-off on its own, so 0 + residual monitoring is the default).
+
+        On a single-GPU handle the host only lays out the structure (once per tree); the numbers are
+        computed on the device (``fc_refactor``), and a later call for the same slot is just that numeric
+        phase (``restructure=True`` uploads the launch geometry again).  Partitioned handles and
+        ``FC_HOST_FACTOR=1`` use the numpy multifrontal of :mod:`ndsolver`.
         """
-        A = self.matrix(slot)
         if self.tree is None:
             th = self.th
             top = int(np.log2(self.world)) if self.world > 1 else 0
@@ -171,11 +187,37 @@ class DeviceSolver:
                 depth = max(merge + top, int(np.ceil(np.log2(max(th.nc, 1) / 12.0))))
             skip = np.zeros(self.N, dtype=bool)
             skip[self.bc_dofs] = True
+            self._skip = skip
             self.tree = ndsolver.build_tree(th.cell_dofs, th.mesh.cell_centroids(), self.N, depth, skip, merge=merge, top_bits=top)
             check(self.lib.fc_set_permutation(self._h, _i32(self.tree.perm)))
             self._upload_energy_matrix()
         t = self.tree
-        fac = ndsolver.split_up_segments(ndsolver.factorize_blocks(A, t), int(os.environ.get("FC_UP_SPLIT", "0")))
+        on_device = self.device_factor and self.world == 1 and not getattr(self, "_force_comm", False)
+        up_split = int(os.environ.get("FC_UP_SPLIT", "0"))
+        if on_device:
+            # structure on the host (index work only, once per tree), numbers on the device
+            if self._fac_struct is None:
+                self._fac_struct = ndsolver.factorize_blocks(None, t, numeric=False)
+                pl = ndsolver.factor_plan(self._fac_struct, self.rowptr, self.colidx, self._skip)
+                check(self.lib.fc_factor_plan(
+                    self._h, int(pl.nodes.shape[0]), pl.nodes, int(pl.level_ptr.size - 1), pl.level_ptr, int(pl.front_size),
+                    int(pl.a_src.size), pl.a_src if pl.a_src.size else np.zeros(1, np.int64), pl.a_dst if pl.a_dst.size else np.zeros(1, np.int64),
+                    pl.a_ptr, pl.ext_off, int(pl.ext_p.size), pl.ext_p, int(pl.ap_src.size), pl.ap_src, int(pl.max_slots)))
+                self._plan = pl
+                tag = sp.csr_matrix((np.ones(self.nnz), self.colidx, self.rowptr), shape=(self.N, self.N))
+                Ap = tag[t.perm][:, t.perm].tocsr()
+                Ap.sort_indices()
+                self._Ap_struct = Ap
+            if slot in self._structured and not restructure:
+                self.refactor(slot)
+                self.set_solver_options(refine, check_residual)
+                return
+            fac, Ap = ndsolver.split_up_segments(self._fac_struct, up_split), self._Ap_struct
+        else:
+            A = self.matrix(slot)
+            fac = ndsolver.split_up_segments(ndsolver.factorize_blocks(A, t), up_split)
+            Ap = A[t.perm][:, t.perm].tocsr()
+            Ap.sort_indices()
         part = ndsolver.partition(fac, self.rank, self.world)
         if getattr(self, "_force_comm", False):
             # single-rank communicator: everything is owned, the root rows are "shared" with nobody
@@ -188,8 +230,6 @@ class DeviceSolver:
             self.part = part
             if self._sensor_rows is not None:
                 self.set_sensors(self._sensor_rows)
-        Ap = A[t.perm][:, t.perm].tocsr()
-        Ap.sort_indices()
         idx = fac.idx if fac.idx.size else np.zeros(1, dtype=np.int32)
         seg_val = part.seg_val if part.seg_val.size else np.zeros(1, dtype=np.int64)
         seg_col = part.seg_col if part.seg_col.size else np.zeros(1, dtype=np.int32)
@@ -214,12 +254,44 @@ class DeviceSolver:
                     pick(bi0, z32), pick(bni, z32), pick(bidx, z32), pick(bnb, z32), int(fac.idx.size), int(fac.vals.size),
                 )
             )
+        if on_device:
+            self._structured.add(slot)
+            self.refactor(slot)
         self.factor_nnz[slot] = int(fac.nnz)
+        self._n_factor_values = int(fac.vals.size)
         self.local_factor_nnz = int(part.seg_len.sum())
         self.n_stages = len(part.stage_kind)
         self.set_solver_options(refine, check_residual)
 
+    def refactor(self, slot: int) -> float:
+        """Numeric factorisation of the slot's current matrix on the device (the structure of the first
+        ``setup_solver`` is reused): what ``solver.set_operator(A)`` costs.  Returns device milliseconds."""
+        if slot not in self._structured:
+            raise RuntimeError("setup_solver(slot) must run once before refactor(slot)")
+        ms = C.c_double()
+        check(self.lib.fc_refactor(self._h, slot, C.byref(ms)))
+        self.refactor_ms[slot] = ms.value
+        # end-to-end acceptance of the new factors: one solve with a fixed right-hand side, residual
+        # against the matrix itself (the dense libraries are not trusted blindly, cf. scripts/micro/getri_check.py)
+        if self._probe is None:
+            self._probe = np.cos(0.37 * np.arange(self.N) + 0.1)
+        opts = getattr(self, "_solver_opts", (0, True))
+        check(self.lib.fc_set_solver_options(self._h, _lib.METHOD_REFINE, 0, 1e-10, 1))
+        _, info = self.solve(slot, self._probe)
+        self.set_solver_options(*opts)
+        if not info[1] < 1e-8:
+            raise _lib.FcError(_lib.FC_ERR_HIP, f"device factorisation of slot {slot} failed its residual check ({info[1]:.2e})")
+        return ms.value
+
+    def factor_values(self, slot: int) -> np.ndarray:
+        """Factor values of ``slot`` as they sit on the device (layout of :class:`ndsolver.BlockFactors`)."""
+        n = int(self._fac_struct.vals.size) if self._fac_struct is not None else int(self._n_factor_values)
+        out = np.empty(n)
+        check(self.lib.fc_get_factor_values(self._h, slot, n, out))
+        return out
+
     def set_solver_options(self, refine: int = 0, check_residual: bool = True) -> None:
+        self._solver_opts = (int(refine), bool(check_residual))
         check(self.lib.fc_set_solver_options(self._h, _lib.METHOD_REFINE, int(refine), 1e-10, int(check_residual)))
 
     def _upload_energy_matrix(self) -> None:

@@ -348,10 +348,16 @@ class BlockFactors:
         return x
 
 
-def factorize_blocks(A: sp.csr_matrix, tree: NDTree) -> BlockFactors:
-    """Numeric multifrontal factorisation with explicit pivot-block inverses → block factors."""
-    N = A.shape[0]
+def factorize_blocks(A: sp.csr_matrix | None, tree: NDTree, numeric: bool = True) -> BlockFactors:
+    """Numeric multifrontal factorisation with explicit pivot-block inverses → block factors.
+
+    ``numeric=False`` lays out the structure only (segment lists, index lists, value offsets; ``vals``
+    all zero, ``A`` may be None): the values are then computed on the device (:func:`factor_plan`,
+    ``fc_refactor``)."""
     t = tree
+    N = int(t.perm.size)
+    if not numeric:
+        A = sp.csr_matrix((N, N))
     Ap = A[t.perm][:, t.perm].tocoo()
     r_, c_, v_ = Ap.row.astype(np.int64), Ap.col.astype(np.int64), Ap.data
     keep = v_ != 0.0
@@ -392,6 +398,8 @@ def factorize_blocks(A: sp.csr_matrix, tree: NDTree) -> BlockFactors:
             nb = B.size
             children = t.children(k, n) if k < t.depth else ()
             if ni == 0:
+                if not numeric:
+                    continue
                 F = np.zeros((nb, nb))
                 for ch in children:
                     cb, cu = updates.pop((k + 1, ch))
@@ -400,56 +408,62 @@ def factorize_blocks(A: sp.csr_matrix, tree: NDTree) -> BlockFactors:
                         F[np.ix_(p, p)] += cu
                 updates[(k, n)] = (B, F)
                 continue
-            idxs = np.concatenate([np.arange(i0, i1), B])
             nf = ni + nb
-            F = np.zeros((nf, nf))
-            g = gid[(k, n)]
-            er, ec, ev = r_[ebeg[g] : ebeg[g + 1]], c_[ebeg[g] : ebeg[g + 1]], v_[ebeg[g] : ebeg[g + 1]]
-            rin, cin = er < i1, ec < i1  # owner = node of min(r, c) ⇒ both ≥ i0
-            pr = np.where(rin, er - i0, ni + np.searchsorted(B, er))
-            pc = np.where(cin, ec - i0, ni + np.searchsorted(B, ec))
-            if nb:
-                bad = (~rin & (B[np.clip(pr - ni, 0, nb - 1)] != er)) | (~cin & (B[np.clip(pc - ni, 0, nb - 1)] != ec))
-            else:
-                bad = ~rin | ~cin
-            if np.any(bad):
-                raise RuntimeError("matrix entry outside the front: tree/boundary sets inconsistent")
-            np.add.at(F, (pr, pc), ev)
-            for ch in children:
-                cb, cu = updates.pop((k + 1, ch))
-                if cb.size:
-                    p = np.searchsorted(idxs, cb)
-                    F[np.ix_(p, p)] += cu
-            Dinv = np.linalg.inv(F[:ni, :ni])
             rows = np.arange(i0, i1)
+            if numeric:
+                idxs = np.concatenate([np.arange(i0, i1), B])
+                F = np.zeros((nf, nf))
+                g = gid[(k, n)]
+                er, ec, ev = r_[ebeg[g] : ebeg[g + 1]], c_[ebeg[g] : ebeg[g + 1]], v_[ebeg[g] : ebeg[g + 1]]
+                rin, cin = er < i1, ec < i1  # owner = node of min(r, c) ⇒ both ≥ i0
+                pr = np.where(rin, er - i0, ni + np.searchsorted(B, er))
+                pc = np.where(cin, ec - i0, ni + np.searchsorted(B, ec))
+                if nb:
+                    bad = (~rin & (B[np.clip(pr - ni, 0, nb - 1)] != er)) | (~cin & (B[np.clip(pc - ni, 0, nb - 1)] != ec))
+                else:
+                    bad = ~rin | ~cin
+                if np.any(bad):
+                    raise RuntimeError("matrix entry outside the front: tree/boundary sets inconsistent")
+                np.add.at(F, (pr, pc), ev)
+                for ch in children:
+                    cb, cu = updates.pop((k + 1, ch))
+                    if cb.size:
+                        p = np.searchsorted(idxs, cb)
+                        F[np.ix_(p, p)] += cu
+                Dinv = np.linalg.inv(F[:ni, :ni])
             if nb:
-                F12, F21 = F[:ni, ni:], F[ni:, :ni]
-                Wt = F21 @ Dinv
-                Vt = Dinv @ F12
-                updates[(k, n)] = (B, F[ni:, ni:] - Wt @ F12)
-                DV = np.hstack([Dinv, -Vt])  # (ni, ni+nb) row-major: one contiguous row per dof
+                if numeric:
+                    F12, F21 = F[:ni, ni:], F[ni:, :ni]
+                    Wt = F21 @ Dinv
+                    Vt = Dinv @ F12
+                    updates[(k, n)] = (B, F[ni:, ni:] - Wt @ F12)
+                    vals_chunks.append(np.hstack([Dinv, -Vt]).ravel())  # (ni, ni+nb) row-major: one contiguous row per dof
+                    vals_chunks.append((-Wt).ravel())  # (nb, ni) row-major: row j feeds dof B[j]
+                else:
+                    vals_chunks.append(np.zeros(ni * nf + nb * ni))
                 node_rows.append((k, n, i0, ni, nb, vpos, ipos))
-                vals_chunks.append(DV.ravel())
                 dn_val[rows, 0] = vpos + np.arange(ni) * nf
                 dn_val[rows, 1] = vpos + np.arange(ni) * nf + ni
-                vpos += DV.size
+                vpos += ni * nf
                 idx_chunks.append((N + B).astype(np.int32))
                 dn_col[rows, 0], dn_len[rows, 0] = i0, ni
                 dn_col[rows, 1], dn_len[rows, 1] = -(ipos + 1), nb
                 ipos += nb
-                vals_chunks.append((-Wt).ravel())  # (nb, ni) row-major: row j feeds dof B[j]
                 up_rows.append(B)
                 up_val.append(vpos + np.arange(nb, dtype=np.int64) * ni)
                 up_col.append(np.full(nb, i0, dtype=np.int32))
                 up_len.append(np.full(nb, ni, dtype=np.int32))
-                vpos += Wt.size
+                vpos += nb * ni
                 nnz += ni * ni + 2 * ni * nb
             else:
-                updates[(k, n)] = (B, np.zeros((0, 0)))
+                if numeric:
+                    updates[(k, n)] = (B, np.zeros((0, 0)))
+                    vals_chunks.append(Dinv.ravel())
+                else:
+                    vals_chunks.append(np.zeros(ni * ni))
                 node_rows.append((k, n, i0, ni, 0, vpos, 0))
-                vals_chunks.append(Dinv.ravel())
                 dn_val[rows, 0] = vpos + np.arange(ni) * ni
-                vpos += Dinv.size
+                vpos += ni * ni
                 dn_col[rows, 0], dn_len[rows, 0] = i0, ni
                 nnz += ni * ni
     vals = np.concatenate(vals_chunks) if vals_chunks else np.zeros(0)
@@ -495,6 +509,166 @@ def factorize_blocks(A: sp.csr_matrix, tree: NDTree) -> BlockFactors:
         stage_kind=np.array(kind, dtype=np.int32), stage_begin=begin, nnz=int(nnz),
         nodes=np.array(node_rows, dtype=np.int64).reshape(-1, 7),
     )
+
+
+@dataclass
+class FactorPlan:
+    """Everything the device needs to redo the NUMERIC factorisation on its own (``fc_refactor``).
+
+    Fronts of all tree nodes live in one buffer (row-major, ``nf = ni + nb`` square).  ``nodes`` rows, in
+    elimination order (deepest level first): level, front offset, nf, ni, value offset of the node's
+    ``[D⁻¹ | −U]`` rows in the factor array (−1: empty pivot block), parent row (−1: root), child slot.
+    Matrix entries are scattered with (``a_src`` → CSR value index in the ORIGINAL numbering,
+    ``a_dst`` → offset in the front buffer), grouped per level by ``a_ptr``; a child's update block is
+    added into its parent through the position list ``ext_p[ext_off : ext_off + nb_child]``.
+    ``ap_src`` refreshes the permuted matrix of the residual monitor."""
+
+    nodes: np.ndarray  # (n_nodes, 7) int64
+    level_ptr: np.ndarray  # (n_levels + 1,) node ranges per level, deepest level first
+    front_size: int
+    a_src: np.ndarray
+    a_dst: np.ndarray
+    a_ptr: np.ndarray  # (n_levels + 1,)
+    ext_off: np.ndarray  # (n_nodes,) int64, −1 for nodes without an update block / parent
+    ext_p: np.ndarray  # int32
+    ap_src: np.ndarray  # (nnz of the permuted matrix,) int64
+    max_slots: int
+
+
+def factor_plan(fac: BlockFactors, indptr: np.ndarray, indices: np.ndarray, skip: np.ndarray | None = None) -> FactorPlan:
+    """Symbolic side of the device factorisation for the CSR pattern (``indptr``, ``indices``; original
+    numbering) — pure index work, done once per (tree, pattern).  ``skip`` marks the decoupled
+    (Dirichlet) dofs: their off-diagonal entries are structural zeros after the symmetric elimination and
+    are left out of the fronts."""
+    t = fac.tree
+    N = fac.N
+    nnz = int(indptr[-1])
+    # permuted pattern carrying the original value index (+1 so that no entry is an explicit zero)
+    tag = sp.csr_matrix((np.arange(1, nnz + 1, dtype=np.float64), indices, indptr), shape=(N, N))
+    Ap = tag[t.perm][:, t.perm].tocsr()
+    Ap.sort_indices()
+    ap_src = np.round(Ap.data).astype(np.int64) - 1
+    coo = Ap.tocoo()
+    r_, c_, src = coo.row.astype(np.int64), coo.col.astype(np.int64), ap_src
+    if skip is not None:
+        sk = np.asarray(skip, dtype=bool)[t.perm]
+        keep = ~((sk[r_] | sk[c_]) & (r_ != c_))
+        r_, c_, src = r_[keep], c_[keep], src[keep]
+    K = t.depth
+    # all tree nodes in elimination order
+    lv, nn_, i0s, nis, nbs = [], [], [], [], []
+    for k in range(K, -1, -1):
+        for n in range(t.nnodes(k)):
+            a, b = int(t.node_ptr[k][n]), int(t.node_ptr[k][n + 1])
+            lv.append(k), nn_.append(n), i0s.append(a), nis.append(b - a), nbs.append(int(t.bnd[k][n].size))
+    lv, nn_, i0s, nis, nbs = (np.array(x, dtype=np.int64) for x in (lv, nn_, i0s, nis, nbs))
+    nfs = nis + nbs
+    gid = {(int(k), int(n)): g for g, (k, n) in enumerate(zip(lv, nn_))}
+    front_off = np.concatenate([[0], np.cumsum(nfs * nfs)])
+    voff = np.full(lv.size, -1, dtype=np.int64)
+    for k, n, _i0, _ni, _nb, vo, _io in fac.nodes:
+        voff[gid[(int(k), int(n))]] = vo
+    # owner (node with a non-empty pivot block) of every permuted dof
+    owner = np.full(N, -1, dtype=np.int64)
+    for g in np.nonzero(nis > 0)[0]:
+        owner[i0s[g] : i0s[g] + nis[g]] = g
+    own = owner[np.minimum(r_, c_)]
+    order = np.argsort(own, kind="stable")
+    r_, c_, src, own = r_[order], c_[order], src[order], own[order]
+    beg = np.searchsorted(own, np.arange(lv.size + 1))
+    a_dst = np.empty(r_.size, dtype=np.int64)
+    for g in range(lv.size):
+        a, b = int(beg[g]), int(beg[g + 1])
+        if a == b:
+            continue
+        i0, ni, nb, nf = int(i0s[g]), int(nis[g]), int(nbs[g]), int(nfs[g])
+        B = t.bnd[int(lv[g])][int(nn_[g])]
+        er, ec = r_[a:b], c_[a:b]
+        rin, cin = er < i0 + ni, ec < i0 + ni
+        pr = np.where(rin, er - i0, ni + np.searchsorted(B, er))
+        pc = np.where(cin, ec - i0, ni + np.searchsorted(B, ec))
+        if nb:
+            bad = (~rin & (B[np.clip(pr - ni, 0, nb - 1)] != er)) | (~cin & (B[np.clip(pc - ni, 0, nb - 1)] != ec))
+        else:
+            bad = ~rin | ~cin
+        if np.any(bad):
+            raise RuntimeError("matrix entry outside the front: tree/boundary sets inconsistent")
+        a_dst[a:b] = front_off[g] + pr * nf + pc
+    # per level ranges (nodes are level-sorted, deepest first; `own` ascending ⇒ entries too)
+    level_ptr = np.searchsorted(-lv, -np.arange(K, -2, -1), side="left").astype(np.int64)
+    a_ptr = beg[level_ptr]
+    # extend-add lists
+    parent = np.full(lv.size, -1, dtype=np.int64)
+    slot = np.zeros(lv.size, dtype=np.int64)
+    ext_off = np.full(lv.size, -1, dtype=np.int64)
+    ext_chunks = []
+    pos = 0
+    max_slots = 1
+    for g in range(lv.size):
+        k, n = int(lv[g]), int(nn_[g])
+        if k == K:
+            continue
+        ch = list(t.children(k, n))
+        max_slots = max(max_slots, len(ch))
+        idxs = np.concatenate([np.arange(i0s[g], i0s[g] + nis[g]), t.bnd[k][n]])
+        for c, chn in enumerate(ch):
+            gc = gid[(k + 1, int(chn))]
+            cb = t.bnd[k + 1][int(chn)]
+            if cb.size == 0:
+                continue
+            pp = np.searchsorted(idxs, cb)
+            if np.any(idxs[np.clip(pp, 0, idxs.size - 1)] != cb):
+                raise RuntimeError("child boundary outside the parent front")
+            parent[gc], slot[gc], ext_off[gc] = g, c, pos
+            ext_chunks.append(pp.astype(np.int32))
+            pos += cb.size
+    ext_p = np.concatenate(ext_chunks) if ext_chunks else np.zeros(1, dtype=np.int32)
+    nodes = np.stack([lv, front_off[:-1], nfs, nis, voff, parent, slot], axis=1).astype(np.int64)
+    return FactorPlan(nodes=np.ascontiguousarray(nodes), level_ptr=level_ptr, front_size=int(front_off[-1]),
+                      a_src=np.ascontiguousarray(src), a_dst=np.ascontiguousarray(a_dst), a_ptr=np.ascontiguousarray(a_ptr, dtype=np.int64),
+                      ext_off=ext_off, ext_p=np.ascontiguousarray(ext_p), ap_src=np.ascontiguousarray(ap_src), max_slots=max_slots)
+
+
+def factorize_with_plan(plan: FactorPlan, fac: BlockFactors, values: np.ndarray) -> np.ndarray:
+    """Host replay of exactly what ``fc_refactor`` does on the device (same order of operations): the
+    factor values for the CSR ``values`` (original numbering).  Test reference, not a product path."""
+    F = np.zeros(plan.front_size)
+    vals = np.zeros(fac.vals.size)
+    nodes = plan.nodes
+    np.add.at(F, plan.a_dst, values[plan.a_src])
+    nlev = plan.level_ptr.size - 1
+    for li in range(nlev):
+        g0, g1 = int(plan.level_ptr[li]), int(plan.level_ptr[li + 1])
+        # children of this level's nodes were finished in the previous round: add their update blocks
+        if li > 0:
+            c0, c1 = int(plan.level_ptr[li - 1]), int(plan.level_ptr[li])
+            for s in range(plan.max_slots):
+                for gc in range(c0, c1):
+                    if plan.ext_off[gc] < 0 or nodes[gc, 6] != s:
+                        continue
+                    _, fo, nf, ni, _, par, _ = nodes[gc]
+                    nbc = nf - ni
+                    S = F[fo : fo + nf * nf].reshape(nf, nf)[ni:, ni:]
+                    pp = plan.ext_p[plan.ext_off[gc] : plan.ext_off[gc] + nbc]
+                    _, pfo, pnf = nodes[par, 0], nodes[par, 1], nodes[par, 2]
+                    P = F[pfo : pfo + pnf * pnf].reshape(pnf, pnf)
+                    P[np.ix_(pp, pp)] += S
+        for g in range(g0, g1):
+            _, fo, nf, ni, vo, _, _ = nodes[g]
+            if ni == 0:
+                continue
+            Fm = F[fo : fo + nf * nf].reshape(nf, nf)
+            Dinv = np.linalg.inv(Fm[:ni, :ni])
+            nb = nf - ni
+            if nb:
+                mVt = -(Dinv @ Fm[:ni, ni:])
+                mWt = -(Fm[ni:, :ni] @ Dinv)
+                Fm[ni:, ni:] += mWt @ Fm[:ni, ni:]
+                vals[vo : vo + ni * nf] = np.hstack([Dinv, mVt]).ravel()
+                vals[vo + ni * nf : vo + ni * nf + nb * ni] = mWt.ravel()
+            else:
+                vals[vo : vo + ni * ni] = Dinv.ravel()
+    return vals
 
 
 def split_up_segments(fac: BlockFactors, maxlen: int) -> BlockFactors:
@@ -583,7 +757,8 @@ def down_blocks(fac: BlockFactors, rank: int = 0, world: int = 1, max_rows: int 
     return begin, count, lpr, arr(0, np.int64), arr(1, np.int32), arr(2, np.int32), arr(3, np.int32), arr(4, np.int32), arr(5, np.int32), arr(6, np.int32)
 
 
-__all__ += ["BlockFactors", "factorize_blocks", "down_blocks", "split_up_segments"]
+__all__ += ["BlockFactors", "factorize_blocks", "down_blocks", "split_up_segments", "FactorPlan", "factor_plan",
+            "factorize_with_plan"]
 
 
 # ──────────────────────────────────────────────────────────────────────────────────────────

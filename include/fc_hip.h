@@ -126,6 +126,28 @@ int fc_solver_set_blocks(fc_handle h, int slot, int32_t n_stages, const int64_t*
                          const int64_t* blk_val, const int32_t* blk_row0, const int32_t* blk_nrows,
                          const int32_t* blk_i0, const int32_t* blk_ni, const int32_t* blk_idx,
                          const int32_t* blk_nb, int64_t n_idx, int64_t n_val);
+/* Numeric factorisation ON THE DEVICE (what `solver.set_operator(A)` costs in the reference,
+ * flowsolver.py:697,812-814 -> PETSc/MUMPS numeric phase; also every Newton/Picard iteration of
+ * steadystate.py:60-159).  fc_factor_plan uploads the symbolic side once per (tree, pattern): all
+ * fronts of the elimination tree live in one row-major buffer; `nodes` has 7 int64 per tree node in
+ * elimination order (level, front offset, front order nf, pivot order ni, offset of the node's
+ * [D^-1 | -U] rows in the factor values or -1, parent row or -1, child slot), `level_ptr`/`a_ptr` give
+ * node and matrix-entry ranges per level (deepest first), (a_src, a_dst) scatter the CSR values of a slot
+ * into the fronts, ext_p[ext_off[g] ...] are the positions of child g's update block in its parent's
+ * front, ap_src maps the permuted matrix of the residual monitor to CSR value indices.
+ * fc_refactor(slot) then recomputes the factor values and the permuted matrix of `slot` from the
+ * slot's current CSR values (after fc_assemble_matrix + fc_apply_bc): scatter, per level extend-add of
+ * the children's Schur complements, pivot-block inverse (rocSOLVER getrf/getri, partial pivoting inside
+ * the block) and three GEMMs per node (rocBLAS), written straight into the layout the sweeps read.
+ * The structure (fc_solver_setup / fc_solver_set_blocks) must have been uploaded before, with any
+ * values.  ms_out (optional): device time of the numeric phase.  Single-GPU handles only. */
+int fc_factor_plan(fc_handle h, int32_t n_nodes, const int64_t* nodes, int32_t n_levels, const int64_t* level_ptr,
+                   int64_t front_size, int64_t n_a, const int64_t* a_src, const int64_t* a_dst,
+                   const int64_t* a_ptr, const int64_t* ext_off, int64_t n_ext, const int32_t* ext_p,
+                   int64_t n_ap, const int64_t* ap_src, int32_t max_slots);
+int fc_refactor(fc_handle h, int slot, double* ms_out);
+/* download the factor values of a slot (n = the n_val given to fc_solver_setup): parity checks */
+int fc_get_factor_values(fc_handle h, int slot, int64_t n, double* out);
 /* optional explicit operator C of the right-hand side, b -= C u_n (rows in the solver's permuted
  * numbering, columns = velocity dofs in W numbering): the explicit half of the linear terms of the
  * Crank-Nicolson form (NSForms._cn, nsforms.py:191-236).  rowptr == NULL removes it. */

@@ -203,14 +203,14 @@ def test_block_and_segment_down_sweeps_agree(setup):
     results = []
     try:
         dev.use_block_kernel = False
-        dev.setup_solver(SLOT_BDF2)
+        dev.setup_solver(SLOT_BDF2, restructure=True)
         x_seg, _ = dev.solve(SLOT_BDF2, b)
         dev.use_block_kernel = True
         # target_blocks 1 / 64 / huge: 32 / intermediate / fewest rows per workgroup, i.e. every
         # (lanes per row, rows per slot) instantiation of the kernel
         for target in (1, 64, 1 << 30):
             ndsolver.down_blocks = lambda fac, rank=0, world=1, **kw: orig(fac, rank, world, target_blocks=target, min_blocks=1)  # noqa: B023
-            dev.setup_solver(SLOT_BDF2)
+            dev.setup_solver(SLOT_BDF2, restructure=True)
             results.append(dev.solve(SLOT_BDF2, b))
     finally:
         ndsolver.down_blocks = orig
@@ -218,3 +218,34 @@ def test_block_and_segment_down_sweeps_agree(setup):
     for x_blk, info in results:
         assert _rel(x_blk, x_seg) < 1e-12
         assert info[1] < 1e-9
+
+
+def test_device_factorisation_matches_host_multifrontal(setup):
+    """fc_refactor (scatter, extend-add, rocSOLVER pivot inverses, rocBLAS front updates on the device)
+    against the numpy multifrontal of ndsolver.factorize_blocks on the same matrix and tree: factor
+    values to round-off, then again after the matrix changed (numeric phase only)."""
+    th, dev, d, O = setup
+    from flowcontrol_amd import ndsolver
+    from flowcontrol_amd.device import SLOT_BDF2
+
+    if not dev.device_factor:
+        pytest.skip("FC_HOST_FACTOR=1")
+    dt, Re = 0.005, 100.0
+    dofs, prof = _bc_setup(th)
+    dev.set_bc(dofs, prof)
+    dev.set_time_scheme(dt, True)
+    for scale in (1.0, 1.7):
+        U0 = scale * _smooth_velocity(th)
+        dev.assemble_matrix(SLOT_BDF2, mass=1.5 / dt, nu=1.0 / Re, adv=U0, lin=U0)
+        dev.apply_bc(SLOT_BDF2)
+        dev.setup_solver(SLOT_BDF2)  # second round: numeric phase only
+        assert SLOT_BDF2 in dev._structured and dev.refactor_ms[SLOT_BDF2] > 0
+        A = dev.matrix(SLOT_BDF2)
+        host = ndsolver.factorize_blocks(A, dev.tree)
+        got = dev.factor_values(SLOT_BDF2)
+        assert got.shape == host.vals.shape
+        assert np.abs(got - host.vals).max() <= 1e-10 * np.abs(host.vals).max()
+        b = np.random.default_rng(5).standard_normal(dev.N)
+        x, info = dev.solve(SLOT_BDF2, b)
+        assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-12
+        assert info[1] < 1e-12
