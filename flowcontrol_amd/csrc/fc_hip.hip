@@ -1545,10 +1545,24 @@ int fc_step(fc_handle h, int order_slot, const double* u_ctrl, const double* u_f
   FCCHK(enqueue_step(h, order_slot, dev, dev + 64, dev + 128, dev + 129, dev + 136, compute_energy, dev + 32, dev + 137, seq));
   // the last kernel publishes `seq` behind a system-scope fence: poll the host-mapped word (bounded),
   // then fall back to a stream synchronisation — which is also what reports a faulted kernel
+  // A record is accepted only when its checksum (fc_publish) agrees with the words actually read: the
+  // individual device writes may become visible to the host in any order.
+  auto bits = [](double v) {
+    unsigned long long u;
+    std::memcpy(&u, &v, sizeof u);
+    return u;
+  };
+  auto record_ok = [&]() {
+    if (pin[137] != seq) return false;
+    unsigned long long x = bits(seq);
+    for (int s = 0; s < h->n_sens; ++s) x ^= bits(pin[64 + s]);
+    x ^= bits(pin[128]) ^ bits(pin[129]) ^ bits(pin[130]) ^ bits(pin[136]);
+    return x == bits(pin[138]);
+  };
   bool seen = false;
   if (!h->timing) {
     for (long spin = 0; spin < 20000000L; ++spin) {
-      if (pin[137] == seq) {
+      if (record_ok()) {
         seen = true;
         break;
       }
@@ -1558,6 +1572,7 @@ int fc_step(fc_handle h, int order_slot, const double* u_ctrl, const double* u_f
   if (!seen) {
     HIPCHK(hipStreamSynchronize(h->stream));
     FCCHK(time_collect(h));
+    if (!record_ok()) return fail(FC_ERR_HIP, "fc_step: the step record failed its checksum after stream synchronisation");
   }
   for (int s = 0; s < h->n_sens; ++s)
     if (y_out) y_out[s] = pin[64 + s];

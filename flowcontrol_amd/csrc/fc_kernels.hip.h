@@ -641,6 +641,36 @@ __global__ __launch_bounds__(256) void fc_finish(int N, int nn2, const int* __re
   }
 }
 
+// The step record (y[n_sens], E, |r|^2, |b|^2, flag) may live in host-mapped memory that the host polls
+// instead of synchronising the stream.  ONE thread writes the whole record, then a checksum (XOR of
+// the bit patterns of every word and of the sequence number) and the sequence number itself: the
+// host accepts a record only when the sequence number matches AND the checksum agrees with what it
+// reads, so it is immune to the order in which the individual writes become visible across PCIe.
+__device__ inline void fc_publish(const double* ysrc, int n_sens, double E, double r0, double r1, double fl,
+                                  double* __restrict__ y, double* __restrict__ E_out, double* __restrict__ r_out,
+                                  double* __restrict__ flag_out, double* __restrict__ seq_out, double seq) {
+  unsigned long long x = (unsigned long long)__double_as_longlong(seq);
+  for (int s = 0; s < n_sens; ++s) {
+    const double v = ysrc[s];
+    if (y) y[s] = v;
+    x ^= (unsigned long long)__double_as_longlong(v);
+  }
+  if (E_out) E_out[0] = E;
+  if (r_out) {
+    r_out[0] = r0;
+    r_out[1] = r1;
+  }
+  if (flag_out) flag_out[0] = fl;
+  x ^= (unsigned long long)__double_as_longlong(E) ^ (unsigned long long)__double_as_longlong(r0) ^
+       (unsigned long long)__double_as_longlong(r1) ^ (unsigned long long)__double_as_longlong(fl);
+  if (seq_out) {
+    __threadfence_system();
+    seq_out[1] = __longlong_as_double((long long)x);
+    seq_out[0] = seq;
+    __threadfence_system();
+  }
+}
+
 // tail of a step, ONE workgroup: folds the energy partials (-> E = 1/2 sum) and, if present, the
 // residual partials (sum r^2, sum b^2), evaluates the sensor rows (y_s = sum_k w[k] up[idx[k]],
 // sensor.py:96-98,166-197) and publishes everything to the (host-mapped) record; the step sequence
@@ -669,14 +699,15 @@ __global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restric
     pr[u] = (r_partial && i < n_r) ? r_partial[i] : 0.0;
     pb[u] = (r_partial && i < n_r) ? r_partial[n_r + i] : 0.0;
   }
-  // sensors: one wave per row, waves take rows round-robin
+  // sensors: one wave per row, waves take rows round-robin; results parked in LDS for the publisher
+  __shared__ double ysh[64];
   const int wave = t >> 6, lane = t & 63;
   for (int s = wave; s < n_sens; s += 4) {
     double acc = 0.0;
     for (int k = s_rowptr[s] + lane; k < s_rowptr[s + 1]; k += 64) acc += s_w[k] * up[s_idx[k]];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if (lane == 0) y[s] = acc;
+    if (lane == 0) ysh[s] = acc;
   }
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll
@@ -704,22 +735,9 @@ __global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restric
     }
     __syncthreads();
   }
-  if (t == 0) {
-    if (e_partial && E_out) E_out[0] = 0.5 * red[0][0];
-    if (r_partial && r_out) {
-      r_out[0] = red[1][0];
-      r_out[1] = red[2][0];
-    }
-    if (flag_out) flag_out[0] = (double)flag[0];
-  }
-  if (seq_out) {
-    __threadfence_system();
-    __syncthreads();
-    if (t == 0) {
-      __threadfence_system();
-      seq_out[0] = seq;
-    }
-  }
+  if (t == 0)
+    fc_publish(ysh, n_sens, e_partial ? 0.5 * red[0][0] : 0.0, r_partial ? red[1][0] : 0.0, r_partial ? red[2][0] : 0.0,
+               flag_out ? (double)flag[0] : 0.0, y, E_out, r_out, flag_out, seq_out, seq);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -851,24 +869,7 @@ __global__ __launch_bounds__(256) void fc_energy_elem(int nc, int nn, const int*
 __global__ void fc_publish_tail(const double* __restrict__ tail, double* __restrict__ y, int n_sens,
                                 double* __restrict__ E, double* __restrict__ r, double* __restrict__ flag_out,
                                 double* __restrict__ seq_out, double seq) {
-  const int t = threadIdx.x;
-  if (t < n_sens && y) y[t] = tail[t];
-  if (t == 0) {
-    if (E) E[0] = tail[64];
-    if (r) {
-      r[0] = tail[65];
-      r[1] = tail[66];
-    }
-    if (flag_out) flag_out[0] = tail[72];
-  }
-  if (seq_out) {
-    __threadfence_system();
-    __syncthreads();
-    if (t == 0) {
-      __threadfence_system();
-      seq_out[0] = seq;
-    }
-  }
+  if (threadIdx.x == 0) fc_publish(tail, n_sens, tail[64], tail[65], tail[66], tail[72], y, E, r, flag_out, seq_out, seq);
 }
 
 // one wave per sensor row: y_s = sum_k w[k] up[idx[k]]   (sensor.py:96-98,166-197)

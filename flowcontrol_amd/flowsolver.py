@@ -284,6 +284,7 @@ class FlowSolver(ABC):
         UP0 = self._define_initial_guess(initial_guess)
         ss = SteadyStateSolver(W=self.W, bcu=self._make_BCs().bcu, forms=self.forms, verbose=bool(self.verbose))
         self._mass_ready = False  # the steady solver may reuse the mass slot
+        self._systems_ready = False  # ... and the BDF1 slot / boundary tables of the device handle
         if method == "newton":
             UP0 = ss.newton(UP0, f=f, max_iter=max_iter, **kwargs)
         elif method == "picard":

@@ -1,9 +1,11 @@
 """Steady-state (base-flow) solvers: Newton and Picard.
 
-API mirror of the reference's ``src/flowcontrol/steadystate.py``.  Setup-only code: every
-iteration assembles its operator with the HIP element loop (``fc_assemble_matrix``), the sparse
-direct solve of the iteration runs on the host (SuperLU with a nested-dissection ordering) —
-moving it onto the device is SURVEY §8f "next" row 1.
+API mirror of the reference's ``src/flowcontrol/steadystate.py``.  Every iteration runs on the
+device: the operator is assembled by the HIP element loop (``fc_assemble_matrix``), factorised by
+the device multifrontal numeric phase (``fc_refactor``, the structure being laid out once) and
+applied with the same sweep kernels as a time step; the host only forms norms and updates the
+iterate.  Partitioned (multi-GPU) handles and ``FC_HOST_FACTOR=1`` keep the earlier host path
+(SuperLU with the nested-dissection ordering).
 """
 
 from __future__ import annotations
@@ -15,7 +17,7 @@ import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
 from . import ndsolver
-from ._lib import SLOT_MASS, SLOT_SCRATCH
+from ._lib import SLOT_BDF1, SLOT_MASS, SLOT_SCRATCH
 from .fem.boundary import combine_bcs
 from .fem.spaces import Function
 from .nsforms import NSForms
@@ -30,6 +32,8 @@ class SteadyStateSolver:
         self.forms = forms
         self.verbose = verbose
         self._perm = None
+        self._bc_set = False
+        self.solve_info = None
 
     # ── helpers ──────────────────────────────────────────────────────────────
     def _device(self):
@@ -51,10 +55,33 @@ class SteadyStateSolver:
         x[p] = lu.solve(b[p])
         return x
 
+    def _assemble_on_device(self, coeff, slot=SLOT_SCRATCH) -> None:
+        self._device().assemble_matrix(slot, mass=coeff.mass, nu=coeff.nu, adv=coeff.adv, lin=coeff.lin, pressure=coeff.pressure,
+                                       divergence=coeff.divergence)
+
     def _assemble(self, coeff) -> sp.csr_matrix:
+        self._assemble_on_device(coeff)
+        return self._device().matrix(SLOT_SCRATCH)
+
+    def _on_device(self) -> bool:
         dev = self._device()
-        dev.assemble_matrix(SLOT_SCRATCH, mass=coeff.mass, nu=coeff.nu, adv=coeff.adv, lin=coeff.lin, pressure=coeff.pressure, divergence=coeff.divergence)
-        return dev.matrix(SLOT_SCRATCH)
+        return bool(dev.device_factor) and dev.world == 1 and not getattr(dev, "_force_comm", False)
+
+    def _solve_increment(self, coeff, r: np.ndarray, dofs: np.ndarray) -> np.ndarray:
+        """δ with  A δ = r  on the free rows and δ = 0 on the Dirichlet dofs (``r[dofs]`` is 0)."""
+        if not self._on_device():
+            return self._solve(self._rows_to_identity(self._assemble(coeff), dofs), r, dofs)
+        dev = self._device()
+        if not self._bc_set:
+            # increments vanish on the Dirichlet dofs: homogeneous symmetric elimination, no lifting
+            dev.set_bc(dofs, np.zeros((len(dofs), 1)))
+            self._bc_set = True
+        self._assemble_on_device(coeff, SLOT_BDF1)
+        dev.apply_bc(SLOT_BDF1)
+        dev.setup_solver(SLOT_BDF1, refine=2)  # numeric factorisation on the device (first call: + structure)
+        x, info = dev.solve(SLOT_BDF1, r)
+        self.solve_info = info
+        return x
 
     def _load(self, f) -> np.ndarray:
         """∫ f·v for the P2-interpolated body force (zero when there is no FORCE actuator)."""
@@ -88,7 +115,7 @@ class SteadyStateSolver:
         dev = self._device()
         r0 = None
         for it in range(max_iter + 1):
-            self._assemble(self.forms.steady(UP0, f))
+            self._assemble_on_device(self.forms.steady(UP0, f))
             F = dev.spmv(SLOT_SCRATCH, up) - Lf
             F[dofs] = 0.0
             r = float(np.linalg.norm(F))
@@ -99,8 +126,7 @@ class SteadyStateSolver:
                 return UP0
             if it == max_iter:
                 break
-            J = self._rows_to_identity(self._assemble(self.forms.steady_jacobian(UP0)), dofs)
-            up -= self._solve(J, F, dofs)
+            up -= self._solve_increment(self.forms.steady_jacobian(UP0), F, dofs)
         raise RuntimeError("Newton solver did not converge")
 
     def picard(self, UP0: Function, f=None, max_iter: int = 10, tol: float = 1e-8) -> Function:
@@ -108,12 +134,18 @@ class SteadyStateSolver:
         th = self.W.th
         dofs, vals = combine_bcs(self.bcu, th.N)
         bp = self._load(f)
-        bp[dofs] = vals
+        dev = self._device()
         UP1 = Function(self.W)
         for i in range(max_iter):
             a, _ = self.forms.picard(UP0, f)
-            Ap = self._rows_to_identity(self._assemble(a), dofs)
-            UP1.vector().set_local(self._solve(Ap, bp, dofs))
+            # x_new = x~ + δ with x~ = the iterate carrying the boundary values: A δ = b − A x~ on the free
+            # rows, δ = 0 on the Dirichlet dofs — the same x_new as the row-replaced system A x = b
+            xt = UP0.vector().array().copy()
+            xt[dofs] = vals
+            self._assemble_on_device(a)
+            r = bp - dev.spmv(SLOT_SCRATCH, xt)
+            r[dofs] = 0.0
+            UP1.vector().set_local(xt + self._solve_increment(a, r, dofs))
             diff = float(np.linalg.norm(UP1.vector().array() - UP0.vector().array()))
             base = float(np.linalg.norm(UP0.vector().array()))
             rel_err = diff / (base + 1e-14)

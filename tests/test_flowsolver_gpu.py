@@ -262,3 +262,30 @@ def test_cavity_closed_loop_force_actuation_vs_oracle(tmp_path_factory, golden_d
     assert _rel_l2(y_dev, np.array(ys)) < 1e-8
     assert _rel_l2(fs.fields.u_.vector().get_local(), u_n) < 1e-8
     fs.th.release_device()
+
+
+def test_eager_and_batched_runs_agree_bitwise(tmp_path_factory, golden_dir):
+    """step() hands (y, dE) back through a host-mapped record that the host polls; run() synchronises
+    once at the end.  Same kernels, same order: the two series must be IDENTICAL.  A record read before
+    all of its words were visible (seen at a rate of 5e-4 per step before the record was checksummed)
+    shows up as a repeated row."""
+    n = 6000
+    u = np.stack([0.05 * np.sin(0.01 * np.arange(n)), -0.02 * np.cos(0.013 * np.arange(n))], axis=1)
+    series = []
+    for mode in ("eager", "batched"):
+        fs = CylinderFlowSolver.make_default(Re=100, path_out=tmp_path_factory.mktemp(f"poll_{mode}"), num_steps=n)
+        fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
+        _load_baseflow(fs, golden_dir)
+        fs.initialize_time_stepping(ic=None)
+        fs.step(u[0])
+        if mode == "eager":
+            y = np.array([fs.step(u[k]).copy() for k in range(1, n)])
+            dE = fs.timeseries["dE"].to_numpy()[2:]
+        else:
+            y, dE = fs.run(n - 1, u[1:])
+        series.append((y, np.asarray(dE)))
+        fs.th.release_device()
+    (ya, ea), (yb, eb) = series
+    assert np.array_equal(ya, yb)
+    assert np.array_equal(ea, eb)
+    assert not np.any(np.all(ya[1:] == ya[:-1], axis=1))
