@@ -194,6 +194,9 @@ struct fc_ctx {
   DevBuf<double> fronts;
   DevBuf<int64_t> pa_src, pa_dst, pap_src;
   DevBuf<FcExt> pext;
+  DevBuf<FcFront> pfront;                              // fronts eliminated by fc_front_eliminate, grouped per level
+  std::vector<std::pair<int64_t, int>> pfront_groups;  // per level: (first, count)
+  std::vector<char> pnode_small;                       // per node: handled by the kernel (else rocSOLVER / rocBLAS)
   DevBuf<int> pext_p, pipiv;
   std::vector<int> tkind;        // 0 sweep, 1 spmv (per recorded pair)
   std::vector<int> tcount;       // kernel launches bracketed by the pair
@@ -1341,6 +1344,24 @@ int fc_factor_plan(fc_handle h, int32_t n_nodes, const int64_t* nodes, int32_t n
     }
   }
   if (ext.empty()) ext.push_back(FcExt{0, 0, 0, 0, 0, 0});
+  // small fronts: one workgroup each (fc_front_eliminate); FC_FRONT_KERNEL_MAX = widest front taken (0: none)
+  int small_max = 400;  // measured on the 56 k-dof cylinder mesh: 0 -> 208 ms, 128 -> 105, 256 -> 69, 400 -> 61, 768 -> 221 ms
+  if (const char* e = std::getenv("FC_FRONT_KERNEL_MAX")) small_max = std::min(FC_FRONT_MAX, std::max(0, std::atoi(e)));
+  std::vector<FcFront> fr;
+  h->pfront_groups.assign((size_t)n_levels, {0, 0});
+  h->pnode_small.assign((size_t)n_nodes, 0);
+  for (int li = 0; li < n_levels; ++li) {
+    const int64_t first = (int64_t)fr.size();
+    for (int64_t g = level_ptr[li]; g < level_ptr[li + 1]; ++g) {
+      const fc_ctx::PlanNode& nd = h->pnodes[(size_t)g];
+      if (nd.ni == 0 || nd.nf > small_max) continue;
+      fr.push_back(FcFront{(long long)nd.front, (long long)nd.voff, nd.nf, nd.ni});
+      h->pnode_small[(size_t)g] = 1;
+    }
+    h->pfront_groups[li] = {first, (int)((int64_t)fr.size() - first)};
+  }
+  if (fr.empty()) fr.push_back(FcFront{0, 0, 0, 0});
+  FCCHK(h->pfront.upload(fr, h->stream));
   FCCHK(h->fronts.alloc((size_t)front_size));
   FCCHK(h->pa_src.upload(a_src, (size_t)std::max<int64_t>(1, n_a), h->stream));
   FCCHK(h->pa_dst.upload(a_dst, (size_t)std::max<int64_t>(1, n_a), h->stream));
@@ -1393,10 +1414,13 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
         hipLaunchKernelGGL(fc_extend_add, dim3(gx, grp.second), dim3(256), 0, h->stream, h->pext.p + grp.first, h->pext_p.p, F);
       }
     }
+    if (h->pfront_groups[li].second > 0)
+      hipLaunchKernelGGL(fc_front_eliminate, dim3(h->pfront_groups[li].second), dim3(256), 0, h->stream,
+                         h->pfront.p + h->pfront_groups[li].first, F, fv);
     for (int64_t g = h->plevel_ptr[li]; g < h->plevel_ptr[li + 1]; ++g) {
       const fc_ctx::PlanNode& nd = h->pnodes[(size_t)g];
       const int ni = nd.ni, nf = nd.nf, nb = nf - ni;
-      if (ni == 0) continue;
+      if (ni == 0 || h->pnode_small[(size_t)g]) continue;
       double* Fn = F + nd.front;  // row-major nf x nf: [F11 F12; F21 F22]
       // D^-1 = F11^-1, written straight into the factor rows [D^-1 | -U] (stride nf).  The column-major
       // view LAPACK sees is F11^T; (F11^T)^-1 stored column-major is F11^-1 stored row-major, which is what
