@@ -292,7 +292,7 @@ def main() -> None:
             except Exception:
                 traffic = None
         roofline = {
-            "bound": "hbm", "kernel": "fc_nd_sweep", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": "fc_nd_sweep + fc_nd_down_block (factor sweeps)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "bytes_per_launch": bytes_per_launch, "launches_per_step": tim["sweep_launches"] / args.steps,
             "mean_launch_us": mean_launch_ms * 1e3, "factor_nnz": dev.factor_nnz.get(SLOT_BDF2),
