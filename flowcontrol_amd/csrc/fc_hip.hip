@@ -1380,7 +1380,6 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
   if (h->partitioned) return fail(FC_ERR_INVALID, "fc_refactor: single-GPU handles only");
   OrderSys& S = h->sys[slot];
   if (!S.structured) return fail(FC_ERR_NOT_READY, "fc_solver_setup (structure) must be called first");
-  if (!S.have_lift) return fail(FC_ERR_NOT_READY, "fc_apply_bc not called for this slot");
   if ((int64_t)h->pap_src.n != S.Ap_nnz) return fail(FC_ERR_INVALID, "fc_refactor: plan and solver structure disagree (matrix)");
   HIPCHK(hipSetDevice(h->device));
   FCCHK(dense_load());
