@@ -198,6 +198,9 @@ struct fc_ctx {
   std::vector<std::pair<int64_t, int>> pfront_groups;  // per level: (first, count)
   std::vector<char> pnode_small;                       // per node: handled by the kernel (else rocSOLVER / rocBLAS)
   DevBuf<int> pext_p, pipiv;
+  DevBuf<int64_t> pshift_slot;  // fc_set_front_shifts: added to the fronts after the scatter
+  DevBuf<double> pshift_val;
+  int pn_shift = 0;
   std::vector<int> tkind;        // 0 sweep, 1 spmv (per recorded pair)
   std::vector<int> tcount;       // kernel launches bracketed by the pair
   size_t tused = 0;
@@ -1370,7 +1373,21 @@ int fc_factor_plan(fc_handle h, int32_t n_nodes, const int64_t* nodes, int32_t n
   FCCHK(h->pext_p.upload(ext_p, (size_t)std::max<int64_t>(1, n_ext), h->stream));
   FCCHK(h->pipiv.alloc((size_t)h->pmax_ni + 8));
   HIPCHK(hipStreamSynchronize(h->stream));
+  h->pn_shift = 0;
   h->have_plan = true;
+  return FC_OK;
+}
+
+int fc_set_front_shifts(fc_handle h, int32_t n, const int64_t* slots, const double* values) {
+  if (!h || n < 0 || (n > 0 && (!slots || !values))) return fail(FC_ERR_INVALID, "fc_set_front_shifts: bad argument");
+  if (!h->have_plan) return fail(FC_ERR_NOT_READY, "fc_factor_plan not called");
+  HIPCHK(hipSetDevice(h->device));
+  for (int k = 0; k < n; ++k)
+    if (slots[k] < 0 || slots[k] >= (int64_t)h->fronts.n) return fail(FC_ERR_INVALID, "fc_set_front_shifts: slot outside the fronts");
+  FCCHK(h->pshift_slot.upload(slots, (size_t)std::max(1, n), h->stream));
+  FCCHK(h->pshift_val.upload(values, (size_t)std::max(1, n), h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->pn_shift = n;
   return FC_OK;
 }
 
@@ -1399,6 +1416,9 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
   const int64_t n_a = h->pa_ptr.back();
   if (n_a > 0)
     hipLaunchKernelGGL(fc_front_scatter, dim3(nblocks(n_a, 256)), dim3(256), 0, h->stream, n_a, h->pa_src.p, h->pa_dst.p, av, F);
+  if (h->pn_shift > 0)
+    hipLaunchKernelGGL(fc_front_shift, dim3(nblocks(h->pn_shift, 64)), dim3(64), 0, h->stream, h->pn_shift, h->pshift_slot.p,
+                       h->pshift_val.p, F);
   const int n_levels = (int)h->plevel_ptr.size() - 1;
   int* ipiv = h->pipiv.p;
   int* info = h->pipiv.p + h->pmax_ni;

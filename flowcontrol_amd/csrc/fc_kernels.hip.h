@@ -536,6 +536,12 @@ __global__ void fc_front_scatter(int64_t n, const int64_t* __restrict__ src, con
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k < n) fronts[dst[k]] = vals[src[k]];
 }
+// fronts[slot[k]] += value[k]: diagonal shifts applied after the scatter (pressure pin of enclosed flows)
+__global__ void fc_front_shift(int n, const int64_t* __restrict__ slot, const double* __restrict__ value,
+                               double* __restrict__ fronts) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) fronts[slot[k]] += value[k];
+}
 __global__ void fc_gather64(int64_t n, const int64_t* __restrict__ src, const double* __restrict__ vals,
                             double* __restrict__ out) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -61,6 +61,8 @@ class DeviceSolver:
         self._structured: set[int] = set()
         self.refactor_ms: dict[int, float] = {}
         self._probe: np.ndarray | None = None
+        self._pin_shift = 1.0
+        self._pin: int | None = None  # pressure dof of an enclosed flow whose level is fixed (diagonal shift in the factors)
         self.device_index = device
 
     # ── multi-GPU ────────────────────────────────────────────────────────────
@@ -204,6 +206,8 @@ class DeviceSolver:
                     int(pl.a_src.size), pl.a_src if pl.a_src.size else np.zeros(1, np.int64), pl.a_dst if pl.a_dst.size else np.zeros(1, np.int64),
                     pl.a_ptr, pl.ext_off, int(pl.ext_p.size), pl.ext_p, int(pl.ap_src.size), pl.ap_src, int(pl.max_slots)))
                 self._plan = pl
+                if self._pin is not None:
+                    self._upload_pin()
                 tag = sp.csr_matrix((np.ones(self.nnz), self.colidx, self.rowptr), shape=(self.N, self.N))
                 Ap = tag[t.perm][:, t.perm].tocsr()
                 Ap.sort_indices()
@@ -215,6 +219,8 @@ class DeviceSolver:
             fac, Ap = ndsolver.split_up_segments(self._fac_struct, up_split), self._Ap_struct
         else:
             A = self.matrix(slot)
+            if self._pin is not None:
+                A = (A + sp.csr_matrix(([self._pin_shift], ([self._pin], [self._pin])), shape=A.shape)).tocsr()
             fac = ndsolver.split_up_segments(ndsolver.factorize_blocks(A, t), up_split)
             Ap = A[t.perm][:, t.perm].tocsr()
             Ap.sort_indices()
@@ -263,6 +269,27 @@ class DeviceSolver:
         self.n_stages = len(part.stage_kind)
         self.set_solver_options(refine, check_residual)
 
+    def set_pressure_pin(self, dof: int | None, shift: float = 1.0) -> None:
+        """Enclosed flows (velocity prescribed on the whole boundary): the monolithic matrix is singular, the
+        pressure being defined up to a constant.  A positive shift on the diagonal of ONE pressure dof inside
+        the factorisation (the matrix itself has no pressure-pressure entries) selects, for every compatible
+        right-hand side, exactly the solution with that pressure = 0 — nothing else changes."""
+        dof = None if dof is None else int(dof)
+        if dof is not None and not 2 * self.nn <= dof < self.N:
+            raise ValueError("the pinned dof must be a pressure dof")
+        if dof != self._pin:
+            self._pin, self._pin_shift = dof, float(shift)
+            self._probe = None
+            if self._plan is not None:
+                self._upload_pin()
+
+    def _upload_pin(self) -> None:
+        if self._pin is None:
+            check(self.lib.fc_set_front_shifts(self._h, 0, np.zeros(1, np.int64), np.zeros(1)))
+        else:
+            slot = ndsolver.front_diagonal_slot(self._plan, self.tree, self._pin)
+            check(self.lib.fc_set_front_shifts(self._h, 1, np.array([slot], dtype=np.int64), np.array([self._pin_shift])))
+
     def refactor(self, slot: int) -> float:
         """Numeric factorisation of the slot's current matrix on the device (the structure of the first
         ``setup_solver`` is reused): what ``solver.set_operator(A)`` costs.  Returns device milliseconds."""
@@ -275,6 +302,8 @@ class DeviceSolver:
         # against the matrix itself (the dense libraries are not trusted blindly, cf. scripts/micro/getri_check.py)
         if self._probe is None:
             self._probe = np.cos(0.37 * np.arange(self.N) + 0.1)
+            if self._pin is not None:
+                self._probe[2 * self.nn :] = 0.0  # compatible with the constant-pressure null space
         opts = getattr(self, "_solver_opts", (0, True))
         check(self.lib.fc_set_solver_options(self._h, _lib.METHOD_REFINE, 0, 1e-10, 1))
         _, info = self.solve(slot, self._probe)

@@ -133,4 +133,38 @@ def combine_bcs(bcs: Sequence[DirichletBC], N: int) -> tuple[np.ndarray, np.ndar
     return dofs, val[dofs]
 
 
-__all__ = ["DOLFIN_EPS", "near", "between", "SubDomain", "Constant", "DirichletBC", "combine_bcs"]
+def pressure_pin(th, dofs: np.ndarray) -> int | None:
+    """Pressure dof to pin (to 0) when the velocity is prescribed on the WHOLE boundary, else None.
+
+    An enclosed flow (lid-driven cavity) leaves the pressure defined up to a constant and the monolithic
+    matrix singular.  The reference hands that matrix to MUMPS as it is (``bcp=[]``,
+    examples/lidcavity/lidcavityflowsolver.py:57-72) and lives with whatever level the null pivot
+    produces; a block factorisation with explicit pivot inverses cannot, so the pressure is fixed at the
+    vertex nearest the lower-left corner of the bounding box.  Velocities (all the reference tests look at)
+    are unaffected: the dropped continuity row is the negative sum of the others."""
+    m = th.mesh
+    be = m.boundary_edges()
+    nodes = np.unique(np.r_[m.edges[be].reshape(-1), th.nv + be])
+    isbc = np.zeros(th.N, dtype=bool)
+    isbc[np.asarray(dofs, dtype=np.int64)] = True
+    if not (np.all(isbc[nodes]) and np.all(isbc[nodes + th.nn])):
+        return None
+    x = th.node_coords[: th.nv]
+    corner = x.min(axis=0)
+    return int(2 * th.nn + np.argmin(((x - corner) ** 2).sum(axis=1)))
+
+
+def with_pressure_pin(th, dofs: np.ndarray, vals: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """(dofs, vals) extended by the pinned pressure dof when :func:`pressure_pin` asks for one
+    (``vals`` may be 1-D values or a 2-D table of per-actuator profiles: the pin is 0 in all)."""
+    pin = pressure_pin(th, dofs)
+    if pin is None or pin in set(np.asarray(dofs).tolist()):
+        return dofs, vals
+    d = np.append(np.asarray(dofs, dtype=np.int64), pin)
+    v = np.concatenate([vals, np.zeros((1,) + np.shape(vals)[1:])])
+    o = np.argsort(d, kind="stable")
+    return d[o], v[o]
+
+
+__all__ = ["DOLFIN_EPS", "near", "between", "SubDomain", "Constant", "DirichletBC", "combine_bcs", "pressure_pin",
+           "with_pressure_pin"]

@@ -32,7 +32,7 @@ from . import flowsolverparameters
 from ._lib import SLOT_BDF1, SLOT_BDF2, SLOT_MASS, FcDiverged
 from .actuator import ACTUATOR_TYPE
 from .exporter import FlowExporter, read_frame, write_frame
-from .fem.boundary import Constant, DirichletBC, combine_bcs
+from .fem.boundary import Constant, DirichletBC, combine_bcs, pressure_pin
 from .fem.mesh import Mesh, read_xdmf_mesh
 from .fem.spaces import Function, TaylorHood
 from .flowfield import BoundaryConditions, FlowField, FlowFieldCollection, SimPaths
@@ -452,6 +452,7 @@ class FlowSolver(ABC):
         U0 = self.fields.U0
         dofs, prof = self._bc_tables()
         dev.set_bc(dofs, prof)
+        dev.set_pressure_pin(pressure_pin(self.th, dofs))  # enclosed flows only (lid-driven cavity)
         dev.set_force(self._force_tables())
         dev.set_sensors([s.row(self) for s in self.params_control.sensor_list])
         dev.set_time_scheme(self.params_time.dt, self.params_solver.is_eq_nonlinear)

@@ -629,6 +629,22 @@ def factor_plan(fac: BlockFactors, indptr: np.ndarray, indices: np.ndarray, skip
                       ext_off=ext_off, ext_p=np.ascontiguousarray(ext_p), ap_src=np.ascontiguousarray(ap_src), max_slots=max_slots)
 
 
+def front_diagonal_slot(plan: FactorPlan, tree: NDTree, dof: int) -> int:
+    """Offset, in the front buffer, of the diagonal entry of ``dof`` (original numbering) in the front of
+    the node that eliminates it (plan nodes are listed level by level, deepest first, node index
+    ascending, empty nodes included)."""
+    ip = int(tree.iperm[dof])
+    for k in range(tree.depth, -1, -1):
+        ptr = tree.node_ptr[k]
+        if int(ptr[0]) <= ip < int(ptr[-1]):
+            n = int(np.searchsorted(ptr, ip, side="right") - 1)
+            g = int(plan.level_ptr[tree.depth - k]) + n
+            lv, fo, nf, ni = (int(v) for v in plan.nodes[g, :4])
+            assert lv == k and 0 <= ip - int(ptr[n]) < ni
+            return fo + (ip - int(ptr[n])) * (nf + 1)
+    raise ValueError("dof is not eliminated by any node of the plan")
+
+
 def factorize_with_plan(plan: FactorPlan, fac: BlockFactors, values: np.ndarray) -> np.ndarray:
     """Host replay of exactly what ``fc_refactor`` does on the device (same order of operations): the
     factor values for the CSR ``values`` (original numbering).  Test reference, not a product path."""
@@ -758,7 +774,7 @@ def down_blocks(fac: BlockFactors, rank: int = 0, world: int = 1, max_rows: int 
 
 
 __all__ += ["BlockFactors", "factorize_blocks", "down_blocks", "split_up_segments", "FactorPlan", "factor_plan",
-            "factorize_with_plan"]
+            "factorize_with_plan", "front_diagonal_slot"]
 
 
 # ──────────────────────────────────────────────────────────────────────────────────────────

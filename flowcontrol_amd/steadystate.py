@@ -18,7 +18,7 @@ import scipy.sparse.linalg as spla
 
 from . import ndsolver
 from ._lib import SLOT_BDF1, SLOT_MASS, SLOT_SCRATCH
-from .fem.boundary import combine_bcs
+from .fem.boundary import combine_bcs, pressure_pin
 from .fem.spaces import Function
 from .nsforms import NSForms
 
@@ -69,12 +69,18 @@ class SteadyStateSolver:
 
     def _solve_increment(self, coeff, r: np.ndarray, dofs: np.ndarray) -> np.ndarray:
         """δ with  A δ = r  on the free rows and δ = 0 on the Dirichlet dofs (``r[dofs]`` is 0)."""
+        pin = pressure_pin(self.W.th, dofs)  # enclosed flow: the pressure level is fixed at one dof
         if not self._on_device():
-            return self._solve(self._rows_to_identity(self._assemble(coeff), dofs), r, dofs)
+            rows = dofs if pin is None else np.append(dofs, pin)
+            if pin is not None:
+                r = r.copy()
+                r[pin] = 0.0
+            return self._solve(self._rows_to_identity(self._assemble(coeff), rows), r, rows)
         dev = self._device()
         if not self._bc_set:
             # increments vanish on the Dirichlet dofs: homogeneous symmetric elimination, no lifting
             dev.set_bc(dofs, np.zeros((len(dofs), 1)))
+            dev.set_pressure_pin(pin)
             self._bc_set = True
         self._assemble_on_device(coeff, SLOT_BDF1)
         dev.apply_bc(SLOT_BDF1)

@@ -146,6 +146,11 @@ int fc_factor_plan(fc_handle h, int32_t n_nodes, const int64_t* nodes, int32_t n
                    const int64_t* a_ptr, const int64_t* ext_off, int64_t n_ext, const int32_t* ext_p,
                    int64_t n_ap, const int64_t* ap_src, int32_t max_slots);
 int fc_refactor(fc_handle h, int slot, double* ms_out);
+/* values added to front entries (offsets into the front buffer of fc_factor_plan) after the matrix has
+ * been scattered, in every later fc_refactor: a positive shift on ONE pressure diagonal selects the
+ * solution with that pressure = 0 of an enclosed flow's singular system (lid-driven cavity; the reference
+ * leaves that system to MUMPS, examples/lidcavity/lidcavityflowsolver.py:57-72).  n = 0 clears. */
+int fc_set_front_shifts(fc_handle h, int32_t n, const int64_t* slots, const double* values);
 /* download the factor values of a slot (n = the n_val given to fc_solver_setup): parity checks */
 int fc_get_factor_values(fc_handle h, int slot, int64_t n, double* out);
 /* optional explicit operator C of the right-hand side, b -= C u_n (rows in the solver's permuted

@@ -2,7 +2,7 @@
 
 Run in the build container (``/root/reference`` is not present on the GPU box):
     python tests/golden/make_mesh_fixtures.py
-Inputs (data, not code): src/examples/{cylinder,cavity,pinball}/data_input/*.xdmf + .h5
+Inputs (data, not code): src/examples/{cylinder,cavity,pinball,lidcavity}/data_input/*.xdmf + .h5
 Outputs: tests/golden/meshes/<name>.npz with ``coords`` (nv,2) f8 and ``cells`` (nc,3) i4 in the
 file's own numbering, read with flowcontrol_amd's HDF5/XDMF reader.
 """
@@ -21,6 +21,7 @@ MESHES = {
     "cavity_coarse": REF / "cavity/data_input/cavity_coarse.xdmf",
     "cavity_fine": REF / "cavity/data_input/cavity_fine.xdmf",
     "mesh_middle_gmsh": REF / "pinball/data_input/mesh_middle_gmsh.xdmf",
+    "lidcavity_mesh64": REF / "lidcavity/data_input/mesh64.xdmf",
 }
 
 if __name__ == "__main__":

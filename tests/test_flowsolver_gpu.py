@@ -289,3 +289,32 @@ def test_eager_and_batched_runs_agree_bitwise(tmp_path_factory, golden_dir):
     assert np.array_equal(ya, yb)
     assert np.array_equal(ea, eb)
     assert not np.any(np.all(ya[1:] == ya[:-1], axis=1))
+
+
+def test_lidcavity_regression(tmp_path_factory, golden_dir):
+    """Mirror of the reference's test_lidcavity_regression (Re = 1000, mesh64, Picard base flow on the
+    device, 10 unactuated steps): enclosed flow, pressure pinned (fem.boundary.pressure_pin).  Against the
+    oracle's golden series to 1e-8 and the reference's constants with the reference's tolerances."""
+    from flowcontrol_amd.examples.lidcavity.lidcavityflowsolver import LidCavityFlowSolver
+
+    fs = LidCavityFlowSolver.make_default(Re=1000, path_out=tmp_path_factory.mktemp("lidcavity"), num_steps=10, save_every=5)
+    fs.compute_steady_state(method="picard", max_iter=40, tol=1e-7, u_ctrl=[0.0])
+    g = np.load(golden_dir / "lidcavity_mesh64.npz")
+    u0_max, u0_mean = flu.apply_fun(fs.fields.U0, np.max), flu.apply_fun(fs.fields.U0, np.mean)
+    assert np.isclose(u0_max, 1.000000000000008, rtol=1e-6)
+    assert np.isclose(u0_mean, 0.0020234251738529907, rtol=1e-6)
+    assert _rel_l2(fs.fields.U0.vector().get_local(), g["UP0"][: 2 * fs.th.nn]) < 1e-8
+    fs.initialize_time_stepping(ic=None)
+    for _ in range(fs.params_time.num_steps):
+        fs.step(u_ctrl=[0.0])
+    ts = fs.timeseries
+    assert _rel_l2(ts[["y_meas_1", "y_meas_2"]].to_numpy(), g["y"]) < 1e-8
+    assert _rel_l2(ts["dE"].to_numpy(), g["dE"]) < 1e-8
+    last = ts.iloc[-1]
+    assert np.isclose(last["time"], 0.05, rtol=1e-6)
+    assert np.isclose(last["y_meas_1"], -0.09584848445257539, rtol=1e-4)
+    assert np.isclose(last["y_meas_2"], -0.06060429836866045, rtol=1e-4)
+    assert np.isclose(last["dE"], 0.0012665481942387678, rtol=1e-4)
+    assert np.isclose(flu.apply_fun(fs.fields.Usave, np.max), 1.000000000000008, rtol=1e-6)
+    assert np.isclose(flu.apply_fun(fs.fields.Usave, np.mean), 0.0020222416653700877, rtol=1e-6)
+    fs.th.release_device()

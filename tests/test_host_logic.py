@@ -388,3 +388,43 @@ def test_factor_plan_replays_the_multifrontal_factorisation():
         assert np.unique(plan.a_dst).size == plan.a_dst.size  # one front slot per matrix entry
         v = nd.factorize_with_plan(plan, f0, vals)
         assert np.array_equal(v, f.vals)
+
+
+def test_pressure_pin_only_for_enclosed_flows():
+    """fem.boundary.pressure_pin: a pressure dof is pinned exactly when the velocity is Dirichlet on the
+    whole boundary (lid-driven cavity); any open piece of boundary (cylinder outlet) → None.  The Dirichlet
+    form used on the host (row replaced) and the diagonal shift used in the device factors select the same
+    solution of the singular system."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    from flowcontrol_amd.fem.boundary import pressure_pin, with_pressure_pin
+    from flowcontrol_amd.fem.mesh import Mesh
+    from flowcontrol_amd.fem.spaces import TaylorHood
+    from oracle import ns_oracle as O
+
+    th = TaylorHood(Mesh.unit_square(6, 6))
+    m = th.mesh
+    be = m.boundary_edges()
+    nodes = np.unique(np.r_[m.edges[be].reshape(-1), th.nv + be])
+    closed = np.sort(np.r_[nodes, nodes + th.nn])
+    opened = closed[th.node_coords[closed % th.nn, 0] < 1 - 1e-9]
+    assert pressure_pin(th, opened) is None
+    pin = pressure_pin(th, closed)
+    assert pin is not None and 2 * th.nn <= pin < th.N
+    assert np.allclose(th.node_coords[pin - 2 * th.nn], [0.0, 0.0])
+    d2, v2 = with_pressure_pin(th, closed, np.zeros((closed.size, 2)))
+    assert d2.size == closed.size + 1 and pin in d2 and v2.shape == (closed.size + 1, 2) and np.all(np.diff(d2) > 0)
+    # the two treatments of the singular enclosed system give the same solution
+    d = O.Disc.from_taylor_hood(th)
+    A = O.assemble_matrix(d, mass=50.0, nu=0.02).tocsr()
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal(th.N)
+    b[2 * th.nn :] = 0.0  # compatible: no net source in the continuity rows
+    A1, b1 = O.apply_bc_symmetric(A, b.copy(), d2, np.zeros(d2.size))
+    x1 = spla.spsolve(A1.tocsc(), b1)
+    A2, b2 = O.apply_bc_symmetric(A, b.copy(), closed, np.zeros(closed.size))
+    A2 = (A2 + sp.csr_matrix(([1.0], ([pin], [pin])), shape=A2.shape)).tocsc()
+    x2 = spla.spsolve(A2, b2)
+    assert abs(x2[pin]) < 1e-12
+    assert np.linalg.norm(x1 - x2) < 1e-10 * np.linalg.norm(x1)
