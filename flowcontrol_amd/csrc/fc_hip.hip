@@ -591,7 +591,7 @@ int enqueue_rhs(fc_ctx* h, int order_slot, const double* d_uctrl, const double* 
   if (S.have_c && h->partitioned) return fail(FC_ERR_INVALID, "an explicit rhs operator (Crank-Nicolson) is not available on a partitioned handle");
   const int ncl = h->partitioned ? h->ncl : h->nc;
   if (ncl > 0)
-    hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks(ncl, 64)), dim3(64), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
+    hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks((int64_t)ncl * 8, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
                        h->u_n.p, h->u_nn.p, h->have_force ? h->fprof.p : nullptr, h->have_force ? h->n_act : 0, d_uforce,
                        c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p, h->partitioned ? h->cell_list.p : nullptr, ncl);
   hipLaunchKernelGGL(fc_rhs_gather, dim3(nblocks(h->N, 256)), dim3(256), 0, h->stream, h->N, h->gptr_p.p, h->gidx_p.p,
@@ -1819,7 +1819,7 @@ int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double*
   for (int s = 0; s < n_steps; ++s) {
     launches = 0;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks(h->nc, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
+    hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks((int64_t)h->nc * 8, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
                        h->u_n.p, h->u_nn.p, h->have_force ? h->fprof.p : nullptr, h->have_force ? h->n_act : 0,
                        h->uctrl.p, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p, (const int*)nullptr, h->nc);
     FCCHK(lap(0));

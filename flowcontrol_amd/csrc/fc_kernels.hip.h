@@ -19,8 +19,13 @@ __constant__ double c_qw[FC_NQ];             // weights (sum = 1; times |detJ|/2
 // ---------------------------------------------------------------------------------------------
 // RHS element loop: the `rhs` of NSForms._order1/_order2 (reference nsforms.py:238-305)
 //   g = cm_n u_n + cm_nn u_nn + cc_n (u_n.grad)u_n + cc_nn (u_nn.grad)u_nn + f ;  L_e[a,j] = ∫ g_j φ_a
-// One thread per cell; element vectors go to ev[slot][cell] (slot = a + 6 j), summed per dof by
-// k_rhs_gather (wavefront-independent, deterministic).
+// EIGHT lanes per cell: lane q < 7 evaluates g at Radon point q (the nodal values of the cell are
+// loaded by all eight lanes from the same addresses: one broadcast transaction), the weighted point
+// values are exchanged inside the group and lane a < 6 sums the contribution to test function a in
+// the fixed order q = 0..6.  With a thread per cell the launch had 12 k threads (< 1 wave per CU) and
+// ran ~1 000 dependent FMAs each; this way it is two memory round trips and ~150 FMAs deep.
+// Element vectors go to ev[slot][cell] (slot = a + 6 j), summed per dof by fc_rhs_gather
+// (wavefront-independent, deterministic).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void fc_rhs_elem(int nc, int nn, const int* __restrict__ cn,
                                                    const double* __restrict__ geom,
@@ -33,70 +38,62 @@ __global__ __launch_bounds__(256) void fc_rhs_elem(int nc, int nn, const int* __
                                                    const int* __restrict__ cell_list, int ncl) {
   // cell_list != nullptr: this rank's share of the cells (multi-GPU partition), else all nc cells
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ncl) return;
-  const int c = cell_list ? cell_list[t] : t;
+  const int cl = t >> 3, lane = t & 7;
+  const bool active = cl < ncl;
+  const int c = active ? (cell_list ? cell_list[cl] : cl) : 0;
+  const int q = lane < FC_NQ ? lane : FC_NQ - 1;  // lane 7 shadows point 6 with zero weight
   const double j00 = geom[c], j01 = geom[nc + c], j10 = geom[2 * nc + c], j11 = geom[3 * nc + c];
-  const double hdet = 0.5 * geom[4 * nc + c];
-  double ax[6], ay[6], bx[6], by[6], fx[6], fy[6];
+  const double wq = lane < FC_NQ ? c_qw[q] * 0.5 * geom[4 * nc + c] : 0.0;
+  double ux = 0, uy = 0, uxi = 0, uet = 0, vxi = 0, vet = 0;  // field n: value, d/dxi, d/deta of (ux, uy)
+  double wx = 0, wy = 0, wxi = 0, wet = 0, zxi = 0, zet = 0;  // field nn
+  double gx = 0, gy = 0;
 #pragma unroll
   for (int a = 0; a < 6; ++a) {
     const int n = cn[a * nc + c];
-    ax[a] = un[n];
-    ay[a] = un[nn + n];
-    bx[a] = unn[n];
-    by[a] = unn[nn + n];
-    double sx = 0.0, sy = 0.0;
+    const double ax = un[n], ay = un[nn + n], bx = unn[n], by = unn[nn + n];
+    double fx = 0.0, fy = 0.0;
     for (int k = 0; k < n_act; ++k) {
       const double uk = uctrl[k];
-      sx += uk * fprof[(size_t)k * 2 * nn + n];
-      sy += uk * fprof[(size_t)k * 2 * nn + nn + n];
+      fx += uk * fprof[(size_t)k * 2 * nn + n];
+      fy += uk * fprof[(size_t)k * 2 * nn + nn + n];
     }
-    fx[a] = sx;
-    fy[a] = sy;
+    const double ph = c_phi2[q * 6 + a], dx = c_dphi2[(q * 6 + a) * 2], de = c_dphi2[(q * 6 + a) * 2 + 1];
+    ux += ph * ax;
+    uy += ph * ay;
+    uxi += dx * ax;
+    uet += de * ax;
+    vxi += dx * ay;
+    vet += de * ay;
+    wx += ph * bx;
+    wy += ph * by;
+    wxi += dx * bx;
+    wet += de * bx;
+    zxi += dx * by;
+    zet += de * by;
+    gx += ph * fx;
+    gy += ph * fy;
   }
-  double accx[6] = {0, 0, 0, 0, 0, 0}, accy[6] = {0, 0, 0, 0, 0, 0};
+  // physical gradients: d/dx = d/dxi*j00 + d/deta*j10 ; d/dy = d/dxi*j01 + d/deta*j11
+  const double ux_x = uxi * j00 + uet * j10, ux_y = uxi * j01 + uet * j11;
+  const double uy_x = vxi * j00 + vet * j10, uy_y = vxi * j01 + vet * j11;
+  const double wx_x = wxi * j00 + wet * j10, wx_y = wxi * j01 + wet * j11;
+  const double wy_x = zxi * j00 + zet * j10, wy_y = zxi * j01 + zet * j11;
+  gx += cm_n * ux + cm_nn * wx + cc_n * (ux * ux_x + uy * ux_y) + cc_nn * (wx * wx_x + wy * wx_y);
+  gy += cm_n * uy + cm_nn * wy + cc_n * (ux * uy_x + uy * uy_y) + cc_nn * (wx * wy_x + wy * wy_y);
+  gx *= wq;
+  gy *= wq;
+  // lane a < 6 gathers the weighted point values and tests them with phi_a
+  const int a = lane < 6 ? lane : 5;
+  double accx = 0.0, accy = 0.0;
 #pragma unroll
-  for (int q = 0; q < FC_NQ; ++q) {
-    double ux = 0, uy = 0, uxi = 0, uet = 0, vxi = 0, vet = 0;  // field n: value, d/dxi, d/deta of (ux, uy)
-    double wx = 0, wy = 0, wxi = 0, wet = 0, zxi = 0, zet = 0;  // field nn
-    double gx = 0, gy = 0;
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      const double ph = c_phi2[q * 6 + a], dx = c_dphi2[(q * 6 + a) * 2], de = c_dphi2[(q * 6 + a) * 2 + 1];
-      ux += ph * ax[a];
-      uy += ph * ay[a];
-      uxi += dx * ax[a];
-      uet += de * ax[a];
-      vxi += dx * ay[a];
-      vet += de * ay[a];
-      wx += ph * bx[a];
-      wy += ph * by[a];
-      wxi += dx * bx[a];
-      wet += de * bx[a];
-      zxi += dx * by[a];
-      zet += de * by[a];
-      gx += ph * fx[a];
-      gy += ph * fy[a];
-    }
-    // physical gradients: d/dx = d/dxi*j00 + d/deta*j10 ; d/dy = d/dxi*j01 + d/deta*j11
-    const double ux_x = uxi * j00 + uet * j10, ux_y = uxi * j01 + uet * j11;
-    const double uy_x = vxi * j00 + vet * j10, uy_y = vxi * j01 + vet * j11;
-    const double wx_x = wxi * j00 + wet * j10, wx_y = wxi * j01 + wet * j11;
-    const double wy_x = zxi * j00 + zet * j10, wy_y = zxi * j01 + zet * j11;
-    gx += cm_n * ux + cm_nn * wx + cc_n * (ux * ux_x + uy * ux_y) + cc_nn * (wx * wx_x + wy * wx_y);
-    gy += cm_n * uy + cm_nn * wy + cc_n * (ux * uy_x + uy * uy_y) + cc_nn * (wx * wy_x + wy * wy_y);
-    const double w = c_qw[q] * hdet;
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      const double wp = w * c_phi2[q * 6 + a];
-      accx[a] += wp * gx;
-      accy[a] += wp * gy;
-    }
+  for (int p = 0; p < FC_NQ; ++p) {
+    const double pa = c_phi2[p * 6 + a];
+    accx += pa * __shfl(gx, p, 8);
+    accy += pa * __shfl(gy, p, 8);
   }
-#pragma unroll
-  for (int a = 0; a < 6; ++a) {
-    ev[(size_t)a * nc + c] = accx[a];
-    ev[(size_t)(6 + a) * nc + c] = accy[a];
+  if (active && lane < 6) {
+    ev[(size_t)lane * nc + c] = accx;
+    ev[(size_t)(6 + lane) * nc + c] = accy;
   }
 }
 
