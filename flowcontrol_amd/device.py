@@ -62,6 +62,7 @@ class DeviceSolver:
         self.refactor_ms: dict[int, float] = {}
         self._probe: np.ndarray | None = None
         self._pin_shift = 1.0
+        self._step_bufs = None
         self._pin: int | None = None  # pressure dof of an enclosed flow whose level is fixed (diagonal shift in the factors)
         self.device_index = device
 
@@ -381,15 +382,26 @@ class DeviceSolver:
         check(self.lib.fc_set_rhs_operator(self._h, slot, ptr(_i32(Cp.indptr)), ptr(_i32(Cp.indices)), ptr(_f64(Cp.data))))
 
     def step(self, order_slot: int, u_ctrl, compute_energy: bool = True, u_force=None):
-        u = _f64(np.atleast_1d(u_ctrl)) if self.n_act else None
-        uf = _f64(np.atleast_1d(u_force)) if (self.n_act and u_force is not None) else None
         if self.world > 1 and getattr(self, "_host_allreduce", None) is not None:
+            u = _f64(np.atleast_1d(u_ctrl)) if self.n_act else None
             return self._step_host_staged(order_slot, u, compute_energy)
-        y = np.empty(max(self.n_sens, 1))
-        info = np.empty(4)
-        dE = C.c_double()
-        check(self.lib.fc_step(self._h, order_slot, ptr(u), ptr(uf), ptr(y), C.byref(dE), int(compute_energy), ptr(info)))
-        return y[: self.n_sens], dE.value, info
+        # persistent argument buffers and their ctypes pointers: the call is on the critical path of
+        # every synchronous step (a fresh ndarray + ctypes cast per argument costs ~1 us each)
+        b = self._step_bufs
+        if b is None or b[0].size != max(self.n_act, 1) or b[2].size != max(self.n_sens, 1):
+            arrs = (np.zeros(max(self.n_act, 1)), np.zeros(max(self.n_act, 1)), np.empty(max(self.n_sens, 1)), np.empty(4))
+            dE = C.c_double()
+            b = self._step_bufs = arrs + (dE, tuple(ptr(a) for a in arrs), C.byref(dE))
+        u, uf, y, info, dE, (pu, puf, py, pinfo), pdE = b
+        if self.n_act:
+            u[:] = u_ctrl
+            if u_force is not None:
+                uf[:] = u_force
+        code = self.lib.fc_step(self._h, order_slot, pu if self.n_act else None, puf if (self.n_act and u_force is not None) else None,
+                                py, pdE, 1 if compute_energy else 0, pinfo)
+        if code:
+            check(code)
+        return y[: self.n_sens].copy(), dE.value, info
 
     def run(self, first_order_slot: int, n_steps: int, u_ctrl, compute_energy: bool = True):
         u = _f64(u_ctrl)

@@ -566,14 +566,14 @@ class FlowSolver(ABC):
             if not self.params_solver.throw_error:
                 return None
             raise RuntimeError("Failed solving: Inf found in solution")
-        self.solve_info = info
+        self.solve_info = info  # (refinement sweeps, relative residual, |b|, flag) of this step; buffer reused by the next
         self.iter = next_iter
         self.t = self.params_time.Tstart + self.iter * self.params_time.dt
         self._u_ctrl_prev = u_ctrl.copy()
         if self.params_solver.time_scheme != "cn":
             self.order = 2
         self.fields._mark_stale()
-        self.y_meas = y.copy()
+        self.y_meas = y
         runtime = time.time() - t0
         if self._niter_multiple_of(self.iter, self.verbose):
             self.exporter.log_progress(self.iter, self.params_time.num_steps, self.t, self.params_time.Tfinal + self.params_time.Tstart, runtime)
