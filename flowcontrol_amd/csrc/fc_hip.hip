@@ -180,6 +180,9 @@ struct fc_ctx {
   // per-launch HIP-event timing (fc_set_timing): pairs recorded around every sweep / SpMV launch
   bool timing = false;
   std::vector<hipEvent_t> tev;   // pool, 2 per launch
+  // element vectors of the NEXT step's right-hand side, enqueued behind a synchronous step while the host
+  // is busy (they depend on the state only): slot whose coefficients they were computed with, or -1
+  int pre_slot = -1;
   // device-side numeric factorisation (fc_factor_plan / fc_refactor)
   struct PlanNode {
     int64_t front, voff;
@@ -590,7 +593,9 @@ int enqueue_rhs(fc_ctx* h, int order_slot, const double* d_uctrl, const double* 
   if (!d_uforce) d_uforce = d_uctrl;
   if (S.have_c && h->partitioned) return fail(FC_ERR_INVALID, "an explicit rhs operator (Crank-Nicolson) is not available on a partitioned handle");
   const int ncl = h->partitioned ? h->ncl : h->nc;
-  if (ncl > 0)
+  const bool have_ev = h->pre_slot == order_slot && !h->have_force && !h->partitioned;
+  h->pre_slot = -1;
+  if (ncl > 0 && !have_ev)
     hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks((int64_t)ncl * 8, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
                        h->u_n.p, h->u_nn.p, h->have_force ? h->fprof.p : nullptr, h->have_force ? h->n_act : 0, d_uforce,
                        c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p, h->partitioned ? h->cell_list.p : nullptr, ncl);
@@ -1047,6 +1052,7 @@ int fc_set_time_scheme(fc_handle h, double dt, int nonlinear) {
   if (!h || !(dt > 0.0)) return fail(FC_ERR_INVALID, "fc_set_time_scheme: dt must be positive");
   h->dt = dt;
   h->nonlinear = nonlinear ? 1 : 0;
+  h->pre_slot = -1;
   return FC_OK;
 }
 
@@ -1541,6 +1547,7 @@ int fc_set_solver_options(fc_handle h, int method, int max_iter, double rtol, in
 
 int fc_set_state(fc_handle h, const double* u_n, const double* u_nn, const double* p_n) {
   if (!h || !u_n || !u_nn) return fail(FC_ERR_INVALID, "fc_set_state: null argument");
+  h->pre_slot = -1;
   HIPCHK(hipSetDevice(h->device));
   const size_t nv2 = 2 * (size_t)h->nn;
   HIPCHK(hipMemcpyAsync(h->u_n.p, u_n, nv2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -1570,6 +1577,26 @@ int fc_get_solution(fc_handle h, double* up) {
   return FC_OK;
 }
 
+// Behind a synchronous step: the element loop of the next right-hand side reads the state only (BC
+// actuation enters in fc_rhs_gather), so it is enqueued now and runs while the host is between two
+// fc_step calls; enqueue_rhs skips its own launch when the prediction (same scheme, BDF2 after BDF1)
+// holds and nothing touched the state in between.  Body-force actuators need u_ctrl: no speculation.
+void speculate_next_rhs(fc_ctx* h, int order_slot) {
+  static const bool enabled = [] {
+    const char* e = std::getenv("FC_SPECULATE");
+    return !(e && e[0] == '0');
+  }();
+  h->pre_slot = -1;
+  if (!enabled || h->have_force || h->partitioned || h->nc <= 0) return;
+  const int next = h->sys[order_slot].have_c ? order_slot : FC_SLOT_BDF2;
+  if (!h->sys[next].ready || !h->sys[next].have_lift) return;
+  const StepCoeffs c = coeffs_for(h, next);
+  hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks((int64_t)h->nc * 8, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
+                     h->u_n.p, h->u_nn.p, (const double*)nullptr, 0, h->pin_dev, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p,
+                     (const int*)nullptr, h->nc);
+  if (hipGetLastError() == hipSuccess) h->pre_slot = next;
+}
+
 int fc_step(fc_handle h, int order_slot, const double* u_ctrl, const double* u_force, double* y_out, double* dE_out,
             int compute_energy, double* info_out) {
   FCCHK(check_step_ready(h, order_slot));
@@ -1586,6 +1613,7 @@ int fc_step(fc_handle h, int order_slot, const double* u_ctrl, const double* u_f
   double* dev = h->pin_dev;
   const double seq = (double)(++h->seq);
   FCCHK(enqueue_step(h, order_slot, dev, dev + 64, dev + 128, dev + 129, dev + 136, compute_energy, dev + 32, dev + 137, seq));
+  speculate_next_rhs(h, order_slot);
   // the last kernel publishes `seq` behind a system-scope fence: poll the host-mapped word (bounded),
   // then fall back to a stream synchronisation — which is also what reports a faulted kernel
   // A record is accepted only when its checksum (fc_publish) agrees with the words actually read: the
@@ -1799,6 +1827,7 @@ int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double*
   if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this order");
   if (!h->have_mp) return fail(FC_ERR_NOT_READY, "fc_set_energy_matrix not called");
   if (h->partitioned) return fail(FC_ERR_INVALID, "fc_profile_steps: single-GPU handles only");
+  h->pre_slot = -1;  // the steps below advance the state with their own launches
   HIPCHK(hipSetDevice(h->device));
   if (h->n_act) HIPCHK(hipMemcpyAsync(h->uctrl.p, u_ctrl, h->n_act * sizeof(double), hipMemcpyHostToDevice, h->stream));
   const int N = h->N, g = nblocks(N, 256);
