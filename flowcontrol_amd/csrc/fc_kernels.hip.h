@@ -125,7 +125,20 @@ __global__ __launch_bounds__(256) void fc_rhs_gather(int N, const int* __restric
     if (once)
       for (int k = 0; k < n_act; ++k) s += uctrl[k] * bcprof[(size_t)bs * n_act + k];
   } else {
-    for (int k = gptr[i]; k < gptr[i + 1]; ++k) s += ev[gidx[k]];
+    // eight element contributions per trip: the index loads, then the value loads, are all in flight
+    // together (a vertex dof has 6-8 cells, an edge dof 2); summed in list order (reproducible)
+    const int k0 = gptr[i], k1 = gptr[i + 1];
+    for (int base = k0; base < k1; base += 8) {
+      int id[8];
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) id[u] = base + u < k1 ? gidx[base + u] : -1;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = id[u] >= 0 ? ev[id[u]] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (id[u] >= 0) s += v[u];
+    }
     if (once)
       for (int k = 0; k < n_act; ++k) s -= uctrl[k] * lift[(size_t)k * N + i];
     // explicit half of the linear terms of Crank-Nicolson (nsforms.py:212-216): -(C u_n)[row]
