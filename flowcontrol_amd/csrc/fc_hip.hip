@@ -148,7 +148,7 @@ struct fc_ctx {
   // permutation
   bool have_perm = false;
   std::vector<int> h_perm;
-  DevBuf<int> perm;
+  DevBuf<int> perm, iperm;  // permuted row -> W dof, and its inverse
   OrderSys sys[2];
   DevBuf<int> mp_rowptr, mp_col;  // velocity mass matrix in permuted numbering (energy)
   DevBuf<double> mp_val;
@@ -629,10 +629,11 @@ bool use_fused_tail(const fc_ctx* h) {
 int launch_tail(fc_ctx* h, OrderSys& S, int compute_energy, double* d_y, double* d_E, double* d_r, double* d_flag_out,
                 double* d_seq, double seq) {
   const bool res = h->check_residual != 0;
-  const int g = nblocks(h->N, 32);
+  const int g_rows = nblocks(h->N, 32), g_cells = compute_energy ? nblocks(h->nc, 32) : 0;
+  const int g = g_rows + g_cells;
   hipLaunchKernelGGL(fc_tail, dim3(g), dim3(256), 0, h->stream, h->N, 2 * h->nn, h->perm.p, h->buf.p + h->N, h->b.p,
-                     res ? S.Ap_rowptr.p : nullptr, S.Ap_col.p, S.Ap_val.p, compute_energy ? h->mp_rowptr.p : nullptr,
-                     h->mp_col.p, h->mp_val.p, h->up.p, h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p, h->partial.p);
+                     res ? S.Ap_rowptr.p : nullptr, S.Ap_col.p, S.Ap_val.p, g_rows, h->nc, compute_energy ? h->cn.p : nullptr,
+                     h->geom.p, h->iperm.p, h->up.p, h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p, h->partial.p);
   hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, g, compute_energy ? h->partial.p + 2 * (size_t)g : nullptr,
                      d_E, res ? g : 0, res ? h->partial.p : nullptr, d_r, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p,
                      h->up.p, d_y, h->flag.p, d_flag_out, d_seq, seq);
@@ -1096,6 +1097,11 @@ int fc_set_permutation(fc_handle h, const int32_t* perm) {
   }
   h->h_perm.assign(perm, perm + h->N);
   FCCHK(h->perm.upload(h->h_perm, h->stream));
+  {
+    std::vector<int> ip((size_t)h->N);
+    for (int i = 0; i < h->N; ++i) ip[(size_t)h->h_perm[i]] = i;
+    FCCHK(h->iperm.upload(ip, h->stream));
+  }
   h->have_perm = true;
   h->have_mp = false;
   for (int o = 0; o < 2; ++o) h->sys[o].ready = h->sys[o].structured = false;

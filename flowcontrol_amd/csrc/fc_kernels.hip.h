@@ -865,70 +865,89 @@ __global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused tail of a single-GPU step (residual monitor + fc_finish in ONE launch, fc_final follows):
-// 8 lanes per permuted row evaluate r_i = b_i - (A x)_i (flowsolver.py:729's solve, checked) and the
-// energy row x_i (M x)_i (utils_flowsolver.py:195-203), lane 0 scatters/shifts the dof; every
-// workgroup leaves (sum r^2 | sum b^2 | sum e) in `partial` (three arrays of gridDim.x) for fc_final.
+// Fused tail of a single-GPU step (residual monitor + state shift + energy in ONE launch, fc_final
+// follows).  Row workgroups: 8 lanes per permuted row evaluate r_i = b_i - (A x)_i (flowsolver.py:729's
+// solve, checked), lane 0 scatters/shifts the dof.  Cell workgroups (appended to the grid): the energy
+// integral of the new velocity, element by element.  Every workgroup leaves (sum r^2 | sum b^2 | sum e)
+// in `partial` (three arrays of gridDim.x) for fc_final.
 // (Folding fc_final in as well, "last workgroup to arrive reduces", was measured: the agent-scope
 // release each workgroup then needs writes back its XCD's L2 and costs 10x what the launch saves.)
 __global__ __launch_bounds__(256) void fc_tail(
     int N, int nn2, const int* __restrict__ perm, const double* __restrict__ x, const double* __restrict__ b,
     const int* __restrict__ a_rowptr, const int* __restrict__ a_col, const double* __restrict__ a_val,
-    const int* __restrict__ m_rowptr, const int* __restrict__ m_col, const double* __restrict__ m_val,
+    int n_row_blocks, int nc, const int* __restrict__ cn, const double* __restrict__ geom, const int* __restrict__ iperm,
     double* __restrict__ up, double* __restrict__ u_n, double* __restrict__ u_nn, double* __restrict__ p_n,
     int* __restrict__ flag, double* __restrict__ partial) {
   constexpr int LANES = 8, RPB = 256 / LANES;
   const int t = threadIdx.x, lane = t % LANES;
-  const int i = blockIdx.x * RPB + t / LANES;
   const int G = gridDim.x;
-  double sa = 0.0, sm = 0.0;
-  int r = 0;
-  bool bad = false;
-  if (i < N) {
-    r = perm[i];
-    if (a_rowptr) {
-      const int k0 = a_rowptr[i], k1 = a_rowptr[i + 1];
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      for (int base = k0; base < k1; base += 4 * LANES) {
-        const int j0 = base + lane, j1 = j0 + LANES, j2 = j1 + LANES, j3 = j2 + LANES;
-        const int c0 = j0 < k1 ? a_col[j0] : 0, c1 = j1 < k1 ? a_col[j1] : 0;
-        const int c2 = j2 < k1 ? a_col[j2] : 0, c3 = j3 < k1 ? a_col[j3] : 0;
-        const double v0 = j0 < k1 ? a_val[j0] : 0.0, v1 = j1 < k1 ? a_val[j1] : 0.0;
-        const double v2 = j2 < k1 ? a_val[j2] : 0.0, v3 = j3 < k1 ? a_val[j3] : 0.0;
-        s0 += v0 * x[c0];
-        s1 += v1 * x[c1];
-        s2 += v2 * x[c2];
-        s3 += v3 * x[c3];
-      }
-      sa = (s0 + s1) + (s2 + s3);
-    }
-    if (m_rowptr && r < nn2)
-      for (int k = m_rowptr[i] + lane; k < m_rowptr[i + 1]; k += LANES) sm += m_val[k] * x[m_col[k]];
-  }
-#pragma unroll
-  for (int off = LANES / 2; off > 0; off >>= 1) {
-    sa += __shfl_down(sa, off, LANES);
-    sm += __shfl_down(sm, off, LANES);
-  }
   double r2 = 0.0, b2 = 0.0, e = 0.0;
-  if (i < N && lane == 0) {
-    const double v = x[i];
-    if (a_rowptr) {
-      const double bb = b[i], res = bb - sa;
-      r2 = res * res;
-      b2 = bb * bb;
+  if ((int)blockIdx.x < n_row_blocks) {
+    // rows: residual monitor, scatter to the W layout, state shift
+    const int i = blockIdx.x * RPB + t / LANES;
+    double sa = 0.0;
+    int r = 0;
+    if (i < N) {
+      r = perm[i];
+      if (a_rowptr) {
+        const int k0 = a_rowptr[i], k1 = a_rowptr[i + 1];
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (int base = k0; base < k1; base += 4 * LANES) {
+          const int j0 = base + lane, j1 = j0 + LANES, j2 = j1 + LANES, j3 = j2 + LANES;
+          const int c0 = j0 < k1 ? a_col[j0] : 0, c1 = j1 < k1 ? a_col[j1] : 0;
+          const int c2 = j2 < k1 ? a_col[j2] : 0, c3 = j3 < k1 ? a_col[j3] : 0;
+          const double v0 = j0 < k1 ? a_val[j0] : 0.0, v1 = j1 < k1 ? a_val[j1] : 0.0;
+          const double v2 = j2 < k1 ? a_val[j2] : 0.0, v3 = j3 < k1 ? a_val[j3] : 0.0;
+          s0 += v0 * x[c0];
+          s1 += v1 * x[c1];
+          s2 += v2 * x[c2];
+          s3 += v3 * x[c3];
+        }
+        sa = (s0 + s1) + (s2 + s3);
+      }
     }
-    up[r] = v;
-    if (r < nn2) {
-      e = v * sm;
-      u_nn[r] = u_n[r];
-      u_n[r] = v;
-      bad = !isfinite(v);
-    } else {
-      p_n[r - nn2] = v;
+#pragma unroll
+    for (int off = LANES / 2; off > 0; off >>= 1) sa += __shfl_down(sa, off, LANES);
+    bool bad = false;
+    if (i < N && lane == 0) {
+      const double v = x[i];
+      if (a_rowptr) {
+        const double bb = b[i], res = bb - sa;
+        r2 = res * res;
+        b2 = bb * bb;
+      }
+      up[r] = v;
+      if (r < nn2) {
+        u_nn[r] = u_n[r];
+        u_n[r] = v;
+        bad = !isfinite(v);
+      } else {
+        p_n[r - nn2] = v;
+      }
     }
+    if (bad) atomicOr(flag, 1);
+  } else if (cn) {
+    // cells: perturbation energy  ∫|u|^2  of the NEW velocity (utils_flowsolver.py:195-203 / flowsolver.py:827-829),
+    // read from the permuted solution through the inverse permutation; lane q = Radon point q (degree-4
+    // integrand: the 7-point rule is exact), 32 cells per workgroup.  2 MB instead of the 11 MB of mass-matrix rows.
+    const int c = ((int)blockIdx.x - n_row_blocks) * RPB + t / LANES;
+    double w = 0.0;
+    if (c < nc && lane < FC_NQ) {
+      double ux = 0.0, uy = 0.0;
+      const int nn = nn2 >> 1;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const int n = cn[(size_t)a * nc + c];
+        const double ph = c_phi2[lane * 6 + a];
+        ux += ph * x[iperm[n]];
+        uy += ph * x[iperm[nn + n]];
+      }
+      w = c_qw[lane] * 0.5 * geom[4 * (size_t)nc + c] * (ux * ux + uy * uy);
+    }
+#pragma unroll
+    for (int off = LANES / 2; off > 0; off >>= 1) w += __shfl_down(w, off, LANES);
+    if (lane == 0) e = w;
   }
-  if (bad) atomicOr(flag, 1);
   __shared__ double red[3][256];
   red[0][t] = r2;
   red[1][t] = b2;
