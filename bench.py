@@ -285,8 +285,8 @@ def main() -> None:
         bytes_per_launch = sweep_bytes / n_stage
         achieved = bytes_per_launch / mean_launch_ms / 1e6  # GB/s
         traffic = None
-        tfile = ROOT / "profiles" / "traffic.json"
-        if tfile.exists():
+        tfile = ROOT / "profiles" / "traffic.json"  # PMC passes of the DEFAULT workload (scripts/profile_gpu.sh)
+        if tfile.exists() and REFINE == 0 and not partitioned:
             try:
                 traffic = json.loads(tfile.read_text()).get("fc_nd_sweep_bytes_per_launch")
             except Exception:
@@ -301,7 +301,9 @@ def main() -> None:
                               "GB/s": spmv_bytes / (tim["spmv_ms"] / tim["spmv_launches"]) / 1e6}
                              if tim["spmv_launches"] and tim["spmv_ms"] > 0 else
                              "fused into fc_tail (residual monitor + state shift + energy, one launch)"),
-            "note": "factors (~200 MB) are re-read every step and largely stay in the 256 MiB Infinity Cache",
+            "note": (f"factors ({sweep_bytes / 1e6:.0f} MB) are re-read every step and largely stay in the 256 MiB Infinity Cache"
+                     if sweep_bytes < 256e6 else
+                     f"factors ({sweep_bytes / 1e6:.0f} MB) exceed the 256 MiB Infinity Cache: HBM streaming"),
         }
         phases, nl = dev.profile_steps(SLOT_BDF2, 50, u0)
         spmv = spmv_probe(fs, include_large=not args.no_large_spmv)
