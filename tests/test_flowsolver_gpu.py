@@ -318,3 +318,26 @@ def test_lidcavity_regression(tmp_path_factory, golden_dir):
     assert np.isclose(flu.apply_fun(fs.fields.Usave, np.max), 1.000000000000008, rtol=1e-6)
     assert np.isclose(flu.apply_fun(fs.fields.Usave, np.mean), 0.0020222416653700877, rtol=1e-6)
     fs.th.release_device()
+
+
+def test_cylinder_1000_actuated_steps_vs_oracle(tmp_path_factory, golden_dir):
+    """north_star: "sensor timeseries within 1e-6 rel-L2 of reference over 1000 steps".  1000 synchronous
+    steps with a time-varying actuation (Dirichlet lifting at every step) against the oracle's series
+    (tests/golden/make_cylinder_1000_steps.py); the bar here is 1e-8."""
+    g = np.load(golden_dir / "cylinder_O1_ol1000.npz")
+    n = 1000
+    k = np.arange(n)
+    u = np.stack([0.05 * np.sin(0.01 * k), -0.02 * np.cos(0.013 * k)], axis=1)
+    fs = CylinderFlowSolver.make_default(Re=100, path_out=tmp_path_factory.mktemp("cyl_1000"), num_steps=n)
+    fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
+    _load_baseflow(fs, golden_dir)
+    fs.initialize_time_stepping(ic=None)
+    for i in range(n):
+        fs.step(u[i])
+    ts = fs.timeseries
+    y = ts[["y_meas_1", "y_meas_2", "y_meas_3"]].to_numpy()
+    assert y.shape == g["y"].shape == (n + 1, 3)
+    assert _rel_l2(y, g["y"]) < 1e-8
+    assert _rel_l2(ts["dE"].to_numpy(), g["dE"]) < 1e-8
+    assert np.isclose(fs.t, 5.0)
+    fs.th.release_device()
