@@ -76,6 +76,9 @@ class FlowSolver(ABC):
         #: number of iterative-refinement sweeps per solve (0 = factor apply + residual monitoring)
         self.nd_depth: int | None = None
         self.refine_steps: int = 0
+        # every step's solve is monitored: relative residual of the linear system above this → error (the
+        # factor apply is exact to round-off, ~1e-16; a larger value means broken factors or a singular system)
+        self.residual_tol: float = 1e-8
         self._setup()
 
     # ── validation (reference :108-165) ──────────────────────────────────────
@@ -567,6 +570,11 @@ class FlowSolver(ABC):
                 return None
             raise RuntimeError("Failed solving: Inf found in solution")
         self.solve_info = info  # (refinement sweeps, relative residual, |b|, flag) of this step; buffer reused by the next
+        if info[1] > self.residual_tol:  # NaN (monitor off) compares False
+            msg = f"linear solve residual {info[1]:.2e} exceeds residual_tol = {self.residual_tol:.1e} at iteration {next_iter}"
+            logger.critical(msg)
+            if self.params_solver.throw_error:
+                raise RuntimeError(msg)
         self.iter = next_iter
         self.t = self.params_time.Tstart + self.iter * self.params_time.dt
         self._u_ctrl_prev = u_ctrl.copy()
