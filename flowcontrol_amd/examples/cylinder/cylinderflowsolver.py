@@ -68,52 +68,17 @@ class CylinderFlowSolver(flowsolver.FlowSolver):
         return BoundaryConditions(bcu=[bcu_inlet, bcu_walls, bcu_cylinder, bcu_actuation_up, bcu_actuation_lo], bcp=[])
 
     @classmethod
-    def make_default(
-        cls,
-        Re: float = 100,
-        path_out=None,
-        num_steps: int = 10,
-        save_every: int = 0,
-        Tstart: float = 0.0,
-        verbose: int = 0,
-        meshpath: str | Path | None = None,
-    ) -> "CylinderFlowSolver":
-        """Standard parameters of the reference (``cylinderflowsolver.py:128-186``): Re=100, dt=0.005,
-        2 parabolic BC actuators of 10° at the poles, 3 V-probes at (3,0), (3.1,±1)."""
-        from ... import flowsolverparameters as fsp
+    def make_default(cls, Re: float = 100, path_out=None, num_steps: int = 10, save_every: int = 0, Tstart: float = 0.0,
+                     verbose: int = 0, meshpath: str | Path | None = None) -> "CylinderFlowSolver":
+        """The reference's standard case (``cylinderflowsolver.py:128-186``): dt = 0.005, two parabolic BC
+        actuators of 10° at the poles of the cylinder, V probes at (3, 0) and (3.1, ±1), mesh O1."""
         from ...actuator import ActuatorBCParabolicV
-        from ...sensor import SENSOR_TYPE, SensorPoint
+        from .._defaults import bundle, probes
 
-        if path_out is None:
-            path_out = Path.cwd() / "data_output"
-        params_flow = fsp.ParamFlow(Re=Re, uinf=1.0)
-        params_flow.user_data["D"] = 1.0
-        params_time = fsp.ParamTime(num_steps=num_steps, dt=0.005, Tstart=Tstart)
-        params_save = fsp.ParamSave(save_every=save_every, path_out=Path(path_out))
-        params_solver = fsp.ParamSolver(throw_error=True, is_eq_nonlinear=True, shift=0.0)
-        params_mesh = fsp.ParamMesh(meshpath=Path(meshpath or DEFAULT_MESH))
-        params_mesh.user_data.update({"xinf": 20, "xinfa": -10, "yinf": 10})
-        radius = params_flow.user_data["D"] / 2
-        width = ActuatorBCParabolicV.angular_size_deg_to_width(10, radius)
-        params_control = fsp.ParamControl(
-            sensor_list=[
-                SensorPoint(sensor_type=SENSOR_TYPE.V, position=np.array([3.0, 0.0])),
-                SensorPoint(sensor_type=SENSOR_TYPE.V, position=np.array([3.1, 1.0])),
-                SensorPoint(sensor_type=SENSOR_TYPE.V, position=np.array([3.1, -1.0])),
-            ],
-            actuator_list=[
-                ActuatorBCParabolicV(width=width, position_x=0.0, boundary_name="actuator_up"),
-                ActuatorBCParabolicV(width=width, position_x=0.0, boundary_name="actuator_lo"),
-            ],
-        )
-        params_ic = fsp.ParamIC()
-        return cls(
-            params_flow=params_flow,
-            params_time=params_time,
-            params_save=params_save,
-            params_solver=params_solver,
-            params_mesh=params_mesh,
-            params_control=params_control,
-            params_ic=params_ic,
-            verbose=verbose,
-        )
+        width = ActuatorBCParabolicV.angular_size_deg_to_width(10, 0.5)  # 10 degrees on the radius-0.5 cylinder
+        poles = [ActuatorBCParabolicV(width=width, position_x=0.0, boundary_name=name) for name in ("actuator_up", "actuator_lo")]
+        return cls(verbose=verbose, **bundle(
+            Re=Re, dt=0.005, num_steps=num_steps, Tstart=Tstart, save_every=save_every,
+            path_out=path_out if path_out is not None else Path.cwd() / "data_output",
+            mesh=meshpath or DEFAULT_MESH, mesh_extent={"xinf": 20, "xinfa": -10, "yinf": 10},
+            sensors=probes([("V", (3.0, 0.0)), ("V", (3.1, 1.0)), ("V", (3.1, -1.0))]), actuators=poles))

@@ -64,27 +64,13 @@ class LidCavityFlowSolver(flowsolver.FlowSolver):
     @classmethod
     def make_default(cls, Re: float = 8000, path_out=None, num_steps: int = 10, save_every: int = 0, Tstart: float = 0.0,
                      verbose: int = 0, meshpath: str | Path | None = None) -> "LidCavityFlowSolver":
-        """Standard parameters of the reference (``:94-148``): dt = 0.005, uniform-U lid actuator, a V probe
-        at (0.05, 0.5) and a U probe at (0.5, 0.95), 64 × 64 mesh."""
-        from ... import flowsolverparameters as fsp
+        """The reference's standard case (``lidcavityflowsolver.py:94-148``): dt = 0.005, uniform-U actuator on the
+        lid, a V probe at (0.05, 0.5) and a U probe at (0.5, 0.95), the 64 × 64 unit-square mesh."""
         from ...actuator import ActuatorBCUniformU
-        from ...sensor import SENSOR_TYPE, SensorPoint
+        from .._defaults import bundle, probes
 
-        if path_out is None:
-            path_out = Path(__file__).parent / "data_output"
-        params_flow = fsp.ParamFlow(Re=Re, uinf=1.0)
-        params_flow.user_data["D"] = 1.0
-        params_time = fsp.ParamTime(num_steps=num_steps, dt=0.005, Tstart=Tstart)
-        params_save = fsp.ParamSave(save_every=save_every, path_out=path_out)
-        params_solver = fsp.ParamSolver(throw_error=True, is_eq_nonlinear=True, shift=0.0)
-        params_mesh = fsp.ParamMesh(meshpath=meshpath or DEFAULT_MESH)
-        params_mesh.user_data.update({"yup": 1, "ylo": 0, "xri": 1, "xle": 0})
-        params_control = fsp.ParamControl(
-            sensor_list=[
-                SensorPoint(sensor_type=SENSOR_TYPE.V, position=np.array([0.05, 0.5])),
-                SensorPoint(sensor_type=SENSOR_TYPE.U, position=np.array([0.5, 0.95])),
-            ],
-            actuator_list=[ActuatorBCUniformU(boundary_name="lid")],
-        )
-        return cls(params_flow=params_flow, params_time=params_time, params_save=params_save, params_solver=params_solver,
-                   params_mesh=params_mesh, params_control=params_control, params_ic=fsp.ParamIC(), verbose=verbose)
+        return cls(verbose=verbose, **bundle(
+            Re=Re, dt=0.005, num_steps=num_steps, Tstart=Tstart, save_every=save_every,
+            path_out=path_out if path_out is not None else Path(__file__).parent / "data_output",
+            mesh=meshpath or DEFAULT_MESH, mesh_extent={"yup": 1, "ylo": 0, "xri": 1, "xle": 0},
+            sensors=probes([("V", (0.05, 0.5)), ("U", (0.5, 0.95))]), actuators=[ActuatorBCUniformU(boundary_name="lid")]))

@@ -489,6 +489,10 @@ class FlowSolver(ABC):
         if getattr(self, "_joined", False):
             return
         self._joined = True
+        import sys
+
+        if "torch" not in sys.modules:
+            return  # nobody in this process can have initialised torch.distributed: do not pay the import
         try:
             import torch.distributed as dist
         except Exception:  # pragma: no cover
