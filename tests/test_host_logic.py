@@ -428,3 +428,37 @@ def test_pressure_pin_only_for_enclosed_flows():
     x2 = spla.spsolve(A2, b2)
     assert abs(x2[pin]) < 1e-12
     assert np.linalg.norm(x1 - x2) < 1e-10 * np.linalg.norm(x1)
+
+
+def test_checkpoint_series_roundtrip(tmp_path):
+    """io.write_xdmf / read_xdmf: a series is an .xdmf index + one mesh file + one small HDF5 file per frame;
+    appending does not touch earlier frames; frames come back bit-exact by counter (−1 = last)."""
+    from flowcontrol_amd.fem.mesh import Mesh
+    from flowcontrol_amd.fem.spaces import Function, FunctionSpace, TaylorHood
+    from flowcontrol_amd.io import read_xdmf, write_xdmf
+
+    th = TaylorHood(Mesh.unit_square(5, 4))
+    V, P = FunctionSpace(th, "V"), FunctionSpace(th, "P")
+    rng = np.random.default_rng(3)
+    frames = [rng.standard_normal(2 * th.nn) for _ in range(4)]
+    path = tmp_path / "U_restart0,000.xdmf"
+    for k, v in enumerate(frames):
+        assert write_xdmf(path, Function(V, v), "U", time_step=0.25 * k, append=k > 0) == k
+    first = (tmp_path / "U_restart0,000.0.h5").read_bytes()
+    assert sorted(p.name for p in tmp_path.iterdir()) == sorted(
+        ["U_restart0,000.xdmf", "U_restart0,000.h5"] + [f"U_restart0,000.{k}.h5" for k in range(4)])
+    f = Function(V)
+    for k, v in enumerate(frames):
+        assert read_xdmf(path, f, "U", counter=k) == 0.25 * k
+        assert np.array_equal(f.vector().get_local(), v)
+    assert read_xdmf(path, f, "U") == 0.75 and np.array_equal(f.vector().get_local(), frames[-1])
+    assert (tmp_path / "U_restart0,000.0.h5").read_bytes() == first  # untouched by the appends
+    xml = path.read_text()
+    assert xml.count("<Time Value=") == 4 and "U_restart0,000.3.h5:/U/vertex_values" in xml and "U_restart0,000.h5:/Mesh/mesh/topology" in xml
+    with pytest.raises(FileNotFoundError):
+        read_xdmf(path, f, "U", counter=4)
+    with pytest.raises(ValueError):
+        read_xdmf(path, Function(P), "U", counter=0)
+    # starting over (append=False) resets the series
+    assert write_xdmf(path, Function(V, frames[1]), "U", time_step=9.0, append=False) == 0
+    assert read_xdmf(path, f, "U") == 9.0
