@@ -629,10 +629,11 @@ bool use_fused_tail(const fc_ctx* h) {
 int launch_tail(fc_ctx* h, OrderSys& S, int compute_energy, double* d_y, double* d_E, double* d_r, double* d_flag_out,
                 double* d_seq, double seq) {
   const bool res = h->check_residual != 0;
-  const int g_rows = nblocks(h->N, 32), g_cells = compute_energy ? nblocks(h->nc, 32) : 0;
+  const int reps = std::max(1, nblocks(h->N, 32 * 1536));  // <= ~1536 + ~400 partials per array for fc_final
+  const int g_rows = nblocks(h->N, 32 * reps), g_cells = compute_energy ? nblocks(h->nc, 32 * reps) : 0;
   const int g = g_rows + g_cells;
   hipLaunchKernelGGL(fc_tail, dim3(g), dim3(256), 0, h->stream, h->N, 2 * h->nn, h->perm.p, h->buf.p + h->N, h->b.p,
-                     res ? S.Ap_rowptr.p : nullptr, S.Ap_col.p, S.Ap_val.p, g_rows, h->nc, compute_energy ? h->cn.p : nullptr,
+                     res ? S.Ap_rowptr.p : nullptr, S.Ap_col.p, S.Ap_val.p, g_rows, reps, h->nc, compute_energy ? h->cn.p : nullptr,
                      h->geom.p, h->iperm.p, h->up.p, h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p, h->partial.p);
   hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, g, compute_energy ? h->partial.p + 2 * (size_t)g : nullptr,
                      d_E, res ? g : 0, res ? h->partial.p : nullptr, d_r, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p,

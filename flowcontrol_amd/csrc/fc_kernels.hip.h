@@ -875,7 +875,7 @@ __global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restric
 __global__ __launch_bounds__(256) void fc_tail(
     int N, int nn2, const int* __restrict__ perm, const double* __restrict__ x, const double* __restrict__ b,
     const int* __restrict__ a_rowptr, const int* __restrict__ a_col, const double* __restrict__ a_val,
-    int n_row_blocks, int nc, const int* __restrict__ cn, const double* __restrict__ geom, const int* __restrict__ iperm,
+    int n_row_blocks, int reps, int nc, const int* __restrict__ cn, const double* __restrict__ geom, const int* __restrict__ iperm,
     double* __restrict__ up, double* __restrict__ u_n, double* __restrict__ u_nn, double* __restrict__ p_n,
     int* __restrict__ flag, double* __restrict__ partial) {
   constexpr int LANES = 8, RPB = 256 / LANES;
@@ -883,8 +883,10 @@ __global__ __launch_bounds__(256) void fc_tail(
   const int G = gridDim.x;
   double r2 = 0.0, b2 = 0.0, e = 0.0;
   if ((int)blockIdx.x < n_row_blocks) {
-    // rows: residual monitor, scatter to the W layout, state shift
-    const int i = blockIdx.x * RPB + t / LANES;
+    // rows: residual monitor, scatter to the W layout, state shift (`reps` row groups per workgroup keep
+    // the number of partials that fc_final folds alone <= ~2000 on large meshes)
+    for (int rep = 0; rep < reps; ++rep) {
+    const int i = (blockIdx.x * reps + rep) * RPB + t / LANES;
     double sa = 0.0;
     int r = 0;
     if (i < N) {
@@ -913,8 +915,8 @@ __global__ __launch_bounds__(256) void fc_tail(
       const double v = x[i];
       if (a_rowptr) {
         const double bb = b[i], res = bb - sa;
-        r2 = res * res;
-        b2 = bb * bb;
+        r2 += res * res;
+        b2 += bb * bb;
       }
       up[r] = v;
       if (r < nn2) {
@@ -926,11 +928,13 @@ __global__ __launch_bounds__(256) void fc_tail(
       }
     }
     if (bad) atomicOr(flag, 1);
+    }
   } else if (cn) {
     // cells: perturbation energy  ∫|u|^2  of the NEW velocity (utils_flowsolver.py:195-203 / flowsolver.py:827-829),
     // read from the permuted solution through the inverse permutation; lane q = Radon point q (degree-4
     // integrand: the 7-point rule is exact), 32 cells per workgroup.  2 MB instead of the 11 MB of mass-matrix rows.
-    const int c = ((int)blockIdx.x - n_row_blocks) * RPB + t / LANES;
+    for (int rep = 0; rep < reps; ++rep) {
+    const int c = (((int)blockIdx.x - n_row_blocks) * reps + rep) * RPB + t / LANES;
     double w = 0.0;
     if (c < nc && lane < FC_NQ) {
       double ux = 0.0, uy = 0.0;
@@ -946,7 +950,8 @@ __global__ __launch_bounds__(256) void fc_tail(
     }
 #pragma unroll
     for (int off = LANES / 2; off > 0; off >>= 1) w += __shfl_down(w, off, LANES);
-    if (lane == 0) e = w;
+    if (lane == 0) e += w;
+    }
   }
   __shared__ double red[3][256];
   red[0][t] = r2;
