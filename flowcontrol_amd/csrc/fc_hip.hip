@@ -1407,7 +1407,6 @@ int fc_set_front_shifts(fc_handle h, int32_t n, const int64_t* slots, const doub
 int fc_refactor(fc_handle h, int slot, double* ms_out) {
   if (!h || slot < 0 || slot > 1) return fail(FC_ERR_INVALID, "fc_refactor: bad argument");
   if (!h->have_plan) return fail(FC_ERR_NOT_READY, "fc_factor_plan not called");
-  if (h->partitioned) return fail(FC_ERR_INVALID, "fc_refactor: single-GPU handles only");
   OrderSys& S = h->sys[slot];
   if (!S.structured) return fail(FC_ERR_NOT_READY, "fc_solver_setup (structure) must be called first");
   if ((int64_t)h->pap_src.n != S.Ap_nnz) return fail(FC_ERR_INVALID, "fc_refactor: plan and solver structure disagree (matrix)");

@@ -195,7 +195,9 @@ class DeviceSolver:
             check(self.lib.fc_set_permutation(self._h, _i32(self.tree.perm)))
             self._upload_energy_matrix()
         t = self.tree
-        on_device = self.device_factor and self.world == 1 and not getattr(self, "_force_comm", False)
+        # partitioned handles too: every rank holds the whole matrix and repeats the (61 ms) numeric phase for the
+        # whole tree; its sweep tables then pick the rank's own segments out of the same value array
+        on_device = bool(self.device_factor)
         up_split = int(os.environ.get("FC_UP_SPLIT", "0"))
         if on_device:
             # structure on the host (index work only, once per tree), numbers on the device
@@ -305,6 +307,8 @@ class DeviceSolver:
             self._probe = np.cos(0.37 * np.arange(self.N) + 0.1)
             if self._pin is not None:
                 self._probe[2 * self.nn :] = 0.0  # compatible with the constant-pressure null space
+        if self.world > 1 or getattr(self, "_force_comm", False):
+            return ms.value  # a probe solve would be a collective; every step's residual is monitored instead
         opts = getattr(self, "_solver_opts", (0, True))
         check(self.lib.fc_set_solver_options(self._h, _lib.METHOD_REFINE, 0, 1e-10, 1))
         _, info = self.solve(slot, self._probe)

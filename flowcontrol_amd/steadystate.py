@@ -4,8 +4,8 @@ API mirror of the reference's ``src/flowcontrol/steadystate.py``.  Every iterati
 device: the operator is assembled by the HIP element loop (``fc_assemble_matrix``), factorised by
 the device multifrontal numeric phase (``fc_refactor``, the structure being laid out once) and
 applied with the same sweep kernels as a time step; the host only forms norms and updates the
-iterate.  Partitioned (multi-GPU) handles and ``FC_HOST_FACTOR=1`` keep the earlier host path
-(SuperLU with the nested-dissection ordering).
+iterate.  Partitioned (multi-GPU) handles and ``FC_HOST_FACTOR=1`` keep the earlier host path for
+these set-up solves (SuperLU with the nested-dissection ordering).
 """
 
 from __future__ import annotations

@@ -140,7 +140,8 @@ int fc_solver_set_blocks(fc_handle h, int slot, int32_t n_stages, const int64_t*
  * the children's Schur complements, pivot-block inverse (rocSOLVER getrf/getri, partial pivoting inside
  * the block) and three GEMMs per node (rocBLAS), written straight into the layout the sweeps read.
  * The structure (fc_solver_setup / fc_solver_set_blocks) must have been uploaded before, with any
- * values.  ms_out (optional): device time of the numeric phase.  Single-GPU handles only. */
+ * values.  ms_out (optional): device time of the numeric phase.  On a partitioned handle every rank
+ * repeats the numeric phase for the whole tree (it holds the whole matrix); no collective involved. */
 int fc_factor_plan(fc_handle h, int32_t n_nodes, const int64_t* nodes, int32_t n_levels, const int64_t* level_ptr,
                    int64_t front_size, int64_t n_a, const int64_t* a_src, const int64_t* a_dst,
                    const int64_t* a_ptr, const int64_t* ext_off, int64_t n_ext, const int32_t* ext_p,
