@@ -13,9 +13,12 @@ from flowcontrol_amd.fem.spaces import TaylorHood  # noqa: E402
 from oracle import ns_oracle as O  # noqa: E402  (scripts/ is tooling, not the product path)
 
 
-def main(merge=2, depth=None):
+def main(merge=2, depth=None, refine=0):
     d = np.load(ROOT / "tests/golden/meshes/O1.npz")
-    th = TaylorHood(Mesh.from_arrays(d["coords"], d["cells"]))
+    mesh = Mesh.from_arrays(d["coords"], d["cells"])
+    for _ in range(refine):
+        mesh = mesh.refine()
+    th = TaylorHood(mesh)
     disc = O.Disc.from_taylor_hood(th)
     U0 = np.zeros(2 * th.nn)
     U0[: th.nn] = 1.0
@@ -27,12 +30,12 @@ def main(merge=2, depth=None):
     nodes = nodes[x[nodes, 0] < x[:, 0].max() - 1e-9]
     dofs = np.sort(np.r_[nodes, nodes + th.nn])
     A, _ = O.apply_bc_symmetric(A, None, dofs, np.zeros(dofs.size))
-    if depth is None:
+    if not depth:
         depth = int(np.ceil(np.log2(th.nc / 12.0)))
     skip = np.zeros(th.N, bool)
     skip[dofs] = True
     t = nd.build_tree(th.cell_dofs, m.cell_centroids(), th.N, depth, skip, merge=merge)
-    fac = nd.factorize_blocks(A.tocsr(), t)
+    fac = nd.factorize_blocks(None, t, numeric=False)  # structure only: sizes do not need the numbers
     print(f"depth {t.depth} nnz {fac.nnz}")
     rowlen = np.zeros(fac.seg_ptr.size - 1, np.int64)
     np.add.at(rowlen, np.repeat(np.arange(rowlen.size), np.diff(fac.seg_ptr)), fac.seg_len)
