@@ -1442,7 +1442,10 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
         const auto grp = h->pext_groups[li - 1][sl];
         if (grp.second == 0) continue;
         const int gx = (h->pext_maxnb[li - 1][sl] + FC_EXT_ROWS - 1) / FC_EXT_ROWS;
-        hipLaunchKernelGGL(fc_extend_add, dim3(gx, grp.second), dim3(256), 0, h->stream, h->pext.p + grp.first, h->pext_p.p, F);
+        for (int c0 = 0; c0 < grp.second; c0 += 65535) {  // grid.y limit
+          const int nc_ = std::min(65535, grp.second - c0);
+          hipLaunchKernelGGL(fc_extend_add, dim3(gx, nc_), dim3(256), 0, h->stream, h->pext.p + grp.first + c0, h->pext_p.p, F);
+        }
       }
     }
     if (h->pfront_groups[li].second > 0)
