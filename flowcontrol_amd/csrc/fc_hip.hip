@@ -593,7 +593,7 @@ int enqueue_rhs(fc_ctx* h, int order_slot, const double* d_uctrl, const double* 
   if (!d_uforce) d_uforce = d_uctrl;
   if (S.have_c && h->partitioned) return fail(FC_ERR_INVALID, "an explicit rhs operator (Crank-Nicolson) is not available on a partitioned handle");
   const int ncl = h->partitioned ? h->ncl : h->nc;
-  const bool have_ev = h->pre_slot == order_slot && !h->have_force && !h->partitioned;
+  const bool have_ev = h->pre_slot == order_slot && !h->have_force;
   h->pre_slot = -1;
   if (ncl > 0 && !have_ev)
     hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks((int64_t)ncl * 8, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
@@ -623,21 +623,38 @@ bool use_fused_tail(const fc_ctx* h) {
     const char* e = std::getenv("FC_FUSED_TAIL");  // 0: residual SpMV and fc_finish as separate launches
     return !(e && e[0] == '0');
   }();
-  return enabled && !h->partitioned && h->max_iter == 0;
+  return enabled && h->max_iter == 0;
 }
 
 int launch_tail(fc_ctx* h, OrderSys& S, int compute_energy, double* d_y, double* d_E, double* d_r, double* d_flag_out,
                 double* d_seq, double seq) {
   const bool res = h->check_residual != 0;
+  const bool part = h->partitioned;
+  const int ncl = part ? h->ncl : h->nc;
   const int reps = std::max(1, nblocks(h->N, 32 * 1536));  // <= ~1536 + ~400 partials per array for fc_final
-  const int g_rows = nblocks(h->N, 32 * reps), g_cells = compute_energy ? nblocks(h->nc, 32 * reps) : 0;
+  const int g_rows = nblocks(h->N, 32 * reps), g_cells = (compute_energy && ncl > 0) ? nblocks(ncl, 32 * reps) : 0;
   const int g = g_rows + g_cells;
   hipLaunchKernelGGL(fc_tail, dim3(g), dim3(256), 0, h->stream, h->N, 2 * h->nn, h->perm.p, h->buf.p + h->N, h->b.p,
-                     res ? S.Ap_rowptr.p : nullptr, S.Ap_col.p, S.Ap_val.p, g_rows, reps, h->nc, compute_energy ? h->cn.p : nullptr,
-                     h->geom.p, h->iperm.p, h->up.p, h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p, h->partial.p);
-  hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, g, compute_energy ? h->partial.p + 2 * (size_t)g : nullptr,
-                     d_E, res ? g : 0, res ? h->partial.p : nullptr, d_r, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p,
-                     h->up.p, d_y, h->flag.p, d_flag_out, d_seq, seq);
+                     res ? S.Ap_rowptr.p : nullptr, S.Ap_col.p, S.Ap_val.p, g_rows, reps, h->nc, g_cells > 0 ? h->cn.p : nullptr,
+                     h->geom.p, h->iperm.p, part ? h->rowkind_p.p : nullptr, part ? h->cell_list.p : nullptr, ncl, h->up.p,
+                     h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p, h->partial.p);
+  const double* e_part = g_cells > 0 ? h->partial.p + 2 * (size_t)g : nullptr;
+  if (!part) {
+    hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, g, e_part, d_E, res ? g : 0, res ? h->partial.p : nullptr, d_r,
+                       h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p, h->up.p, d_y, h->flag.p, d_flag_out, d_seq, seq);
+  } else {
+    // partitioned: this rank's share (owned rows, its cells, its part of every sensor row) goes to the 80-double
+    // tail record, ONE all-reduce sums the ranks' records, the result is published (fc_final rewrites every
+    // used word of the record each step)
+    hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, g, e_part, h->tail.p + 64, res ? g : 0,
+                       res ? h->partial.p : nullptr, h->tail.p + 65, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p, h->up.p,
+                       h->tail.p, h->flag.p, h->tail.p + 72, (double*)nullptr, 0.0);
+    if (d_y) {  // d_y == nullptr: the caller (host-staged exchange) sums the records itself
+      if (h->comm) NCCLCHK(g_rccl.AllReduce(h->tail.p, h->tail.p, 80, kNcclDouble, kNcclSum, h->comm, h->stream));
+      hipLaunchKernelGGL(fc_publish_tail, dim3(1), dim3(64), 0, h->stream, h->tail.p, d_y, h->n_sens, d_E, d_r, d_flag_out, d_seq,
+                         seq);
+    }
+  }
   HIPCHK(hipGetLastError());
   return FC_OK;
 }
@@ -1596,13 +1613,14 @@ void speculate_next_rhs(fc_ctx* h, int order_slot) {
     return !(e && e[0] == '0');
   }();
   h->pre_slot = -1;
-  if (!enabled || h->have_force || h->partitioned || h->nc <= 0) return;
+  const int ncl = h->partitioned ? h->ncl : h->nc;
+  if (!enabled || h->have_force || ncl <= 0) return;
   const int next = h->sys[order_slot].have_c ? order_slot : FC_SLOT_BDF2;
   if (!h->sys[next].ready || !h->sys[next].have_lift) return;
   const StepCoeffs c = coeffs_for(h, next);
-  hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks((int64_t)h->nc * 8, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
+  hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks((int64_t)ncl * 8, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
                      h->u_n.p, h->u_nn.p, (const double*)nullptr, 0, h->pin_dev, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p,
-                     (const int*)nullptr, h->nc);
+                     h->partitioned ? h->cell_list.p : nullptr, ncl);
   if (hipGetLastError() == hipSuccess) h->pre_slot = next;
 }
 
@@ -1699,31 +1717,37 @@ int fc_step_phase(fc_handle h, int order_slot, int phase, const double* u_ctrl, 
   if (phase != 1 || !tail_io) return fail(FC_ERR_INVALID, "fc_step_phase: bad phase");
   HIPCHK(hipMemcpyAsync(root, root_io, (size_t)S.ar_n * sizeof(double), hipMemcpyHostToDevice, h->stream));
   FCCHK(apply_factors(h, S, S.ar_stage + 1, -1));
-  const double* x = h->buf.p + N;
-  int nrp = 0;
-  if (h->check_residual) {
-    const double mean = (double)S.Ap_nnz / std::max(1, N);
-    nrp = launch_spmv<1>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, x, h->b.p, h->tmpN.p, nullptr, h->partial.p,
-                         h->rowkind_p.p);
-    if (nrp < 0) return nrp;
+  if (use_fused_tail(h)) {
+    // this rank's record only (d_y == nullptr): the caller sums the records of the ranks
+    FCCHK(launch_tail(h, S, compute_energy, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0));
+  } else {
+    const double* x = h->buf.p + N;
+    int nrp = 0;
+    if (h->check_residual) {
+      const double mean = (double)S.Ap_nnz / std::max(1, N);
+      nrp = launch_spmv<1>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, x, h->b.p, h->tmpN.p, nullptr, h->partial.p,
+                           h->rowkind_p.p);
+      if (nrp < 0) return nrp;
+    }
+    double* e_partial = h->partial.p + 2 * (size_t)h->nblk_N;
+    hipLaunchKernelGGL(fc_finish, dim3(nblocks(N, 32)), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, x, (const double*)nullptr, h->up.p,
+                       h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p, (const int*)nullptr, (const int*)nullptr,
+                       (const double*)nullptr, (double*)nullptr, h->rowkind_p.p);
+    int ne = 0;
+    if (compute_energy && h->ncl > 0) {
+      ne = nblocks(h->ncl, 256);
+      hipLaunchKernelGGL(fc_energy_elem, dim3(ne), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p, h->u_n.p,
+                         h->cell_list.p, h->ncl, e_partial);
+    }
+    HIPCHK(hipMemsetAsync(h->tail.p, 0, 128 * sizeof(double), h->stream));
+    hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, ne, ne > 0 ? e_partial : nullptr, h->tail.p + 64,
+                       nrp, nrp > 0 ? h->partial.p : nullptr, h->tail.p + 65, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p,
+                       h->up.p, h->tail.p, h->flag.p, h->tail.p + 72, (double*)nullptr, 0.0);
+    HIPCHK(hipGetLastError());
   }
-  double* e_partial = h->partial.p + 2 * (size_t)h->nblk_N;
-  hipLaunchKernelGGL(fc_finish, dim3(nblocks(N, 32)), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, x, (const double*)nullptr, h->up.p,
-                     h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p, (const int*)nullptr, (const int*)nullptr,
-                     (const double*)nullptr, (double*)nullptr, h->rowkind_p.p);
-  int ne = 0;
-  if (compute_energy && h->ncl > 0) {
-    ne = nblocks(h->ncl, 256);
-    hipLaunchKernelGGL(fc_energy_elem, dim3(ne), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p, h->u_n.p,
-                       h->cell_list.p, h->ncl, e_partial);
-  }
-  HIPCHK(hipMemsetAsync(h->tail.p, 0, 128 * sizeof(double), h->stream));
-  hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, ne, ne > 0 ? e_partial : nullptr, h->tail.p + 64,
-                     nrp, nrp > 0 ? h->partial.p : nullptr, h->tail.p + 65, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p,
-                     h->up.p, h->tail.p, h->flag.p, h->tail.p + 72, (double*)nullptr, 0.0);
-  HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(tail_io, h->tail.p, 80 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  speculate_next_rhs(h, order_slot);  // runs while the host sums the records and prepares the next step
   return FC_OK;
 }
 

@@ -876,6 +876,7 @@ __global__ __launch_bounds__(256) void fc_tail(
     int N, int nn2, const int* __restrict__ perm, const double* __restrict__ x, const double* __restrict__ b,
     const int* __restrict__ a_rowptr, const int* __restrict__ a_col, const double* __restrict__ a_val,
     int n_row_blocks, int reps, int nc, const int* __restrict__ cn, const double* __restrict__ geom, const int* __restrict__ iperm,
+    const unsigned char* __restrict__ rowkind, const int* __restrict__ cell_list, int ncl,
     double* __restrict__ up, double* __restrict__ u_n, double* __restrict__ u_nn, double* __restrict__ p_n,
     int* __restrict__ flag, double* __restrict__ partial) {
   constexpr int LANES = 8, RPB = 256 / LANES;
@@ -889,9 +890,12 @@ __global__ __launch_bounds__(256) void fc_tail(
     const int i = (blockIdx.x * reps + rep) * RPB + t / LANES;
     double sa = 0.0;
     int r = 0;
-    if (i < N) {
+    // multi-GPU (rowkind != nullptr): 0 = another rank's row (skipped), 1 = owned (residual + scatter),
+    // 2 = replicated root row (scatter only)
+    const int kind = i < N ? (rowkind ? rowkind[i] : 1) : 0;
+    if (kind != 0) {
       r = perm[i];
-      if (a_rowptr) {
+      if (a_rowptr && kind == 1) {
         const int k0 = a_rowptr[i], k1 = a_rowptr[i + 1];
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         for (int base = k0; base < k1; base += 4 * LANES) {
@@ -911,9 +915,9 @@ __global__ __launch_bounds__(256) void fc_tail(
 #pragma unroll
     for (int off = LANES / 2; off > 0; off >>= 1) sa += __shfl_down(sa, off, LANES);
     bool bad = false;
-    if (i < N && lane == 0) {
+    if (kind != 0 && lane == 0) {
       const double v = x[i];
-      if (a_rowptr) {
+      if (a_rowptr && kind == 1) {
         const double bb = b[i], res = bb - sa;
         r2 += res * res;
         b2 += bb * bb;
@@ -934,9 +938,10 @@ __global__ __launch_bounds__(256) void fc_tail(
     // read from the permuted solution through the inverse permutation; lane q = Radon point q (degree-4
     // integrand: the 7-point rule is exact), 32 cells per workgroup.  2 MB instead of the 11 MB of mass-matrix rows.
     for (int rep = 0; rep < reps; ++rep) {
-    const int c = (((int)blockIdx.x - n_row_blocks) * reps + rep) * RPB + t / LANES;
+    const int cl = (((int)blockIdx.x - n_row_blocks) * reps + rep) * RPB + t / LANES;
+    const int c = cl < ncl ? (cell_list ? cell_list[cl] : cl) : 0;  // multi-GPU: this rank's cells
     double w = 0.0;
-    if (c < nc && lane < FC_NQ) {
+    if (cl < ncl && lane < FC_NQ) {
       double ux = 0.0, uy = 0.0;
       const int nn = nn2 >> 1;
 #pragma unroll
