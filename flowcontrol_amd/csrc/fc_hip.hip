@@ -631,7 +631,7 @@ int launch_tail(fc_ctx* h, OrderSys& S, int compute_energy, double* d_y, double*
   const bool res = h->check_residual != 0;
   const bool part = h->partitioned;
   const int ncl = part ? h->ncl : h->nc;
-  const int reps = std::max(1, nblocks(h->N, 32 * 1536));  // <= ~1536 + ~400 partials per array for fc_final
+  const int reps = std::max(1, nblocks(h->N, 32 * 2048));  // <= ~2048 + ~500 partials per array for fc_final
   const int g_rows = nblocks(h->N, 32 * reps), g_cells = (compute_energy && ncl > 0) ? nblocks(ncl, 32 * reps) : 0;
   const int g = g_rows + g_cells;
   hipLaunchKernelGGL(fc_tail, dim3(g), dim3(256), 0, h->stream, h->N, 2 * h->nn, h->perm.p, h->buf.p + h->N, h->b.p,
