@@ -81,6 +81,7 @@ SIGNATURES: dict[str, list] = {
     "fc_set_energy_matrix": [_H, _ip, _ip, _dp],
     "fc_factor_plan": [_H, C.c_int32, _lp, C.c_int32, _lp, C.c_int64, C.c_int64, _lp, _lp, _lp, _lp, C.c_int64, _ip, C.c_int64, _lp, C.c_int32],
     "fc_refactor": [_H, C.c_int, C.c_void_p],
+    "fc_update_operator": [_H, C.c_int],
     "fc_set_front_shifts": [_H, C.c_int32, _lp, _dp],
     "fc_get_factor_values": [_H, C.c_int, C.c_int64, _dp],
     "fc_solver_set_blocks": [_H, C.c_int, C.c_int32, _lp, _ip, _ip, C.c_int64, _lp, _ip, _ip, _ip, _ip, _ip, _ip, C.c_int64, C.c_int64],

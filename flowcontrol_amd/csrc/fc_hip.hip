@@ -155,6 +155,7 @@ struct fc_ctx {
   bool have_mp = false;
   // solver options
   int method = FC_METHOD_REFINE, max_iter = 1, check_residual = 1;
+  DevBuf<double> kry;  // BiCGStab work vectors (8 N), allocated on first use
   double rtol = 1e-10;
   // state + work
   DevBuf<double> u_n, u_nn, p_n, up;
@@ -665,6 +666,7 @@ int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, 
                  double seq = 0.0) {
   OrderSys& S = h->sys[order_slot];
   if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this order");
+  if (h->method != FC_METHOD_REFINE) return fail(FC_ERR_INVALID, "time steps use the factor sweeps directly: set FC_METHOD_REFINE");
   if (compute_energy && !h->partitioned && !h->have_mp) return fail(FC_ERR_NOT_READY, "fc_set_energy_matrix not called");
   FCCHK(enqueue_rhs(h, order_slot, d_uctrl, d_uforce));
   const double *x = nullptr, *dx = nullptr;
@@ -1508,6 +1510,20 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
   return FC_OK;
 }
 
+int fc_update_operator(fc_handle h, int slot) {
+  if (!h || slot < 0 || slot > 1) return fail(FC_ERR_INVALID, "fc_update_operator: bad argument");
+  if (!h->have_plan) return fail(FC_ERR_NOT_READY, "fc_factor_plan not called");
+  OrderSys& S = h->sys[slot];
+  if (!S.structured) return fail(FC_ERR_NOT_READY, "fc_solver_setup (structure) must be called first");
+  if ((int64_t)h->pap_src.n != S.Ap_nnz) return fail(FC_ERR_INVALID, "fc_update_operator: plan and solver structure disagree");
+  HIPCHK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(fc_gather64, dim3(nblocks(S.Ap_nnz, 256)), dim3(256), 0, h->stream, S.Ap_nnz, h->pap_src.p, h->vals[slot].p, S.Ap_val.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  S.ready = true;  // the factors of the earlier operator stay: a preconditioner for FC_METHOD_BICGSTAB
+  return FC_OK;
+}
+
 int fc_get_factor_values(fc_handle h, int slot, int64_t n, double* out) {
   if (!h || slot < 0 || slot > 1 || !out) return fail(FC_ERR_INVALID, "fc_get_factor_values: bad argument");
   OrderSys& S = h->sys[slot];
@@ -1563,7 +1579,10 @@ int fc_set_energy_matrix(fc_handle h, const int32_t* rowptr, const int32_t* col,
 
 int fc_set_solver_options(fc_handle h, int method, int max_iter, double rtol, int check_residual) {
   if (!h || max_iter < 0 || max_iter > 1000) return fail(FC_ERR_INVALID, "fc_set_solver_options: bad argument");
-  if (method != FC_METHOD_REFINE) return fail(FC_ERR_INVALID, "fc_set_solver_options: method not available in this build");
+  if (method != FC_METHOD_REFINE && method != FC_METHOD_BICGSTAB)
+    return fail(FC_ERR_INVALID, "fc_set_solver_options: method not available in this build (REFINE, BICGSTAB)");
+  if (method == FC_METHOD_BICGSTAB && (max_iter < 1 || !(rtol > 0.0)))
+    return fail(FC_ERR_INVALID, "fc_set_solver_options: BiCGStab needs max_iter >= 1 and rtol > 0");
   h->method = method;
   h->max_iter = max_iter;
   h->rtol = rtol;
@@ -1799,6 +1818,95 @@ int fc_assemble_rhs(fc_handle h, int order_slot, const double* u_ctrl, double* b
   return FC_OK;
 }
 
+// Right-preconditioned BiCGStab on the permuted system A_p x = b_p, M^-1 = the factor sweeps of the slot
+// (exact factors: one iteration; factors of an EARLIER operator — fc_update_operator without
+// fc_refactor — : a few).  b_p in h->b on entry, x_p in kry[0..N) on exit.  Scalars come back to the
+// host once per dot pair; fixed reduction order.  iters/relres report what happened.
+int bicgstab_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
+  const int N = h->N, g = nblocks(N, 256), gd = std::min(g, 512);
+  if (h->kry.n != 8 * (size_t)N) FCCHK(h->kry.alloc(8 * (size_t)N));
+  double *x = h->kry.p, *r = x + N, *rh = r + N, *p = rh + N, *v = p + N, *s = v + N, *t = s + N, *ph = t + N;
+  double* sh = h->tmpN2.p;
+  const double mean = (double)S.Ap_nnz / std::max(1, N);
+  auto dots = [&](const double* a, const double* b_, const double* c, const double* d, double* out2) -> int {
+    hipLaunchKernelGGL(fc_dots2, dim3(gd), dim3(256), 0, h->stream, N, a, b_, c, d, h->partial.p);
+    hipLaunchKernelGGL(fc_reduce_final, dim3(2), dim3(256), 0, h->stream, gd, h->partial.p, 1.0, h->scal.p + 4);
+    HIPCHK(hipMemcpyAsync(out2, h->scal.p + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return FC_OK;
+  };
+  auto lin3 = [&](double* out, double c0, const double* v0, double c1, const double* v1, double c2, const double* v2) {
+    hipLaunchKernelGGL(fc_lin3, dim3(g), dim3(256), 0, h->stream, N, out, c0, v0, c1, v1, c2, v2);
+  };
+  auto precond = [&](const double* in, double* out) -> int {  // out = M^-1 in
+    hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, in, h->buf.p);
+    FCCHK(apply_factors(h, S));
+    hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->buf.p + N, out);
+    return FC_OK;
+  };
+  auto matvec = [&](const double* in, double* out) -> int {
+    const int nb = launch_spmv<0>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, in, nullptr, out, nullptr, nullptr);
+    return nb < 0 ? nb : FC_OK;
+  };
+  HIPCHK(hipMemsetAsync(x, 0, (size_t)N * sizeof(double), h->stream));
+  hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, r);
+  hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, rh);
+  double d2[2];
+  FCCHK(dots(r, r, rh, r, d2));
+  const double bnorm = std::sqrt(d2[0]);
+  *iters = 0;
+  *relres = 0.0;
+  if (!(bnorm > 0.0)) return FC_OK;  // b = 0 -> x = 0
+  double rho = d2[1], rho_old = 1.0, alpha = 1.0, omega = 1.0, rnorm = bnorm;
+  for (int it = 1; it <= h->max_iter; ++it) {
+    if (!std::isfinite(rho) || std::fabs(rho) < 1e-300 * bnorm * bnorm) return fail(FC_ERR_NOT_CONVERGED, "BiCGStab breakdown (rho = 0)");
+    if (it == 1) {
+      hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, r, p);
+    } else {
+      const double beta = (rho / rho_old) * (alpha / omega);
+      lin3(p, 1.0, r, beta, p, -beta * omega, v);
+    }
+    FCCHK(precond(p, ph));
+    FCCHK(matvec(ph, v));
+    FCCHK(dots(rh, v, rh, v, d2));
+    if (!std::isfinite(d2[0]) || d2[0] == 0.0) return fail(FC_ERR_NOT_CONVERGED, "BiCGStab breakdown (r^.v = 0)");
+    alpha = rho / d2[0];
+    lin3(s, 1.0, r, -alpha, v, 0.0, nullptr);
+    FCCHK(dots(s, s, s, s, d2));
+    *iters = it;
+    if (std::sqrt(d2[0]) <= h->rtol * bnorm) {
+      lin3(x, 1.0, x, alpha, ph, 0.0, nullptr);
+      rnorm = std::sqrt(d2[0]);
+      break;
+    }
+    FCCHK(precond(s, sh));
+    FCCHK(matvec(sh, t));
+    FCCHK(dots(t, s, t, t, d2));
+    if (!std::isfinite(d2[1]) || d2[1] == 0.0) return fail(FC_ERR_NOT_CONVERGED, "BiCGStab breakdown (t.t = 0)");
+    omega = d2[0] / d2[1];
+    lin3(x, 1.0, x, alpha, ph, omega, sh);
+    lin3(r, 1.0, s, -omega, t, 0.0, nullptr);
+    FCCHK(dots(r, r, rh, r, d2));
+    rnorm = std::sqrt(d2[0]);
+    rho_old = rho;
+    rho = d2[1];
+    if (rnorm <= h->rtol * bnorm) break;
+    if (omega == 0.0) return fail(FC_ERR_NOT_CONVERGED, "BiCGStab breakdown (omega = 0)");
+    if (it == h->max_iter) {
+      *relres = rnorm / bnorm;
+      return fail(FC_ERR_NOT_CONVERGED, "BiCGStab: residual " + std::to_string(rnorm / bnorm) + " after " + std::to_string(it) +
+                                            " iterations (rtol " + std::to_string(h->rtol) + ")");
+    }
+  }
+  // report the TRUE residual of the returned x
+  FCCHK(matvec(x, t));
+  lin3(t, 1.0, h->b.p, -1.0, t, 0.0, nullptr);
+  FCCHK(dots(t, t, t, t, d2));
+  *relres = std::sqrt(d2[0]) / bnorm;
+  HIPCHK(hipGetLastError());
+  return FC_OK;
+}
+
 int fc_solve(fc_handle h, int slot, const double* b, double* x, double* info_out) {
   if (!h || slot < 0 || slot > 1 || !b || !x) return fail(FC_ERR_INVALID, "fc_solve: bad argument");
   OrderSys& S = h->sys[slot];
@@ -1808,6 +1916,23 @@ int fc_solve(fc_handle h, int slot, const double* b, double* x, double* info_out
   HIPCHK(hipMemcpyAsync(h->tmpN.p, b, (size_t)N * sizeof(double), hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(fc_gather_perm, dim3(g), dim3(256), 0, h->stream, N, h->perm.p, h->tmpN.p, h->b.p);
   hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, h->buf.p);
+  if (h->method == FC_METHOD_BICGSTAB) {
+    if (h->partitioned) return fail(FC_ERR_INVALID, "fc_solve: BiCGStab is not available on a partitioned handle");
+    int iters = 0;
+    double relres = 0.0;
+    const int code = bicgstab_permuted(h, S, &iters, &relres);
+    if (info_out) {
+      info_out[0] = iters;
+      info_out[1] = relres;
+      info_out[2] = 0.0;
+      info_out[3] = 0.0;
+    }
+    if (code != FC_OK) return code;
+    hipLaunchKernelGGL(fc_scatter_perm, dim3(g), dim3(256), 0, h->stream, N, h->perm.p, h->kry.p, (const double*)nullptr, h->tmpN2.p);
+    HIPCHK(hipMemcpyAsync(x, h->tmpN2.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return FC_OK;
+  }
   const double *xs = nullptr, *dx = nullptr;
   int nrp = 0;
   FCCHK(solve_permuted(h, S, &xs, &dx, &nrp));

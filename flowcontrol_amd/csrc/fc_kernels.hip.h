@@ -710,6 +710,43 @@ __global__ void fc_scatter_perm(int n, const int* __restrict__ perm, const doubl
   if (i < n) dst[perm[i]] = add ? src[i] + add[i] : src[i];
 }
 
+// Krylov building blocks (fc_solve with FC_METHOD_BICGSTAB): two dot products per pass with a fixed
+// workgroup -> partial -> fc_reduce_final order (reproducible), and a three-term linear combination.
+__global__ __launch_bounds__(256) void fc_dots2(int n, const double* __restrict__ a, const double* __restrict__ b,
+                                                const double* __restrict__ c, const double* __restrict__ d,
+                                                double* __restrict__ partial) {
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    s0 += a[i] * b[i];
+    s1 += c[i] * d[i];
+  }
+  __shared__ double r0[256], r1[256];
+  r0[threadIdx.x] = s0;
+  r1[threadIdx.x] = s1;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) {
+      r0[threadIdx.x] += r0[threadIdx.x + st];
+      r1[threadIdx.x] += r1[threadIdx.x + st];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = r0[0];
+    partial[gridDim.x + blockIdx.x] = r1[0];
+  }
+}
+// out = c0 v0 + c1 v1 (+ c2 v2); out may alias any input
+__global__ void fc_lin3(int n, double* out, double c0, const double* v0, double c1, const double* v1, double c2,
+                        const double* v2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    double s = c0 * v0[i] + c1 * v1[i];
+    if (v2) s += c2 * v2[i];
+    out[i] = s;
+  }
+}
+
 // x (permuted) [+ dx] -> up (W layout); shift u_nn <- u_n <- u, p_n <- p; non-finite flag
 // (reference flowsolver.py:730-731,746-751,816-819).  Fused: per-row share of the perturbation
 // energy 1/2 u^T M u (flowsolver.py:827-829) with the velocity mass matrix in permuted numbering

@@ -309,7 +309,7 @@ class DeviceSolver:
                 self._probe[2 * self.nn :] = 0.0  # compatible with the constant-pressure null space
         if self.world > 1 or getattr(self, "_force_comm", False):
             return ms.value  # a probe solve would be a collective; every step's residual is monitored instead
-        opts = getattr(self, "_solver_opts", (0, True))
+        opts = getattr(self, "_solver_opts", (0, True, "refine", 1e-10))
         check(self.lib.fc_set_solver_options(self._h, _lib.METHOD_REFINE, 0, 1e-10, 1))
         _, info = self.solve(slot, self._probe)
         self.set_solver_options(*opts)
@@ -324,9 +324,20 @@ class DeviceSolver:
         check(self.lib.fc_get_factor_values(self._h, slot, n, out))
         return out
 
-    def set_solver_options(self, refine: int = 0, check_residual: bool = True) -> None:
-        self._solver_opts = (int(refine), bool(check_residual))
-        check(self.lib.fc_set_solver_options(self._h, _lib.METHOD_REFINE, int(refine), 1e-10, int(check_residual)))
+    def set_solver_options(self, refine: int = 0, check_residual: bool = True, method: str = "refine", rtol: float = 1e-10) -> None:
+        """``method="refine"``: factor sweeps (+ ``refine`` iterative-refinement sweeps) — what the time steps use.
+        ``method="bicgstab"``: right-preconditioned BiCGStab (``refine`` = iteration cap, ``rtol`` = relative
+        residual target) with the slot's current factors as preconditioner; for :meth:`solve` only."""
+        self._solver_opts = (int(refine), bool(check_residual), method, float(rtol))
+        m = {"refine": _lib.METHOD_REFINE, "bicgstab": _lib.METHOD_BICGSTAB}[method]
+        check(self.lib.fc_set_solver_options(self._h, m, int(refine), float(rtol), int(check_residual)))
+
+    def update_operator(self, slot: int) -> None:
+        """The slot's matrix changed (assemble + apply_bc) but its factors are kept: refresh the permuted copy
+        only.  ``solve`` with ``method="bicgstab"`` then uses the old factors as preconditioner."""
+        if slot not in self._structured:
+            raise RuntimeError("setup_solver(slot) must run once before update_operator(slot)")
+        check(self.lib.fc_update_operator(self._h, slot))
 
     def _upload_energy_matrix(self) -> None:
         """(u, v) mass matrix in the permuted numbering for the fused energy evaluation."""

@@ -16,7 +16,7 @@ import numpy as np
 import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
-from . import ndsolver
+from . import _lib, ndsolver
 from ._lib import SLOT_BDF1, SLOT_MASS, SLOT_SCRATCH
 from .fem.boundary import combine_bcs, pressure_pin
 from .fem.spaces import Function
@@ -34,6 +34,13 @@ class SteadyStateSolver:
         self._perm = None
         self._bc_set = False
         self.solve_info = None
+        # linear solves of the iterations: factors are reused across iterations as BiCGStab preconditioner and
+        # renewed when an iteration needed more than `refactor_after` Krylov steps (0 in the list = direct solve)
+        self.lag_factors = True
+        self.krylov_max_iter, self.krylov_rtol, self.refactor_after = 40, 1e-12, 12
+        self.krylov_iterations: list[int] = []
+        self._factors_age: int | None = None
+        self._krylov_failures = 0
 
     # ── helpers ──────────────────────────────────────────────────────────────
     def _device(self):
@@ -84,7 +91,28 @@ class SteadyStateSolver:
             self._bc_set = True
         self._assemble_on_device(coeff, SLOT_BDF1)
         dev.apply_bc(SLOT_BDF1)
+        if self.lag_factors and self._factors_age is not None and self._krylov_failures < 2:
+            # keep the factors of an earlier iterate as preconditioner: BiCGStab on the new operator costs a few
+            # sweeps, a numeric factorisation tens of milliseconds (the reference refactorises every iteration)
+            dev.update_operator(SLOT_BDF1)
+            dev.set_solver_options(refine=self.krylov_max_iter, method="bicgstab", rtol=self.krylov_rtol)
+            try:
+                x, info = dev.solve(SLOT_BDF1, r)
+                self.solve_info = info
+                self.krylov_iterations.append(int(info[0]))
+                self._factors_age += 1
+                self._krylov_failures = 0
+                if info[0] > self.refactor_after:
+                    self._factors_age = None  # the iterate has moved too far: refactorise next time
+                return x
+            except _lib.FcError as err:
+                logger.info(f"BiCGStab with lagged factors gave up ({err}); refactorising")
+                self._krylov_failures += 1  # twice in a row (e.g. a singular enclosed-flow system near convergence): stop trying
+            finally:
+                dev.set_solver_options(0, True)
         dev.setup_solver(SLOT_BDF1, refine=2)  # numeric factorisation on the device (first call: + structure)
+        self._factors_age = 0
+        self.krylov_iterations.append(0)
         x, info = dev.solve(SLOT_BDF1, r)
         self.solve_info = info
         return x

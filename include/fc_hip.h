@@ -162,6 +162,11 @@ int fc_set_rhs_operator(fc_handle h, int slot, const int32_t* rowptr, const int3
  * empty): the matrix behind compute_perturbation_energy (flowsolver.py:827-829), used by the
  * fused step tail */
 int fc_set_energy_matrix(fc_handle h, const int32_t* rowptr, const int32_t* col, const double* val);
+/* the slot's matrix changed (fc_assemble_matrix + fc_apply_bc) but its factors are kept as they are: only the
+ * permuted copy that SpMV / residuals use is refreshed.  With FC_METHOD_BICGSTAB the old factors then act as
+ * preconditioner of the new operator (Picard / Newton iterations of steadystate.py:60-159 between two
+ * refactorisations; the reference re-factorises with MUMPS at every iteration). */
+int fc_update_operator(fc_handle h, int slot);
 int fc_set_solver_options(fc_handle h, int method, int max_iter, double rtol, int check_residual);
 
 /* ── state: FlowFieldCollection u_n, u_nn, p_n (flowfield.py:67-105; flowsolver.py:487-491) ─ */

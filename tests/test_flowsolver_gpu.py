@@ -341,3 +341,34 @@ def test_cylinder_1000_actuated_steps_vs_oracle(tmp_path_factory, golden_dir):
     assert _rel_l2(ts["dE"].to_numpy(), g["dE"]) < 1e-8
     assert np.isclose(fs.t, 5.0)
     fs.th.release_device()
+
+
+def test_steady_state_with_lagged_factors_matches_refactorising_every_iteration(tmp_path_factory):
+    """Base flow of the cylinder (Picard ×3 → Newton): the default keeps the factors of an earlier iterate as
+    BiCGStab preconditioner; refactorising at every iteration (what the reference does with MUMPS) must give
+    the same base flow, and the Krylov path must actually have been taken."""
+    import flowcontrol_amd.steadystate as ss_mod
+
+    flows, stats = [], []
+    for lag in (True, False):
+        fs = CylinderFlowSolver.make_default(Re=100, path_out=tmp_path_factory.mktemp(f"ss_lag{int(lag)}"), num_steps=1)
+        orig_init = ss_mod.SteadyStateSolver.__init__
+        created = []
+
+        def init(self, *a, _o=orig_init, _lag=lag, **k):
+            _o(self, *a, **k)
+            self.lag_factors = _lag
+            created.append(self)
+
+        ss_mod.SteadyStateSolver.__init__ = init
+        try:
+            fs.compute_steady_state(method="picard", max_iter=3, tol=1e-7, u_ctrl=[0.0, 0.0])
+            fs.compute_steady_state(method="newton", max_iter=25, u_ctrl=[0.0, 0.0], initial_guess=fs.fields.UP0)
+        finally:
+            ss_mod.SteadyStateSolver.__init__ = orig_init
+        flows.append(fs.fields.UP0.vector().get_local().copy())
+        stats.append([k for s in created for k in s.krylov_iterations])
+        fs.th.release_device()
+    assert _rel_l2(flows[0], flows[1]) < 1e-9
+    assert any(k > 0 for k in stats[0]) and all(k == 0 for k in stats[1])
+    assert np.isclose(flows[0][: flows[0].size * 2 // 3].max(), _U0_MAX_REF, rtol=1e-3)  # sanity: it is the cylinder base flow

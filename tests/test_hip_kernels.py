@@ -278,3 +278,46 @@ def test_host_factorisation_path_still_agrees(setup):
         dev.setup_solver(SLOT_BDF2, restructure=True)
     assert _rel(x_host, x_dev) < 1e-11
     assert info[1] < 1e-12
+
+
+def test_bicgstab_with_exact_and_lagged_factors(setup):
+    """Device BiCGStab (fc_solve, FC_METHOD_BICGSTAB), right-preconditioned by the factor sweeps: one
+    iteration with the operator's own factors; a handful with the factors of a different (earlier)
+    operator — fc_update_operator — and the same solution as a fresh factorisation."""
+    th, dev, d, O = setup
+    from flowcontrol_amd._lib import FcError
+    from flowcontrol_amd.device import SLOT_BDF2
+
+    dt, Re = 0.005, 100.0
+    dofs, prof = _bc_setup(th)
+    dev.set_bc(dofs, prof)
+    dev.set_time_scheme(dt, True)
+    U0 = _smooth_velocity(th)
+    dev.assemble_matrix(SLOT_BDF2, mass=1.5 / dt, nu=1.0 / Re, adv=U0, lin=U0)
+    dev.apply_bc(SLOT_BDF2)
+    dev.setup_solver(SLOT_BDF2)
+    b = np.random.default_rng(21).standard_normal(dev.N)
+    x_direct, _ = dev.solve(SLOT_BDF2, b)
+    try:
+        dev.set_solver_options(refine=20, method="bicgstab", rtol=1e-12)
+        x_k, info = dev.solve(SLOT_BDF2, b)
+        assert info[0] == 1 and info[1] < 1e-12  # exact preconditioner: one iteration
+        assert _rel(x_k, x_direct) < 1e-11
+        # a different operator (stronger, rotated advection; dt halved) behind the OLD factors
+        U1 = 1.6 * _smooth_velocity(th, 1.3)
+        dev.assemble_matrix(SLOT_BDF2, mass=3.0 / dt, nu=1.0 / Re, adv=U1, lin=U1)
+        dev.apply_bc(SLOT_BDF2)
+        dev.update_operator(SLOT_BDF2)
+        A1 = dev.matrix(SLOT_BDF2)
+        x_lag, info = dev.solve(SLOT_BDF2, b)
+        assert 1 < info[0] <= 20 and info[1] < 1e-11
+        assert np.linalg.norm(A1 @ x_lag - b) / np.linalg.norm(b) < 1e-11
+        # iteration cap too small -> loud failure
+        dev.set_solver_options(refine=1, method="bicgstab", rtol=1e-14)
+        with pytest.raises(FcError):
+            dev.solve(SLOT_BDF2, b)
+    finally:
+        dev.set_solver_options(0, True)
+    dev.setup_solver(SLOT_BDF2)  # fresh factors of the new operator: direct solve agrees with the Krylov one
+    x_new, _ = dev.solve(SLOT_BDF2, b)
+    assert _rel(x_lag, x_new) < 1e-10
