@@ -825,10 +825,10 @@ __device__ inline void fc_publish(const double* ysrc, int n_sens, double E, doub
   x ^= (unsigned long long)__double_as_longlong(E) ^ (unsigned long long)__double_as_longlong(r0) ^
        (unsigned long long)__double_as_longlong(r1) ^ (unsigned long long)__double_as_longlong(fl);
   if (seq_out) {
-    __threadfence_system();
+    // no fences: the host does not rely on the order in which these words arrive (it re-checks the
+    // checksum until it fits), and the end of the kernel makes all of them visible
     seq_out[1] = __longlong_as_double((long long)x);
     seq_out[0] = seq;
-    __threadfence_system();
   }
 }
 
