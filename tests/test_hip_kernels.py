@@ -321,3 +321,46 @@ def test_bicgstab_with_exact_and_lagged_factors(setup):
     dev.setup_solver(SLOT_BDF2)  # fresh factors of the new operator: direct solve agrees with the Krylov one
     x_new, _ = dev.solve(SLOT_BDF2, b)
     assert _rel(x_lag, x_new) < 1e-10
+
+
+def test_error_paths_of_the_factorisation_and_krylov_entry_points(golden_dir):
+    """Call-order and argument errors come back as status codes with a message, never as a crash."""
+    import ctypes as C
+
+    from flowcontrol_amd import _lib
+    from flowcontrol_amd._lib import FC_ERR_INVALID, FcError, check
+    from flowcontrol_amd.device import SLOT_BDF2, DeviceSolver
+
+    th = TaylorHood(Mesh.unit_square(6, 6))
+    dev = DeviceSolver(th, 0)
+    lib, h = dev.lib, dev._h
+    FC_ERR_NOT_READY = -5
+    assert lib.fc_refactor(h, SLOT_BDF2, None) == FC_ERR_NOT_READY  # no plan yet
+    assert lib.fc_update_operator(h, SLOT_BDF2) == FC_ERR_NOT_READY
+    assert lib.fc_set_front_shifts(h, 1, np.zeros(1, np.int64), np.ones(1)) == FC_ERR_NOT_READY
+    assert b"fc_factor_plan" in lib.fc_last_error()
+    assert lib.fc_set_solver_options(h, _lib.METHOD_BICGSTAB, 0, 1e-10, 1) == FC_ERR_INVALID  # needs >= 1 iteration
+    assert lib.fc_set_solver_options(h, _lib.METHOD_GMRES, 5, 1e-10, 1) == FC_ERR_INVALID  # not built
+    assert lib.fc_refactor(h, 7, None) == FC_ERR_INVALID
+    # a working system, then misuse
+    dofs, prof = _bc_setup(th)
+    dev.set_bc(dofs, prof)
+    dev.set_time_scheme(0.01, True)
+    dev.assemble_matrix(SLOT_BDF2, mass=150.0, nu=0.01)
+    dev.apply_bc(SLOT_BDF2)
+    dev.setup_solver(SLOT_BDF2)
+    assert lib.fc_set_front_shifts(h, 1, np.array([1 << 40], dtype=np.int64), np.ones(1)) == FC_ERR_INVALID
+    with pytest.raises(ValueError):
+        dev.set_pressure_pin(3)  # a velocity dof
+    dev.set_state(np.zeros(2 * th.nn), np.zeros(2 * th.nn), np.zeros(th.nv))
+    dev.set_sensors([th.point_eval_row((0.3, 0.4), 0)])
+    dev.set_solver_options(refine=5, method="bicgstab")
+    with pytest.raises(FcError, match="FC_METHOD_REFINE"):
+        dev.step(SLOT_BDF2, np.zeros(prof.shape[1]))
+    dev.set_solver_options(0, True)
+    y, dE, info = dev.step(SLOT_BDF2, np.zeros(prof.shape[1]))
+    assert np.isfinite(y).all() and info[1] < 1e-10
+    n = C.c_int64(dev._n_factor_values + 1)
+    assert lib.fc_get_factor_values(h, SLOT_BDF2, n, np.empty(n.value)) == FC_ERR_INVALID
+    check(lib.fc_refactor(h, SLOT_BDF2, None))
+    dev.close()
