@@ -372,3 +372,26 @@ def test_steady_state_with_lagged_factors_matches_refactorising_every_iteration(
     assert _rel_l2(flows[0], flows[1]) < 1e-9
     assert any(k > 0 for k in stats[0]) and all(k == 0 for k in stats[1])
     assert np.isclose(flows[0][: flows[0].size * 2 // 3].max(), _U0_MAX_REF, rtol=1e-3)  # sanity: it is the cylinder base flow
+
+
+@pytest.mark.parametrize("case", ["cavity_coarse", "pinball_middle"])
+def test_device_base_flow_matches_golden(case, tmp_path_factory, golden_dir):
+    """The reference's base-flow recipes (cavity Re=7500: Picard ×10 → Newton; pinball Re=30: Picard ×15 →
+    Newton), every iteration on the device (assembly, factorisation or BiCGStab on lagged factors, sweeps),
+    against the oracle's golden base flows — which carry the reference's U0 constants to 1e-13."""
+    if case == "cavity_coarse":
+        from flowcontrol_amd.examples.cavity.cavityflowsolver import CavityFlowSolver
+
+        fs, n_act, picard = CavityFlowSolver.make_default(Re=7500, path_out=tmp_path_factory.mktemp(case)), 1, 10
+    else:
+        from flowcontrol_amd.actuator import CYLINDER_ACTUATION_MODE
+        from flowcontrol_amd.examples.pinball.pinballflowsolver import PinballFlowSolver
+
+        fs, n_act, picard = PinballFlowSolver.make_default(Re=30, mode_actuation=CYLINDER_ACTUATION_MODE.SUCTION,
+                                                           path_out=tmp_path_factory.mktemp(case)), 3, 15
+    g = np.load(golden_dir / f"{case}.npz")
+    fs.compute_steady_state(method="picard", max_iter=picard, tol=1e-7, u_ctrl=[0.0] * n_act)
+    fs.compute_steady_state(method="newton", max_iter=10, u_ctrl=[0.0] * n_act, initial_guess=fs.fields.UP0)
+    nv2 = 2 * fs.th.nn
+    assert _rel_l2(fs.fields.UP0.vector().get_local()[:nv2], g["UP0"][:nv2]) < 1e-10
+    fs.th.release_device()
