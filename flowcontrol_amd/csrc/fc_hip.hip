@@ -231,10 +231,19 @@ Rccl g_rccl;
 
 int rccl_load() {
   if (g_rccl.lib) return FC_OK;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  // first the copy that sits next to the HIP runtime this library is bound to (PyTorch ships its own set and
+  // has it loaded already), then by soname, then the system one
+  std::string dir;
+  Dl_info di;
+  if (dladdr((void*)&hipStreamSynchronize, &di) && di.dli_fname) {
+    dir = di.dli_fname;
+    const size_t cut = dir.rfind('/');
+    dir = cut == std::string::npos ? std::string() : dir.substr(0, cut + 1);
+  }
+  const std::string names[] = {dir + "librccl.so", dir + "librccl.so.1", "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* lib = nullptr;
-  for (const char* n : names) {
-    lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+  for (const std::string& n : names) {
+    lib = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL);
     if (lib) break;
   }
   if (!lib) return fail(FC_ERR_HIP, std::string("cannot load RCCL: ") + dlerror());
