@@ -178,10 +178,10 @@ class DeviceSolver:
         per rank); ``refine`` iterative-refinement sweeps per solve (the fp64 selected inverse is
         accurate to round-off on its own, so 0 + residual monitoring is the default).
 
-        On a single-GPU handle the host only lays out the structure (once per tree); the numbers are
-        computed on the device (``fc_refactor``), and a later call for the same slot is just that numeric
-        phase (``restructure=True`` uploads the launch geometry again).  Partitioned handles and
-        ``FC_HOST_FACTOR=1`` use the numpy multifrontal of :mod:`ndsolver`.
+        The host only lays out the structure (once per tree); the numbers are computed on the device
+        (``fc_refactor``; on a partitioned handle every rank repeats it for the whole tree), and a later call
+        for the same slot is just that numeric phase (``restructure=True`` uploads the launch geometry
+        again).  ``FC_HOST_FACTOR=1`` uses the numpy multifrontal of :mod:`ndsolver` instead.
         """
         if self.tree is None:
             th = self.th
