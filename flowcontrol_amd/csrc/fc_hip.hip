@@ -1730,7 +1730,7 @@ int fc_step_phase(fc_handle h, int order_slot, int phase, const double* u_ctrl, 
   if (S.ar_stage < 0 || !root_io) return fail(FC_ERR_INVALID, "fc_step_phase: no exchange stage configured");
   if (h->max_iter > 0) return fail(FC_ERR_INVALID, "iterative refinement is not available on a partitioned handle");
   HIPCHK(hipSetDevice(h->device));
-  const int N = h->N, g = nblocks(N, 256);
+  const int N = h->N;
   double* root = h->buf.p + S.ar_row0;
   if (phase == 0) {
     if (h->n_act > 0 && !u_ctrl) return fail(FC_ERR_INVALID, "fc_step_phase: u_ctrl is null");

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void fc_spmv_csr(int nrows, const int* __restr
     redb[threadIdx.x] = b2;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
-      if (threadIdx.x < st) {
+      if ((int)threadIdx.x < st) {
         red[threadIdx.x] += red[threadIdx.x + st];
         redb[threadIdx.x] += redb[threadIdx.x + st];
       }
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(256) void fc_dots2(int n, const double* __restrict_
   r1[threadIdx.x] = s1;
   __syncthreads();
   for (int st = 128; st > 0; st >>= 1) {
-    if (threadIdx.x < st) {
+    if ((int)threadIdx.x < st) {
       r0[threadIdx.x] += r0[threadIdx.x + st];
       r1[threadIdx.x] += r1[threadIdx.x + st];
     }
@@ -795,7 +795,7 @@ __global__ __launch_bounds__(256) void fc_finish(int N, int nn2, const int* __re
     red[threadIdx.x] = e;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
-      if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+      if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
       __syncthreads();
     }
     if (threadIdx.x == 0) e_partial[blockIdx.x] = red[0];
@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(256) void fc_energy_elem(int nc, int nn, const int*
   red[threadIdx.x] = e;
   __syncthreads();
   for (int st = 128; st > 0; st >>= 1) {
-    if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
     __syncthreads();
   }
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(256) void fc_energy_partial(int nrows, const int* _
   red[threadIdx.x] = s;
   __syncthreads();
   for (int st = 128; st > 0; st >>= 1) {
-    if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
     __syncthreads();
   }
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
@@ -1113,7 +1113,7 @@ __global__ void fc_reduce_final(int n, const double* __restrict__ partial, doubl
   red[threadIdx.x] = s;
   __syncthreads();
   for (int st = 128; st > 0; st >>= 1) {
-    if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
     __syncthreads();
   }
   if (threadIdx.x == 0) out[0] = scale * red[0];

@@ -14,7 +14,6 @@ import json
 import logging
 from pathlib import Path
 
-import numpy as np
 import pandas as pd
 
 from .fem.spaces import Function

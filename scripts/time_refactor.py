@@ -1,5 +1,5 @@
 """Setup cost on the GPU box: structure (host) + numeric factorisation (device) vs the numpy multifrontal."""
-import os, sys, time
+import sys, time
 from pathlib import Path
 import numpy as np
 ROOT = Path(__file__).resolve().parents[1]
@@ -14,7 +14,7 @@ t0 = time.time()
 fs.step(np.zeros(2))
 print(f"first step (assemble + factorise both systems) {time.time()-t0:.2f}s", flush=True)
 dev = fs.th.device()
-from flowcontrol_amd._lib import SLOT_BDF2, SLOT_BDF1
+from flowcontrol_amd._lib import SLOT_BDF2
 for i in range(3):
     t0 = time.time()
     ms = dev.refactor(SLOT_BDF2)
