@@ -49,23 +49,9 @@ REFINE = 0  # --refine K: BASELINE config 4 (O1 red-refined K times, cylinder mi
 
 
 def refined_mesh_file(levels: int) -> Path:
-    """Write the refined O1 mesh next to the temp outputs and return its path (.npz)."""
-    from flowcontrol_amd.fem.mesh import read_xdmf_mesh
+    from flowcontrol_amd.examples.cylinder.cylinderflowsolver import refined_cylinder_mesh
 
-    m = read_xdmf_mesh(GOLDEN / "meshes" / "O1.npz", reorder=False)
-
-    def project(mid, is_boundary):
-        r = np.hypot(mid[:, 0], mid[:, 1])
-        on_cyl = is_boundary & (r < 0.6)
-        out = mid.copy()
-        out[on_cyl] *= (0.5 / r[on_cyl])[:, None]
-        return out
-
-    for _ in range(levels):
-        m = m.refine(project)
-    path = Path(tempfile.mkdtemp(prefix="fc_mesh_")) / f"O1_refined{levels}.npz"
-    np.savez(path, coords=m.coords, cells=m.cells)
-    return path
+    return refined_cylinder_mesh(levels)
 
 
 def build_solver(device: int, distributed: bool = False):

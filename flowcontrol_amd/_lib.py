@@ -17,7 +17,7 @@ import numpy as np
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = Path(os.environ["FC_LIB_PATH"]) if os.environ.get("FC_LIB_PATH") else CSRC / "libfc_hip.so"  # FC_LIB_PATH: tuning builds
-SOURCES = [CSRC / "fc_hip.hip", CSRC / "fc_kernels.hip.h", CSRC.parent.parent / "include" / "fc_hip.h"]
+SOURCES = [CSRC / "fc_hip.hip", *sorted(CSRC.glob("*.hip.h")), CSRC.parent.parent / "include" / "fc_hip.h"]
 
 FC_OK = 0
 FC_ERR_INVALID, FC_ERR_HIP, FC_ERR_DIVERGED, FC_ERR_NOT_CONVERGED, FC_ERR_NOT_READY = -1, -2, -3, -4, -5
@@ -105,6 +105,11 @@ SIGNATURES: dict[str, list] = {
     "fc_set_timing": [_H, C.c_int],
     "fc_get_timing": [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "fc_algorithmic_bytes": [_H, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    "fc_solver_set_dag": [_H, C.c_int, C.c_int32, _lp, np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS"), _ip, _ip, _ip],
+    "fc_get_dag_info": [_H, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+    "fc_set_dag": [_H, C.c_int],
+    "fc_debug_inject_dag_failure": [_H, C.c_int],
+    "fc_debug_trace_apply": [_H, C.c_int, C.c_int32, _lp, _ip, _ip],
 }
 
 _lib = None
@@ -141,7 +146,9 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         try:
             build()
         except FcError:
-            if not LIB_PATH.exists():
+            # a failed rebuild may only be ignored when the existing binary is not older than any source:
+            # testing a stale library silently would void every parity claim
+            if not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < max(p.stat().st_mtime for p in SOURCES):
                 raise
     if not LIB_PATH.exists():
         raise FcError(FC_ERR_HIP, f"{LIB_PATH} is missing: the HIP extension is required (no CPU fallback)")

@@ -1,0 +1,301 @@
+// One-launch factor apply: the level sweeps of fc_kernels.hip.h as ONE grid in which every workgroup is a
+// task of the elimination tree and waits for the tasks it depends on through per-node arrival counters
+// (instead of a kernel boundary per tree level).  Included by fc_hip.hip only.
+//
+//   up task    rows of tree node t (segment lists, y[r] += sum -L . y_deeper): needs the up tasks of t's
+//              children (by induction: of every descendant) to have arrived
+//   down task  a tile of rows of node t ([D^-1 | -U] block x shared operand): needs the down tasks of t's
+//              parent (by induction: of every ancestor); the root needs its own up tasks
+//
+// Tasks are numbered in topological order (level by level) and blockIdx.x = task number, so a task's
+// dependencies have smaller block indices: they were handed to the dispatcher earlier and are resident or done.
+// Every wait is nevertheless BOUNDED: a workgroup that gives up raises `err`, the step's tail then leaves the
+// state untouched and the host redoes the step with the level launches (fc_hip.hip: dag_failed).
+//
+// Why this is faster than a launch per level (MI355X_MICROARCH.md price list): the factor VALUES of a task do
+// not depend on any other task, so every workgroup issues its value loads (a whole tile, <= 24 fp64 per lane)
+// BEFORE it waits; while one level's dependencies resolve, the value stream of the next levels is already in
+// flight, and the wide levels of different sub-trees overlap freely.  A level costs one point-to-point hand-off
+// instead of a launch boundary + a cold dependent-load chain.
+//
+// Hand-off protocol (cdna_hip_programming.md Guideline 16, form R1 with write-through payload): every word of
+// the work buffer `buf` is stored with sc1 stores and loaded with sc1 loads inside this kernel (agent-scope
+// relaxed atomics on 8-byte words: global_store/load_dwordx2 ... sc1, never through L1); a producer drains
+// its stores (s_waitcnt vmcnt(0) in every wave), the workgroup meets at a barrier, ONE lane adds 1 to its
+// node's counter (agent-scope atomic); a consumer polls the counters with ONE wave (relaxed agent-scope loads),
+// the workgroup meets at a barrier, then every wave loads.  Counters are never reset: the target of the k-th
+// apply is k x (tasks of the node), compared modulo 2^32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct __attribute__((aligned(16))) FcDagTask {
+  int kind;   // 0: up rows (segment lists, accumulate into y); 1: down tile (block, assign into x)
+  int a;      // kind 0: index of the first row in seg_ptr; kind 1: index of the tile in the DAG block array
+  int nrows;  // kind 0: rows of this task
+  int dest0;  // kind 0: buf index of the first row
+  int dep0, ndep;  // dependency records
+  int sig;         // counter word this task adds 1 to when it is done
+  int geom;        // kind 0: lanes << 16 | sub; kind 1: lanes per row
+};
+struct __attribute__((aligned(16))) FcDagDep {
+  int base;        // first counter word
+  int nshard;      // words base, base + 32, ... (one 128-B line each)
+  unsigned target; // arrivals per apply
+  int pad;
+};
+
+#define FC_DAG_SHARD_STRIDE 32  // counter words per 128-byte line
+#define FC_DAG_MAX_SHARDS 16
+#define FC_DAG_PV 24            // fp64 values a lane holds in registers while it waits
+#define FC_DAG_TILE 2048        // operand entries staged in LDS at a time
+#define FC_DAG_SPIN_LIMIT 200000
+
+typedef unsigned long long fc_u64;
+
+__device__ __forceinline__ double fc_ld_sc1(const double* p) {
+  const fc_u64 v = __hip_atomic_load(reinterpret_cast<const fc_u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __longlong_as_double((long long)v);
+}
+__device__ __forceinline__ void fc_st_sc1(double* p, double x) {
+  __hip_atomic_store(reinterpret_cast<fc_u64*>(p), (fc_u64)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// wave 0 only: wait until every dependency's counters have reached  epoch x target  (mod 2^32).
+// 16 lanes per dependency (one per shard), four dependencies per pass.
+__device__ __forceinline__ bool fc_dag_wait(const FcDagDep* __restrict__ deps, int dep0, int ndep, const unsigned* cnt,
+                                            unsigned epoch, int* err) {
+  const int lane = threadIdx.x & 63;
+  const int grp = lane >> 4, s = lane & 15;
+  for (int d0 = 0; d0 < ndep; d0 += 4) {
+    const int d = d0 + grp;
+    const bool has = d < ndep;
+    FcDagDep dp = {0, 0, 0u, 0};
+    if (has) dp = deps[dep0 + d];
+    const bool mine = has && s < dp.nshard;
+    const unsigned* p = cnt + dp.base + (mine ? s : 0) * FC_DAG_SHARD_STRIDE;
+    const unsigned want = dp.target * epoch;
+    int spin = 0;
+    for (;;) {
+      unsigned v = mine ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      v += __shfl_xor(v, 8, 16);
+      v += __shfl_xor(v, 4, 16);
+      v += __shfl_xor(v, 2, 16);
+      v += __shfl_xor(v, 1, 16);
+      const bool ok = !has || v == want;
+      if (__all(ok)) break;
+      if (++spin > FC_DAG_SPIN_LIMIT) {
+        if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+      if ((spin & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(256) void fc_nd_dag(const FcDagTask* __restrict__ tasks, const FcDagDep* __restrict__ deps,
+                                                 unsigned* cnt, unsigned epoch, int* err,
+                                                 const int64_t* __restrict__ seg_ptr, const FcSeg* __restrict__ seg,
+                                                 const FcBlk* __restrict__ blk, const int* __restrict__ idx,
+                                                 const double* __restrict__ val, double* buf, int N, fc_u64* trace) {
+  // trace (diagnostic launches only, fc_debug_trace_apply): 100 MHz wall-clock stamps of thread 0 at
+  // entry / prefetch issued / dependencies met / products done / stores drained
+  __shared__ double xs[FC_DAG_TILE];
+  __shared__ double part[4];
+  __shared__ int go;
+  const FcDagTask t = tasks[blockIdx.x];
+  const int tid = threadIdx.x;
+  const bool waits = t.ndep > 0;
+#define FC_STAMP(k) \
+  if (trace && tid == 0) trace[(size_t)blockIdx.x * 8 + (k)] = wall_clock64()
+  FC_STAMP(0);
+
+  if (t.kind == 1) {
+    // ── down tile: up to 256/LPR rows of one node, operand [ y[i0..i0+ni) | x[idx[..nb)] ] shared by all rows ──
+    const FcBlk b = blk[t.a];
+    const int LPR = t.geom;
+    const int slot = tid / LPR, l = tid % LPR;
+    const int wd = b.ni + b.nb;
+    const bool rowok = slot < b.nrows;
+    const double* __restrict__ vrow = val + b.val + (long long)(rowok ? slot : 0) * wd;
+    // 1. the whole tile (or its first FC_DAG_PV x LPR columns) into registers: depends on nothing.
+    //    Every load is UNCONDITIONAL with a clamped address (a select around a load makes hipcc branch around it and
+    //    wait for it at once: 24 dependent round trips); columns beyond the row are masked when they are used.
+    double pv[FC_DAG_PV];
+#pragma unroll
+    for (int u = 0; u < FC_DAG_PV; ++u) {
+      const int col = l + u * LPR;
+      pv[u] = vrow[col < wd ? col : 0];
+    }
+    // the index list of the coupling part of the first operand tile as well (clamped the same way)
+    constexpr int NG = FC_DAG_TILE / 256;
+    int pidx[NG];
+    const int nbm1 = b.nb > 0 ? b.nb - 1 : 0;
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+      int o = tid + 256 * k - b.ni;
+      o = o < 0 ? 0 : (o > nbm1 ? nbm1 : o);
+      pidx[k] = idx[b.idx + o];
+    }
+    FC_STAMP(1);
+    // 2. dependencies
+    if (waits) {
+      if (tid < 64) {
+        const bool ok = fc_dag_wait(deps, t.dep0, t.ndep, cnt, epoch, err);
+        if (tid == 0) go = ok ? 1 : 0;
+      }
+      __syncthreads();
+      if (!go) return;
+    }
+    FC_STAMP(2);
+    // 3. operand -> LDS (sc1 loads, all in flight together), products from registers, remainder columns streamed
+    double acc = 0.0;
+    const int npre = FC_DAG_PV * LPR;  // columns held in registers
+    const int wdm1 = wd - 1;
+    auto consume = [&](int t0, int tl) {
+      if (t0 < npre) {
+#pragma unroll
+        for (int u = 0; u < FC_DAG_PV; ++u) {
+          const int c = l + u * LPR - t0;
+          const bool in = c >= 0 && c < tl;
+          acc += (in ? pv[u] : 0.0) * xs[in ? c : 0];
+        }
+      }
+      int c0 = t0 > npre ? t0 : npre;
+      c0 += (l - (c0 % LPR) + LPR) % LPR;  // first column >= max(t0, npre) owned by this lane
+      for (int col = c0; col < t0 + tl; col += LPR) acc += vrow[col] * xs[col - t0];
+    };
+    {
+      // first operand tile: addresses from the prefetched index list, NG loads in flight per lane
+      const int tl = wd < FC_DAG_TILE ? wd : FC_DAG_TILE;
+      double ov[NG];
+#pragma unroll
+      for (int k = 0; k < NG; ++k) {
+        int col = tid + 256 * k;
+        col = col > wdm1 ? wdm1 : col;
+        ov[k] = fc_ld_sc1(buf + (col < b.ni ? b.i0 + col : pidx[k]));
+      }
+#pragma unroll
+      for (int k = 0; k < NG; ++k)
+        if (tid + 256 * k < tl) xs[tid + 256 * k] = ov[k];
+      __syncthreads();
+      consume(0, tl);
+    }
+    for (int t0 = FC_DAG_TILE; t0 < wd; t0 += FC_DAG_TILE) {  // fronts wider than one tile (large meshes, near the root)
+      const int tl = wd - t0 < FC_DAG_TILE ? wd - t0 : FC_DAG_TILE;
+      __syncthreads();
+      for (int j = tid; j < tl; j += 256) {
+        const int col = t0 + j;
+        xs[j] = fc_ld_sc1(buf + (col < b.ni ? b.i0 + col : idx[b.idx + (col - b.ni)]));
+      }
+      __syncthreads();
+      consume(t0, tl);
+    }
+    // 4. row sums: lanes of a row are consecutive; LPR <= 64: inside the wave, 256: through LDS
+    double s = acc;
+    const int w = LPR < 64 ? LPR : 64;
+    for (int off = w >> 1; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (LPR == 256) {
+      if ((tid & 63) == 0) part[tid >> 6] = s;
+      __syncthreads();
+      if (tid == 0 && rowok) fc_st_sc1(buf + N + b.row0, (part[0] + part[1]) + (part[2] + part[3]));
+    } else if (l == 0 && rowok) {
+      fc_st_sc1(buf + N + b.row0 + slot, s);
+    }
+  } else {
+    // ── up rows: segment lists (see fc_nd_sweep); the first trip of the first round of segments is loaded
+    //    before the wait ──
+    const int LANES = t.geom >> 16, SUB = t.geom & 0xffff;
+    const int SW = LANES < 64 ? LANES : 64;
+    const int G = LANES / SUB;
+    const int lane = tid % LANES, sl = tid % SW, g = lane / SUB, l2 = lane % SUB;
+    const int rloc = tid / LANES;
+    const bool rowok = rloc < t.nrows;
+    const int64_t q0 = rowok ? seg_ptr[t.a + rloc] : 0, q1 = rowok ? seg_ptr[t.a + rloc + 1] : 0;
+    FcSeg first = {0, 0, 0};
+    if (q0 + sl < q1) first = seg[q0 + sl];
+    double pv0 = 0.0, pv1 = 0.0, pv2 = 0.0, pv3 = 0.0;
+    {
+      const int cnt0 = (int)((q1 - q0) < SW ? (q1 - q0) : SW);
+      const int src = g < cnt0 ? (g % SW) : 0;
+      const long long vo = __shfl(first.val, src, SW);
+      int len = __shfl(first.len, src, SW);
+      if (g >= cnt0) len = 0;
+      const double* __restrict__ v = val + vo;
+      const int j0 = l2, j1 = j0 + SUB, j2 = j1 + SUB, j3 = j2 + SUB;
+      const double a0 = v[j0 < len ? j0 : 0], a1 = v[j1 < len ? j1 : 0], a2 = v[j2 < len ? j2 : 0], a3 = v[j3 < len ? j3 : 0];
+      pv0 = j0 < len ? a0 : 0.0;
+      pv1 = j1 < len ? a1 : 0.0;
+      pv2 = j2 < len ? a2 : 0.0;
+      pv3 = j3 < len ? a3 : 0.0;
+    }
+    FC_STAMP(1);
+    if (waits) {
+      if (tid < 64) {
+        const bool ok = fc_dag_wait(deps, t.dep0, t.ndep, cnt, epoch, err);
+        if (tid == 0) go = ok ? 1 : 0;
+      }
+      __syncthreads();
+      if (!go) return;
+    }
+    FC_STAMP(2);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int64_t qb = q0; qb < q1; qb += SW) {
+      FcSeg mine = first;
+      if (qb != q0) {
+        mine = FcSeg{0, 0, 0};
+        if (qb + sl < q1) mine = seg[qb + sl];
+      }
+      const int cntb = (int)((q1 - qb) < SW ? (q1 - qb) : SW);
+      for (int sbase = 0; sbase < cntb; sbase += G) {
+        const int sidx = sbase + g;
+        const int src = sidx < cntb ? (sidx % SW) : 0;
+        const long long vo = __shfl(mine.val, src, SW);
+        const int c = __shfl(mine.col, src, SW);
+        int len = __shfl(mine.len, src, SW);
+        if (sidx >= cntb) len = 0;
+        const double* __restrict__ v = val + vo;
+        const double* x = buf + c;  // up segments are contiguous slices of y (validated at setup)
+        const bool pre = qb == q0 && sbase == 0;
+        for (int base = 0; base < len; base += 4 * SUB) {
+          const int j0 = base + l2, j1 = j0 + SUB, j2 = j1 + SUB, j3 = j2 + SUB;
+          double v0, v1, v2, v3;
+          if (pre && base == 0) {
+            v0 = pv0, v1 = pv1, v2 = pv2, v3 = pv3;
+          } else {
+            const double a0 = v[j0 < len ? j0 : 0], a1 = v[j1 < len ? j1 : 0], a2 = v[j2 < len ? j2 : 0], a3 = v[j3 < len ? j3 : 0];
+            v0 = j0 < len ? a0 : 0.0, v1 = j1 < len ? a1 : 0.0, v2 = j2 < len ? a2 : 0.0, v3 = j3 < len ? a3 : 0.0;
+          }
+          const double x0 = fc_ld_sc1(x + (j0 < len ? j0 : 0)), x1 = fc_ld_sc1(x + (j1 < len ? j1 : 0));
+          const double x2 = fc_ld_sc1(x + (j2 < len ? j2 : 0)), x3 = fc_ld_sc1(x + (j3 < len ? j3 : 0));
+          s0 += v0 * x0;
+          s1 += v1 * x1;
+          s2 += v2 * x2;
+          s3 += v3 * x3;
+        }
+      }
+    }
+    double s = (s0 + s1) + (s2 + s3);
+    for (int off = SW >> 1; off > 0; off >>= 1) s += __shfl_down(s, off, SW);
+    if (LANES == 256) {
+      if (sl == 0) part[tid >> 6] = s;
+      __syncthreads();
+      if (tid == 0 && rowok) {
+        double* d = buf + t.dest0;
+        fc_st_sc1(d, fc_ld_sc1(d) + ((part[0] + part[1]) + (part[2] + part[3])));
+      }
+    } else if (rowok && lane == 0) {
+      double* d = buf + t.dest0 + rloc;
+      fc_st_sc1(d, fc_ld_sc1(d) + s);
+    }
+  }
+  // ── arrival: every wave drains its write-through stores, the workgroup meets, ONE lane signals ──
+  FC_STAMP(3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  FC_STAMP(4);
+  if (tid == 0) __hip_atomic_fetch_add(cnt + t.sig, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#undef FC_STAMP
+}

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "fc_kernels.hip.h"
+#include "fc_dag.hip.h"
 
 namespace {
 
@@ -84,6 +85,7 @@ struct Stage {
   int64_t blk_begin = 0;  // down stages: LDS-tiled block kernel (fc_nd_down_block) when blk_count > 0
   int blk_count = 0, blk_lpr = 64, blk_rps = 1;
   double bytes;  // algorithmic bytes of this launch
+  int dag_task0 = 0, dag_ntasks = 0;  // one-launch apply (fc_nd_dag): this stage's tasks
 };
 
 struct OrderSys {
@@ -103,6 +105,13 @@ struct OrderSys {
   std::vector<Stage> stages;
   double sweep_bytes = 0.0;
   int ar_stage = -1, ar_row0 = 0, ar_n = 0;  // all-reduce buf[ar_row0 .. +ar_n) after this stage
+  // one-launch apply (fc_solver_set_dag): tasks in topological order, dependency records, arrival counters
+  bool dag_ready = false;
+  DevBuf<FcDagTask> dag_tasks;
+  DevBuf<FcDagDep> dag_deps;
+  DevBuf<FcBlk> dag_blk;
+  DevBuf<unsigned> dag_cnt;
+  unsigned dag_epoch = 0;
   // optional explicit operator of the rhs (Crank-Nicolson): rows permuted, columns index u_n (W layout)
   DevBuf<int> c_rowptr, c_col;
   DevBuf<double> c_val;
@@ -184,6 +193,12 @@ struct fc_ctx {
   // element vectors of the NEXT step's right-hand side, enqueued behind a synchronous step while the host
   // is busy (they depend on the state only): slot whose coefficients they were computed with, or -1
   int pre_slot = -1;
+  // one-launch factor apply: [0] != 0 when a workgroup of fc_nd_dag gave up waiting, [1] = id of the first step that saw it
+  DevBuf<int> dag_err;
+  bool dag_enabled = false;  // FC_DAG=1 / fc_set_dag turn the one-launch apply on; a give-up turns it off again
+  int dag_failures = 0;
+  int dag_inject = -1;
+  DevBuf<fc_u64> dag_trace;  // fc_debug_trace_apply: 8 stamps per task of the traced apply  // test aid (fc_debug_inject_dag_failure): raise the give-up word behind the n-th apply from now
   // device-side numeric factorisation (fc_factor_plan / fc_refactor)
   struct PlanNode {
     int64_t front, voff;
@@ -480,8 +495,45 @@ int launch_sweep(fc_ctx* h, const OrderSys& S, const Stage& st) {
 }
 
 // x_p (in buf[N..2N)) = M^-1 rhs_p, rhs_p must already be in buf[0..N)
-int apply_factors(fc_ctx* h, const OrderSys& S, int first = 0, int last = -1) {
+// one-launch apply: the tasks of stages [first, last] as ONE grid whose workgroups wait on per-node
+// counters (fc_dag.hip.h); with an RCCL communicator the grid is cut at the exchange stage
+int apply_factors_dag(fc_ctx* h, OrderSys& S, int first, int last) {
+  if (first == 0) ++S.dag_epoch;  // a new apply (fc_step_phase resumes the same one with first > 0)
+  const bool cut = h->comm && S.ar_n > 0 && S.ar_stage >= first && S.ar_stage < last;
+  FCCHK(time_begin(h, 0, cut ? 2 : 1));
+  auto launch = [&](int s0, int s1) -> int {
+    const int t0 = S.stages[s0].dag_task0, t1 = S.stages[s1].dag_task0 + S.stages[s1].dag_ntasks;
+    if (t1 > t0)
+      hipLaunchKernelGGL(fc_nd_dag, dim3(t1 - t0), dim3(256), 0, h->stream, S.dag_tasks.p + t0, S.dag_deps.p, S.dag_cnt.p,
+                         S.dag_epoch, h->dag_err.p, S.seg_ptr.p, S.seg.p, S.dag_blk.p, S.f_idx.p, S.f_val.p, h->buf.p, h->N,
+                         h->dag_trace.p ? h->dag_trace.p + (size_t)t0 * 8 : nullptr);
+    HIPCHK(hipGetLastError());
+    return FC_OK;
+  };
+  if (cut) {
+    FCCHK(launch(first, S.ar_stage));
+    double* p = h->buf.p + S.ar_row0;
+    NCCLCHK(g_rccl.AllReduce(p, p, (size_t)S.ar_n, kNcclDouble, kNcclSum, h->comm, h->stream));
+    FCCHK(launch(S.ar_stage + 1, last));
+  } else {
+    FCCHK(launch(first, last));
+    if (h->comm && S.ar_n > 0 && S.ar_stage == last) {
+      double* p = h->buf.p + S.ar_row0;
+      NCCLCHK(g_rccl.AllReduce(p, p, (size_t)S.ar_n, kNcclDouble, kNcclSum, h->comm, h->stream));
+    }
+  }
+  FCCHK(time_end(h));
+  if (h->dag_inject >= 0 && h->dag_inject-- == 0) {
+    // test aid: what a workgroup that gave up waiting leaves behind (the results of this apply are then ignored)
+    static const int one = 1;
+    HIPCHK(hipMemcpyAsync(h->dag_err.p, &one, sizeof(int), hipMemcpyHostToDevice, h->stream));
+  }
+  return FC_OK;
+}
+
+int apply_factors(fc_ctx* h, OrderSys& S, int first = 0, int last = -1) {
   if (last < 0) last = (int)S.stages.size() - 1;
+  if (h->dag_enabled && S.dag_ready) return apply_factors_dag(h, S, first, last);
   // timing: ONE event pair around the back-to-back sweep launches of this apply (a pair per launch
   // would serialise the short kernels and read ~2 us high); the launch count is recorded with it
   int nlaunch = 0;
@@ -578,6 +630,24 @@ int refresh_permuted(fc_ctx* h) {
   return FC_OK;
 }
 
+// A workgroup of the one-launch apply gave up waiting (fc_dag.hip.h): the step's tail left the state
+// untouched.  Drain the stream, clear the error word and the arrival counters, and use the level launches
+// for the rest of this handle's life; the caller then redoes the step.
+int dag_recover(fc_ctx* h) {
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemsetAsync(h->dag_err.p, 0, 2 * sizeof(int), h->stream));
+  for (int o = 0; o < 2; ++o) {
+    OrderSys& S = h->sys[o];
+    if (S.dag_cnt.n) HIPCHK(hipMemsetAsync(S.dag_cnt.p, 0, S.dag_cnt.n * sizeof(unsigned), h->stream));
+    S.dag_epoch = 0;
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->dag_enabled = false;
+  ++h->dag_failures;
+  h->pre_slot = -1;
+  return FC_OK;
+}
+
 struct StepCoeffs {
   double cm_n, cm_nn, cc_n, cc_nn;
 };
@@ -637,7 +707,7 @@ bool use_fused_tail(const fc_ctx* h) {
 }
 
 int launch_tail(fc_ctx* h, OrderSys& S, int compute_energy, double* d_y, double* d_E, double* d_r, double* d_flag_out,
-                double* d_seq, double seq) {
+                double* d_seq, double seq, int step_id = 1) {
   const bool res = h->check_residual != 0;
   const bool part = h->partitioned;
   const int ncl = part ? h->ncl : h->nc;
@@ -647,18 +717,18 @@ int launch_tail(fc_ctx* h, OrderSys& S, int compute_energy, double* d_y, double*
   hipLaunchKernelGGL(fc_tail, dim3(g), dim3(256), 0, h->stream, h->N, 2 * h->nn, h->perm.p, h->buf.p + h->N, h->b.p,
                      res ? S.Ap_rowptr.p : nullptr, S.Ap_col.p, S.Ap_val.p, g_rows, reps, h->nc, g_cells > 0 ? h->cn.p : nullptr,
                      h->geom.p, h->iperm.p, part ? h->rowkind_p.p : nullptr, part ? h->cell_list.p : nullptr, ncl, h->up.p,
-                     h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p, h->partial.p);
+                     h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p, h->partial.p, h->dag_err.p);
   const double* e_part = g_cells > 0 ? h->partial.p + 2 * (size_t)g : nullptr;
   if (!part) {
     hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, g, e_part, d_E, res ? g : 0, res ? h->partial.p : nullptr, d_r,
-                       h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p, h->up.p, d_y, h->flag.p, d_flag_out, d_seq, seq);
+                       h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p, h->up.p, d_y, h->flag.p, d_flag_out, d_seq, seq, h->dag_err.p, step_id);
   } else {
     // partitioned: this rank's share (owned rows, its cells, its part of every sensor row) goes to the 80-double
     // tail record, ONE all-reduce sums the ranks' records, the result is published (fc_final rewrites every
     // used word of the record each step)
     hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, g, e_part, h->tail.p + 64, res ? g : 0,
                        res ? h->partial.p : nullptr, h->tail.p + 65, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p, h->up.p,
-                       h->tail.p, h->flag.p, h->tail.p + 72, (double*)nullptr, 0.0);
+                       h->tail.p, h->flag.p, h->tail.p + 72, (double*)nullptr, 0.0, h->dag_err.p, step_id);
     if (d_y) {  // d_y == nullptr: the caller (host-staged exchange) sums the records itself
       if (h->comm) NCCLCHK(g_rccl.AllReduce(h->tail.p, h->tail.p, 80, kNcclDouble, kNcclSum, h->comm, h->stream));
       hipLaunchKernelGGL(fc_publish_tail, dim3(1), dim3(64), 0, h->stream, h->tail.p, d_y, h->n_sens, d_E, d_r, d_flag_out, d_seq,
@@ -672,7 +742,7 @@ int launch_tail(fc_ctx* h, OrderSys& S, int compute_energy, double* d_y, double*
 // enqueue one full step; y -> d_y, E -> d_E; residual norms -> scal[1], scal[2]
 int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, double* d_E, double* d_r,
                  double* d_flag_out, int compute_energy, const double* d_uforce = nullptr, double* d_seq = nullptr,
-                 double seq = 0.0) {
+                 double seq = 0.0, int step_id = 1) {
   OrderSys& S = h->sys[order_slot];
   if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this order");
   if (h->method != FC_METHOD_REFINE) return fail(FC_ERR_INVALID, "time steps use the factor sweeps directly: set FC_METHOD_REFINE");
@@ -682,7 +752,7 @@ int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, 
   int nrp = 0;
   if (use_fused_tail(h)) {
     FCCHK(apply_factors(h, S));
-    return launch_tail(h, S, compute_energy, d_y, d_E, d_r, d_flag_out, d_seq, seq);
+    return launch_tail(h, S, compute_energy, d_y, d_E, d_r, d_flag_out, d_seq, seq, step_id);
   }
   FCCHK(solve_permuted(h, S, &x, &dx, &nrp));
   const int g = nblocks(h->N, 32);  // fc_finish: 8 lanes per row, 32 rows per workgroup
@@ -690,16 +760,16 @@ int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, 
   if (!h->partitioned) {
     hipLaunchKernelGGL(fc_finish, dim3(g), dim3(256), 0, h->stream, h->N, 2 * h->nn, h->perm.p, x, dx, h->up.p, h->u_n.p,
                        h->u_nn.p, h->p_n.p, h->flag.p, compute_energy ? h->mp_rowptr.p : nullptr, h->mp_col.p,
-                       h->mp_val.p, compute_energy ? e_partial : nullptr, (const unsigned char*)nullptr);
+                       h->mp_val.p, compute_energy ? e_partial : nullptr, (const unsigned char*)nullptr, h->dag_err.p);
     hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, g, compute_energy ? e_partial : nullptr,
                        d_E, nrp, nrp > 0 ? h->partial.p : nullptr, d_r, h->n_sens, h->s_rowptr.p, h->s_idx.p,
-                       h->s_w.p, h->up.p, d_y, h->flag.p, d_flag_out, d_seq, seq);
+                       h->s_w.p, h->up.p, d_y, h->flag.p, d_flag_out, d_seq, seq, h->dag_err.p, step_id);
   } else {
     // partitioned: scatter owned + root rows, energy from this rank's cells, sensor rows restricted to
     // owned dofs; the partial tail is summed over the ranks with one small all-reduce
     hipLaunchKernelGGL(fc_finish, dim3(g), dim3(256), 0, h->stream, h->N, 2 * h->nn, h->perm.p, x, dx, h->up.p, h->u_n.p,
                        h->u_nn.p, h->p_n.p, h->flag.p, (const int*)nullptr, (const int*)nullptr, (const double*)nullptr,
-                       (double*)nullptr, h->rowkind_p.p);
+                       (double*)nullptr, h->rowkind_p.p, h->dag_err.p);
     int ne = 0;
     if (compute_energy && h->ncl > 0) {
       ne = nblocks(h->ncl, 256);
@@ -709,7 +779,7 @@ int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, 
     HIPCHK(hipMemsetAsync(h->tail.p, 0, 128 * sizeof(double), h->stream));
     hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, ne, ne > 0 ? e_partial : nullptr,
                        h->tail.p + 64, nrp, nrp > 0 ? h->partial.p : nullptr, h->tail.p + 65, h->n_sens, h->s_rowptr.p,
-                       h->s_idx.p, h->s_w.p, h->up.p, h->tail.p, h->flag.p, h->tail.p + 72, (double*)nullptr, 0.0);
+                       h->s_idx.p, h->s_w.p, h->up.p, h->tail.p, h->flag.p, h->tail.p + 72, (double*)nullptr, 0.0, h->dag_err.p, step_id);
     if (h->comm) NCCLCHK(g_rccl.AllReduce(h->tail.p, h->tail.p, 80, kNcclDouble, kNcclSum, h->comm, h->stream));
     hipLaunchKernelGGL(fc_publish_tail, dim3(1), dim3(64), 0, h->stream, h->tail.p, d_y, h->n_sens, d_E, d_r, d_flag_out,
                        d_seq, seq);
@@ -904,6 +974,9 @@ int fc_create(fc_handle* out, int device, int32_t nv, int32_t ne, int32_t nc, co
   TRY(h->ydev.alloc(64));
   TRY(h->tail.alloc(128));
   TRY(h->tail.zero(h->stream));
+  TRY(h->dag_err.alloc(2));
+  TRY(h->dag_err.zero(h->stream));
+  if (const char* e = std::getenv("FC_DAG")) h->dag_enabled = e[0] != '0';  // 1: one-launch factor apply (fc_dag.hip.h)
   TRYHIP(hipStreamSynchronize(h->stream));
 #undef TRY
 #undef TRYHIP
@@ -1271,6 +1344,7 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
   HIPCHK(hipStreamSynchronize(h->stream));
   S.ready = true;
   S.structured = true;
+  S.dag_ready = false;  // fc_solver_set_dag must follow
   return FC_OK;
 }
 
@@ -1325,6 +1399,222 @@ int fc_solver_set_blocks(fc_handle h, int slot, int32_t n_stages, const int64_t*
   }
   FCCHK(S.blk.upload(packed, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  return FC_OK;
+}
+
+int fc_solver_set_dag(fc_handle h, int slot, int32_t n_nodes, const int64_t* nodes, const uint8_t* mine, const int32_t* dn_dep,
+                      const int32_t* up_dep_ptr, const int32_t* up_dep_idx) {
+  if (!h || slot < 0 || slot > 1 || n_nodes <= 0 || !nodes || !dn_dep || !up_dep_ptr || (up_dep_ptr[n_nodes] > 0 && !up_dep_idx))
+    return fail(FC_ERR_INVALID, "fc_solver_set_dag: bad argument");
+  OrderSys& S = h->sys[slot];
+  if (!S.structured) return fail(FC_ERR_NOT_READY, "fc_solver_setup must be called first");
+  HIPCHK(hipSetDevice(h->device));
+  S.dag_ready = false;
+  const int N = h->N;
+  const int64_t n_idx = (int64_t)S.f_idx.n, n_val = S.f_nnz;
+  struct Nd {
+    int level, i0, ni, nb;
+    int64_t voff, ioff;
+    int up_stage = -1, dn_stage = -1;
+    int up_n = 0, dn_n = 0;                          // tasks
+    int up_base = 0, up_sh = 1, dn_base = 0, dn_sh = 1;  // counters
+    int up_dep0 = 0, up_ndep = 0, dn_dep0 = 0, dn_ndep = 0;
+  };
+  std::vector<Nd> nd((size_t)n_nodes);
+  for (int g = 0; g < n_nodes; ++g) {
+    const int64_t* r = nodes + (size_t)g * 7;  // level, index in level, i0, ni, nb, value offset, index-list offset
+    Nd& d = nd[g];
+    d.level = (int)r[0];
+    d.i0 = (int)r[2];
+    d.ni = (int)r[3];
+    d.nb = (int)r[4];
+    d.voff = r[5];
+    d.ioff = r[6];
+    if (d.ni <= 0 || d.nb < 0 || d.i0 < 0 || (int64_t)d.i0 + d.ni > N || d.voff < 0 ||
+        d.voff + (int64_t)d.ni * (d.ni + d.nb) > n_val || (d.nb > 0 && (d.ioff < 0 || d.ioff + d.nb > n_idx)))
+      return fail(FC_ERR_INVALID, "fc_solver_set_dag: node table out of range");
+    if (dn_dep[g] >= n_nodes || up_dep_ptr[g] < 0 || up_dep_ptr[g + 1] < up_dep_ptr[g])
+      return fail(FC_ERR_INVALID, "fc_solver_set_dag: dependency table out of range");
+  }
+  for (int k = 0; k < up_dep_ptr[n_nodes]; ++k)
+    if (up_dep_idx[k] < 0 || up_dep_idx[k] >= n_nodes) return fail(FC_ERR_INVALID, "fc_solver_set_dag: dependency index out of range");
+  auto is_mine = [&](int g) { return !mine || mine[g] != 0; };
+  // the stage every node's rows belong to; a stage must be tiled exactly by its nodes
+  const int nst = (int)S.stages.size();
+  std::vector<std::vector<int>> stage_nodes((size_t)nst);
+  for (int g = 0; g < n_nodes; ++g) {
+    if (!is_mine(g)) continue;
+    for (int s = 0; s < nst; ++s) {
+      const Stage& st = S.stages[s];
+      if (st.row0 <= nd[g].i0 && nd[g].i0 + nd[g].ni <= st.row0 + st.nrows) {
+        (st.kind == 0 ? nd[g].up_stage : nd[g].dn_stage) = s;
+        stage_nodes[s].push_back(g);
+      }
+    }
+    if (nd[g].dn_stage < 0) return fail(FC_ERR_INVALID, "fc_solver_set_dag: a node's rows lie in no down stage");
+  }
+  for (int s = 0; s < nst; ++s) {
+    std::sort(stage_nodes[s].begin(), stage_nodes[s].end(), [&](int a, int b) { return nd[a].i0 < nd[b].i0; });
+    int64_t rows = 0;
+    int next = S.stages[s].row0;
+    for (int g : stage_nodes[s]) {
+      if (nd[g].i0 != next) return fail(FC_ERR_INVALID, "fc_solver_set_dag: the nodes do not tile their stage");
+      next += nd[g].ni;
+      rows += nd[g].ni;
+    }
+    if (rows != S.stages[s].nrows) return fail(FC_ERR_INVALID, "fc_solver_set_dag: the nodes do not cover their stage");
+  }
+  // tasks, stage by stage (= topological order)
+  std::vector<FcDagTask> tasks;
+  std::vector<FcBlk> blocks;
+  std::vector<int> task_node;
+  auto pow2_ceil = [](int v) { int p = 1; while (p < v) p <<= 1; return p; };
+  for (int s = 0; s < nst; ++s) {
+    Stage& st = S.stages[s];
+    st.dag_task0 = (int)tasks.size();
+    for (int g : stage_nodes[s]) {
+      Nd& d = nd[g];
+      if (st.kind == 0) {
+        const int rpb = 256 / st.lanes;
+        for (int r0 = 0; r0 < d.ni; r0 += rpb) {
+          FcDagTask t{};
+          t.kind = 0;
+          t.a = (int)(st.rp_begin + (d.i0 - st.row0) + r0);
+          t.nrows = std::min(rpb, d.ni - r0);
+          t.dest0 = d.i0 + r0;
+          t.geom = (st.lanes << 16) | st.sub;
+          tasks.push_back(t);
+          task_node.push_back(g);
+          ++d.up_n;
+        }
+      } else {
+        // tile of R = 256 / LPR rows; a lane holds <= FC_DAG_PV values of its row in registers
+        const int wd = d.ni + d.nb;
+        const int lpr = std::min(256, std::max(8, pow2_ceil((wd + FC_DAG_PV - 1) / FC_DAG_PV)));
+        const int R = 256 / lpr;
+        for (int r0 = 0; r0 < d.ni; r0 += R) {
+          FcDagTask t{};
+          t.kind = 1;
+          t.a = (int)blocks.size();
+          t.geom = lpr;
+          blocks.push_back(FcBlk{(long long)(d.voff + (int64_t)r0 * wd), d.i0 + r0, std::min(R, d.ni - r0), d.i0, d.ni, (int)d.ioff, d.nb});
+          tasks.push_back(t);
+          task_node.push_back(g);
+          ++d.dn_n;
+        }
+      }
+    }
+    st.dag_ntasks = (int)tasks.size() - st.dag_task0;
+  }
+  // arrival counters: one 128-byte line per shard
+  int words = 0;
+  auto shards = [](int ntasks) { return ntasks <= 12 ? 1 : std::min(FC_DAG_MAX_SHARDS, (ntasks + 11) / 12); };
+  for (int g = 0; g < n_nodes; ++g) {
+    Nd& d = nd[g];
+    d.up_sh = shards(d.up_n);
+    d.up_base = words;
+    words += d.up_sh * FC_DAG_SHARD_STRIDE;
+    d.dn_sh = shards(d.dn_n);
+    d.dn_base = words;
+    words += d.dn_sh * FC_DAG_SHARD_STRIDE;
+  }
+  // dependency records, shared by all tasks of a node
+  std::vector<FcDagDep> deps;
+  for (int g = 0; g < n_nodes; ++g) {
+    Nd& d = nd[g];
+    if (!is_mine(g)) continue;
+    d.up_dep0 = (int)deps.size();
+    for (int k = up_dep_ptr[g]; k < up_dep_ptr[g + 1]; ++k) {
+      const Nd& c = nd[up_dep_idx[k]];
+      if (!is_mine(up_dep_idx[k]) || c.up_n == 0) continue;  // leaves: y = b is complete before the launch
+      if (c.level <= d.level) return fail(FC_ERR_INVALID, "fc_solver_set_dag: an up dependency is not deeper in the tree");
+      deps.push_back(FcDagDep{c.up_base, c.up_sh, (unsigned)c.up_n, 0});
+    }
+    d.up_ndep = (int)deps.size() - d.up_dep0;
+    d.dn_dep0 = (int)deps.size();
+    if (dn_dep[g] >= 0) {
+      const Nd& a = nd[dn_dep[g]];
+      if (!is_mine(dn_dep[g]) || a.level >= d.level) return fail(FC_ERR_INVALID, "fc_solver_set_dag: a down dependency is not an ancestor of this rank");
+      deps.push_back(FcDagDep{a.dn_base, a.dn_sh, (unsigned)a.dn_n, 0});
+    } else if (d.up_n > 0) {
+      deps.push_back(FcDagDep{d.up_base, d.up_sh, (unsigned)d.up_n, 0});  // the root: its own up rows
+    }
+    d.dn_ndep = (int)deps.size() - d.dn_dep0;
+  }
+  if (deps.empty()) deps.push_back(FcDagDep{0, 0, 0u, 0});
+  std::vector<int> seen_up((size_t)n_nodes, 0), seen_dn((size_t)n_nodes, 0);
+  for (size_t i = 0; i < tasks.size(); ++i) {
+    FcDagTask& t = tasks[i];
+    Nd& d = nd[task_node[i]];
+    if (t.kind == 0) {
+      t.dep0 = d.up_dep0;
+      t.ndep = d.up_ndep;
+      t.sig = d.up_base + (seen_up[task_node[i]]++ % d.up_sh) * FC_DAG_SHARD_STRIDE;
+    } else {
+      t.dep0 = d.dn_dep0;
+      t.ndep = d.dn_ndep;
+      t.sig = d.dn_base + (seen_dn[task_node[i]]++ % d.dn_sh) * FC_DAG_SHARD_STRIDE;
+    }
+  }
+  if (tasks.empty()) return fail(FC_ERR_INVALID, "fc_solver_set_dag: no tasks");
+  if (blocks.empty()) blocks.push_back(FcBlk{0, 0, 0, 0, 0, 0, 0});
+  FCCHK(S.dag_tasks.upload(tasks, h->stream));
+  FCCHK(S.dag_deps.upload(deps, h->stream));
+  FCCHK(S.dag_blk.upload(blocks, h->stream));
+  FCCHK(S.dag_cnt.alloc((size_t)std::max(words, FC_DAG_SHARD_STRIDE)));
+  FCCHK(S.dag_cnt.zero(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  S.dag_epoch = 0;
+  S.dag_ready = true;
+  return FC_OK;
+}
+
+int fc_get_dag_info(fc_handle h, int slot, int32_t* n_tasks, int32_t* enabled, int32_t* failures) {
+  if (!h || slot < 0 || slot > 1) return fail(FC_ERR_INVALID, "fc_get_dag_info: bad argument");
+  if (n_tasks) *n_tasks = h->sys[slot].dag_ready ? (int32_t)h->sys[slot].dag_tasks.n : 0;
+  if (enabled) *enabled = (h->dag_enabled && h->sys[slot].dag_ready) ? 1 : 0;
+  if (failures) *failures = h->dag_failures;
+  return FC_OK;
+}
+
+int fc_debug_trace_apply(fc_handle h, int slot, int32_t n_tasks, int64_t* stamps, int32_t* task_stage, int32_t* task_kind) {
+  if (!h || slot < 0 || slot > 1 || !stamps) return fail(FC_ERR_INVALID, "fc_debug_trace_apply: bad argument");
+  OrderSys& S = h->sys[slot];
+  if (!S.ready || !S.dag_ready || !h->dag_enabled) return fail(FC_ERR_NOT_READY, "fc_debug_trace_apply: one-launch apply not set up");
+  if (n_tasks != (int32_t)S.dag_tasks.n) return fail(FC_ERR_INVALID, "fc_debug_trace_apply: n_tasks differs from fc_get_dag_info");
+  HIPCHK(hipSetDevice(h->device));
+  const int N = h->N, g = nblocks(N, 256);
+  for (int i = 0; i < 3; ++i) {
+    hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, h->buf.p);
+    FCCHK(apply_factors(h, S));
+  }
+  FCCHK(h->dag_trace.alloc((size_t)n_tasks * 8));
+  FCCHK(h->dag_trace.zero(h->stream));
+  hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, h->buf.p);
+  const int code = apply_factors(h, S);
+  HIPCHK(hipMemcpyAsync(stamps, h->dag_trace.p, (size_t)n_tasks * 8 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->dag_trace.release();
+  if (code != FC_OK) return code;
+  for (size_t s = 0; s < S.stages.size(); ++s)
+    for (int i = 0; i < S.stages[s].dag_ntasks; ++i) {
+      if (task_stage) task_stage[S.stages[s].dag_task0 + i] = (int32_t)s;
+      if (task_kind) task_kind[S.stages[s].dag_task0 + i] = S.stages[s].kind;
+    }
+  return FC_OK;
+}
+
+int fc_debug_inject_dag_failure(fc_handle h, int after_n_applies) {
+  if (!h) return fail(FC_ERR_INVALID, "null handle");
+  h->dag_inject = after_n_applies;
+  return FC_OK;
+}
+
+int fc_set_dag(fc_handle h, int on) {
+  if (!h) return fail(FC_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->dag_enabled = on != 0;
   return FC_OK;
 }
 
@@ -1666,6 +1956,7 @@ int fc_step(fc_handle h, int order_slot, const double* u_ctrl, const double* u_f
     pin[32 + k] = u_force ? u_force[k] : u_ctrl[k];  // body-force amplitudes (CN: mean of new and old)
   }
   double* dev = h->pin_dev;
+  for (int attempt = 0;; ++attempt) {
   const double seq = (double)(++h->seq);
   FCCHK(enqueue_step(h, order_slot, dev, dev + 64, dev + 128, dev + 129, dev + 136, compute_energy, dev + 32, dev + 137, seq));
   speculate_next_rhs(h, order_slot);
@@ -1700,10 +1991,19 @@ int fc_step(fc_handle h, int order_slot, const double* u_ctrl, const double* u_f
     FCCHK(time_collect(h));
     if (!record_ok()) return fail(FC_ERR_HIP, "fc_step: the step record failed its checksum after stream synchronisation");
   }
+  if (pin[136] >= 1024.0) {
+    // the one-launch factor apply gave up (bounded wait): nothing was written to the state; redo with level launches
+    if (h->partitioned) return fail(FC_ERR_HIP, "fc_step: the one-launch factor apply gave up waiting on a partitioned handle (set FC_DAG=0)");
+    if (attempt > 0) return fail(FC_ERR_HIP, "fc_step: factor apply failed twice");
+    FCCHK(dag_recover(h));
+    continue;
+  }
+  break;
+  }
   for (int s = 0; s < h->n_sens; ++s)
     if (y_out) y_out[s] = pin[64 + s];
   if (dE_out) *dE_out = compute_energy ? pin[128] : std::numeric_limits<double>::quiet_NaN();
-  const int flag = (int)pin[136];
+  const int flag = ((int)pin[136]) % 1024;
   if (info_out) {
     const double r2 = pin[129], b2 = pin[130];
     info_out[0] = h->max_iter;
@@ -1760,7 +2060,7 @@ int fc_step_phase(fc_handle h, int order_slot, int phase, const double* u_ctrl, 
     double* e_partial = h->partial.p + 2 * (size_t)h->nblk_N;
     hipLaunchKernelGGL(fc_finish, dim3(nblocks(N, 32)), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, x, (const double*)nullptr, h->up.p,
                        h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p, (const int*)nullptr, (const int*)nullptr,
-                       (const double*)nullptr, (double*)nullptr, h->rowkind_p.p);
+                       (const double*)nullptr, (double*)nullptr, h->rowkind_p.p, h->dag_err.p);
     int ne = 0;
     if (compute_energy && h->ncl > 0) {
       ne = nblocks(h->ncl, 256);
@@ -1770,7 +2070,7 @@ int fc_step_phase(fc_handle h, int order_slot, int phase, const double* u_ctrl, 
     HIPCHK(hipMemsetAsync(h->tail.p, 0, 128 * sizeof(double), h->stream));
     hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, ne, ne > 0 ? e_partial : nullptr, h->tail.p + 64,
                        nrp, nrp > 0 ? h->partial.p : nullptr, h->tail.p + 65, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p,
-                       h->up.p, h->tail.p, h->flag.p, h->tail.p + 72, (double*)nullptr, 0.0);
+                       h->up.p, h->tail.p, h->flag.p, h->tail.p + 72, (double*)nullptr, 0.0, h->dag_err.p, 1);
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipMemcpyAsync(tail_io, h->tail.p, 80 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1792,19 +2092,30 @@ int fc_run(fc_handle h, int first_order_slot, int32_t n_steps, const double* u_c
   FCCHK(h->useq.upload(uh, h->stream));
   FCCHK(h->yseq.alloc((size_t)n_steps * ns));
   FCCHK(h->Eseq.alloc((size_t)n_steps));
-  int order = first_order_slot;
-  for (int s = 0; s < n_steps; ++s) {
-    const double* du = h->useq.p + (u_ctrl_is_sequence ? (size_t)s * h->n_act : 0);
-    FCCHK(enqueue_step(h, order, du, h->yseq.p + (size_t)s * ns, h->Eseq.p + s, h->scal.p + 1, nullptr, compute_energy));
-    order = FC_SLOT_BDF2;
-  }
   std::vector<double> yh((size_t)n_steps * ns), Eh(n_steps);
   int flag = 0;
-  HIPCHK(hipMemcpyAsync(yh.data(), h->yseq.p, yh.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(Eh.data(), h->Eseq.p, Eh.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(&flag, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  FCCHK(time_collect(h));
+  for (int s_begin = 0, attempt = 0;; ++attempt) {
+    for (int s = s_begin; s < n_steps; ++s) {
+      const int order = s == 0 ? first_order_slot : FC_SLOT_BDF2;
+      const double* du = h->useq.p + (u_ctrl_is_sequence ? (size_t)s * h->n_act : 0);
+      FCCHK(enqueue_step(h, order, du, h->yseq.p + (size_t)s * ns, h->Eseq.p + s, h->scal.p + 1, nullptr, compute_energy, nullptr,
+                         nullptr, 0.0, s + 1));
+    }
+    int derr[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(yh.data(), h->yseq.p, yh.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(Eh.data(), h->Eseq.p, Eh.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&flag, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(derr, h->dag_err.p, sizeof(derr), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    FCCHK(time_collect(h));
+    if (!derr[0]) break;
+    // the one-launch factor apply gave up in step derr[1]: that step and all later ones left the state untouched
+    // (fc_tail / fc_finish return early); redo them with the level launches
+    if (h->partitioned || attempt > 0 || derr[1] < 1 || derr[1] > n_steps)
+      return fail(FC_ERR_HIP, "fc_run: the one-launch factor apply gave up waiting (set FC_DAG=0)");
+    FCCHK(dag_recover(h));
+    s_begin = derr[1] - 1;
+  }
   if (y_seq)
     for (int s = 0; s < n_steps; ++s)
       for (int k = 0; k < h->n_sens; ++k) y_seq[(size_t)s * h->n_sens + k] = yh[(size_t)s * ns + k];
@@ -1916,8 +2227,23 @@ int bicgstab_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
   return FC_OK;
 }
 
+static int solve_once(fc_handle h, int slot, const double* b, double* x, double* info_out);
+
 int fc_solve(fc_handle h, int slot, const double* b, double* x, double* info_out) {
   if (!h || slot < 0 || slot > 1 || !b || !x) return fail(FC_ERR_INVALID, "fc_solve: bad argument");
+  int code = solve_once(h, slot, b, x, info_out);
+  if (code == FC_ERR_INVALID || code == FC_ERR_NOT_READY || !(h->dag_enabled && h->sys[slot].dag_ready)) return code;
+  int derr[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(derr, h->dag_err.p, sizeof(derr), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (!derr[0]) return code;
+  // the one-launch factor apply gave up waiting somewhere in this solve: redo it with the level launches
+  if (h->partitioned) return fail(FC_ERR_HIP, "fc_solve: the one-launch factor apply gave up waiting on a partitioned handle (set FC_DAG=0)");
+  FCCHK(dag_recover(h));
+  return solve_once(h, slot, b, x, info_out);
+}
+
+static int solve_once(fc_handle h, int slot, const double* b, double* x, double* info_out) {
   OrderSys& S = h->sys[slot];
   if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this slot");
   HIPCHK(hipSetDevice(h->device));
@@ -2054,10 +2380,10 @@ int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double*
     }
     hipLaunchKernelGGL(fc_finish, dim3(nblocks(N, 32)), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, x, dx, h->up.p, h->u_n.p,
                        h->u_nn.p, h->p_n.p, h->flag.p, h->mp_rowptr.p, h->mp_col.p, h->mp_val.p, e_partial,
-                       (const unsigned char*)nullptr);
+                       (const unsigned char*)nullptr, h->dag_err.p);
     hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, nblocks(N, 32), e_partial, h->scal.p, nrp,
                        nrp > 0 ? h->partial.p : nullptr, h->scal.p + 1, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p,
-                       h->up.p, h->ydev.p, h->flag.p, (double*)nullptr, (double*)nullptr, 0.0);
+                       h->up.p, h->ydev.p, h->flag.p, (double*)nullptr, (double*)nullptr, 0.0, h->dag_err.p, 1);
     FCCHK(lap(4));
   }
   HIPCHK(hipStreamSynchronize(h->stream));

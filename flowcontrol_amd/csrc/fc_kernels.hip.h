@@ -760,7 +760,9 @@ __global__ __launch_bounds__(256) void fc_finish(int N, int nn2, const int* __re
                                                  const int* __restrict__ m_col,
                                                  const double* __restrict__ m_val,
                                                  double* __restrict__ e_partial,
-                                                 const unsigned char* __restrict__ rowkind) {
+                                                 const unsigned char* __restrict__ rowkind,
+                                                 const int* __restrict__ err) {
+  if (err && err[0]) return;  // the factor apply gave up (fc_nd_dag): leave the state as it is, the host redoes the step
   // 8 lanes per (permuted) row: they share the mass-matrix row of the energy term (coalesced 8 x 12 B
   // per trip), lane 0 scatters / shifts the row's dof
   constexpr int LANES = 8, RPB = 256 / LANES;
@@ -846,7 +848,9 @@ __global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restric
                                                 const double* __restrict__ s_w,
                                                 const double* __restrict__ up, double* __restrict__ y,
                                                 const int* __restrict__ flag, double* __restrict__ flag_out,
-                                                double* __restrict__ seq_out, double seq) {
+                                                double* __restrict__ seq_out, double seq, int* err, int step_id) {
+  // flag word of the record: bit 0 = non-finite velocity, + 1024 when the one-launch factor apply gave up
+  // (err[0]; the first step that sees it leaves its id in err[1]) -- partitioned runs sum the word over the ranks
   __shared__ double red[3][256];
   const int t = threadIdx.x;
   // a single workgroup is pure latency: issue every load up front (8 partials per thread and array,
@@ -896,9 +900,15 @@ __global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restric
     }
     __syncthreads();
   }
-  if (t == 0)
+  if (t == 0) {
+    double fl = flag ? (double)(flag[0] & 1) : 0.0;
+    if (err && err[0]) {
+      fl += 1024.0;
+      if (err[1] == 0) err[1] = step_id;
+    }
     fc_publish(ysh, n_sens, e_partial ? 0.5 * red[0][0] : 0.0, r_partial ? red[1][0] : 0.0, r_partial ? red[2][0] : 0.0,
-               flag_out ? (double)flag[0] : 0.0, y, E_out, r_out, flag_out, seq_out, seq);
+               fl, y, E_out, r_out, flag_out, seq_out, seq);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -915,7 +925,8 @@ __global__ __launch_bounds__(256) void fc_tail(
     int n_row_blocks, int reps, int nc, const int* __restrict__ cn, const double* __restrict__ geom, const int* __restrict__ iperm,
     const unsigned char* __restrict__ rowkind, const int* __restrict__ cell_list, int ncl,
     double* __restrict__ up, double* __restrict__ u_n, double* __restrict__ u_nn, double* __restrict__ p_n,
-    int* __restrict__ flag, double* __restrict__ partial) {
+    int* __restrict__ flag, double* __restrict__ partial, const int* __restrict__ err) {
+  if (err && err[0]) return;  // the factor apply gave up (fc_nd_dag): leave the state as it is, the host redoes the step
   constexpr int LANES = 8, RPB = 256 / LANES;
   const int t = threadIdx.x, lane = t % LANES;
   const int G = gridDim.x;

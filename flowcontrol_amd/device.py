@@ -263,6 +263,9 @@ class DeviceSolver:
                     pick(bi0, z32), pick(bni, z32), pick(bidx, z32), pick(bnb, z32), int(fac.idx.size), int(fac.vals.size),
                 )
             )
+        # one-launch factor apply: dependency lists of the elimination tree (the task tables are built in the library)
+        nodes, mine, dn_dep, up_ptr, up_idx = ndsolver.dag_dependencies(fac, self.rank, self.world)
+        check(self.lib.fc_solver_set_dag(self._h, slot, int(nodes.shape[0]), nodes, mine, dn_dep, up_ptr, up_idx))
         if on_device:
             self._structured.add(slot)
             self.refactor(slot)
@@ -381,6 +384,8 @@ class DeviceSolver:
         self._host_allreduce(root)
         check(self.lib.fc_step_phase(self._h, order_slot, 1, ptr(u), int(compute_energy), ptr(root), ptr(tail)))
         self._host_allreduce(tail)
+        if tail[72] >= 1024.0:  # a rank's one-launch factor apply gave up waiting (fc_dag.hip.h): no redo across ranks
+            raise _lib.FcError(_lib.FC_ERR_HIP, "the one-launch factor apply gave up waiting on a partitioned handle (set FC_DAG=0)")
         info = np.array([0.0, np.sqrt(tail[65] / tail[66]) if tail[66] > 0 else np.nan, np.sqrt(tail[66]), tail[72]])
         if tail[72] > 0:
             raise _lib.FcDiverged(_lib.FC_ERR_DIVERGED, "non-finite velocity after solve")
@@ -472,6 +477,16 @@ class DeviceSolver:
         na, nb = C.c_int64(), C.c_int64()
         check(self.lib.fc_get_timing(self._h, C.byref(a), C.byref(na), C.byref(b), C.byref(nb)))
         return {"sweep_ms": a.value, "sweep_launches": na.value, "spmv_ms": b.value, "spmv_launches": nb.value}
+
+    def dag_info(self, slot: int) -> dict:
+        """One-launch factor apply of ``slot``: number of tasks, whether it is in use, give-ups so far."""
+        n, on, bad = C.c_int32(), C.c_int32(), C.c_int32()
+        check(self.lib.fc_get_dag_info(self._h, slot, C.byref(n), C.byref(on), C.byref(bad)))
+        return {"tasks": n.value, "enabled": bool(on.value), "failures": bad.value}
+
+    def set_dag(self, on: bool) -> None:
+        """Switch between the one-launch factor apply and one launch per tree level (A/B, tests)."""
+        check(self.lib.fc_set_dag(self._h, int(bool(on))))
 
     def algorithmic_bytes(self, slot: int):
         a, b = C.c_double(), C.c_double()

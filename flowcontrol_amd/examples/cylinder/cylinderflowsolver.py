@@ -21,6 +21,33 @@ from ...flowfield import BoundaryConditions
 DEFAULT_MESH = Path(__file__).resolve().parents[3] / "tests" / "golden" / "meshes" / "O1.npz"
 
 
+def refined_cylinder_mesh(levels: int = 1, path: str | Path | None = None, source: str | Path | None = None) -> Path:
+    """BASELINE config 4: the shipped mesh red-refined ``levels`` times (each triangle → 4), new boundary
+    midpoints on the cylinder projected back onto r = 0.5.  Deterministic; written as
+    an ``.npz`` mesh file (``coords``, ``cells``) and returned as a path for ``make_default(meshpath=...)``."""
+    import tempfile
+
+    import numpy as np
+
+    from ...fem.mesh import read_xdmf_mesh
+
+    m = read_xdmf_mesh(source or DEFAULT_MESH, reorder=False)
+
+    def project(mid, is_boundary):
+        r = np.hypot(mid[:, 0], mid[:, 1])
+        on_cyl = is_boundary & (r < 0.6)
+        out = mid.copy()
+        out[on_cyl] *= (0.5 / r[on_cyl])[:, None]
+        return out
+
+    for _ in range(levels):
+        m = m.refine(project)
+    path = Path(path) if path else Path(tempfile.mkdtemp(prefix="fc_mesh_")) / f"O1_refined{levels}.npz"
+    path.parent.mkdir(parents=True, exist_ok=True)
+    np.savez(path, coords=m.coords, cells=m.cells)
+    return path
+
+
 class CylinderFlowSolver(flowsolver.FlowSolver):
     """Flow past a cylinder. Proposed Re=100."""
 

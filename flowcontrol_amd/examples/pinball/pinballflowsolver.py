@@ -20,6 +20,37 @@ from ...flowfield import BoundaryConditions
 DEFAULT_MESH = Path(__file__).resolve().parents[3] / "tests" / "golden" / "meshes" / "mesh_middle_gmsh.npz"
 
 
+class PinballCustomInitialGuess:
+    """Initial guess of the base-flow iterations (reference ``pinballflowsolver.py:328-358``): a uniform
+    (u, v, p) chosen by ``mode`` — symmetric (1, 0, 0), antisymmetric_top (1/√2, +1/√2, 0) or
+    antisymmetric_bot (1/√2, −1/√2, 0); the antisymmetric ones steer Picard towards one of the two
+    asymmetric steady branches the pinball has at Re ≳ 70."""
+
+    _MODES = {"symmetric": (1.0, 0.0), "antisymmetric_top": (2.0**-0.5, 2.0**-0.5), "antisymmetric_bot": (2.0**-0.5, -(2.0**-0.5))}
+
+    def __init__(self, mode: str = "symmetric"):
+        if mode not in self._MODES:
+            raise ValueError(f"Unknown mode '{mode}'")
+        self.mode = mode
+
+    def __call__(self, x):
+        out = np.zeros((np.shape(x)[0], 3))
+        out[:, 0], out[:, 1] = self._MODES[self.mode]
+        return out
+
+    def value_shape(self):
+        return (3,)
+
+    def as_dolfin_function(self, function_space, interp: bool = True):
+        """The guess as a field on ``function_space`` (nodal interpolation; for a constant the L2
+        projection of the reference's ``interp=False`` branch is the same field)."""
+        from ...fem.spaces import Function
+
+        f = Function(function_space)
+        f.interpolate(self)
+        return f
+
+
 class PinballFlowSolver(flowsolver.FlowSolver):
     """Flow past 3 cylinders (fluidic pinball). Proposed Re=100."""
 

@@ -126,6 +126,26 @@ int fc_solver_set_blocks(fc_handle h, int slot, int32_t n_stages, const int64_t*
                          const int64_t* blk_val, const int32_t* blk_row0, const int32_t* blk_nrows,
                          const int32_t* blk_i0, const int32_t* blk_ni, const int32_t* blk_idx,
                          const int32_t* blk_nb, int64_t n_idx, int64_t n_val);
+/* One-launch factor apply (replaces the 2*depth+1 level launches of LUSolver.solve, flowsolver.py:729, by ONE
+ * grid whose workgroups wait for each other through per-node arrival counters; fc_dag.hip.h).  `nodes` has 7
+ * int64 per tree node that owns dofs, elimination order: level, index in level, first row i0, rows ni, boundary
+ * size nb, offset of its [D^-1 | -U] rows in the factor values, offset of its index list.  mine[g] (NULL = all):
+ * the node is swept by this rank.  dn_dep[g]: nearest ancestor that owns dofs (-1: none); up_dep_idx[up_dep_ptr[g]
+ * .. up_dep_ptr[g+1]): nearest owners below g, one per branch.  Must follow fc_solver_setup for the slot.
+ * Every wait inside the launch is bounded; after a give-up the step is redone with the level launches and the
+ * handle stays on them (fc_get_dag_info reports it).  FC_DAG=0 / fc_set_dag(h, 0): level launches throughout. */
+int fc_solver_set_dag(fc_handle h, int slot, int32_t n_nodes, const int64_t* nodes /* [n_nodes][7] */,
+                      const uint8_t* mine /* [n_nodes] or NULL */, const int32_t* dn_dep /* [n_nodes] */,
+                      const int32_t* up_dep_ptr /* [n_nodes+1] */, const int32_t* up_dep_idx);
+int fc_get_dag_info(fc_handle h, int slot, int32_t* n_tasks, int32_t* enabled, int32_t* failures);
+int fc_set_dag(fc_handle h, int on);
+/* test aid: behind the n-th factor apply from now (0 = the next one) the give-up word is raised as a workgroup
+ * that timed out would raise it, so that the redo path can be exercised; -1 disarms */
+int fc_debug_inject_dag_failure(fc_handle h, int after_n_applies);
+/* diagnostic: one traced factor apply; stamps[task][8] = 100 MHz wall-clock ticks of the task's workgroup at
+ * entry / value loads issued / dependencies met / products done / stores drained (rest 0) */
+int fc_debug_trace_apply(fc_handle h, int slot, int32_t n_tasks, int64_t* stamps /* [n_tasks][8] */,
+                         int32_t* task_stage /* [n_tasks] or NULL */, int32_t* task_kind /* [n_tasks] or NULL */);
 /* Numeric factorisation ON THE DEVICE (what `solver.set_operator(A)` costs in the reference,
  * flowsolver.py:697,812-814 -> PETSc/MUMPS numeric phase; also every Newton/Picard iteration of
  * steadystate.py:60-159).  fc_factor_plan uploads the symbolic side once per (tree, pattern): all
