@@ -30,13 +30,13 @@
 #include <stdint.h>
 
 struct __attribute__((aligned(16))) FcDagTask {
-  int kind;   // 0: up rows (segment lists, accumulate into y); 1: down tile (block, assign into x)
-  int a;      // kind 0: index of the first row in seg_ptr; kind 1: index of the tile in the DAG block array
+  int kind;   // 0: up rows (expanded sparse rows, accumulate into y); 1: down tile (block, assign into x)
+  int a;      // kind 0: index of the first row in up_ptr; kind 1: index of the tile in the DAG block array
   int nrows;  // kind 0: rows of this task
   int dest0;  // kind 0: buf index of the first row
   int dep0, ndep;  // dependency records
   int sig;         // counter word this task adds 1 to when it is done
-  int geom;        // kind 0: lanes << 16 | sub; kind 1: lanes per row
+  int geom;        // lanes per row
 };
 struct __attribute__((aligned(16))) FcDagDep {
   int base;        // first counter word
@@ -47,9 +47,15 @@ struct __attribute__((aligned(16))) FcDagDep {
 
 #define FC_DAG_SHARD_STRIDE 32  // counter words per 128-byte line
 #define FC_DAG_MAX_SHARDS 16
-#define FC_DAG_PV 24            // fp64 values a lane holds in registers while it waits
+#define FC_DAG_PV 16            // fp64 values a lane holds in registers while it waits
 #define FC_DAG_TILE 2048        // operand entries staged in LDS at a time
 #define FC_DAG_SPIN_LIMIT 200000
+#ifndef FC_DAG_SLEEP_MAX
+#define FC_DAG_SLEEP_MAX 32  // poll back-off cap in units of 64 clocks (waiters of one node poll the same counter lines)
+#endif
+#ifndef FC_DAG_WAVES_PER_SIMD
+#define FC_DAG_WAVES_PER_SIMD 6  // register budget: 6 workgroups of 256 threads per CU stay resident
+#endif
 
 typedef unsigned long long fc_u64;
 
@@ -75,7 +81,7 @@ __device__ __forceinline__ bool fc_dag_wait(const FcDagDep* __restrict__ deps, i
     const bool mine = has && s < dp.nshard;
     const unsigned* p = cnt + dp.base + (mine ? s : 0) * FC_DAG_SHARD_STRIDE;
     const unsigned want = dp.target * epoch;
-    int spin = 0;
+    int spin = 0, nap = 1;
     for (;;) {
       unsigned v = mine ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
       v += __shfl_xor(v, 8, 16);
@@ -89,17 +95,18 @@ __device__ __forceinline__ bool fc_dag_wait(const FcDagDep* __restrict__ deps, i
         return false;
       }
       if ((spin & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-      __builtin_amdgcn_s_sleep(2);
+      for (int k = 0; k < nap; ++k) __builtin_amdgcn_s_sleep(1);
+      if (nap < FC_DAG_SLEEP_MAX) nap *= 2;
     }
   }
   return true;
 }
 
-__global__ __launch_bounds__(256) void fc_nd_dag(const FcDagTask* __restrict__ tasks, const FcDagDep* __restrict__ deps,
-                                                 unsigned* cnt, unsigned epoch, int* err,
-                                                 const int64_t* __restrict__ seg_ptr, const FcSeg* __restrict__ seg,
-                                                 const FcBlk* __restrict__ blk, const int* __restrict__ idx,
-                                                 const double* __restrict__ val, double* buf, int N, fc_u64* trace) {
+__global__ __launch_bounds__(256, FC_DAG_WAVES_PER_SIMD) void fc_nd_dag(
+    const FcDagTask* __restrict__ tasks, const FcDagDep* __restrict__ deps, unsigned* cnt, unsigned epoch, int* err,
+    const int64_t* __restrict__ up_ptr, const int* __restrict__ up_col, const double* __restrict__ up_val,
+    const FcBlk* __restrict__ blk, const int* __restrict__ idx, const double* __restrict__ val, double* buf, int N,
+    fc_u64* trace) {
   // trace (diagnostic launches only, fc_debug_trace_apply): 100 MHz wall-clock stamps of thread 0 at
   // entry / prefetch issued / dependencies met / products done / stores drained
   __shared__ double xs[FC_DAG_TILE];
@@ -197,39 +204,36 @@ __global__ __launch_bounds__(256) void fc_nd_dag(const FcDagTask* __restrict__ t
     double s = acc;
     const int w = LPR < 64 ? LPR : 64;
     for (int off = w >> 1; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (LPR == 256) {
+    if (LPR > 64) {  // a row spans 2 or 4 waves: combine their sums through LDS in a fixed order
       if ((tid & 63) == 0) part[tid >> 6] = s;
       __syncthreads();
-      if (tid == 0 && rowok) fc_st_sc1(buf + N + b.row0, (part[0] + part[1]) + (part[2] + part[3]));
+      if (l == 0 && rowok) {
+        const int w0 = tid >> 6;
+        fc_st_sc1(buf + N + b.row0 + slot, LPR == 128 ? part[w0] + part[w0 + 1] : (part[0] + part[1]) + (part[2] + part[3]));
+      }
     } else if (l == 0 && rowok) {
       fc_st_sc1(buf + N + b.row0 + slot, s);
     }
   } else {
-    // ── up rows: segment lists (see fc_nd_sweep); the first trip of the first round of segments is loaded
-    //    before the wait ──
-    const int LANES = t.geom >> 16, SUB = t.geom & 0xffff;
-    const int SW = LANES < 64 ? LANES : 64;
-    const int G = LANES / SUB;
-    const int lane = tid % LANES, sl = tid % SW, g = lane / SUB, l2 = lane % SUB;
-    const int rloc = tid / LANES;
-    const bool rowok = rloc < t.nrows;
-    const int64_t q0 = rowok ? seg_ptr[t.a + rloc] : 0, q1 = rowok ? seg_ptr[t.a + rloc + 1] : 0;
-    FcSeg first = {0, 0, 0};
-    if (q0 + sl < q1) first = seg[q0 + sl];
-    double pv0 = 0.0, pv1 = 0.0, pv2 = 0.0, pv3 = 0.0;
-    {
-      const int cnt0 = (int)((q1 - q0) < SW ? (q1 - q0) : SW);
-      const int src = g < cnt0 ? (g % SW) : 0;
-      const long long vo = __shfl(first.val, src, SW);
-      int len = __shfl(first.len, src, SW);
-      if (g >= cnt0) len = 0;
-      const double* __restrict__ v = val + vo;
-      const int j0 = l2, j1 = j0 + SUB, j2 = j1 + SUB, j3 = j2 + SUB;
-      const double a0 = v[j0 < len ? j0 : 0], a1 = v[j1 < len ? j1 : 0], a2 = v[j2 < len ? j2 : 0], a3 = v[j3 < len ? j3 : 0];
-      pv0 = j0 < len ? a0 : 0.0;
-      pv1 = j1 < len ? a1 : 0.0;
-      pv2 = j2 < len ? a2 : 0.0;
-      pv3 = j3 < len ? a3 : 0.0;
+    // ── up rows: the -L rows of node t, one expanded sparse row per dof (values re-laid out row by row, explicit
+    //    int32 columns into y): values AND columns are in registers before the wait, afterwards one trip of sc1
+    //    operand loads (all in flight) and the products ──
+    const int LPR = t.geom;
+    const int slot = tid / LPR, l = tid % LPR;
+    const bool rowok = slot < t.nrows;
+    const int r = t.a + (rowok ? slot : 0);
+    const int64_t k0 = up_ptr[r];
+    const int len = rowok ? (int)(up_ptr[r + 1] - k0) : 0;
+    const double* __restrict__ v = up_val + k0;
+    const int* __restrict__ c = up_col + k0;
+    double pv[FC_DAG_PV];
+    int pc[FC_DAG_PV];
+#pragma unroll
+    for (int u = 0; u < FC_DAG_PV; ++u) {
+      const int e = l + u * LPR;
+      const int ee = e < len ? e : 0;  // (the arrays carry one padding entry behind the last row)
+      pv[u] = v[ee];
+      pc[u] = c[ee];
     }
     FC_STAMP(1);
     if (waits) {
@@ -241,54 +245,27 @@ __global__ __launch_bounds__(256) void fc_nd_dag(const FcDagTask* __restrict__ t
       if (!go) return;
     }
     FC_STAMP(2);
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int64_t qb = q0; qb < q1; qb += SW) {
-      FcSeg mine = first;
-      if (qb != q0) {
-        mine = FcSeg{0, 0, 0};
-        if (qb + sl < q1) mine = seg[qb + sl];
-      }
-      const int cntb = (int)((q1 - qb) < SW ? (q1 - qb) : SW);
-      for (int sbase = 0; sbase < cntb; sbase += G) {
-        const int sidx = sbase + g;
-        const int src = sidx < cntb ? (sidx % SW) : 0;
-        const long long vo = __shfl(mine.val, src, SW);
-        const int c = __shfl(mine.col, src, SW);
-        int len = __shfl(mine.len, src, SW);
-        if (sidx >= cntb) len = 0;
-        const double* __restrict__ v = val + vo;
-        const double* x = buf + c;  // up segments are contiguous slices of y (validated at setup)
-        const bool pre = qb == q0 && sbase == 0;
-        for (int base = 0; base < len; base += 4 * SUB) {
-          const int j0 = base + l2, j1 = j0 + SUB, j2 = j1 + SUB, j3 = j2 + SUB;
-          double v0, v1, v2, v3;
-          if (pre && base == 0) {
-            v0 = pv0, v1 = pv1, v2 = pv2, v3 = pv3;
-          } else {
-            const double a0 = v[j0 < len ? j0 : 0], a1 = v[j1 < len ? j1 : 0], a2 = v[j2 < len ? j2 : 0], a3 = v[j3 < len ? j3 : 0];
-            v0 = j0 < len ? a0 : 0.0, v1 = j1 < len ? a1 : 0.0, v2 = j2 < len ? a2 : 0.0, v3 = j3 < len ? a3 : 0.0;
-          }
-          const double x0 = fc_ld_sc1(x + (j0 < len ? j0 : 0)), x1 = fc_ld_sc1(x + (j1 < len ? j1 : 0));
-          const double x2 = fc_ld_sc1(x + (j2 < len ? j2 : 0)), x3 = fc_ld_sc1(x + (j3 < len ? j3 : 0));
-          s0 += v0 * x0;
-          s1 += v1 * x1;
-          s2 += v2 * x2;
-          s3 += v3 * x3;
-        }
-      }
-    }
-    double s = (s0 + s1) + (s2 + s3);
-    for (int off = SW >> 1; off > 0; off >>= 1) s += __shfl_down(s, off, SW);
-    if (LANES == 256) {
-      if (sl == 0) part[tid >> 6] = s;
+    double* dst = buf + t.dest0 + (rowok ? slot : 0);
+    const double own = fc_ld_sc1(dst);
+    double xv[FC_DAG_PV];
+#pragma unroll
+    for (int u = 0; u < FC_DAG_PV; ++u) xv[u] = fc_ld_sc1(buf + pc[u]);
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < FC_DAG_PV; ++u) acc += (l + u * LPR < len ? pv[u] : 0.0) * xv[u];
+    for (int e = l + FC_DAG_PV * LPR; e < len; e += LPR) acc += v[e] * fc_ld_sc1(buf + c[e]);  // rows longer than the register tile
+    double s = acc;
+    const int w = LPR < 64 ? LPR : 64;
+    for (int off = w >> 1; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (LPR > 64) {
+      if ((tid & 63) == 0) part[tid >> 6] = s;
       __syncthreads();
-      if (tid == 0 && rowok) {
-        double* d = buf + t.dest0;
-        fc_st_sc1(d, fc_ld_sc1(d) + ((part[0] + part[1]) + (part[2] + part[3])));
+      if (l == 0 && rowok) {
+        const int w0 = tid >> 6;
+        fc_st_sc1(dst, own + (LPR == 128 ? part[w0] + part[w0 + 1] : (part[0] + part[1]) + (part[2] + part[3])));
       }
-    } else if (rowok && lane == 0) {
-      double* d = buf + t.dest0 + rloc;
-      fc_st_sc1(d, fc_ld_sc1(d) + s);
+    } else if (l == 0 && rowok) {
+      fc_st_sc1(dst, own + s);
     }
   }
   // ── arrival: every wave drains its write-through stores, the workgroup meets, ONE lane signals ──

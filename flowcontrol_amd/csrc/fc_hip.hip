@@ -112,6 +112,14 @@ struct OrderSys {
   DevBuf<FcBlk> dag_blk;
   DevBuf<unsigned> dag_cnt;
   unsigned dag_epoch = 0;
+  // up-sweep rows of the one-launch apply: the -L values re-laid out row by row with explicit columns
+  // (dag_up_src: where each value sits in f_val; refreshed after every numeric factorisation)
+  DevBuf<int64_t> dag_up_ptr, dag_up_src;
+  DevBuf<int> dag_up_col;
+  DevBuf<double> dag_up_val;
+  int64_t dag_up_n = 0;
+  std::vector<int64_t> h_seg_ptr, h_seg_val;  // host copies of the segment lists (fc_solver_set_dag expands them)
+  std::vector<int> h_seg_col, h_seg_len;
   // optional explicit operator of the rhs (Crank-Nicolson): rows permuted, columns index u_n (W layout)
   DevBuf<int> c_rowptr, c_col;
   DevBuf<double> c_val;
@@ -503,9 +511,13 @@ int apply_factors_dag(fc_ctx* h, OrderSys& S, int first, int last) {
   FCCHK(time_begin(h, 0, cut ? 2 : 1));
   auto launch = [&](int s0, int s1) -> int {
     const int t0 = S.stages[s0].dag_task0, t1 = S.stages[s1].dag_task0 + S.stages[s1].dag_ntasks;
+    // FC_DAG_LDS_PAD (tuning aid): extra dynamic LDS per workgroup = fewer resident workgroups per CU, i.e. a
+    // shallower queue of value loads in front of the dependency-critical loads
+    // (measured on the 56 k-dof cylinder mesh: 6 / 4 / 3 / 2 / 1 workgroups per CU -> 101 / 93 / 85 / 108 / 168 us per apply)
+    static const int lds_pad = [] { const char* e = std::getenv("FC_DAG_LDS_PAD"); return e ? std::max(0, std::atoi(e)) : 36000; }();
     if (t1 > t0)
-      hipLaunchKernelGGL(fc_nd_dag, dim3(t1 - t0), dim3(256), 0, h->stream, S.dag_tasks.p + t0, S.dag_deps.p, S.dag_cnt.p,
-                         S.dag_epoch, h->dag_err.p, S.seg_ptr.p, S.seg.p, S.dag_blk.p, S.f_idx.p, S.f_val.p, h->buf.p, h->N,
+      hipLaunchKernelGGL(fc_nd_dag, dim3(t1 - t0), dim3(256), lds_pad, h->stream, S.dag_tasks.p + t0, S.dag_deps.p, S.dag_cnt.p,
+                         S.dag_epoch, h->dag_err.p, S.dag_up_ptr.p, S.dag_up_col.p, S.dag_up_val.p, S.dag_blk.p, S.f_idx.p, S.f_val.p, h->buf.p, h->N,
                          h->dag_trace.p ? h->dag_trace.p + (size_t)t0 * 8 : nullptr);
     HIPCHK(hipGetLastError());
     return FC_OK;
@@ -1331,6 +1343,10 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
   FCCHK(S.Ap_rowptr.upload(Ap_rowptr, N + 1, h->stream));
   FCCHK(S.Ap_col.upload(Ap_col, (size_t)S.Ap_nnz, h->stream));
   FCCHK(S.Ap_val.upload(Ap_val, (size_t)S.Ap_nnz, h->stream));
+  S.h_seg_ptr.assign(seg_ptr, seg_ptr + total_rows + 1);
+  S.h_seg_val.assign(seg_val, seg_val + n_seg);
+  S.h_seg_col.assign(seg_col, seg_col + n_seg);
+  S.h_seg_len.assign(seg_len, seg_len + n_seg);
   FCCHK(S.seg_ptr.upload(seg_ptr, (size_t)total_rows + 1, h->stream));
   {
     std::vector<FcSeg> packed((size_t)std::max<int64_t>(1, n_seg));
@@ -1464,6 +1480,31 @@ int fc_solver_set_dag(fc_handle h, int slot, int32_t n_nodes, const int64_t* nod
     }
     if (rows != S.stages[s].nrows) return fail(FC_ERR_INVALID, "fc_solver_set_dag: the nodes do not cover their stage");
   }
+  // the up-sweep rows, expanded: row r = concatenation of its segments, value source and buffer column per entry
+  int64_t n_up_rows = 0;
+  for (int s = 0; s < nst; ++s)
+    if (S.stages[s].kind == 0) {
+      if (S.stages[s].rp_begin != n_up_rows) return fail(FC_ERR_INVALID, "fc_solver_set_dag: up stages must come first");
+      n_up_rows += S.stages[s].nrows;
+    }
+  if ((int64_t)S.h_seg_ptr.size() < n_up_rows + 1) return fail(FC_ERR_INVALID, "fc_solver_set_dag: segment tables missing");
+  std::vector<int64_t> up_ptr((size_t)n_up_rows + 1, 0);
+  for (int64_t r = 0; r < n_up_rows; ++r) {
+    int64_t len = 0;
+    for (int64_t q = S.h_seg_ptr[r]; q < S.h_seg_ptr[r + 1]; ++q) len += S.h_seg_len[q];
+    up_ptr[r + 1] = up_ptr[r] + len;
+  }
+  const int64_t n_up = up_ptr[n_up_rows];
+  std::vector<int64_t> up_src((size_t)n_up + 1, 0);
+  std::vector<int> up_col((size_t)n_up + 1, 0);
+  for (int64_t r = 0; r < n_up_rows; ++r) {
+    int64_t k = up_ptr[r];
+    for (int64_t q = S.h_seg_ptr[r]; q < S.h_seg_ptr[r + 1]; ++q)
+      for (int j = 0; j < S.h_seg_len[q]; ++j, ++k) {
+        up_src[k] = S.h_seg_val[q] + j;
+        up_col[k] = S.h_seg_col[q] + j;  // up segments are contiguous slices of y (checked in fc_solver_setup)
+      }
+  }
   // tasks, stage by stage (= topological order)
   std::vector<FcDagTask> tasks;
   std::vector<FcBlk> blocks;
@@ -1475,14 +1516,19 @@ int fc_solver_set_dag(fc_handle h, int slot, int32_t n_nodes, const int64_t* nod
     for (int g : stage_nodes[s]) {
       Nd& d = nd[g];
       if (st.kind == 0) {
-        const int rpb = 256 / st.lanes;
-        for (int r0 = 0; r0 < d.ni; r0 += rpb) {
+        // rows of one node; lanes per row from the node's longest row (a lane holds <= FC_DAG_PV of its values)
+        const int64_t row_first = st.rp_begin + (d.i0 - st.row0);
+        int64_t maxlen = 1;
+        for (int r = 0; r < d.ni; ++r) maxlen = std::max(maxlen, up_ptr[row_first + r + 1] - up_ptr[row_first + r]);
+        const int lpr = std::min(256, std::max(8, pow2_ceil((int)((maxlen + FC_DAG_PV - 1) / FC_DAG_PV))));
+        const int R = 256 / lpr;
+        for (int r0 = 0; r0 < d.ni; r0 += R) {
           FcDagTask t{};
           t.kind = 0;
-          t.a = (int)(st.rp_begin + (d.i0 - st.row0) + r0);
-          t.nrows = std::min(rpb, d.ni - r0);
+          t.a = (int)(row_first + r0);
+          t.nrows = std::min(R, d.ni - r0);
           t.dest0 = d.i0 + r0;
-          t.geom = (st.lanes << 16) | st.sub;
+          t.geom = lpr;
           tasks.push_back(t);
           task_node.push_back(g);
           ++d.up_n;
@@ -1563,6 +1609,14 @@ int fc_solver_set_dag(fc_handle h, int slot, int32_t n_nodes, const int64_t* nod
   FCCHK(S.dag_blk.upload(blocks, h->stream));
   FCCHK(S.dag_cnt.alloc((size_t)std::max(words, FC_DAG_SHARD_STRIDE)));
   FCCHK(S.dag_cnt.zero(h->stream));
+  FCCHK(S.dag_up_ptr.upload(up_ptr, h->stream));
+  FCCHK(S.dag_up_src.upload(up_src, h->stream));
+  FCCHK(S.dag_up_col.upload(up_col, h->stream));
+  FCCHK(S.dag_up_val.alloc((size_t)n_up + 1));
+  S.dag_up_n = n_up;
+  // values as they stand now (host factorisation: final; device factorisation: refreshed by fc_refactor)
+  hipLaunchKernelGGL(fc_gather64, dim3(nblocks(n_up + 1, 256)), dim3(256), 0, h->stream, n_up + 1, S.dag_up_src.p, S.f_val.p, S.dag_up_val.p);
+  HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
   S.dag_epoch = 0;
   S.dag_ready = true;
@@ -1800,6 +1854,9 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
       }
     }
   }
+  if (S.dag_ready)  // row-by-row copy of the -L values for the one-launch apply
+    hipLaunchKernelGGL(fc_gather64, dim3(nblocks(S.dag_up_n + 1, 256)), dim3(256), 0, h->stream, S.dag_up_n + 1, S.dag_up_src.p, fv,
+                       S.dag_up_val.p);
   HIPCHK(hipEventRecord(h->ev1, h->stream));
   HIPCHK(hipEventSynchronize(h->ev1));
   float ms = 0.f;

@@ -12,6 +12,7 @@ import bench  # noqa: E402
 from flowcontrol_amd._lib import SLOT_BDF2  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+bench.REFINE = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 fs = bench.build_solver(0)
 u0 = np.zeros(2)
 fs.step(u0)

@@ -11,9 +11,11 @@ import bench  # noqa: E402
 from flowcontrol_amd._lib import SLOT_BDF2, check  # noqa: E402
 
 fs = bench.build_solver(0)
+import os
 fs.step(np.zeros(2))
 fs.step(np.zeros(2))
 dev = fs.th.device()
+dev.set_dag(True)
 n = dev.dag_info(SLOT_BDF2)["tasks"]
 st = np.zeros((n, 8), dtype=np.int64)
 stage = np.zeros(n, dtype=np.int32)
