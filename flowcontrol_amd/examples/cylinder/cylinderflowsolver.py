@@ -93,6 +93,18 @@ class CylinderFlowSolver(flowsolver.FlowSolver):
         bcu_actuation_lo = DirichletBC(W.sub(0), acts[1].expression, self.get_subdomain("actuator_lo"))
         return BoundaryConditions(bcu=[bcu_inlet, bcu_walls, bcu_cylinder, bcu_actuation_up, bcu_actuation_lo], bcp=[])
 
+    def compute_steady_state(self, u_ctrl, method="newton", **kwargs):
+        """Base flow, then the lift / drag coefficients of it as ``self.cl0, self.cd0`` (reference ``:110-113``)."""
+        super().compute_steady_state(method=method, u_ctrl=u_ctrl, **kwargs)
+        self.cl0, self.cd0 = self.compute_force_coefficients(self.fields.U0, self.fields.P0)
+
+    def compute_force_coefficients(self, u, p):
+        """(cl, cd) of the whole cylinder surface: body + both actuator slots (reference ``:115-126``)."""
+        from ...fem.forces import force_coefficients
+
+        parts = force_coefficients(self, u, p, ["cylinder", "actuator_up", "actuator_lo"])
+        return sum(v[0] for v in parts.values()), sum(v[1] for v in parts.values())
+
     @classmethod
     def make_default(cls, Re: float = 100, path_out=None, num_steps: int = 10, save_every: int = 0, Tstart: float = 0.0,
                      verbose: int = 0, meshpath: str | Path | None = None) -> "CylinderFlowSolver":

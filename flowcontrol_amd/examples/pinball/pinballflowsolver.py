@@ -115,6 +115,16 @@ class PinballFlowSolver(flowsolver.FlowSolver):
             bcp=[],
         )
 
+    def compute_force_coefficients(self, u, p) -> dict:
+        """{surface name: (cl, cd)} of every cylinder surface (reference ``pinballflowsolver.py:202-232``)."""
+        from ...fem.forces import force_coefficients
+
+        if self.params_control.user_data["mode_actuation"] == CYLINDER_ACTUATION_MODE.SUCTION:
+            surfaces = ["cylinder_mid", "actuator_mid", "cylinder_top", "actuator_top", "cylinder_bot", "actuator_bot"]
+        else:
+            surfaces = ["actuator_mid", "actuator_top", "actuator_bot"]
+        return force_coefficients(self, u, p, surfaces)
+
     @classmethod
     def make_default(cls, Re: float = 50, mode_actuation=None, path_out=None, num_steps: int = 10, save_every: int = 0,
                      Tstart: float = 0.0, verbose: int = 0, meshpath: str | Path | None = None) -> "PinballFlowSolver":

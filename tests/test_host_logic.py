@@ -462,3 +462,31 @@ def test_checkpoint_series_roundtrip(tmp_path):
     # starting over (append=False) resets the series
     assert write_xdmf(path, Function(V, frames[1]), "U", time_step=9.0, append=False) == 0
     assert read_xdmf(path, f, "U") == 9.0
+
+
+def test_boundary_force_of_a_linear_flow_on_the_unit_square():
+    """F = ∫ −σ·n ds with σ = ν(∇u + ∇uᵀ) − p I (reference physics.py:17-19, pinballflowsolver.py:202-232): for a
+    linear velocity and a linear pressure the facet integrals are known in closed form; over the closed boundary
+    the constant part of σ integrates to zero and the pressure gradient leaves −∇p · |Ω|."""
+    from flowcontrol_amd.fem.forces import boundary_force
+    from flowcontrol_amd.fem.mesh import Mesh
+    from flowcontrol_amd.fem.spaces import TaylorHood
+
+    th = TaylorHood(Mesh.unit_square(6, 6))
+    x = th.node_coords
+    a, b, c, d = 0.3, -1.1, 0.7, 0.45
+    u = np.r_[a * x[:, 0] + b * x[:, 1], c * x[:, 0] + d * x[:, 1]]
+    xv = th.mesh.coords
+    p = 2.0 + 0.5 * xv[:, 0] - 0.25 * xv[:, 1]
+    nu = 0.02
+    m = th.mesh
+    be = m.boundary_edges()
+    mid = m.edge_midpoints()[be]
+    right = be[np.isclose(mid[:, 0], 1.0)]
+    G = np.array([[a, b], [c, d]])
+    S = nu * (G + G.T)
+    # right edge: n = (1, 0); ∫ p ds over x = 1, y in [0, 1] = 2 + 0.5 − 0.125
+    Fx, Fy = boundary_force(th, right, nu, u, p)
+    assert np.isclose(Fx, -(S[0, 0] - 2.375)) and np.isclose(Fy, -S[1, 0])
+    Fx, Fy = boundary_force(th, be, nu, u, p)  # closed boundary: ∮ p n ds = ∇p |Ω|
+    assert np.isclose(Fx, 0.5, atol=1e-12) and np.isclose(Fy, -0.25, atol=1e-12)
