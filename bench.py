@@ -6,7 +6,7 @@
 Workload (BASELINE.json configs[1]): shipped coarse mesh O1 (12 284 P2/P1 triangles, 56 203
 DoFs), Re=100, dt=0.005, BDF1→BDF2, IC ParamIC(xloc=2, yloc=0, radius=0.5, amplitude=1), open loop
 u_ctrl=[0,0], energy every step.  A "step" is one public ``FlowSolver.step()`` call: RHS element
-loop with BC lifting → LU-grade solve (ND selected-inverse sweeps + 1 refinement) → shift →
+loop with BC lifting → LU-grade solve (ND selected-inverse sweeps, residual monitored every step) → shift →
 sensors → energy, synchronised back to the host every step as the reference's loop is.
 
 One JSON line on rank 0 with the driver's keys plus
@@ -199,22 +199,11 @@ def main() -> None:
         torch.cuda.synchronize()
 
     partitioned = world > 1 and not args.replicas
-    mode_note = ""
     t_setup = time.time()
     u0 = np.zeros(2)
-    fs = None
-    if partitioned:
-        try:
-            fs = build_solver(local, distributed=True)
-            fs.step(u0)  # BDF1 step: assembles, factorises, creates the RCCL communicator (setup, untimed)
-        except Exception as e:  # keep the N-GPU line alive: fall back to replicas and say so
-            mode_note = f"partitioned path failed ({type(e).__name__}: {e}); "
-            log(f"[rank {rank}] {mode_note}falling back to replicas")
-            partitioned = False
-            fs = None
-    if fs is None:
-        fs = build_solver(local, distributed=False)
-        fs.step(u0)  # BDF1 step: assembles + factorises both systems (setup, untimed)
+    # a failure of the partitioned path is a failure of the run: no silent fall-back to replicas
+    fs = build_solver(local, distributed=partitioned)
+    fs.step(u0)  # BDF1 step: assembles, factorises (partitioned: creates the RCCL communicator); setup, untimed
     log(f"[rank {rank}] setup {time.time() - t_setup:.1f}s; N={fs.th.N}; partitioned={partitioned}")
     for _ in range(max(args.warmup - 1, 0)):
         fs.step(u0)
@@ -310,14 +299,15 @@ def main() -> None:
             "scaling": "strong" if partitioned else "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "the reference's shipped mesh O1 (converted data file) + base flow computed by the oracle (golden fixture); "
+                    "IC and actuation as run_cylinder_example.py",
             "config": {
                 "workload": f"cylinder Re=100, mesh O1{' red-refined x' + str(REFINE) if REFINE else ''} ({fs.th.nc} cells, {fs.th.N} dofs), "
                 "dt=0.005, BDF2, open loop, IC div-free vortex (2,0) r=0.5, sensors+energy every step",
                 "parallelism": "single GPU" if world == 1 else (
                     f"row-partitioned over {world} GPUs: one elimination sub-tree + its cells per rank, replicated root "
                     f"separator, 2 RCCL all-reduces per step" if partitioned
-                    else mode_note + f"{world} independent replicas (no data-path collective)"),
+                    else f"{world} independent replicas (no data-path collective)"),
                 "partition": part_info,
                 "solver": f"ND selected-inverse depth {dev.tree.depth}, {fs.refine_steps} refinement",
             },

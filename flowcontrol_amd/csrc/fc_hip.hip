@@ -2017,9 +2017,9 @@ int fc_step(fc_handle h, int order_slot, const double* u_ctrl, const double* u_f
   const double seq = (double)(++h->seq);
   FCCHK(enqueue_step(h, order_slot, dev, dev + 64, dev + 128, dev + 129, dev + 136, compute_energy, dev + 32, dev + 137, seq));
   speculate_next_rhs(h, order_slot);
-  // the last kernel publishes `seq` behind a system-scope fence: poll the host-mapped word (bounded),
-  // then fall back to a stream synchronisation — which is also what reports a faulted kernel
-  // A record is accepted only when its checksum (fc_publish) agrees with the words actually read: the
+  // the last kernel publishes the record and `seq` with no fence: poll the host-mapped words (bounded), then fall
+  // back to a stream synchronisation — which is also what reports a faulted kernel.
+  // A record is accepted only when both of its checksums (fc_publish) agree with the words actually read: the
   // individual device writes may become visible to the host in any order.
   auto bits = [](double v) {
     unsigned long long u;
@@ -2028,10 +2028,18 @@ int fc_step(fc_handle h, int order_slot, const double* u_ctrl, const double* u_f
   };
   auto record_ok = [&]() {
     if (pin[137] != seq) return false;
-    unsigned long long x = bits(seq);
-    for (int s = 0; s < h->n_sens; ++s) x ^= bits(pin[64 + s]);
-    x ^= bits(pin[128]) ^ bits(pin[129]) ^ bits(pin[130]) ^ bits(pin[136]);
-    return x == bits(pin[138]);
+    unsigned long long x = bits(seq), w = x, k = 3;
+    for (int s = 0; s < h->n_sens; ++s, k += 2) {
+      const unsigned long long v = bits(pin[64 + s]);
+      x ^= v;
+      w += k * v;
+    }
+    const unsigned long long tail[4] = {bits(pin[128]), bits(pin[129]), bits(pin[130]), bits(pin[136])};
+    for (int i = 0; i < 4; ++i, k += 2) {
+      x ^= tail[i];
+      w += k * tail[i];
+    }
+    return x == bits(pin[138]) && w == bits(pin[139]);
   };
   bool seen = false;
   if (!h->timing) {

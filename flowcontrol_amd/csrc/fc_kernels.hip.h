@@ -805,18 +805,23 @@ __global__ __launch_bounds__(256) void fc_finish(int N, int nn2, const int* __re
 }
 
 // The step record (y[n_sens], E, |r|^2, |b|^2, flag) may live in host-mapped memory that the host polls
-// instead of synchronising the stream.  ONE thread writes the whole record, then a checksum (XOR of
-// the bit patterns of every word and of the sequence number) and the sequence number itself: the
-// host accepts a record only when the sequence number matches AND the checksum agrees with what it
+// instead of synchronising the stream.  ONE thread writes the whole record, then two checksums over the bit
+// patterns of every word and of the sequence number (an XOR, and a position-weighted sum modulo 2^64 with odd
+// weights: two torn words that cancel in the XOR do not cancel in the weighted sum) and the sequence number
+// itself: the host accepts a record only when the sequence number matches AND both checksums agree with what it
 // reads, so it is immune to the order in which the individual writes become visible across PCIe.
 __device__ inline void fc_publish(const double* ysrc, int n_sens, double E, double r0, double r1, double fl,
                                   double* __restrict__ y, double* __restrict__ E_out, double* __restrict__ r_out,
                                   double* __restrict__ flag_out, double* __restrict__ seq_out, double seq) {
-  unsigned long long x = (unsigned long long)__double_as_longlong(seq);
-  for (int s = 0; s < n_sens; ++s) {
+  typedef unsigned long long u64;
+  u64 x = (u64)__double_as_longlong(seq);
+  u64 w = x;  // weights 1, 3, 5, ... (odd: invertible modulo 2^64)
+  u64 k = 3;
+  for (int s = 0; s < n_sens; ++s, k += 2) {
     const double v = ysrc[s];
     if (y) y[s] = v;
-    x ^= (unsigned long long)__double_as_longlong(v);
+    x ^= (u64)__double_as_longlong(v);
+    w += k * (u64)__double_as_longlong(v);
   }
   if (E_out) E_out[0] = E;
   if (r_out) {
@@ -824,20 +829,25 @@ __device__ inline void fc_publish(const double* ysrc, int n_sens, double E, doub
     r_out[1] = r1;
   }
   if (flag_out) flag_out[0] = fl;
-  x ^= (unsigned long long)__double_as_longlong(E) ^ (unsigned long long)__double_as_longlong(r0) ^
-       (unsigned long long)__double_as_longlong(r1) ^ (unsigned long long)__double_as_longlong(fl);
+  const u64 tail[4] = {(u64)__double_as_longlong(E), (u64)__double_as_longlong(r0), (u64)__double_as_longlong(r1),
+                       (u64)__double_as_longlong(fl)};
+  for (int i = 0; i < 4; ++i, k += 2) {
+    x ^= tail[i];
+    w += k * tail[i];
+  }
   if (seq_out) {
     // no fences: the host does not rely on the order in which these words arrive (it re-checks the
-    // checksum until it fits), and the end of the kernel makes all of them visible
+    // checksums until they fit), and the end of the kernel makes all of them visible
     seq_out[1] = __longlong_as_double((long long)x);
+    seq_out[2] = __longlong_as_double((long long)w);
     seq_out[0] = seq;
   }
 }
 
 // tail of a step, ONE workgroup: folds the energy partials (-> E = 1/2 sum) and, if present, the
 // residual partials (sum r^2, sum b^2), evaluates the sensor rows (y_s = sum_k w[k] up[idx[k]],
-// sensor.py:96-98,166-197) and publishes everything to the (host-mapped) record; the step sequence
-// number is written last, behind a system-scope fence, so the host can poll it instead of
+// sensor.py:96-98,166-197) and publishes everything to the (host-mapped) record with its checksums
+// (fc_publish: no fence, the host validates what it reads), so the host can poll it instead of
 // synchronising the stream.  Fixed summation order => reproducible.
 __global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restrict__ e_partial,
                                                 double* __restrict__ E_out, int n_r,

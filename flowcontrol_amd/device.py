@@ -85,6 +85,14 @@ class DeviceSolver:
             # host-staged exchange (fc_step_phase): no RCCL communicator; ``host_allreduce(array)``
             # sums a float64 array over the ranks in place
             return
+        import sys
+
+        torch = sys.modules.get("torch")
+        if world > 1 and torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized() \
+                and torch.cuda.current_device() != self.device_index:
+            # one process per GPU: RCCL would see duplicate devices if every rank's handle sat on GPU 0
+            raise _lib.FcError(_lib.FC_ERR_INVALID, f"rank {rank}: the solver handle lives on GPU {self.device_index} but this process's "
+                               f"current GPU is {torch.cuda.current_device()} (create the solver after torch.cuda.set_device(LOCAL_RANK))")
         buf = C.create_string_buffer(128)
         if rank == 0:
             check(self.lib.fc_comm_unique_id(buf))

@@ -319,12 +319,34 @@ class TaylorHood:
 __all__ = ["Vector", "FunctionSpace", "Function", "TaylorHood"]
 
 
-def _th_device(self, device_index: int = 0):
-    """The MI355X handle bound to this discretisation (created on first use; no CPU fallback)."""
+def default_device_index() -> int:
+    """GPU of this process: ``FC_DEVICE`` if set; else, in a one-process-per-GPU launch (``LOCAL_RANK`` in the
+    environment, as ``torchrun`` sets it), the local rank folded onto the visible devices; else torch's current
+    device when torch has already initialised the GPU runtime in this process; else 0."""
+    import os
+    import sys
+
+    from .. import _lib
+
+    if os.environ.get("FC_DEVICE"):
+        return int(os.environ["FC_DEVICE"])
+    if os.environ.get("LOCAL_RANK"):
+        return int(os.environ["LOCAL_RANK"]) % max(_lib.device_count(), 1)
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+        return int(torch.cuda.current_device())
+    return 0
+
+
+def _th_device(self, device_index: int | None = None):
+    """The MI355X handle bound to this discretisation (created on first use; no CPU fallback).
+    ``device_index=None``: :func:`default_device_index` — one process per GPU binds its own GPU."""
     if getattr(self, "_device", None) is None:
         from ..device import DeviceSolver
 
-        self._device = DeviceSolver(self, device_index)
+        self._device = DeviceSolver(self, default_device_index() if device_index is None else int(device_index))
+    elif device_index is not None and int(device_index) != self._device.device_index:
+        raise RuntimeError(f"this discretisation is already bound to GPU {self._device.device_index}, not {device_index}")
     return self._device
 
 

@@ -62,12 +62,22 @@ class FlowFieldCollection:
         self._store: dict[str, Function | None] = {k: None for k in _LAZY}
         self._sync: Callable[[], None] | None = None
         self._stale = False
+        self._dirty = False  # a field was replaced on the host after the state went to the device
 
     def _set_sync(self, fn: Callable[[], None] | None) -> None:
         self._sync = fn
 
     def _mark_stale(self) -> None:
         self._stale = True
+
+    def push(self) -> None:
+        """Declare the host copies of ``u_n, u_nn, p_n`` authoritative: the next ``step()`` / ``run()`` uploads them
+        before it advances.  Assigning a field (``fields.u_n = f``) does this by itself; IN-PLACE edits
+        (``fields.u_n.vector()[:] = ...``) cannot be seen and need this call.  (In the reference these Functions
+        are the state the next right-hand side reads; here that state lives in HBM while stepping.)
+        On several ranks reading a field is collective (every rank contributes its dofs): read on all ranks."""
+        self._get("u_n")  # make sure the host copies are current before they become the source
+        self._dirty = True
 
     def _get(self, name: str):
         if self._stale and self._sync is not None:
@@ -81,6 +91,9 @@ def _lazy_property(name: str):
         return self._get(name)
 
     def setter(self, value):
+        if self._sync is not None and name in ("u_n", "u_nn", "p_n"):
+            self._get(name)  # bring the other fields up to date first: the upload takes all three from the host
+            self._dirty = True
         self._store[name] = value
 
     return property(getter, setter)

@@ -296,7 +296,7 @@ class FlowSolver(ABC):
             raise ValueError(f"method must be 'newton' or 'picard', got {method!r}")
         self._mass_ready = False
         U0, P0 = UP0.split(deepcopy=True)
-        if self.params_save.save_every:
+        if self.params_save.save_every and self._is_writer():
             write_frame(self.paths.U0, U0, 0, name="U0")
             write_frame(self.paths.P0, P0, 0, name="P0")
             self.paths.steady_meta.parent.mkdir(parents=True, exist_ok=True)
@@ -382,7 +382,7 @@ class FlowSolver(ABC):
         p_n = self.fields.ic.p.copy(deepcopy=True)
         u_ = u_n.copy(deepcopy=True)
         p_ = p_n.copy(deepcopy=True)
-        if self.params_save.save_every:
+        if self.params_save.save_every and self._is_writer():
             self.exporter.export_xdmf(u_n, u_nn, p_n, time=0.0, append=False, write_mesh=True, adjust_baseflow=1.0)
         return u_, p_, u_n, u_nn, p_n
 
@@ -433,7 +433,7 @@ class FlowSolver(ABC):
         U_n, P_n = U_.copy(deepcopy=True), P_.copy(deepcopy=True)
         if self.fields.U0 is None:
             raise RuntimeError("no base flow: call load_steady_state() before restarting")
-        if self.params_save.save_every:
+        if self.params_save.save_every and self._is_writer():
             # full fields were read: no base-flow adjustment (reference :633-643)
             self.exporter.export_xdmf(U_n, U_nn, P_n, time=Tstart, append=False, write_mesh=True, adjust_baseflow=0.0)
         U0v, P0v = self.fields.U0.vector().array(), self.fields.P0.vector().array()
@@ -520,7 +520,26 @@ class FlowSolver(ABC):
         f = self.fields
         self.th.device().set_state(f._store["u_n"].vector().array(), f._store["u_nn"].vector().array(), f._store["p_n"].vector().array())
         self._state_uploaded = True
+        f._dirty = False
+        f._stale = False
         self.fields._set_sync(self._download_fields)
+
+    def _begin_stepping(self) -> None:
+        """Operators on the device, state in HBM — and again whenever the host replaced a field (``fields.push()``)."""
+        if self.first_step:
+            if not self._systems_ready:
+                self._prepare_systems(self.fields._store["u_n"], self.fields._store["u_nn"])
+            if not self._state_uploaded:
+                self._upload_state()
+            self.first_step = False
+        if self.fields._dirty:
+            self._upload_state()  # fc_set_state also drops the speculated right-hand side and the divergence flag
+
+    def _is_writer(self) -> bool:
+        """Files (checkpoints, sidecars, CSV) are written by rank 0 only, as the reference does (exporter.py:260,266)."""
+        from .utils import get_rank
+
+        return get_rank() == 0
 
     def _download_fields(self) -> None:
         dev = self.th.device()
@@ -535,7 +554,7 @@ class FlowSolver(ABC):
             flat = np.concatenate([np.where(m[:nn2], u_n, 0.0), np.where(m[:nn2], u_nn, 0.0), np.where(m[nn2:], p_n, 0.0)])
             tns = torch.from_numpy(flat)
             if dist.get_backend() == "nccl":
-                tns = tns.cuda()
+                tns = tns.to(torch.device("cuda", dev.device_index))  # the GPU this rank's handle lives on
             dist.all_reduce(tns)
             flat = tns.cpu().numpy()
             u_n, u_nn, p_n = flat[:nn2], flat[nn2 : 2 * nn2], flat[2 * nn2 :]
@@ -549,13 +568,9 @@ class FlowSolver(ABC):
 
     def step(self, u_ctrl: NDArray[np.float64]) -> NDArray[np.float64] | None:
         """Advance by one Δt; returns the measurement vector, or ``None`` if the solver diverged and
-        ``params_solver.throw_error`` is False (reference ``:703-799``)."""
-        if self.first_step:
-            if not self._systems_ready:
-                self._prepare_systems(self.fields._store["u_n"], self.fields._store["u_nn"])
-            if not self._state_uploaded:
-                self._upload_state()
-            self.first_step = False
+        ``params_solver.throw_error`` is False (reference ``:703-799``).  After a divergence the device state holds
+        the non-finite field (the reference leaves ``u_n`` untouched): re-initialise or ``fields.push()`` a state."""
+        self._begin_stepping()
         t0 = time.time()
         u_ctrl = np.atleast_1d(np.asarray(u_ctrl, dtype=np.float64))
         self.set_actuators_u_ctrl(u_ctrl)
@@ -570,6 +585,7 @@ class FlowSolver(ABC):
             y, dE, info = self.th.device().step(SLOT_BDF2 if self.order == 2 else SLOT_BDF1, u_ctrl, compute_energy=want_energy, u_force=u_force)
         except FcDiverged:
             logger.critical("Solver diverged (Inf detected)")
+            self.fields._mark_stale()  # the host mirrors no longer describe the device state
             if not self.params_solver.throw_error:
                 return None
             raise RuntimeError("Failed solving: Inf found in solution")
@@ -579,6 +595,7 @@ class FlowSolver(ABC):
             logger.critical(msg)
             if self.params_solver.throw_error:
                 raise RuntimeError(msg)
+            return None  # as a divergence: the factors (or the system) are broken, do not keep stepping silently
         self.iter = next_iter
         self.t = self.params_time.Tstart + self.iter * self.params_time.dt
         self._u_ctrl_prev = u_ctrl.copy()
@@ -592,43 +609,63 @@ class FlowSolver(ABC):
         at_checkpoint = self._niter_multiple_of(self.iter, self.params_save.save_every)
         self.exporter.log(u_ctrl=u_ctrl, y_meas=self.y_meas, dE=dE if want_energy else np.nan, t=self.t, runtime=runtime)
         if at_checkpoint:
-            self.exporter.export_xdmf(self.fields.u_n, self.fields.u_nn, self.fields.p_n, time=self.t, adjust_baseflow=1.0)
-            self.exporter.write_metadata(restart_order="cn" if self.params_solver.time_scheme == "cn" else 2)
-            self.exporter.write_timeseries()
+            self._checkpoint()
         return self.y_meas
 
-    def run(self, n_steps: int, u_ctrl) -> tuple[np.ndarray, np.ndarray]:
+    def _checkpoint(self) -> None:
+        u_n, u_nn, p_n = self.fields.u_n, self.fields.u_nn, self.fields.p_n  # collective on several ranks
+        if self._is_writer():
+            self.exporter.export_xdmf(u_n, u_nn, p_n, time=self.t, adjust_baseflow=1.0)
+            self.exporter.write_metadata(restart_order="cn" if self.params_solver.time_scheme == "cn" else 2)
+            self.exporter.write_timeseries()
+
+    def run(self, n_steps: int, u_ctrl) -> tuple[np.ndarray, np.ndarray] | None:
         """Open-loop batch of ``n_steps`` steps with no host synchronisation in between (device
-        extension; not in the reference).  ``u_ctrl``: (n_act,) constant or (n_steps, n_act)."""
-        if self.first_step:
-            if not self._systems_ready:
-                self._prepare_systems(self.fields._store["u_n"], self.fields._store["u_nn"])
-            if not self._state_uploaded:
-                self._upload_state()
-            self.first_step = False
+        extension; not in the reference).  ``u_ctrl``: (n_act,) constant or (n_steps, n_act).
+
+        Same log as ``n_steps`` calls of :meth:`step`: dE is NaN off the ``energy_every`` multiples, checkpoints are
+        written at the ``save_every`` multiples (the batch is cut there).  On a divergence the device state has
+        advanced to the non-finite step; ``None`` is returned when ``throw_error`` is False."""
+        self._begin_stepping()
         u = np.asarray(u_ctrl, dtype=np.float64)
         if self.order == "cn":
             raise NotImplementedError("FlowSolver.run (batched) supports the BDF scheme only; use step() with time_scheme='cn'")
-        t0 = time.time()
-        try:
-            y, dE = self.th.device().run(SLOT_BDF1 if self.order == 1 else SLOT_BDF2, n_steps, u, compute_energy=bool(self.params_save.energy_every))
-        except FcDiverged:
-            if not self.params_solver.throw_error:
-                return None
-            raise RuntimeError("Failed solving: Inf found in solution")
-        runtime = (time.time() - t0) / n_steps
-        for s in range(n_steps):
-            self.iter += 1
-            self.t = self.params_time.Tstart + self.iter * self.params_time.dt
-            us = u[s] if u.ndim == 2 else np.atleast_1d(u)
-            self.exporter.log(u_ctrl=us, y_meas=y[s], dE=dE[s], t=self.t, runtime=runtime)
-        self.order = 2
-        self.y_meas = y[-1].copy()
-        self.fields._mark_stale()
-        return y, dE
+        every = self.params_save.energy_every
+        ys, dEs = [], []
+        done = 0
+        while done < n_steps:
+            n = n_steps - done
+            if self.params_save.save_every:  # stop at the next checkpoint
+                n = min(n, self.params_save.save_every - self.iter % self.params_save.save_every)
+            t0 = time.time()
+            try:
+                y, dE = self.th.device().run(SLOT_BDF1 if self.order == 1 else SLOT_BDF2, n, u[done : done + n] if u.ndim == 2 else u,
+                                             compute_energy=bool(every))
+            except FcDiverged:
+                self.fields._mark_stale()
+                if not self.params_solver.throw_error:
+                    return None
+                raise RuntimeError("Failed solving: Inf found in solution")
+            runtime = (time.time() - t0) / n
+            for s in range(n):
+                self.iter += 1
+                self.t = self.params_time.Tstart + self.iter * self.params_time.dt
+                us = u[done + s] if u.ndim == 2 else np.atleast_1d(u)
+                if not self._niter_multiple_of(self.iter, every):
+                    dE[s] = np.nan
+                self.exporter.log(u_ctrl=us, y_meas=y[s], dE=dE[s], t=self.t, runtime=runtime)
+            self.order = 2
+            self.y_meas = y[-1].copy()
+            self.fields._mark_stale()
+            ys.append(y), dEs.append(dE)
+            done += n
+            if self._niter_multiple_of(self.iter, self.params_save.save_every):
+                self._checkpoint()
+        return np.vstack(ys), np.concatenate(dEs)
 
     def write_timeseries(self) -> None:
-        self.exporter.write_timeseries()
+        if self._is_writer():
+            self.exporter.write_timeseries()
 
     @property
     def timeseries(self) -> pd.DataFrame:

@@ -395,3 +395,88 @@ def test_device_base_flow_matches_golden(case, tmp_path_factory, golden_dir):
     nv2 = 2 * fs.th.nn
     assert _rel_l2(fs.fields.UP0.vector().get_local()[:nv2], g["UP0"][:nv2]) < 1e-10
     fs.th.release_device()
+
+
+def test_non_finite_state_is_reported_as_divergence(tmp_path_factory, golden_dir):
+    """reference flowsolver.py:727-737,816-819: a non-finite velocity after the solve is FC_ERR_DIVERGED at the C ABI,
+    RuntimeError("Failed solving…") from FlowSolver.step — or None when ParamSolver.throw_error is False."""
+    from flowcontrol_amd._lib import FC_ERR_DIVERGED, SLOT_BDF2, FcDiverged
+
+    for throw in (True, False):
+        fs = CylinderFlowSolver.make_default(Re=100, path_out=tmp_path_factory.mktemp(f"diverge{int(throw)}"), num_steps=5)
+        fs.params_solver.throw_error = throw
+        _load_baseflow(fs, golden_dir)
+        fs.initialize_time_stepping(ic=None)
+        assert fs.step([0.0, 0.0]) is not None
+        dev = fs.th.device()
+        u_n, u_nn, p_n = dev.get_state()
+        u_bad = u_n.copy()
+        u_bad[17] = np.inf
+        dev.set_state(u_bad, u_nn, p_n)
+        if throw:
+            with pytest.raises(FcDiverged) as e:  # the C ABI status itself
+                dev.step(SLOT_BDF2, np.zeros(2))
+            assert e.value.code == FC_ERR_DIVERGED
+            dev.set_state(u_bad, u_nn, p_n)
+            with pytest.raises(RuntimeError, match="Failed solving"):
+                fs.step([0.0, 0.0])
+        else:
+            assert fs.step([0.0, 0.0]) is None
+            # a pushed finite state makes the solver usable again
+            fs.fields.u_n = Function(fs.V, u_n)
+            fs.fields.u_nn = Function(fs.V, u_nn)
+            y = fs.step([0.0, 0.0])
+            assert y is not None and np.all(np.isfinite(y))
+        fs.th.release_device()
+
+
+def test_host_edits_of_the_state_reach_the_device(tmp_path_factory, golden_dir):
+    """Assigning fields.u_n (or fields.push() after an in-place edit) makes the next step start from the edited state,
+    as in the reference where these Functions ARE the state (flowsolver.py:746-751)."""
+    fs = CylinderFlowSolver.make_default(Re=100, path_out=tmp_path_factory.mktemp("push_a"), num_steps=5)
+    fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
+    _load_baseflow(fs, golden_dir)
+    fs.initialize_time_stepping(ic=None)
+    fs.step([0.0, 0.0])
+    fs.step([0.0, 0.0])
+    u_n = fs.fields.u_n.vector().get_local().copy()
+    u_nn = fs.fields.u_nn.vector().get_local().copy()
+    y_plain = fs.step([0.01, 0.0]).copy()
+    # rewind by assignment, halve by an in-place edit + push: both must be seen by the next step
+    fs.fields.u_n = Function(fs.V, u_n)
+    fs.fields.u_nn = Function(fs.V, u_nn)
+    y_again = fs.step([0.01, 0.0]).copy()
+    assert np.array_equal(y_again, y_plain)
+    fs.fields.u_n = Function(fs.V, u_n)
+    fs.fields.u_nn = Function(fs.V, u_nn)
+    fs.fields.u_n.vector()[:] = 0.5 * u_n
+    fs.fields.push()
+    y_half = fs.step([0.01, 0.0]).copy()
+    assert not np.allclose(y_half, y_plain, rtol=1e-6)
+    fs.th.release_device()
+
+
+def test_batched_run_logs_like_eager_steps(tmp_path_factory, golden_dir):
+    """FlowSolver.run must leave the same log as step(): NaN off the energy_every multiples, checkpoints at save_every."""
+    logs = []
+    for mode in ("eager", "batched"):
+        out = tmp_path_factory.mktemp(f"runlog_{mode}")
+        fs = CylinderFlowSolver.make_default(Re=100, path_out=out, num_steps=12, save_every=5)
+        fs.params_save.energy_every = 3
+        fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
+        _load_baseflow(fs, golden_dir)
+        fs.initialize_time_stepping(ic=None)
+        fs.step([0.0, 0.0])
+        if mode == "eager":
+            for _ in range(11):
+                fs.step([0.0, 0.0])
+        else:
+            fs.run(11, np.zeros(2))
+        ts = fs.timeseries
+        logs.append((ts["dE"].to_numpy(), ts[["y_meas_1", "y_meas_2", "y_meas_3"]].to_numpy(), fs.exporter._checkpoints_written,
+                     fs.fields.Usave.vector().get_local().copy()))
+        fs.th.release_device()
+    (ea, ya, ca, ua), (eb, yb, cb, ub) = logs
+    assert np.array_equal(np.isnan(ea), np.isnan(eb)) and np.isnan(ea[1]) and not np.isnan(ea[3])
+    assert np.array_equal(ea[~np.isnan(ea)], eb[~np.isnan(eb)]) and np.array_equal(ya, yb)
+    assert ca == cb == 2 and np.array_equal(ua, ub)
