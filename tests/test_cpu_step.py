@@ -1,0 +1,34 @@
+"""The compiled CPU restatement (oracle/cpu_step.cpp: the CPU baseline of bench.py) against the numpy oracle."""
+import numpy as np
+
+from flowcontrol_amd.fem.mesh import read_xdmf_mesh
+from flowcontrol_amd.fem.spaces import TaylorHood
+from oracle import cpu_step
+from oracle import ns_oracle as O
+
+
+def test_compiled_step_matches_the_numpy_oracle(golden_dir):
+    th = TaylorHood(read_xdmf_mesh(golden_dir / "meshes" / "O1.npz"))
+    d = O.Disc.from_taylor_hood(th)
+    rng = np.random.default_rng(0)
+    x = th.node_coords
+    U0 = np.r_[1.0 + 0.3 * np.sin(x[:, 0]), 0.2 * np.cos(x[:, 1])]
+    m = th.mesh
+    be = m.boundary_edges()
+    nodes = np.unique(np.r_[m.edges[be].reshape(-1), th.nv + be])[:200]
+    dofs = np.sort(np.r_[nodes, nodes + th.nn])
+    prof = np.stack([np.sin(3.0 * np.arange(dofs.size)), np.cos(2.0 * np.arange(dofs.size))], axis=1)
+    force = 0.1 * rng.standard_normal((2 * th.nn, 2))
+    ts = O.TimeStepper(d, 100.0, 0.005, U0, dofs, prof, force_profiles=force)
+    rows = [th.point_eval_row((3.0, 0.0), 1), th.point_eval_row((3.1, 1.0), 0)]
+    cs = cpu_step.CompiledStepper(ts, rows)
+    u_n, u_nn = 0.1 * rng.standard_normal(2 * th.nn), 0.1 * rng.standard_normal(2 * th.nn)
+    uc = np.array([0.3, -0.2])
+    for order in (1, 2):
+        b_ref = ts.rhs(order, u_n, u_nn, uc)
+        b = cs.rhs(order, u_n, u_nn, uc)
+        assert np.linalg.norm(b - b_ref) <= 1e-12 * np.linalg.norm(b_ref)
+    M = O.velocity_mass(d)
+    assert np.isclose(cs.energy(u_n), 0.5 * u_n @ (M @ u_n), rtol=1e-12)
+    up = rng.standard_normal(th.N)
+    assert np.allclose(cs.sensors(up), [w @ up[i] for i, w in rows], rtol=1e-13)
