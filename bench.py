@@ -134,7 +134,7 @@ def _cpu_baseline_1core(fs, O, n_steps, warm) -> dict:
         "cores": 1,
         "kind": "port",
         "sample": f"{n_steps} steps of the same workload after {warm} warm-up steps (factorisations excluded), compiled C++ restatement "
-        f"(oracle/cpu_step.cpp, g++ -O3 -march=native): {mean_c * 1e3:.2f} ms/step = element-loop RHS + lifting {asm_c * 1e3:.2f} ms + SuperLU "
+        f"(oracle/cpu_step.cpp, g++ -O3 -march=x86-64-v3 (portable to the GPU box's host CPU)): {mean_c * 1e3:.2f} ms/step = element-loop RHS + lifting {asm_c * 1e3:.2f} ms + SuperLU "
         f"triangular solves (ND ordering) {sol_c * 1e3:.2f} ms + sensors/energy; 1 thread (threadpool_limits); host has {os.cpu_count()} logical cores",
         "numpy_oracle": {"value": 1.0 / mean_n, "ms_per_step": mean_n * 1e3, "rhs_ms": asm_n * 1e3, "solve_ms": sol_n * 1e3, "steps": n_np,
                          "note": "ns_oracle.py (einsum element loop): the parity specification, not a fair timing baseline"},

@@ -1,6 +1,6 @@
 """ctypes wrapper of ``oracle/cpu_step.cpp`` — TEST INFRASTRUCTURE / CPU BASELINE, never imported by the product.
 
-``build()`` compiles the C++ restatement in-tree (``oracle/_build/libcpu_step.so``; g++ -O3 -march=native, one thread).
+``build()`` compiles the C++ restatement in-tree (``oracle/_build/libcpu_step.so``; g++ -O3 -march=x86-64-v3, one thread).
 :class:`CompiledStepper` is the compiled counterpart of ``ns_oracle.TimeStepper``: same operators and SuperLU factors,
 but the per-step right-hand side (element loop + lifting), the sensors and the energy run as compiled scalar code —
 what FFC-generated kernels do for the reference (``flowsolver.py:721-762``)."""
@@ -26,7 +26,7 @@ def build(force: bool = False) -> Path:
     if gxx is None:
         raise RuntimeError("g++ not found: cannot build oracle/cpu_step.cpp")
     LIB.parent.mkdir(parents=True, exist_ok=True)
-    cmd = [gxx, "-O3", "-march=native", "-std=c++17", "-fPIC", "-shared", "-o", str(LIB), str(SRC)]
+    cmd = [gxx, "-O3", "-march=x86-64-v3", "-std=c++17", "-fPIC", "-shared", "-o", str(LIB), str(SRC)]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"g++ failed:\n{res.stderr}")
