@@ -77,7 +77,7 @@ SIGNATURES: dict[str, list] = {
     "fc_set_time_scheme": [_H, C.c_double, C.c_int],
     "fc_apply_bc": [_H, C.c_int],
     "fc_set_permutation": [_H, _ip],
-    "fc_solver_setup": [_H, C.c_int, _ip, _ip, _dp, C.c_int32, _lp, _ip, _ip, _ip, _lp, C.c_int64, _lp, _ip, _ip, C.c_int64, _ip, C.c_int64, _dp, C.c_int32, C.c_int32, C.c_int32],
+    "fc_solver_setup": [_H, C.c_int, _ip, _ip, _dp, C.c_int32, _lp, _ip, _ip, _ip, _lp, C.c_int64, _lp, _ip, _ip, C.c_int64, _ip, C.c_int64, _dp, C.c_int32, C.c_int32, C.c_int32, C.c_int32],
     "fc_set_energy_matrix": [_H, _ip, _ip, _dp],
     "fc_factor_plan": [_H, C.c_int32, _lp, C.c_int32, _lp, C.c_int64, C.c_int64, _lp, _lp, _lp, _lp, C.c_int64, _ip, C.c_int64, _lp, C.c_int32],
     "fc_refactor": [_H, C.c_int, C.c_void_p],
@@ -101,7 +101,7 @@ SIGNATURES: dict[str, list] = {
     "fc_set_partition": [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_int],
     "fc_comm_unique_id": [C.c_char_p],
     "fc_comm_init": [_H, C.c_int, C.c_int, C.c_char_p],
-    "fc_step_phase": [_H, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
+    "fc_set_host_exchange": [_H, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     "fc_set_timing": [_H, C.c_int],
     "fc_get_timing": [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "fc_algorithmic_bytes": [_H, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)],
@@ -111,6 +111,9 @@ SIGNATURES: dict[str, list] = {
     "fc_debug_inject_dag_failure": [_H, C.c_int],
     "fc_debug_trace_apply": [_H, C.c_int, C.c_int32, _lp, _ip, _ip],
 }
+
+#: void (*fc_exchange_fn)(double* buf, int64_t n, void* user)
+EXCHANGE_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int64, C.c_void_p)
 
 _lib = None
 

@@ -105,6 +105,7 @@ struct OrderSys {
   std::vector<Stage> stages;
   double sweep_bytes = 0.0;
   int ar_stage = -1, ar_row0 = 0, ar_n = 0;  // all-reduce buf[ar_row0 .. +ar_n) after this stage
+  int ar2_stage = -1;  // the root's down stage (this rank's block of rows): x[ar_row0 .. +ar_n) is zeroed before, summed after
   // one-launch apply (fc_solver_set_dag): tasks in topological order, dependency records, arrival counters
   bool dag_ready = false;
   DevBuf<FcDagTask> dag_tasks;
@@ -194,6 +195,11 @@ struct fc_ctx {
   DevBuf<unsigned char> rowkind_p;  // permuted numbering
   void* comm = nullptr;             // ncclComm_t
   int nranks = 1, rank = 0;
+  // exchange staged through the host when the ranks have no RCCL communicator (CPU collectives, ranks sharing a GPU)
+  fc_exchange_fn host_xchg = nullptr;
+  void* host_xchg_user = nullptr;
+  double* xstage = nullptr;  // pinned
+  size_t xstage_n = 0;
   DevBuf<double> tail;  // [y(64) | E | r2 | b2 | .. | flag@72] partial sums of a step, all-reduced
   // per-launch HIP-event timing (fc_set_timing): pairs recorded around every sweep / SpMV launch
   bool timing = false;
@@ -503,12 +509,38 @@ int launch_sweep(fc_ctx* h, const OrderSys& S, const Stage& st) {
 }
 
 // x_p (in buf[N..2N)) = M^-1 rhs_p, rhs_p must already be in buf[0..N)
+// The exchange step of the partitioned path: sum buf[0..n) over the ranks, in place, in stream order.
+// RCCL communicator: in-stream ncclAllReduce over xGMI.  Host exchange (fc_set_host_exchange): device -> pinned host,
+// the caller's all-reduce (e.g. torch.distributed / gloo), host -> device.  Same launch sequence either way.
+int exchange(fc_ctx* h, double* dptr, size_t n) {
+  if (n == 0) return FC_OK;
+  if (h->comm) {
+    NCCLCHK(g_rccl.AllReduce(dptr, dptr, n, kNcclDouble, kNcclSum, h->comm, h->stream));
+    return FC_OK;
+  }
+  if (!h->host_xchg) return fail(FC_ERR_NOT_READY, "partitioned handle without communicator: call fc_comm_init or fc_set_host_exchange");
+  if (h->xstage_n < n) {
+    if (h->xstage) (void)hipHostFree(h->xstage);
+    h->xstage = nullptr;
+    HIPCHK(hipHostMalloc((void**)&h->xstage, n * sizeof(double), hipHostMallocDefault));
+    h->xstage_n = n;
+  }
+  HIPCHK(hipMemcpyAsync(h->xstage, dptr, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->host_xchg(h->xstage, (int64_t)n, h->host_xchg_user);
+  HIPCHK(hipMemcpyAsync(dptr, h->xstage, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  return FC_OK;
+}
+bool exchanges(const fc_ctx* h) { return h->comm != nullptr || h->host_xchg != nullptr; }
+
 // one-launch apply: the tasks of stages [first, last] as ONE grid whose workgroups wait on per-node
 // counters (fc_dag.hip.h); with an RCCL communicator the grid is cut at the exchange stage
 int apply_factors_dag(fc_ctx* h, OrderSys& S, int first, int last) {
-  if (first == 0) ++S.dag_epoch;  // a new apply (fc_step_phase resumes the same one with first > 0)
-  const bool cut = h->comm && S.ar_n > 0 && S.ar_stage >= first && S.ar_stage < last;
-  FCCHK(time_begin(h, 0, cut ? 2 : 1));
+  if (first == 0) ++S.dag_epoch;
+  const bool ex = exchanges(h) && S.ar_n > 0;
+  int nl = 1;
+  for (int s = first; s < last; ++s) nl += ex && (s == S.ar_stage || s == S.ar2_stage) ? 1 : 0;
+  FCCHK(time_begin(h, 0, nl));
   auto launch = [&](int s0, int s1) -> int {
     const int t0 = S.stages[s0].dag_task0, t1 = S.stages[s1].dag_task0 + S.stages[s1].dag_ntasks;
     // FC_DAG_LDS_PAD (tuning aid): extra dynamic LDS per workgroup = fewer resident workgroups per CU, i.e. a
@@ -522,17 +554,16 @@ int apply_factors_dag(fc_ctx* h, OrderSys& S, int first, int last) {
     HIPCHK(hipGetLastError());
     return FC_OK;
   };
-  if (cut) {
-    FCCHK(launch(first, S.ar_stage));
-    double* p = h->buf.p + S.ar_row0;
-    NCCLCHK(g_rccl.AllReduce(p, p, (size_t)S.ar_n, kNcclDouble, kNcclSum, h->comm, h->stream));
-    FCCHK(launch(S.ar_stage + 1, last));
-  } else {
-    FCCHK(launch(first, last));
-    if (h->comm && S.ar_n > 0 && S.ar_stage == last) {
-      double* p = h->buf.p + S.ar_row0;
-      NCCLCHK(g_rccl.AllReduce(p, p, (size_t)S.ar_n, kNcclDouble, kNcclSum, h->comm, h->stream));
-    }
+  // the grid is cut behind every exchange stage inside the range
+  int s0 = first;
+  for (int s = first; s <= last; ++s) {
+    const bool cut = ex && (s == S.ar_stage || s == S.ar2_stage);
+    if (!cut && s != last) continue;
+    if (ex && S.ar2_stage >= s0 && S.ar2_stage <= s)
+      HIPCHK(hipMemsetAsync(h->buf.p + h->N + S.ar_row0, 0, (size_t)S.ar_n * sizeof(double), h->stream));  // the other ranks' blocks
+    FCCHK(launch(s0, s));
+    if (cut) FCCHK(exchange(h, h->buf.p + (s == S.ar_stage ? 0 : h->N) + S.ar_row0, (size_t)S.ar_n));
+    s0 = s + 1;
   }
   FCCHK(time_end(h));
   if (h->dag_inject >= 0 && h->dag_inject-- == 0) {
@@ -553,13 +584,14 @@ int apply_factors(fc_ctx* h, OrderSys& S, int first = 0, int last = -1) {
   FCCHK(time_begin(h, 0, nlaunch));
   for (size_t i = (size_t)first; i < S.stages.size() && (int)i <= last; ++i) {
     const Stage& st = S.stages[i];
+    const bool ex = exchanges(h) && S.ar_n > 0;
+    if (ex && (int)i == S.ar2_stage)  // root down-sweep: this rank fills its block of rows, the others' stay zero
+      HIPCHK(hipMemsetAsync(h->buf.p + h->N + S.ar_row0, 0, (size_t)S.ar_n * sizeof(double), h->stream));
     if (st.nrows > 0) FCCHK(launch_sweep(h, S, st));
-    if ((int)i == S.ar_stage && h->comm && S.ar_n > 0) {
-      // multi-GPU: the root separator's right-hand side is the sum of every rank's element and
-      // sub-tree contributions — the one exchange step of a solve (RCCL all-reduce over xGMI)
-      double* p = h->buf.p + S.ar_row0;
-      NCCLCHK(g_rccl.AllReduce(p, p, (size_t)S.ar_n, kNcclDouble, kNcclSum, h->comm, h->stream));
-    }
+    // multi-GPU: (1) the root separator's right-hand side is the sum of every rank's element and sub-tree
+    // contributions; (2) the root solution is assembled from the ranks' row blocks — the two exchange steps of a solve
+    if (ex && (int)i == S.ar_stage) FCCHK(exchange(h, h->buf.p + S.ar_row0, (size_t)S.ar_n));
+    if (ex && (int)i == S.ar2_stage) FCCHK(exchange(h, h->buf.p + h->N + S.ar_row0, (size_t)S.ar_n));
   }
   FCCHK(time_end(h));
   return FC_OK;
@@ -741,11 +773,8 @@ int launch_tail(fc_ctx* h, OrderSys& S, int compute_energy, double* d_y, double*
     hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, g, e_part, h->tail.p + 64, res ? g : 0,
                        res ? h->partial.p : nullptr, h->tail.p + 65, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p, h->up.p,
                        h->tail.p, h->flag.p, h->tail.p + 72, (double*)nullptr, 0.0, h->dag_err.p, step_id);
-    if (d_y) {  // d_y == nullptr: the caller (host-staged exchange) sums the records itself
-      if (h->comm) NCCLCHK(g_rccl.AllReduce(h->tail.p, h->tail.p, 80, kNcclDouble, kNcclSum, h->comm, h->stream));
-      hipLaunchKernelGGL(fc_publish_tail, dim3(1), dim3(64), 0, h->stream, h->tail.p, d_y, h->n_sens, d_E, d_r, d_flag_out, d_seq,
-                         seq);
-    }
+    FCCHK(exchange(h, h->tail.p, 80));  // the third exchange of a step: 80 doubles
+    hipLaunchKernelGGL(fc_publish_tail, dim3(1), dim3(64), 0, h->stream, h->tail.p, d_y, h->n_sens, d_E, d_r, d_flag_out, d_seq, seq);
   }
   HIPCHK(hipGetLastError());
   return FC_OK;
@@ -792,7 +821,7 @@ int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, 
     hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, ne, ne > 0 ? e_partial : nullptr,
                        h->tail.p + 64, nrp, nrp > 0 ? h->partial.p : nullptr, h->tail.p + 65, h->n_sens, h->s_rowptr.p,
                        h->s_idx.p, h->s_w.p, h->up.p, h->tail.p, h->flag.p, h->tail.p + 72, (double*)nullptr, 0.0, h->dag_err.p, step_id);
-    if (h->comm) NCCLCHK(g_rccl.AllReduce(h->tail.p, h->tail.p, 80, kNcclDouble, kNcclSum, h->comm, h->stream));
+    FCCHK(exchange(h, h->tail.p, 80));
     hipLaunchKernelGGL(fc_publish_tail, dim3(1), dim3(64), 0, h->stream, h->tail.p, d_y, h->n_sens, d_E, d_r, d_flag_out,
                        d_seq, seq);
   }
@@ -1002,6 +1031,7 @@ int fc_destroy(fc_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
   if (h->pin) (void)hipHostFree(h->pin);
+  if (h->xstage) (void)hipHostFree(h->xstage);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   for (hipEvent_t e : h->tev) (void)hipEventDestroy(e);
@@ -1227,7 +1257,7 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
                     const int32_t* stage_nrows, const int32_t* stage_kind, const int64_t* seg_ptr, int64_t n_seg,
                     const int64_t* seg_val, const int32_t* seg_col, const int32_t* seg_len, int64_t n_idx,
                     const int32_t* idx, int64_t n_val, const double* vals, int32_t ar_stage, int32_t ar_row0,
-                    int32_t ar_n) {
+                    int32_t ar_n, int32_t ar2_stage) {
   if (!h || slot < 0 || slot > 1 || !Ap_rowptr || !Ap_col || !Ap_val || n_stages <= 0 || !stage_begin || !stage_row0 ||
       !stage_nrows || !stage_kind || !seg_ptr || !seg_val || !seg_col || !seg_len || !vals || n_seg < 0 || n_idx < 0 ||
       n_val <= 0 || (n_idx > 0 && !idx))
@@ -1336,6 +1366,10 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
   }
   if (ar_stage >= n_stages || ar_row0 < 0 || ar_n < 0 || (int64_t)ar_row0 + ar_n > N)
     return fail(FC_ERR_INVALID, "fc_solver_setup: bad all-reduce range");
+  if (ar2_stage >= n_stages || (ar2_stage >= 0 && (ar2_stage <= ar_stage || S.stages[ar2_stage].kind != 1 || S.stages[ar2_stage].row0 < ar_row0 ||
+                                                   S.stages[ar2_stage].row0 + S.stages[ar2_stage].nrows > ar_row0 + ar_n)))
+    return fail(FC_ERR_INVALID, "fc_solver_setup: the second exchange stage must be a down stage inside the exchanged rows");
+  S.ar2_stage = ar2_stage;
   S.ar_stage = ar_stage;
   S.ar_row0 = ar_row0;
   S.ar_n = ar_n;
@@ -1462,7 +1496,10 @@ int fc_solver_set_dag(fc_handle h, int slot, int32_t n_nodes, const int64_t* nod
     if (!is_mine(g)) continue;
     for (int s = 0; s < nst; ++s) {
       const Stage& st = S.stages[s];
-      if (st.row0 <= nd[g].i0 && nd[g].i0 + nd[g].ni <= st.row0 + st.nrows) {
+      // (a rank's root down stage holds only its block of the root's rows: overlap is enough there)
+      const bool inside = st.row0 <= nd[g].i0 && nd[g].i0 + nd[g].ni <= st.row0 + st.nrows;
+      const bool overlap = st.kind == 1 && s == S.ar2_stage && nd[g].i0 < st.row0 + st.nrows && st.row0 < nd[g].i0 + nd[g].ni;
+      if (inside || overlap) {
         (st.kind == 0 ? nd[g].up_stage : nd[g].dn_stage) = s;
         stage_nodes[s].push_back(g);
       }
@@ -1474,9 +1511,10 @@ int fc_solver_set_dag(fc_handle h, int slot, int32_t n_nodes, const int64_t* nod
     int64_t rows = 0;
     int next = S.stages[s].row0;
     for (int g : stage_nodes[s]) {
-      if (nd[g].i0 != next) return fail(FC_ERR_INVALID, "fc_solver_set_dag: the nodes do not tile their stage");
-      next += nd[g].ni;
-      rows += nd[g].ni;
+      const int lo = std::max(nd[g].i0, S.stages[s].row0), hi = std::min(nd[g].i0 + nd[g].ni, S.stages[s].row0 + S.stages[s].nrows);
+      if (lo != next) return fail(FC_ERR_INVALID, "fc_solver_set_dag: the nodes do not tile their stage");
+      next = hi;
+      rows += hi - lo;
     }
     if (rows != S.stages[s].nrows) return fail(FC_ERR_INVALID, "fc_solver_set_dag: the nodes do not cover their stage");
   }
@@ -1538,12 +1576,13 @@ int fc_solver_set_dag(fc_handle h, int slot, int32_t n_nodes, const int64_t* nod
         const int wd = d.ni + d.nb;
         const int lpr = std::min(256, std::max(8, pow2_ceil((wd + FC_DAG_PV - 1) / FC_DAG_PV)));
         const int R = 256 / lpr;
-        for (int r0 = 0; r0 < d.ni; r0 += R) {
+        const int r_lo = std::max(0, st.row0 - d.i0), r_hi = std::min(d.ni, st.row0 + st.nrows - d.i0);  // this rank's rows of the node
+        for (int r0 = r_lo; r0 < r_hi; r0 += R) {
           FcDagTask t{};
           t.kind = 1;
           t.a = (int)blocks.size();
           t.geom = lpr;
-          blocks.push_back(FcBlk{(long long)(d.voff + (int64_t)r0 * wd), d.i0 + r0, std::min(R, d.ni - r0), d.i0, d.ni, (int)d.ioff, d.nb});
+          blocks.push_back(FcBlk{(long long)(d.voff + (int64_t)r0 * wd), d.i0 + r0, std::min(R, r_hi - r0), d.i0, d.ni, (int)d.ioff, d.nb});
           tasks.push_back(t);
           task_node.push_back(g);
           ++d.dn_n;
@@ -2080,70 +2119,6 @@ int fc_step(fc_handle h, int order_slot, const double* u_ctrl, const double* u_f
   return FC_OK;
 }
 
-int fc_step_phase(fc_handle h, int order_slot, int phase, const double* u_ctrl, int compute_energy, double* root_io,
-                  double* tail_io) {
-  // Host-staged exchange for a partitioned handle WITHOUT an RCCL communicator (debug / CPU-collective
-  // fallback of the *exchange only*; all arithmetic stays on the device):
-  //   phase 0: RHS element loop + up-sweeps through the root stage; root partial -> root_io[ar_n]
-  //   (caller sums root_io over the ranks)
-  //   phase 1: root_io -> device; remaining sweeps, residual monitor, finish, energy, sensors;
-  //            partial tail -> tail_io[80]   (caller sums tail_io over the ranks)
-  FCCHK(check_step_ready(h, order_slot));
-  if (!h->partitioned || h->comm) return fail(FC_ERR_INVALID, "fc_step_phase: needs a partitioned handle without RCCL communicator");
-  OrderSys& S = h->sys[order_slot];
-  if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this order");
-  if (S.ar_stage < 0 || !root_io) return fail(FC_ERR_INVALID, "fc_step_phase: no exchange stage configured");
-  if (h->max_iter > 0) return fail(FC_ERR_INVALID, "iterative refinement is not available on a partitioned handle");
-  HIPCHK(hipSetDevice(h->device));
-  const int N = h->N;
-  double* root = h->buf.p + S.ar_row0;
-  if (phase == 0) {
-    if (h->n_act > 0 && !u_ctrl) return fail(FC_ERR_INVALID, "fc_step_phase: u_ctrl is null");
-    volatile double* pin = h->pin;
-    for (int k = 0; k < h->n_act; ++k) pin[k] = u_ctrl[k];
-    FCCHK(enqueue_rhs(h, order_slot, h->pin_dev));
-    FCCHK(apply_factors(h, S, 0, S.ar_stage));
-    HIPCHK(hipMemcpyAsync(root_io, root, (size_t)S.ar_n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return FC_OK;
-  }
-  if (phase != 1 || !tail_io) return fail(FC_ERR_INVALID, "fc_step_phase: bad phase");
-  HIPCHK(hipMemcpyAsync(root, root_io, (size_t)S.ar_n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  FCCHK(apply_factors(h, S, S.ar_stage + 1, -1));
-  if (use_fused_tail(h)) {
-    // this rank's record only (d_y == nullptr): the caller sums the records of the ranks
-    FCCHK(launch_tail(h, S, compute_energy, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0));
-  } else {
-    const double* x = h->buf.p + N;
-    int nrp = 0;
-    if (h->check_residual) {
-      const double mean = (double)S.Ap_nnz / std::max(1, N);
-      nrp = launch_spmv<1>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, x, h->b.p, h->tmpN.p, nullptr, h->partial.p,
-                           h->rowkind_p.p);
-      if (nrp < 0) return nrp;
-    }
-    double* e_partial = h->partial.p + 2 * (size_t)h->nblk_N;
-    hipLaunchKernelGGL(fc_finish, dim3(nblocks(N, 32)), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, x, (const double*)nullptr, h->up.p,
-                       h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p, (const int*)nullptr, (const int*)nullptr,
-                       (const double*)nullptr, (double*)nullptr, h->rowkind_p.p, h->dag_err.p);
-    int ne = 0;
-    if (compute_energy && h->ncl > 0) {
-      ne = nblocks(h->ncl, 256);
-      hipLaunchKernelGGL(fc_energy_elem, dim3(ne), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p, h->u_n.p,
-                         h->cell_list.p, h->ncl, e_partial);
-    }
-    HIPCHK(hipMemsetAsync(h->tail.p, 0, 128 * sizeof(double), h->stream));
-    hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, ne, ne > 0 ? e_partial : nullptr, h->tail.p + 64,
-                       nrp, nrp > 0 ? h->partial.p : nullptr, h->tail.p + 65, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p,
-                       h->up.p, h->tail.p, h->flag.p, h->tail.p + 72, (double*)nullptr, 0.0, h->dag_err.p, 1);
-    HIPCHK(hipGetLastError());
-  }
-  HIPCHK(hipMemcpyAsync(tail_io, h->tail.p, 80 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  speculate_next_rhs(h, order_slot);  // runs while the host sums the records and prepares the next step
-  return FC_OK;
-}
-
 int fc_run(fc_handle h, int first_order_slot, int32_t n_steps, const double* u_ctrl, int u_ctrl_is_sequence,
            double* y_seq, double* dE_seq, int compute_energy) {
   FCCHK(check_step_ready(h, first_order_slot));
@@ -2545,6 +2520,16 @@ int fc_comm_init(fc_handle h, int nranks, int rank, const char* id128) {
   void* comm = nullptr;
   NCCLCHK(g_rccl.CommInitRank(&comm, nranks, id, rank));
   h->comm = comm;
+  h->nranks = nranks;
+  h->rank = rank;
+  return FC_OK;
+}
+
+int fc_set_host_exchange(fc_handle h, int nranks, int rank, fc_exchange_fn fn, void* user) {
+  if (!h || nranks < 1 || rank < 0 || rank >= nranks) return fail(FC_ERR_INVALID, "fc_set_host_exchange: bad argument");
+  if (h->comm) return fail(FC_ERR_INVALID, "fc_set_host_exchange: the handle already has an RCCL communicator");
+  h->host_xchg = fn;
+  h->host_xchg_user = user;
   h->nranks = nranks;
   h->rank = rank;
   return FC_OK;

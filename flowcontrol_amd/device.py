@@ -81,9 +81,16 @@ class DeviceSolver:
         # FC_FORCE_COMM=1 (test aid): build a 1-rank RCCL communicator and run the partitioned code
         # path (cell list, row kinds, in-stream all-reduces) on a single GPU
         self._force_comm = world == 1 and os.environ.get("FC_FORCE_COMM", "0") == "1"
-        if (world == 1 and not self._force_comm) or host_allreduce is not None:
-            # host-staged exchange (fc_step_phase): no RCCL communicator; ``host_allreduce(array)``
-            # sums a float64 array over the ranks in place
+        if world == 1 and not self._force_comm:
+            return
+        if host_allreduce is not None:
+            # exchange through the host (fc_set_host_exchange): no RCCL communicator; ``host_allreduce(array)`` sums a
+            # float64 array over the ranks in place.  The launch sequence is the one of the RCCL path.
+            def _cb(ptr, n, _user):
+                host_allreduce(np.ctypeslib.as_array(ptr, shape=(int(n),)))
+
+            self._xchg_cb = _lib.EXCHANGE_FN(_cb)  # keep the callback object alive as long as the handle
+            check(self.lib.fc_set_host_exchange(self._h, world, rank, C.cast(self._xchg_cb, C.c_void_p), None))
             return
         import sys
 
@@ -240,7 +247,7 @@ class DeviceSolver:
             # single-rank communicator: everything is owned, the root rows are "shared" with nobody
             root0, root1 = int(t.node_ptr[0][0]), int(t.node_ptr[0][-1])
             part.rowkind[t.perm[root0:root1]] = 2
-            part.ar_stage, part.ar_row0, part.ar_n = t.depth - 1, root0, root1 - root0
+            part.ar_stage, part.ar_row0, part.ar_n, part.ar2_stage = t.depth - 1, root0, root1 - root0, t.depth
         if (self.world > 1 or getattr(self, "_force_comm", False)) and self.part is None:
             check(self.lib.fc_set_partition(self._h, int(part.local_cells.size), ptr(_i32(part.local_cells)),
                                             ptr(np.ascontiguousarray(part.rowkind, dtype=np.uint8)), int(self.rank == 0)))
@@ -256,7 +263,7 @@ class DeviceSolver:
                 self._h, slot, _i32(Ap.indptr), _i32(Ap.indices), _f64(Ap.data), len(part.stage_kind), part.stage_begin,
                 part.stage_row0, part.stage_nrows, part.stage_kind, part.seg_ptr, int(part.seg_val.size), seg_val,
                 seg_col, seg_len, int(fac.idx.size), _i32(idx), int(fac.vals.size), fac.vals,
-                int(part.ar_stage), int(part.ar_row0), int(part.ar_n),
+                int(part.ar_stage), int(part.ar_row0), int(part.ar_n), int(part.ar2_stage),
             )
         )
         if self.use_block_kernel:
@@ -385,20 +392,6 @@ class DeviceSolver:
         return up
 
     # ── hot path ─────────────────────────────────────────────────────────────
-    def _step_host_staged(self, order_slot: int, u, compute_energy: bool):
-        root = np.empty(max(1, self.part.ar_n))
-        tail = np.empty(80)
-        check(self.lib.fc_step_phase(self._h, order_slot, 0, ptr(u), int(compute_energy), ptr(root), ptr(tail)))
-        self._host_allreduce(root)
-        check(self.lib.fc_step_phase(self._h, order_slot, 1, ptr(u), int(compute_energy), ptr(root), ptr(tail)))
-        self._host_allreduce(tail)
-        if tail[72] >= 1024.0:  # a rank's one-launch factor apply gave up waiting (fc_dag.hip.h): no redo across ranks
-            raise _lib.FcError(_lib.FC_ERR_HIP, "the one-launch factor apply gave up waiting on a partitioned handle (set FC_DAG=0)")
-        info = np.array([0.0, np.sqrt(tail[65] / tail[66]) if tail[66] > 0 else np.nan, np.sqrt(tail[66]), tail[72]])
-        if tail[72] > 0:
-            raise _lib.FcDiverged(_lib.FC_ERR_DIVERGED, "non-finite velocity after solve")
-        return tail[: self.n_sens].copy(), (float(tail[64]) if compute_energy else float("nan")), info
-
     def set_rhs_operator(self, slot: int, Cmat: sp.csr_matrix | None) -> None:
         """b -= C u_n with C given in W numbering (N × 2nn); rows are permuted here."""
         if Cmat is None:
@@ -410,9 +403,6 @@ class DeviceSolver:
         check(self.lib.fc_set_rhs_operator(self._h, slot, ptr(_i32(Cp.indptr)), ptr(_i32(Cp.indices)), ptr(_f64(Cp.data))))
 
     def step(self, order_slot: int, u_ctrl, compute_energy: bool = True, u_force=None):
-        if self.world > 1 and getattr(self, "_host_allreduce", None) is not None:
-            u = _f64(np.atleast_1d(u_ctrl)) if self.n_act else None
-            return self._step_host_staged(order_slot, u, compute_energy)
         # persistent argument buffers and their ctypes pointers: the call is on the critical path of
         # every synchronous step (a fresh ndarray + ctypes cast per argument costs ~1 us each)
         b = self._step_bufs

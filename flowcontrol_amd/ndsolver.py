@@ -749,8 +749,15 @@ def down_blocks(fac: BlockFactors, rank: int = 0, world: int = 1, max_rows: int 
             sh = t.cum[k] - p
             sel = sel[(sel[:, 1] >> sh) == rank]
         sel = sel[np.argsort(sel[:, 2])]
-        values = float(((sel[:, 3] + sel[:, 4]) * sel[:, 3]).sum())
-        rows = int(sel[:, 3].sum())
+        lo, hi = 0, np.iinfo(np.int64).max  # rows of the node this rank sweeps (the root is split in row blocks)
+        if world > 1 and k == 0:
+            r_lo, r_hi = int(t.node_ptr[0][0]), int(t.node_ptr[0][-1])
+            bs = -(-(r_hi - r_lo) // world)
+            lo = min(r_hi, r_lo + rank * bs)
+            hi = min(r_hi, lo + bs)
+        nrows_of = np.clip(np.minimum(sel[:, 2] + sel[:, 3], hi) - np.maximum(sel[:, 2], lo), 0, None)
+        values = float(((sel[:, 3] + sel[:, 4]) * nrows_of).sum())
+        rows = int(nrows_of.sum())
         wd_mean = values / max(rows, 1)
         lpr[s] = 16 if wd_mean <= 64 else (32 if wd_mean <= 128 else 64)
         slots = 256 // int(lpr[s])
@@ -763,8 +770,9 @@ def down_blocks(fac: BlockFactors, rank: int = 0, world: int = 1, max_rows: int 
         begin[s] = nblk
         for _, n, i0, ni, nb, voff, ioff in sel:
             wd = ni + nb
-            for r0 in range(0, int(ni), rc):
-                nr = min(rc, int(ni) - r0)
+            first, last = max(0, lo - int(i0)), min(int(ni), hi - int(i0))
+            for r0 in range(first, last, rc):
+                nr = min(rc, last - r0)
                 for lst, v in zip(cols, (voff + r0 * wd, i0 + r0, nr, i0, ni, ioff, nb)):
                     lst.append(int(v))
                 nblk += 1
@@ -835,9 +843,10 @@ class RankPartition:
 
     * rows of tree levels ≥ 1 that lie in the rank's sub-tree (contiguous ranges per level);
     * the root level: every rank sweeps *its* columns of the root's L rows into a partial
-      right-hand side, an all-reduce sums the partials (the single exchange step of a solve), and
-      every rank then applies the root's D⁻¹ redundantly (it is small), so the solution on the root
-      separator is replicated and no halo exchange is needed afterwards.
+      right-hand side, an all-reduce sums the partials (exchange 1), every rank applies ITS block of
+      rows of the root's D⁻¹ (rows ``[root_row0, root_row0 + root_nrows)`` of the root), and a second
+      all-reduce of the zero-padded blocks assembles the root solution on every rank (exchange 2: an
+      all-gather in effect) — no factor value is applied twice, and no halo exchange is needed afterwards.
     """
 
     rank: int
@@ -856,6 +865,9 @@ class RankPartition:
     ar_stage: int
     ar_row0: int
     ar_n: int
+    ar2_stage: int = -1  # the root's down stage: its result x[ar_row0 .. +ar_n) is summed over the ranks as well
+    root_row0: int = 0  # this rank's block of root rows (permuted numbering)
+    root_nrows: int = 0
 
 
 def partition(fac: BlockFactors, rank: int, world: int) -> RankPartition:
@@ -882,9 +894,13 @@ def partition(fac: BlockFactors, rank: int, world: int) -> RankPartition:
     seg_ptr = [np.zeros(1, dtype=np.int64)]
     sv, sc, sl = [], [], []
     row0, nrows, kinds = [], [], []
-    ar_stage = -1
+    ar_stage = ar2_stage = -1
     nseg = 0
     nstages = len(fac.stage_kind)
+    root_lo, root_hi = int(t.node_ptr[0][0]), int(t.node_ptr[0][-1])
+    blk = -(-(root_hi - root_lo) // world)
+    my_lo = min(root_hi, root_lo + rank * blk)
+    my_hi = min(root_hi, my_lo + blk)
     for s in range(nstages):
         k = (t.depth - 1 - s) if s < t.depth else (s - t.depth)  # level of this stage
         g0 = int(fac.stage_begin[s])
@@ -910,6 +926,14 @@ def partition(fac: BlockFactors, rank: int, world: int) -> RankPartition:
             row0.append(gr0), nrows.append(gn)
             sv.append(fac.seg_val[q0:q1][keep]), sc.append(cols[keep]), sl.append(fac.seg_len[q0:q1][keep])
             ar_stage = len(kinds)
+        elif k == 0 and world > 1 and fac.stage_kind[s] == 1:
+            # root down-sweep: this rank's block of rows only (the blocks are assembled by the second exchange)
+            a, b = my_lo - gr0, my_hi - gr0
+            q0, q1 = int(ptr[a]), int(ptr[b])
+            cnt = np.diff(ptr[a : b + 1])
+            row0.append(my_lo), nrows.append(my_hi - my_lo)
+            sv.append(fac.seg_val[q0:q1]), sc.append(fac.seg_col[q0:q1]), sl.append(fac.seg_len[q0:q1])
+            ar2_stage = len(kinds)
         else:
             q0, q1 = int(ptr[0]), int(ptr[-1])
             cnt = np.diff(ptr)
@@ -929,6 +953,8 @@ def partition(fac: BlockFactors, rank: int, world: int) -> RankPartition:
         stage_row0=np.array(row0, dtype=np.int32), stage_nrows=nrows, stage_kind=np.array(kinds, dtype=np.int32),
         stage_begin=np.concatenate([[0], np.cumsum(nrows)[:-1]]).astype(np.int64),
         ar_stage=ar_stage if world > 1 else -1, ar_row0=root0, ar_n=(root1 - root0) if world > 1 else 0,
+        ar2_stage=ar2_stage if world > 1 else -1, root_row0=my_lo if world > 1 else root0,
+        root_nrows=(my_hi - my_lo) if world > 1 else root1 - root0,
     )
 
 
@@ -950,11 +976,17 @@ def solve_partitioned_reference(fac: BlockFactors, part: RankPartition, b_local_
         if part.stage_kind[s] == 0:
             buf[r0 : r0 + nr] += acc
         else:
+            if s == part.ar2_stage:
+                buf[N + part.ar_row0 : N + part.ar_row0 + part.ar_n] = 0.0  # the other ranks' blocks
             buf[N + r0 : N + r0 + nr] = acc
         if s == part.ar_stage and part.ar_n > 0:
             seg = buf[part.ar_row0 : part.ar_row0 + part.ar_n].copy()
             allreduce(seg)
             buf[part.ar_row0 : part.ar_row0 + part.ar_n] = seg
+        if s == part.ar2_stage and part.ar_n > 0:
+            seg = buf[N + part.ar_row0 : N + part.ar_row0 + part.ar_n].copy()
+            allreduce(seg)
+            buf[N + part.ar_row0 : N + part.ar_row0 + part.ar_n] = seg
     return buf[N:]
 
 

@@ -116,7 +116,10 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
                     int64_t n_val, const double* vals,
                     /* multi-GPU: after stage `ar_stage` (-1: none) the rows [ar_row0, ar_row0+ar_n) of the
                      * work buffer are summed over the ranks (RCCL all-reduce) */
-                    int32_t ar_stage, int32_t ar_row0, int32_t ar_n);
+                    int32_t ar_stage, int32_t ar_row0, int32_t ar_n,
+                    /* and the rows x[ar_row0 .. +ar_n) after stage `ar2_stage` (-1: none): the root's down stage, in which
+                     * every rank fills its own block of the root's rows (the others are zeroed before the launch) */
+                    int32_t ar2_stage);
 /* optional: hand the down-sweep stages to the LDS-tiled block kernel.  Every block is up to 32
  * consecutive rows of ONE tree node, whose rows all read the same operand
  * [ y[i0..i0+ni) | x[idx[idx_off..+nb)] ] and whose values lie row-major (stride ni+nb) at blk_val.
@@ -234,18 +237,20 @@ int fc_bench_sweeps(fc_handle h, int slot, int reps, double* ms_per_apply, int32
  *    (flowsolver.py:236-238) and PETSc/MUMPS' internal MPI.  Each rank holds the whole (small)
  *    discretisation but assembles only its cells and sweeps only its sub-tree of the elimination
  *    tree; rowkind[N] (W numbering): 0 = other rank's dof, 1 = owned, 2 = root separator (replicated).
- *    Exchange steps per step: one all-reduce of the root right-hand side inside the solve and one of
- *    the 80-double step tail (sensor partials, energy, residual norms, divergence flag). */
+ *    Exchange steps per step (all-reduces over RCCL/xGMI, or fc_set_host_exchange): the root right-hand side and the
+ *    root solution (every rank applies its block of the root's rows) inside the solve, and the 80-double step
+ *    tail (sensor partials, energy, residual norms, divergence flag). */
 int fc_set_partition(fc_handle h, int32_t n_local_cells, const int32_t* local_cells,
                      const uint8_t* rowkind /* [N] */, int lead);
 int fc_comm_unique_id(char* out128 /* ncclUniqueId bytes, made on rank 0 and broadcast by the host */);
 int fc_comm_init(fc_handle h, int nranks, int rank, const char* id128);
-/* Host-staged exchange for a partitioned handle that has NO RCCL communicator (several ranks on one
- * GPU, CPU-only collectives): the step is cut at its two exchange points and the caller sums
- * root_io[ar_n] (after phase 0) and tail_io[80] (after phase 1) over the ranks.  All arithmetic stays
- * on the device.  tail layout: y[0..63], E at 64, |r|^2 65, |b|^2 66, non-finite flag 72. */
-int fc_step_phase(fc_handle h, int order_slot, int phase, const double* u_ctrl, int compute_energy,
-                  double* root_io, double* tail_io);
+/* Exchange through the host for a partitioned handle that has NO RCCL communicator (several ranks on one GPU,
+ * CPU-only collectives such as gloo): `fn(buf, n, user)` must sum the n doubles of `buf` over the ranks, in place.
+ * The launch sequence of a step is the one of the RCCL path; only the exchange itself differs (device -> pinned
+ * host buffer -> fn -> device instead of an in-stream ncclAllReduce).  Three exchanges per step: the root
+ * right-hand side, the root solution (row blocks), the 80-double step record. */
+typedef void (*fc_exchange_fn)(double* buf, int64_t n, void* user);
+int fc_set_host_exchange(fc_handle h, int nranks, int rank, fc_exchange_fn fn, void* user);
 
 /* HIP-event timing inside fc_step / fc_run: when on, the back-to-back factor-sweep launches of
  * every apply are bracketed by ONE event pair on the handle's stream (sweep_ms / sweep_launches =

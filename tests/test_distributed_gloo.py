@@ -2,8 +2,8 @@
 
 The HIP kernels need a GPU; what is exercised here is everything *around* them that makes the N > 1
 path correct by construction: the 2**p-ary root split of the elimination tree, the per-rank stage
-tables, the ownership masks / cell lists, and the exchange pattern (one all-reduce of the root
-right-hand side per solve).  Each rank runs the host emulation of its device program
+tables, the ownership masks / cell lists, and the exchange pattern (per solve: one all-reduce of the root
+right-hand side and one of the root solution, whose rows are split over the ranks).  Each rank runs the host emulation of its device program
 (``ndsolver.solve_partitioned_reference``) and the union of the ranks' results must equal the
 serial solve of the same system.
 """
@@ -87,6 +87,8 @@ def _worker(rank, world, port, out):
             out["calls"] = list(calls)
             out["root"] = int(part.ar_n)
             out["cells"] = int(part.local_cells.size)
+        out[f"values{rank}"] = int(part.seg_len.sum())
+        out["total_values"] = int(fac.nnz)
     finally:
         dist.destroy_process_group()
 
@@ -98,8 +100,12 @@ def test_partitioned_solve_matches_serial(world):
         out = mgr.dict()
         mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
         assert out["err"] < 1e-11 and out["res"] < 1e-12
-        assert out["calls"] == [out["root"]]  # exactly one exchange per solve, of the root separator
+        assert out["calls"] == [out["root"], out["root"]]  # two exchanges per solve, both of the root separator's size
         assert 0 < out["cells"] < 128
+        # every factor value is applied by exactly one rank (no replicated work), and the shares are balanced
+        shares = [out[f"values{r}"] for r in range(world)]
+        assert sum(shares) == out["total_values"]
+        assert max(shares) < 1.35 * out["total_values"] / world
 
 
 def test_partition_covers_everything_once():
@@ -112,8 +118,10 @@ def test_partition_covers_everything_once():
     assert np.all(owned.sum(axis=0) + root == 1)  # every dof is owned by exactly one rank or is root
     cells = np.concatenate([p.local_cells for p in parts])
     assert sorted(cells.tolist()) == list(range(th.nc))
-    # segments: the ranks' tables together hold every segment of the serial tables exactly once,
-    # except the (replicated) root down-sweep
-    n_serial = fac.seg_val.size
-    root_down = int(np.diff(fac.seg_ptr[int(fac.stage_begin[tree.depth]) : int(fac.stage_begin[tree.depth]) + int(fac.stage_nrows[tree.depth]) + 1]).sum())
-    assert sum(p.seg_val.size for p in parts) == n_serial + 3 * root_down
+    # segments: the ranks' tables together hold every segment of the serial tables exactly once (the root's
+    # down-sweep rows are split in blocks), i.e. every factor value is applied by exactly one rank
+    assert sum(p.seg_val.size for p in parts) == fac.seg_val.size
+    assert sum(int(p.seg_len.sum()) for p in parts) == fac.nnz
+    blocks = sorted((p.root_row0, p.root_nrows) for p in parts)
+    assert blocks[0][0] == parts[0].ar_row0 and sum(b[1] for b in blocks) == parts[0].ar_n
+    assert all(blocks[i][0] + blocks[i][1] == blocks[i + 1][0] for i in range(3))

@@ -1,9 +1,9 @@
 """Partitioned (multi-GPU) device path on a single MI355X: two and four ranks share GPU 0.
 
-RCCL refuses two ranks on one device, so the two exchange steps of a time step (root right-hand side,
-step tail) are staged through the host over gloo (``fc_step_phase``); everything else — per-rank cell
-lists and row ownership, the rank-local sweep tables, the replicated root solve, the element-wise
-energy, the restricted sensor rows — is exactly what runs with an RCCL communicator on N GPUs.
+RCCL refuses two ranks on one device, so the three exchange steps of a time step (root right-hand side, root
+solution, step tail) go through the host over gloo (``fc_set_host_exchange``).  The launch sequence is the one of
+the RCCL path — per-rank cell lists and row ownership, the rank-local sweep tables, the root's rows split over the
+ranks, the element-wise energy, the restricted sensor rows — only the all-reduce call itself differs.
 The merged result must reproduce the golden open-loop series of the serial run.
 """
 import os
@@ -51,6 +51,10 @@ def _worker(rank, world, port, out, nsteps):
             out["u"] = u
             out["cells"] = int(fs.th.device().part.local_cells.size)
             out["resid"] = float(fs.solve_info[1])
+        from flowcontrol_amd._lib import SLOT_BDF2
+
+        out[f"values{rank}"] = int(fs.th.device().local_factor_nnz)
+        out["total_values"] = int(fs.th.device().factor_nnz[SLOT_BDF2])
         fs.th.release_device()
     finally:
         dist.destroy_process_group()
@@ -89,6 +93,46 @@ def test_partitioned_ranks_reproduce_the_serial_run(world):
         assert rel(out["u"], u_ref) < 1e-10
         assert out["resid"] < 1e-9
         assert abs(out["cells"] - 12284 // world) <= 1
+        # no replicated sweep work: the ranks' factor values add up to the serial count, evenly
+        shares = [out[f"values{r}"] for r in range(world)]
+        assert sum(shares) == out["total_values"]
+        assert max(shares) < 1.25 * out["total_values"] / world
+
+
+def test_rccl_plumbing_on_the_refined_mesh(monkeypatch):
+    """The same single-rank RCCL communicator on BASELINE config 4's mesh (222 962 dofs), with the one-launch factor
+    apply cut at the two exchange stages: 6 actuated steps against the oracle's series."""
+    import sys
+
+    sys.path.insert(0, str(ROOT / "tests" / "golden"))
+    from make_config45_fixtures import config4_actuation
+
+    from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver, refined_cylinder_mesh
+    from flowcontrol_amd.fem.spaces import Function
+    from flowcontrol_amd.flowsolverparameters import ParamIC
+
+    monkeypatch.setenv("FC_FORCE_COMM", "1")
+    g = np.load(ROOT / "tests" / "golden" / "cylinder_O1_refined1.npz")
+    rel = lambda a, b: np.linalg.norm(np.asarray(a) - b) / np.linalg.norm(b)  # noqa: E731
+    for dag in (False, True):
+        fs = CylinderFlowSolver.make_default(Re=100, path_out=tempfile.mkdtemp(), num_steps=6, meshpath=refined_cylinder_mesh(1))
+        fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
+        U0, P0 = Function(fs.W, g["UP0"]).split()
+        fs._assign_steady_state(U0, P0)
+        fs.initialize_time_stepping(ic=None)
+        dev = fs.th.device()
+        dev.join(0, 1, lambda b: b)
+        fs._joined = True
+        u = config4_actuation(6)
+        fs.step(u[0])
+        dev.set_dag(dag)
+        for k in range(1, 6):
+            fs.step(u[k])
+        ts = fs.timeseries
+        assert dev.part is not None and dev.part.ar2_stage > dev.part.ar_stage >= 0
+        assert rel(ts[["y_meas_1", "y_meas_2", "y_meas_3"]].to_numpy(), g["y"][:7]) < 1e-8
+        assert rel(ts["dE"].to_numpy(), g["dE"][:7]) < 1e-8
+        fs.th.release_device()
 
 
 def test_rccl_plumbing_with_a_single_rank_communicator(monkeypatch):
