@@ -19,7 +19,7 @@ One JSON line on rank 0 with the driver's keys plus
   spmv          CSR SpMV probe on the assembled BDF2 matrix (cache resident) and on a
                 cavity_fine-sized matrix (> Infinity Cache), % of 8 TB/s
 N > 1 (torchrun, one rank per GPU): the SAME mesh is row-partitioned over the ranks (one sub-tree of the
-elimination tree and its cells per GPU, root separator replicated; two RCCL all-reduces per step) —
+elimination tree and its cells per GPU, the root's rows split over the ranks; three small RCCL all-reduces per step) —
 total work fixed, "scaling": "strong", value = steps ÷ max time.  The shipped mesh is tiny (56 k
 DoFs), so this is latency-bound; ``replicas_steps_per_s`` (N × the single-GPU rate measured on rank 0
 in the same run) is reported next to it.  ``--replicas`` times N independent simulations instead.
@@ -238,7 +238,9 @@ def main() -> None:
     if partitioned:
         # collective-free extras below run on rank 0 only with a private single-GPU solver
         part_info = {"local_cells": int(fs.th.device().part.local_cells.size), "root_dofs": int(fs.th.device().part.ar_n),
-                     "local_factor_nnz": int(fs.th.device().local_factor_nnz)}
+                     "local_factor_nnz": int(fs.th.device().local_factor_nnz),  # factor values this rank sweeps per solve
+                     "stored_factor_nnz": int(fs.th.device()._n_factor_values),  # ... and stores: its sub-tree + the root block
+                     "exchanges_per_step": 3}
         dist.barrier()
         if rank == 0:
             fs.th.release_device()
@@ -320,8 +322,8 @@ def main() -> None:
                 "workload": f"cylinder Re=100, mesh O1{' red-refined x' + str(REFINE) if REFINE else ''} ({fs.th.nc} cells, {fs.th.N} dofs), "
                 "dt=0.005, BDF2, open loop, IC div-free vortex (2,0) r=0.5, sensors+energy every step",
                 "parallelism": "single GPU" if world == 1 else (
-                    f"row-partitioned over {world} GPUs: one elimination sub-tree + its cells per rank, replicated root "
-                    f"separator, 2 RCCL all-reduces per step" if partitioned
+                    f"row-partitioned over {world} GPUs: one elimination sub-tree + its cells per rank, the root's rows split "
+                    f"over the ranks, 3 RCCL all-reduces per step" if partitioned
                     else f"{world} independent replicas (no data-path collective)"),
                 "partition": part_info,
                 "solver": f"ND selected-inverse depth {dev.tree.depth}, {fs.refine_steps} refinement",

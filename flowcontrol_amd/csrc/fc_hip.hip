@@ -1836,13 +1836,17 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
   // permuted copy of the matrix for the residual monitor
   hipLaunchKernelGGL(fc_gather64, dim3(nblocks(S.Ap_nnz, 256)), dim3(256), 0, h->stream, S.Ap_nnz, h->pap_src.p, av, S.Ap_val.p);
   HIPCHK(hipMemsetAsync(F, 0, h->fronts.n * sizeof(double), h->stream));
-  const int64_t n_a = h->pa_ptr.back();
+  const int n_levels = (int)h->plevel_ptr.size() - 1;
+  // multi-GPU: this rank's plan holds its own sub-tree and the root (fc_factor_plan built with keep=): the root front is
+  // the sum over the ranks of the sub-trees' Schur complements plus the matrix entries, which only the lead rank scatters
+  const bool dist = h->partitioned && exchanges(h) && h->nranks > 1;
+  int64_t n_a = h->pa_ptr.back();
+  if (dist && !h->lead) n_a = h->pa_ptr[(size_t)n_levels - 1];  // entries below the root level
   if (n_a > 0)
     hipLaunchKernelGGL(fc_front_scatter, dim3(nblocks(n_a, 256)), dim3(256), 0, h->stream, n_a, h->pa_src.p, h->pa_dst.p, av, F);
-  if (h->pn_shift > 0)
+  if (h->pn_shift > 0 && (!dist || h->lead))
     hipLaunchKernelGGL(fc_front_shift, dim3(nblocks(h->pn_shift, 64)), dim3(64), 0, h->stream, h->pn_shift, h->pshift_slot.p,
                        h->pshift_val.p, F);
-  const int n_levels = (int)h->plevel_ptr.size() - 1;
   int* ipiv = h->pipiv.p;
   int* info = h->pipiv.p + h->pmax_ni;
   const double one = 1.0, zero = 0.0, minus = -1.0;
@@ -1858,6 +1862,12 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
           hipLaunchKernelGGL(fc_extend_add, dim3(gx, nc_), dim3(256), 0, h->stream, h->pext.p + grp.first + c0, h->pext_p.p, F);
         }
       }
+    }
+    if (dist && li == n_levels - 1) {
+      // the one exchange of a numeric factorisation: sum the root front over the ranks
+      if (h->plevel_ptr[li + 1] - h->plevel_ptr[li] != 1) return fail(FC_ERR_INVALID, "fc_refactor: a partitioned plan needs a single root node");
+      const fc_ctx::PlanNode& root = h->pnodes[(size_t)h->plevel_ptr[li]];
+      FCCHK(exchange(h, F + root.front, (size_t)root.nf * root.nf));
     }
     if (h->pfront_groups[li].second > 0)
       hipLaunchKernelGGL(fc_front_eliminate, dim3(h->pfront_groups[li].second), dim3(256), 0, h->stream,

@@ -210,15 +210,17 @@ class DeviceSolver:
             check(self.lib.fc_set_permutation(self._h, _i32(self.tree.perm)))
             self._upload_energy_matrix()
         t = self.tree
-        # partitioned handles too: every rank holds the whole matrix and repeats the (61 ms) numeric phase for the
-        # whole tree; its sweep tables then pick the rank's own segments out of the same value array
+        # partitioned handles: every rank holds the whole (small) matrix but lays out and factorises its own sub-tree
+        # and the root only; the root front is summed over the ranks inside fc_refactor
         on_device = bool(self.device_factor)
         up_split = int(os.environ.get("FC_UP_SPLIT", "0"))
         if on_device:
             # structure on the host (index work only, once per tree), numbers on the device
             if self._fac_struct is None:
-                self._fac_struct = ndsolver.factorize_blocks(None, t, numeric=False)
-                pl = ndsolver.factor_plan(self._fac_struct, self.rowptr, self.colidx, self._skip)
+                # a rank of a multi-GPU run lays out, stores and factorises its own sub-tree and the root only
+                keep = ndsolver.rank_keeps(t, self.rank, self.world) if self.world > 1 else None
+                self._fac_struct = ndsolver.factorize_blocks(None, t, numeric=False, keep=keep)
+                pl = ndsolver.factor_plan(self._fac_struct, self.rowptr, self.colidx, self._skip, keep=keep)
                 check(self.lib.fc_factor_plan(
                     self._h, int(pl.nodes.shape[0]), pl.nodes, int(pl.level_ptr.size - 1), pl.level_ptr, int(pl.front_size),
                     int(pl.a_src.size), pl.a_src if pl.a_src.size else np.zeros(1, np.int64), pl.a_dst if pl.a_dst.size else np.zeros(1, np.int64),
@@ -309,7 +311,10 @@ class DeviceSolver:
             check(self.lib.fc_set_front_shifts(self._h, 0, np.zeros(1, np.int64), np.zeros(1)))
         else:
             slot = ndsolver.front_diagonal_slot(self._plan, self.tree, self._pin)
-            check(self.lib.fc_set_front_shifts(self._h, 1, np.array([slot], dtype=np.int64), np.array([self._pin_shift])))
+            if slot < 0:  # the pinned dof is eliminated by another rank
+                check(self.lib.fc_set_front_shifts(self._h, 0, np.zeros(1, np.int64), np.zeros(1)))
+            else:
+                check(self.lib.fc_set_front_shifts(self._h, 1, np.array([slot], dtype=np.int64), np.array([self._pin_shift])))
 
     def refactor(self, slot: int) -> float:
         """Numeric factorisation of the slot's current matrix on the device (the structure of the first

@@ -348,20 +348,35 @@ class BlockFactors:
         return x
 
 
-def factorize_blocks(A: sp.csr_matrix | None, tree: NDTree, numeric: bool = True) -> BlockFactors:
+def rank_keeps(tree: NDTree, rank: int, world: int):
+    """Predicate (level, node) → this rank stores and factorises the node: its own sub-tree of the ``world``-ary
+    root, and the root itself."""
+    p = int(np.log2(world)) if world > 1 else 0
+
+    def keep(k: int, n: int) -> bool:
+        return world == 1 or k == 0 or (n >> (tree.cum[k] - p)) == rank
+
+    return keep
+
+
+def factorize_blocks(A: sp.csr_matrix | None, tree: NDTree, numeric: bool = True, keep=None) -> BlockFactors:
     """Numeric multifrontal factorisation with explicit pivot-block inverses → block factors.
 
     ``numeric=False`` lays out the structure only (segment lists, index lists, value offsets; ``vals``
     all zero, ``A`` may be None): the values are then computed on the device (:func:`factor_plan`,
-    ``fc_refactor``)."""
+    ``fc_refactor``).  ``keep(level, node)`` (structure only): nodes for which it is False get no storage at all —
+    a rank of a multi-GPU run lays out its own sub-tree and the root (:func:`rank_keeps`), so its factor array
+    is ~1/world of the whole."""
     t = tree
+    if keep is not None and numeric:
+        raise ValueError("keep= is for the structure-only layout (numeric=False)")
     N = int(t.perm.size)
     if not numeric:
         A = sp.csr_matrix((N, N))
     Ap = A[t.perm][:, t.perm].tocoo()
     r_, c_, v_ = Ap.row.astype(np.int64), Ap.col.astype(np.int64), Ap.data
-    keep = v_ != 0.0
-    r_, c_, v_ = r_[keep], c_[keep], v_[keep]
+    nonzero = v_ != 0.0
+    r_, c_, v_ = r_[nonzero], c_[nonzero], v_[nonzero]
     # node id (global, in elimination order) of every permuted dof
     starts = np.concatenate([t.node_ptr[k][:-1] for k in range(t.depth, -1, -1)])
     node_level = np.concatenate([np.full(len(t.node_ptr[k]) - 1, k) for k in range(t.depth, -1, -1)])
@@ -397,6 +412,8 @@ def factorize_blocks(A: sp.csr_matrix | None, tree: NDTree, numeric: bool = True
             B = t.bnd[k][n]
             nb = B.size
             children = t.children(k, n) if k < t.depth else ()
+            if keep is not None and not keep(k, n):
+                continue
             if ni == 0:
                 if not numeric:
                     continue
@@ -533,13 +550,16 @@ class FactorPlan:
     ext_p: np.ndarray  # int32
     ap_src: np.ndarray  # (nnz of the permuted matrix,) int64
     max_slots: int
+    node_i0: np.ndarray | None = None  # (n_nodes,) first permuted dof of every plan node
 
 
-def factor_plan(fac: BlockFactors, indptr: np.ndarray, indices: np.ndarray, skip: np.ndarray | None = None) -> FactorPlan:
+def factor_plan(fac: BlockFactors, indptr: np.ndarray, indices: np.ndarray, skip: np.ndarray | None = None, keep=None) -> FactorPlan:
     """Symbolic side of the device factorisation for the CSR pattern (``indptr``, ``indices``; original
     numbering) — pure index work, done once per (tree, pattern).  ``skip`` marks the decoupled
     (Dirichlet) dofs: their off-diagonal entries are structural zeros after the symmetric elimination and
-    are left out of the fronts."""
+    are left out of the fronts.  ``keep(level, node)``: as in :func:`factorize_blocks` — only the kept nodes get a
+    front; the root's front then holds this rank's share only (its sub-tree's Schur complement; the matrix
+    entries of the root front are scattered by the lead rank) and is summed over the ranks by ``fc_refactor``."""
     t = fac.tree
     N = fac.N
     nnz = int(indptr[-1])
@@ -552,13 +572,15 @@ def factor_plan(fac: BlockFactors, indptr: np.ndarray, indices: np.ndarray, skip
     r_, c_, src = coo.row.astype(np.int64), coo.col.astype(np.int64), ap_src
     if skip is not None:
         sk = np.asarray(skip, dtype=bool)[t.perm]
-        keep = ~((sk[r_] | sk[c_]) & (r_ != c_))
-        r_, c_, src = r_[keep], c_[keep], src[keep]
+        coupled = ~((sk[r_] | sk[c_]) & (r_ != c_))
+        r_, c_, src = r_[coupled], c_[coupled], src[coupled]
     K = t.depth
     # all tree nodes in elimination order
     lv, nn_, i0s, nis, nbs = [], [], [], [], []
     for k in range(K, -1, -1):
         for n in range(t.nnodes(k)):
+            if keep is not None and not keep(k, n):
+                continue
             a, b = int(t.node_ptr[k][n]), int(t.node_ptr[k][n + 1])
             lv.append(k), nn_.append(n), i0s.append(a), nis.append(b - a), nbs.append(int(t.bnd[k][n].size))
     lv, nn_, i0s, nis, nbs = (np.array(x, dtype=np.int64) for x in (lv, nn_, i0s, nis, nbs))
@@ -573,6 +595,8 @@ def factor_plan(fac: BlockFactors, indptr: np.ndarray, indices: np.ndarray, skip
     for g in np.nonzero(nis > 0)[0]:
         owner[i0s[g] : i0s[g] + nis[g]] = g
     own = owner[np.minimum(r_, c_)]
+    mine = own >= 0  # entries of fronts that another rank builds are not ours
+    r_, c_, src, own = r_[mine], c_[mine], src[mine], own[mine]
     order = np.argsort(own, kind="stable")
     r_, c_, src, own = r_[order], c_[order], src[order], own[order]
     beg = np.searchsorted(own, np.arange(lv.size + 1))
@@ -612,7 +636,9 @@ def factor_plan(fac: BlockFactors, indptr: np.ndarray, indices: np.ndarray, skip
         max_slots = max(max_slots, len(ch))
         idxs = np.concatenate([np.arange(i0s[g], i0s[g] + nis[g]), t.bnd[k][n]])
         for c, chn in enumerate(ch):
-            gc = gid[(k + 1, int(chn))]
+            gc = gid.get((k + 1, int(chn)))
+            if gc is None:
+                continue  # another rank's sub-tree
             cb = t.bnd[k + 1][int(chn)]
             if cb.size == 0:
                 continue
@@ -626,32 +652,36 @@ def factor_plan(fac: BlockFactors, indptr: np.ndarray, indices: np.ndarray, skip
     nodes = np.stack([lv, front_off[:-1], nfs, nis, voff, parent, slot], axis=1).astype(np.int64)
     return FactorPlan(nodes=np.ascontiguousarray(nodes), level_ptr=level_ptr, front_size=int(front_off[-1]),
                       a_src=np.ascontiguousarray(src), a_dst=np.ascontiguousarray(a_dst), a_ptr=np.ascontiguousarray(a_ptr, dtype=np.int64),
-                      ext_off=ext_off, ext_p=np.ascontiguousarray(ext_p), ap_src=np.ascontiguousarray(ap_src), max_slots=max_slots)
+                      ext_off=ext_off, ext_p=np.ascontiguousarray(ext_p), ap_src=np.ascontiguousarray(ap_src), max_slots=max_slots,
+                      node_i0=i0s.copy())
 
 
 def front_diagonal_slot(plan: FactorPlan, tree: NDTree, dof: int) -> int:
     """Offset, in the front buffer, of the diagonal entry of ``dof`` (original numbering) in the front of
-    the node that eliminates it (plan nodes are listed level by level, deepest first, node index
-    ascending, empty nodes included)."""
+    the plan node that eliminates it; −1 when that node is not in this rank's plan."""
     ip = int(tree.iperm[dof])
-    for k in range(tree.depth, -1, -1):
-        ptr = tree.node_ptr[k]
-        if int(ptr[0]) <= ip < int(ptr[-1]):
-            n = int(np.searchsorted(ptr, ip, side="right") - 1)
-            g = int(plan.level_ptr[tree.depth - k]) + n
-            lv, fo, nf, ni = (int(v) for v in plan.nodes[g, :4])
-            assert lv == k and 0 <= ip - int(ptr[n]) < ni
-            return fo + (ip - int(ptr[n])) * (nf + 1)
-    raise ValueError("dof is not eliminated by any node of the plan")
+    i0, ni = plan.node_i0, plan.nodes[:, 3]
+    hit = np.nonzero((i0 <= ip) & (ip < i0 + ni))[0]
+    if hit.size == 0:
+        return -1
+    g = int(hit[0])
+    fo, nf = int(plan.nodes[g, 1]), int(plan.nodes[g, 2])
+    return fo + (ip - int(i0[g])) * (nf + 1)
 
 
-def factorize_with_plan(plan: FactorPlan, fac: BlockFactors, values: np.ndarray) -> np.ndarray:
+def factorize_with_plan(plan: FactorPlan, fac: BlockFactors, values: np.ndarray, lead: bool = True, allreduce=None) -> np.ndarray:
     """Host replay of exactly what ``fc_refactor`` does on the device (same order of operations): the
-    factor values for the CSR ``values`` (original numbering).  Test reference, not a product path."""
+    factor values for the CSR ``values`` (original numbering).  Test reference, not a product path.
+
+    Per-rank plans (``keep=`` of :func:`factor_plan`): ``lead`` — this rank scatters the matrix entries of the root
+    front; ``allreduce(array)`` sums the root front over the ranks before the root is eliminated."""
     F = np.zeros(plan.front_size)
     vals = np.zeros(fac.vals.size)
     nodes = plan.nodes
-    np.add.at(F, plan.a_dst, values[plan.a_src])
+    n_lower = int(plan.a_ptr[-2]) if allreduce is not None else int(plan.a_ptr[-1])  # entries below the root level
+    np.add.at(F, plan.a_dst[:n_lower], values[plan.a_src[:n_lower]])
+    if allreduce is not None and lead:
+        np.add.at(F, plan.a_dst[n_lower:], values[plan.a_src[n_lower:]])
     nlev = plan.level_ptr.size - 1
     for li in range(nlev):
         g0, g1 = int(plan.level_ptr[li]), int(plan.level_ptr[li + 1])
@@ -669,6 +699,10 @@ def factorize_with_plan(plan: FactorPlan, fac: BlockFactors, values: np.ndarray)
                     _, pfo, pnf = nodes[par, 0], nodes[par, 1], nodes[par, 2]
                     P = F[pfo : pfo + pnf * pnf].reshape(pnf, pnf)
                     P[np.ix_(pp, pp)] += S
+        if allreduce is not None and li == nlev - 1:
+            _, fo, nf = nodes[g0, 0], nodes[g0, 1], nodes[g0, 2]
+            root = F[fo : fo + nf * nf]
+            allreduce(root)  # every rank's sub-tree contributes its Schur complement, the lead the matrix entries
         for g in range(g0, g1):
             _, fo, nf, ni, vo, _, _ = nodes[g]
             if ni == 0:
@@ -830,7 +864,7 @@ def dag_dependencies(fac: BlockFactors, rank: int = 0, world: int = 1):
     return nodes, mine, dn_dep, up_ptr, np.ascontiguousarray(up_idx if up_idx else [0], dtype=np.int32)
 
 
-__all__ += ["BlockFactors", "factorize_blocks", "down_blocks", "dag_dependencies", "split_up_segments", "FactorPlan", "factor_plan",
+__all__ += ["BlockFactors", "factorize_blocks", "rank_keeps", "down_blocks", "dag_dependencies", "split_up_segments", "FactorPlan", "factor_plan",
             "factorize_with_plan", "front_diagonal_slot"]
 
 

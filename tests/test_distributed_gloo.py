@@ -125,3 +125,61 @@ def test_partition_covers_everything_once():
     blocks = sorted((p.root_row0, p.root_nrows) for p in parts)
     assert blocks[0][0] == parts[0].ar_row0 and sum(b[1] for b in blocks) == parts[0].ar_n
     assert all(blocks[i][0] + blocks[i][1] == blocks[i + 1][0] for i in range(3))
+
+
+def _factor_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        th, d, A, skip = _system()
+        p = int(np.log2(world))
+        tree = ndsolver.build_tree(th.cell_dofs, th.mesh.cell_centroids(), th.N, 4, skip, merge=2, top_bits=p)
+        A = A.tocsr()
+        A.sort_indices()
+        keep = ndsolver.rank_keeps(tree, rank, world)
+        fac = ndsolver.factorize_blocks(None, tree, numeric=False, keep=keep)
+        plan = ndsolver.factor_plan(fac, A.indptr, A.indices, skip, keep=keep)
+
+        def allreduce(a):
+            tns = torch.from_numpy(a)
+            dist.all_reduce(tns, op=dist.ReduceOp.SUM)
+
+        vals = ndsolver.factorize_with_plan(plan, fac, A.data, lead=rank == 0, allreduce=allreduce)
+        out[f"nodes{rank}"] = fac.nodes.copy()
+        out[f"vals{rank}"] = vals
+        out[f"fronts{rank}"] = int(plan.front_size)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_per_rank_factorisation_matches_serial(world):
+    """Every rank lays out, stores and factorises its own sub-tree and the root only; the root front is summed over the
+    ranks once.  The values each rank ends up with must be the serial factor values of the nodes it keeps, and its
+    storage about 1/world of the whole (+ the root)."""
+    th, d, A, skip = _system()
+    p = int(np.log2(world))
+    tree = ndsolver.build_tree(th.cell_dofs, th.mesh.cell_centroids(), th.N, 4, skip, merge=2, top_bits=p)
+    ref = ndsolver.factorize_blocks(A, tree)
+    where = {(int(k), int(n)): (int(vo), int(ni), int(nb)) for k, n, _, ni, nb, vo, _ in ref.nodes}
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_factor_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        sizes = []
+        seen = set()
+        for r in range(world):
+            vals, nodes = out[f"vals{r}"], out[f"nodes{r}"]
+            sizes.append(vals.size)
+            for k, n, _, ni, nb, vo, _ in nodes:
+                v0, ni0, nb0 = where[(int(k), int(n))]
+                cnt = ni * (ni + nb) + nb * ni
+                assert (ni, nb) == (ni0, nb0)
+                a, b = vals[vo : vo + cnt], ref.vals[v0 : v0 + cnt]
+                assert np.linalg.norm(a - b) <= 1e-10 * np.linalg.norm(b)
+                seen.add((int(k), int(n)))
+        assert seen == set(where)  # together the ranks hold every node
+        root = where[(0, 0)]
+        root_vals = root[1] * root[1]
+        assert sum(sizes) == ref.vals.size + (world - 1) * root_vals  # only the root's pivot block is stored on every rank
+        assert max(sizes) - root_vals < 1.35 * (ref.vals.size - root_vals) / world

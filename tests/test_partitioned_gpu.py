@@ -53,8 +53,13 @@ def _worker(rank, world, port, out, nsteps):
             out["resid"] = float(fs.solve_info[1])
         from flowcontrol_amd._lib import SLOT_BDF2
 
-        out[f"values{rank}"] = int(fs.th.device().local_factor_nnz)
-        out["total_values"] = int(fs.th.device().factor_nnz[SLOT_BDF2])
+        from flowcontrol_amd import ndsolver
+
+        dev = fs.th.device()
+        out[f"values{rank}"] = int(dev.local_factor_nnz)  # factor values this rank sweeps per solve
+        out[f"stored{rank}"] = int(dev.factor_nnz[SLOT_BDF2])  # ... and stores (its sub-tree + the root's pivot block)
+        if rank == 0:
+            out["total_values"] = int(ndsolver.factorize_blocks(None, dev.tree, numeric=False).nnz)  # the whole tree
         fs.th.release_device()
     finally:
         dist.destroy_process_group()
@@ -97,6 +102,8 @@ def test_partitioned_ranks_reproduce_the_serial_run(world):
         shares = [out[f"values{r}"] for r in range(world)]
         assert sum(shares) == out["total_values"]
         assert max(shares) < 1.25 * out["total_values"] / world
+        # ... and no replicated storage beyond the root's pivot block: each rank holds about 1/world of the factors
+        assert max(out[f"stored{r}"] for r in range(world)) < 1.35 * out["total_values"] / world
 
 
 def test_rccl_plumbing_on_the_refined_mesh(monkeypatch):
