@@ -29,14 +29,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-struct __attribute__((aligned(16))) FcDagTask {
-  int kind;   // 0: up rows (expanded sparse rows, accumulate into y); 1: down tile (block, assign into x)
-  int a;      // kind 0: index of the first row in up_ptr; kind 1: index of the tile in the DAG block array
-  int nrows;  // kind 0: rows of this task
-  int dest0;  // kind 0: buf index of the first row
+struct __attribute__((aligned(16))) FcDagTask {  // 64 bytes: everything a workgroup needs to issue its value loads
+  int kind;   // 0: up rows (expanded sparse rows, accumulate into y); 1: down tile (dense rows, assign into x)
+  int lpr;    // lanes per row (8 .. 256, power of two); a task covers 256 / lpr rows of ONE tree node
+  int nrows;
+  int dest0;  // buf index of the first row's result (up: the row in y; down: the row in x)
   int dep0, ndep;  // dependency records
   int sig;         // counter word this task adds 1 to when it is done
-  int geom;        // lanes per row
+  int stride;      // values per row: down = ni + nb; up = padded row length of the tile (ELL)
+  long long val;   // down: offset of the first row in the factor values; up: offset of the tile in up_val / up_col
+  int i0, ni;      // down: operand = [ y[i0 .. i0+ni) | x[idx[ioff .. ioff+nb)] ]
+  int ioff, nb;
+  int pad[2];
 };
 struct __attribute__((aligned(16))) FcDagDep {
   int base;        // first counter word
@@ -54,7 +58,7 @@ struct __attribute__((aligned(16))) FcDagDep {
 #define FC_DAG_SLEEP_MAX 32  // poll back-off cap in units of 64 clocks (waiters of one node poll the same counter lines)
 #endif
 #ifndef FC_DAG_WAVES_PER_SIMD
-#define FC_DAG_WAVES_PER_SIMD 6  // register budget: 6 workgroups of 256 threads per CU stay resident
+#define FC_DAG_WAVES_PER_SIMD 3  // register budget for 3 resident workgroups of 256 threads per CU (the launch keeps it to that)
 #endif
 
 typedef unsigned long long fc_u64;
@@ -102,141 +106,69 @@ __device__ __forceinline__ bool fc_dag_wait(const FcDagDep* __restrict__ deps, i
   return true;
 }
 
+// PERSISTENT: workgroup w of G runs tasks w, w + G, w + 2G, ... (topological order: a task's dependencies have
+// smaller numbers, so they belong to workgroups that are resident and get to them first; all G workgroups must be
+// resident, which the launch ensures by its size — and every wait is bounded anyway).  Software pipeline: the
+// descriptor of the NEXT task is fetched while the current one runs, and its values are requested right after the
+// current task's results are out — before the wait for its dependencies.
 __global__ __launch_bounds__(256, FC_DAG_WAVES_PER_SIMD) void fc_nd_dag(
-    const FcDagTask* __restrict__ tasks, const FcDagDep* __restrict__ deps, unsigned* cnt, unsigned epoch, int* err,
-    const int64_t* __restrict__ up_ptr, const int* __restrict__ up_col, const double* __restrict__ up_val,
-    const FcBlk* __restrict__ blk, const int* __restrict__ idx, const double* __restrict__ val, double* buf, int N,
-    fc_u64* trace) {
-  // trace (diagnostic launches only, fc_debug_trace_apply): 100 MHz wall-clock stamps of thread 0 at
-  // entry / prefetch issued / dependencies met / products done / stores drained
+    const FcDagTask* __restrict__ tasks, int ntasks, const FcDagDep* __restrict__ deps, unsigned* cnt, unsigned epoch, int* err,
+    const int* __restrict__ up_col, const double* __restrict__ up_val, const int* __restrict__ idx,
+    const double* __restrict__ val, double* buf, fc_u64* trace) {
+  // trace (diagnostic launches only, fc_debug_trace_apply): 100 MHz wall-clock stamps of thread 0 per task at
+  // values requested / dependencies met / products done / stores drained
   __shared__ double xs[FC_DAG_TILE];
   __shared__ double part[4];
   __shared__ int go;
-  const FcDagTask t = tasks[blockIdx.x];
   const int tid = threadIdx.x;
-  const bool waits = t.ndep > 0;
+  const int G = gridDim.x;
+  int i = blockIdx.x;
+  if (i >= ntasks) return;
 #define FC_STAMP(k) \
-  if (trace && tid == 0) trace[(size_t)blockIdx.x * 8 + (k)] = wall_clock64()
-  FC_STAMP(0);
-
-  if (t.kind == 1) {
-    // ── down tile: up to 256/LPR rows of one node, operand [ y[i0..i0+ni) | x[idx[..nb)] ] shared by all rows ──
-    const FcBlk b = blk[t.a];
-    const int LPR = t.geom;
+  if (trace && tid == 0) trace[(size_t)i * 8 + (k)] = wall_clock64()
+  constexpr int NG = FC_DAG_TILE / 256;
+  FcDagTask t = tasks[i];
+  double pv[FC_DAG_PV];
+  int pa[FC_DAG_PV];  // up: buffer column of every value; down: [0, NG) the coupling part's index list
+  // values (and index data) of task t into registers: depends on nothing but the descriptor.  Every load is
+  // UNCONDITIONAL with a clamped address (a select around a load makes hipcc branch around it and wait at once)
+  auto prefetch = [&]() {
+    const int LPR = t.lpr;
     const int slot = tid / LPR, l = tid % LPR;
-    const int wd = b.ni + b.nb;
-    const bool rowok = slot < b.nrows;
-    const double* __restrict__ vrow = val + b.val + (long long)(rowok ? slot : 0) * wd;
-    // 1. the whole tile (or its first FC_DAG_PV x LPR columns) into registers: depends on nothing.
-    //    Every load is UNCONDITIONAL with a clamped address (a select around a load makes hipcc branch around it and
-    //    wait for it at once: 24 dependent round trips); columns beyond the row are masked when they are used.
-    double pv[FC_DAG_PV];
+    const long long row = t.val + (long long)(slot < t.nrows ? slot : 0) * t.stride;
+    if (t.kind == 1) {
+      const double* __restrict__ v = val + row;
 #pragma unroll
-    for (int u = 0; u < FC_DAG_PV; ++u) {
-      const int col = l + u * LPR;
-      pv[u] = vrow[col < wd ? col : 0];
-    }
-    // the index list of the coupling part of the first operand tile as well (clamped the same way)
-    constexpr int NG = FC_DAG_TILE / 256;
-    int pidx[NG];
-    const int nbm1 = b.nb > 0 ? b.nb - 1 : 0;
-#pragma unroll
-    for (int k = 0; k < NG; ++k) {
-      int o = tid + 256 * k - b.ni;
-      o = o < 0 ? 0 : (o > nbm1 ? nbm1 : o);
-      pidx[k] = idx[b.idx + o];
-    }
-    FC_STAMP(1);
-    // 2. dependencies
-    if (waits) {
-      if (tid < 64) {
-        const bool ok = fc_dag_wait(deps, t.dep0, t.ndep, cnt, epoch, err);
-        if (tid == 0) go = ok ? 1 : 0;
+      for (int u = 0; u < FC_DAG_PV; ++u) {
+        const int col = l + u * LPR;
+        pv[u] = v[col < t.stride ? col : 0];
       }
-      __syncthreads();
-      if (!go) return;
-    }
-    FC_STAMP(2);
-    // 3. operand -> LDS (sc1 loads, all in flight together), products from registers, remainder columns streamed
-    double acc = 0.0;
-    const int npre = FC_DAG_PV * LPR;  // columns held in registers
-    const int wdm1 = wd - 1;
-    auto consume = [&](int t0, int tl) {
-      if (t0 < npre) {
-#pragma unroll
-        for (int u = 0; u < FC_DAG_PV; ++u) {
-          const int c = l + u * LPR - t0;
-          const bool in = c >= 0 && c < tl;
-          acc += (in ? pv[u] : 0.0) * xs[in ? c : 0];
-        }
-      }
-      int c0 = t0 > npre ? t0 : npre;
-      c0 += (l - (c0 % LPR) + LPR) % LPR;  // first column >= max(t0, npre) owned by this lane
-      for (int col = c0; col < t0 + tl; col += LPR) acc += vrow[col] * xs[col - t0];
-    };
-    {
-      // first operand tile: addresses from the prefetched index list, NG loads in flight per lane
-      const int tl = wd < FC_DAG_TILE ? wd : FC_DAG_TILE;
-      double ov[NG];
+      const int nbm1 = t.nb > 0 ? t.nb - 1 : 0;
 #pragma unroll
       for (int k = 0; k < NG; ++k) {
-        int col = tid + 256 * k;
-        col = col > wdm1 ? wdm1 : col;
-        ov[k] = fc_ld_sc1(buf + (col < b.ni ? b.i0 + col : pidx[k]));
+        int o = tid + 256 * k - t.ni;
+        o = o < 0 ? 0 : (o > nbm1 ? nbm1 : o);
+        pa[k] = idx[t.ioff + o];
       }
+    } else {
+      const double* __restrict__ v = up_val + row;
+      const int* __restrict__ c = up_col + row;
 #pragma unroll
-      for (int k = 0; k < NG; ++k)
-        if (tid + 256 * k < tl) xs[tid + 256 * k] = ov[k];
-      __syncthreads();
-      consume(0, tl);
-    }
-    for (int t0 = FC_DAG_TILE; t0 < wd; t0 += FC_DAG_TILE) {  // fronts wider than one tile (large meshes, near the root)
-      const int tl = wd - t0 < FC_DAG_TILE ? wd - t0 : FC_DAG_TILE;
-      __syncthreads();
-      for (int j = tid; j < tl; j += 256) {
-        const int col = t0 + j;
-        xs[j] = fc_ld_sc1(buf + (col < b.ni ? b.i0 + col : idx[b.idx + (col - b.ni)]));
+      for (int u = 0; u < FC_DAG_PV; ++u) {
+        const int e = l + u * LPR;
+        const int ee = e < t.stride ? e : 0;
+        pv[u] = v[ee];
+        pa[u] = c[ee];
       }
-      __syncthreads();
-      consume(t0, tl);
     }
-    // 4. row sums: lanes of a row are consecutive; LPR <= 64: inside the wave, 256: through LDS
-    double s = acc;
-    const int w = LPR < 64 ? LPR : 64;
-    for (int off = w >> 1; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (LPR > 64) {  // a row spans 2 or 4 waves: combine their sums through LDS in a fixed order
-      if ((tid & 63) == 0) part[tid >> 6] = s;
-      __syncthreads();
-      if (l == 0 && rowok) {
-        const int w0 = tid >> 6;
-        fc_st_sc1(buf + N + b.row0 + slot, LPR == 128 ? part[w0] + part[w0 + 1] : (part[0] + part[1]) + (part[2] + part[3]));
-      }
-    } else if (l == 0 && rowok) {
-      fc_st_sc1(buf + N + b.row0 + slot, s);
-    }
-  } else {
-    // ── up rows: the -L rows of node t, one expanded sparse row per dof (values re-laid out row by row, explicit
-    //    int32 columns into y): values AND columns are in registers before the wait, afterwards one trip of sc1
-    //    operand loads (all in flight) and the products ──
-    const int LPR = t.geom;
-    const int slot = tid / LPR, l = tid % LPR;
-    const bool rowok = slot < t.nrows;
-    const int r = t.a + (rowok ? slot : 0);
-    const int64_t k0 = up_ptr[r];
-    const int len = rowok ? (int)(up_ptr[r + 1] - k0) : 0;
-    const double* __restrict__ v = up_val + k0;
-    const int* __restrict__ c = up_col + k0;
-    double pv[FC_DAG_PV];
-    int pc[FC_DAG_PV];
-#pragma unroll
-    for (int u = 0; u < FC_DAG_PV; ++u) {
-      const int e = l + u * LPR;
-      const int ee = e < len ? e : 0;  // (the arrays carry one padding entry behind the last row)
-      pv[u] = v[ee];
-      pc[u] = c[ee];
-    }
-    FC_STAMP(1);
-    if (waits) {
+  };
+  prefetch();
+  for (;;) {
+    FC_STAMP(0);
+    const int inext = i + G;
+    FcDagTask tn = t;
+    if (inext < ntasks) tn = tasks[inext];  // in flight while this task runs
+    if (t.ndep > 0) {
       if (tid < 64) {
         const bool ok = fc_dag_wait(deps, t.dep0, t.ndep, cnt, epoch, err);
         if (tid == 0) go = ok ? 1 : 0;
@@ -244,16 +176,68 @@ __global__ __launch_bounds__(256, FC_DAG_WAVES_PER_SIMD) void fc_nd_dag(
       __syncthreads();
       if (!go) return;
     }
-    FC_STAMP(2);
+    FC_STAMP(1);
+    const int LPR = t.lpr;
+    const int slot = tid / LPR, l = tid % LPR;
+    const bool rowok = slot < t.nrows;
     double* dst = buf + t.dest0 + (rowok ? slot : 0);
-    const double own = fc_ld_sc1(dst);
-    double xv[FC_DAG_PV];
+    double acc = 0.0, own = 0.0;
+    if (t.kind == 1) {
+      // ── down tile: operand [ y[i0..i0+ni) | x[idx[..nb)] ] shared by all rows -> LDS (sc1 loads, all in flight) ──
+      const int wd = t.stride;
+      const double* __restrict__ vrow = val + t.val + (long long)(rowok ? slot : 0) * wd;
+      const int npre = FC_DAG_PV * LPR;  // columns held in registers
+      const int wdm1 = wd - 1;
+      auto consume = [&](int t0, int tl) {
+        if (t0 < npre) {
 #pragma unroll
-    for (int u = 0; u < FC_DAG_PV; ++u) xv[u] = fc_ld_sc1(buf + pc[u]);
-    double acc = 0.0;
+          for (int u = 0; u < FC_DAG_PV; ++u) {
+            const int c = l + u * LPR - t0;
+            const bool in = c >= 0 && c < tl;
+            acc += (in ? pv[u] : 0.0) * xs[in ? c : 0];
+          }
+        }
+        int c0 = t0 > npre ? t0 : npre;
+        c0 += (l - (c0 % LPR) + LPR) % LPR;  // first column >= max(t0, npre) owned by this lane
+        for (int col = c0; col < t0 + tl; col += LPR) acc += vrow[col] * xs[col - t0];
+      };
+      {
+        const int tl = wd < FC_DAG_TILE ? wd : FC_DAG_TILE;
+        double ov[NG];
 #pragma unroll
-    for (int u = 0; u < FC_DAG_PV; ++u) acc += (l + u * LPR < len ? pv[u] : 0.0) * xv[u];
-    for (int e = l + FC_DAG_PV * LPR; e < len; e += LPR) acc += v[e] * fc_ld_sc1(buf + c[e]);  // rows longer than the register tile
+        for (int k = 0; k < NG; ++k) {
+          int col = tid + 256 * k;
+          col = col > wdm1 ? wdm1 : col;
+          ov[k] = fc_ld_sc1(buf + (col < t.ni ? t.i0 + col : pa[k]));
+        }
+#pragma unroll
+        for (int k = 0; k < NG; ++k)
+          if (tid + 256 * k < tl) xs[tid + 256 * k] = ov[k];
+        __syncthreads();
+        consume(0, tl);
+      }
+      for (int t0 = FC_DAG_TILE; t0 < wd; t0 += FC_DAG_TILE) {  // fronts wider than one tile (large meshes, near the root)
+        const int tl = wd - t0 < FC_DAG_TILE ? wd - t0 : FC_DAG_TILE;
+        __syncthreads();
+        for (int j = tid; j < tl; j += 256) {
+          const int col = t0 + j;
+          xs[j] = fc_ld_sc1(buf + (col < t.ni ? t.i0 + col : idx[t.ioff + (col - t.ni)]));
+        }
+        __syncthreads();
+        consume(t0, tl);
+      }
+    } else {
+      // ── up rows: one trip of sc1 operand loads (all in flight), products with the values held in registers ──
+      own = fc_ld_sc1(dst);
+      double xv[FC_DAG_PV];
+#pragma unroll
+      for (int u = 0; u < FC_DAG_PV; ++u) xv[u] = fc_ld_sc1(buf + pa[u]);
+#pragma unroll
+      for (int u = 0; u < FC_DAG_PV; ++u) acc += (l + u * LPR < t.stride ? pv[u] : 0.0) * xv[u];
+      const long long row = t.val + (long long)(rowok ? slot : 0) * t.stride;
+      for (int e = l + FC_DAG_PV * LPR; e < t.stride; e += LPR) acc += up_val[row + e] * fc_ld_sc1(buf + up_col[row + e]);  // rows longer than the register tile
+    }
+    // row sums: lanes of a row are consecutive; LPR <= 64: inside the wave, 128 / 256: through LDS in a fixed order
     double s = acc;
     const int w = LPR < 64 ? LPR : 64;
     for (int off = w >> 1; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
@@ -267,12 +251,16 @@ __global__ __launch_bounds__(256, FC_DAG_WAVES_PER_SIMD) void fc_nd_dag(
     } else if (l == 0 && rowok) {
       fc_st_sc1(dst, own + s);
     }
+    FC_STAMP(2);
+    // ── arrival: every wave drains its write-through stores, the workgroup meets, ONE lane signals ──
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    FC_STAMP(3);
+    if (tid == 0) __hip_atomic_fetch_add(cnt + t.sig, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (inext >= ntasks) break;
+    t = tn;
+    i = inext;
+    prefetch();  // the next task's values: requested before its dependencies are waited for
   }
-  // ── arrival: every wave drains its write-through stores, the workgroup meets, ONE lane signals ──
-  FC_STAMP(3);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  FC_STAMP(4);
-  if (tid == 0) __hip_atomic_fetch_add(cnt + t.sig, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #undef FC_STAMP
 }

@@ -110,12 +110,11 @@ struct OrderSys {
   bool dag_ready = false;
   DevBuf<FcDagTask> dag_tasks;
   DevBuf<FcDagDep> dag_deps;
-  DevBuf<FcBlk> dag_blk;
   DevBuf<unsigned> dag_cnt;
   unsigned dag_epoch = 0;
   // up-sweep rows of the one-launch apply: the -L values re-laid out row by row with explicit columns
   // (dag_up_src: where each value sits in f_val; refreshed after every numeric factorisation)
-  DevBuf<int64_t> dag_up_ptr, dag_up_src;
+  DevBuf<int64_t> dag_up_src;
   DevBuf<int> dag_up_col;
   DevBuf<double> dag_up_val;
   int64_t dag_up_n = 0;
@@ -136,6 +135,7 @@ constexpr int kPinDoubles = 4096;
 
 struct fc_ctx {
   int device = 0;
+  int n_cu = 256;  // compute units of the device (persistent launches are sized by it)
   hipStream_t stream = nullptr;
   int nv = 0, ne = 0, nc = 0, nn = 0, N = 0;
   int64_t nnz = 0;
@@ -543,13 +543,19 @@ int apply_factors_dag(fc_ctx* h, OrderSys& S, int first, int last) {
   FCCHK(time_begin(h, 0, nl));
   auto launch = [&](int s0, int s1) -> int {
     const int t0 = S.stages[s0].dag_task0, t1 = S.stages[s1].dag_task0 + S.stages[s1].dag_ntasks;
-    // FC_DAG_LDS_PAD (tuning aid): extra dynamic LDS per workgroup = fewer resident workgroups per CU, i.e. a
-    // shallower queue of value loads in front of the dependency-critical loads
-    // (measured on the 56 k-dof cylinder mesh: 6 / 4 / 3 / 2 / 1 workgroups per CU -> 101 / 93 / 85 / 108 / 168 us per apply)
-    static const int lds_pad = [] { const char* e = std::getenv("FC_DAG_LDS_PAD"); return e ? std::max(0, std::atoi(e)) : 36000; }();
-    if (t1 > t0)
-      hipLaunchKernelGGL(fc_nd_dag, dim3(t1 - t0), dim3(256), lds_pad, h->stream, S.dag_tasks.p + t0, S.dag_deps.p, S.dag_cnt.p,
-                         S.dag_epoch, h->dag_err.p, S.dag_up_ptr.p, S.dag_up_col.p, S.dag_up_val.p, S.dag_blk.p, S.f_idx.p, S.f_val.p, h->buf.p, h->N,
+    // persistent grid: every workgroup must be resident (static task assignment).  FC_DAG_WGS workgroups, kept to
+    // FC_DAG_PER_CU per CU by a dynamic-LDS pad: more resident workgroups only deepen the queue of value loads in
+    // front of the dependency-critical loads (measured on the 56 k-dof cylinder mesh, non-persistent version:
+    // 6 / 4 / 3 / 2 / 1 workgroups per CU -> 101 / 93 / 85 / 108 / 168 us per apply)
+    static const int per_cu = [] { const char* e = std::getenv("FC_DAG_PER_CU"); return e ? std::min(6, std::max(1, std::atoi(e))) : 3; }();
+    static const int wgs_env = [] { const char* e = std::getenv("FC_DAG_WGS"); return e ? std::max(1, std::atoi(e)) : 0; }();
+    int wgs = wgs_env ? wgs_env : per_cu * h->n_cu;
+    if (h->host_xchg) wgs = std::min(wgs, 128);  // ranks sharing one GPU (host exchange): leave room for the other ranks' grids
+    const int lds_pad = std::max(0, (160 * 1024) / per_cu - (int)(FC_DAG_TILE * sizeof(double)) - 1024);
+    const int n = t1 - t0;
+    if (n > 0)
+      hipLaunchKernelGGL(fc_nd_dag, dim3(std::min(n, wgs)), dim3(256), lds_pad, h->stream, S.dag_tasks.p + t0, n, S.dag_deps.p, S.dag_cnt.p,
+                         S.dag_epoch, h->dag_err.p, S.dag_up_col.p, S.dag_up_val.p, S.f_idx.p, S.f_val.p, h->buf.p,
                          h->dag_trace.p ? h->dag_trace.p + (size_t)t0 * 8 : nullptr);
     HIPCHK(hipGetLastError());
     return FC_OK;
@@ -875,6 +881,11 @@ int fc_create(fc_handle* out, int device, int32_t nv, int32_t ne, int32_t nc, co
     hipError_t _e = (expr);                                                                        \
     if (_e != hipSuccess) return bail(fail(FC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); \
   } while (0)
+  {
+    hipDeviceProp_t prop;
+    TRYHIP(hipGetDeviceProperties(&prop, device));
+    h->n_cu = std::max(1, prop.multiProcessorCount);
+  }
   TRYHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   TRYHIP(hipEventCreate(&h->ev0));
   TRYHIP(hipEventCreate(&h->ev1));
@@ -1518,7 +1529,7 @@ int fc_solver_set_dag(fc_handle h, int slot, int32_t n_nodes, const int64_t* nod
     }
     if (rows != S.stages[s].nrows) return fail(FC_ERR_INVALID, "fc_solver_set_dag: the nodes do not cover their stage");
   }
-  // the up-sweep rows, expanded: row r = concatenation of its segments, value source and buffer column per entry
+  // length of every up-sweep row (= concatenation of its segments)
   int64_t n_up_rows = 0;
   for (int s = 0; s < nst; ++s)
     if (S.stages[s].kind == 0) {
@@ -1526,27 +1537,15 @@ int fc_solver_set_dag(fc_handle h, int slot, int32_t n_nodes, const int64_t* nod
       n_up_rows += S.stages[s].nrows;
     }
   if ((int64_t)S.h_seg_ptr.size() < n_up_rows + 1) return fail(FC_ERR_INVALID, "fc_solver_set_dag: segment tables missing");
-  std::vector<int64_t> up_ptr((size_t)n_up_rows + 1, 0);
-  for (int64_t r = 0; r < n_up_rows; ++r) {
-    int64_t len = 0;
-    for (int64_t q = S.h_seg_ptr[r]; q < S.h_seg_ptr[r + 1]; ++q) len += S.h_seg_len[q];
-    up_ptr[r + 1] = up_ptr[r] + len;
-  }
-  const int64_t n_up = up_ptr[n_up_rows];
-  std::vector<int64_t> up_src((size_t)n_up + 1, 0);
-  std::vector<int> up_col((size_t)n_up + 1, 0);
-  for (int64_t r = 0; r < n_up_rows; ++r) {
-    int64_t k = up_ptr[r];
-    for (int64_t q = S.h_seg_ptr[r]; q < S.h_seg_ptr[r + 1]; ++q)
-      for (int j = 0; j < S.h_seg_len[q]; ++j, ++k) {
-        up_src[k] = S.h_seg_val[q] + j;
-        up_col[k] = S.h_seg_col[q] + j;  // up segments are contiguous slices of y (checked in fc_solver_setup)
-      }
-  }
-  // tasks, stage by stage (= topological order)
+  std::vector<int64_t> row_len((size_t)n_up_rows, 0);
+  for (int64_t r = 0; r < n_up_rows; ++r)
+    for (int64_t q = S.h_seg_ptr[r]; q < S.h_seg_ptr[r + 1]; ++q) row_len[r] += S.h_seg_len[q];
+  // tasks, stage by stage (= topological order).  Up tasks are ELL tiles: the rows of a tile are padded to the tile's
+  // longest row (value 0, column = the row itself), so that a lane finds its values from the task record alone.
   std::vector<FcDagTask> tasks;
-  std::vector<FcBlk> blocks;
   std::vector<int> task_node;
+  std::vector<int64_t> up_src;  // per expanded entry: index into f_val, -1 = padding
+  std::vector<int> up_col;
   auto pow2_ceil = [](int v) { int p = 1; while (p < v) p <<= 1; return p; };
   for (int s = 0; s < nst; ++s) {
     Stage& st = S.stages[s];
@@ -1554,19 +1553,37 @@ int fc_solver_set_dag(fc_handle h, int slot, int32_t n_nodes, const int64_t* nod
     for (int g : stage_nodes[s]) {
       Nd& d = nd[g];
       if (st.kind == 0) {
-        // rows of one node; lanes per row from the node's longest row (a lane holds <= FC_DAG_PV of its values)
+        // lanes per row from the node's longest row (a lane holds <= FC_DAG_PV of its values in registers)
         const int64_t row_first = st.rp_begin + (d.i0 - st.row0);
         int64_t maxlen = 1;
-        for (int r = 0; r < d.ni; ++r) maxlen = std::max(maxlen, up_ptr[row_first + r + 1] - up_ptr[row_first + r]);
+        for (int r = 0; r < d.ni; ++r) maxlen = std::max(maxlen, row_len[row_first + r]);
         const int lpr = std::min(256, std::max(8, pow2_ceil((int)((maxlen + FC_DAG_PV - 1) / FC_DAG_PV))));
         const int R = 256 / lpr;
         for (int r0 = 0; r0 < d.ni; r0 += R) {
+          const int nr = std::min(R, d.ni - r0);
+          int64_t stride = 1;
+          for (int r = 0; r < nr; ++r) stride = std::max(stride, row_len[row_first + r0 + r]);
+          if (stride > std::numeric_limits<int>::max()) return fail(FC_ERR_INVALID, "fc_solver_set_dag: row too long");
           FcDagTask t{};
           t.kind = 0;
-          t.a = (int)(row_first + r0);
-          t.nrows = std::min(R, d.ni - r0);
+          t.lpr = lpr;
+          t.nrows = nr;
           t.dest0 = d.i0 + r0;
-          t.geom = lpr;
+          t.stride = (int)stride;
+          t.val = (long long)up_src.size();
+          for (int r = 0; r < nr; ++r) {
+            const int64_t row = row_first + r0 + r;
+            int64_t k = 0;
+            for (int64_t q = S.h_seg_ptr[row]; q < S.h_seg_ptr[row + 1]; ++q)
+              for (int j = 0; j < S.h_seg_len[q]; ++j, ++k) {
+                up_src.push_back(S.h_seg_val[q] + j);
+                up_col.push_back(S.h_seg_col[q] + j);  // up segments are contiguous slices of y (checked in fc_solver_setup)
+              }
+            for (; k < stride; ++k) {
+              up_src.push_back(-1);
+              up_col.push_back(d.i0 + r0 + r);
+            }
+          }
           tasks.push_back(t);
           task_node.push_back(g);
           ++d.up_n;
@@ -1580,9 +1597,15 @@ int fc_solver_set_dag(fc_handle h, int slot, int32_t n_nodes, const int64_t* nod
         for (int r0 = r_lo; r0 < r_hi; r0 += R) {
           FcDagTask t{};
           t.kind = 1;
-          t.a = (int)blocks.size();
-          t.geom = lpr;
-          blocks.push_back(FcBlk{(long long)(d.voff + (int64_t)r0 * wd), d.i0 + r0, std::min(R, r_hi - r0), d.i0, d.ni, (int)d.ioff, d.nb});
+          t.lpr = lpr;
+          t.nrows = std::min(R, r_hi - r0);
+          t.dest0 = N + d.i0 + r0;
+          t.stride = wd;
+          t.val = (long long)(d.voff + (int64_t)r0 * wd);
+          t.i0 = d.i0;
+          t.ni = d.ni;
+          t.ioff = (int)d.ioff;
+          t.nb = d.nb;
           tasks.push_back(t);
           task_node.push_back(g);
           ++d.dn_n;
@@ -1591,6 +1614,9 @@ int fc_solver_set_dag(fc_handle h, int slot, int32_t n_nodes, const int64_t* nod
     }
     st.dag_ntasks = (int)tasks.size() - st.dag_task0;
   }
+  const int64_t n_up = (int64_t)up_src.size();
+  up_src.push_back(-1);
+  up_col.push_back(0);
   // arrival counters: one 128-byte line per shard
   int words = 0;
   auto shards = [](int ntasks) { return ntasks <= 12 ? 1 : std::min(FC_DAG_MAX_SHARDS, (ntasks + 11) / 12); };
@@ -1642,19 +1668,16 @@ int fc_solver_set_dag(fc_handle h, int slot, int32_t n_nodes, const int64_t* nod
     }
   }
   if (tasks.empty()) return fail(FC_ERR_INVALID, "fc_solver_set_dag: no tasks");
-  if (blocks.empty()) blocks.push_back(FcBlk{0, 0, 0, 0, 0, 0, 0});
   FCCHK(S.dag_tasks.upload(tasks, h->stream));
   FCCHK(S.dag_deps.upload(deps, h->stream));
-  FCCHK(S.dag_blk.upload(blocks, h->stream));
   FCCHK(S.dag_cnt.alloc((size_t)std::max(words, FC_DAG_SHARD_STRIDE)));
   FCCHK(S.dag_cnt.zero(h->stream));
-  FCCHK(S.dag_up_ptr.upload(up_ptr, h->stream));
   FCCHK(S.dag_up_src.upload(up_src, h->stream));
   FCCHK(S.dag_up_col.upload(up_col, h->stream));
   FCCHK(S.dag_up_val.alloc((size_t)n_up + 1));
   S.dag_up_n = n_up;
   // values as they stand now (host factorisation: final; device factorisation: refreshed by fc_refactor)
-  hipLaunchKernelGGL(fc_gather64, dim3(nblocks(n_up + 1, 256)), dim3(256), 0, h->stream, n_up + 1, S.dag_up_src.p, S.f_val.p, S.dag_up_val.p);
+  hipLaunchKernelGGL(fc_gather64_pad, dim3(nblocks(n_up + 1, 256)), dim3(256), 0, h->stream, n_up + 1, S.dag_up_src.p, S.f_val.p, S.dag_up_val.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
   S.dag_epoch = 0;
@@ -1904,7 +1927,7 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
     }
   }
   if (S.dag_ready)  // row-by-row copy of the -L values for the one-launch apply
-    hipLaunchKernelGGL(fc_gather64, dim3(nblocks(S.dag_up_n + 1, 256)), dim3(256), 0, h->stream, S.dag_up_n + 1, S.dag_up_src.p, fv,
+    hipLaunchKernelGGL(fc_gather64_pad, dim3(nblocks(S.dag_up_n + 1, 256)), dim3(256), 0, h->stream, S.dag_up_n + 1, S.dag_up_src.p, fv,
                        S.dag_up_val.p);
   HIPCHK(hipEventRecord(h->ev1, h->stream));
   HIPCHK(hipEventSynchronize(h->ev1));

@@ -557,6 +557,12 @@ __global__ void fc_gather64(int64_t n, const int64_t* __restrict__ src, const do
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k < n) out[k] = vals[src[k]];
 }
+// out[k] = vals[src[k]], 0 where src[k] < 0 (padding of the one-launch apply's row tiles)
+__global__ void fc_gather64_pad(int64_t n, const int64_t* __restrict__ src, const double* __restrict__ vals,
+                                double* __restrict__ out) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) out[k] = src[k] >= 0 ? vals[src[k]] : 0.0;
+}
 // extend-add: parent[p[i], p[j]] += child update block [i, j].  One launch covers the c-th child of
 // every parent of a level, so no two workgroups of a launch touch the same parent entry.
 struct __attribute__((aligned(16))) FcExt {
