@@ -173,7 +173,10 @@ struct fc_ctx {
   bool have_mp = false;
   // solver options
   int method = FC_METHOD_REFINE, max_iter = 1, check_residual = 1;
-  DevBuf<double> kry;  // BiCGStab work vectors (8 N), allocated on first use
+  DevBuf<double> kry;  // Krylov work vectors (BiCGStab: 8 N; GMRES(m): (m + 4) N), allocated on first use
+  DevBuf<double> ks;   // device-resident scalars of the Krylov recurrences (KS_* in fc_kernels.hip.h)
+  DevBuf<double> gm, mdot;  // GMRES: Hessenberg / rotations / small vectors; multi-dot partials
+  int gmres_m = 30;    // restart length
   double rtol = 1e-10;
   // state + work
   DevBuf<double> u_n, u_nn, p_n, up;
@@ -2007,10 +2010,10 @@ int fc_set_energy_matrix(fc_handle h, const int32_t* rowptr, const int32_t* col,
 
 int fc_set_solver_options(fc_handle h, int method, int max_iter, double rtol, int check_residual) {
   if (!h || max_iter < 0 || max_iter > 1000) return fail(FC_ERR_INVALID, "fc_set_solver_options: bad argument");
-  if (method != FC_METHOD_REFINE && method != FC_METHOD_BICGSTAB)
-    return fail(FC_ERR_INVALID, "fc_set_solver_options: method not available in this build (REFINE, BICGSTAB)");
-  if (method == FC_METHOD_BICGSTAB && (max_iter < 1 || !(rtol > 0.0)))
-    return fail(FC_ERR_INVALID, "fc_set_solver_options: BiCGStab needs max_iter >= 1 and rtol > 0");
+  if (method != FC_METHOD_REFINE && method != FC_METHOD_BICGSTAB && method != FC_METHOD_GMRES)
+    return fail(FC_ERR_INVALID, "fc_set_solver_options: unknown method (REFINE, BICGSTAB, GMRES)");
+  if (method != FC_METHOD_REFINE && (max_iter < 1 || !(rtol > 0.0)))
+    return fail(FC_ERR_INVALID, "fc_set_solver_options: the Krylov methods need max_iter >= 1 and rtol > 0");
   h->method = method;
   h->max_iter = max_iter;
   h->rtol = rtol;
@@ -2213,23 +2216,33 @@ int fc_assemble_rhs(fc_handle h, int order_slot, const double* u_ctrl, double* b
 
 // Right-preconditioned BiCGStab on the permuted system A_p x = b_p, M^-1 = the factor sweeps of the slot
 // (exact factors: one iteration; factors of an EARLIER operator — fc_update_operator without
-// fc_refactor — : a few).  b_p in h->b on entry, x_p in kry[0..N) on exit.  Scalars come back to the
-// host once per dot pair; fixed reduction order.  iters/relres report what happened.
+// fc_refactor — : a few; truncated factors: the memory-lean preconditioner).  b_p in h->b on entry, x_p in
+// kry[0..N) on exit.  DEVICE-RESIDENT: rho, alpha, omega, the update coefficients and the convergence state live in
+// h->ks; the vector kernels read them there and become no-ops once the state says "done".  The host enqueues
+// FC_KRYLOV_CHECK iterations at a time and reads the state word once per batch — no synchronisation per dot product.
+// Fixed reduction order.  iters / relres report what happened.
+constexpr int kKrylovCheck = 4;
+
+int krylov_state(fc_ctx* h, double* ks_host) {
+  HIPCHK(hipMemcpyAsync(ks_host, h->ks.p, KS_SIZE * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return FC_OK;
+}
+
 int bicgstab_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
   const int N = h->N, g = nblocks(N, 256), gd = std::min(g, 512);
   if (h->kry.n != 8 * (size_t)N) FCCHK(h->kry.alloc(8 * (size_t)N));
+  if (h->ks.n != KS_SIZE) FCCHK(h->ks.alloc(KS_SIZE));
   double *x = h->kry.p, *r = x + N, *rh = r + N, *p = rh + N, *v = p + N, *s = v + N, *t = s + N, *ph = t + N;
   double* sh = h->tmpN2.p;
+  double* ks = h->ks.p;
   const double mean = (double)S.Ap_nnz / std::max(1, N);
-  auto dots = [&](const double* a, const double* b_, const double* c, const double* d, double* out2) -> int {
+  auto dots = [&](int phase, const double* a, const double* b_, const double* c, const double* d) {
     hipLaunchKernelGGL(fc_dots2, dim3(gd), dim3(256), 0, h->stream, N, a, b_, c, d, h->partial.p);
-    hipLaunchKernelGGL(fc_reduce_final, dim3(2), dim3(256), 0, h->stream, gd, h->partial.p, 1.0, h->scal.p + 4);
-    HIPCHK(hipMemcpyAsync(out2, h->scal.p + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return FC_OK;
+    hipLaunchKernelGGL(fc_bicg_phase, dim3(1), dim3(256), 0, h->stream, phase, gd, h->partial.p, ks, h->rtol, 1, 1);
   };
-  auto lin3 = [&](double* out, double c0, const double* v0, double c1, const double* v1, double c2, const double* v2) {
-    hipLaunchKernelGGL(fc_lin3, dim3(g), dim3(256), 0, h->stream, N, out, c0, v0, c1, v1, c2, v2);
+  auto lin3 = [&](double* out, int coef, const double* v0, const double* v1, const double* v2) {
+    hipLaunchKernelGGL(fc_lin3_dev, dim3(g), dim3(256), 0, h->stream, N, out, ks + KS_COEF + 3 * coef, v0, v1, v2, ks);
   };
   auto precond = [&](const double* in, double* out) -> int {  // out = M^-1 in
     hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, in, h->buf.p);
@@ -2241,62 +2254,163 @@ int bicgstab_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
     const int nb = launch_spmv<0>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, in, nullptr, out, nullptr, nullptr);
     return nb < 0 ? nb : FC_OK;
   };
+  HIPCHK(hipMemsetAsync(ks, 0, KS_SIZE * sizeof(double), h->stream));
   HIPCHK(hipMemsetAsync(x, 0, (size_t)N * sizeof(double), h->stream));
   hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, r);
   hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, rh);
-  double d2[2];
-  FCCHK(dots(r, r, rh, r, d2));
-  const double bnorm = std::sqrt(d2[0]);
+  dots(0, r, r, rh, r);
+  double kh[KS_SIZE];
   *iters = 0;
   *relres = 0.0;
-  if (!(bnorm > 0.0)) return FC_OK;  // b = 0 -> x = 0
-  double rho = d2[1], rho_old = 1.0, alpha = 1.0, omega = 1.0, rnorm = bnorm;
   for (int it = 1; it <= h->max_iter; ++it) {
-    if (!std::isfinite(rho) || std::fabs(rho) < 1e-300 * bnorm * bnorm) return fail(FC_ERR_NOT_CONVERGED, "BiCGStab breakdown (rho = 0)");
-    if (it == 1) {
-      hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, r, p);
-    } else {
-      const double beta = (rho / rho_old) * (alpha / omega);
-      lin3(p, 1.0, r, beta, p, -beta * omega, v);
-    }
+    lin3(p, 3, r, p, v);  // p = r + beta (p - omega v)   (first iteration: p = r)
     FCCHK(precond(p, ph));
     FCCHK(matvec(ph, v));
-    FCCHK(dots(rh, v, rh, v, d2));
-    if (!std::isfinite(d2[0]) || d2[0] == 0.0) return fail(FC_ERR_NOT_CONVERGED, "BiCGStab breakdown (r^.v = 0)");
-    alpha = rho / d2[0];
-    lin3(s, 1.0, r, -alpha, v, 0.0, nullptr);
-    FCCHK(dots(s, s, s, s, d2));
-    *iters = it;
-    if (std::sqrt(d2[0]) <= h->rtol * bnorm) {
-      lin3(x, 1.0, x, alpha, ph, 0.0, nullptr);
-      rnorm = std::sqrt(d2[0]);
-      break;
-    }
+    dots(1, rh, v, rh, v);
+    lin3(s, 0, r, v, nullptr);  // s = r - alpha v
+    dots(2, s, s, s, s);
     FCCHK(precond(s, sh));
     FCCHK(matvec(sh, t));
-    FCCHK(dots(t, s, t, t, d2));
-    if (!std::isfinite(d2[1]) || d2[1] == 0.0) return fail(FC_ERR_NOT_CONVERGED, "BiCGStab breakdown (t.t = 0)");
-    omega = d2[0] / d2[1];
-    lin3(x, 1.0, x, alpha, ph, omega, sh);
-    lin3(r, 1.0, s, -omega, t, 0.0, nullptr);
-    FCCHK(dots(r, r, rh, r, d2));
-    rnorm = std::sqrt(d2[0]);
-    rho_old = rho;
-    rho = d2[1];
-    if (rnorm <= h->rtol * bnorm) break;
-    if (omega == 0.0) return fail(FC_ERR_NOT_CONVERGED, "BiCGStab breakdown (omega = 0)");
-    if (it == h->max_iter) {
-      *relres = rnorm / bnorm;
-      return fail(FC_ERR_NOT_CONVERGED, "BiCGStab: residual " + std::to_string(rnorm / bnorm) + " after " + std::to_string(it) +
-                                            " iterations (rtol " + std::to_string(h->rtol) + ")");
+    dots(3, t, s, t, t);
+    lin3(x, 1, x, ph, sh);      // x += alpha ph + omega sh
+    lin3(r, 2, s, t, nullptr);  // r = s - omega t
+    dots(4, r, r, rh, r);
+    if (it % kKrylovCheck == 0 || it == h->max_iter) {
+      FCCHK(krylov_state(h, kh));
+      if (kh[KS_STATE] != 0.0) break;
     }
+  }
+  FCCHK(krylov_state(h, kh));
+  *iters = (int)kh[KS_ITERS];
+  const double bnorm = std::sqrt(kh[KS_BNORM2]);
+  if (kh[KS_STATE] < 0.0) return fail(FC_ERR_NOT_CONVERGED, "BiCGStab breakdown (code " + std::to_string((int)kh[KS_STATE]) + ")");
+  if (!(bnorm > 0.0)) return FC_OK;  // b = 0 -> x = 0
+  if (kh[KS_STATE] != 1.0) {
+    *relres = std::sqrt(kh[KS_RNORM2]) / bnorm;
+    return fail(FC_ERR_NOT_CONVERGED, "BiCGStab: residual " + std::to_string(*relres) + " after " + std::to_string(*iters) +
+                                          " iterations (rtol " + std::to_string(h->rtol) + ")");
   }
   // report the TRUE residual of the returned x
   FCCHK(matvec(x, t));
-  lin3(t, 1.0, h->b.p, -1.0, t, 0.0, nullptr);
-  FCCHK(dots(t, t, t, t, d2));
-  *relres = std::sqrt(d2[0]) / bnorm;
+  hipLaunchKernelGGL(fc_lin3, dim3(g), dim3(256), 0, h->stream, N, t, 1.0, h->b.p, -1.0, t, 0.0, (const double*)nullptr);
+  hipLaunchKernelGGL(fc_dots2, dim3(gd), dim3(256), 0, h->stream, N, t, t, t, t, h->partial.p);
+  hipLaunchKernelGGL(fc_bicg_phase, dim3(1), dim3(256), 0, h->stream, -1, gd, h->partial.p, ks, h->rtol, 1, 0);
+  FCCHK(krylov_state(h, kh));
+  *relres = std::sqrt(kh[KS_D0]) / bnorm;
   HIPCHK(hipGetLastError());
+  return FC_OK;
+}
+
+// Restarted GMRES(m), right-preconditioned by the slot's factor sweeps: x = M^-1 (V y).  Classical Gram-Schmidt with
+// one re-orthogonalisation (two multi-dot launches per Arnoldi step instead of j sequential dots), Givens rotations and
+// the back substitution in a one-thread kernel, everything on the device; the host reads the state word once per
+// kKrylovCheck Arnoldi steps.  b_p in h->b on entry, x_p in kry[0..N) on exit.
+int gmres_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
+  const int N = h->N, g = nblocks(N, 256), gd = std::min(g, 256);
+  const int m = std::max(1, std::min(h->gmres_m, h->max_iter));
+  const size_t need = (size_t)(m + 4) * N;
+  if (h->kry.n < need) FCCHK(h->kry.alloc(need));
+  if (h->ks.n != KS_SIZE) FCCHK(h->ks.alloc(KS_SIZE));
+  const size_t gm_n = (size_t)(m + 1) * m + 2 * m + (m + 1) + m + (m + 2) + 2 + (m + 2);  // ... | norm2 | used | hcol2
+  if (h->gm.n < gm_n) FCCHK(h->gm.alloc(gm_n));
+  if (h->mdot.n < (size_t)(m + 1) * gd) FCCHK(h->mdot.alloc((size_t)(m + 1) * gd));
+  double *x = h->kry.p, *r = x + N, *w = r + N, *z = w + N, *V = z + N;
+  double *ks = h->ks.p, *gm = h->gm.p;
+  double* hcol = gm + (size_t)(m + 1) * m + 2 * m + (m + 1) + m;
+  double* norm2 = hcol + m + 2;
+  double* used_p = norm2 + 1;
+  double* hcol2 = used_p + 1;
+  double* yv = gm + (size_t)(m + 1) * m + 2 * m + (m + 1);
+  const double mean = (double)S.Ap_nnz / std::max(1, N);
+  auto precond = [&](const double* in, double* out) -> int {
+    hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, in, h->buf.p);
+    FCCHK(apply_factors(h, S));
+    hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->buf.p + N, out);
+    return FC_OK;
+  };
+  auto matvec = [&](const double* in, double* out) -> int {
+    const int nb = launch_spmv<0>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, in, nullptr, out, nullptr, nullptr);
+    return nb < 0 ? nb : FC_OK;
+  };
+  auto begin_cycle = [&](int first) {
+    hipLaunchKernelGGL(fc_dots2, dim3(gd), dim3(256), 0, h->stream, N, r, r, h->b.p, h->b.p, h->partial.p);
+    hipLaunchKernelGGL(fc_bicg_phase, dim3(1), dim3(256), 0, h->stream, -1, gd, h->partial.p, ks, h->rtol, 1, 0);
+    hipLaunchKernelGGL(fc_gmres_begin, dim3(1), dim3(1), 0, h->stream, m, gm, ks, h->rtol, first);
+    hipLaunchKernelGGL(fc_scale_by_norm, dim3(g), dim3(256), 0, h->stream, N, r, norm2, V, ks);
+  };
+  HIPCHK(hipMemsetAsync(ks, 0, KS_SIZE * sizeof(double), h->stream));
+  HIPCHK(hipMemsetAsync(gm, 0, gm_n * sizeof(double), h->stream));
+  HIPCHK(hipMemsetAsync(x, 0, (size_t)N * sizeof(double), h->stream));
+  hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, r);
+  begin_cycle(1);
+  double kh[KS_SIZE];
+  *iters = 0;
+  *relres = 0.0;
+  int total = 0;
+  bool done = false;
+  while (!done) {
+    int j = 0;
+    double state = 0.0;
+    for (; j < m && total < h->max_iter; ++j, ++total) {
+      double* vj = V + (size_t)j * N;
+      FCCHK(precond(vj, z));
+      FCCHK(matvec(z, w));
+      // classical Gram-Schmidt, twice: h = V^T w, w -= V h; h2 = V^T w, w -= V h2; Hessenberg column = h + h2
+      hipLaunchKernelGGL(fc_multidot, dim3(gd, j + 1), dim3(256), 0, h->stream, N, j + 1, V, w, h->mdot.p, ks);
+      hipLaunchKernelGGL(fc_multidot_reduce, dim3(j + 1), dim3(64), 0, h->stream, j + 1, gd, h->mdot.p, hcol, 0, ks);
+      hipLaunchKernelGGL(fc_gmres_project, dim3(g), dim3(256), 0, h->stream, N, j + 1, V, hcol, w, ks);
+      hipLaunchKernelGGL(fc_multidot, dim3(gd, j + 1), dim3(256), 0, h->stream, N, j + 1, V, w, h->mdot.p, ks);
+      hipLaunchKernelGGL(fc_multidot_reduce, dim3(j + 1), dim3(64), 0, h->stream, j + 1, gd, h->mdot.p, hcol2, 0, ks);
+      hipLaunchKernelGGL(fc_multidot_reduce, dim3(j + 1), dim3(64), 0, h->stream, j + 1, gd, h->mdot.p, hcol, 1, ks);
+      hipLaunchKernelGGL(fc_gmres_project, dim3(g), dim3(256), 0, h->stream, N, j + 1, V, hcol2, w, ks);
+      hipLaunchKernelGGL(fc_multidot, dim3(gd, 1), dim3(256), 0, h->stream, N, 1, w, w, h->mdot.p, ks);
+      hipLaunchKernelGGL(fc_multidot_reduce, dim3(1), dim3(64), 0, h->stream, 1, gd, h->mdot.p, norm2, 0, ks);
+      hipLaunchKernelGGL(fc_gmres_givens, dim3(1), dim3(1), 0, h->stream, j, m, gm, ks, h->rtol);
+      hipLaunchKernelGGL(fc_scale_by_norm, dim3(g), dim3(256), 0, h->stream, N, w, norm2, V + (size_t)(j + 1) * N, ks);
+      if ((j + 1) % kKrylovCheck == 0 || j + 1 == m || total + 1 == h->max_iter) {
+        FCCHK(krylov_state(h, kh));
+        state = kh[KS_STATE];
+        if (state != 0.0) {
+          ++j, ++total;
+          break;
+        }
+      }
+    }
+    FCCHK(krylov_state(h, kh));
+    state = kh[KS_STATE];
+    if (state < 0.0) return fail(FC_ERR_NOT_CONVERGED, "GMRES breakdown (code " + std::to_string((int)state) + ")");
+    if (state == 1.0) break;  // converged before the cycle started (or b = 0)
+    HIPCHK(hipMemcpyAsync(kh, used_p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int used = (int)kh[0];
+    if (state == 0.0) {
+      // iteration cap inside a cycle: close it (back substitution for the columns built so far)
+      return fail(FC_ERR_NOT_CONVERGED, "GMRES: iteration cap reached inside a cycle");
+    }
+    // x += M^-1 (V y)
+    hipLaunchKernelGGL(fc_gmres_combine, dim3(g), dim3(256), 0, h->stream, N, used, V, yv, w);
+    FCCHK(precond(w, z));
+    hipLaunchKernelGGL(fc_axpy, dim3(g), dim3(256), 0, h->stream, N, 1.0, z, x);
+    // true residual
+    FCCHK(matvec(x, w));
+    hipLaunchKernelGGL(fc_lin3, dim3(g), dim3(256), 0, h->stream, N, r, 1.0, h->b.p, -1.0, w, 0.0, (const double*)nullptr);
+    if (state == 3.0) {
+      done = true;
+    } else if (total >= h->max_iter) {
+      done = true;
+    } else {
+      begin_cycle(0);
+    }
+  }
+  hipLaunchKernelGGL(fc_dots2, dim3(gd), dim3(256), 0, h->stream, N, r, r, h->b.p, h->b.p, h->partial.p);
+  hipLaunchKernelGGL(fc_bicg_phase, dim3(1), dim3(256), 0, h->stream, -1, gd, h->partial.p, ks, h->rtol, 1, 0);
+  FCCHK(krylov_state(h, kh));
+  *iters = (int)kh[KS_ITERS];
+  const double bnorm = std::sqrt(kh[KS_D1]);
+  *relres = bnorm > 0.0 ? std::sqrt(kh[KS_D0]) / bnorm : 0.0;
+  HIPCHK(hipGetLastError());
+  if (bnorm > 0.0 && !(*relres <= 10.0 * h->rtol))
+    return fail(FC_ERR_NOT_CONVERGED, "GMRES: residual " + std::to_string(*relres) + " after " + std::to_string(*iters) + " iterations");
   return FC_OK;
 }
 
@@ -2324,11 +2438,11 @@ static int solve_once(fc_handle h, int slot, const double* b, double* x, double*
   HIPCHK(hipMemcpyAsync(h->tmpN.p, b, (size_t)N * sizeof(double), hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(fc_gather_perm, dim3(g), dim3(256), 0, h->stream, N, h->perm.p, h->tmpN.p, h->b.p);
   hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, h->buf.p);
-  if (h->method == FC_METHOD_BICGSTAB) {
-    if (h->partitioned) return fail(FC_ERR_INVALID, "fc_solve: BiCGStab is not available on a partitioned handle");
+  if (h->method == FC_METHOD_BICGSTAB || h->method == FC_METHOD_GMRES) {
+    if (h->partitioned) return fail(FC_ERR_INVALID, "fc_solve: the Krylov drivers are not available on a partitioned handle");
     int iters = 0;
     double relres = 0.0;
-    const int code = bicgstab_permuted(h, S, &iters, &relres);
+    const int code = h->method == FC_METHOD_GMRES ? gmres_permuted(h, S, &iters, &relres) : bicgstab_permuted(h, S, &iters, &relres);
     if (info_out) {
       info_out[0] = iters;
       info_out[1] = relres;

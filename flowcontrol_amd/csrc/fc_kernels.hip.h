@@ -1145,3 +1145,225 @@ __global__ void fc_reduce_final(int n, const double* __restrict__ partial, doubl
   }
   if (threadIdx.x == 0) out[0] = scale * red[0];
 }
+
+// ---------------------------------------------------------------------------------------------
+// Device-resident Krylov drivers (fc_solve with FC_METHOD_BICGSTAB / FC_METHOD_GMRES): every scalar of the
+// recurrences lives in `ks` on the device, the vector kernels read their coefficients from there and turn into
+// no-ops once ks[KS_STATE] says "done", so the host enqueues several iterations ahead and looks at the state word
+// only every few iterations (no synchronisation per dot product).
+// ---------------------------------------------------------------------------------------------
+enum { KS_STATE = 0, KS_ITERS, KS_BNORM2, KS_RNORM2, KS_RHO, KS_RHO_OLD, KS_ALPHA, KS_OMEGA, KS_COEF = 8 /* 4 triples */, KS_D0 = 24, KS_D1, KS_SIZE = 32 };
+// state: 0 running, 1 converged, 2 (BiCGStab) converged at the half step: finish with omega = 0, < 0 breakdown
+
+// out = c[0] v0 + c[1] v1 (+ c[2] v2), coefficients on the device; no-op when the solver is done
+__global__ void fc_lin3_dev(int n, double* out, const double* __restrict__ c, const double* v0, const double* v1, const double* v2,
+                            const double* __restrict__ ks) {
+  if (ks[KS_STATE] == 1.0 || ks[KS_STATE] < 0.0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    double s = c[0] * v0[i] + c[1] * v1[i];
+    if (v2) s += c[2] * v2[i];
+    out[i] = s;
+  }
+}
+
+// sum the two partial arrays of fc_dots2 (grid blocks each) into ks[KS_D0], ks[KS_D1] (fixed order), then thread 0
+// advances the BiCGStab recurrences (phase = which pair of dot products just finished)
+__global__ __launch_bounds__(256) void fc_bicg_phase(int phase, int nblk, const double* __restrict__ partial, double* ks, double rtol,
+                                                     int reduce, int update) {
+  __shared__ double r0[256], r1[256];
+  if (reduce) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) {
+      s0 += partial[i];
+      s1 += partial[nblk + i];
+    }
+    r0[threadIdx.x] = s0;
+    r1[threadIdx.x] = s1;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if ((int)threadIdx.x < st) {
+        r0[threadIdx.x] += r0[threadIdx.x + st];
+        r1[threadIdx.x] += r1[threadIdx.x + st];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      ks[KS_D0] = r0[0];
+      ks[KS_D1] = r1[0];
+    }
+  }
+  if (!update || threadIdx.x != 0) return;
+  const double d0 = ks[KS_D0], d1 = ks[KS_D1];
+  double* cS = ks + KS_COEF;       // s = r - alpha v
+  double* cX = ks + KS_COEF + 3;   // x = x + alpha ph + omega sh
+  double* cR = ks + KS_COEF + 6;   // r = s - omega t
+  double* cP = ks + KS_COEF + 9;   // p = r + beta p - beta omega v
+  const double st = ks[KS_STATE];
+  if (phase == 0) {  // d0 = r.r = |b|^2, d1 = rh.r
+    ks[KS_BNORM2] = d0;
+    ks[KS_RNORM2] = d0;
+    ks[KS_RHO] = d1;
+    ks[KS_RHO_OLD] = 1.0;
+    ks[KS_ALPHA] = 1.0;
+    ks[KS_OMEGA] = 1.0;
+    ks[KS_ITERS] = 0.0;
+    ks[KS_STATE] = d0 > 0.0 ? 0.0 : 1.0;  // b = 0 -> x = 0
+    cP[0] = 1.0, cP[1] = 0.0, cP[2] = 0.0;  // first iteration: p = r
+    return;
+  }
+  if (st == 1.0 || st < 0.0) return;
+  if (phase == 1) {  // d0 = rh.v
+    if (!isfinite(d0) || d0 == 0.0 || !isfinite(ks[KS_RHO]) || fabs(ks[KS_RHO]) < 1e-300 * ks[KS_BNORM2]) {
+      ks[KS_STATE] = -1.0;
+      return;
+    }
+    const double alpha = ks[KS_RHO] / d0;
+    ks[KS_ALPHA] = alpha;
+    cS[0] = 1.0, cS[1] = -alpha, cS[2] = 0.0;
+  } else if (phase == 2) {  // d0 = s.s
+    ks[KS_ITERS] += 1.0;
+    if (sqrt(d0) <= rtol * sqrt(ks[KS_BNORM2])) ks[KS_STATE] = 2.0;
+  } else if (phase == 3) {  // d0 = t.s, d1 = t.t
+    double omega = 0.0;
+    if (st != 2.0) {
+      if (!isfinite(d1) || d1 == 0.0) {
+        ks[KS_STATE] = -2.0;
+        return;
+      }
+      omega = d0 / d1;
+    }
+    ks[KS_OMEGA] = omega;
+    cX[0] = 1.0, cX[1] = ks[KS_ALPHA], cX[2] = omega;
+    cR[0] = 1.0, cR[1] = -omega, cR[2] = 0.0;
+  } else if (phase == 4) {  // d0 = r.r, d1 = rh.r
+    ks[KS_RNORM2] = d0;
+    if (st == 2.0 || sqrt(d0) <= rtol * sqrt(ks[KS_BNORM2])) {
+      ks[KS_STATE] = 1.0;
+      return;
+    }
+    if (ks[KS_OMEGA] == 0.0) {
+      ks[KS_STATE] = -3.0;
+      return;
+    }
+    ks[KS_RHO_OLD] = ks[KS_RHO];
+    ks[KS_RHO] = d1;
+    const double beta = (d1 / ks[KS_RHO_OLD]) * (ks[KS_ALPHA] / ks[KS_OMEGA]);
+    cP[0] = 1.0, cP[1] = beta, cP[2] = -beta * ks[KS_OMEGA];
+  }
+}
+
+// GMRES(m): h[i] = V_i . w for i < nv (one block per (vector, chunk); partial[i * gx + blockIdx.x])
+__global__ __launch_bounds__(256) void fc_multidot(int n, int nv, const double* __restrict__ V, const double* __restrict__ w,
+                                                   double* __restrict__ partial, const double* __restrict__ ks) {
+  if (ks[KS_STATE] != 0.0) return;
+  const int i = blockIdx.y;
+  const double* __restrict__ v = V + (size_t)i * n;
+  double s = 0.0;
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) s += v[k] * w[k];
+  __shared__ double red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[(size_t)i * gridDim.x + blockIdx.x] = red[0];
+}
+// h[i] (+)= sum of its gx partials (fixed order); one wave per dot
+__global__ void fc_multidot_reduce(int nv, int gx, const double* __restrict__ partial, double* h, int accumulate, const double* __restrict__ ks) {
+  if (ks[KS_STATE] != 0.0) return;
+  const int i = blockIdx.x;
+  double s = 0.0;
+  for (int k = threadIdx.x; k < gx; k += 64) s += partial[(size_t)i * gx + k];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (threadIdx.x == 0 && i < nv) h[i] = accumulate ? h[i] + s : s;
+}
+// w -= sum_i h[i] V_i
+__global__ void fc_gmres_project(int n, int nv, const double* __restrict__ V, const double* __restrict__ h, double* w,
+                                 const double* __restrict__ ks) {
+  if (ks[KS_STATE] != 0.0) return;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  double s = w[k];
+  for (int i = 0; i < nv; ++i) s -= h[i] * V[(size_t)i * n + k];
+  w[k] = s;
+}
+// out = scale_num / sqrt(*norm2) * in   (v_{j+1} = w / |w|; norm2 on the device)
+__global__ void fc_scale_by_norm(int n, const double* __restrict__ in, const double* __restrict__ norm2, double* out,
+                                 const double* __restrict__ ks) {
+  if (ks[KS_STATE] != 0.0) return;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) out[k] = in[k] / sqrt(norm2[0]);
+}
+// out = sum_i y[i] V_i  (the correction in the Krylov basis)
+__global__ void fc_gmres_combine(int n, int nv, const double* __restrict__ V, const double* __restrict__ y, double* out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  double s = 0.0;
+  for (int i = 0; i < nv; ++i) s += y[i] * V[(size_t)i * n + k];
+  out[k] = s;
+}
+// One thread: column j of the Hessenberg matrix (h[0..j] from the projections, h[j+1] = |w| from norm2) through the
+// stored Givens rotations, new rotation, residual estimate |g[j+1]|; when converged or at j + 1 == m: back substitution
+// y = R^-1 g.  gm layout: H (m+1) x m column-major | cs[m] | sn[m] | g[m+1] | y[m] | hcol[m+2] | norm2 | used
+__global__ void fc_gmres_givens(int j, int m, double* gm, double* ks, double rtol) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double* H = gm;
+  double* cs = H + (size_t)(m + 1) * m;
+  double* sn = cs + m;
+  double* g = sn + m;
+  double* y = g + m + 1;
+  double* hcol = y + m;
+  double* norm2 = hcol + m + 2;
+  double* used = norm2 + 1;
+  if (ks[KS_STATE] != 0.0) return;
+  double* Hj = H + (size_t)j * (m + 1);
+  for (int i = 0; i <= j; ++i) Hj[i] = hcol[i];
+  Hj[j + 1] = sqrt(norm2[0]);
+  for (int i = 0; i < j; ++i) {
+    const double a = cs[i] * Hj[i] + sn[i] * Hj[i + 1], b = -sn[i] * Hj[i] + cs[i] * Hj[i + 1];
+    Hj[i] = a;
+    Hj[i + 1] = b;
+  }
+  const double a = Hj[j], b = Hj[j + 1], r = hypot(a, b);
+  if (!(r > 0.0) || !isfinite(r)) {
+    ks[KS_STATE] = -4.0;
+    return;
+  }
+  cs[j] = a / r;
+  sn[j] = b / r;
+  Hj[j] = r;
+  Hj[j + 1] = 0.0;
+  g[j + 1] = -sn[j] * g[j];
+  g[j] = cs[j] * g[j];
+  ks[KS_ITERS] += 1.0;
+  ks[KS_RNORM2] = g[j + 1] * g[j + 1];
+  used[0] = (double)(j + 1);
+  const bool conv = fabs(g[j + 1]) <= rtol * sqrt(ks[KS_BNORM2]);
+  if (conv || j + 1 == m) {
+    for (int i = j; i >= 0; --i) {
+      double s = g[i];
+      for (int k = i + 1; k <= j; ++k) s -= H[(size_t)k * (m + 1) + i] * y[k];
+      y[i] = s / H[(size_t)i * (m + 1) + i];
+    }
+    ks[KS_STATE] = conv ? 3.0 : 4.0;  // 3: converged, 4: restart — both: the cycle's correction must be applied
+  }
+}
+// start of a GMRES cycle: norm2[0] = |r|^2 (from D0), g = (|r|, 0, ...), state -> running or converged
+__global__ void fc_gmres_begin(int m, double* gm, double* ks, double rtol, int first) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double* g = gm + (size_t)(m + 1) * m + 2 * m;
+  double* norm2 = g + (m + 1) + m + (m + 2);
+  const double r2 = ks[KS_D0];
+  if (first) {
+    ks[KS_BNORM2] = ks[KS_D1];
+    ks[KS_ITERS] = 0.0;
+  }
+  ks[KS_RNORM2] = r2;
+  norm2[0] = r2;
+  for (int i = 0; i <= m; ++i) g[i] = 0.0;
+  g[0] = sqrt(r2);
+  ks[KS_STATE] = (sqrt(r2) <= rtol * sqrt(ks[KS_BNORM2]) || !(ks[KS_BNORM2] > 0.0)) ? 1.0 : 0.0;
+}

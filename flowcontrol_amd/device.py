@@ -349,10 +349,11 @@ class DeviceSolver:
 
     def set_solver_options(self, refine: int = 0, check_residual: bool = True, method: str = "refine", rtol: float = 1e-10) -> None:
         """``method="refine"``: factor sweeps (+ ``refine`` iterative-refinement sweeps) — what the time steps use.
-        ``method="bicgstab"``: right-preconditioned BiCGStab (``refine`` = iteration cap, ``rtol`` = relative
-        residual target) with the slot's current factors as preconditioner; for :meth:`solve` only."""
+        ``method="bicgstab"`` / ``"gmres"``: right-preconditioned BiCGStab / restarted GMRES(30), device-resident
+        (``refine`` = iteration cap, ``rtol`` = relative residual target), with the slot's current factors as
+        preconditioner; for :meth:`solve` only."""
         self._solver_opts = (int(refine), bool(check_residual), method, float(rtol))
-        m = {"refine": _lib.METHOD_REFINE, "bicgstab": _lib.METHOD_BICGSTAB}[method]
+        m = {"refine": _lib.METHOD_REFINE, "bicgstab": _lib.METHOD_BICGSTAB, "gmres": _lib.METHOD_GMRES}[method]
         check(self.lib.fc_set_solver_options(self._h, m, int(refine), float(rtol), int(check_residual)))
 
     def update_operator(self, slot: int) -> None:
