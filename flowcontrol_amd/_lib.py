@@ -108,6 +108,7 @@ SIGNATURES: dict[str, list] = {
     "fc_solver_set_dag": [_H, C.c_int, C.c_int32, _lp, np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS"), _ip, _ip, _ip],
     "fc_get_dag_info": [_H, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "fc_set_dag": [_H, C.c_int],
+    "fc_set_stage_diag": [_H, C.c_int, _dp],
     "fc_debug_inject_dag_failure": [_H, C.c_int],
     "fc_debug_trace_apply": [_H, C.c_int, C.c_int32, _lp, _ip, _ip],
 }

@@ -80,7 +80,7 @@ struct Stage {
   int64_t rp_begin;  // offset of the stage's first row in seg_ptr
   int row0;          // first destination row (permuted numbering)
   int nrows;
-  int kind;  // 0 up, 1 down
+  int kind;  // 0 up, 1 down, 2 diagonal (truncated factors: x = dscale * y on the rows whose pivot blocks are not kept)
   int lanes, sub;  // lanes per row, lanes per segment slot
   int64_t blk_begin = 0;  // down stages: LDS-tiled block kernel (fc_nd_down_block) when blk_count > 0
   int blk_count = 0, blk_lpr = 64, blk_rps = 1;
@@ -102,6 +102,8 @@ struct OrderSys {
   DevBuf<int> f_idx;
   DevBuf<double> f_val;
   int64_t f_nnz = 0;
+  DevBuf<double> dscale;  // kind-2 stages (fc_set_stage_diag), permuted numbering
+  bool truncated = false;  // the factors are a preconditioner only (some pivot blocks replaced by a diagonal)
   std::vector<Stage> stages;
   double sweep_bytes = 0.0;
   int ar_stage = -1, ar_row0 = 0, ar_n = 0;  // all-reduce buf[ar_row0 .. +ar_n) after this stage
@@ -177,6 +179,7 @@ struct fc_ctx {
   DevBuf<double> ks;   // device-resident scalars of the Krylov recurrences (KS_* in fc_kernels.hip.h)
   DevBuf<double> gm, mdot;  // GMRES: Hessenberg / rotations / small vectors; multi-dot partials
   int gmres_m = 30;    // restart length
+  int last_krylov_iters = 0;
   double rtol = 1e-10;
   // state + work
   DevBuf<double> u_n, u_nn, p_n, up;
@@ -454,6 +457,13 @@ int launch_spmv(fc_ctx* h, int nrows, double mean, const int* rp, const int* col
 }
 
 int launch_sweep(fc_ctx* h, const OrderSys& S, const Stage& st) {
+  if (st.kind == 2) {
+    if (S.dscale.n != (size_t)h->N) return fail(FC_ERR_NOT_READY, "fc_set_stage_diag not called for a truncated factorisation");
+    hipLaunchKernelGGL(fc_diag_stage, dim3(nblocks(st.nrows, 256)), dim3(256), 0, h->stream, st.nrows, S.dscale.p + st.row0, h->buf.p + st.row0,
+                       h->buf.p + h->N + st.row0);
+    HIPCHK(hipGetLastError());
+    return FC_OK;
+  }
   if (st.kind == 1 && st.blk_count > 0) {
     const FcBlk* bp = S.blk.p + st.blk_begin;
 #define FC_BLOCK(L, R)                                                                                                   \
@@ -789,17 +799,229 @@ int launch_tail(fc_ctx* h, OrderSys& S, int compute_energy, double* d_y, double*
   return FC_OK;
 }
 
+// Right-preconditioned BiCGStab on the permuted system A_p x = b_p, M^-1 = the factor sweeps of the slot
+// (exact factors: one iteration; factors of an EARLIER operator — fc_update_operator without
+// fc_refactor — : a few; truncated factors: the memory-lean preconditioner).  b_p in h->b on entry, x_p in
+// kry[0..N) on exit.  DEVICE-RESIDENT: rho, alpha, omega, the update coefficients and the convergence state live in
+// h->ks; the vector kernels read them there and become no-ops once the state says "done".  The host enqueues
+// FC_KRYLOV_CHECK iterations at a time and reads the state word once per batch — no synchronisation per dot product.
+// Fixed reduction order.  iters / relres report what happened.
+constexpr int kKrylovCheck = 4;
+
+int krylov_state(fc_ctx* h, double* ks_host) {
+  HIPCHK(hipMemcpyAsync(ks_host, h->ks.p, KS_SIZE * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return FC_OK;
+}
+
+int bicgstab_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
+  const int N = h->N, g = nblocks(N, 256), gd = std::min(g, 512);
+  if (h->kry.n != 8 * (size_t)N) FCCHK(h->kry.alloc(8 * (size_t)N));
+  if (h->ks.n != KS_SIZE) FCCHK(h->ks.alloc(KS_SIZE));
+  double *x = h->kry.p, *r = x + N, *rh = r + N, *p = rh + N, *v = p + N, *s = v + N, *t = s + N, *ph = t + N;
+  double* sh = h->tmpN2.p;
+  double* ks = h->ks.p;
+  const double mean = (double)S.Ap_nnz / std::max(1, N);
+  auto dots = [&](int phase, const double* a, const double* b_, const double* c, const double* d) {
+    hipLaunchKernelGGL(fc_dots2, dim3(gd), dim3(256), 0, h->stream, N, a, b_, c, d, h->partial.p);
+    hipLaunchKernelGGL(fc_bicg_phase, dim3(1), dim3(256), 0, h->stream, phase, gd, h->partial.p, ks, h->rtol, 1, 1);
+  };
+  auto lin3 = [&](double* out, int coef, const double* v0, const double* v1, const double* v2) {
+    hipLaunchKernelGGL(fc_lin3_dev, dim3(g), dim3(256), 0, h->stream, N, out, ks + KS_COEF + 3 * coef, v0, v1, v2, ks);
+  };
+  auto precond = [&](const double* in, double* out) -> int {  // out = M^-1 in
+    hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, in, h->buf.p);
+    FCCHK(apply_factors(h, S));
+    hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->buf.p + N, out);
+    return FC_OK;
+  };
+  auto matvec = [&](const double* in, double* out) -> int {
+    const int nb = launch_spmv<0>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, in, nullptr, out, nullptr, nullptr);
+    return nb < 0 ? nb : FC_OK;
+  };
+  HIPCHK(hipMemsetAsync(ks, 0, KS_SIZE * sizeof(double), h->stream));
+  HIPCHK(hipMemsetAsync(x, 0, (size_t)N * sizeof(double), h->stream));
+  hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, r);
+  hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, rh);
+  dots(0, r, r, rh, r);
+  double kh[KS_SIZE];
+  *iters = 0;
+  *relres = 0.0;
+  for (int it = 1; it <= h->max_iter; ++it) {
+    lin3(p, 3, r, p, v);  // p = r + beta (p - omega v)   (first iteration: p = r)
+    FCCHK(precond(p, ph));
+    FCCHK(matvec(ph, v));
+    dots(1, rh, v, rh, v);
+    lin3(s, 0, r, v, nullptr);  // s = r - alpha v
+    dots(2, s, s, s, s);
+    FCCHK(precond(s, sh));
+    FCCHK(matvec(sh, t));
+    dots(3, t, s, t, t);
+    lin3(x, 1, x, ph, sh);      // x += alpha ph + omega sh
+    lin3(r, 2, s, t, nullptr);  // r = s - omega t
+    dots(4, r, r, rh, r);
+    if (it % kKrylovCheck == 0 || it == h->max_iter) {
+      FCCHK(krylov_state(h, kh));
+      if (kh[KS_STATE] != 0.0) break;
+    }
+  }
+  FCCHK(krylov_state(h, kh));
+  *iters = (int)kh[KS_ITERS];
+  const double bnorm = std::sqrt(kh[KS_BNORM2]);
+  if (kh[KS_STATE] < 0.0) return fail(FC_ERR_NOT_CONVERGED, "BiCGStab breakdown (code " + std::to_string((int)kh[KS_STATE]) + ")");
+  if (!(bnorm > 0.0)) return FC_OK;  // b = 0 -> x = 0
+  if (kh[KS_STATE] != 1.0) {
+    *relres = std::sqrt(kh[KS_RNORM2]) / bnorm;
+    return fail(FC_ERR_NOT_CONVERGED, "BiCGStab: residual " + std::to_string(*relres) + " after " + std::to_string(*iters) +
+                                          " iterations (rtol " + std::to_string(h->rtol) + ")");
+  }
+  // report the TRUE residual of the returned x
+  FCCHK(matvec(x, t));
+  hipLaunchKernelGGL(fc_lin3, dim3(g), dim3(256), 0, h->stream, N, t, 1.0, h->b.p, -1.0, t, 0.0, (const double*)nullptr);
+  hipLaunchKernelGGL(fc_dots2, dim3(gd), dim3(256), 0, h->stream, N, t, t, t, t, h->partial.p);
+  hipLaunchKernelGGL(fc_bicg_phase, dim3(1), dim3(256), 0, h->stream, -1, gd, h->partial.p, ks, h->rtol, 1, 0);
+  FCCHK(krylov_state(h, kh));
+  *relres = std::sqrt(kh[KS_D0]) / bnorm;
+  HIPCHK(hipGetLastError());
+  return FC_OK;
+}
+
+// Restarted GMRES(m), right-preconditioned by the slot's factor sweeps: x = M^-1 (V y).  Classical Gram-Schmidt with
+// one re-orthogonalisation (two multi-dot launches per Arnoldi step instead of j sequential dots), Givens rotations and
+// the back substitution in a one-thread kernel, everything on the device; the host reads the state word once per
+// kKrylovCheck Arnoldi steps.  b_p in h->b on entry, x_p in kry[0..N) on exit.
+int gmres_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
+  const int N = h->N, g = nblocks(N, 256), gd = std::min(g, 256);
+  const int m = std::max(1, std::min(h->gmres_m, h->max_iter));
+  const size_t need = (size_t)(m + 4) * N;
+  if (h->kry.n < need) FCCHK(h->kry.alloc(need));
+  if (h->ks.n != KS_SIZE) FCCHK(h->ks.alloc(KS_SIZE));
+  const size_t gm_n = (size_t)(m + 1) * m + 2 * m + (m + 1) + m + (m + 2) + 2 + (m + 2);  // ... | norm2 | used | hcol2
+  if (h->gm.n < gm_n) FCCHK(h->gm.alloc(gm_n));
+  if (h->mdot.n < (size_t)(m + 1) * gd) FCCHK(h->mdot.alloc((size_t)(m + 1) * gd));
+  double *x = h->kry.p, *r = x + N, *w = r + N, *z = w + N, *V = z + N;
+  double *ks = h->ks.p, *gm = h->gm.p;
+  double* hcol = gm + (size_t)(m + 1) * m + 2 * m + (m + 1) + m;
+  double* norm2 = hcol + m + 2;
+  double* used_p = norm2 + 1;
+  double* hcol2 = used_p + 1;
+  double* yv = gm + (size_t)(m + 1) * m + 2 * m + (m + 1);
+  const double mean = (double)S.Ap_nnz / std::max(1, N);
+  auto precond = [&](const double* in, double* out) -> int {
+    hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, in, h->buf.p);
+    FCCHK(apply_factors(h, S));
+    hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->buf.p + N, out);
+    return FC_OK;
+  };
+  auto matvec = [&](const double* in, double* out) -> int {
+    const int nb = launch_spmv<0>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, in, nullptr, out, nullptr, nullptr);
+    return nb < 0 ? nb : FC_OK;
+  };
+  auto begin_cycle = [&](int first) {
+    hipLaunchKernelGGL(fc_dots2, dim3(gd), dim3(256), 0, h->stream, N, r, r, h->b.p, h->b.p, h->partial.p);
+    hipLaunchKernelGGL(fc_bicg_phase, dim3(1), dim3(256), 0, h->stream, -1, gd, h->partial.p, ks, h->rtol, 1, 0);
+    hipLaunchKernelGGL(fc_gmres_begin, dim3(1), dim3(1), 0, h->stream, m, gm, ks, h->rtol, first);
+    hipLaunchKernelGGL(fc_scale_by_norm, dim3(g), dim3(256), 0, h->stream, N, r, norm2, V, ks);
+  };
+  HIPCHK(hipMemsetAsync(ks, 0, KS_SIZE * sizeof(double), h->stream));
+  HIPCHK(hipMemsetAsync(gm, 0, gm_n * sizeof(double), h->stream));
+  HIPCHK(hipMemsetAsync(x, 0, (size_t)N * sizeof(double), h->stream));
+  hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, r);
+  begin_cycle(1);
+  double kh[KS_SIZE];
+  *iters = 0;
+  *relres = 0.0;
+  int total = 0;
+  bool done = false;
+  while (!done) {
+    int j = 0;
+    double state = 0.0;
+    for (; j < m && total < h->max_iter; ++j, ++total) {
+      double* vj = V + (size_t)j * N;
+      FCCHK(precond(vj, z));
+      FCCHK(matvec(z, w));
+      // classical Gram-Schmidt, twice: h = V^T w, w -= V h; h2 = V^T w, w -= V h2; Hessenberg column = h + h2
+      hipLaunchKernelGGL(fc_multidot, dim3(gd, j + 1), dim3(256), 0, h->stream, N, j + 1, V, w, h->mdot.p, ks);
+      hipLaunchKernelGGL(fc_multidot_reduce, dim3(j + 1), dim3(64), 0, h->stream, j + 1, gd, h->mdot.p, hcol, 0, ks);
+      hipLaunchKernelGGL(fc_gmres_project, dim3(g), dim3(256), 0, h->stream, N, j + 1, V, hcol, w, ks);
+      hipLaunchKernelGGL(fc_multidot, dim3(gd, j + 1), dim3(256), 0, h->stream, N, j + 1, V, w, h->mdot.p, ks);
+      hipLaunchKernelGGL(fc_multidot_reduce, dim3(j + 1), dim3(64), 0, h->stream, j + 1, gd, h->mdot.p, hcol2, 0, ks);
+      hipLaunchKernelGGL(fc_multidot_reduce, dim3(j + 1), dim3(64), 0, h->stream, j + 1, gd, h->mdot.p, hcol, 1, ks);
+      hipLaunchKernelGGL(fc_gmres_project, dim3(g), dim3(256), 0, h->stream, N, j + 1, V, hcol2, w, ks);
+      hipLaunchKernelGGL(fc_multidot, dim3(gd, 1), dim3(256), 0, h->stream, N, 1, w, w, h->mdot.p, ks);
+      hipLaunchKernelGGL(fc_multidot_reduce, dim3(1), dim3(64), 0, h->stream, 1, gd, h->mdot.p, norm2, 0, ks);
+      hipLaunchKernelGGL(fc_gmres_givens, dim3(1), dim3(1), 0, h->stream, j, m, gm, ks, h->rtol);
+      hipLaunchKernelGGL(fc_scale_by_norm, dim3(g), dim3(256), 0, h->stream, N, w, norm2, V + (size_t)(j + 1) * N, ks);
+      if ((j + 1) % kKrylovCheck == 0 || j + 1 == m || total + 1 == h->max_iter) {
+        FCCHK(krylov_state(h, kh));
+        state = kh[KS_STATE];
+        if (state != 0.0) {
+          ++j, ++total;
+          break;
+        }
+      }
+    }
+    FCCHK(krylov_state(h, kh));
+    state = kh[KS_STATE];
+    if (state < 0.0) return fail(FC_ERR_NOT_CONVERGED, "GMRES breakdown (code " + std::to_string((int)state) + ")");
+    if (state == 1.0) break;  // converged before the cycle started (or b = 0)
+    HIPCHK(hipMemcpyAsync(kh, used_p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int used = (int)kh[0];
+    if (state == 0.0) {
+      // iteration cap inside a cycle: close it (back substitution for the columns built so far)
+      return fail(FC_ERR_NOT_CONVERGED, "GMRES: iteration cap reached inside a cycle");
+    }
+    // x += M^-1 (V y)
+    hipLaunchKernelGGL(fc_gmres_combine, dim3(g), dim3(256), 0, h->stream, N, used, V, yv, w);
+    FCCHK(precond(w, z));
+    hipLaunchKernelGGL(fc_axpy, dim3(g), dim3(256), 0, h->stream, N, 1.0, z, x);
+    // true residual
+    FCCHK(matvec(x, w));
+    hipLaunchKernelGGL(fc_lin3, dim3(g), dim3(256), 0, h->stream, N, r, 1.0, h->b.p, -1.0, w, 0.0, (const double*)nullptr);
+    if (state == 3.0) {
+      done = true;
+    } else if (total >= h->max_iter) {
+      done = true;
+    } else {
+      begin_cycle(0);
+    }
+  }
+  hipLaunchKernelGGL(fc_dots2, dim3(gd), dim3(256), 0, h->stream, N, r, r, h->b.p, h->b.p, h->partial.p);
+  hipLaunchKernelGGL(fc_bicg_phase, dim3(1), dim3(256), 0, h->stream, -1, gd, h->partial.p, ks, h->rtol, 1, 0);
+  FCCHK(krylov_state(h, kh));
+  *iters = (int)kh[KS_ITERS];
+  const double bnorm = std::sqrt(kh[KS_D1]);
+  *relres = bnorm > 0.0 ? std::sqrt(kh[KS_D0]) / bnorm : 0.0;
+  HIPCHK(hipGetLastError());
+  if (bnorm > 0.0 && !(*relres <= 10.0 * h->rtol))
+    return fail(FC_ERR_NOT_CONVERGED, "GMRES: residual " + std::to_string(*relres) + " after " + std::to_string(*iters) + " iterations");
+  return FC_OK;
+}
+
 // enqueue one full step; y -> d_y, E -> d_E; residual norms -> scal[1], scal[2]
 int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, double* d_E, double* d_r,
                  double* d_flag_out, int compute_energy, const double* d_uforce = nullptr, double* d_seq = nullptr,
                  double seq = 0.0, int step_id = 1) {
   OrderSys& S = h->sys[order_slot];
   if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this order");
-  if (h->method != FC_METHOD_REFINE) return fail(FC_ERR_INVALID, "time steps use the factor sweeps directly: set FC_METHOD_REFINE");
+  if (S.truncated && h->method == FC_METHOD_REFINE)
+    return fail(FC_ERR_INVALID, "truncated factors are a preconditioner: set FC_METHOD_GMRES or FC_METHOD_BICGSTAB");
   if (compute_energy && !h->partitioned && !h->have_mp) return fail(FC_ERR_NOT_READY, "fc_set_energy_matrix not called");
   FCCHK(enqueue_rhs(h, order_slot, d_uctrl, d_uforce));
   const double *x = nullptr, *dx = nullptr;
   int nrp = 0;
+  if (h->method != FC_METHOD_REFINE) {
+    // Krylov solve inside the step (the memory-lean path: truncated factors as preconditioner; or lagged factors):
+    // the drivers synchronise with the host every few iterations; the residual monitor of the tail checks the result
+    if (h->partitioned) return fail(FC_ERR_INVALID, "the Krylov drivers are not available on a partitioned handle");
+    int iters = 0;
+    double relres = 0.0;
+    FCCHK(h->method == FC_METHOD_GMRES ? gmres_permuted(h, S, &iters, &relres) : bicgstab_permuted(h, S, &iters, &relres));
+    h->last_krylov_iters = iters;
+    hipLaunchKernelGGL(fc_copy, dim3(nblocks(h->N, 256)), dim3(256), 0, h->stream, h->N, h->kry.p, h->buf.p + h->N);
+    return launch_tail(h, S, compute_energy, d_y, d_E, d_r, d_flag_out, d_seq, seq, step_id);
+  }
   if (use_fused_tail(h)) {
     FCCHK(apply_factors(h, S));
     return launch_tail(h, S, compute_energy, d_y, d_E, d_r, d_flag_out, d_seq, seq, step_id);
@@ -1306,7 +1528,7 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
     st.row0 = stage_row0[s];
     st.nrows = stage_nrows[s];
     st.kind = stage_kind[s];
-    if (st.nrows < 0 || st.row0 < 0 || st.row0 + st.nrows > N || (st.kind != 0 && st.kind != 1) || st.rp_begin != total_rows)
+    if (st.nrows < 0 || st.row0 < 0 || st.row0 + st.nrows > N || st.kind < 0 || st.kind > 2 || st.rp_begin != total_rows)
       return fail(FC_ERR_INVALID, "fc_solver_setup: inconsistent stage table");
     const int64_t q0 = seg_ptr[total_rows], q1 = seg_ptr[total_rows + st.nrows];
     if (q0 < 0 || q1 < q0 || q1 > n_seg) return fail(FC_ERR_INVALID, "fc_solver_setup: segment pointers out of range");
@@ -1406,9 +1628,19 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
   else FCCHK(S.f_idx.alloc(1));
   FCCHK(S.f_val.upload(vals, (size_t)n_val, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  S.truncated = false;
+  for (const Stage& st : S.stages) S.truncated = S.truncated || st.kind == 2;
   S.ready = true;
   S.structured = true;
   S.dag_ready = false;  // fc_solver_set_dag must follow
+  return FC_OK;
+}
+
+int fc_set_stage_diag(fc_handle h, int slot, const double* dscale) {
+  if (!h || slot < 0 || slot > 1 || !dscale) return fail(FC_ERR_INVALID, "fc_set_stage_diag: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  FCCHK(h->sys[slot].dscale.upload(dscale, (size_t)h->N, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
   return FC_OK;
 }
 
@@ -1474,6 +1706,7 @@ int fc_solver_set_dag(fc_handle h, int slot, int32_t n_nodes, const int64_t* nod
   if (!S.structured) return fail(FC_ERR_NOT_READY, "fc_solver_setup must be called first");
   HIPCHK(hipSetDevice(h->device));
   S.dag_ready = false;
+  if (S.truncated) return FC_OK;  // truncated (preconditioner-only) factors are applied with the level launches
   const int N = h->N;
   const int64_t n_idx = (int64_t)S.f_idx.n, n_val = S.f_nnz;
   struct Nd {
@@ -2146,7 +2379,7 @@ int fc_step(fc_handle h, int order_slot, const double* u_ctrl, const double* u_f
   const int flag = ((int)pin[136]) % 1024;
   if (info_out) {
     const double r2 = pin[129], b2 = pin[130];
-    info_out[0] = h->max_iter;
+    info_out[0] = h->method == FC_METHOD_REFINE ? h->max_iter : h->last_krylov_iters;  // refinement sweeps / Krylov iterations
     info_out[1] = h->check_residual ? std::sqrt(r2 / (b2 > 0 ? b2 : 1.0)) : std::numeric_limits<double>::quiet_NaN();
     info_out[2] = h->check_residual ? std::sqrt(b2) : std::numeric_limits<double>::quiet_NaN();
     info_out[3] = flag;
@@ -2211,206 +2444,6 @@ int fc_assemble_rhs(fc_handle h, int order_slot, const double* u_ctrl, double* b
                      (const double*)nullptr, h->tmpN.p);
   HIPCHK(hipMemcpyAsync(b_out, h->tmpN.p, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  return FC_OK;
-}
-
-// Right-preconditioned BiCGStab on the permuted system A_p x = b_p, M^-1 = the factor sweeps of the slot
-// (exact factors: one iteration; factors of an EARLIER operator — fc_update_operator without
-// fc_refactor — : a few; truncated factors: the memory-lean preconditioner).  b_p in h->b on entry, x_p in
-// kry[0..N) on exit.  DEVICE-RESIDENT: rho, alpha, omega, the update coefficients and the convergence state live in
-// h->ks; the vector kernels read them there and become no-ops once the state says "done".  The host enqueues
-// FC_KRYLOV_CHECK iterations at a time and reads the state word once per batch — no synchronisation per dot product.
-// Fixed reduction order.  iters / relres report what happened.
-constexpr int kKrylovCheck = 4;
-
-int krylov_state(fc_ctx* h, double* ks_host) {
-  HIPCHK(hipMemcpyAsync(ks_host, h->ks.p, KS_SIZE * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  return FC_OK;
-}
-
-int bicgstab_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
-  const int N = h->N, g = nblocks(N, 256), gd = std::min(g, 512);
-  if (h->kry.n != 8 * (size_t)N) FCCHK(h->kry.alloc(8 * (size_t)N));
-  if (h->ks.n != KS_SIZE) FCCHK(h->ks.alloc(KS_SIZE));
-  double *x = h->kry.p, *r = x + N, *rh = r + N, *p = rh + N, *v = p + N, *s = v + N, *t = s + N, *ph = t + N;
-  double* sh = h->tmpN2.p;
-  double* ks = h->ks.p;
-  const double mean = (double)S.Ap_nnz / std::max(1, N);
-  auto dots = [&](int phase, const double* a, const double* b_, const double* c, const double* d) {
-    hipLaunchKernelGGL(fc_dots2, dim3(gd), dim3(256), 0, h->stream, N, a, b_, c, d, h->partial.p);
-    hipLaunchKernelGGL(fc_bicg_phase, dim3(1), dim3(256), 0, h->stream, phase, gd, h->partial.p, ks, h->rtol, 1, 1);
-  };
-  auto lin3 = [&](double* out, int coef, const double* v0, const double* v1, const double* v2) {
-    hipLaunchKernelGGL(fc_lin3_dev, dim3(g), dim3(256), 0, h->stream, N, out, ks + KS_COEF + 3 * coef, v0, v1, v2, ks);
-  };
-  auto precond = [&](const double* in, double* out) -> int {  // out = M^-1 in
-    hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, in, h->buf.p);
-    FCCHK(apply_factors(h, S));
-    hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->buf.p + N, out);
-    return FC_OK;
-  };
-  auto matvec = [&](const double* in, double* out) -> int {
-    const int nb = launch_spmv<0>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, in, nullptr, out, nullptr, nullptr);
-    return nb < 0 ? nb : FC_OK;
-  };
-  HIPCHK(hipMemsetAsync(ks, 0, KS_SIZE * sizeof(double), h->stream));
-  HIPCHK(hipMemsetAsync(x, 0, (size_t)N * sizeof(double), h->stream));
-  hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, r);
-  hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, rh);
-  dots(0, r, r, rh, r);
-  double kh[KS_SIZE];
-  *iters = 0;
-  *relres = 0.0;
-  for (int it = 1; it <= h->max_iter; ++it) {
-    lin3(p, 3, r, p, v);  // p = r + beta (p - omega v)   (first iteration: p = r)
-    FCCHK(precond(p, ph));
-    FCCHK(matvec(ph, v));
-    dots(1, rh, v, rh, v);
-    lin3(s, 0, r, v, nullptr);  // s = r - alpha v
-    dots(2, s, s, s, s);
-    FCCHK(precond(s, sh));
-    FCCHK(matvec(sh, t));
-    dots(3, t, s, t, t);
-    lin3(x, 1, x, ph, sh);      // x += alpha ph + omega sh
-    lin3(r, 2, s, t, nullptr);  // r = s - omega t
-    dots(4, r, r, rh, r);
-    if (it % kKrylovCheck == 0 || it == h->max_iter) {
-      FCCHK(krylov_state(h, kh));
-      if (kh[KS_STATE] != 0.0) break;
-    }
-  }
-  FCCHK(krylov_state(h, kh));
-  *iters = (int)kh[KS_ITERS];
-  const double bnorm = std::sqrt(kh[KS_BNORM2]);
-  if (kh[KS_STATE] < 0.0) return fail(FC_ERR_NOT_CONVERGED, "BiCGStab breakdown (code " + std::to_string((int)kh[KS_STATE]) + ")");
-  if (!(bnorm > 0.0)) return FC_OK;  // b = 0 -> x = 0
-  if (kh[KS_STATE] != 1.0) {
-    *relres = std::sqrt(kh[KS_RNORM2]) / bnorm;
-    return fail(FC_ERR_NOT_CONVERGED, "BiCGStab: residual " + std::to_string(*relres) + " after " + std::to_string(*iters) +
-                                          " iterations (rtol " + std::to_string(h->rtol) + ")");
-  }
-  // report the TRUE residual of the returned x
-  FCCHK(matvec(x, t));
-  hipLaunchKernelGGL(fc_lin3, dim3(g), dim3(256), 0, h->stream, N, t, 1.0, h->b.p, -1.0, t, 0.0, (const double*)nullptr);
-  hipLaunchKernelGGL(fc_dots2, dim3(gd), dim3(256), 0, h->stream, N, t, t, t, t, h->partial.p);
-  hipLaunchKernelGGL(fc_bicg_phase, dim3(1), dim3(256), 0, h->stream, -1, gd, h->partial.p, ks, h->rtol, 1, 0);
-  FCCHK(krylov_state(h, kh));
-  *relres = std::sqrt(kh[KS_D0]) / bnorm;
-  HIPCHK(hipGetLastError());
-  return FC_OK;
-}
-
-// Restarted GMRES(m), right-preconditioned by the slot's factor sweeps: x = M^-1 (V y).  Classical Gram-Schmidt with
-// one re-orthogonalisation (two multi-dot launches per Arnoldi step instead of j sequential dots), Givens rotations and
-// the back substitution in a one-thread kernel, everything on the device; the host reads the state word once per
-// kKrylovCheck Arnoldi steps.  b_p in h->b on entry, x_p in kry[0..N) on exit.
-int gmres_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
-  const int N = h->N, g = nblocks(N, 256), gd = std::min(g, 256);
-  const int m = std::max(1, std::min(h->gmres_m, h->max_iter));
-  const size_t need = (size_t)(m + 4) * N;
-  if (h->kry.n < need) FCCHK(h->kry.alloc(need));
-  if (h->ks.n != KS_SIZE) FCCHK(h->ks.alloc(KS_SIZE));
-  const size_t gm_n = (size_t)(m + 1) * m + 2 * m + (m + 1) + m + (m + 2) + 2 + (m + 2);  // ... | norm2 | used | hcol2
-  if (h->gm.n < gm_n) FCCHK(h->gm.alloc(gm_n));
-  if (h->mdot.n < (size_t)(m + 1) * gd) FCCHK(h->mdot.alloc((size_t)(m + 1) * gd));
-  double *x = h->kry.p, *r = x + N, *w = r + N, *z = w + N, *V = z + N;
-  double *ks = h->ks.p, *gm = h->gm.p;
-  double* hcol = gm + (size_t)(m + 1) * m + 2 * m + (m + 1) + m;
-  double* norm2 = hcol + m + 2;
-  double* used_p = norm2 + 1;
-  double* hcol2 = used_p + 1;
-  double* yv = gm + (size_t)(m + 1) * m + 2 * m + (m + 1);
-  const double mean = (double)S.Ap_nnz / std::max(1, N);
-  auto precond = [&](const double* in, double* out) -> int {
-    hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, in, h->buf.p);
-    FCCHK(apply_factors(h, S));
-    hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->buf.p + N, out);
-    return FC_OK;
-  };
-  auto matvec = [&](const double* in, double* out) -> int {
-    const int nb = launch_spmv<0>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, in, nullptr, out, nullptr, nullptr);
-    return nb < 0 ? nb : FC_OK;
-  };
-  auto begin_cycle = [&](int first) {
-    hipLaunchKernelGGL(fc_dots2, dim3(gd), dim3(256), 0, h->stream, N, r, r, h->b.p, h->b.p, h->partial.p);
-    hipLaunchKernelGGL(fc_bicg_phase, dim3(1), dim3(256), 0, h->stream, -1, gd, h->partial.p, ks, h->rtol, 1, 0);
-    hipLaunchKernelGGL(fc_gmres_begin, dim3(1), dim3(1), 0, h->stream, m, gm, ks, h->rtol, first);
-    hipLaunchKernelGGL(fc_scale_by_norm, dim3(g), dim3(256), 0, h->stream, N, r, norm2, V, ks);
-  };
-  HIPCHK(hipMemsetAsync(ks, 0, KS_SIZE * sizeof(double), h->stream));
-  HIPCHK(hipMemsetAsync(gm, 0, gm_n * sizeof(double), h->stream));
-  HIPCHK(hipMemsetAsync(x, 0, (size_t)N * sizeof(double), h->stream));
-  hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, r);
-  begin_cycle(1);
-  double kh[KS_SIZE];
-  *iters = 0;
-  *relres = 0.0;
-  int total = 0;
-  bool done = false;
-  while (!done) {
-    int j = 0;
-    double state = 0.0;
-    for (; j < m && total < h->max_iter; ++j, ++total) {
-      double* vj = V + (size_t)j * N;
-      FCCHK(precond(vj, z));
-      FCCHK(matvec(z, w));
-      // classical Gram-Schmidt, twice: h = V^T w, w -= V h; h2 = V^T w, w -= V h2; Hessenberg column = h + h2
-      hipLaunchKernelGGL(fc_multidot, dim3(gd, j + 1), dim3(256), 0, h->stream, N, j + 1, V, w, h->mdot.p, ks);
-      hipLaunchKernelGGL(fc_multidot_reduce, dim3(j + 1), dim3(64), 0, h->stream, j + 1, gd, h->mdot.p, hcol, 0, ks);
-      hipLaunchKernelGGL(fc_gmres_project, dim3(g), dim3(256), 0, h->stream, N, j + 1, V, hcol, w, ks);
-      hipLaunchKernelGGL(fc_multidot, dim3(gd, j + 1), dim3(256), 0, h->stream, N, j + 1, V, w, h->mdot.p, ks);
-      hipLaunchKernelGGL(fc_multidot_reduce, dim3(j + 1), dim3(64), 0, h->stream, j + 1, gd, h->mdot.p, hcol2, 0, ks);
-      hipLaunchKernelGGL(fc_multidot_reduce, dim3(j + 1), dim3(64), 0, h->stream, j + 1, gd, h->mdot.p, hcol, 1, ks);
-      hipLaunchKernelGGL(fc_gmres_project, dim3(g), dim3(256), 0, h->stream, N, j + 1, V, hcol2, w, ks);
-      hipLaunchKernelGGL(fc_multidot, dim3(gd, 1), dim3(256), 0, h->stream, N, 1, w, w, h->mdot.p, ks);
-      hipLaunchKernelGGL(fc_multidot_reduce, dim3(1), dim3(64), 0, h->stream, 1, gd, h->mdot.p, norm2, 0, ks);
-      hipLaunchKernelGGL(fc_gmres_givens, dim3(1), dim3(1), 0, h->stream, j, m, gm, ks, h->rtol);
-      hipLaunchKernelGGL(fc_scale_by_norm, dim3(g), dim3(256), 0, h->stream, N, w, norm2, V + (size_t)(j + 1) * N, ks);
-      if ((j + 1) % kKrylovCheck == 0 || j + 1 == m || total + 1 == h->max_iter) {
-        FCCHK(krylov_state(h, kh));
-        state = kh[KS_STATE];
-        if (state != 0.0) {
-          ++j, ++total;
-          break;
-        }
-      }
-    }
-    FCCHK(krylov_state(h, kh));
-    state = kh[KS_STATE];
-    if (state < 0.0) return fail(FC_ERR_NOT_CONVERGED, "GMRES breakdown (code " + std::to_string((int)state) + ")");
-    if (state == 1.0) break;  // converged before the cycle started (or b = 0)
-    HIPCHK(hipMemcpyAsync(kh, used_p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    const int used = (int)kh[0];
-    if (state == 0.0) {
-      // iteration cap inside a cycle: close it (back substitution for the columns built so far)
-      return fail(FC_ERR_NOT_CONVERGED, "GMRES: iteration cap reached inside a cycle");
-    }
-    // x += M^-1 (V y)
-    hipLaunchKernelGGL(fc_gmres_combine, dim3(g), dim3(256), 0, h->stream, N, used, V, yv, w);
-    FCCHK(precond(w, z));
-    hipLaunchKernelGGL(fc_axpy, dim3(g), dim3(256), 0, h->stream, N, 1.0, z, x);
-    // true residual
-    FCCHK(matvec(x, w));
-    hipLaunchKernelGGL(fc_lin3, dim3(g), dim3(256), 0, h->stream, N, r, 1.0, h->b.p, -1.0, w, 0.0, (const double*)nullptr);
-    if (state == 3.0) {
-      done = true;
-    } else if (total >= h->max_iter) {
-      done = true;
-    } else {
-      begin_cycle(0);
-    }
-  }
-  hipLaunchKernelGGL(fc_dots2, dim3(gd), dim3(256), 0, h->stream, N, r, r, h->b.p, h->b.p, h->partial.p);
-  hipLaunchKernelGGL(fc_bicg_phase, dim3(1), dim3(256), 0, h->stream, -1, gd, h->partial.p, ks, h->rtol, 1, 0);
-  FCCHK(krylov_state(h, kh));
-  *iters = (int)kh[KS_ITERS];
-  const double bnorm = std::sqrt(kh[KS_D1]);
-  *relres = bnorm > 0.0 ? std::sqrt(kh[KS_D0]) / bnorm : 0.0;
-  HIPCHK(hipGetLastError());
-  if (bnorm > 0.0 && !(*relres <= 10.0 * h->rtol))
-    return fail(FC_ERR_NOT_CONVERGED, "GMRES: residual " + std::to_string(*relres) + " after " + std::to_string(*iters) + " iterations");
   return FC_OK;
 }
 

@@ -1367,3 +1367,9 @@ __global__ void fc_gmres_begin(int m, double* gm, double* ks, double rtol, int f
   g[0] = sqrt(r2);
   ks[KS_STATE] = (sqrt(r2) <= rtol * sqrt(ks[KS_BNORM2]) || !(ks[KS_BNORM2] > 0.0)) ? 1.0 : 0.0;
 }
+
+// truncated factors: x = dscale * y on the rows whose pivot blocks are not kept (diagonal stand-in for their Schur complement)
+__global__ void fc_diag_stage(int n, const double* __restrict__ dscale, const double* __restrict__ y, double* __restrict__ x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = dscale[i] * y[i];
+}

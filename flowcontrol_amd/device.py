@@ -64,6 +64,7 @@ class DeviceSolver:
         self._pin_shift = 1.0
         self._step_bufs = None
         self._pin: int | None = None  # pressure dof of an enclosed flow whose level is fixed (diagonal shift in the factors)
+        self._truncate = 0  # > 0: only the tree levels >= this are factorised (memory-lean preconditioner)
         self.device_index = device
 
     # ── multi-GPU ────────────────────────────────────────────────────────────
@@ -185,7 +186,7 @@ class DeviceSolver:
 
     # ── solver setup (host analysis + factorisation, device upload) ──────────
     def setup_solver(self, slot: int, depth: int | None = None, refine: int = 0, check_residual: bool = True, merge: int = 2,
-                     restructure: bool = False) -> None:
+                     restructure: bool = False, truncate: int = 0) -> None:
         """Factorise the (BC-eliminated) matrix of ``slot`` and hand the factors to the device.
 
         ``depth`` binary bisections (default: leaves of ≈ 12 cells), fused ``merge`` at a time into a
@@ -197,7 +198,11 @@ class DeviceSolver:
         (``fc_refactor``; on a partitioned handle every rank repeats it for the whole tree), and a later call
         for the same slot is just that numeric phase (``restructure=True`` uploads the launch geometry
         again).  ``FC_HOST_FACTOR=1`` uses the numpy multifrontal of :mod:`ndsolver` instead.
-        """
+
+        ``truncate = d > 0`` (memory-lean preconditioner): only the tree levels ≥ d are factorised and stored (the
+        sub-domain solves and their couplings to the separators above — memory shrinks towards O(nnz) as d grows); the
+        Schur complement on the top d levels is replaced by a diagonal estimate.  The slot is then a PRECONDITIONER:
+        solves and time steps go through GMRES / BiCGStab (``set_solver_options(method=...)``)."""
         if self.tree is None:
             th = self.th
             top = int(np.log2(self.world)) if self.world > 1 else 0
@@ -219,6 +224,11 @@ class DeviceSolver:
             if self._fac_struct is None:
                 # a rank of a multi-GPU run lays out, stores and factorises its own sub-tree and the root only
                 keep = ndsolver.rank_keeps(t, self.rank, self.world) if self.world > 1 else None
+                self._truncate = int(truncate)
+                if truncate:
+                    if self.world > 1 or truncate > t.depth:
+                        raise ValueError("truncate needs a single-GPU handle and 0 < truncate <= tree depth")
+                    keep = lambda k, n: k >= truncate  # noqa: E731
                 self._fac_struct = ndsolver.factorize_blocks(None, t, numeric=False, keep=keep)
                 pl = ndsolver.factor_plan(self._fac_struct, self.rowptr, self.colidx, self._skip, keep=keep)
                 check(self.lib.fc_factor_plan(
@@ -226,6 +236,8 @@ class DeviceSolver:
                     int(pl.a_src.size), pl.a_src if pl.a_src.size else np.zeros(1, np.int64), pl.a_dst if pl.a_dst.size else np.zeros(1, np.int64),
                     pl.a_ptr, pl.ext_off, int(pl.ext_p.size), pl.ext_p, int(pl.ap_src.size), pl.ap_src, int(pl.max_slots)))
                 self._plan = pl
+                if truncate:  # the top levels' down stages become diagonal stages
+                    self._fac_struct.stage_kind[t.depth : t.depth + truncate] = 2
                 if self._pin is not None:
                     self._upload_pin()
                 tag = sp.csr_matrix((np.ones(self.nnz), self.colidx, self.rowptr), shape=(self.N, self.N))
@@ -280,6 +292,8 @@ class DeviceSolver:
                     pick(bi0, z32), pick(bni, z32), pick(bidx, z32), pick(bnb, z32), int(fac.idx.size), int(fac.vals.size),
                 )
             )
+        if getattr(self, "_truncate", 0):
+            check(self.lib.fc_set_stage_diag(self._h, slot, _f64(ndsolver.schur_diagonal_scaling(self.matrix(slot), self.nn)[t.perm])))
         # one-launch factor apply: dependency lists of the elimination tree (the task tables are built in the library)
         nodes, mine, dn_dep, up_ptr, up_idx = ndsolver.dag_dependencies(fac, self.rank, self.world)
         check(self.lib.fc_solver_set_dag(self._h, slot, int(nodes.shape[0]), nodes, mine, dn_dep, up_ptr, up_idx))
@@ -330,6 +344,9 @@ class DeviceSolver:
             self._probe = np.cos(0.37 * np.arange(self.N) + 0.1)
             if self._pin is not None:
                 self._probe[2 * self.nn :] = 0.0  # compatible with the constant-pressure null space
+        if getattr(self, "_truncate", 0):
+            check(self.lib.fc_set_stage_diag(self._h, slot, _f64(ndsolver.schur_diagonal_scaling(self.matrix(slot), self.nn)[self.tree.perm])))
+            return ms.value  # a preconditioner: nothing to probe
         if self.world > 1 or getattr(self, "_force_comm", False):
             return ms.value  # a probe solve would be a collective; every step's residual is monitored instead
         opts = getattr(self, "_solver_opts", (0, True, "refine", 1e-10))

@@ -79,6 +79,12 @@ class FlowSolver(ABC):
         # every step's solve is monitored: relative residual of the linear system above this → error (the
         # factor apply is exact to round-off, ~1e-16; a larger value means broken factors or a singular system)
         self.residual_tol: float = 1e-8
+        #: memory-lean mode: factorise only the tree levels >= nd_truncate and solve every step with a Krylov method
+        #: preconditioned by those truncated factors (0 = full selected inverse, applied directly)
+        self.nd_truncate: int = 0
+        self.krylov_method: str = "gmres"
+        self.krylov_max_iter: int = 500
+        self.krylov_rtol: float = 1e-12
         self._setup()
 
     # ── validation (reference :108-165) ──────────────────────────────────────
@@ -748,7 +754,11 @@ class _DeviceNDSolver:
 
     def set_operator(self, slot: int) -> None:
         self.slot = slot
-        self.fs.th.device().setup_solver(slot, depth=self.fs.nd_depth, refine=self.fs.refine_steps)
+        fs = self.fs
+        dev = fs.th.device()
+        dev.setup_solver(slot, depth=fs.nd_depth, refine=fs.refine_steps, truncate=fs.nd_truncate)
+        if fs.nd_truncate:
+            dev.set_solver_options(refine=fs.krylov_max_iter, method=fs.krylov_method, rtol=fs.krylov_rtol)
 
     def solve(self, x: np.ndarray, b: np.ndarray) -> None:
         sol, _ = self.fs.th.device().solve(self.slot, b)

@@ -815,6 +815,22 @@ def down_blocks(fac: BlockFactors, rank: int = 0, world: int = 1, max_rows: int 
     return begin, count, lpr, arr(0, np.int64), arr(1, np.int32), arr(2, np.int32), arr(3, np.int32), arr(4, np.int32), arr(5, np.int32), arr(6, np.int32)
 
 
+def schur_diagonal_scaling(A: sp.csr_matrix, nn: int) -> np.ndarray:
+    """Diagonal stand-in for the inverse of the operator on rows whose pivot blocks are not kept (truncated factors):
+    velocity rows 1 / A_ii; pressure rows the SIMPLE-type estimate of the Schur complement −D F⁻¹ G,
+    1 / (−Σ_j D_ij G_ji / F_jj), for the saddle-point matrix [[F, G], [D, 0]] (W numbering, velocity dofs first)."""
+    A = A.tocsr()
+    nn2 = 2 * nn
+    diag = A.diagonal()
+    out = np.ones(A.shape[0])
+    fd = np.where(diag[:nn2] != 0.0, diag[:nn2], 1.0)
+    out[:nn2] = 1.0 / fd
+    D, G = A[nn2:, :nn2], A[:nn2, nn2:]
+    s = -np.asarray(D.multiply(G.T.tocsr()) @ (1.0 / fd)).reshape(-1)
+    out[nn2:] = np.where(s != 0.0, 1.0 / np.where(s != 0.0, s, 1.0), 1.0)
+    return out
+
+
 def dag_dependencies(fac: BlockFactors, rank: int = 0, world: int = 1):
     """Dependency lists of the one-launch factor apply (``fc_solver_set_dag``), over the rows of
     ``fac.nodes`` (the tree nodes that own dofs, elimination order).
@@ -864,7 +880,7 @@ def dag_dependencies(fac: BlockFactors, rank: int = 0, world: int = 1):
     return nodes, mine, dn_dep, up_ptr, np.ascontiguousarray(up_idx if up_idx else [0], dtype=np.int32)
 
 
-__all__ += ["BlockFactors", "factorize_blocks", "rank_keeps", "down_blocks", "dag_dependencies", "split_up_segments", "FactorPlan", "factor_plan",
+__all__ += ["BlockFactors", "factorize_blocks", "rank_keeps", "schur_diagonal_scaling", "down_blocks", "dag_dependencies", "split_up_segments", "FactorPlan", "factor_plan",
             "factorize_with_plan", "front_diagonal_slot"]
 
 

@@ -108,7 +108,7 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
                     int32_t n_stages, const int64_t* stage_begin /* [n_stages] first row in seg_ptr */,
                     const int32_t* stage_row0 /* [n_stages] first destination row */,
                     const int32_t* stage_nrows /* [n_stages] */,
-                    const int32_t* stage_kind /* [n_stages] 0 = up (y += ..), 1 = down (x = ..) */,
+                    const int32_t* stage_kind /* [n_stages] 0 = up (y += ..), 1 = down (x = ..), 2 = diagonal (x = dscale y) */,
                     const int64_t* seg_ptr /* [total_rows + 1] */, int64_t n_seg,
                     const int64_t* seg_val /* [n_seg] offset into vals */,
                     const int32_t* seg_col /* [n_seg] >=0: first buffer index; <0: -(offset into idx)-1 */,
@@ -120,6 +120,10 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
                     /* and the rows x[ar_row0 .. +ar_n) after stage `ar2_stage` (-1: none): the root's down stage, in which
                      * every rank fills its own block of the root's rows (the others are zeroed before the launch) */
                     int32_t ar2_stage);
+/* Truncated factors (memory-lean preconditioner): stages of kind 2 stand for tree levels whose pivot blocks are NOT
+ * stored; on their rows x = dscale * y (dscale [N], permuted numbering: a diagonal stand-in for the Schur complement).
+ * Such a slot is a preconditioner only: fc_solve / fc_step need FC_METHOD_GMRES or FC_METHOD_BICGSTAB. */
+int fc_set_stage_diag(fc_handle h, int slot, const double* dscale /* [N] */);
 /* optional: hand the down-sweep stages to the LDS-tiled block kernel.  Every block is up to 32
  * consecutive rows of ONE tree node, whose rows all read the same operand
  * [ y[i0..i0+ni) | x[idx[idx_off..+nb)] ] and whose values lie row-major (stride ni+nb) at blk_val.
