@@ -9,8 +9,6 @@
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rocblas/rocblas.h>
-#include <rocsolver/rocsolver.h>
 
 #include <algorithm>
 #include <cmath>
@@ -23,6 +21,7 @@
 
 #include "fc_kernels.hip.h"
 #include "fc_dag.hip.h"
+#include "fc_front.hip.h"
 
 namespace {
 
@@ -233,10 +232,11 @@ struct fc_ctx {
   DevBuf<double> fronts;
   DevBuf<int64_t> pa_src, pa_dst, pap_src;
   DevBuf<FcExt> pext;
-  DevBuf<FcFront> pfront;                              // fronts eliminated by fc_front_eliminate, grouped per level
+  DevBuf<FcFront> pfront;                              // fronts with a pivot block, grouped per level
   std::vector<std::pair<int64_t, int>> pfront_groups;  // per level: (first, count)
-  std::vector<char> pnode_small;                       // per node: handled by the kernel (else rocSOLVER / rocBLAS)
-  DevBuf<int> pext_p, pipiv;
+  std::vector<int> plevel_max_ni, plevel_max_nf;       // per level: block steps / tile grid of the elimination kernels
+  DevBuf<double> pscratch;                             // per front: inverse of the current pivot block + copied column panel
+  DevBuf<int> pext_p;
   DevBuf<int64_t> pshift_slot;  // fc_set_front_shifts: added to the fronts after the scatter
   DevBuf<double> pshift_val;
   int pn_shift = 0;
@@ -299,65 +299,6 @@ int rccl_load() {
     if (_r != 0)                                                                                  \
       return fail(FC_ERR_HIP, std::string(#expr) + ": " +                                         \
                                   (g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "rccl error")); \
-  } while (0)
-
-// rocBLAS / rocSOLVER (dense pivot-block inverses and front updates of fc_refactor) are resolved at run
-// time as well: the time-stepping path does not depend on them, and inside a torch process the
-// copies torch already loaded are reused.
-struct DenseLibs {
-  void* blas = nullptr;
-  void* solver = nullptr;
-  rocblas_handle handle = nullptr;
-  decltype(&rocblas_create_handle) create_handle = nullptr;
-  decltype(&rocblas_destroy_handle) destroy_handle = nullptr;
-  decltype(&rocblas_set_stream) set_stream = nullptr;
-  decltype(&rocblas_dgemm) dgemm = nullptr;
-  decltype(&rocsolver_dgetrf) dgetrf = nullptr;
-  decltype(&rocsolver_dgetri_outofplace) dgetri = nullptr;
-};
-DenseLibs g_dense;
-
-int dense_load() {
-  if (g_dense.handle) return FC_OK;
-  // take the copies that sit next to the HIP runtime this library is bound to (PyTorch ships its own
-  // set): a rocBLAS bound to another runtime would not understand our stream
-  std::string dir;
-  Dl_info di;
-  if (dladdr((void*)&hipStreamSynchronize, &di) && di.dli_fname) {
-    dir = di.dli_fname;
-    const size_t cut = dir.rfind('/');
-    dir = cut == std::string::npos ? std::string() : dir.substr(0, cut + 1);
-  }
-  const std::string blas_names[] = {dir + "librocblas.so", dir + "librocblas.so.5", "librocblas.so.5", "librocblas.so",
-                                    "/opt/rocm/lib/librocblas.so.5"};
-  const std::string solver_names[] = {dir + "librocsolver.so", dir + "librocsolver.so.0", "librocsolver.so.0", "librocsolver.so",
-                                      "/opt/rocm/lib/librocsolver.so.0"};
-  for (const std::string& n : blas_names)
-    if ((g_dense.blas = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL))) break;
-  if (!g_dense.blas) return fail(FC_ERR_HIP, std::string("cannot load rocBLAS: ") + dlerror());
-  for (const std::string& n : solver_names)
-    if ((g_dense.solver = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL))) break;
-  if (!g_dense.solver) return fail(FC_ERR_HIP, std::string("cannot load rocSOLVER: ") + dlerror());
-  g_dense.create_handle = (decltype(g_dense.create_handle))dlsym(g_dense.blas, "rocblas_create_handle");
-  g_dense.destroy_handle = (decltype(g_dense.destroy_handle))dlsym(g_dense.blas, "rocblas_destroy_handle");
-  g_dense.set_stream = (decltype(g_dense.set_stream))dlsym(g_dense.blas, "rocblas_set_stream");
-  g_dense.dgemm = (decltype(g_dense.dgemm))dlsym(g_dense.blas, "rocblas_dgemm");
-  g_dense.dgetrf = (decltype(g_dense.dgetrf))dlsym(g_dense.solver, "rocsolver_dgetrf");
-  g_dense.dgetri = (decltype(g_dense.dgetri))dlsym(g_dense.solver, "rocsolver_dgetri_outofplace");
-  if (!g_dense.create_handle || !g_dense.set_stream || !g_dense.dgemm || !g_dense.dgetrf || !g_dense.dgetri)
-    return fail(FC_ERR_HIP, "rocBLAS / rocSOLVER symbols missing");
-  rocblas_handle hd = nullptr;
-  const rocblas_status cs = g_dense.create_handle(&hd);
-  if (cs != rocblas_status_success) return fail(FC_ERR_HIP, "rocblas_create_handle failed with status " + std::to_string((int)cs));
-  g_dense.handle = hd;
-  return FC_OK;
-}
-
-#define ROCCHK(expr)                                                                             \
-  do {                                                                                           \
-    rocblas_status _r = (expr);                                                                  \
-    if (_r != rocblas_status_success)                                                            \
-      return fail(FC_ERR_HIP, std::string(#expr) + ": rocblas status " + std::to_string((int)_r)); \
   } while (0)
 
 constexpr int kNcclDouble = 8, kNcclSum = 0;
@@ -2030,23 +1971,29 @@ int fc_factor_plan(fc_handle h, int32_t n_nodes, const int64_t* nodes, int32_t n
     }
   }
   if (ext.empty()) ext.push_back(FcExt{0, 0, 0, 0, 0, 0});
-  // small fronts: one workgroup each (fc_front_eliminate); FC_FRONT_KERNEL_MAX = widest front taken (0: none)
-  int small_max = 400;  // measured on the 56 k-dof cylinder mesh: 0 -> 208 ms, 128 -> 105, 256 -> 69, 400 -> 61, 768 -> 221 ms
-  if (const char* e = std::getenv("FC_FRONT_KERNEL_MAX")) small_max = std::min(FC_FRONT_MAX, std::max(0, std::atoi(e)));
+  // fronts with a pivot block, level by level, with their scratch (fc_front.hip.h)
   std::vector<FcFront> fr;
   h->pfront_groups.assign((size_t)n_levels, {0, 0});
-  h->pnode_small.assign((size_t)n_nodes, 0);
+  h->plevel_max_ni.assign((size_t)n_levels, 0);
+  h->plevel_max_nf.assign((size_t)n_levels, 0);
+  int64_t scratch_max = 1;
   for (int li = 0; li < n_levels; ++li) {
     const int64_t first = (int64_t)fr.size();
+    int64_t off = 0;
     for (int64_t g = level_ptr[li]; g < level_ptr[li + 1]; ++g) {
       const fc_ctx::PlanNode& nd = h->pnodes[(size_t)g];
-      if (nd.ni == 0 || nd.nf > small_max) continue;
-      fr.push_back(FcFront{(long long)nd.front, (long long)nd.voff, nd.nf, nd.ni});
-      h->pnode_small[(size_t)g] = 1;
+      if (nd.ni == 0) continue;
+      fr.push_back(FcFront{(long long)nd.front, (long long)nd.voff, nd.nf, nd.ni, (long long)off});
+      off += (int64_t)FC_FE_KB * FC_FE_KB + (int64_t)nd.nf * FC_FE_KB;
+      h->plevel_max_ni[li] = std::max(h->plevel_max_ni[li], nd.ni);
+      h->plevel_max_nf[li] = std::max(h->plevel_max_nf[li], nd.nf);
     }
+    scratch_max = std::max(scratch_max, off);
     h->pfront_groups[li] = {first, (int)((int64_t)fr.size() - first)};
+    if (h->pfront_groups[li].second > 65535) return fail(FC_ERR_INVALID, "fc_factor_plan: more than 65535 fronts in one level");
   }
-  if (fr.empty()) fr.push_back(FcFront{0, 0, 0, 0});
+  if (fr.empty()) fr.push_back(FcFront{0, 0, 0, 0, 0});
+  FCCHK(h->pscratch.alloc((size_t)scratch_max));
   FCCHK(h->pfront.upload(fr, h->stream));
   FCCHK(h->fronts.alloc((size_t)front_size));
   FCCHK(h->pa_src.upload(a_src, (size_t)std::max<int64_t>(1, n_a), h->stream));
@@ -2054,7 +2001,6 @@ int fc_factor_plan(fc_handle h, int32_t n_nodes, const int64_t* nodes, int32_t n
   FCCHK(h->pap_src.upload(ap_src, (size_t)n_ap, h->stream));
   FCCHK(h->pext.upload(ext, h->stream));
   FCCHK(h->pext_p.upload(ext_p, (size_t)std::max<int64_t>(1, n_ext), h->stream));
-  FCCHK(h->pipiv.alloc((size_t)h->pmax_ni + 8));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->pn_shift = 0;
   h->have_plan = true;
@@ -2081,8 +2027,6 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
   if (!S.structured) return fail(FC_ERR_NOT_READY, "fc_solver_setup (structure) must be called first");
   if ((int64_t)h->pap_src.n != S.Ap_nnz) return fail(FC_ERR_INVALID, "fc_refactor: plan and solver structure disagree (matrix)");
   HIPCHK(hipSetDevice(h->device));
-  FCCHK(dense_load());
-  ROCCHK(g_dense.set_stream(g_dense.handle, h->stream));
   for (const fc_ctx::PlanNode& nd : h->pnodes) {
     const int nb = nd.nf - nd.ni;
     if (nd.ni > 0 && nd.voff + (int64_t)nd.ni * nd.nf + (int64_t)nb * nd.ni > S.f_nnz)
@@ -2106,9 +2050,6 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
   if (h->pn_shift > 0 && (!dist || h->lead))
     hipLaunchKernelGGL(fc_front_shift, dim3(nblocks(h->pn_shift, 64)), dim3(64), 0, h->stream, h->pn_shift, h->pshift_slot.p,
                        h->pshift_val.p, F);
-  int* ipiv = h->pipiv.p;
-  int* info = h->pipiv.p + h->pmax_ni;
-  const double one = 1.0, zero = 0.0, minus = -1.0;
   for (int li = 0; li < n_levels; ++li) {
     if (li > 0) {
       // update blocks of the level below, one launch per child slot (deterministic, conflict-free)
@@ -2128,38 +2069,20 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
       const fc_ctx::PlanNode& root = h->pnodes[(size_t)h->plevel_ptr[li]];
       FCCHK(exchange(h, F + root.front, (size_t)root.nf * root.nf));
     }
-    if (h->pfront_groups[li].second > 0)
-      hipLaunchKernelGGL(fc_front_eliminate, dim3(h->pfront_groups[li].second), dim3(256), 0, h->stream,
-                         h->pfront.p + h->pfront_groups[li].first, F, fv);
-    for (int64_t g = h->plevel_ptr[li]; g < h->plevel_ptr[li + 1]; ++g) {
-      const fc_ctx::PlanNode& nd = h->pnodes[(size_t)g];
-      const int ni = nd.ni, nf = nd.nf, nb = nf - ni;
-      if (ni == 0 || h->pnode_small[(size_t)g]) continue;
-      double* Fn = F + nd.front;  // row-major nf x nf: [F11 F12; F21 F22]
-      // D^-1 = F11^-1, written straight into the factor rows [D^-1 | -U] (stride nf).  The column-major
-      // view LAPACK sees is F11^T; (F11^T)^-1 stored column-major is F11^-1 stored row-major, which is what
-      // the sweeps read.  Out-of-place getri: the in-place rocsolver_dgetri of ROCm 7.0/7.2 returns wrong
-      // inverses for n = 255, 383, 511, 639, 1023, 1151, ... (n = 127 mod 128; scripts/micro/getri_check.py).
-      double* dv = fv + nd.voff;
-      ROCCHK(g_dense.dgetrf(g_dense.handle, ni, ni, Fn, nf, ipiv, info));
-      ROCCHK(g_dense.dgetri(g_dense.handle, ni, Fn, nf, ipiv, dv, nf, info));
-      if (nb > 0) {
-        double* F12 = Fn + ni;
-        double* F21 = Fn + (size_t)ni * nf;
-        double* F22 = F21 + ni;
-        double* mW = dv + (size_t)ni * nf;  // -L rows (nb x ni), stride ni
-        // row-major C = A B  <=>  column-major C' = B' A' (same memory): operands swapped below
-        // -U = -D^-1 F12   (ni x nb), written next to D^-1
-        ROCCHK(g_dense.dgemm(g_dense.handle, rocblas_operation_none, rocblas_operation_none, nb, ni, ni, &minus, F12, nf, dv, nf, &zero,
-                             dv + ni, nf));
-        // -L = -F21 D^-1   (nb x ni)
-        ROCCHK(g_dense.dgemm(g_dense.handle, rocblas_operation_none, rocblas_operation_none, ni, nb, ni, &minus, dv, nf, F21, nf, &zero,
-                             mW, ni));
-        // Schur complement handed to the parent: F22 += (-L) F12
-        if (nd.parent >= 0)
-          ROCCHK(g_dense.dgemm(g_dense.handle, rocblas_operation_none, rocblas_operation_none, nb, nb, ni, &one, F12, nf, mW, ni, &one,
-                               F22, nf));
+    // all fronts of the level together: block steps of FC_FE_KB pivot columns (fc_front.hip.h)
+    const auto grp = h->pfront_groups[li];
+    if (grp.second > 0) {
+      const FcFront* fp = h->pfront.p + grp.first;
+      const int nfmax = h->plevel_max_nf[li];
+      const int ct = (nfmax + 63) / 64;  // 64-wide tiles per side of the widest front
+      const int steps = (h->plevel_max_ni[li] + FC_FE_KB - 1) / FC_FE_KB;
+      for (int k = 0; k < steps; ++k) {
+        hipLaunchKernelGGL(fc_fe_pivot, dim3(grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k);
+        hipLaunchKernelGGL(fc_fe_panels, dim3(2 * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
+        hipLaunchKernelGGL(fc_fe_update, dim3(ct * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
       }
+      hipLaunchKernelGGL(fc_fe_export, dim3((nfmax + 15) / 16, grp.second), dim3(256), 0, h->stream, fp, F, fv);
+      HIPCHK(hipGetLastError());
     }
   }
   if (S.dag_ready)  // row-by-row copy of the -L values for the one-launch apply

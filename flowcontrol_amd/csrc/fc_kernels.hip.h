@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void fc_nd_down_block(const FcBlk* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// Device-side numeric factorisation (fc_refactor): index kernels around the dense library calls.
+// Device-side numeric factorisation (fc_refactor): index kernels around the dense front elimination (fc_front.hip.h).
 // ---------------------------------------------------------------------------------------------
 // fronts[a_dst[k]] = vals[a_src[k]]: every matrix entry has exactly one slot in exactly one front
 __global__ void fc_front_scatter(int64_t n, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
@@ -584,114 +584,6 @@ __global__ __launch_bounds__(256) void fc_extend_add(const FcExt* __restrict__ e
     double* __restrict__ drow = fronts + d.dst + (long long)pp[i] * d.nfp;
     for (int j = threadIdx.x; j < d.nbc; j += 256) drow[pp[j]] += srow[j];
   }
-}
-
-// One workgroup eliminates one front IN PLACE: ni Gauss-Jordan sweeps with partial pivoting among the
-// pivot rows turn  [F11 F12; F21 F22]  into  [F11^-1, F11^-1 F12; -F21 F11^-1, F22 - F21 F11^-1 F12]
-// (row swaps P act on the first ni rows only: the two left blocks come out column-permuted and are put
-// right by applying the swaps to the columns in reverse order, as LAPACK's getri does).  The factor
-// rows [D^-1 | -U] and the -L block are then exported to the layout the sweeps read; the Schur
-// complement stays in the front for the parent's extend-add.  Used for the many small fronts near the
-// leaves, where a library call per node and operation is all launch overhead; fronts wider than
-// FC_FRONT_MAX go through rocSOLVER / rocBLAS.
-struct __attribute__((aligned(16))) FcFront {
-  long long front;  // offset of the nf x nf row-major front
-  long long voff;   // offset of the node's factor values
-  int nf, ni;
-};
-#define FC_FRONT_MAX 1024
-__global__ __launch_bounds__(256) void fc_front_eliminate(const FcFront* __restrict__ nodes, double* fronts,
-                                                          double* __restrict__ fvals) {
-  __shared__ double rowk[FC_FRONT_MAX], colk[FC_FRONT_MAX];
-  __shared__ int piv[FC_FRONT_MAX];
-  __shared__ double wv[4];
-  __shared__ int wi[4];
-  const FcFront nd = nodes[blockIdx.x];
-  const int nf = nd.nf, ni = nd.ni;
-  double* A = fronts + nd.front;
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-  for (int k = 0; k < ni; ++k) {
-    // 1. pivot: largest |A[i][k]| among the remaining pivot rows (ties -> smallest row: reproducible)
-    double best = -1.0;
-    int bi = k;
-    for (int i = k + t; i < ni; i += 256) {
-      const double v = fabs(A[(size_t)i * nf + k]);
-      if (v > best) {
-        best = v;
-        bi = i;
-      }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const double ov = __shfl_down(best, off, 64);
-      const int oi = __shfl_down(bi, off, 64);
-      if (ov > best || (ov == best && oi < bi)) {
-        best = ov;
-        bi = oi;
-      }
-    }
-    if (lane == 0) {
-      wv[wave] = best;
-      wi[wave] = bi;
-    }
-    __syncthreads();
-    int p = wi[0];
-    double pb = wv[0];
-#pragma unroll
-    for (int w = 1; w < 4; ++w)
-      if (wv[w] > pb || (wv[w] == pb && wi[w] < p)) {
-        pb = wv[w];
-        p = wi[w];
-      }
-    if (t == 0) piv[k] = p;
-    // 2. swap rows k and p
-    if (p != k)
-      for (int j = t; j < nf; j += 256) {
-        const double a = A[(size_t)k * nf + j], b = A[(size_t)p * nf + j];
-        A[(size_t)k * nf + j] = b;
-        A[(size_t)p * nf + j] = a;
-      }
-    __syncthreads();
-    // 3. scaled pivot row and the pivot column
-    const double d = 1.0 / A[(size_t)k * nf + k];
-    for (int j = t; j < nf; j += 256) {
-      rowk[j] = j == k ? 0.0 : A[(size_t)k * nf + j] * d;
-      colk[j] = j == k ? 0.0 : A[(size_t)j * nf + k];
-    }
-    __syncthreads();
-    // 4. rank-one update of everything else; row k and column k take their swept values
-    for (int i = wave; i < nf; i += 4) {
-      double* __restrict__ Ai = A + (size_t)i * nf;
-      const double ci = colk[i];
-      if (i == k) {
-        for (int j = lane; j < nf; j += 64) Ai[j] = j == k ? d : rowk[j];
-      } else {
-        for (int j = lane; j < nf; j += 64) Ai[j] = j == k ? -ci * d : Ai[j] - ci * rowk[j];
-      }
-    }
-    __syncthreads();
-  }
-  // undo the row swaps on the columns of the two left blocks
-  for (int k = ni - 1; k >= 0; --k) {
-    const int p = piv[k];
-    if (p != k) {
-      for (int i = t; i < nf; i += 256) {
-        const double a = A[(size_t)i * nf + k], b = A[(size_t)i * nf + p];
-        A[(size_t)i * nf + k] = b;
-        A[(size_t)i * nf + p] = a;
-      }
-      __syncthreads();
-    }
-  }
-  __syncthreads();
-  // export: [D^-1 | -U] rows (stride nf), then the -L block (nb x ni, stride ni)
-  double* __restrict__ dv = fvals + nd.voff;
-  for (int i = wave; i < ni; i += 4)
-    for (int j = lane; j < nf; j += 64) dv[(size_t)i * nf + j] = j < ni ? A[(size_t)i * nf + j] : -A[(size_t)i * nf + j];
-  double* __restrict__ mw = dv + (size_t)ni * nf;
-  const int nb = nf - ni;
-  for (int i = wave; i < nb; i += 4)
-    for (int j = lane; j < ni; j += 64) mw[(size_t)i * ni + j] = A[(size_t)(ni + i) * nf + j];
 }
 
 // ---------------------------------------------------------------------------------------------

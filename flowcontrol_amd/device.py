@@ -339,7 +339,7 @@ class DeviceSolver:
         check(self.lib.fc_refactor(self._h, slot, C.byref(ms)))
         self.refactor_ms[slot] = ms.value
         # end-to-end acceptance of the new factors: one solve with a fixed right-hand side, residual
-        # against the matrix itself (the dense libraries are not trusted blindly, cf. scripts/micro/getri_check.py)
+        # against the matrix itself (block-local pivoting in fc_fe_pivot is not trusted blindly)
         if self._probe is None:
             self._probe = np.cos(0.37 * np.arange(self.N) + 0.1)
             if self._pin is not None:

@@ -164,11 +164,13 @@ int fc_debug_trace_apply(fc_handle h, int slot, int32_t n_tasks, int64_t* stamps
  * front, ap_src maps the permuted matrix of the residual monitor to CSR value indices.
  * fc_refactor(slot) then recomputes the factor values and the permuted matrix of `slot` from the
  * slot's current CSR values (after fc_assemble_matrix + fc_apply_bc): scatter, per level extend-add of
- * the children's Schur complements, pivot-block inverse (rocSOLVER getrf/getri, partial pivoting inside
- * the block) and three GEMMs per node (rocBLAS), written straight into the layout the sweeps read.
+ * the children's Schur complements, then the in-place elimination of all fronts of the level together by blocked
+ * Gauss-Jordan steps of 32 pivot columns (pivot block inverted in LDS with partial pivoting inside the block, panels,
+ * trailing update on the fp64 matrix cores, v_mfma_f64_16x16x4_f64: csrc/fc_front.hip.h), exported straight into the
+ * layout the sweeps read.  No vendor BLAS / LAPACK is involved.
  * The structure (fc_solver_setup / fc_solver_set_blocks) must have been uploaded before, with any
- * values.  ms_out (optional): device time of the numeric phase.  On a partitioned handle every rank
- * repeats the numeric phase for the whole tree (it holds the whole matrix); no collective involved. */
+ * values.  ms_out (optional): device time of the numeric phase.  On a partitioned handle every rank factorises its own
+ * sub-tree and the root (plan built with keep=); the root front is summed over the ranks once (exchange). */
 int fc_factor_plan(fc_handle h, int32_t n_nodes, const int64_t* nodes, int32_t n_levels, const int64_t* level_ptr,
                    int64_t front_size, int64_t n_a, const int64_t* a_src, const int64_t* a_dst,
                    const int64_t* a_ptr, const int64_t* ext_off, int64_t n_ext, const int32_t* ext_p,

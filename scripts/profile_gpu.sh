@@ -2,7 +2,7 @@
 # Run on the GPU box (through gpurun): rocprofv3 kernel stats + HBM traffic counters for bench.py.
 # Counters go in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950), with few
 # steps (counter collection serialises every kernel) and the numpy factorisation for the setup
-# (FC_HOST_FACTOR=1: the thousands of short rocSOLVER kernels of the device setup are not what is measured).
+# (FC_HOST_FACTOR=1: the setup kernels are not what is measured).
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profile

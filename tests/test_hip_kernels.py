@@ -221,7 +221,7 @@ def test_block_and_segment_down_sweeps_agree(setup):
 
 
 def test_device_factorisation_matches_host_multifrontal(setup):
-    """fc_refactor (scatter, extend-add, rocSOLVER pivot inverses, rocBLAS front updates on the device)
+    """fc_refactor (scatter, extend-add, blocked Gauss-Jordan front elimination on the fp64 matrix cores)
     against the numpy multifrontal of ndsolver.factorize_blocks on the same matrix and tree: factor
     values to round-off, then again after the matrix changed (numeric phase only)."""
     th, dev, d, O = setup
@@ -340,7 +340,8 @@ def test_error_paths_of_the_factorisation_and_krylov_entry_points(golden_dir):
     assert lib.fc_set_front_shifts(h, 1, np.zeros(1, np.int64), np.ones(1)) == FC_ERR_NOT_READY
     assert b"fc_factor_plan" in lib.fc_last_error()
     assert lib.fc_set_solver_options(h, _lib.METHOD_BICGSTAB, 0, 1e-10, 1) == FC_ERR_INVALID  # needs >= 1 iteration
-    assert lib.fc_set_solver_options(h, _lib.METHOD_GMRES, 5, 1e-10, 1) == FC_ERR_INVALID  # not built
+    assert lib.fc_set_solver_options(h, _lib.METHOD_GMRES, 0, 1e-10, 1) == FC_ERR_INVALID  # needs >= 1 iteration
+    assert lib.fc_set_solver_options(h, 9, 5, 1e-10, 1) == FC_ERR_INVALID  # unknown method
     assert lib.fc_refactor(h, 7, None) == FC_ERR_INVALID
     # a working system, then misuse
     dofs, prof = _bc_setup(th)
@@ -354,12 +355,13 @@ def test_error_paths_of_the_factorisation_and_krylov_entry_points(golden_dir):
         dev.set_pressure_pin(3)  # a velocity dof
     dev.set_state(np.zeros(2 * th.nn), np.zeros(2 * th.nn), np.zeros(th.nv))
     dev.set_sensors([th.point_eval_row((0.3, 0.4), 0)])
-    dev.set_solver_options(refine=5, method="bicgstab")
-    with pytest.raises(FcError, match="FC_METHOD_REFINE"):
-        dev.step(SLOT_BDF2, np.zeros(prof.shape[1]))
+    dev.set_solver_options(refine=5, method="bicgstab")  # a Krylov method inside the step: one iteration with exact factors
+    y_k, _, info_k = dev.step(SLOT_BDF2, np.zeros(prof.shape[1]))
+    assert np.isfinite(y_k).all() and info_k[0] <= 1  # (zero state, zero actuation: b = 0, no iteration needed)
     dev.set_solver_options(0, True)
     y, dE, info = dev.step(SLOT_BDF2, np.zeros(prof.shape[1]))
     assert np.isfinite(y).all() and info[1] < 1e-10
+    assert lib.fc_set_stage_diag(h, 5, np.ones(dev.N)) == FC_ERR_INVALID
     n = C.c_int64(dev._n_factor_values + 1)
     assert lib.fc_get_factor_values(h, SLOT_BDF2, n, np.empty(n.value)) == FC_ERR_INVALID
     check(lib.fc_refactor(h, SLOT_BDF2, None))
