@@ -99,7 +99,7 @@ def _cpu_baseline_1core(fs, O, n_steps, warm) -> dict:
     d = O.Disc.from_taylor_hood(th)
     U0 = fs.fields.U0.vector().array()
     dofs, prof = fs._bc_tables()
-    perm = th.device().tree.perm
+    perm = th.device().perm
     ts = O.TimeStepper(d, fs.params_flow.Re, fs.params_time.dt, U0, dofs, prof, perm=perm)
     rows = [s.row(fs) for s in fs.params_control.sensor_list]
     cs = cpu_step.CompiledStepper(ts, rows)
@@ -271,7 +271,7 @@ def main() -> None:
         tim = dev.get_timing()
         dev.set_timing(False)
         sweep_bytes, spmv_bytes = dev.algorithmic_bytes(SLOT_BDF2)
-        n_stage = 2 * dev.tree.depth + 1
+        n_stage = 2 * dev.depth + 1
         applies = tim["sweep_launches"] / max(n_stage, 1)
         mean_launch_ms = tim["sweep_ms"] / max(tim["sweep_launches"], 1)
         bytes_per_launch = sweep_bytes / n_stage
@@ -326,7 +326,7 @@ def main() -> None:
                     f"over the ranks, 3 RCCL all-reduces per step" if partitioned
                     else f"{world} independent replicas (no data-path collective)"),
                 "partition": part_info,
-                "solver": f"ND selected-inverse depth {dev.tree.depth}, {fs.refine_steps} refinement",
+                "solver": f"ND selected-inverse depth {dev.depth}, {fs.refine_steps} refinement",
             },
             "batched_steps_per_s": args.steps / t_batched,
             "replicas_steps_per_s": (world * single_rate) if single_rate else None,

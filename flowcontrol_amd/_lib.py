@@ -17,7 +17,7 @@ import numpy as np
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = Path(os.environ["FC_LIB_PATH"]) if os.environ.get("FC_LIB_PATH") else CSRC / "libfc_hip.so"  # FC_LIB_PATH: tuning builds
-SOURCES = [CSRC / "fc_hip.hip", *sorted(CSRC.glob("*.hip.h")), CSRC.parent.parent / "include" / "fc_hip.h"]
+SOURCES = [CSRC / "fc_hip.hip", *sorted(CSRC.glob("*.hip.h")), *sorted(CSRC.glob("*.hpp")), CSRC.parent.parent / "include" / "fc_hip.h"]
 
 FC_OK = 0
 FC_ERR_INVALID, FC_ERR_HIP, FC_ERR_DIVERGED, FC_ERR_NOT_CONVERGED, FC_ERR_NOT_READY = -1, -2, -3, -4, -5
@@ -108,6 +108,18 @@ SIGNATURES: dict[str, list] = {
     "fc_solver_set_dag": [_H, C.c_int, C.c_int32, _lp, np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS"), _ip, _ip, _ip],
     "fc_get_dag_info": [_H, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "fc_set_dag": [_H, C.c_int],
+    "fc_setup_solver": [_H, C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32],
+    "fc_get_permutation": [_H, _ip],
+    "fc_set_pressure_pin": [_H, C.c_int32, C.c_double],
+    "fc_get_local_cells": [_H, _ip],
+    "fc_get_refactor_ms": [_H, C.c_int, C.POINTER(C.c_double)],
+    "fc_sym_build": [C.c_int32, C.c_int32, C.c_int32, _dp, _ip, _ip, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                     C.POINTER(C.c_void_p)],
+    "fc_sym_size": [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)],
+    "fc_sym_get": [C.c_void_p, C.c_char_p, _lp],
+    "fc_sym_free": [C.c_void_p],
+    "fc_get_solver_info": [_H, C.c_int, _lp],
+    "fc_get_rowkind": [_H, np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")],
     "fc_set_stage_diag": [_H, C.c_int, _dp],
     "fc_debug_inject_dag_failure": [_H, C.c_int],
     "fc_debug_trace_apply": [_H, C.c_int, C.c_int32, _lp, _ip, _ip],

@@ -16,12 +16,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <string>
 #include <vector>
 
 #include "fc_kernels.hip.h"
 #include "fc_dag.hip.h"
 #include "fc_front.hip.h"
+#include "fc_symbolic.hpp"
 
 namespace {
 
@@ -147,6 +149,21 @@ struct fc_ctx {
   DevBuf<int> rowptr, col;
   DevBuf<int> mptr, midx;  // matrix scatter (per CSR slot)
   std::vector<int> h_gptr, h_gidx;  // vector scatter per W row (original numbering)
+  std::vector<int> h_cell_dofs;     // [nc][15] W dofs of every cell (fc_setup_solver: elimination tree)
+  std::vector<double> h_cent;       // [nc][2] cell centroids
+  // symbolic phase done inside the library (fc_setup_solver): kept for the second slot and for the getters
+  bool sym_ready = false;
+  int sym_truncate = 0;
+  fcsym::Tree sym_tree;
+  fcsym::Factors sym_fac;
+  fcsym::Plan sym_plan;
+  int64_t sym_total_nnz = 0;  // factor values of the WHOLE tree (all ranks, no truncation)
+  double refactor_ms[2] = {0.0, 0.0};  // device time of the last fc_refactor per slot
+  int pin_dof = -1;           // fc_set_pressure_pin: pressure dof whose diagonal is shifted inside the factorisation
+  double pin_shift = 1.0;
+  int64_t sym_local_values[2] = {0, 0};  // factor values this rank sweeps per solve, per slot
+  std::vector<int> h_s_rowptr, h_s_idx;  // sensors as given by the caller (restricted to owned dofs on a partitioned handle)
+  std::vector<double> h_s_w;
   DevBuf<int> gptr_p, gidx_p;       // permuted row order
   DevBuf<double> em, ev;
   DevBuf<double> vals[FC_NUM_SLOTS];
@@ -781,13 +798,16 @@ int bicgstab_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
     return nb < 0 ? nb : FC_OK;
   };
   HIPCHK(hipMemsetAsync(ks, 0, KS_SIZE * sizeof(double), h->stream));
-  HIPCHK(hipMemsetAsync(x, 0, (size_t)N * sizeof(double), h->stream));
+  // all work vectors start at 0: the first p = 1 r + 0 p + 0 v must not meet NaN bit patterns in fresh memory
+  HIPCHK(hipMemsetAsync(x, 0, 8 * (size_t)N * sizeof(double), h->stream));
   hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, r);
   hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, rh);
   dots(0, r, r, rh, r);
   double kh[KS_SIZE];
   *iters = 0;
   *relres = 0.0;
+  constexpr int kBicgRestarts = 8;
+  int restarts = 0;
   for (int it = 1; it <= h->max_iter; ++it) {
     lin3(p, 3, r, p, v);  // p = r + beta (p - omega v)   (first iteration: p = r)
     FCCHK(precond(p, ph));
@@ -803,6 +823,17 @@ int bicgstab_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
     dots(4, r, r, rh, r);
     if (it % kKrylovCheck == 0 || it == h->max_iter) {
       FCCHK(krylov_state(h, kh));
+      if (kh[KS_STATE] < 0.0 && restarts < kBicgRestarts && it < h->max_iter) {
+        // breakdown (rh.v or t.t vanished): x is the last complete iterate (the vector kernels are no-ops once the state
+        // is negative) — restart the recurrences from it with a new shadow residual rh = r = b - A x
+        ++restarts;
+        const int nb = launch_spmv<1>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, x, h->b.p, r, nullptr, nullptr);
+        if (nb < 0) return nb;
+        hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, r, rh);
+        hipLaunchKernelGGL(fc_dots2, dim3(gd), dim3(256), 0, h->stream, N, r, r, rh, r, h->partial.p);
+        hipLaunchKernelGGL(fc_bicg_phase, dim3(1), dim3(256), 0, h->stream, 5, gd, h->partial.p, ks, h->rtol, 1, 1);
+        continue;
+      }
       if (kh[KS_STATE] != 0.0) break;
     }
   }
@@ -835,7 +866,10 @@ int gmres_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
   const int N = h->N, g = nblocks(N, 256), gd = std::min(g, 256);
   const int m = std::max(1, std::min(h->gmres_m, h->max_iter));
   const size_t need = (size_t)(m + 4) * N;
-  if (h->kry.n < need) FCCHK(h->kry.alloc(need));
+  if (h->kry.n < need) {
+    FCCHK(h->kry.alloc(need));
+    FCCHK(h->kry.zero(h->stream));  // basis columns not reached yet meet zero coefficients: keep NaN bit patterns out
+  }
   if (h->ks.n != KS_SIZE) FCCHK(h->ks.alloc(KS_SIZE));
   const size_t gm_n = (size_t)(m + 1) * m + 2 * m + (m + 1) + m + (m + 2) + 2 + (m + 2);  // ... | norm2 | used | hcol2
   if (h->gm.n < gm_n) FCCHK(h->gm.alloc(gm_n));
@@ -1097,6 +1131,11 @@ int fc_create(fc_handle* out, int device, int32_t nv, int32_t ne, int32_t nc, co
     }
     for (int k = 0; k < 3; ++k) cd[(size_t)c * 15 + 12 + k] = 2 * nn + v[k];
   }
+  h->h_cell_dofs = cd;
+  h->h_cent.resize((size_t)nc * 2);
+  for (int c = 0; c < nc; ++c)
+    for (int d = 0; d < 2; ++d)
+      h->h_cent[2 * (size_t)c + d] = (coords[2 * cells[3 * c] + d] + coords[2 * cells[3 * c + 1] + d] + coords[2 * cells[3 * c + 2] + d]) / 3.0;
   TRY(h->cn.upload(cn, h->stream));
   TRY(h->geom.upload(geom, h->stream));
   // CSR pattern (no pressure-pressure coupling)
@@ -1326,6 +1365,17 @@ int fc_set_bc(fc_handle h, int32_t n_bc, const int32_t* bc_dofs, int32_t n_act, 
     if (isbc[bc_dofs[k]]) return fail(FC_ERR_INVALID, "fc_set_bc: duplicate dof");
     isbc[bc_dofs[k]] = 1;
   }
+  {
+    // the elimination tree parks the Dirichlet dofs in the leaves: a different SET needs a new tree
+    std::vector<int> a(h->h_bc_dofs), b(bc_dofs, bc_dofs + n_bc);
+    std::sort(a.begin(), a.end());
+    std::sort(b.begin(), b.end());
+    if (a != b && h->sym_ready) {
+      h->sym_ready = false;
+      h->have_plan = false;
+      for (int o = 0; o < 2; ++o) h->sys[o].structured = h->sys[o].dag_ready = false;
+    }
+  }
   h->n_bc = n_bc;
   h->n_act = n_act;
   h->h_bc_dofs.assign(bc_dofs, bc_dofs + n_bc);
@@ -1354,20 +1404,48 @@ int fc_set_force(fc_handle h, int32_t n_act, const double* profiles) {
   return FC_OK;
 }
 
+static int upload_sensors(fc_ctx* h) {
+  // partitioned: every rank evaluates the part of each sensor row that lives on dofs it owns (root dofs: lead rank
+  // only); the partial readings are summed by the step's last exchange
+  const int n_sens = h->n_sens;
+  if (n_sens == 0) return FC_OK;
+  std::vector<int> rp(1, 0), idx;
+  std::vector<double> w;
+  for (int s = 0; s < n_sens; ++s) {
+    for (int k = h->h_s_rowptr[s]; k < h->h_s_rowptr[s + 1]; ++k) {
+      const int d = h->h_s_idx[k];
+      if (h->partitioned && !h->h_rowkind.empty()) {
+        const unsigned char kind = h->h_rowkind[(size_t)d];
+        if (!(kind == 1 || (kind == 2 && h->lead))) continue;
+      }
+      idx.push_back(d);
+      w.push_back(h->h_s_w[k]);
+    }
+    rp.push_back((int)idx.size());
+  }
+  if (idx.empty()) {
+    idx.push_back(0);
+    w.push_back(0.0);
+  }
+  FCCHK(h->s_rowptr.upload(rp, h->stream));
+  FCCHK(h->s_idx.upload(idx, h->stream));
+  FCCHK(h->s_w.upload(w, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return FC_OK;
+}
+
 int fc_set_sensors(fc_handle h, int32_t n_sens, const int32_t* rowptr, const int32_t* idx, const double* w) {
   if (!h || n_sens < 0 || n_sens > 64 || (n_sens > 0 && (!rowptr || !idx || !w)))
     return fail(FC_ERR_INVALID, "fc_set_sensors: bad argument");
   HIPCHK(hipSetDevice(h->device));
-  h->n_sens = n_sens;
-  if (n_sens == 0) return FC_OK;
-  const int nz = rowptr[n_sens];
+  const int nz = n_sens ? rowptr[n_sens] : 0;
   for (int k = 0; k < nz; ++k)
     if (idx[k] < 0 || idx[k] >= h->N) return fail(FC_ERR_INVALID, "fc_set_sensors: index out of range");
-  FCCHK(h->s_rowptr.upload(rowptr, n_sens + 1, h->stream));
-  FCCHK(h->s_idx.upload(idx, std::max(1, nz), h->stream));
-  FCCHK(h->s_w.upload(w, std::max(1, nz), h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  return FC_OK;
+  h->n_sens = n_sens;
+  h->h_s_rowptr.assign(rowptr, rowptr + (n_sens ? n_sens + 1 : 0));
+  h->h_s_idx.assign(idx, idx + nz);
+  h->h_s_w.assign(w, w + nz);
+  return upload_sensors(h);
 }
 
 int fc_set_time_scheme(fc_handle h, double dt, int nonlinear) {
@@ -1435,8 +1513,8 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
                     const int64_t* seg_val, const int32_t* seg_col, const int32_t* seg_len, int64_t n_idx,
                     const int32_t* idx, int64_t n_val, const double* vals, int32_t ar_stage, int32_t ar_row0,
                     int32_t ar_n, int32_t ar2_stage) {
-  if (!h || slot < 0 || slot > 1 || !Ap_rowptr || !Ap_col || !Ap_val || n_stages <= 0 || !stage_begin || !stage_row0 ||
-      !stage_nrows || !stage_kind || !seg_ptr || !seg_val || !seg_col || !seg_len || !vals || n_seg < 0 || n_idx < 0 ||
+  if (!h || slot < 0 || slot > 1 || !Ap_rowptr || !Ap_col || n_stages <= 0 || !stage_begin || !stage_row0 ||
+      !stage_nrows || !stage_kind || !seg_ptr || !seg_val || !seg_col || !seg_len || n_seg < 0 || n_idx < 0 ||
       n_val <= 0 || (n_idx > 0 && !idx))
     return fail(FC_ERR_INVALID, "fc_solver_setup: bad argument");
   if (!h->have_perm) return fail(FC_ERR_NOT_READY, "fc_set_permutation not called");
@@ -1553,7 +1631,12 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
   S.f_nnz = n_val;
   FCCHK(S.Ap_rowptr.upload(Ap_rowptr, N + 1, h->stream));
   FCCHK(S.Ap_col.upload(Ap_col, (size_t)S.Ap_nnz, h->stream));
-  FCCHK(S.Ap_val.upload(Ap_val, (size_t)S.Ap_nnz, h->stream));
+  if (Ap_val) {
+    FCCHK(S.Ap_val.upload(Ap_val, (size_t)S.Ap_nnz, h->stream));
+  } else {  // structure only: fc_refactor / fc_update_operator fill the values
+    FCCHK(S.Ap_val.alloc((size_t)S.Ap_nnz));
+    FCCHK(S.Ap_val.zero(h->stream));
+  }
   S.h_seg_ptr.assign(seg_ptr, seg_ptr + total_rows + 1);
   S.h_seg_val.assign(seg_val, seg_val + n_seg);
   S.h_seg_col.assign(seg_col, seg_col + n_seg);
@@ -1567,7 +1650,12 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
   }
   if (n_idx > 0) FCCHK(S.f_idx.upload(idx, (size_t)n_idx, h->stream));
   else FCCHK(S.f_idx.alloc(1));
-  FCCHK(S.f_val.upload(vals, (size_t)n_val, h->stream));
+  if (vals) {
+    FCCHK(S.f_val.upload(vals, (size_t)n_val, h->stream));
+  } else {  // structure only: the values are computed on the device (fc_refactor)
+    FCCHK(S.f_val.alloc((size_t)n_val));
+    FCCHK(S.f_val.zero(h->stream));
+  }
   HIPCHK(hipStreamSynchronize(h->stream));
   S.truncated = false;
   for (const Stage& st : S.stages) S.truncated = S.truncated || st.kind == 2;
@@ -2013,8 +2101,10 @@ int fc_set_front_shifts(fc_handle h, int32_t n, const int64_t* slots, const doub
   HIPCHK(hipSetDevice(h->device));
   for (int k = 0; k < n; ++k)
     if (slots[k] < 0 || slots[k] >= (int64_t)h->fronts.n) return fail(FC_ERR_INVALID, "fc_set_front_shifts: slot outside the fronts");
-  FCCHK(h->pshift_slot.upload(slots, (size_t)std::max(1, n), h->stream));
-  FCCHK(h->pshift_val.upload(values, (size_t)std::max(1, n), h->stream));
+  const int64_t no_slot = 0;
+  const double no_value = 0.0;
+  FCCHK(h->pshift_slot.upload(n > 0 ? slots : &no_slot, (size_t)std::max(1, n), h->stream));
+  FCCHK(h->pshift_val.upload(n > 0 ? values : &no_value, (size_t)std::max(1, n), h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->pn_shift = n;
   return FC_OK;
@@ -2047,9 +2137,16 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
   if (dist && !h->lead) n_a = h->pa_ptr[(size_t)n_levels - 1];  // entries below the root level
   if (n_a > 0)
     hipLaunchKernelGGL(fc_front_scatter, dim3(nblocks(n_a, 256)), dim3(256), 0, h->stream, n_a, h->pa_src.p, h->pa_dst.p, av, F);
-  if (h->pn_shift > 0 && (!dist || h->lead))
+  if (h->pn_shift > 0) {
+    int64_t skip0 = 0, skip1 = 0;  // the root front is summed over the ranks: only the lead rank shifts there
+    if (dist && !h->lead) {
+      const fc_ctx::PlanNode& root = h->pnodes[(size_t)h->plevel_ptr[(size_t)n_levels - 1]];
+      skip0 = root.front;
+      skip1 = root.front + (int64_t)root.nf * root.nf;
+    }
     hipLaunchKernelGGL(fc_front_shift, dim3(nblocks(h->pn_shift, 64)), dim3(64), 0, h->stream, h->pn_shift, h->pshift_slot.p,
-                       h->pshift_val.p, F);
+                       h->pshift_val.p, F, skip0, skip1);
+  }
   for (int li = 0; li < n_levels; ++li) {
     if (li > 0) {
       // update blocks of the level below, one launch per child slot (deterministic, conflict-free)
@@ -2093,7 +2190,376 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   if (ms_out) *ms_out = (double)ms;
+  h->refactor_ms[slot] = (double)ms;
   S.ready = true;
+  return FC_OK;
+}
+
+int fc_get_refactor_ms(fc_handle h, int slot, double* ms) {
+  if (!h || slot < 0 || slot > 1 || !ms) return fail(FC_ERR_INVALID, "fc_get_refactor_ms: bad argument");
+  *ms = h->refactor_ms[slot];
+  return FC_OK;
+}
+
+// ── the whole solver setup behind the C ABI: symbolic analysis (fc_symbolic.hpp) + uploads + numeric factorisation ──
+static int upload_energy_matrix(fc_ctx* h) {
+  // (u, v) mass matrix in the permuted numbering for the un-fused energy evaluation (fc_finish)
+  FCCHK(fc_assemble_matrix(h, FC_SLOT_MASS, 1.0, 0.0, nullptr, 1.0, nullptr, 1.0, 0.0, 0.0));
+  std::vector<double> mv((size_t)h->nnz);
+  HIPCHK(hipMemcpy(mv.data(), h->vals[FC_SLOT_MASS].p, mv.size() * sizeof(double), hipMemcpyDeviceToHost));
+  const int N = h->N, nn2 = 2 * h->nn;
+  const std::vector<int>& perm = h->sym_tree.perm;
+  const std::vector<int>& iperm = h->sym_tree.iperm;
+  std::vector<int> rp((size_t)N + 1, 0), col;
+  std::vector<double> val;
+  std::vector<std::pair<int, double>> row;
+  for (int i = 0; i < N; ++i) {
+    const int r = perm[i];
+    row.clear();
+    if (r < nn2)
+      for (int k = h->h_rowptr[r]; k < h->h_rowptr[r + 1]; ++k)
+        if (h->h_col[k] < nn2 && mv[(size_t)k] != 0.0) row.emplace_back(iperm[h->h_col[k]], mv[(size_t)k]);
+    std::sort(row.begin(), row.end());
+    for (auto& e : row) {
+      col.push_back(e.first);
+      val.push_back(e.second);
+    }
+    rp[(size_t)i + 1] = (int)col.size();
+  }
+  if (col.empty()) {
+    col.push_back(0);
+    val.push_back(0.0);
+  }
+  return fc_set_energy_matrix(h, rp.data(), col.data(), val.data());
+}
+
+// ndsolver.schur_diagonal_scaling in the permuted numbering (truncated factors)
+static int upload_stage_diag(fc_ctx* h, int slot) {
+  std::vector<double> av((size_t)h->nnz);
+  HIPCHK(hipMemcpy(av.data(), h->vals[slot].p, av.size() * sizeof(double), hipMemcpyDeviceToHost));
+  const int N = h->N, nn2 = 2 * h->nn;
+  std::vector<double> diag((size_t)N, 0.0), out((size_t)N, 1.0);
+  auto entry = [&](int r, int c) -> double {
+    const int* b0 = h->h_col.data() + h->h_rowptr[r];
+    const int* b1 = h->h_col.data() + h->h_rowptr[r + 1];
+    const int* it = std::lower_bound(b0, b1, c);
+    return (it != b1 && *it == c) ? av[(size_t)(it - h->h_col.data())] : 0.0;
+  };
+  for (int r = 0; r < N; ++r) diag[r] = entry(r, r);
+  for (int r = 0; r < nn2; ++r) out[r] = 1.0 / (diag[r] != 0.0 ? diag[r] : 1.0);
+  for (int r = nn2; r < N; ++r) {
+    double sacc = 0.0;
+    for (int k = h->h_rowptr[r]; k < h->h_rowptr[r + 1]; ++k) {
+      const int j = h->h_col[k];
+      if (j < nn2) sacc += av[(size_t)k] * entry(j, r) / (diag[j] != 0.0 ? diag[j] : 1.0);
+    }
+    sacc = -sacc;
+    out[r] = sacc != 0.0 ? 1.0 / sacc : 1.0;
+  }
+  std::vector<double> dp((size_t)N);
+  for (int i = 0; i < N; ++i) dp[i] = out[(size_t)h->sym_tree.perm[i]];
+  return fc_set_stage_diag(h, slot, dp.data());
+}
+
+// diagonal entry of the pinned dof in the front of the plan node that eliminates it (ndsolver.front_diagonal_slot)
+static int apply_pressure_pin(fc_ctx* h) {
+  if (!h->sym_ready || !h->have_plan) return FC_OK;
+  if (h->pin_dof < 0) return fc_set_front_shifts(h, 0, nullptr, nullptr);
+  const int ip = h->sym_tree.iperm[(size_t)h->pin_dof];
+  const fcsym::Plan& pl = h->sym_plan;
+  for (size_t g = 0; g < pl.node_i0.size(); ++g) {
+    const int64_t i0 = pl.node_i0[g], nf = pl.nodes[g * 7 + 2], ni = pl.nodes[g * 7 + 3];
+    if (ip >= i0 && ip < i0 + ni) {
+      const int64_t slot = pl.nodes[g * 7 + 1] + (ip - i0) * (nf + 1);
+      return fc_set_front_shifts(h, 1, &slot, &h->pin_shift);
+    }
+  }
+  return fc_set_front_shifts(h, 0, nullptr, nullptr);  // eliminated by another rank
+}
+
+int fc_set_pressure_pin(fc_handle h, int32_t dof, double shift) {
+  if (!h || dof >= h->N || (dof >= 0 && dof < 2 * h->nn)) return fail(FC_ERR_INVALID, "fc_set_pressure_pin: the pinned dof must be a pressure dof (or -1)");
+  h->pin_dof = dof;
+  h->pin_shift = shift;
+  return apply_pressure_pin(h);
+}
+
+int fc_get_local_cells(fc_handle h, int32_t* cells) {
+  if (!h || !cells) return fail(FC_ERR_INVALID, "fc_get_local_cells: null argument");
+  if (h->partitioned)
+    std::copy(h->h_cell_list.begin(), h->h_cell_list.end(), cells);
+  else
+    for (int c = 0; c < h->nc; ++c) cells[c] = c;
+  return FC_OK;
+}
+
+int fc_setup_solver(fc_handle h, int slot, int32_t depth, int32_t merge, int32_t truncate, int32_t refine, int32_t check_residual) {
+  if (!h || slot < 0 || slot > 1 || merge < 1 || merge > 4 || depth < 0 || truncate < 0 || refine < 0)
+    return fail(FC_ERR_INVALID, "fc_setup_solver: bad argument");
+  if (!h->slot_ok[slot] || !h->sys[slot].have_lift) return fail(FC_ERR_NOT_READY, "fc_setup_solver: assemble the slot and call fc_apply_bc first");
+  HIPCHK(hipSetDevice(h->device));
+  const int N = h->N;
+  const int world = (h->comm || h->host_xchg) ? h->nranks : 1, rank = world > 1 ? h->rank : 0;
+  int top = 0;
+  while ((1 << top) < world) ++top;
+  if ((1 << top) != world) return fail(FC_ERR_INVALID, "fc_setup_solver: the number of ranks must be a power of two");
+  try {
+    fcsym::Keep keep;
+    if (world > 1) {
+      const std::vector<int>* cum = &h->sym_tree.cum;
+      keep = [cum, rank, top](int k, int n) { return k == 0 || (n >> ((*cum)[k] - top)) == rank; };
+    }
+    if (truncate > 0) {
+      if (world > 1) return fail(FC_ERR_INVALID, "fc_setup_solver: truncated factors need a single-GPU handle");
+      keep = [truncate](int k, int) { return k >= truncate; };
+    }
+    if (!h->sym_ready) {
+      int d = depth;
+      if (d == 0) d = std::max(merge + top, (int)std::ceil(std::log2(std::max(h->nc, 1) / 12.0)));
+      std::vector<unsigned char> skip((size_t)N, 0);
+      for (int k = 0; k < h->n_bc; ++k) skip[(size_t)h->h_bc_dofs[k]] = 1;
+      h->sym_tree = fcsym::build_tree(h->h_cell_dofs, 15, h->h_cent, h->nc, N, d, &skip, merge, top);
+      if (truncate > h->sym_tree.depth) return fail(FC_ERR_INVALID, "fc_setup_solver: truncate exceeds the tree depth");
+      FCCHK(fc_set_permutation(h, h->sym_tree.perm.data()));
+      FCCHK(upload_energy_matrix(h));
+      h->sym_fac = fcsym::layout_factors(h->sym_tree, keep);
+      if (truncate > 0)
+        for (int k = 0; k < truncate; ++k) h->sym_fac.stage_kind[(size_t)h->sym_tree.depth + k] = 2;
+      h->sym_plan = fcsym::factor_plan(h->sym_tree, h->sym_fac, h->h_rowptr, h->h_col, &skip, keep);
+      h->sym_total_nnz = (world > 1 || truncate > 0) ? fcsym::layout_factors(h->sym_tree, nullptr).nnz : h->sym_fac.nnz;
+      const fcsym::Plan& pl = h->sym_plan;
+      const int64_t zero64 = 0;
+      FCCHK(fc_factor_plan(h, (int)(pl.nodes.size() / 7), pl.nodes.data(), (int)pl.level_ptr.size() - 1, pl.level_ptr.data(), pl.front_size,
+                           (int64_t)pl.a_src.size(), pl.a_src.empty() ? &zero64 : pl.a_src.data(), pl.a_dst.empty() ? &zero64 : pl.a_dst.data(),
+                           pl.a_ptr.data(), pl.ext_off.data(), (int64_t)pl.ext_p.size(), pl.ext_p.data(), (int64_t)pl.ap_src.size(),
+                           pl.ap_src.data(), pl.max_slots));
+      h->sym_truncate = truncate;
+      h->sym_ready = true;
+      FCCHK(apply_pressure_pin(h));
+    } else if (truncate != h->sym_truncate) {
+      return fail(FC_ERR_INVALID, "fc_setup_solver: both slots of a handle share one tree: same truncate");
+    }
+    OrderSys& S = h->sys[slot];
+    if (!S.structured) {
+      const fcsym::Tree& t = h->sym_tree;
+      const fcsym::Factors& fac = h->sym_fac;
+      const fcsym::Partition part = fcsym::partition(t, fac, rank, world);
+      if (world > 1 && !h->partitioned)
+        FCCHK(fc_set_partition(h, (int)part.local_cells.size(), part.local_cells.data(), part.rowkind.data(), rank == 0 ? 1 : 0));
+      const int zero32 = 0;
+      const int64_t zero64 = 0;
+      FCCHK(fc_solver_setup(h, slot, h->sym_plan.Ap_rowptr.data(), h->sym_plan.Ap_col.data(), nullptr, (int)part.stage_kind.size(),
+                            part.stage_begin.data(), part.stage_row0.data(), part.stage_nrows.data(), part.stage_kind.data(),
+                            part.seg_ptr.data(), (int64_t)part.seg_val.size(), part.seg_val.empty() ? &zero64 : part.seg_val.data(),
+                            part.seg_col.empty() ? &zero32 : part.seg_col.data(), part.seg_len.empty() ? &zero32 : part.seg_len.data(),
+                            (int64_t)fac.idx.size(), fac.idx.empty() ? &zero32 : fac.idx.data(), std::max<int64_t>(1, fac.n_val), nullptr,
+                            part.ar_stage, part.ar_row0, part.ar_n, part.ar2_stage));
+      int64_t local = 0;
+      for (int v : part.seg_len) local += v;
+      h->sym_local_values[slot] = local;
+      const fcsym::Blocks B = fcsym::down_blocks(t, fac, rank, world);
+      FCCHK(fc_solver_set_blocks(h, slot, (int)B.begin.size(), B.begin.data(), B.count.data(), B.lpr.data(), (int64_t)B.val.size(),
+                                 B.val.empty() ? &zero64 : B.val.data(), B.row0.empty() ? &zero32 : B.row0.data(),
+                                 B.nrows.empty() ? &zero32 : B.nrows.data(), B.i0.empty() ? &zero32 : B.i0.data(),
+                                 B.ni.empty() ? &zero32 : B.ni.data(), B.idx.empty() ? &zero32 : B.idx.data(),
+                                 B.nb.empty() ? &zero32 : B.nb.data(), (int64_t)fac.idx.size(), std::max<int64_t>(1, fac.n_val)));
+      const fcsym::Dag D = fcsym::dag_dependencies(t, fac, rank, world);
+      FCCHK(fc_solver_set_dag(h, slot, (int)(fac.nodes.size() / 7), fac.nodes.data(), D.mine.data(), D.dn_dep.data(), D.up_ptr.data(), D.up_idx.data()));
+    }
+    if (truncate > 0) FCCHK(upload_stage_diag(h, slot));
+  } catch (const std::exception& e) {
+    return fail(FC_ERR_INVALID, std::string("fc_setup_solver: ") + e.what());
+  }
+  FCCHK(fc_refactor(h, slot, nullptr));
+  // end-to-end acceptance of the new factors: one solve with a fixed right-hand side, residual against the matrix itself
+  // (partitioned: a probe solve would be a collective and every step's residual is monitored instead; truncated factors
+  // are a preconditioner: nothing to probe)
+  if (world == 1 && !h->partitioned && truncate == 0) {
+    std::vector<double> b((size_t)N), x((size_t)N);
+    for (int i = 0; i < N; ++i) b[i] = std::cos(0.37 * i + 0.1);
+    if (h->pn_shift > 0)
+      for (int i = 2 * h->nn; i < N; ++i) b[i] = 0.0;  // compatible with the constant-pressure null space of an enclosed flow
+    double info[4];
+    FCCHK(fc_set_solver_options(h, FC_METHOD_REFINE, 0, 1e-10, 1));
+    FCCHK(fc_solve(h, slot, b.data(), x.data(), info));
+    if (!(info[1] < 1e-8)) return fail(FC_ERR_HIP, "fc_setup_solver: the factorisation failed its residual check (" + std::to_string(info[1]) + ")");
+  }
+  return fc_set_solver_options(h, FC_METHOD_REFINE, refine, 1e-10, check_residual);
+}
+
+// ── the symbolic phase on its own, no device involved (tests compare it with flowcontrol_amd/ndsolver.py) ──
+struct fc_sym {
+  std::map<std::string, std::vector<int64_t>> v;
+};
+
+int fc_sym_build(int32_t nv, int32_t ne, int32_t nc, const double* coords, const int32_t* cells, const int32_t* cell_edges, int32_t n_bc,
+                 const int32_t* bc_dofs, int32_t depth, int32_t merge, int32_t world, int32_t rank, int32_t truncate, void** out) {
+  if (!out || !coords || !cells || !cell_edges || nv <= 0 || ne <= 0 || nc <= 0 || merge < 1 || world < 1 || rank < 0 || rank >= world)
+    return fail(FC_ERR_INVALID, "fc_sym_build: bad argument");
+  *out = nullptr;
+  try {
+    const int nn = nv + ne, N = 2 * nn + nv;
+    std::vector<int> cd((size_t)nc * 15);
+    std::vector<double> cent((size_t)nc * 2);
+    for (int c = 0; c < nc; ++c) {
+      for (int k = 0; k < 3; ++k) {
+        const int v = cells[3 * c + k], e = cell_edges[3 * c + k];
+        cd[(size_t)c * 15 + k] = v;
+        cd[(size_t)c * 15 + 3 + k] = nv + e;
+        cd[(size_t)c * 15 + 6 + k] = nn + v;
+        cd[(size_t)c * 15 + 9 + k] = nn + nv + e;
+        cd[(size_t)c * 15 + 12 + k] = 2 * nn + v;
+      }
+      for (int d = 0; d < 2; ++d)
+        cent[2 * (size_t)c + d] = (coords[2 * cells[3 * c] + d] + coords[2 * cells[3 * c + 1] + d] + coords[2 * cells[3 * c + 2] + d]) / 3.0;
+    }
+    // CSR pattern (no pressure-pressure coupling), as fc_create builds it
+    std::vector<uint64_t> keys;
+    keys.reserve((size_t)nc * 216);
+    for (int c = 0; c < nc; ++c)
+      for (int i = 0; i < 15; ++i)
+        for (int j = 0; j < 15; ++j) {
+          if (i >= 12 && j >= 12) continue;
+          keys.push_back(((uint64_t)cd[(size_t)c * 15 + i] << 32) | (uint32_t)cd[(size_t)c * 15 + j]);
+        }
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    std::vector<int> rowptr((size_t)N + 1, 0), col(keys.size());
+    for (size_t k = 0; k < keys.size(); ++k) {
+      rowptr[(keys[k] >> 32) + 1]++;
+      col[k] = (int)(keys[k] & 0xFFFFFFFFu);
+    }
+    for (int r = 0; r < N; ++r) rowptr[r + 1] += rowptr[r];
+    std::vector<unsigned char> skip((size_t)N, 0);
+    for (int k = 0; k < n_bc; ++k) skip[(size_t)bc_dofs[k]] = 1;
+    int top = 0;
+    while ((1 << top) < world) ++top;
+    int d = depth;
+    if (d == 0) d = std::max(merge + top, (int)std::ceil(std::log2(std::max(nc, 1) / 12.0)));
+    fcsym::Tree t = fcsym::build_tree(cd, 15, cent, nc, N, d, &skip, merge, top);
+    fcsym::Keep keep;
+    if (world > 1) keep = [&t, rank, top](int k, int n) { return k == 0 || (n >> (t.cum[k] - top)) == rank; };
+    if (truncate > 0) keep = [truncate](int k, int) { return k >= truncate; };
+    fcsym::Factors fac = fcsym::layout_factors(t, keep);
+    if (truncate > 0)
+      for (int k = 0; k < truncate; ++k) fac.stage_kind[(size_t)t.depth + k] = 2;
+    fcsym::Plan pl = fcsym::factor_plan(t, fac, rowptr, col, &skip, keep);
+    fcsym::Partition part = fcsym::partition(t, fac, rank, world);
+    fcsym::Blocks B = fcsym::down_blocks(t, fac, rank, world);
+    fcsym::Dag D = fcsym::dag_dependencies(t, fac, rank, world);
+    fc_sym* sy = new fc_sym();
+    auto put = [&](const char* name, auto const& vec) { sy->v[name].assign(vec.begin(), vec.end()); };
+    put("perm", t.perm);
+    put("cum", t.cum);
+    put("leaf_of_cell", t.leaf_of_cell);
+    put("idx", fac.idx);
+    put("seg_ptr", fac.seg_ptr);
+    put("seg_val", fac.seg_val);
+    put("seg_col", fac.seg_col);
+    put("seg_len", fac.seg_len);
+    put("stage_begin", fac.stage_begin);
+    put("stage_row0", fac.stage_row0);
+    put("stage_nrows", fac.stage_nrows);
+    put("stage_kind", fac.stage_kind);
+    put("nodes", fac.nodes);
+    sy->v["n_val"] = {fac.n_val};
+    sy->v["nnz"] = {fac.nnz};
+    put("plan_nodes", pl.nodes);
+    put("level_ptr", pl.level_ptr);
+    put("a_src", pl.a_src);
+    put("a_dst", pl.a_dst);
+    put("a_ptr", pl.a_ptr);
+    put("ext_off", pl.ext_off);
+    put("ext_p", pl.ext_p);
+    put("ap_src", pl.ap_src);
+    put("Ap_rowptr", pl.Ap_rowptr);
+    put("Ap_col", pl.Ap_col);
+    sy->v["front_size"] = {pl.front_size};
+    sy->v["max_slots"] = {pl.max_slots};
+    put("part_rowkind", part.rowkind);
+    put("part_local_cells", part.local_cells);
+    put("part_seg_ptr", part.seg_ptr);
+    put("part_seg_val", part.seg_val);
+    put("part_seg_col", part.seg_col);
+    put("part_seg_len", part.seg_len);
+    put("part_stage_begin", part.stage_begin);
+    put("part_stage_row0", part.stage_row0);
+    put("part_stage_nrows", part.stage_nrows);
+    put("part_stage_kind", part.stage_kind);
+    sy->v["part_ar"] = {part.ar_stage, part.ar_row0, part.ar_n, part.ar2_stage, part.root_row0, part.root_nrows};
+    put("blk_begin", B.begin);
+    put("blk_count", B.count);
+    put("blk_lpr", B.lpr);
+    put("blk_val", B.val);
+    put("blk_row0", B.row0);
+    put("blk_nrows", B.nrows);
+    put("blk_i0", B.i0);
+    put("blk_ni", B.ni);
+    put("blk_idx", B.idx);
+    put("blk_nb", B.nb);
+    put("dag_mine", D.mine);
+    put("dag_dn_dep", D.dn_dep);
+    put("dag_up_ptr", D.up_ptr);
+    put("dag_up_idx", D.up_idx);
+    *out = sy;
+  } catch (const std::exception& e) {
+    return fail(FC_ERR_INVALID, std::string("fc_sym_build: ") + e.what());
+  }
+  return FC_OK;
+}
+
+int fc_sym_size(void* sym, const char* name, int64_t* n) {
+  if (!sym || !name || !n) return fail(FC_ERR_INVALID, "fc_sym_size: null argument");
+  const auto& m = static_cast<fc_sym*>(sym)->v;
+  const auto it = m.find(name);
+  if (it == m.end()) return fail(FC_ERR_INVALID, std::string("fc_sym_size: no table named ") + name);
+  *n = (int64_t)it->second.size();
+  return FC_OK;
+}
+
+int fc_sym_get(void* sym, const char* name, int64_t* out) {
+  if (!sym || !name || !out) return fail(FC_ERR_INVALID, "fc_sym_get: null argument");
+  const auto& m = static_cast<fc_sym*>(sym)->v;
+  const auto it = m.find(name);
+  if (it == m.end()) return fail(FC_ERR_INVALID, std::string("fc_sym_get: no table named ") + name);
+  std::copy(it->second.begin(), it->second.end(), out);
+  return FC_OK;
+}
+
+int fc_sym_free(void* sym) {
+  delete static_cast<fc_sym*>(sym);
+  return FC_OK;
+}
+
+int fc_get_permutation(fc_handle h, int32_t* perm) {
+  if (!h || !perm) return fail(FC_ERR_INVALID, "fc_get_permutation: null argument");
+  if (!h->have_perm) return fail(FC_ERR_NOT_READY, "no permutation yet (fc_setup_solver / fc_set_permutation)");
+  std::copy(h->h_perm.begin(), h->h_perm.end(), perm);
+  return FC_OK;
+}
+
+int fc_get_solver_info(fc_handle h, int slot, int64_t* info) {
+  if (!h || slot < 0 || slot > 1 || !info) return fail(FC_ERR_INVALID, "fc_get_solver_info: bad argument");
+  const OrderSys& S = h->sys[slot];
+  info[0] = S.f_nnz;                   // factor values stored on this rank
+  info[1] = h->sym_ready ? h->sym_total_nnz : S.f_nnz;  // ... of the whole tree (all ranks, no truncation)
+  info[2] = h->sym_ready ? h->sym_local_values[slot] : 0;  // factor values this rank sweeps per solve
+  info[3] = (int64_t)S.stages.size();
+  info[4] = h->sym_ready ? h->sym_tree.depth : 0;
+  info[5] = S.ar_n;
+  info[6] = S.ar_stage;
+  info[7] = S.ar2_stage;
+  info[8] = h->partitioned ? h->ncl : h->nc;
+  info[9] = h->sym_ready ? h->sym_truncate : 0;
+  return FC_OK;
+}
+
+int fc_get_rowkind(fc_handle h, uint8_t* rowkind) {
+  if (!h || !rowkind) return fail(FC_ERR_INVALID, "fc_get_rowkind: null argument");
+  if (h->h_rowkind.empty())
+    std::fill(rowkind, rowkind + h->N, (uint8_t)1);
+  else
+    std::copy(h->h_rowkind.begin(), h->h_rowkind.end(), rowkind);
   return FC_OK;
 }
 
@@ -2602,6 +3068,7 @@ int fc_set_partition(fc_handle h, int32_t n_local_cells, const int32_t* local_ce
   }
   HIPCHK(hipStreamSynchronize(h->stream));
   if (h->have_perm) FCCHK(refresh_permuted(h));
+  FCCHK(upload_sensors(h));
   return FC_OK;
 }
 

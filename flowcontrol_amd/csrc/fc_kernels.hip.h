@@ -547,10 +547,11 @@ __global__ void fc_front_scatter(int64_t n, const int64_t* __restrict__ src, con
   if (k < n) fronts[dst[k]] = vals[src[k]];
 }
 // fronts[slot[k]] += value[k]: diagonal shifts applied after the scatter (pressure pin of enclosed flows)
+// (multi-GPU: slots in [skip0, skip1) — the root front, which is summed over the ranks — are left to the lead rank)
 __global__ void fc_front_shift(int n, const int64_t* __restrict__ slot, const double* __restrict__ value,
-                               double* __restrict__ fronts) {
+                               double* __restrict__ fronts, int64_t skip0, int64_t skip1) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < n) fronts[slot[k]] += value[k];
+  if (k < n && !(slot[k] >= skip0 && slot[k] < skip1)) fronts[slot[k]] += value[k];
 }
 __global__ void fc_gather64(int64_t n, const int64_t* __restrict__ src, const double* __restrict__ vals,
                             double* __restrict__ out) {
@@ -1102,6 +1103,16 @@ __global__ __launch_bounds__(256) void fc_bicg_phase(int phase, int nblk, const 
     ks[KS_ITERS] = 0.0;
     ks[KS_STATE] = d0 > 0.0 ? 0.0 : 1.0;  // b = 0 -> x = 0
     cP[0] = 1.0, cP[1] = 0.0, cP[2] = 0.0;  // first iteration: p = r
+    return;
+  }
+  if (phase == 5) {  // restart after a breakdown, rh = r = b - A x: d0 = r.r, d1 = rh.r
+    ks[KS_RNORM2] = d0;
+    ks[KS_RHO] = d1;
+    ks[KS_RHO_OLD] = 1.0;
+    ks[KS_ALPHA] = 1.0;
+    ks[KS_OMEGA] = 1.0;
+    ks[KS_STATE] = sqrt(d0) <= rtol * sqrt(ks[KS_BNORM2]) ? 1.0 : 0.0;
+    cP[0] = 1.0, cP[1] = 0.0, cP[2] = 0.0;  // p = r
     return;
   }
   if (st == 1.0 || st < 0.0) return;

@@ -48,7 +48,8 @@ class DeviceSolver:
         check(self.lib.fc_get_pattern(self._h, self.rowptr, self.colidx))
         self.n_act = 0
         self.n_sens = 0
-        self.tree: ndsolver.NDTree | None = None
+        self._tree: ndsolver.NDTree | None = None
+        self.perm: np.ndarray | None = None  # elimination ordering (new position -> W dof)
         self.factor_nnz: dict[int, int] = {}
         self.rank, self.world = 0, 1
         self.use_block_kernel = os.environ.get("FC_BLOCK_KERNEL", "1") != "0"  # LDS-tiled down-sweeps
@@ -56,6 +57,10 @@ class DeviceSolver:
         self._sensor_rows: list | None = None
         # numeric factorisation on the device (fc_refactor); FC_HOST_FACTOR=1 keeps the numpy multifrontal
         self.device_factor = os.environ.get("FC_HOST_FACTOR", "0") != "1"
+        # the symbolic phase (tree, factor layout, elimination plan, sweep tables) runs inside the library
+        # (fc_setup_solver); FC_PY_SYMBOLIC=1 keeps the numpy one of :mod:`ndsolver` that it mirrors
+        self.py_symbolic = os.environ.get("FC_PY_SYMBOLIC", "0") == "1" or not self.device_factor
+        self._tree_args = None
         self._fac_struct: ndsolver.BlockFactors | None = None
         self._plan: ndsolver.FactorPlan | None = None
         self._structured: set[int] = set()
@@ -82,6 +87,8 @@ class DeviceSolver:
         # FC_FORCE_COMM=1 (test aid): build a 1-rank RCCL communicator and run the partitioned code
         # path (cell list, row kinds, in-stream all-reduces) on a single GPU
         self._force_comm = world == 1 and os.environ.get("FC_FORCE_COMM", "0") == "1"
+        if self._force_comm:
+            self.py_symbolic = True  # the one-rank partition is patched together on the host
         if world == 1 and not self._force_comm:
             return
         if host_allreduce is not None:
@@ -148,9 +155,9 @@ class DeviceSolver:
         bc_dofs = _i32(bc_dofs)
         profiles = _f64(profiles).reshape(len(bc_dofs), -1) if len(bc_dofs) else np.zeros((0, np.shape(profiles)[-1] if np.ndim(profiles) > 1 else 0))
         self.n_act = profiles.shape[1]
-        if self.tree is not None and not np.array_equal(np.sort(bc_dofs), np.sort(getattr(self, "bc_dofs", bc_dofs))):
+        if self.perm is not None and not np.array_equal(np.sort(bc_dofs), np.sort(getattr(self, "bc_dofs", bc_dofs))):
             # the elimination tree parks the Dirichlet dofs in the leaves: a different set needs a new tree
-            self.tree, self._fac_struct, self._plan = None, None, None
+            self._tree, self.perm, self._fac_struct, self._plan = None, None, None, None
             self._structured.clear()
         self.bc_dofs = bc_dofs
         check(self.lib.fc_set_bc(self._h, len(bc_dofs), ptr(bc_dofs), self.n_act, ptr(np.ascontiguousarray(profiles))))
@@ -164,8 +171,8 @@ class DeviceSolver:
 
     def set_sensors(self, rows: list[tuple[np.ndarray, np.ndarray]]) -> None:
         self._sensor_rows = rows
-        if self.part is not None:
-            # partitioned: every rank evaluates the part of each sensor row that lives on dofs it owns
+        if self.part is not None and self.py_symbolic:
+            # partitioned (the library does this itself on the fc_setup_solver path): every rank evaluates the part of each sensor row that lives on dofs it owns
             # (root dofs: lead rank only); the partial readings are summed by the step's all-reduce
             k = self.part.rowkind
             keep = [(k[np.asarray(i)] == 1) | ((k[np.asarray(i)] == 2) & (self.rank == 0)) for i, _ in rows]
@@ -203,7 +210,10 @@ class DeviceSolver:
         sub-domain solves and their couplings to the separators above — memory shrinks towards O(nnz) as d grows); the
         Schur complement on the top d levels is replaced by a diagonal estimate.  The slot is then a PRECONDITIONER:
         solves and time steps go through GMRES / BiCGStab (``set_solver_options(method=...)``)."""
-        if self.tree is None:
+        if not self.py_symbolic:
+            self._setup_solver_native(slot, depth, refine, check_residual, merge, truncate)
+            return
+        if self._tree is None:
             th = self.th
             top = int(np.log2(self.world)) if self.world > 1 else 0
             if depth is None:
@@ -211,10 +221,12 @@ class DeviceSolver:
             skip = np.zeros(self.N, dtype=bool)
             skip[self.bc_dofs] = True
             self._skip = skip
-            self.tree = ndsolver.build_tree(th.cell_dofs, th.mesh.cell_centroids(), self.N, depth, skip, merge=merge, top_bits=top)
-            check(self.lib.fc_set_permutation(self._h, _i32(self.tree.perm)))
+            self._tree = ndsolver.build_tree(th.cell_dofs, th.mesh.cell_centroids(), self.N, depth, skip, merge=merge, top_bits=top)
+            self.perm = self._tree.perm
+            self.depth = self._tree.depth
+            check(self.lib.fc_set_permutation(self._h, _i32(self.perm)))
             self._upload_energy_matrix()
-        t = self.tree
+        t = self._tree
         # partitioned handles: every rank holds the whole (small) matrix but lays out and factorises its own sub-tree
         # and the root only; the root front is summed over the ranks inside fc_refactor
         on_device = bool(self.device_factor)
@@ -306,6 +318,49 @@ class DeviceSolver:
         self.n_stages = len(part.stage_kind)
         self.set_solver_options(refine, check_residual)
 
+    def _setup_solver_native(self, slot, depth, refine, check_residual, merge, truncate) -> None:
+        """``fc_setup_solver``: tree, factor layout, elimination plan, sweep tables, numeric factorisation and its
+        acceptance solve all happen inside the library; only sizes come back."""
+        check(self.lib.fc_setup_solver(self._h, slot, int(depth or 0), int(merge), int(truncate), int(refine), int(bool(check_residual))))
+        info = np.zeros(10, dtype=np.int64)
+        check(self.lib.fc_get_solver_info(self._h, slot, info))
+        self._n_factor_values, self.total_factor_nnz, self.local_factor_nnz = int(info[0]), int(info[1]), int(info[2])
+        self.factor_nnz[slot] = int(info[0])
+        self.n_stages, self.depth = int(info[3]), int(info[4])
+        self._truncate = int(truncate)
+        if self.perm is None:
+            self.perm = np.empty(self.N, dtype=np.int32)
+            check(self.lib.fc_get_permutation(self._h, self.perm))
+            self._tree_args = (int(depth or 0), int(merge))
+        if self.world > 1 and self.part is None:
+            from types import SimpleNamespace
+
+            kind = np.empty(self.N, dtype=np.uint8)
+            check(self.lib.fc_get_rowkind(self._h, kind))
+            cells = np.empty(int(info[8]), dtype=np.int32)
+            check(self.lib.fc_get_local_cells(self._h, cells))
+            self.part = SimpleNamespace(rowkind=kind, local_cells=cells, ar_n=int(info[5]), ar_stage=int(info[6]), ar2_stage=int(info[7]))
+        ms = C.c_double()
+        check(self.lib.fc_get_refactor_ms(self._h, slot, C.byref(ms)))
+        self.refactor_ms[slot] = ms.value
+        self._structured.add(slot)
+        self._solver_opts = (int(refine), bool(check_residual), "refine", 1e-10)
+
+    @property
+    def tree(self) -> "ndsolver.NDTree | None":
+        """The elimination tree as :mod:`ndsolver` builds it (tests and tools only: on the default path the library owns
+        the tree and this rebuilds the identical one on the host on first use)."""
+        if self._tree is None and self.perm is not None:
+            depth, merge = self._tree_args
+            top = int(np.log2(self.world)) if self.world > 1 else 0
+            if depth == 0:
+                depth = max(merge + top, int(np.ceil(np.log2(max(self.th.nc, 1) / 12.0))))
+            skip = np.zeros(self.N, dtype=bool)
+            skip[self.bc_dofs] = True
+            self._tree = ndsolver.build_tree(self.th.cell_dofs, self.th.mesh.cell_centroids(), self.N, depth, skip, merge=merge, top_bits=top)
+            assert np.array_equal(self._tree.perm, self.perm)
+        return self._tree
+
     def set_pressure_pin(self, dof: int | None, shift: float = 1.0) -> None:
         """Enclosed flows (velocity prescribed on the whole boundary): the monolithic matrix is singular, the
         pressure being defined up to a constant.  A positive shift on the diagonal of ONE pressure dof inside
@@ -317,14 +372,16 @@ class DeviceSolver:
         if dof != self._pin:
             self._pin, self._pin_shift = dof, float(shift)
             self._probe = None
-            if self._plan is not None:
+            if not self.py_symbolic:
+                check(self.lib.fc_set_pressure_pin(self._h, -1 if dof is None else dof, float(shift)))
+            elif self._plan is not None:
                 self._upload_pin()
 
     def _upload_pin(self) -> None:
         if self._pin is None:
             check(self.lib.fc_set_front_shifts(self._h, 0, np.zeros(1, np.int64), np.zeros(1)))
         else:
-            slot = ndsolver.front_diagonal_slot(self._plan, self.tree, self._pin)
+            slot = ndsolver.front_diagonal_slot(self._plan, self._tree, self._pin)
             if slot < 0:  # the pinned dof is eliminated by another rank
                 check(self.lib.fc_set_front_shifts(self._h, 0, np.zeros(1, np.int64), np.zeros(1)))
             else:
@@ -345,7 +402,7 @@ class DeviceSolver:
             if self._pin is not None:
                 self._probe[2 * self.nn :] = 0.0  # compatible with the constant-pressure null space
         if getattr(self, "_truncate", 0):
-            check(self.lib.fc_set_stage_diag(self._h, slot, _f64(ndsolver.schur_diagonal_scaling(self.matrix(slot), self.nn)[self.tree.perm])))
+            check(self.lib.fc_set_stage_diag(self._h, slot, _f64(ndsolver.schur_diagonal_scaling(self.matrix(slot), self.nn)[self.perm])))
             return ms.value  # a preconditioner: nothing to probe
         if self.world > 1 or getattr(self, "_force_comm", False):
             return ms.value  # a probe solve would be a collective; every step's residual is monitored instead
@@ -387,7 +444,7 @@ class DeviceSolver:
         nn2 = 2 * self.nn
         M = sp.block_diag([M[:nn2, :nn2], sp.csr_matrix((self.N - nn2, self.N - nn2))]).tocsr()
         M.eliminate_zeros()
-        p = self.tree.perm
+        p = self.perm
         Mp = M[p][:, p].tocsr()
         Mp.sort_indices()
         check(self.lib.fc_set_energy_matrix(self._h, _i32(Mp.indptr), _i32(Mp.indices), _f64(Mp.data)))
@@ -420,7 +477,7 @@ class DeviceSolver:
         if Cmat is None:
             check(self.lib.fc_set_rhs_operator(self._h, slot, None, None, None))
             return
-        Cp = Cmat.tocsr()[self.tree.perm].tocsr()
+        Cp = Cmat.tocsr()[self.perm].tocsr()
         Cp.eliminate_zeros()
         Cp.sort_indices()
         check(self.lib.fc_set_rhs_operator(self._h, slot, ptr(_i32(Cp.indptr)), ptr(_i32(Cp.indices)), ptr(_f64(Cp.data))))

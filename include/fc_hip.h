@@ -133,6 +133,36 @@ int fc_solver_set_blocks(fc_handle h, int slot, int32_t n_stages, const int64_t*
                          const int64_t* blk_val, const int32_t* blk_row0, const int32_t* blk_nrows,
                          const int32_t* blk_i0, const int32_t* blk_ni, const int32_t* blk_idx,
                          const int32_t* blk_nb, int64_t n_idx, int64_t n_val);
+/* THE solver setup in one call (what LUSolver.set_operator + the first solve cost the reference, flowsolver.py:697,729):
+ * symbolic analysis inside the library from the mesh the handle holds (element-based nested-dissection tree of
+ * `depth` bisections — 0: leaves of ~12 cells — fused `merge` at a time; on a handle with a communicator / host exchange
+ * the root is nranks-ary and this rank lays out its own sub-tree and the root), permutation, segment tables, workgroup
+ * tiles, factorisation plan, task dependencies, then the numeric factorisation of the slot's current matrix on the
+ * device and a probe solve (error if its relative residual is not < 1e-8).  truncate = d > 0: only the tree levels >= d
+ * are factorised (memory-lean preconditioner; use FC_METHOD_GMRES / FC_METHOD_BICGSTAB afterwards).  A later call for the
+ * same slot redoes only the numeric phase.  Needs: fc_set_bc, fc_assemble_matrix(slot), fc_apply_bc(slot).  The
+ * array-level entry points below (fc_set_permutation ... fc_solver_set_dag) remain for tests and for callers that bring
+ * their own analysis (flowcontrol_amd/ndsolver.py is the readable specification of the in-library one). */
+int fc_setup_solver(fc_handle h, int slot, int32_t depth, int32_t merge, int32_t truncate, int32_t refine, int32_t check_residual);
+int fc_get_permutation(fc_handle h, int32_t* perm /* [N] new -> old */);
+/* the symbolic phase on its own, no device involved: every table fc_setup_solver derives, by name, widened to int64
+ * (tests compare them with flowcontrol_amd/ndsolver.py entry by entry) */
+int fc_sym_build(int32_t nv, int32_t ne, int32_t nc, const double* coords, const int32_t* cells, const int32_t* cell_edges,
+                 int32_t n_bc, const int32_t* bc_dofs, int32_t depth, int32_t merge, int32_t world, int32_t rank, int32_t truncate,
+                 void** out);
+int fc_sym_size(void* sym, const char* name, int64_t* n);
+int fc_sym_get(void* sym, const char* name, int64_t* out);
+int fc_sym_free(void* sym);
+/* info[10]: factor values stored on this rank, of the whole tree, swept by this rank per solve; stages; tree depth;
+ * exchanged rows, the two exchange stages; cells assembled by this rank; truncate */
+int fc_get_solver_info(fc_handle h, int slot, int64_t* info /* [10] */);
+/* enclosed flows (velocity prescribed on the whole boundary: pressure defined up to a constant): a positive shift on the
+ * diagonal of ONE pressure dof inside the factorisation of fc_setup_solver (dof = -1: none); cf. fc_set_front_shifts */
+int fc_set_pressure_pin(fc_handle h, int32_t dof, double shift);
+/* device milliseconds of the slot's last numeric factorisation (fc_refactor, also inside fc_setup_solver) */
+int fc_get_refactor_ms(fc_handle h, int slot, double* ms);
+int fc_get_local_cells(fc_handle h, int32_t* cells /* [info[8] of fc_get_solver_info] */);
+int fc_get_rowkind(fc_handle h, uint8_t* rowkind /* [N]: 0 other rank, 1 owned, 2 root (all 1 on a single-GPU handle) */);
 /* One-launch factor apply (replaces the 2*depth+1 level launches of LUSolver.solve, flowsolver.py:729, by ONE
  * grid whose workgroups wait for each other through per-node arrival counters; fc_dag.hip.h).  `nodes` has 7
  * int64 per tree node that owns dofs, elimination order: level, index in level, first row i0, rows ni, boundary
