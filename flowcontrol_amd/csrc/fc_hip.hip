@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -2436,17 +2437,30 @@ int fc_sym_build(int32_t nv, int32_t ne, int32_t nc, const double* coords, const
     while ((1 << top) < world) ++top;
     int d = depth;
     if (d == 0) d = std::max(merge + top, (int)std::ceil(std::log2(std::max(nc, 1) / 12.0)));
+    const bool timing = getenv("FC_SYM_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto lap = [&](const char* what, std::chrono::steady_clock::time_point& t0) {
+      if (timing) fprintf(stderr, "[fc_sym] %-18s %.3f s\n", what, std::chrono::duration<double>(now() - t0).count());
+      t0 = now();
+    };
+    auto t0 = now();
     fcsym::Tree t = fcsym::build_tree(cd, 15, cent, nc, N, d, &skip, merge, top);
+    lap("build_tree", t0);
     fcsym::Keep keep;
     if (world > 1) keep = [&t, rank, top](int k, int n) { return k == 0 || (n >> (t.cum[k] - top)) == rank; };
     if (truncate > 0) keep = [truncate](int k, int) { return k >= truncate; };
     fcsym::Factors fac = fcsym::layout_factors(t, keep);
+    lap("layout_factors", t0);
     if (truncate > 0)
       for (int k = 0; k < truncate; ++k) fac.stage_kind[(size_t)t.depth + k] = 2;
     fcsym::Plan pl = fcsym::factor_plan(t, fac, rowptr, col, &skip, keep);
+    lap("factor_plan", t0);
     fcsym::Partition part = fcsym::partition(t, fac, rank, world);
+    lap("partition", t0);
     fcsym::Blocks B = fcsym::down_blocks(t, fac, rank, world);
+    lap("down_blocks", t0);
     fcsym::Dag D = fcsym::dag_dependencies(t, fac, rank, world);
+    lap("dag_dependencies", t0);
     fc_sym* sy = new fc_sym();
     auto put = [&](const char* name, auto const& vec) { sy->v[name].assign(vec.begin(), vec.end()); };
     put("perm", t.perm);

@@ -11,9 +11,39 @@
 #include <map>
 #include <numeric>
 #include <stdexcept>
+#include <exception>
+#include <thread>
 #include <vector>
 
 namespace fcsym {
+
+// index work over independent rows / nodes on a few host threads (FC_SYM_THREADS, default min(16, cores))
+template <class F>
+inline void parallel_for(int64_t n, F&& fn) {
+  int nt = 0;
+  if (const char* e = getenv("FC_SYM_THREADS")) nt = atoi(e);
+  if (nt <= 0) nt = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+  nt = (int)std::min<int64_t>(nt, std::max<int64_t>(1, n / 1024));
+  if (nt <= 1) {
+    for (int64_t i = 0; i < n; ++i) fn(i);
+    return;
+  }
+  std::vector<std::thread> th;
+  std::vector<std::exception_ptr> err((size_t)nt);
+  for (int w = 0; w < nt; ++w)
+    th.emplace_back([&, w] {
+      try {
+        const int64_t a = n * w / nt, b = n * (w + 1) / nt;
+        for (int64_t i = a; i < b; ++i) fn(i);
+      } catch (...) {
+        err[(size_t)w] = std::current_exception();
+      }
+    });
+  for (auto& t : th) t.join();
+  for (auto& e : err)
+    if (e) std::rethrow_exception(e);
+}
+
 
 struct Tree {
   int depth = 0;       // tree levels 0 .. depth (leaves at `depth`)
@@ -292,19 +322,17 @@ inline Plan factor_plan(const Tree& t, const Factors& fac, const std::vector<int
   const int64_t nnz = p.Ap_rowptr[N];
   p.Ap_col.resize((size_t)nnz);
   p.ap_src.resize((size_t)nnz);
-  {
+  parallel_for(N, [&](int64_t i) {
+    const int r = t.perm[(size_t)i];
     std::vector<std::pair<int, int64_t>> row;
-    for (int i = 0; i < N; ++i) {
-      const int r = t.perm[i];
-      row.clear();
-      for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) row.emplace_back(t.iperm[col[k]], (int64_t)k);
-      std::sort(row.begin(), row.end());
-      for (size_t q = 0; q < row.size(); ++q) {
-        p.Ap_col[(size_t)p.Ap_rowptr[i] + q] = row[q].first;
-        p.ap_src[(size_t)p.Ap_rowptr[i] + q] = row[q].second;
-      }
+    row.reserve((size_t)(rowptr[r + 1] - rowptr[r]));
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) row.emplace_back(t.iperm[col[k]], (int64_t)k);
+    std::sort(row.begin(), row.end());
+    for (size_t q = 0; q < row.size(); ++q) {
+      p.Ap_col[(size_t)p.Ap_rowptr[(size_t)i] + q] = row[q].first;
+      p.ap_src[(size_t)p.Ap_rowptr[(size_t)i] + q] = row[q].second;
     }
-  }
+  });
   // kept tree nodes in elimination order
   std::vector<int64_t> lv, nn_, i0s, nis, nbs;
   for (int k = K; k >= 0; --k)
@@ -335,43 +363,49 @@ inline Plan factor_plan(const Tree& t, const Factors& fac, const std::vector<int
     sk.resize(N);
     for (int i = 0; i < N; ++i) sk[i] = (*skip)[t.perm[i]];
   }
-  struct Ent {
-    int own;
-    int r, c;
-    int64_t src;
+  // counting sort by owner node (stable: row-major order inside a node, as the specification's argsort(kind="stable"))
+  auto owner_of = [&](int i, int k) -> int {
+    const int c = p.Ap_col[(size_t)k];
+    if (skip && (sk[(size_t)i] || sk[(size_t)c]) && i != c) return -1;
+    return owner[(size_t)std::min(i, c)];  // < 0: a front another rank builds
   };
-  std::vector<Ent> ents;
-  ents.reserve((size_t)nnz);
+  std::vector<int64_t> beg(G + 1, 0);
   for (int i = 0; i < N; ++i)
     for (int k = p.Ap_rowptr[i]; k < p.Ap_rowptr[i + 1]; ++k) {
-      const int c = p.Ap_col[k];
-      if (skip && (sk[i] || sk[c]) && i != c) continue;
-      const int own = owner[(size_t)std::min(i, c)];
-      if (own < 0) continue;  // a front another rank builds
-      ents.push_back({own, i, c, p.ap_src[k]});
+      const int own = owner_of(i, k);
+      if (own >= 0) beg[(size_t)own + 1]++;
     }
-  std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.own < b.own; });
-  std::vector<int64_t> beg(G + 1, 0);
-  for (const Ent& e : ents) beg[(size_t)e.own + 1]++;
   for (size_t g = 0; g < G; ++g) beg[g + 1] += beg[g];
-  p.a_src.resize(ents.size());
-  p.a_dst.resize(ents.size());
-  for (size_t g = 0; g < G; ++g) {
-    const int64_t i0 = i0s[g], ni = nis[g], nb = nbs[g], nf = ni + nb;
-    const std::vector<int>& B = t.bnd[(size_t)lv[g]][(size_t)nn_[g]];
-    for (int64_t q = beg[g]; q < beg[g + 1]; ++q) {
-      const Ent& e = ents[(size_t)q];
-      auto pos = [&](int d) -> int64_t {
-        if (d < i0 + ni) return d - i0;
-        const auto it = std::lower_bound(B.begin(), B.end(), d);
-        if (it == B.end() || *it != d) throw std::runtime_error("matrix entry outside the front: tree/boundary sets inconsistent");
-        return ni + (it - B.begin());
-      };
-      p.a_src[(size_t)q] = e.src;
-      p.a_dst[(size_t)q] = front_off[g] + pos(e.r) * nf + pos(e.c);
-    }
-    (void)nb;
+  const int64_t n_ent = beg[G];
+  struct Ent {
+    int r, c;
+  };
+  std::vector<Ent> ents((size_t)n_ent);
+  p.a_src.resize((size_t)n_ent);
+  p.a_dst.resize((size_t)n_ent);
+  {
+    std::vector<int64_t> fill(beg.begin(), beg.end() - 1);
+    for (int i = 0; i < N; ++i)
+      for (int k = p.Ap_rowptr[i]; k < p.Ap_rowptr[i + 1]; ++k) {
+        const int own = owner_of(i, k);
+        if (own < 0) continue;
+        const int64_t q = fill[(size_t)own]++;
+        ents[(size_t)q] = {i, p.Ap_col[(size_t)k]};
+        p.a_src[(size_t)q] = p.ap_src[(size_t)k];
+      }
   }
+  parallel_for((int64_t)G, [&](int64_t g) {
+    const int64_t i0 = i0s[(size_t)g], ni = nis[(size_t)g], nf = ni + nbs[(size_t)g];
+    const std::vector<int>& B = t.bnd[(size_t)lv[(size_t)g]][(size_t)nn_[(size_t)g]];
+    auto pos = [&](int d) -> int64_t {
+      if (d < i0 + ni) return d - i0;
+      const auto it = std::lower_bound(B.begin(), B.end(), d);
+      if (it == B.end() || *it != d) throw std::runtime_error("matrix entry outside the front: tree/boundary sets inconsistent");
+      return ni + (it - B.begin());
+    };
+    for (int64_t q = beg[(size_t)g]; q < beg[(size_t)g + 1]; ++q)
+      p.a_dst[(size_t)q] = front_off[(size_t)g] + pos(ents[(size_t)q].r) * nf + pos(ents[(size_t)q].c);
+  });
   // per level ranges (nodes are level-sorted, deepest first)
   p.level_ptr.assign((size_t)K + 2, 0);
   for (int li = 0; li <= K + 1; ++li) {

@@ -1,8 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun): rocprofv3 kernel stats + HBM traffic counters for bench.py.
 # Counters go in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950), with few
-# steps (counter collection serialises every kernel) and the numpy factorisation for the setup
-# (FC_HOST_FACTOR=1: the setup kernels are not what is measured).
+# steps (counter collection serialises every kernel).
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profile
@@ -13,7 +12,6 @@ trap 'kill $HB 2>/dev/null' EXIT
 ARGS="--warmup 20 --no-cpu-baseline --no-large-spmv"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python bench.py --steps ${STEPS:-1000} $ARGS > "$OUT/bench_stats.json" 2> "$OUT/stats.err"
 echo "stats pass done"
-export FC_HOST_FACTOR=1
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python bench.py --steps 100 $ARGS > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err"
 echo "fetch pass done"
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python bench.py --steps 100 $ARGS > "$OUT/bench_write.json" 2> "$OUT/write.err"
