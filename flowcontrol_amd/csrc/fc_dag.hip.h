@@ -61,16 +61,6 @@ struct __attribute__((aligned(16))) FcDagDep {
 #define FC_DAG_WAVES_PER_SIMD 3  // register budget for 3 resident workgroups of 256 threads per CU (the launch keeps it to that)
 #endif
 
-typedef unsigned long long fc_u64;
-
-__device__ __forceinline__ double fc_ld_sc1(const double* p) {
-  const fc_u64 v = __hip_atomic_load(reinterpret_cast<const fc_u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return __longlong_as_double((long long)v);
-}
-__device__ __forceinline__ void fc_st_sc1(double* p, double x) {
-  __hip_atomic_store(reinterpret_cast<fc_u64*>(p), (fc_u64)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // wave 0 only: wait until every dependency's counters have reached  epoch x target  (mod 2^32).
 // 16 lanes per dependency (one per shard), four dependencies per pass.
 __device__ __forceinline__ bool fc_dag_wait(const FcDagDep* __restrict__ deps, int dep0, int ndep, const unsigned* cnt,

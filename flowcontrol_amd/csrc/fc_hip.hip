@@ -178,6 +178,9 @@ struct fc_ctx {
   DevBuf<double> bcprof, fprof;
   bool have_force = false;
   DevBuf<int> s_rowptr, s_idx;
+  DevBuf<int> s_idxp;        // sensor dofs as positions in the sweep buffer's x half (N + permuted index): fused final of fc_tail
+  bool have_sidxp = false;
+  DevBuf<unsigned> fin_cnt;  // arrival counters of the fused final (self-resetting)
   DevBuf<double> s_w;
   // time scheme
   double dt = 0.0;
@@ -736,12 +739,33 @@ int launch_tail(fc_ctx* h, OrderSys& S, int compute_energy, double* d_y, double*
   const int reps = std::max(1, nblocks(h->N, 32 * 2048));  // <= ~2048 + ~500 partials per array for fc_final
   const int g_rows = nblocks(h->N, 32 * reps), g_cells = (compute_energy && ncl > 0) ? nblocks(ncl, 32 * reps) : 0;
   const int g = g_rows + g_cells;
+  // FC_FUSED_FINAL=1 (single GPU): the last workgroup to arrive does fc_final's work inside this launch.  Measured equal
+  // to the separate launch (24.7 vs 24.2 us for tail + final on O1, identical results): the last arriver's serial chain
+  // (sc1 loads of the partials, sensor rows, PCIe publish) is what fc_final costs, the boundary itself is ~1.5 us
+  static const bool fuse_final = [] {
+    const char* e = std::getenv("FC_FUSED_FINAL");
+    return e && e[0] == '1';
+  }();
+  FcFin fin = {};
+  const bool fused = fuse_final && !part && (h->n_sens == 0 || h->have_sidxp);
+  if (fused) {
+    constexpr int kGroup = 32;
+    const int n_groups = nblocks(g, kGroup);
+    const size_t need = 32 * ((size_t)n_groups + 1);
+    if (h->fin_cnt.n < need) {
+      FCCHK(h->fin_cnt.alloc(std::max(need, (size_t)32 * 4096)));
+      FCCHK(h->fin_cnt.zero(h->stream));
+    }
+    fin = FcFin{h->fin_cnt.p, kGroup, n_groups, h->n_sens, h->s_rowptr.p, h->s_idxp.p, h->s_w.p, d_y, d_E, d_r, d_flag_out, d_seq, seq, step_id};
+  }
   hipLaunchKernelGGL(fc_tail, dim3(g), dim3(256), 0, h->stream, h->N, 2 * h->nn, h->perm.p, h->buf.p + h->N, h->b.p,
                      res ? S.Ap_rowptr.p : nullptr, S.Ap_col.p, S.Ap_val.p, g_rows, reps, h->nc, g_cells > 0 ? h->cn.p : nullptr,
                      h->geom.p, h->iperm.p, part ? h->rowkind_p.p : nullptr, part ? h->cell_list.p : nullptr, ncl, h->up.p,
-                     h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p, h->partial.p, h->dag_err.p);
+                     h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p, h->partial.p, h->dag_err.p, fin);
   const double* e_part = g_cells > 0 ? h->partial.p + 2 * (size_t)g : nullptr;
-  if (!part) {
+  if (fused) {
+    // nothing more to launch
+  } else if (!part) {
     hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, g, e_part, d_E, res ? g : 0, res ? h->partial.p : nullptr, d_r,
                        h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p, h->up.p, d_y, h->flag.p, d_flag_out, d_seq, seq, h->dag_err.p, step_id);
   } else {
@@ -1431,6 +1455,14 @@ static int upload_sensors(fc_ctx* h) {
   FCCHK(h->s_rowptr.upload(rp, h->stream));
   FCCHK(h->s_idx.upload(idx, h->stream));
   FCCHK(h->s_w.upload(w, h->stream));
+  h->have_sidxp = false;
+  if (h->have_perm) {
+    std::vector<int> ip((size_t)h->N), idxp(idx.size());
+    for (int i = 0; i < h->N; ++i) ip[(size_t)h->h_perm[i]] = i;
+    for (size_t k = 0; k < idx.size(); ++k) idxp[k] = h->N + ip[(size_t)idx[k]];
+    FCCHK(h->s_idxp.upload(idxp, h->stream));
+    h->have_sidxp = true;
+  }
   HIPCHK(hipStreamSynchronize(h->stream));
   return FC_OK;
 }
@@ -1505,6 +1537,7 @@ int fc_set_permutation(fc_handle h, const int32_t* perm) {
   h->have_perm = true;
   h->have_mp = false;
   for (int o = 0; o < 2; ++o) h->sys[o].ready = h->sys[o].structured = false;
+  FCCHK(upload_sensors(h));  // sensor positions in the permuted numbering
   return refresh_permuted(h);
 }
 

@@ -703,6 +703,17 @@ __global__ __launch_bounds__(256) void fc_finish(int N, int nn2, const int* __re
   }
 }
 
+// agent-scope relaxed atomic accesses (sc1: served at the memory-side coherence point, no L2 write-back or invalidate
+// involved): how workgroups of ONE launch on different XCDs hand data to each other (fc_tail's last arriver, fc_nd_dag)
+typedef unsigned long long fc_u64;
+__device__ __forceinline__ double fc_ld_sc1(const double* p) {
+  const fc_u64 v = __hip_atomic_load(reinterpret_cast<const fc_u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __longlong_as_double((long long)v);
+}
+__device__ __forceinline__ void fc_st_sc1(double* p, double x) {
+  __hip_atomic_store(reinterpret_cast<fc_u64*>(p), (fc_u64)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // The step record (y[n_sens], E, |r|^2, |b|^2, flag) may live in host-mapped memory that the host polls
 // instead of synchronising the stream.  ONE thread writes the whole record, then two checksums over the bit
 // patterns of every word and of the sequence number (an XOR, and a position-weighted sum modulo 2^64 with odd
@@ -748,16 +759,16 @@ __device__ inline void fc_publish(const double* ysrc, int n_sens, double E, doub
 // sensor.py:96-98,166-197) and publishes everything to the (host-mapped) record with its checksums
 // (fc_publish: no fence, the host validates what it reads), so the host can poll it instead of
 // synchronising the stream.  Fixed summation order => reproducible.
-__global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restrict__ e_partial,
-                                                double* __restrict__ E_out, int n_r,
-                                                const double* __restrict__ r_partial,
-                                                double* __restrict__ r_out, int n_sens,
-                                                const int* __restrict__ s_rowptr,
-                                                const int* __restrict__ s_idx,
-                                                const double* __restrict__ s_w,
-                                                const double* __restrict__ up, double* __restrict__ y,
-                                                const int* __restrict__ flag, double* __restrict__ flag_out,
-                                                double* __restrict__ seq_out, double seq, int* err, int step_id) {
+// SC1: the partials were written by other workgroups of the SAME launch (fc_tail's last arriver) and are read at
+// the coherence point; the summation order is the same either way.
+template <bool SC1>
+__device__ __forceinline__ void fc_final_body(int n_e, const double* __restrict__ e_partial, double* __restrict__ E_out, int n_r,
+                                              const double* __restrict__ r_partial, double* __restrict__ r_out, int n_sens,
+                                              const int* __restrict__ s_rowptr, const int* __restrict__ s_idx,
+                                              const double* __restrict__ s_w, const double* __restrict__ up, double* __restrict__ y,
+                                              const int* __restrict__ flag, double* __restrict__ flag_out,
+                                              double* __restrict__ seq_out, double seq, int* err, int step_id) {
+  auto ld = [](const double* q) -> double { return SC1 ? fc_ld_sc1(q) : *q; };
   // flag word of the record: bit 0 = non-finite velocity, + 1024 when the one-launch factor apply gave up
   // (err[0]; the first step that sees it leaves its id in err[1]) -- partitioned runs sum the word over the ranks
   __shared__ double red[3][256];
@@ -769,9 +780,9 @@ __global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restric
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int i = t + 256 * u;
-    pe[u] = (e_partial && i < n_e) ? e_partial[i] : 0.0;
-    pr[u] = (r_partial && i < n_r) ? r_partial[i] : 0.0;
-    pb[u] = (r_partial && i < n_r) ? r_partial[n_r + i] : 0.0;
+    pe[u] = (e_partial && i < n_e) ? ld(e_partial + i) : 0.0;
+    pr[u] = (r_partial && i < n_r) ? ld(r_partial + i) : 0.0;
+    pb[u] = (r_partial && i < n_r) ? ld(r_partial + n_r + i) : 0.0;
   }
   // sensors: one wave per row, waves take rows round-robin; results parked in LDS for the publisher
   __shared__ double ysh[64];
@@ -791,11 +802,11 @@ __global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restric
     a2 += pb[u];
   }
   if (e_partial)
-    for (int i = t + 256 * U; i < n_e; i += 256) a0 += e_partial[i];
+    for (int i = t + 256 * U; i < n_e; i += 256) a0 += ld(e_partial + i);
   if (r_partial)
     for (int i = t + 256 * U; i < n_r; i += 256) {
-      a1 += r_partial[i];
-      a2 += r_partial[n_r + i];
+      a1 += ld(r_partial + i);
+      a2 += ld(r_partial + n_r + i);
     }
   red[0][t] = a0;
   red[1][t] = a1;
@@ -810,7 +821,7 @@ __global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restric
     __syncthreads();
   }
   if (t == 0) {
-    double fl = flag ? (double)(flag[0] & 1) : 0.0;
+    double fl = flag ? (double)((SC1 ? __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : flag[0]) & 1) : 0.0;
     if (err && err[0]) {
       fl += 1024.0;
       if (err[1] == 0) err[1] = step_id;
@@ -820,26 +831,70 @@ __global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restric
   }
 }
 
+__global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restrict__ e_partial,
+                                                double* __restrict__ E_out, int n_r,
+                                                const double* __restrict__ r_partial,
+                                                double* __restrict__ r_out, int n_sens,
+                                                const int* __restrict__ s_rowptr,
+                                                const int* __restrict__ s_idx,
+                                                const double* __restrict__ s_w,
+                                                const double* __restrict__ up, double* __restrict__ y,
+                                                const int* __restrict__ flag, double* __restrict__ flag_out,
+                                                double* __restrict__ seq_out, double seq, int* err, int step_id) {
+  fc_final_body<false>(n_e, e_partial, E_out, n_r, r_partial, r_out, n_sens, s_rowptr, s_idx, s_w, up, y, flag, flag_out, seq_out, seq,
+                       err, step_id);
+}
+
+// what the LAST workgroup of a fused fc_tail does instead of a separate fc_final launch (enabled: cnt != nullptr)
+struct FcFin {
+  unsigned* cnt;         // arrival counters: group g at cnt[32 g] (one 128-byte line each), the top counter at cnt[32 n_groups]
+  int group, n_groups;   // workgroups per group; groups
+  int n_sens;
+  const int* s_rowptr;
+  const int* s_idxp;     // sensor dofs as positions in the sweep buffer (N + permuted index: its x half)
+  const double* s_w;
+  double* y;
+  double* E_out;
+  double* r_out;
+  double* flag_out;
+  double* seq_out;
+  double seq;
+  int step_id;
+};
+
 // ---------------------------------------------------------------------------------------------
 // Fused tail of a single-GPU step (residual monitor + state shift + energy in ONE launch, fc_final
 // follows).  Row workgroups: 8 lanes per permuted row evaluate r_i = b_i - (A x)_i (flowsolver.py:729's
 // solve, checked), lane 0 scatters/shifts the dof.  Cell workgroups (appended to the grid): the energy
 // integral of the new velocity, element by element.  Every workgroup leaves (sum r^2 | sum b^2 | sum e)
 // in `partial` (three arrays of gridDim.x) for fc_final.
-// (Folding fc_final in as well, "last workgroup to arrive reduces", was measured: the agent-scope
-// release each workgroup then needs writes back its XCD's L2 and costs 10x what the launch saves.)
+// (Folding fc_final in as well, "last workgroup to arrive reduces": with an agent-scope release per workgroup it cost
+// 10x what the launch saves; with sc1 partials + drained two-level arrival counters (FcFin below, FC_FUSED_FINAL=1) it
+// costs exactly what the separate launch costs.  Kept opt-in.)
 __global__ __launch_bounds__(256) void fc_tail(
     int N, int nn2, const int* __restrict__ perm, const double* __restrict__ x, const double* __restrict__ b,
     const int* __restrict__ a_rowptr, const int* __restrict__ a_col, const double* __restrict__ a_val,
     int n_row_blocks, int reps, int nc, const int* __restrict__ cn, const double* __restrict__ geom, const int* __restrict__ iperm,
     const unsigned char* __restrict__ rowkind, const int* __restrict__ cell_list, int ncl,
     double* __restrict__ up, double* __restrict__ u_n, double* __restrict__ u_nn, double* __restrict__ p_n,
-    int* __restrict__ flag, double* __restrict__ partial, const int* __restrict__ err) {
-  if (err && err[0]) return;  // the factor apply gave up (fc_nd_dag): leave the state as it is, the host redoes the step
+    int* __restrict__ flag, double* __restrict__ partial, int* __restrict__ err, FcFin fin) {
+  if (err && err[0]) {
+    // the factor apply gave up (fc_nd_dag): leave the state as it is, the host redoes the step; a fused tail still owes
+    // the host its record (flag word + 1024)
+    if (fin.cnt && blockIdx.x == 0 && threadIdx.x == 0) {
+      if (err[1] == 0) err[1] = fin.step_id;
+      double none[64];
+      for (int k = 0; k < 64; ++k) none[k] = 0.0;
+      fc_publish(none, fin.n_sens, 0.0, 0.0, 0.0, (double)(flag[0] & 1) + 1024.0, fin.y, fin.E_out, fin.r_out, fin.flag_out, fin.seq_out,
+                 fin.seq);
+    }
+    return;
+  }
   constexpr int LANES = 8, RPB = 256 / LANES;
   const int t = threadIdx.x, lane = t % LANES;
   const int G = gridDim.x;
   double r2 = 0.0, b2 = 0.0, e = 0.0;
+  bool bad = false;
   if ((int)blockIdx.x < n_row_blocks) {
     // rows: residual monitor, scatter to the W layout, state shift (`reps` row groups per workgroup keep
     // the number of partials that fc_final folds alone <= ~2000 on large meshes)
@@ -871,7 +926,6 @@ __global__ __launch_bounds__(256) void fc_tail(
     }
 #pragma unroll
     for (int off = LANES / 2; off > 0; off >>= 1) sa += __shfl_down(sa, off, LANES);
-    bool bad = false;
     if (kind != 0 && lane == 0) {
       const double v = x[i];
       if (a_rowptr && kind == 1) {
@@ -883,12 +937,11 @@ __global__ __launch_bounds__(256) void fc_tail(
       if (r < nn2) {
         u_nn[r] = u_n[r];
         u_n[r] = v;
-        bad = !isfinite(v);
+        bad |= !isfinite(v);
       } else {
         p_n[r - nn2] = v;
       }
     }
-    if (bad) atomicOr(flag, 1);
     }
   } else if (cn) {
     // cells: perturbation energy  ∫|u|^2  of the NEW velocity (utils_flowsolver.py:195-203 / flowsolver.py:827-829),
@@ -928,11 +981,46 @@ __global__ __launch_bounds__(256) void fc_tail(
     }
     __syncthreads();
   }
-  if (t == 0) {
-    partial[blockIdx.x] = red[0][0];
-    partial[G + blockIdx.x] = red[1][0];
-    partial[2 * G + blockIdx.x] = red[2][0];
+  const int any_bad = __syncthreads_or(bad ? 1 : 0);
+  if (!fin.cnt) {
+    if (t == 0) {
+      if (any_bad) atomicOr(flag, 1);
+      partial[blockIdx.x] = red[0][0];
+      partial[G + blockIdx.x] = red[1][0];
+      partial[2 * G + blockIdx.x] = red[2][0];
+    }
+    return;
   }
+  // fused final: partials and the flag go to the coherence point (sc1), are drained, then the workgroup arrives on its
+  // group's counter and the group's last arriver on the top counter (two levels: ~12 ns per same-address atomic would
+  // serialise thousands of arrivals on one word).  The last arriver of all folds the partials in fc_final's fixed order,
+  // evaluates the sensors from the sweep buffer (complete before this launch) and publishes; counters reset themselves.
+  __shared__ int last;
+  if (t == 0) {
+    if (any_bad) atomicOr(flag, 1);
+    fc_st_sc1(partial + blockIdx.x, red[0][0]);
+    fc_st_sc1(partial + G + blockIdx.x, red[1][0]);
+    fc_st_sc1(partial + 2 * G + blockIdx.x, red[2][0]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int grp = blockIdx.x / fin.group;
+    const int gsz = (grp + 1) * fin.group <= G ? fin.group : G - grp * fin.group;
+    int l = 0;
+    unsigned* c = fin.cnt + 32 * (size_t)grp;
+    if (__hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)gsz - 1u) {
+      __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned* top = fin.cnt + 32 * (size_t)fin.n_groups;
+      if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)fin.n_groups - 1u) {
+        __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        l = 1;
+      }
+    }
+    last = l;
+  }
+  __syncthreads();
+  if (!last) return;
+  const bool res = a_rowptr != nullptr;
+  fc_final_body<true>(G, cn ? partial + 2 * (size_t)G : nullptr, fin.E_out, res ? G : 0, res ? partial : nullptr, fin.r_out, fin.n_sens,
+                      fin.s_rowptr, fin.s_idxp, fin.s_w, x - N, fin.y, flag, fin.flag_out, fin.seq_out, fin.seq, err, fin.step_id);
 }
 
 // multi-GPU: energy share of this rank's cells, 1/2 ∫ |u|^2 (degree-4 integrand: exact with the 7-pt rule);
