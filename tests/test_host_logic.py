@@ -351,6 +351,78 @@ def test_hdf5_writer_round_trip_and_xdmf_checkpoints(tmp_path):
     assert m.num_cells == th.nc and m.num_vertices == th.nv
 
 
+def _emulated_dolfin_read_checkpoint(xdmf, name, counter, coords_o, cells_o):
+    """What ``dolfin.XDMFFile.read_checkpoint`` does (HDF5Utility::set_local_vector_values), on a P2-vector space built
+    here from the ORIGINAL mesh arrays with dolfin's conventions (cells with ascending vertex ids, local dofs
+    v0 v1 v2 e0 e1 e2 per component, edge i opposite vertex i) and a global numbering of its own (interleaved
+    components, edges numbered by np.unique) — nothing of flowcontrol_amd's numbering is used.
+    Returns (x, dof coordinates, dof component)."""
+    import xml.etree.ElementTree as ET
+
+    from flowcontrol_amd.fem.hdf5_min import MinimalHDF5
+
+    cells_o = np.sort(np.asarray(cells_o, dtype=np.int64), axis=1)
+    nv = coords_o.shape[0]
+    pairs = np.stack([cells_o[:, [1, 2]], cells_o[:, [0, 2]], cells_o[:, [0, 1]]], axis=1)  # local edge i: opposite vertex i
+    uniq, inv = np.unique(pairs.reshape(-1, 2), axis=0, return_inverse=True)
+    node = np.hstack([cells_o, nv + inv.reshape(-1, 3)])  # (nc, 6) scalar P2 nodes, reader's numbering
+    xy = np.vstack([coords_o, 0.5 * (coords_o[uniq[:, 0]] + coords_o[uniq[:, 1]])])
+    dofmap = np.hstack([2 * node, 2 * node + 1])  # (nc, 12)
+    grid = [g for g in ET.parse(xdmf).getroot().iter("Grid") if g.get("Name") == f"{name}_{counter}"][0]
+    att = [a for a in grid.findall("Attribute") if a.get("ItemType") == "FiniteElementFunction"][0]
+    assert (att.get("ElementFamily"), att.get("ElementDegree"), att.get("ElementCell")) == ("CG", "2", "triangle")
+    data = []
+    for d in att.findall("DataItem"):
+        f, _, path = d.text.strip().partition(":")
+        data.append(np.asarray(MinimalHDF5(Path(xdmf).parent / f).read(path)).reshape(-1))
+    cell_dofs, vector, x_cell_dofs, cells = data
+    x = np.full(2 * xy.shape[0], np.nan)
+    for r, cell in enumerate(cells):
+        for j in range(12):
+            x[dofmap[cell, j]] = vector[cell_dofs[x_cell_dofs[r] + j]]
+    return x, np.repeat(xy, 2, axis=0), np.tile([0, 1], xy.shape[0])
+
+
+@pytest.mark.parametrize("mesh", ["square", "O1"])
+def test_checkpoints_follow_dolfins_write_checkpoint_layout(mesh, tmp_path, golden_dir):
+    """A velocity field written by write_xdmf, read back the way dolfin's read_checkpoint reads it — into a space with a
+    different dof numbering built from the original mesh arrays — lands on the right nodes; files with another dof
+    numbering and cell order (what dolfin itself would write) are read correctly by read_xdmf."""
+    from flowcontrol_amd.fem.hdf5_min import read_hdf5_tree, write_hdf5
+    from flowcontrol_amd.io import read_xdmf, write_xdmf
+
+    if mesh == "square":
+        base = Mesh.unit_square(5, 4, reorder=False)
+        coords_o, cells_o = base.coords.copy(), base.cells.copy()
+    else:
+        z = np.load(golden_dir / "meshes" / "O1.npz")
+        coords_o, cells_o = z["coords"], z["cells"]
+    th = TaylorHood(Mesh.from_arrays(coords_o, cells_o, reorder=True))  # Morton-ordered cells, renumbered vertices
+    f = lambda xy, c: np.sin(1.3 * xy[:, 0] + 0.2 * c) * np.cos(0.7 * xy[:, 1]) + 0.1 * c * xy[:, 0]  # noqa: E731
+    u = Function(th.V, np.r_[f(th.node_coords, 0), f(th.node_coords, 1)])
+    path = tmp_path / "U.xdmf"
+    write_xdmf(path, Function(th.V), "U", 0.0)
+    write_xdmf(path, u, "U", 0.5, append=True)
+    x, xy, comp = _emulated_dolfin_read_checkpoint(path, "U", 1, coords_o, cells_o)
+    assert not np.isnan(x).any()
+    assert np.array_equal(x[comp == 0], f(xy[comp == 0], 0)) and np.array_equal(x[comp == 1], f(xy[comp == 1], 1))
+    # the other direction: rewrite frame 1 with a shuffled dof numbering and reversed cell rows, as a foreign writer may
+    rng = np.random.default_rng(1)
+    tree0 = read_hdf5_tree(tmp_path / "U.h5")["U"]["U_0"]
+    tree1 = read_hdf5_tree(tmp_path / "U.1.h5")["U"]["U_1"]
+    perm = rng.permutation(2 * th.nn)  # new dof id of old dof i
+    vec = np.empty(2 * th.nn)
+    vec[perm] = tree1["vector"].reshape(-1)
+    cd = perm[tree0["cell_dofs"].reshape(th.nc, 12)][::-1]
+    tree0.update(cell_dofs=cd.reshape(-1, 1), cells=tree0["cells"][::-1].copy())
+    tree1.update(vector=vec.reshape(-1, 1))
+    write_hdf5(tmp_path / "U.h5", {"U": {"U_0": tree0}})
+    write_hdf5(tmp_path / "U.1.h5", {"U": {"U_1": tree1}})
+    v = Function(th.V)
+    assert read_xdmf(path, v, "U", 1) == 0.5
+    assert np.array_equal(v.vector().array(), u.vector().array())
+
+
 def test_factor_plan_replays_the_multifrontal_factorisation():
     """The symbolic plan handed to the device (fc_factor_plan) + its host replay reproduce the numpy
     multifrontal factors bit for bit, and the structure-only layout equals the numeric one."""
@@ -431,8 +503,9 @@ def test_pressure_pin_only_for_enclosed_flows():
 
 
 def test_checkpoint_series_roundtrip(tmp_path):
-    """io.write_xdmf / read_xdmf: a series is an .xdmf index + one mesh file + one small HDF5 file per frame;
-    appending does not touch earlier frames; frames come back bit-exact by counter (−1 = last)."""
+    """io.write_xdmf / read_xdmf: a series is an .xdmf index + <stem>.h5 (frame 0, mesh, cell tables: dolfin's file
+    name) + one small HDF5 file per later frame; appending does not touch earlier frames; frames come back bit-exact
+    by counter (−1 = last)."""
     from flowcontrol_amd.fem.mesh import Mesh
     from flowcontrol_amd.fem.spaces import Function, FunctionSpace, TaylorHood
     from flowcontrol_amd.io import read_xdmf, write_xdmf
@@ -444,17 +517,23 @@ def test_checkpoint_series_roundtrip(tmp_path):
     path = tmp_path / "U_restart0,000.xdmf"
     for k, v in enumerate(frames):
         assert write_xdmf(path, Function(V, v), "U", time_step=0.25 * k, append=k > 0) == k
-    first = (tmp_path / "U_restart0,000.0.h5").read_bytes()
+    first = (tmp_path / "U_restart0,000.h5").read_bytes()
     assert sorted(p.name for p in tmp_path.iterdir()) == sorted(
-        ["U_restart0,000.xdmf", "U_restart0,000.h5"] + [f"U_restart0,000.{k}.h5" for k in range(4)])
+        ["U_restart0,000.xdmf", "U_restart0,000.h5"] + [f"U_restart0,000.{k}.h5" for k in range(1, 4)])
     f = Function(V)
     for k, v in enumerate(frames):
         assert read_xdmf(path, f, "U", counter=k) == 0.25 * k
         assert np.array_equal(f.vector().get_local(), v)
     assert read_xdmf(path, f, "U") == 0.75 and np.array_equal(f.vector().get_local(), frames[-1])
-    assert (tmp_path / "U_restart0,000.0.h5").read_bytes() == first  # untouched by the appends
+    assert (tmp_path / "U_restart0,000.h5").read_bytes() == first  # untouched by the appends
     xml = path.read_text()
-    assert xml.count("<Time Value=") == 4 and "U_restart0,000.3.h5:/U/vertex_values" in xml and "U_restart0,000.h5:/Mesh/mesh/topology" in xml
+    assert xml.count("<Time Value=") == 4 and "U_restart0,000.3.h5:/U/U_3/vector" in xml and "U_restart0,000.h5:/U/U_0/mesh/topology" in xml
+    assert xml.count('ItemType="FiniteElementFunction"') == 4 and "U_restart0,000.h5:/U/U_0/cell_dofs" in xml
+    # pressure and mixed fields take the same road
+    pq = Function(P, rng.standard_normal(th.nv))
+    write_xdmf(tmp_path / "P0.xdmf", pq, "P0")
+    back = Function(P)
+    assert read_xdmf(tmp_path / "P0.xdmf", back, "P0") == 0.0 and np.array_equal(back.vector().get_local(), pq.vector().get_local())
     with pytest.raises(FileNotFoundError):
         read_xdmf(path, f, "U", counter=4)
     with pytest.raises(ValueError):
