@@ -2406,9 +2406,9 @@ int fc_setup_solver(fc_handle h, int slot, int32_t depth, int32_t merge, int32_t
   }
   FCCHK(fc_refactor(h, slot, nullptr));
   // end-to-end acceptance of the new factors: one solve with a fixed right-hand side, residual against the matrix itself
-  // (partitioned: a probe solve would be a collective and every step's residual is monitored instead; truncated factors
-  // are a preconditioner: nothing to probe)
-  if (world == 1 && !h->partitioned && truncate == 0) {
+  // (partitioned: the probe is a collective, every rank calls fc_setup_solver; truncated factors are a preconditioner:
+  // nothing to probe)
+  if (truncate == 0 && (world == 1 ? !h->partitioned : exchanges(h))) {
     std::vector<double> b((size_t)N), x((size_t)N);
     for (int i = 0; i < N; ++i) b[i] = std::cos(0.37 * i + 0.1);
     if (h->pn_shift > 0)
@@ -2906,6 +2906,14 @@ static int solve_once(fc_handle h, int slot, const double* b, double* x, double*
   const int N = h->N, g = nblocks(N, 256);
   HIPCHK(hipMemcpyAsync(h->tmpN.p, b, (size_t)N * sizeof(double), hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(fc_gather_perm, dim3(g), dim3(256), 0, h->stream, N, h->perm.p, h->tmpN.p, h->b.p);
+  const bool dist = h->partitioned && exchanges(h);
+  if (dist) {
+    // every rank was handed the whole right-hand side: keep the rows this rank accounts for (its own, and the root's on
+    // the lead rank -- the apply sums the root rows over the ranks), solve, then merge the ranks' parts of the solution
+    if (h->max_iter > 0 && h->method == FC_METHOD_REFINE)
+      return fail(FC_ERR_INVALID, "fc_solve: iterative refinement is not available on a partitioned (multi-GPU) handle");
+    hipLaunchKernelGGL(fc_mask_rows, dim3(g), dim3(256), 0, h->stream, N, h->rowkind_p.p, h->lead ? 1 : 0, h->b.p);
+  }
   hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, h->buf.p);
   if (h->method == FC_METHOD_BICGSTAB || h->method == FC_METHOD_GMRES) {
     if (h->partitioned) return fail(FC_ERR_INVALID, "fc_solve: the Krylov drivers are not available on a partitioned handle");
@@ -2928,6 +2936,12 @@ static int solve_once(fc_handle h, int slot, const double* b, double* x, double*
   int nrp = 0;
   FCCHK(solve_permuted(h, S, &xs, &dx, &nrp));
   if (nrp > 0) hipLaunchKernelGGL(fc_reduce_final, dim3(2), dim3(256), 0, h->stream, nrp, h->partial.p, 1.0, h->scal.p + 1);
+  if (dist) {
+    // x: this rank's rows and the (replicated) root rows are valid; |r|^2, |b|^2: this rank's rows
+    hipLaunchKernelGGL(fc_mask_rows, dim3(g), dim3(256), 0, h->stream, N, h->rowkind_p.p, h->lead ? 1 : 0, h->buf.p + N);
+    FCCHK(exchange(h, h->buf.p + N, (size_t)N));
+    if (nrp > 0) FCCHK(exchange(h, h->scal.p + 1, 2));
+  }
   hipLaunchKernelGGL(fc_scatter_perm, dim3(g), dim3(256), 0, h->stream, N, h->perm.p, xs, dx, h->tmpN2.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(x, h->tmpN2.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -3128,6 +3142,14 @@ int fc_comm_unique_id(char* out128) {
   return FC_OK;
 }
 
+// the handle becomes (or stops being) one rank of several: the elimination tree gets another root, so whatever was set up
+// for the old role is void
+static void forget_solver_structure(fc_ctx* h) {
+  h->sym_ready = false;
+  h->have_plan = false;
+  for (int o = 0; o < 2; ++o) h->sys[o].ready = h->sys[o].structured = h->sys[o].dag_ready = false;
+}
+
 int fc_comm_init(fc_handle h, int nranks, int rank, const char* id128) {
   if (!h || nranks < 1 || rank < 0 || rank >= nranks || !id128) return fail(FC_ERR_INVALID, "fc_comm_init: bad argument");
   FCCHK(rccl_load());
@@ -3139,6 +3161,7 @@ int fc_comm_init(fc_handle h, int nranks, int rank, const char* id128) {
   h->comm = comm;
   h->nranks = nranks;
   h->rank = rank;
+  forget_solver_structure(h);
   return FC_OK;
 }
 
@@ -3149,6 +3172,7 @@ int fc_set_host_exchange(fc_handle h, int nranks, int rank, fc_exchange_fn fn, v
   h->host_xchg_user = user;
   h->nranks = nranks;
   h->rank = rank;
+  forget_solver_structure(h);
   return FC_OK;
 }
 

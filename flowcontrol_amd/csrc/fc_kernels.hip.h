@@ -1063,6 +1063,15 @@ __global__ __launch_bounds__(256) void fc_energy_elem(int nc, int nn, const int*
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
+// multi-GPU: v[i] = 0 on the rows this rank does not account for (another rank's rows; the root's rows unless lead)
+__global__ void fc_mask_rows(int n, const unsigned char* __restrict__ rowkind, int lead, double* __restrict__ v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const int kind = rowkind[i];
+    if (!(kind == 1 || (kind == 2 && lead))) v[i] = 0.0;
+  }
+}
+
 // multi-GPU: after the all-reduce of the step tail [y(64) | E | r2 | b2 | ... | flag@72] publish it
 __global__ void fc_publish_tail(const double* __restrict__ tail, double* __restrict__ y, int n_sens,
                                 double* __restrict__ E, double* __restrict__ r, double* __restrict__ flag_out,

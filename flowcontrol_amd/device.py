@@ -91,6 +91,9 @@ class DeviceSolver:
             self.py_symbolic = True  # the one-rank partition is patched together on the host
         if world == 1 and not self._force_comm:
             return
+        # another root for the elimination tree: whatever was set up for the single-GPU role is void
+        self._tree, self.perm, self._fac_struct, self._plan, self.part = None, None, None, None, None
+        self._structured.clear()
         if host_allreduce is not None:
             # exchange through the host (fc_set_host_exchange): no RCCL communicator; ``host_allreduce(array)`` sums a
             # float64 array over the ranks in place.  The launch sequence is the one of the RCCL path.
@@ -404,8 +407,7 @@ class DeviceSolver:
         if getattr(self, "_truncate", 0):
             check(self.lib.fc_set_stage_diag(self._h, slot, _f64(ndsolver.schur_diagonal_scaling(self.matrix(slot), self.nn)[self.perm])))
             return ms.value  # a preconditioner: nothing to probe
-        if self.world > 1 or getattr(self, "_force_comm", False):
-            return ms.value  # a probe solve would be a collective; every step's residual is monitored instead
+        # (on a partitioned handle the probe is a collective: every rank refactorises, every rank probes)
         opts = getattr(self, "_solver_opts", (0, True, "refine", 1e-10))
         check(self.lib.fc_set_solver_options(self._h, _lib.METHOD_REFINE, 0, 1e-10, 1))
         _, info = self.solve(slot, self._probe)

@@ -4,8 +4,10 @@ API mirror of the reference's ``src/flowcontrol/steadystate.py``.  Every iterati
 device: the operator is assembled by the HIP element loop (``fc_assemble_matrix``), factorised by
 the device multifrontal numeric phase (``fc_refactor``, the structure being laid out once) and
 applied with the same sweep kernels as a time step; the host only forms norms and updates the
-iterate.  Partitioned (multi-GPU) handles and ``FC_HOST_FACTOR=1`` keep the earlier host path for
-these set-up solves (SuperLU with the nested-dissection ordering).
+iterate.  On a partitioned (multi-GPU) handle every rank assembles the whole (small) operator, factorises its own
+sub-tree and the root, and the solves are collectives (``fc_solve`` merges the ranks' parts); before time stepping
+starts the handle is not partitioned yet and every rank simply computes the base flow on its own GPU.
+``FC_HOST_FACTOR=1`` keeps the earlier host path (SuperLU with the nested-dissection ordering).
 """
 
 from __future__ import annotations
@@ -72,7 +74,7 @@ class SteadyStateSolver:
 
     def _on_device(self) -> bool:
         dev = self._device()
-        return bool(dev.device_factor) and dev.world == 1 and not getattr(dev, "_force_comm", False)
+        return bool(dev.device_factor)
 
     def _solve_increment(self, coeff, r: np.ndarray, dofs: np.ndarray) -> np.ndarray:
         """δ with  A δ = r  on the free rows and δ = 0 on the Dirichlet dofs (``r[dofs]`` is 0)."""
@@ -91,7 +93,8 @@ class SteadyStateSolver:
             self._bc_set = True
         self._assemble_on_device(coeff, SLOT_BDF1)
         dev.apply_bc(SLOT_BDF1)
-        if self.lag_factors and self._factors_age is not None and self._krylov_failures < 2:
+        partitioned = dev.world > 1 or getattr(dev, "_force_comm", False)  # collective solves: no Krylov, no refinement there
+        if self.lag_factors and not partitioned and self._factors_age is not None and self._krylov_failures < 2:
             # keep the factors of an earlier iterate as preconditioner: BiCGStab on the new operator costs a few
             # sweeps, a numeric factorisation tens of milliseconds (the reference refactorises every iteration)
             dev.update_operator(SLOT_BDF1)
@@ -110,7 +113,7 @@ class SteadyStateSolver:
                 self._krylov_failures += 1  # twice in a row (e.g. a singular enclosed-flow system near convergence): stop trying
             finally:
                 dev.set_solver_options(0, True)
-        dev.setup_solver(SLOT_BDF1, refine=2)  # numeric factorisation on the device (first call: + structure)
+        dev.setup_solver(SLOT_BDF1, refine=0 if partitioned else 2)  # numeric factorisation on the device (first call: + structure)
         self._factors_age = 0
         self.krylov_iterations.append(0)
         x, info = dev.solve(SLOT_BDF1, r)

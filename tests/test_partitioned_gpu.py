@@ -106,6 +106,48 @@ def test_partitioned_ranks_reproduce_the_serial_run(world):
         assert max(out[f"stored{r}"] for r in range(world)) < 1.35 * out["total_values"] / world
 
 
+def _steady_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from flowcontrol_amd._lib import SLOT_BDF1
+        from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver
+
+        fs = CylinderFlowSolver.make_default(Re=100, path_out=tempfile.mkdtemp(), num_steps=2)
+        dev = fs.th.device()
+        fs._join_process_group(dev)  # partition BEFORE the base flow: its solves are collectives then
+        assert dev.world == world
+        fs.compute_steady_state(method="picard", max_iter=3, tol=1e-7, u_ctrl=[0.0, 0.0])
+        fs.compute_steady_state(method="newton", max_iter=25, u_ctrl=[0.0, 0.0], initial_guess=fs.fields.UP0)
+        assert dev.part is not None and dev.part.ar_n > 0  # the solves did run on the partitioned handle
+        # a collective solve with the last Jacobian's factors: every rank passes the whole right-hand side and gets the whole
+        # solution; info[1] is the residual over all ranks' rows
+        b = np.cos(0.37 * np.arange(dev.N) + 0.1)
+        x, info = dev.solve(SLOT_BDF1, b)
+        A = dev.matrix(SLOT_BDF1)
+        if rank == 0:
+            out["UP0"] = fs.fields.UP0.vector().get_local()
+            out["solve_res"] = float(np.linalg.norm(A @ x - b) / np.linalg.norm(b))
+            out["info_res"] = float(info[1])
+        fs.th.release_device()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_base_flow_on_a_partitioned_handle():
+    """Picard -> Newton with every linear solve a collective over two ranks (assembly replicated, factorisation and
+    sweeps partitioned, fc_solve merging the ranks' parts): the base flow of the golden fixture."""
+    g = np.load(ROOT / "tests" / "golden" / "cylinder_O1.npz")
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_steady_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+        nn2 = int(np.count_nonzero(np.isfinite(g["UP0"])))  # whole vector
+        rel = np.linalg.norm(out["UP0"][:nn2] - g["UP0"][:nn2]) / np.linalg.norm(g["UP0"][:nn2])
+        assert rel < 1e-9, rel
+        assert out["solve_res"] < 1e-10 and out["info_res"] < 1e-10
+
+
 def test_rccl_plumbing_on_the_refined_mesh(monkeypatch):
     """The same single-rank RCCL communicator on BASELINE config 4's mesh (222 962 dofs), with the one-launch factor
     apply cut at the two exchange stages: 6 actuated steps against the oracle's series."""
