@@ -219,6 +219,7 @@ struct fc_ctx {
   std::vector<unsigned char> h_rowkind;  // original numbering: 0 other rank, 1 owned, 2 shared root
   DevBuf<int> cell_list;
   DevBuf<unsigned char> rowkind_p;  // permuted numbering
+  DevBuf<unsigned char> rootmask_p;  // 1 on the root's rows (permuted numbering): row mask of the partitioned Krylov mat-vec
   void* comm = nullptr;             // ncclComm_t
   int nranks = 1, rank = 0;
   // exchange staged through the host when the ranks have no RCCL communicator (CPU collectives, ranks sharing a GPU)
@@ -642,6 +643,8 @@ int refresh_permuted(fc_ctx* h) {
     std::vector<unsigned char> rk(N);
     for (int i = 0; i < N; ++i) rk[i] = h->h_rowkind[h->h_perm[i]];
     FCCHK(h->rowkind_p.upload(rk.data(), rk.size(), h->stream));
+    for (int i = 0; i < N; ++i) rk[i] = rk[i] == 2 ? 1 : 0;
+    FCCHK(h->rootmask_p.upload(rk.data(), rk.size(), h->stream));
   }
   for (int o = 0; o < 2; ++o) {
     OrderSys& S = h->sys[o];
@@ -805,29 +808,57 @@ int bicgstab_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
   double* sh = h->tmpN2.p;
   double* ks = h->ks.p;
   const double mean = (double)S.Ap_nnz / std::max(1, N);
-  auto dots = [&](int phase, const double* a, const double* b_, const double* c, const double* d) {
-    hipLaunchKernelGGL(fc_dots2, dim3(gd), dim3(256), 0, h->stream, N, a, b_, c, d, h->partial.p);
-    hipLaunchKernelGGL(fc_bicg_phase, dim3(1), dim3(256), 0, h->stream, phase, gd, h->partial.p, ks, h->rtol, 1, 1);
+  // Partitioned handles: every vector lives in the "distributed" form -- this rank's rows valid, the root's rows replicated
+  // on all ranks, other ranks' rows zero.  Dot products run over the rows a rank accounts for and are summed over the ranks;
+  // a mat-vec evaluates the rank's rows in full and the root's rows over the columns the rank accounts for, then sums the
+  // root block over the ranks; the preconditioner is the partitioned factor apply (its own two exchanges).
+  const bool dist = h->partitioned && exchanges(h);
+  const unsigned char* kinds = dist ? h->rowkind_p.p : nullptr;
+  const int lead = h->lead ? 1 : 0;
+  auto dots = [&](int phase, const double* a, const double* b_, const double* c, const double* d) -> int {
+    hipLaunchKernelGGL(fc_dots2, dim3(gd), dim3(256), 0, h->stream, N, a, b_, c, d, h->partial.p, kinds, lead);
+    if (!dist) {
+      hipLaunchKernelGGL(fc_bicg_phase, dim3(1), dim3(256), 0, h->stream, phase, gd, h->partial.p, ks, h->rtol, 1, 1);
+      return FC_OK;
+    }
+    hipLaunchKernelGGL(fc_bicg_phase, dim3(1), dim3(256), 0, h->stream, phase, gd, h->partial.p, ks, h->rtol, 1, 0);
+    FCCHK(exchange(h, ks + KS_D0, 2));
+    hipLaunchKernelGGL(fc_bicg_phase, dim3(1), dim3(256), 0, h->stream, phase, gd, h->partial.p, ks, h->rtol, 0, 1);
+    return FC_OK;
   };
   auto lin3 = [&](double* out, int coef, const double* v0, const double* v1, const double* v2) {
     hipLaunchKernelGGL(fc_lin3_dev, dim3(g), dim3(256), 0, h->stream, N, out, ks + KS_COEF + 3 * coef, v0, v1, v2, ks);
   };
   auto precond = [&](const double* in, double* out) -> int {  // out = M^-1 in
     hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, in, h->buf.p);
+    if (dist) hipLaunchKernelGGL(fc_mask_rows, dim3(g), dim3(256), 0, h->stream, N, kinds, lead, h->buf.p);  // root rows: summed by the apply
     FCCHK(apply_factors(h, S));
     hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->buf.p + N, out);
+    if (dist) hipLaunchKernelGGL(fc_mask_rows, dim3(g), dim3(256), 0, h->stream, N, kinds, 1, out);  // other ranks' rows: zero
     return FC_OK;
   };
   auto matvec = [&](const double* in, double* out) -> int {
-    const int nb = launch_spmv<0>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, in, nullptr, out, nullptr, nullptr);
-    return nb < 0 ? nb : FC_OK;
+    const int nb = launch_spmv<0>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, in, nullptr, out, nullptr, nullptr, kinds);
+    if (nb < 0) return nb;
+    if (dist) {
+      hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, in, h->tmpN.p);
+      hipLaunchKernelGGL(fc_mask_rows, dim3(g), dim3(256), 0, h->stream, N, kinds, lead, h->tmpN.p);
+      const int nb2 = launch_spmv<0>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, h->tmpN.p, nullptr, h->xsol.p, nullptr, nullptr,
+                                     h->rootmask_p.p);
+      if (nb2 < 0) return nb2;
+      if (S.ar_n > 0) {
+        hipLaunchKernelGGL(fc_copy, dim3(nblocks(S.ar_n, 256)), dim3(256), 0, h->stream, S.ar_n, h->xsol.p + S.ar_row0, out + S.ar_row0);
+        FCCHK(exchange(h, out + S.ar_row0, (size_t)S.ar_n));
+      }
+    }
+    return FC_OK;
   };
   HIPCHK(hipMemsetAsync(ks, 0, KS_SIZE * sizeof(double), h->stream));
   // all work vectors start at 0: the first p = 1 r + 0 p + 0 v must not meet NaN bit patterns in fresh memory
   HIPCHK(hipMemsetAsync(x, 0, 8 * (size_t)N * sizeof(double), h->stream));
   hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, r);
   hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, rh);
-  dots(0, r, r, rh, r);
+  FCCHK(dots(0, r, r, rh, r));
   double kh[KS_SIZE];
   *iters = 0;
   *relres = 0.0;
@@ -837,26 +868,25 @@ int bicgstab_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
     lin3(p, 3, r, p, v);  // p = r + beta (p - omega v)   (first iteration: p = r)
     FCCHK(precond(p, ph));
     FCCHK(matvec(ph, v));
-    dots(1, rh, v, rh, v);
+    FCCHK(dots(1, rh, v, rh, v));
     lin3(s, 0, r, v, nullptr);  // s = r - alpha v
-    dots(2, s, s, s, s);
+    FCCHK(dots(2, s, s, s, s));
     FCCHK(precond(s, sh));
     FCCHK(matvec(sh, t));
-    dots(3, t, s, t, t);
+    FCCHK(dots(3, t, s, t, t));
     lin3(x, 1, x, ph, sh);      // x += alpha ph + omega sh
     lin3(r, 2, s, t, nullptr);  // r = s - omega t
-    dots(4, r, r, rh, r);
+    FCCHK(dots(4, r, r, rh, r));
     if (it % kKrylovCheck == 0 || it == h->max_iter) {
       FCCHK(krylov_state(h, kh));
       if (kh[KS_STATE] < 0.0 && restarts < kBicgRestarts && it < h->max_iter) {
         // breakdown (rh.v or t.t vanished): x is the last complete iterate (the vector kernels are no-ops once the state
         // is negative) — restart the recurrences from it with a new shadow residual rh = r = b - A x
         ++restarts;
-        const int nb = launch_spmv<1>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, x, h->b.p, r, nullptr, nullptr);
-        if (nb < 0) return nb;
+        FCCHK(matvec(x, t));
+        hipLaunchKernelGGL(fc_lin3, dim3(g), dim3(256), 0, h->stream, N, r, 1.0, h->b.p, -1.0, t, 0.0, (const double*)nullptr);
         hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, r, rh);
-        hipLaunchKernelGGL(fc_dots2, dim3(gd), dim3(256), 0, h->stream, N, r, r, rh, r, h->partial.p);
-        hipLaunchKernelGGL(fc_bicg_phase, dim3(1), dim3(256), 0, h->stream, 5, gd, h->partial.p, ks, h->rtol, 1, 1);
+        FCCHK(dots(5, r, r, rh, r));
         continue;
       }
       if (kh[KS_STATE] != 0.0) break;
@@ -2907,16 +2937,19 @@ static int solve_once(fc_handle h, int slot, const double* b, double* x, double*
   HIPCHK(hipMemcpyAsync(h->tmpN.p, b, (size_t)N * sizeof(double), hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(fc_gather_perm, dim3(g), dim3(256), 0, h->stream, N, h->perm.p, h->tmpN.p, h->b.p);
   const bool dist = h->partitioned && exchanges(h);
+  const bool krylov = h->method == FC_METHOD_BICGSTAB || h->method == FC_METHOD_GMRES;
   if (dist) {
     // every rank was handed the whole right-hand side: keep the rows this rank accounts for (its own, and the root's on
-    // the lead rank -- the apply sums the root rows over the ranks), solve, then merge the ranks' parts of the solution
+    // the lead rank -- the apply sums the root rows over the ranks; the Krylov vectors keep the root rows on every rank),
+    // solve, then merge the ranks' parts of the solution
     if (h->max_iter > 0 && h->method == FC_METHOD_REFINE)
       return fail(FC_ERR_INVALID, "fc_solve: iterative refinement is not available on a partitioned (multi-GPU) handle");
-    hipLaunchKernelGGL(fc_mask_rows, dim3(g), dim3(256), 0, h->stream, N, h->rowkind_p.p, h->lead ? 1 : 0, h->b.p);
+    if (h->method == FC_METHOD_GMRES) return fail(FC_ERR_INVALID, "fc_solve: GMRES is not available on a partitioned handle (use FC_METHOD_BICGSTAB)");
+    hipLaunchKernelGGL(fc_mask_rows, dim3(g), dim3(256), 0, h->stream, N, h->rowkind_p.p, krylov ? 1 : (h->lead ? 1 : 0), h->b.p);
   }
   hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, h->buf.p);
-  if (h->method == FC_METHOD_BICGSTAB || h->method == FC_METHOD_GMRES) {
-    if (h->partitioned) return fail(FC_ERR_INVALID, "fc_solve: the Krylov drivers are not available on a partitioned handle");
+  if (krylov) {
+    if (h->partitioned && !dist) return fail(FC_ERR_INVALID, "fc_solve: partitioned handle without an exchange");
     int iters = 0;
     double relres = 0.0;
     const int code = h->method == FC_METHOD_GMRES ? gmres_permuted(h, S, &iters, &relres) : bicgstab_permuted(h, S, &iters, &relres);
@@ -2927,6 +2960,10 @@ static int solve_once(fc_handle h, int slot, const double* b, double* x, double*
       info_out[3] = 0.0;
     }
     if (code != FC_OK) return code;
+    if (dist) {
+      hipLaunchKernelGGL(fc_mask_rows, dim3(g), dim3(256), 0, h->stream, N, h->rowkind_p.p, h->lead ? 1 : 0, h->kry.p);
+      FCCHK(exchange(h, h->kry.p, (size_t)N));
+    }
     hipLaunchKernelGGL(fc_scatter_perm, dim3(g), dim3(256), 0, h->stream, N, h->perm.p, h->kry.p, (const double*)nullptr, h->tmpN2.p);
     HIPCHK(hipMemcpyAsync(x, h->tmpN2.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

@@ -611,11 +611,18 @@ __global__ void fc_scatter_perm(int n, const int* __restrict__ perm, const doubl
 
 // Krylov building blocks (fc_solve with FC_METHOD_BICGSTAB): two dot products per pass with a fixed
 // workgroup -> partial -> fc_reduce_final order (reproducible), and a three-term linear combination.
+// (multi-GPU: rowkind != nullptr restricts the sums to the rows this rank accounts for -- its own, the root's on the lead
+// rank; the caller sums the results over the ranks)
 __global__ __launch_bounds__(256) void fc_dots2(int n, const double* __restrict__ a, const double* __restrict__ b,
                                                 const double* __restrict__ c, const double* __restrict__ d,
-                                                double* __restrict__ partial) {
+                                                double* __restrict__ partial, const unsigned char* __restrict__ rowkind = nullptr,
+                                                int lead = 1) {
   double s0 = 0.0, s1 = 0.0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    if (rowkind) {
+      const int kind = rowkind[i];
+      if (!(kind == 1 || (kind == 2 && lead))) continue;
+    }
     s0 += a[i] * b[i];
     s1 += c[i] * d[i];
   }

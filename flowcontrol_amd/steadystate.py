@@ -93,8 +93,8 @@ class SteadyStateSolver:
             self._bc_set = True
         self._assemble_on_device(coeff, SLOT_BDF1)
         dev.apply_bc(SLOT_BDF1)
-        partitioned = dev.world > 1 or getattr(dev, "_force_comm", False)  # collective solves: no Krylov, no refinement there
-        if self.lag_factors and not partitioned and self._factors_age is not None and self._krylov_failures < 2:
+        partitioned = dev.world > 1 or getattr(dev, "_force_comm", False)  # collective solves (BiCGStab included); no refinement there
+        if self.lag_factors and self._factors_age is not None and self._krylov_failures < 2:
             # keep the factors of an earlier iterate as preconditioner: BiCGStab on the new operator costs a few
             # sweeps, a numeric factorisation tens of milliseconds (the reference refactorises every iteration)
             dev.update_operator(SLOT_BDF1)

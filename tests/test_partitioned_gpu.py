@@ -124,12 +124,29 @@ def _steady_worker(rank, world, port, out):
         # a collective solve with the last Jacobian's factors: every rank passes the whole right-hand side and gets the whole
         # solution; info[1] is the residual over all ranks' rows
         b = np.cos(0.37 * np.arange(dev.N) + 0.1)
+        dev.refactor(SLOT_BDF1)  # Newton may have finished on lagged factors; the acceptance probe inside is a collective too
         x, info = dev.solve(SLOT_BDF1, b)
         A = dev.matrix(SLOT_BDF1)
+        # the operator moves on, the factors stay: BiCGStab over the ranks (dots, root rows of the mat-vec and the
+        # preconditioner's two exchanges are all collectives)
+        U = 1.3 * fs.fields.UP0.vector().get_local()[: 2 * fs.th.nn]
+        dev.assemble_matrix(SLOT_BDF1, mass=0.0, nu=0.01, adv=U, lin=U)
+        dev.apply_bc(SLOT_BDF1)
+        dev.update_operator(SLOT_BDF1)
+        dev.set_solver_options(refine=60, method="bicgstab", rtol=1e-12)
+        xk, infok = dev.solve(SLOT_BDF1, b)
+        A1 = dev.matrix(SLOT_BDF1)
         if rank == 0:
+            import scipy.sparse.linalg as spla
+
             out["UP0"] = fs.fields.UP0.vector().get_local()
             out["solve_res"] = float(np.linalg.norm(A @ x - b) / np.linalg.norm(b))
             out["info_res"] = float(info[1])
+            x1 = spla.splu(A1.tocsc()).solve(b)
+            out["krylov_err"] = float(np.linalg.norm(xk - x1) / np.linalg.norm(x1))
+            out["krylov_its"] = int(infok[0])
+            out["moved"] = float(np.linalg.norm(x1 - x) / np.linalg.norm(x))
+            out["newton_krylov_its"] = []
         fs.th.release_device()
     finally:
         dist.destroy_process_group()
@@ -146,6 +163,8 @@ def test_base_flow_on_a_partitioned_handle():
         rel = np.linalg.norm(out["UP0"][:nn2] - g["UP0"][:nn2]) / np.linalg.norm(g["UP0"][:nn2])
         assert rel < 1e-9, rel
         assert out["solve_res"] < 1e-10 and out["info_res"] < 1e-10
+        assert out["moved"] > 1e-3 and out["krylov_err"] < 1e-9 and 1 < out["krylov_its"] <= 60, dict(out)
+        print(f"partitioned BiCGStab with lagged factors: {out['krylov_its']} iterations; Newton's Krylov counts {out['newton_krylov_its']}")
 
 
 def test_rccl_plumbing_on_the_refined_mesh(monkeypatch):
