@@ -16,8 +16,8 @@ One JSON line on rank 0 with the driver's keys plus
   cpu_baseline  compiled single-thread restatement of the reference's per-step work (oracle/cpu_step.cpp element
                 loop + SuperLU triangular solves, 1 core) timed on a bounded sample of the same workload; the numpy
                 oracle's figure is reported next to it
-  spmv          CSR SpMV probe on the assembled BDF2 matrix (cache resident) and on a
-                cavity_fine-sized matrix (> Infinity Cache), % of 8 TB/s
+  spmv          CSR SpMV probe on the assembled BDF2 matrices of the five shipped meshes (O1: the run's own matrix; the
+                others with a synthetic uniform base flow; cavity_fine is the one beyond the Infinity Cache), % of 8 TB/s
 N > 1 (torchrun, one rank per GPU): the SAME mesh is row-partitioned over the ranks (one sub-tree of the
 elimination tree and its cells per GPU, the root's rows split over the ranks; three small RCCL all-reduces per step) —
 total work fixed, "scaling": "strong", value = steps ÷ max time.  The shipped mesh is tiny (56 k

@@ -25,20 +25,6 @@ def read_matfile(path):
         return sio.loadmat(str(path))
 
 
-def _mat(M, rows: int | None = None, cols: int | None = None) -> np.ndarray:
-    M = np.array(M, dtype=np.float64)
-    if M.ndim == 0:
-        M = M.reshape(1, 1)
-    elif M.ndim == 1:
-        M = M.reshape(1, -1) if (rows == 1 or cols == M.size) else M.reshape(-1, 1)
-    if rows is not None and cols is not None and M.shape != (rows, cols):
-        if M.size == rows * cols:
-            M = M.reshape(rows, cols)
-        elif M.size == 1:
-            M = np.full((rows, cols), float(M.reshape(-1)[0])) if M.reshape(-1)[0] == 0 or (rows == cols == 1) else M
-    return M
-
-
 class Controller:
     def __init__(self, A, B, C, D, file: Path | None = None, x0: NDArray[np.float64] | None = None):
         A = np.atleast_2d(np.array(A, dtype=np.float64))

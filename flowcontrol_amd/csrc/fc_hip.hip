@@ -761,10 +761,12 @@ int launch_tail(fc_ctx* h, OrderSys& S, int compute_energy, double* d_y, double*
     }
     fin = FcFin{h->fin_cnt.p, kGroup, n_groups, h->n_sens, h->s_rowptr.p, h->s_idxp.p, h->s_w.p, d_y, d_E, d_r, d_flag_out, d_seq, seq, step_id};
   }
-  hipLaunchKernelGGL(fc_tail, dim3(g), dim3(256), 0, h->stream, h->N, 2 * h->nn, h->perm.p, h->buf.p + h->N, h->b.p,
-                     res ? S.Ap_rowptr.p : nullptr, S.Ap_col.p, S.Ap_val.p, g_rows, reps, h->nc, g_cells > 0 ? h->cn.p : nullptr,
-                     h->geom.p, h->iperm.p, part ? h->rowkind_p.p : nullptr, part ? h->cell_list.p : nullptr, ncl, h->up.p,
-                     h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p, h->partial.p, h->dag_err.p, fin);
+#define FC_TAIL_ARGS h->N, 2 * h->nn, h->perm.p, h->buf.p + h->N, h->b.p, res ? S.Ap_rowptr.p : nullptr, S.Ap_col.p, S.Ap_val.p, g_rows, reps, h->nc, g_cells > 0 ? h->cn.p : nullptr, h->geom.p, h->iperm.p, part ? h->rowkind_p.p : nullptr, part ? h->cell_list.p : nullptr, ncl, h->up.p, h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p, h->partial.p, h->dag_err.p, fin
+  if (fused)
+    hipLaunchKernelGGL(fc_tail<true>, dim3(g), dim3(256), 0, h->stream, FC_TAIL_ARGS);
+  else
+    hipLaunchKernelGGL(fc_tail<false>, dim3(g), dim3(256), 0, h->stream, FC_TAIL_ARGS);
+#undef FC_TAIL_ARGS
   const double* e_part = g_cells > 0 ? h->partial.p + 2 * (size_t)g : nullptr;
   if (fused) {
     // nothing more to launch

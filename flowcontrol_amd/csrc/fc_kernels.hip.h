@@ -878,6 +878,7 @@ struct FcFin {
 // (Folding fc_final in as well, "last workgroup to arrive reduces": with an agent-scope release per workgroup it cost
 // 10x what the launch saves; with sc1 partials + drained two-level arrival counters (FcFin below, FC_FUSED_FINAL=1) it
 // costs exactly what the separate launch costs.  Kept opt-in.)
+template <bool FUSED>
 __global__ __launch_bounds__(256) void fc_tail(
     int N, int nn2, const int* __restrict__ perm, const double* __restrict__ x, const double* __restrict__ b,
     const int* __restrict__ a_rowptr, const int* __restrict__ a_col, const double* __restrict__ a_val,
@@ -888,7 +889,7 @@ __global__ __launch_bounds__(256) void fc_tail(
   if (err && err[0]) {
     // the factor apply gave up (fc_nd_dag): leave the state as it is, the host redoes the step; a fused tail still owes
     // the host its record (flag word + 1024)
-    if (fin.cnt && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (FUSED && blockIdx.x == 0 && threadIdx.x == 0) {
       if (err[1] == 0) err[1] = fin.step_id;
       double none[64];
       for (int k = 0; k < 64; ++k) none[k] = 0.0;
@@ -902,11 +903,15 @@ __global__ __launch_bounds__(256) void fc_tail(
   const int G = gridDim.x;
   double r2 = 0.0, b2 = 0.0, e = 0.0;
   bool bad = false;
-  if ((int)blockIdx.x < n_row_blocks) {
+  // the cell workgroups (a chain of three dependent gathers per lane) come FIRST in the grid, so that their latency
+  // overlaps with the row workgroups' streaming instead of forming the launch's tail
+  const int n_cell_blocks = G - n_row_blocks;
+  const int rb = (int)blockIdx.x - n_cell_blocks;  // row block of this workgroup (< 0: a cell workgroup)
+  if (rb >= 0) {
     // rows: residual monitor, scatter to the W layout, state shift (`reps` row groups per workgroup keep
     // the number of partials that fc_final folds alone <= ~2000 on large meshes)
     for (int rep = 0; rep < reps; ++rep) {
-    const int i = (blockIdx.x * reps + rep) * RPB + t / LANES;
+    const int i = (rb * reps + rep) * RPB + t / LANES;
     double sa = 0.0;
     int r = 0;
     // multi-GPU (rowkind != nullptr): 0 = another rank's row (skipped), 1 = owned (residual + scatter),
@@ -955,7 +960,7 @@ __global__ __launch_bounds__(256) void fc_tail(
     // read from the permuted solution through the inverse permutation; lane q = Radon point q (degree-4
     // integrand: the 7-point rule is exact), 32 cells per workgroup.  2 MB instead of the 11 MB of mass-matrix rows.
     for (int rep = 0; rep < reps; ++rep) {
-    const int cl = (((int)blockIdx.x - n_row_blocks) * reps + rep) * RPB + t / LANES;
+    const int cl = ((int)blockIdx.x * reps + rep) * RPB + t / LANES;
     const int c = cl < ncl ? (cell_list ? cell_list[cl] : cl) : 0;  // multi-GPU: this rank's cells
     double w = 0.0;
     if (cl < ncl && lane < FC_NQ) {
@@ -988,16 +993,16 @@ __global__ __launch_bounds__(256) void fc_tail(
     }
     __syncthreads();
   }
-  const int any_bad = __syncthreads_or(bad ? 1 : 0);
-  if (!fin.cnt) {
+  if (!FUSED) {
+    if (bad) atomicOr(flag, 1);
     if (t == 0) {
-      if (any_bad) atomicOr(flag, 1);
       partial[blockIdx.x] = red[0][0];
       partial[G + blockIdx.x] = red[1][0];
       partial[2 * G + blockIdx.x] = red[2][0];
     }
     return;
   }
+  const int any_bad = __syncthreads_or(bad ? 1 : 0);
   // fused final: partials and the flag go to the coherence point (sc1), are drained, then the workgroup arrives on its
   // group's counter and the group's last arriver on the top counter (two levels: ~12 ns per same-address atomic would
   // serialise thousands of arrivals on one word).  The last arriver of all folds the partials in fc_final's fixed order,
