@@ -635,7 +635,15 @@ class FlowSolver(ABC):
         self._begin_stepping()
         u = np.asarray(u_ctrl, dtype=np.float64)
         if self.order == "cn":
-            raise NotImplementedError("FlowSolver.run (batched) supports the BDF scheme only; use step() with time_scheme='cn'")
+            # Crank-Nicolson needs the previous control for its averaged forcing: the steps go one by one (same log)
+            ys, dEs = [], []
+            for k in range(n_steps):
+                y = self.step(u[k] if u.ndim == 2 else u)
+                if y is None:
+                    return None
+                ys.append(np.asarray(y, dtype=np.float64).copy())
+                dEs.append(float(self.exporter._records[-1]["dE"]))
+            return np.vstack(ys), np.asarray(dEs)
         every = self.params_save.energy_every
         ys, dEs = [], []
         done = 0

@@ -1,5 +1,6 @@
 """Small helpers user scripts import from the reference's ``utils`` package
-(``utils/utils_flowsolver.py`` aggregator: ``flu.apply_fun``, ``flu.MpiUtils``, ``flu.summarize_timings``)."""
+(``utils/utils_flowsolver.py`` aggregator: ``flu.apply_fun``, ``flu.MpiUtils``, ``flu.summarize_timings``,
+``flu.read_xdmf`` / ``flu.write_xdmf`` as the lid-cavity scripts use them, ``flu.boundary_force``)."""
 
 from __future__ import annotations
 
@@ -8,6 +9,9 @@ import time
 from typing import Any, Callable
 
 import numpy as np
+
+from .fem.forces import boundary_force, force_coefficients  # noqa: F401  (flu.* names)
+from .io import read_xdmf, write_xdmf  # noqa: F401
 
 logger = logging.getLogger(__name__)
 

@@ -207,13 +207,18 @@ def test_cylinder_crank_nicolson_vs_oracle(tmp_path_factory, golden_dir):
     rows = [s.row(fs) for s in fs.params_control.sensor_list]
     u_n = fs.fields.ic.u.vector().get_local()
     ys = []
+    ucs = np.array([[0.05 * np.sin(0.4 * k), -0.03] for k in range(10)])
     for k in range(10):
-        uc = np.array([0.05 * np.sin(0.4 * k), -0.03])
-        fs.step(uc)
-        up = ts.step(u_n, uc)
+        if k < 6:
+            fs.step(ucs[k])
+        elif k == 6:  # FlowSolver.run with the CN scheme: same steps, same log
+            yb, dEb = fs.run(4, ucs[6:])
+            assert yb.shape == (4, 3) and dEb.shape == (4,) and np.all(np.isfinite(dEb))
+        up = ts.step(u_n, ucs[k])
         u_n = up[: 2 * th.nn]
         ys.append([w @ up[i] for i, w in rows])
     y_dev = fs.timeseries[["y_meas_1", "y_meas_2", "y_meas_3"]].to_numpy()[1:]
+    assert np.array_equal(yb, y_dev[6:])
     assert _rel_l2(y_dev, np.array(ys)) < 1e-8
     assert _rel_l2(fs.fields.u_.vector().get_local(), u_n) < 1e-9
     assert fs.order == "cn" and np.isclose(fs.t, 0.05)
