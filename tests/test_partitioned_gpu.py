@@ -26,10 +26,17 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out, nsteps):
+def _worker(rank, world, port, out, nsteps, backend="gloo"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":  # one GPU per rank, RCCL inside the library (the production path)
+        import torch
+
+        os.environ["LOCAL_RANK"] = str(rank)
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver
         from flowcontrol_amd.fem.spaces import Function
@@ -165,6 +172,26 @@ def test_base_flow_on_a_partitioned_handle():
         assert out["solve_res"] < 1e-10 and out["info_res"] < 1e-10
         assert out["moved"] > 1e-3 and out["krylov_err"] < 1e-9 and 1 < out["krylov_its"] <= 60, dict(out)
         print(f"partitioned BiCGStab with lagged factors: {out['krylov_its']} iterations; Newton's Krylov counts {out['newton_krylov_its']}")
+
+
+def _gpu_count():
+    import torch
+
+    return torch.cuda.device_count()  # does not initialise the GPU in this (parent) process
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: one rank per GPU over RCCL")
+def test_two_gpus_over_rccl_reproduce_the_serial_run():
+    """The production launch: one process per GPU, torch.distributed backend nccl (= RCCL), the library's own
+    communicator on the solver's stream.  Skipped on single-GPU boxes (the only kind available so far)."""
+    nsteps = 12
+    y_ref, dE_ref, u_ref = _serial(nsteps)
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(2, _free_port(), out, nsteps, "nccl"), nprocs=2, join=True)
+        rel = lambda a, b: np.linalg.norm(np.asarray(a) - b) / np.linalg.norm(b)  # noqa: E731
+        assert rel(out["y"], y_ref) < 1e-10 and rel(out["dE"], dE_ref) < 1e-10 and rel(out["u"], u_ref) < 1e-10
+        assert out["resid"] < 1e-9
 
 
 def test_rccl_plumbing_on_the_refined_mesh(monkeypatch):
