@@ -592,7 +592,8 @@ int solve_permuted(fc_ctx* h, OrderSys& S, const double** x_out, const double** 
   const double mean = (double)S.Ap_nnz / std::max(1, N);
   *n_rpartial = 0;
   const int iters = h->max_iter;
-  if (h->partitioned && iters > 0) return fail(FC_ERR_INVALID, "iterative refinement is not available on a partitioned (multi-GPU) handle");
+  const bool dist = h->partitioned && exchanges(h);
+  if (h->partitioned && !dist && iters > 0) return fail(FC_ERR_INVALID, "iterative refinement on a partitioned handle needs its exchange");
   if (iters == 0 && h->check_residual) {
     // monitor only: r0 -> tmpN (x stays in the x-half of buf); partitioned: owned rows only
     const int nb = launch_spmv<1>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, x, h->b.p, h->tmpN.p, nullptr,
@@ -600,8 +601,32 @@ int solve_permuted(fc_ctx* h, OrderSys& S, const double** x_out, const double** 
     if (nb < 0) return nb;
     *n_rpartial = nb;
   }
+  // partitioned refinement: the residual is formed in the form the apply consumes -- a rank's own rows in full, the root's
+  // rows as this rank's share (its columns; the right-hand side's root rows are shares already), summed by the apply's
+  // first exchange.  h->b holds that right-hand side (fc_rhs_gather / fc_solve's masking).
+  auto dist_residual = [&](const double* xin, bool want_partials) -> int {
+    const int nb = launch_spmv<1>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, xin, h->b.p, h->buf.p, nullptr,
+                                  want_partials ? h->partial.p : nullptr, h->rowkind_p.p);
+    if (nb < 0) return nb;
+    hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, xin, h->tmpN.p);
+    hipLaunchKernelGGL(fc_mask_rows, dim3(g), dim3(256), 0, h->stream, N, h->rowkind_p.p, h->lead ? 1 : 0, h->tmpN.p);
+    const int nb2 = launch_spmv<1>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, h->tmpN.p, h->b.p, h->tmpN2.p, nullptr, nullptr,
+                                   h->rootmask_p.p);
+    if (nb2 < 0) return nb2;
+    if (S.ar_n > 0)
+      hipLaunchKernelGGL(fc_copy, dim3(nblocks(S.ar_n, 256)), dim3(256), 0, h->stream, S.ar_n, h->tmpN2.p + S.ar_row0, h->buf.p + S.ar_row0);
+    return nb;
+  };
   for (int it = 0; it < iters; ++it) {
-    if (it == 0) {
+    if (dist) {
+      if (it == 0)
+        hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->buf.p + N, h->xsol.p);
+      else
+        hipLaunchKernelGGL(fc_axpy, dim3(g), dim3(256), 0, h->stream, N, 1.0, h->buf.p + N, h->xsol.p);
+      const int nb = dist_residual(h->xsol.p, it == 0 && h->check_residual);
+      if (nb < 0) return nb;
+      if (it == 0 && h->check_residual) *n_rpartial = nb;
+    } else if (it == 0) {
       const int nb = launch_spmv<1>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, x, h->b.p, h->buf.p, h->xsol.p,
                                     h->check_residual ? h->partial.p : nullptr);
       if (nb < 0) return nb;
@@ -2944,8 +2969,6 @@ static int solve_once(fc_handle h, int slot, const double* b, double* x, double*
     // every rank was handed the whole right-hand side: keep the rows this rank accounts for (its own, and the root's on
     // the lead rank -- the apply sums the root rows over the ranks; the Krylov vectors keep the root rows on every rank),
     // solve, then merge the ranks' parts of the solution
-    if (h->max_iter > 0 && h->method == FC_METHOD_REFINE)
-      return fail(FC_ERR_INVALID, "fc_solve: iterative refinement is not available on a partitioned (multi-GPU) handle");
     if (h->method == FC_METHOD_GMRES) return fail(FC_ERR_INVALID, "fc_solve: GMRES is not available on a partitioned handle (use FC_METHOD_BICGSTAB)");
     hipLaunchKernelGGL(fc_mask_rows, dim3(g), dim3(256), 0, h->stream, N, h->rowkind_p.p, krylov ? 1 : (h->lead ? 1 : 0), h->b.p);
   }
@@ -2976,7 +2999,13 @@ static int solve_once(fc_handle h, int slot, const double* b, double* x, double*
   FCCHK(solve_permuted(h, S, &xs, &dx, &nrp));
   if (nrp > 0) hipLaunchKernelGGL(fc_reduce_final, dim3(2), dim3(256), 0, h->stream, nrp, h->partial.p, 1.0, h->scal.p + 1);
   if (dist) {
-    // x: this rank's rows and the (replicated) root rows are valid; |r|^2, |b|^2: this rank's rows
+    // x (+ dx after refinement): this rank's rows and the (replicated) root rows are valid; |r|^2, |b|^2: this rank's rows
+    if (dx) {
+      hipLaunchKernelGGL(fc_axpy, dim3(g), dim3(256), 0, h->stream, N, 1.0, dx, h->xsol.p);
+      hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->xsol.p, h->buf.p + N);
+      xs = h->buf.p + N;
+      dx = nullptr;
+    }
     hipLaunchKernelGGL(fc_mask_rows, dim3(g), dim3(256), 0, h->stream, N, h->rowkind_p.p, h->lead ? 1 : 0, h->buf.p + N);
     FCCHK(exchange(h, h->buf.p + N, (size_t)N));
     if (nrp > 0) FCCHK(exchange(h, h->scal.p + 1, 2));

@@ -26,7 +26,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out, nsteps, backend="gloo"):
+def _worker(rank, world, port, out, nsteps, backend="gloo", refine=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     if backend == "nccl":  # one GPU per rank, RCCL inside the library (the production path)
@@ -45,6 +45,7 @@ def _worker(rank, world, port, out, nsteps, backend="gloo"):
         g = np.load(ROOT / "tests" / "golden" / "cylinder_O1.npz")
         fs = CylinderFlowSolver.make_default(Re=100, path_out=tempfile.mkdtemp(), num_steps=nsteps)
         fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
+        fs.refine_steps = refine  # > 0: iterative refinement, its residual formed over the ranks
         U0, P0 = Function(fs.W, g["UP0"]).split()
         fs._assign_steady_state(U0, P0)
         fs.initialize_time_stepping(ic=None)
@@ -91,14 +92,14 @@ def _serial(nsteps):
     return out
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_partitioned_ranks_reproduce_the_serial_run(world):
+@pytest.mark.parametrize("world,refine", [(2, 0), (4, 0), (2, 1)])
+def test_partitioned_ranks_reproduce_the_serial_run(world, refine):
     nsteps = 12
     y_ref, dE_ref, u_ref = _serial(nsteps)
     port = _free_port()
     with mp.Manager() as mgr:
         out = mgr.dict()
-        mp.spawn(_worker, args=(world, port, out, nsteps), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, out, nsteps, "gloo", refine), nprocs=world, join=True)
         rel = lambda a, b: np.linalg.norm(np.asarray(a) - b) / np.linalg.norm(b)  # noqa: E731
         assert rel(out["y"], y_ref) < 1e-10
         assert rel(out["dE"], dE_ref) < 1e-10
@@ -143,6 +144,12 @@ def _steady_worker(rank, world, port, out):
         dev.set_solver_options(refine=60, method="bicgstab", rtol=1e-12)
         xk, infok = dev.solve(SLOT_BDF1, b)
         A1 = dev.matrix(SLOT_BDF1)
+        # ... and refinement on the lagged factors: two sweeps of a (here slowly converging) Richardson iteration must at
+        # least cut the residual of the plain apply
+        dev.set_solver_options(refine=0, method="refine")
+        x_0, _ = dev.solve(SLOT_BDF1, b)
+        dev.set_solver_options(refine=3, method="refine")
+        x_3, _ = dev.solve(SLOT_BDF1, b)
         if rank == 0:
             import scipy.sparse.linalg as spla
 
@@ -152,6 +159,7 @@ def _steady_worker(rank, world, port, out):
             x1 = spla.splu(A1.tocsc()).solve(b)
             out["krylov_err"] = float(np.linalg.norm(xk - x1) / np.linalg.norm(x1))
             out["krylov_its"] = int(infok[0])
+            out["refine_gain"] = float(np.linalg.norm(A1 @ x_3 - b) / np.linalg.norm(A1 @ x_0 - b))
             out["moved"] = float(np.linalg.norm(x1 - x) / np.linalg.norm(x))
             out["newton_krylov_its"] = []
         fs.th.release_device()
@@ -171,6 +179,7 @@ def test_base_flow_on_a_partitioned_handle():
         assert rel < 1e-9, rel
         assert out["solve_res"] < 1e-10 and out["info_res"] < 1e-10
         assert out["moved"] > 1e-3 and out["krylov_err"] < 1e-9 and 1 < out["krylov_its"] <= 60, dict(out)
+        assert out["refine_gain"] < 0.2, out["refine_gain"]  # three refinement sweeps over the ranks do reduce the residual
         print(f"partitioned BiCGStab with lagged factors: {out['krylov_its']} iterations; Newton's Krylov counts {out['newton_krylov_its']}")
 
 

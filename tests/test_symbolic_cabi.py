@@ -39,13 +39,15 @@ def _bc(th):
     return np.sort(np.r_[nodes, nodes + th.nn])
 
 
-@pytest.mark.parametrize("case", ["square", "O1", "O1_world4_rank2", "O1_truncate2"])
+@pytest.mark.parametrize("case", ["square", "O1", "O1_world4_rank2", "O1_world8_rank5", "O1_truncate2"])
 def test_library_symbolic_phase_equals_the_python_specification(case, golden_dir):
     if case == "square":
         th, depth, world, rank, truncate = TaylorHood(Mesh.unit_square(12, 12)), 6, 1, 0, 0
     else:
         th = TaylorHood(read_xdmf_mesh(golden_dir / "meshes" / "O1.npz"))
-        depth, world, rank, truncate = 10, (4 if "world4" in case else 1), (2 if "world4" in case else 0), (2 if "truncate" in case else 0)
+        world = 4 if "world4" in case else 8 if "world8" in case else 1
+        rank = 2 if "world4" in case else 5 if "world8" in case else 0
+        depth, truncate = 10, (2 if "truncate" in case else 0)
     dofs = _bc(th)
     skip = np.zeros(th.N, bool)
     skip[dofs] = True
