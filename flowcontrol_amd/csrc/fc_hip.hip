@@ -219,6 +219,7 @@ struct fc_ctx {
   std::vector<unsigned char> h_rowkind;  // original numbering: 0 other rank, 1 owned, 2 shared root
   DevBuf<int> cell_list;
   DevBuf<unsigned char> rowkind_p;  // permuted numbering
+  DevBuf<unsigned char> rowkind_w;  // W numbering (columns of an explicit rhs operator)
   DevBuf<unsigned char> rootmask_p;  // 1 on the root's rows (permuted numbering): row mask of the partitioned Krylov mat-vec
   void* comm = nullptr;             // ncclComm_t
   int nranks = 1, rank = 0;
@@ -668,6 +669,7 @@ int refresh_permuted(fc_ctx* h) {
     std::vector<unsigned char> rk(N);
     for (int i = 0; i < N; ++i) rk[i] = h->h_rowkind[h->h_perm[i]];
     FCCHK(h->rowkind_p.upload(rk.data(), rk.size(), h->stream));
+    FCCHK(h->rowkind_w.upload(h->h_rowkind.data(), h->h_rowkind.size(), h->stream));
     for (int i = 0; i < N; ++i) rk[i] = rk[i] == 2 ? 1 : 0;
     FCCHK(h->rootmask_p.upload(rk.data(), rk.size(), h->stream));
   }
@@ -724,7 +726,6 @@ int enqueue_rhs(fc_ctx* h, int order_slot, const double* d_uctrl, const double* 
   const StepCoeffs c = coeffs_for(h, order_slot);
   OrderSys& S = h->sys[order_slot];
   if (!d_uforce) d_uforce = d_uctrl;
-  if (S.have_c && h->partitioned) return fail(FC_ERR_INVALID, "an explicit rhs operator (Crank-Nicolson) is not available on a partitioned handle");
   const int ncl = h->partitioned ? h->ncl : h->nc;
   const bool have_ev = h->pre_slot == order_slot && !h->have_force;
   h->pre_slot = -1;
@@ -735,7 +736,7 @@ int enqueue_rhs(fc_ctx* h, int order_slot, const double* d_uctrl, const double* 
   hipLaunchKernelGGL(fc_rhs_gather, dim3(nblocks(h->N, 256)), dim3(256), 0, h->stream, h->N, h->gptr_p.p, h->gidx_p.p,
                      h->ev.p, h->bcslot_p.p, h->bcprof.p, S.lift_p.p, h->n_act, d_uctrl, h->b.p, h->buf.p,
                      h->partitioned ? h->rowkind_p.p : nullptr, h->lead ? 1 : 0, S.have_c ? S.c_rowptr.p : nullptr,
-                     S.c_col.p, S.c_val.p, h->u_n.p);
+                     S.c_col.p, S.c_val.p, h->u_n.p, h->partitioned ? h->rowkind_w.p : nullptr);
   HIPCHK(hipGetLastError());
   return FC_OK;
 }

@@ -110,9 +110,11 @@ __global__ __launch_bounds__(256) void fc_rhs_gather(int N, const int* __restric
                                                      const int* __restrict__ c_rowptr,
                                                      const int* __restrict__ c_col,
                                                      const double* __restrict__ c_val,
-                                                     const double* __restrict__ un) {
+                                                     const double* __restrict__ un,
+                                                     const unsigned char* __restrict__ colkind = nullptr) {
   // rowkind (multi-GPU): 0 = another rank's row, 1 = owned, 2 = root separator shared by all ranks
-  // (every rank adds its cells' share; the BC value / lifting is added once, by the lead rank)
+  // (every rank adds its cells' share; the BC value / lifting is added once, by the lead rank; of an explicit operator's
+  // root rows every rank takes the columns it accounts for -- colkind: the dof kinds in the W numbering of `un`)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   double s = 0.0;
@@ -143,7 +145,14 @@ __global__ __launch_bounds__(256) void fc_rhs_gather(int N, const int* __restric
       for (int k = 0; k < n_act; ++k) s -= uctrl[k] * lift[(size_t)k * N + i];
     // explicit half of the linear terms of Crank-Nicolson (nsforms.py:212-216): -(C u_n)[row]
     if (c_rowptr)
-      for (int k = c_rowptr[i]; k < c_rowptr[i + 1]; ++k) s -= c_val[k] * un[c_col[k]];
+      for (int k = c_rowptr[i]; k < c_rowptr[i + 1]; ++k) {
+        const int j = c_col[k];
+        if (kind == 2 && colkind) {
+          const int ck = colkind[j];
+          if (!(ck == 1 || (ck == 2 && lead))) continue;
+        }
+        s -= c_val[k] * un[j];
+      }
   }
   b[i] = s;
   y[i] = s;  // y-half of the solver work buffer: the first factor sweep starts from b

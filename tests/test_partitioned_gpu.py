@@ -26,7 +26,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out, nsteps, backend="gloo", refine=0):
+def _worker(rank, world, port, out, nsteps, backend="gloo", refine=0, scheme="bdf"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     if backend == "nccl":  # one GPU per rank, RCCL inside the library (the production path)
@@ -46,6 +46,7 @@ def _worker(rank, world, port, out, nsteps, backend="gloo", refine=0):
         fs = CylinderFlowSolver.make_default(Re=100, path_out=tempfile.mkdtemp(), num_steps=nsteps)
         fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
         fs.refine_steps = refine  # > 0: iterative refinement, its residual formed over the ranks
+        fs.params_solver.time_scheme = scheme
         U0, P0 = Function(fs.W, g["UP0"]).split()
         fs._assign_steady_state(U0, P0)
         fs.initialize_time_stepping(ic=None)
@@ -64,8 +65,9 @@ def _worker(rank, world, port, out, nsteps, backend="gloo", refine=0):
         from flowcontrol_amd import ndsolver
 
         dev = fs.th.device()
+        slot = next(iter(dev.factor_nnz))  # Crank-Nicolson keeps its one operator in the first slot
         out[f"values{rank}"] = int(dev.local_factor_nnz)  # factor values this rank sweeps per solve
-        out[f"stored{rank}"] = int(dev.factor_nnz[SLOT_BDF2])  # ... and stores (its sub-tree + the root's pivot block)
+        out[f"stored{rank}"] = int(dev.factor_nnz[slot])  # ... and stores (its sub-tree + the root's pivot block)
         if rank == 0:
             out["total_values"] = int(ndsolver.factorize_blocks(None, dev.tree, numeric=False).nnz)  # the whole tree
         fs.th.release_device()
@@ -73,7 +75,7 @@ def _worker(rank, world, port, out, nsteps, backend="gloo", refine=0):
         dist.destroy_process_group()
 
 
-def _serial(nsteps):
+def _serial(nsteps, scheme="bdf"):
     from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver
     from flowcontrol_amd.fem.spaces import Function
     from flowcontrol_amd.flowsolverparameters import ParamIC
@@ -81,6 +83,7 @@ def _serial(nsteps):
     g = np.load(ROOT / "tests" / "golden" / "cylinder_O1.npz")
     fs = CylinderFlowSolver.make_default(Re=100, path_out=tempfile.mkdtemp(), num_steps=nsteps)
     fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
+    fs.params_solver.time_scheme = scheme
     U0, P0 = Function(fs.W, g["UP0"]).split()
     fs._assign_steady_state(U0, P0)
     fs.initialize_time_stepping(ic=None)
@@ -92,14 +95,14 @@ def _serial(nsteps):
     return out
 
 
-@pytest.mark.parametrize("world,refine", [(2, 0), (4, 0), (2, 1)])
-def test_partitioned_ranks_reproduce_the_serial_run(world, refine):
+@pytest.mark.parametrize("world,refine,scheme", [(2, 0, "bdf"), (4, 0, "bdf"), (2, 1, "bdf"), (2, 0, "cn")])
+def test_partitioned_ranks_reproduce_the_serial_run(world, refine, scheme):
     nsteps = 12
-    y_ref, dE_ref, u_ref = _serial(nsteps)
+    y_ref, dE_ref, u_ref = _serial(nsteps, scheme)
     port = _free_port()
     with mp.Manager() as mgr:
         out = mgr.dict()
-        mp.spawn(_worker, args=(world, port, out, nsteps, "gloo", refine), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, out, nsteps, "gloo", refine, scheme), nprocs=world, join=True)
         rel = lambda a, b: np.linalg.norm(np.asarray(a) - b) / np.linalg.norm(b)  # noqa: E731
         assert rel(out["y"], y_ref) < 1e-10
         assert rel(out["dE"], dE_ref) < 1e-10
