@@ -57,3 +57,35 @@ def test_product_never_imports_the_oracle():
     for py in (ROOT / "flowcontrol_amd").rglob("*.py"):
         src = py.read_text()
         assert "import oracle" not in src and "from oracle" not in src, f"{py} imports the oracle"
+
+
+def test_a_stale_library_is_never_loaded_silently(monkeypatch, tmp_path):
+    """_lib.load(): when the rebuild fails, an existing libfc_hip.so may only be used if it is not older than any of its
+    sources (a stale binary under test would void every parity claim); without a library the first call raises."""
+    import os
+    import time
+
+    from flowcontrol_amd import _lib
+
+    def failing_build(*a, **k):
+        raise _lib.FcError(_lib.FC_ERR_HIP, "hipcc failed (simulated)")
+
+    lib_file = tmp_path / "libfc_hip.so"
+    src = tmp_path / "fc_hip.hip"
+    src.write_text("// source")
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "build", failing_build)
+    monkeypatch.setattr(_lib, "LIB_PATH", lib_file)
+    monkeypatch.setattr(_lib, "SOURCES", [src])
+    monkeypatch.delenv("FC_NO_BUILD", raising=False)
+    with pytest.raises(_lib.FcError, match="simulated"):  # nothing to fall back to
+        _lib.load()
+    lib_file.write_bytes(b"old binary")
+    old = time.time() - 100
+    os.utime(lib_file, (old, old))
+    with pytest.raises(_lib.FcError, match="simulated"):  # older than its source: refused
+        _lib.load()
+    monkeypatch.setenv("FC_NO_BUILD", "1")
+    lib_file.unlink()
+    with pytest.raises(_lib.FcError, match="no CPU fallback"):
+        _lib.load()
