@@ -77,7 +77,7 @@ def build_solver(device: int, distributed: bool = False):
     return fs
 
 
-def cpu_baseline(fs, n_steps: int = 120, warm: int = 3) -> dict:
+def cpu_baseline(fs, n_steps: int = 700, warm: int = 3) -> dict:
     """Oracle leg: same mesh/dt/IC; element-loop RHS (numpy) + SuperLU triangular solves with the
     nested-dissection ordering (the best CPU ordering found, BASELINE.md §2) + sensors + energy;
     1 thread; mean over steps ≥ 3 so both factorisations are excluded (utils/fem.py:94-96)."""
@@ -125,7 +125,7 @@ def _cpu_baseline_1core(fs, O, n_steps, warm) -> dict:
         return float(np.mean(times[warm:])), float(np.mean(t_asm[warm:])), float(np.mean(t_sol[warm:])), y, dE
 
     mean_c, asm_c, sol_c, y_c, dE_c = run(cs.rhs, cs.sensors, cs.energy, n_steps)
-    n_np = max(10, n_steps // 6)
+    n_np = max(10, n_steps // 20)  # ~10 s of compiled stepping + ~3 s of the numpy oracle on one core
     mean_n, asm_n, sol_n, y_n, dE_n = run(ts.rhs, lambda up: np.array([w @ up[i] for i, w in rows]),
                                           lambda u: 0.5 * u @ (M @ u), n_np)
     return {
