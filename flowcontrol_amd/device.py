@@ -213,6 +213,10 @@ class DeviceSolver:
         sub-domain solves and their couplings to the separators above — memory shrinks towards O(nnz) as d grows); the
         Schur complement on the top d levels is replaced by a diagonal estimate.  The slot is then a PRECONDITIONER:
         solves and time steps go through GMRES / BiCGStab (``set_solver_options(method=...)``)."""
+        if os.environ.get("FC_ND_DEPTH"):  # tuning aids: tree shape (binary bisections, levels fused per tree level)
+            depth = int(os.environ["FC_ND_DEPTH"])
+        if os.environ.get("FC_ND_MERGE"):
+            merge = int(os.environ["FC_ND_MERGE"])
         if not self.py_symbolic:
             self._setup_solver_native(slot, depth, refine, check_residual, merge, truncate)
             return
