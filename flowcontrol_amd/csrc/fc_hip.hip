@@ -160,6 +160,9 @@ struct fc_ctx {
   fcsym::Plan sym_plan;
   int64_t sym_total_nnz = 0;  // factor values of the WHOLE tree (all ranks, no truncation)
   double refactor_ms[2] = {0.0, 0.0};  // device time of the last fc_refactor per slot
+  bool step_pending = false;  // fc_step_begin without its fc_step_end
+  int pend_slot = 0, pend_energy = 0;
+  double pend_seq = 0.0;
   int pin_dof = -1;           // fc_set_pressure_pin: pressure dof whose diagonal is shifted inside the factorisation
   double pin_shift = 1.0;
   int64_t sym_local_values[2] = {0, 0};  // factor values this rank sweeps per solve, per slot
@@ -2801,11 +2804,22 @@ void speculate_next_rhs(fc_ctx* h, int order_slot) {
   if (hipGetLastError() == hipSuccess) h->pre_slot = next;
 }
 
-int fc_step(fc_handle h, int order_slot, const double* u_ctrl, const double* u_force, double* y_out, double* dE_out,
-            int compute_energy, double* info_out) {
+// fc_step in two halves: fc_step_begin writes the controls into the mapped record and enqueues the step's launches (the GPU
+// works from here on), fc_step_end waits for the record.  A host program can do its own per-step bookkeeping in between
+// (FlowSolver.step appends the previous step's log row there); fc_step is begin + end.
+static int step_enqueue(fc_ctx* h) {
+  double* dev = h->pin_dev;
+  h->pend_seq = (double)(++h->seq);
+  FCCHK(enqueue_step(h, h->pend_slot, dev, dev + 64, dev + 128, dev + 129, dev + 136, h->pend_energy, dev + 32, dev + 137, h->pend_seq));
+  speculate_next_rhs(h, h->pend_slot);
+  return FC_OK;
+}
+
+int fc_step_begin(fc_handle h, int order_slot, const double* u_ctrl, const double* u_force, int compute_energy) {
   FCCHK(check_step_ready(h, order_slot));
   if (h->n_act > 0 && !u_ctrl) return fail(FC_ERR_INVALID, "fc_step: u_ctrl is null");
   if (h->n_act > 32) return fail(FC_ERR_INVALID, "fc_step: at most 32 actuators");
+  if (h->step_pending) return fail(FC_ERR_INVALID, "fc_step_begin: the previous step was not collected (fc_step_end)");
   HIPCHK(hipSetDevice(h->device));
   // zero-copy record in pinned, device-mapped host memory: the kernels read u_ctrl from it and the
   // last kernel of the step writes (y, dE, |r|^2, |b|^2, flag) into it — no memcpy on the stream.
@@ -2814,58 +2828,69 @@ int fc_step(fc_handle h, int order_slot, const double* u_ctrl, const double* u_f
     pin[k] = u_ctrl[k];
     pin[32 + k] = u_force ? u_force[k] : u_ctrl[k];  // body-force amplitudes (CN: mean of new and old)
   }
-  double* dev = h->pin_dev;
+  h->pend_slot = order_slot;
+  h->pend_energy = compute_energy;
+  FCCHK(step_enqueue(h));
+  h->step_pending = true;
+  return FC_OK;
+}
+
+int fc_step_end(fc_handle h, double* y_out, double* dE_out, double* info_out) {
+  if (!h || !h->step_pending) return fail(FC_ERR_INVALID, "fc_step_end: no step in flight (fc_step_begin)");
+  h->step_pending = false;
+  HIPCHK(hipSetDevice(h->device));
+  volatile double* pin = h->pin;
+  const int compute_energy = h->pend_energy;
   for (int attempt = 0;; ++attempt) {
-  const double seq = (double)(++h->seq);
-  FCCHK(enqueue_step(h, order_slot, dev, dev + 64, dev + 128, dev + 129, dev + 136, compute_energy, dev + 32, dev + 137, seq));
-  speculate_next_rhs(h, order_slot);
-  // the last kernel publishes the record and `seq` with no fence: poll the host-mapped words (bounded), then fall
-  // back to a stream synchronisation — which is also what reports a faulted kernel.
-  // A record is accepted only when both of its checksums (fc_publish) agree with the words actually read: the
-  // individual device writes may become visible to the host in any order.
-  auto bits = [](double v) {
-    unsigned long long u;
-    std::memcpy(&u, &v, sizeof u);
-    return u;
-  };
-  auto record_ok = [&]() {
-    if (pin[137] != seq) return false;
-    unsigned long long x = bits(seq), w = x, k = 3;
-    for (int s = 0; s < h->n_sens; ++s, k += 2) {
-      const unsigned long long v = bits(pin[64 + s]);
-      x ^= v;
-      w += k * v;
-    }
-    const unsigned long long tail[4] = {bits(pin[128]), bits(pin[129]), bits(pin[130]), bits(pin[136])};
-    for (int i = 0; i < 4; ++i, k += 2) {
-      x ^= tail[i];
-      w += k * tail[i];
-    }
-    return x == bits(pin[138]) && w == bits(pin[139]);
-  };
-  bool seen = false;
-  if (!h->timing) {
-    for (long spin = 0; spin < 20000000L; ++spin) {
-      if (record_ok()) {
-        seen = true;
-        break;
+    const double seq = h->pend_seq;
+    // the last kernel publishes the record and `seq` with no fence: poll the host-mapped words (bounded), then fall
+    // back to a stream synchronisation — which is also what reports a faulted kernel.
+    // A record is accepted only when both of its checksums (fc_publish) agree with the words actually read: the
+    // individual device writes may become visible to the host in any order.
+    auto bits = [](double v) {
+      unsigned long long u;
+      std::memcpy(&u, &v, sizeof u);
+      return u;
+    };
+    auto record_ok = [&]() {
+      if (pin[137] != seq) return false;
+      unsigned long long x = bits(seq), w = x, k = 3;
+      for (int s = 0; s < h->n_sens; ++s, k += 2) {
+        const unsigned long long v = bits(pin[64 + s]);
+        x ^= v;
+        w += k * v;
       }
-      __builtin_ia32_pause();
+      const unsigned long long tail[4] = {bits(pin[128]), bits(pin[129]), bits(pin[130]), bits(pin[136])};
+      for (int i = 0; i < 4; ++i, k += 2) {
+        x ^= tail[i];
+        w += k * tail[i];
+      }
+      return x == bits(pin[138]) && w == bits(pin[139]);
+    };
+    bool seen = false;
+    if (!h->timing) {
+      for (long spin = 0; spin < 20000000L; ++spin) {
+        if (record_ok()) {
+          seen = true;
+          break;
+        }
+        __builtin_ia32_pause();
+      }
     }
-  }
-  if (!seen) {
-    HIPCHK(hipStreamSynchronize(h->stream));
-    FCCHK(time_collect(h));
-    if (!record_ok()) return fail(FC_ERR_HIP, "fc_step: the step record failed its checksum after stream synchronisation");
-  }
-  if (pin[136] >= 1024.0) {
-    // the one-launch factor apply gave up (bounded wait): nothing was written to the state; redo with level launches
-    if (h->partitioned) return fail(FC_ERR_HIP, "fc_step: the one-launch factor apply gave up waiting on a partitioned handle (set FC_DAG=0)");
-    if (attempt > 0) return fail(FC_ERR_HIP, "fc_step: factor apply failed twice");
-    FCCHK(dag_recover(h));
-    continue;
-  }
-  break;
+    if (!seen) {
+      HIPCHK(hipStreamSynchronize(h->stream));
+      FCCHK(time_collect(h));
+      if (!record_ok()) return fail(FC_ERR_HIP, "fc_step: the step record failed its checksum after stream synchronisation");
+    }
+    if (pin[136] >= 1024.0) {
+      // the one-launch factor apply gave up (bounded wait): nothing was written to the state; redo with level launches
+      if (h->partitioned) return fail(FC_ERR_HIP, "fc_step: the one-launch factor apply gave up waiting on a partitioned handle (set FC_DAG=0)");
+      if (attempt > 0) return fail(FC_ERR_HIP, "fc_step: factor apply failed twice");
+      FCCHK(dag_recover(h));
+      FCCHK(step_enqueue(h));
+      continue;
+    }
+    break;
   }
   for (int s = 0; s < h->n_sens; ++s)
     if (y_out) y_out[s] = pin[64 + s];
@@ -2880,6 +2905,12 @@ int fc_step(fc_handle h, int order_slot, const double* u_ctrl, const double* u_f
   }
   if (flag) return fail(FC_ERR_DIVERGED, "non-finite velocity after solve");
   return FC_OK;
+}
+
+int fc_step(fc_handle h, int order_slot, const double* u_ctrl, const double* u_force, double* y_out, double* dE_out,
+            int compute_energy, double* info_out) {
+  FCCHK(fc_step_begin(h, order_slot, u_ctrl, u_force, compute_energy));
+  return fc_step_end(h, y_out, dE_out, info_out);
 }
 
 int fc_run(fc_handle h, int first_order_slot, int32_t n_steps, const double* u_ctrl, int u_ctrl_is_sequence,

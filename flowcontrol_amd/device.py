@@ -488,7 +488,7 @@ class DeviceSolver:
         Cp.sort_indices()
         check(self.lib.fc_set_rhs_operator(self._h, slot, ptr(_i32(Cp.indptr)), ptr(_i32(Cp.indices)), ptr(_f64(Cp.data))))
 
-    def step(self, order_slot: int, u_ctrl, compute_energy: bool = True, u_force=None):
+    def _step_buffers(self):
         # persistent argument buffers and their ctypes pointers: the call is on the critical path of
         # every synchronous step (a fresh ndarray + ctypes cast per argument costs ~1 us each)
         b = self._step_bufs
@@ -496,16 +496,31 @@ class DeviceSolver:
             arrs = (np.zeros(max(self.n_act, 1)), np.zeros(max(self.n_act, 1)), np.empty(max(self.n_sens, 1)), np.empty(4))
             dE = C.c_double()
             b = self._step_bufs = arrs + (dE, tuple(ptr(a) for a in arrs), C.byref(dE))
-        u, uf, y, info, dE, (pu, puf, py, pinfo), pdE = b
+        return b
+
+    def step_begin(self, order_slot: int, u_ctrl, compute_energy: bool = True, u_force=None) -> None:
+        """First half of :meth:`step`: hand the controls over and enqueue the step; the GPU works from here on."""
+        u, uf, y, info, dE, (pu, puf, py, pinfo), pdE = self._step_buffers()
         if self.n_act:
             u[:] = u_ctrl
             if u_force is not None:
                 uf[:] = u_force
-        code = self.lib.fc_step(self._h, order_slot, pu if self.n_act else None, puf if (self.n_act and u_force is not None) else None,
-                                py, pdE, 1 if compute_energy else 0, pinfo)
+        code = self.lib.fc_step_begin(self._h, order_slot, pu if self.n_act else None, puf if (self.n_act and u_force is not None) else None,
+                                      1 if compute_energy else 0)
+        if code:
+            check(code)
+
+    def step_end(self):
+        """Second half: wait for the step's record; returns (y, dE, info) like :meth:`step`."""
+        u, uf, y, info, dE, (pu, puf, py, pinfo), pdE = self._step_bufs
+        code = self.lib.fc_step_end(self._h, py, pdE, pinfo)
         if code:
             check(code)
         return y[: self.n_sens].copy(), dE.value, info
+
+    def step(self, order_slot: int, u_ctrl, compute_energy: bool = True, u_force=None):
+        self.step_begin(order_slot, u_ctrl, compute_energy, u_force)
+        return self.step_end()
 
     def run(self, first_order_slot: int, n_steps: int, u_ctrl, compute_energy: bool = True):
         u = _f64(u_ctrl)

@@ -243,6 +243,11 @@ int fc_step(fc_handle h, int order_slot, const double* u_ctrl /* [n_act] */,
             const double* u_force /* [n_act] body-force amplitudes, NULL = u_ctrl (CN passes the
                                      mean of the new and the previous control, nsforms.py:224-226) */,
             double* y_out, double* dE_out, int compute_energy, double* info_out);
+/* the same step in two halves: fc_step_begin writes the controls and enqueues the launches (the GPU works from here),
+ * fc_step_end waits for the record -- the caller's own per-step bookkeeping fits in between (flowsolver.py:775-799: the
+ * reference's exporter.log / progress / checkpoint work of the previous step).  fc_step = begin + end. */
+int fc_step_begin(fc_handle h, int order_slot, const double* u_ctrl, const double* u_force, int compute_energy);
+int fc_step_end(fc_handle h, double* y_out, double* dE_out, double* info_out);
 /* n_steps open-loop steps without host synchronisation in between (u_ctrl constant or a
  * sequence [n_steps][n_act]); y_seq [n_steps][n_sens], dE_seq [n_steps] (may be NULL). */
 int fc_run(fc_handle h, int first_order_slot, int32_t n_steps, const double* u_ctrl,

@@ -102,7 +102,12 @@ def test_setup_and_step_through_the_c_abi_only():
         for k in range(6):
             u = np.array([0.3 * np.sin(0.5 * k), 0.1])
             slot, order = (_lib.SLOT_BDF1, 1) if k == 0 else (_lib.SLOT_BDF2, 2)
-            _check(lib, lib.fc_step(h, slot, u.ctypes.data_as(C.c_void_p), None, y_out.ctypes.data_as(C.c_void_p), C.byref(dE), 1, inf.ctypes.data_as(C.c_void_p)))
+            if k % 2 == 0:
+                _check(lib, lib.fc_step(h, slot, u.ctypes.data_as(C.c_void_p), None, y_out.ctypes.data_as(C.c_void_p), C.byref(dE), 1, inf.ctypes.data_as(C.c_void_p)))
+            else:  # the same step in two halves: enqueue, (host work), collect
+                _check(lib, lib.fc_step_begin(h, slot, u.ctypes.data_as(C.c_void_p), None, 1))
+                assert lib.fc_step_begin(h, slot, u.ctypes.data_as(C.c_void_p), None, 1) != 0  # one step in flight at a time
+                _check(lib, lib.fc_step_end(h, y_out.ctypes.data_as(C.c_void_p), C.byref(dE), inf.ctypes.data_as(C.c_void_p)))
             up = ts.step(order, u_n, u_nn, u)
             u_nn, u_n = u_n, up[: 2 * nn]
             y_ref = np.array([sw[a:b] @ up[sidx[a:b]] for a, b in zip(rp[:-1], rp[1:])])
