@@ -4,7 +4,9 @@
 // A front  [F11 F12; F21 F22]  (nf x nf row-major, ni pivot columns) is swept IN PLACE into
 //     [ F11^-1 ,  F11^-1 F12 ;  -F21 F11^-1 ,  F22 - F21 F11^-1 F12 ]
 // (= pivot-block inverse D^-1, the U block, the -L block and the Schur complement the parent receives) by block
-// steps of FC_FE_KB = 32 pivot columns K = [k0, k0 + kb):
+// steps of KB pivot columns K = [k0, k0 + kb) (KB = 32 on levels of small fronts, where the pivot inversions' dependent
+// chain dominates; KB = 64 on levels whose largest front has order >= FC_FE_WIDE_NF: half the steps, twice the arithmetic per byte
+// of front touched by the trailing update):
 //     W        = A[K,K]^-1                      fc_fe_pivot   one workgroup per front: Gauss-Jordan in LDS with partial
 //                                                              pivoting inside the block (the inverse of the block
 //                                                              does not depend on the pivoting; it only needs it)
@@ -19,7 +21,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define FC_FE_KB 32
+#define FC_FE_KB 32          // block step of the levels of small fronts
+#define FC_FE_KB_WIDE 64     // ... of the levels of wide fronts
+#ifndef FC_FE_WIDE_NF
+#define FC_FE_WIDE_NF 3072   // a level is "wide" when its largest front has at least this order (below, the longer pivot chain costs more than the update gains)
+#endif
+#define FC_FE_KB_MAX 64      // scratch layout: W (KB_MAX x KB_MAX) then Cs (nf x KB_MAX), whatever KB a level uses
 
 struct __attribute__((aligned(16))) FcFront {
   long long front;  // offset of the nf x nf row-major front
@@ -31,20 +38,20 @@ struct __attribute__((aligned(16))) FcFront {
 typedef double fc_d4 __attribute__((ext_vector_type(4)));
 
 // W = A[K,K]^-1 by Gauss-Jordan with partial pivoting among the block's rows (ties -> smallest row: reproducible)
+template <int KB>
 __global__ __launch_bounds__(256) void fc_fe_pivot(const FcFront* __restrict__ nodes, double* fronts, double* __restrict__ scratch, int step) {
-  __shared__ double a[FC_FE_KB][FC_FE_KB + 1];
-  __shared__ int piv[FC_FE_KB];
-  __shared__ double wv[4];
-  __shared__ int wi[4];
+  __shared__ double a[KB][KB + 1];
+  __shared__ int piv[KB];
+  constexpr int EPT = KB * KB / 256;
   const FcFront nd = nodes[blockIdx.x];
-  const int k0 = step * FC_FE_KB;
+  const int k0 = step * KB;
   if (k0 >= nd.ni) return;
-  const int kb = nd.ni - k0 < FC_FE_KB ? nd.ni - k0 : FC_FE_KB;
+  const int kb = nd.ni - k0 < KB ? nd.ni - k0 : KB;
   const int nf = nd.nf;
   const double* A = fronts + nd.front;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-  for (int e = t; e < FC_FE_KB * FC_FE_KB; e += 256) {
-    const int r = e / FC_FE_KB, c = e % FC_FE_KB;
+  for (int e = t; e < KB * KB; e += 256) {
+    const int r = e / KB, c = e % KB;
     a[r][c] = (r < kb && c < kb) ? A[(size_t)(k0 + r) * nf + k0 + c] : (r == c ? 1.0 : 0.0);
   }
   __syncthreads();
@@ -70,7 +77,7 @@ __global__ __launch_bounds__(256) void fc_fe_pivot(const FcFront* __restrict__ n
     }
     __syncthreads();
     const int p = piv[k];
-    if (p != k && t < FC_FE_KB) {
+    if (p != k && t < KB) {
       const double u = a[k][t], v = a[p][t];
       a[k][t] = v;
       a[p][t] = u;
@@ -78,10 +85,10 @@ __global__ __launch_bounds__(256) void fc_fe_pivot(const FcFront* __restrict__ n
     __syncthreads();
     const double d = 1.0 / a[k][k];
     // every thread updates its entries: row k scaled, other rows eliminated; column k takes the swept values
-    double nv[4];
+    double nv[EPT];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int e = t + 256 * q, r = e / FC_FE_KB, c = e % FC_FE_KB;
+    for (int q = 0; q < EPT; ++q) {
+      const int e = t + 256 * q, r = e / KB, c = e % KB;
       const double ark = a[r][k], akc = a[k][c];
       double v;
       if (r == k)
@@ -92,16 +99,16 @@ __global__ __launch_bounds__(256) void fc_fe_pivot(const FcFront* __restrict__ n
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < EPT; ++q) {
       const int e = t + 256 * q;
-      a[e / FC_FE_KB][e % FC_FE_KB] = nv[q];
+      a[e / KB][e % KB] = nv[q];
     }
     __syncthreads();
   }
   // the row swaps act on the columns of the inverse, in reverse order
   for (int k = kb - 1; k >= 0; --k) {
     const int p = piv[k];
-    if (p != k && t < FC_FE_KB) {
+    if (p != k && t < KB) {
       const double u = a[t][k], v = a[t][p];
       a[t][k] = v;
       a[t][p] = u;
@@ -109,106 +116,135 @@ __global__ __launch_bounds__(256) void fc_fe_pivot(const FcFront* __restrict__ n
     __syncthreads();
   }
   double* W = scratch + nd.scratch;
-  for (int e = t; e < FC_FE_KB * FC_FE_KB; e += 256) {
-    const int r = e / FC_FE_KB, c = e % FC_FE_KB;
+  for (int e = t; e < KB * KB; e += 256) {
+    const int r = e / KB, c = e % KB;
     W[e] = (r < kb && c < kb) ? a[r][c] : 0.0;
   }
-  (void)wv;
-  (void)wi;
 }
 
-// blockIdx.x < ct: row panel, 64 columns per workgroup:  A[K, j] = sum_c W[., c] A[k0 + c, j]  (j in K: = W)
+// blockIdx.x < ct: row panel, 64 columns per workgroup (two passes of 32):  A[K, j] = sum_c W[., c] A[k0 + c, j]  (j in K: = W)
 // blockIdx.x >= ct: column panel copy, 64 rows per workgroup: Cs[i, c] = A[i, k0 + c]  (zero beyond kb)
+template <int KB>
 __global__ __launch_bounds__(256) void fc_fe_panels(const FcFront* __restrict__ nodes, double* fronts, double* __restrict__ scratch, int step,
                                                     int ct) {
-  __shared__ double Ws[FC_FE_KB][FC_FE_KB + 1];
-  __shared__ double Rs[FC_FE_KB][64 + 1];
+  __shared__ double Ws[KB][KB];  // read as Ws[r][c] with r (nearly) uniform over a wave: broadcast, no padding needed
+  __shared__ double Rs[KB][32 + 1];
   const FcFront nd = nodes[blockIdx.y];
-  const int k0 = step * FC_FE_KB;
+  const int k0 = step * KB;
   if (k0 >= nd.ni) return;
-  const int kb = nd.ni - k0 < FC_FE_KB ? nd.ni - k0 : FC_FE_KB;
+  const int kb = nd.ni - k0 < KB ? nd.ni - k0 : KB;
   const int nf = nd.nf;
   double* A = fronts + nd.front;
   const double* W = scratch + nd.scratch;
-  double* Cs = scratch + nd.scratch + FC_FE_KB * FC_FE_KB;
+  double* Cs = scratch + nd.scratch + FC_FE_KB_MAX * FC_FE_KB_MAX;
   const int t = threadIdx.x;
   if ((int)blockIdx.x >= ct) {
     const int i0 = ((int)blockIdx.x - ct) * 64;
     if (i0 >= nf) return;
-    for (int e = t; e < 64 * FC_FE_KB; e += 256) {
-      const int i = i0 + e / FC_FE_KB, c = e % FC_FE_KB;
-      if (i < nf) Cs[(size_t)i * FC_FE_KB + c] = c < kb ? A[(size_t)i * nf + k0 + c] : 0.0;
+    for (int e = t; e < 64 * KB; e += 256) {
+      const int i = i0 + e / KB, c = e % KB;
+      if (i < nf) Cs[(size_t)i * KB + c] = c < kb ? A[(size_t)i * nf + k0 + c] : 0.0;
     }
     return;
   }
   const int j0 = blockIdx.x * 64;
   if (j0 >= nf) return;
-  for (int e = t; e < FC_FE_KB * FC_FE_KB; e += 256) Ws[e / FC_FE_KB][e % FC_FE_KB] = W[e];
-  for (int e = t; e < FC_FE_KB * 64; e += 256) {
-    const int c = e / 64, j = j0 + e % 64;
-    Rs[c][e % 64] = (c < kb && j < nf) ? A[(size_t)(k0 + c) * nf + j] : 0.0;
-  }
-  __syncthreads();
-  for (int e = t; e < FC_FE_KB * 64; e += 256) {
-    const int r = e / 64, jj = e % 64, j = j0 + jj;
-    if (r >= kb || j >= nf) continue;
-    double s;
-    if (j >= k0 && j < k0 + kb) {
-      s = Ws[r][j - k0];
-    } else {
-      s = 0.0;
-#pragma unroll 8
-      for (int c = 0; c < FC_FE_KB; ++c) s += Ws[r][c] * Rs[c][jj];
+  for (int e = t; e < KB * KB; e += 256) Ws[e / KB][e % KB] = W[e];
+  for (int half = 0; half < 2; ++half) {
+    const int jh = j0 + 32 * half;
+    if (jh >= nf) break;
+    __syncthreads();
+    for (int e = t; e < KB * 32; e += 256) {
+      const int c = e / 32, j = jh + e % 32;
+      Rs[c][e % 32] = (c < kb && j < nf) ? A[(size_t)(k0 + c) * nf + j] : 0.0;
     }
-    A[(size_t)(k0 + r) * nf + j] = s;
+    __syncthreads();
+    for (int e = t; e < KB * 32; e += 256) {
+      const int r = e / 32, jj = e % 32, j = jh + jj;
+      if (r >= kb || j >= nf) continue;
+      double sum;
+      if (j >= k0 && j < k0 + kb) {
+        sum = Ws[r][j - k0];
+      } else {
+        sum = 0.0;
+#pragma unroll 8
+        for (int c = 0; c < KB; ++c) sum += Ws[r][c] * Rs[c][jj];
+      }
+      A[(size_t)(k0 + r) * nf + j] = sum;
+    }
   }
 }
 
 // 64 x 64 tile of the trailing update on the fp64 matrix cores: wave w owns rows [16 w, 16 w + 16) x 64 columns
-// (four 16 x 16 accumulators).  A operand: Cs (rows of the tile, K = 32); B operand: the new pivot rows A[K, :].
+// (four 16 x 16 accumulators).  A operand: Cs (rows of the tile, K = KB) in registers; B operand: the new pivot rows
+// A[K, j0 .. j0 + 64), staged once per workgroup in LDS (the four waves share them).  Everything a wave needs from memory —
+// its Cs rows, its share of the B panel, its 16 entries of the C tile — is requested before the first MFMA, so a tile pays
+// the memory latency once.
 //   v_mfma_f64_16x16x4_f64: lane l holds A[row l & 15][k = l >> 4], B[k = l >> 4][col l & 15];
 //   D[row (l >> 4) + 4 r][col l & 15] in register r.
+template <int KB>
 __global__ __launch_bounds__(256) void fc_fe_update(const FcFront* __restrict__ nodes, double* fronts, const double* __restrict__ scratch,
                                                     int step, int tiles_per_side) {
+  __shared__ double Bs[KB][64];
   const FcFront nd = nodes[blockIdx.y];
-  const int k0 = step * FC_FE_KB;
+  const int k0 = step * KB;
   if (k0 >= nd.ni) return;
-  const int kb = nd.ni - k0 < FC_FE_KB ? nd.ni - k0 : FC_FE_KB;
+  const int kb = nd.ni - k0 < KB ? nd.ni - k0 : KB;
   const int nf = nd.nf;
   const int ti = blockIdx.x / tiles_per_side, tj = blockIdx.x % tiles_per_side;
   const int i0 = ti * 64, j0 = tj * 64;
   if (i0 >= nf || j0 >= nf) return;
   double* A = fronts + nd.front;
-  const double* Cs = scratch + nd.scratch + FC_FE_KB * FC_FE_KB;
+  const double* Cs = scratch + nd.scratch + FC_FE_KB_MAX * FC_FE_KB_MAX;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int lr = lane & 15, lk = lane >> 4;
-  const int arow = i0 + 16 * wave + lr;
-  double av[FC_FE_KB / 4];
+  // B panel: KB x 64, a row of 64 columns per 64 consecutive threads (coalesced)
+  constexpr int BPT = KB * 64 / 256;
+  double bq[BPT];
 #pragma unroll
-  for (int s = 0; s < FC_FE_KB / 4; ++s) av[s] = arow < nf ? Cs[(size_t)arow * FC_FE_KB + 4 * s + lk] : 0.0;  // zero beyond kb (fc_fe_panels)
+  for (int q = 0; q < BPT; ++q) {
+    const int e = t + 256 * q, k = e / 64, col = j0 + e % 64;
+    bq[q] = (k < kb && col < nf) ? A[(size_t)(k0 + k) * nf + col] : 0.0;
+  }
+  const int arow = i0 + 16 * wave + lr;
+  double av[KB / 4];
+#pragma unroll
+  for (int s = 0; s < KB / 4; ++s) av[s] = arow < nf ? Cs[(size_t)arow * KB + 4 * s + lk] : 0.0;  // zero beyond kb (fc_fe_panels)
+  // the wave's entries of the C tile (pivot rows and everything outside the front: not touched)
+  double cv[4][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int col = j0 + 16 * c + lr;
+    const bool inK = col >= k0 && col < k0 + kb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i0 + 16 * wave + lk + 4 * r;
+      const bool live = col < nf && row < nf && !(row >= k0 && row < k0 + kb);
+      cv[c][r] = (live && !inK) ? A[(size_t)row * nf + col] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < BPT; ++q) {
+    const int e = t + 256 * q;
+    Bs[e / 64][e % 64] = bq[q];
+  }
+  __syncthreads();
   fc_d4 acc[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     acc[c] = fc_d4{0.0, 0.0, 0.0, 0.0};
-    const int col = j0 + 16 * c + lr;
 #pragma unroll
-    for (int s = 0; s < FC_FE_KB / 4; ++s) {
-      const int k = 4 * s + lk;
-      const double bv = (k < kb && col < nf) ? A[(size_t)(k0 + k) * nf + col] : 0.0;
-      acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv, acc[c], 0, 0, 0);
-    }
+    for (int s = 0; s < KB / 4; ++s) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], Bs[4 * s + lk][16 * c + lr], acc[c], 0, 0, 0);
   }
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int col = j0 + 16 * c + lr;
     if (col >= nf) continue;
-    const bool inK = col >= k0 && col < k0 + kb;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = i0 + 16 * wave + lk + 4 * r;
       if (row >= nf || (row >= k0 && row < k0 + kb)) continue;  // the pivot rows are final (fc_fe_panels)
-      double* p = A + (size_t)row * nf + col;
-      *p = (inK ? 0.0 : *p) - acc[c][r];
+      A[(size_t)row * nf + col] = cv[c][r] - acc[c][r];
     }
   }
 }

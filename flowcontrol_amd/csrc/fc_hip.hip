@@ -2167,7 +2167,7 @@ int fc_factor_plan(fc_handle h, int32_t n_nodes, const int64_t* nodes, int32_t n
       const fc_ctx::PlanNode& nd = h->pnodes[(size_t)g];
       if (nd.ni == 0) continue;
       fr.push_back(FcFront{(long long)nd.front, (long long)nd.voff, nd.nf, nd.ni, (long long)off});
-      off += (int64_t)FC_FE_KB * FC_FE_KB + (int64_t)nd.nf * FC_FE_KB;
+      off += (int64_t)FC_FE_KB_MAX * FC_FE_KB_MAX + (int64_t)nd.nf * FC_FE_KB_MAX;
       h->plevel_max_ni[li] = std::max(h->plevel_max_ni[li], nd.ni);
       h->plevel_max_nf[li] = std::max(h->plevel_max_nf[li], nd.nf);
     }
@@ -2267,11 +2267,20 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
       const FcFront* fp = h->pfront.p + grp.first;
       const int nfmax = h->plevel_max_nf[li];
       const int ct = (nfmax + 63) / 64;  // 64-wide tiles per side of the widest front
-      const int steps = (h->plevel_max_ni[li] + FC_FE_KB - 1) / FC_FE_KB;
+      // block step of the level: wide fronts take 64 pivot columns at a time, small ones 32 (fc_front.hip.h)
+      const bool wide = h->plevel_max_nf[li] >= FC_FE_WIDE_NF;
+      const int kbs = wide ? FC_FE_KB_WIDE : FC_FE_KB;
+      const int steps = (h->plevel_max_ni[li] + kbs - 1) / kbs;
       for (int k = 0; k < steps; ++k) {
-        hipLaunchKernelGGL(fc_fe_pivot, dim3(grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k);
-        hipLaunchKernelGGL(fc_fe_panels, dim3(2 * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
-        hipLaunchKernelGGL(fc_fe_update, dim3(ct * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
+        if (wide) {
+          hipLaunchKernelGGL(fc_fe_pivot<FC_FE_KB_WIDE>, dim3(grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k);
+          hipLaunchKernelGGL(fc_fe_panels<FC_FE_KB_WIDE>, dim3(2 * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
+          hipLaunchKernelGGL(fc_fe_update<FC_FE_KB_WIDE>, dim3(ct * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
+        } else {
+          hipLaunchKernelGGL(fc_fe_pivot<FC_FE_KB>, dim3(grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k);
+          hipLaunchKernelGGL(fc_fe_panels<FC_FE_KB>, dim3(2 * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
+          hipLaunchKernelGGL(fc_fe_update<FC_FE_KB>, dim3(ct * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
+        }
       }
       hipLaunchKernelGGL(fc_fe_export, dim3((nfmax + 15) / 16, grp.second), dim3(256), 0, h->stream, fp, F, fv);
       HIPCHK(hipGetLastError());

@@ -4,7 +4,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_refactor
 rm -rf "$OUT" && mkdir -p "$OUT"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python scripts/refactor_time.py O1 > "$OUT/log.txt" 2> "$OUT/err.txt"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python scripts/refactor_time.py ${MESH:-O1} > "$OUT/log.txt" 2> "$OUT/err.txt"
 python - <<PY
 import glob, pandas as pd
 f = glob.glob("$OUT/stats/**/*_kernel_stats.csv", recursive=True)[0]
