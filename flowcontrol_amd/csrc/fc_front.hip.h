@@ -38,14 +38,13 @@ struct __attribute__((aligned(16))) FcFront {
 typedef double fc_d4 __attribute__((ext_vector_type(4)));
 
 // W = A[K,K]^-1 by Gauss-Jordan with partial pivoting among the block's rows (ties -> smallest row: reproducible)
+// (a: KB x (KB + 1) doubles and piv: KB ints of LDS, provided by the caller: the stand-alone kernel below for a front's
+// first step, fc_fe_update for every later one)
 template <int KB>
-__global__ __launch_bounds__(256) void fc_fe_pivot(const FcFront* __restrict__ nodes, double* fronts, double* __restrict__ scratch, int step) {
-  __shared__ double a[KB][KB + 1];
-  __shared__ int piv[KB];
+__device__ __forceinline__ void fc_fe_pivot_block(const FcFront& nd, const double* fronts, double* __restrict__ scratch, int step,
+                                                  double (*a)[KB + 1], int* piv) {
   constexpr int EPT = KB * KB / 256;
-  const FcFront nd = nodes[blockIdx.x];
   const int k0 = step * KB;
-  if (k0 >= nd.ni) return;
   const int kb = nd.ni - k0 < KB ? nd.ni - k0 : KB;
   const int nf = nd.nf;
   const double* A = fronts + nd.front;
@@ -122,6 +121,15 @@ __global__ __launch_bounds__(256) void fc_fe_pivot(const FcFront* __restrict__ n
   }
 }
 
+template <int KB>
+__global__ __launch_bounds__(256) void fc_fe_pivot(const FcFront* __restrict__ nodes, double* fronts, double* __restrict__ scratch, int step) {
+  __shared__ double a[KB][KB + 1];
+  __shared__ int piv[KB];
+  const FcFront nd = nodes[blockIdx.x];
+  if (step * KB >= nd.ni) return;
+  fc_fe_pivot_block<KB>(nd, fronts, scratch, step, a, piv);
+}
+
 // blockIdx.x < ct: row panel, 64 columns per workgroup (two passes of 32):  A[K, j] = sum_c W[., c] A[k0 + c, j]  (j in K: = W)
 // blockIdx.x >= ct: column panel copy, 64 rows per workgroup: Cs[i, c] = A[i, k0 + c]  (zero beyond kb)
 template <int KB>
@@ -185,13 +193,20 @@ __global__ __launch_bounds__(256) void fc_fe_panels(const FcFront* __restrict__ 
 template <int KB>
 __global__ __launch_bounds__(256) void fc_fe_update(const FcFront* __restrict__ nodes, double* fronts, const double* __restrict__ scratch,
                                                     int step, int tiles_per_side) {
-  __shared__ double Bs[KB][64];
+  __shared__ double smem[KB * (KB + 1) > KB * 64 ? KB * (KB + 1) : KB * 64];  // the B panel, then (one tile only) the next pivot block
+  __shared__ int piv[KB];
+  double (*Bs)[64] = reinterpret_cast<double (*)[64]>(smem);
   const FcFront nd = nodes[blockIdx.y];
   const int k0 = step * KB;
   if (k0 >= nd.ni) return;
   const int kb = nd.ni - k0 < KB ? nd.ni - k0 : KB;
   const int nf = nd.nf;
-  const int ti = blockIdx.x / tiles_per_side, tj = blockIdx.x % tiles_per_side;
+  // the tile holding the next pivot block goes FIRST (block 0): its workgroup carries on with the inversion (below) and
+  // needs the rest of the launch to hide behind
+  const int k1 = k0 + KB;
+  const int tk = k1 / 64, special = k1 < nd.ni && tk < tiles_per_side ? tk * tiles_per_side + tk : 0;
+  const int tile = (int)blockIdx.x == 0 ? special : ((int)blockIdx.x <= special ? (int)blockIdx.x - 1 : (int)blockIdx.x);
+  const int ti = tile / tiles_per_side, tj = tile % tiles_per_side;
   const int i0 = ti * 64, j0 = tj * 64;
   if (i0 >= nf || j0 >= nf) return;
   double* A = fronts + nd.front;
@@ -246,6 +261,12 @@ __global__ __launch_bounds__(256) void fc_fe_update(const FcFront* __restrict__ 
       if (row >= nf || (row >= k0 && row < k0 + kb)) continue;  // the pivot rows are final (fc_fe_panels)
       A[(size_t)row * nf + col] = cv[c][r] - acc[c][r];
     }
+  }
+  // look-ahead: the tile that holds the NEXT pivot block inverts it right away (its entries are final for this step), while
+  // the other workgroups of the launch are still updating theirs -- the next step then starts with its panels
+  if (k1 < nd.ni && ti == tk && tj == tk) {
+    __syncthreads();  // the tile's stores are visible to the whole workgroup; Bs is free
+    fc_fe_pivot_block<KB>(nd, fronts, const_cast<double*>(scratch), step + 1, reinterpret_cast<double (*)[KB + 1]>(smem), piv);
   }
 }
 

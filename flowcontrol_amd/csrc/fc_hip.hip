@@ -2273,11 +2273,11 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
       const int steps = (h->plevel_max_ni[li] + kbs - 1) / kbs;
       for (int k = 0; k < steps; ++k) {
         if (wide) {
-          hipLaunchKernelGGL(fc_fe_pivot<FC_FE_KB_WIDE>, dim3(grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k);
+          if (k == 0) hipLaunchKernelGGL(fc_fe_pivot<FC_FE_KB_WIDE>, dim3(grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k);
           hipLaunchKernelGGL(fc_fe_panels<FC_FE_KB_WIDE>, dim3(2 * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
           hipLaunchKernelGGL(fc_fe_update<FC_FE_KB_WIDE>, dim3(ct * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
         } else {
-          hipLaunchKernelGGL(fc_fe_pivot<FC_FE_KB>, dim3(grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k);
+          if (k == 0) hipLaunchKernelGGL(fc_fe_pivot<FC_FE_KB>, dim3(grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k);
           hipLaunchKernelGGL(fc_fe_panels<FC_FE_KB>, dim3(2 * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
           hipLaunchKernelGGL(fc_fe_update<FC_FE_KB>, dim3(ct * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
         }
