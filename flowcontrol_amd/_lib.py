@@ -125,6 +125,16 @@ SIGNATURES: dict[str, list] = {
     "fc_set_stage_diag": [_H, C.c_int, _dp],
     "fc_debug_inject_dag_failure": [_H, C.c_int],
     "fc_debug_trace_apply": [_H, C.c_int, C.c_int32, _lp, _ip, _ip],
+    "fc_set_batch": [_H, C.c_int32],
+    "fc_set_state_batch": [_H, C.c_int32, _dp, _dp, C.c_void_p],
+    "fc_get_state_batch": [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
+    "fc_get_solution_batch": [_H, C.c_int32, _dp],
+    "fc_step_batch": [_H, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
+    "fc_step_batch_begin": [_H, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_int],
+    "fc_step_batch_end": [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
+    "fc_get_batch_info": [_H, _dp],
+    "fc_bench_batch_apply": [_H, C.c_int, C.c_int, C.POINTER(C.c_double)],
+    "fc_solve_batch": [_H, C.c_int, C.c_int32, _dp, _dp],
 }
 
 #: void (*fc_exchange_fn)(double* buf, int64_t n, void* user)

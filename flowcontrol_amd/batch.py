@@ -1,0 +1,165 @@
+"""``BatchedFlowSolver`` — k lock-step simulations of ONE ``FlowSolver``'s operators on one MI355X.
+
+The reference's outer workloads are sweeps of independent runs of the same case: initial-condition sweeps
+(``src/examples/lidcavity/batch_run_lidcavity.py:197-215``), controller optimisation
+(``src/utils/optim.py:95-102``: one closed-loop simulation per candidate controller).  There every run owns a
+``FlowSolver`` and calls ``step`` (``src/flowcontrol/flowsolver.py:703-799``) once per time step — and re-reads
+the whole LU factorisation for one right-hand side.  Here the k runs share the device handle of one prepared
+``FlowSolver`` (same mesh, base flow, Δt, actuators, sensors ⇒ same operators and factors) and are advanced
+together by ``fc_step_batch``: one pass over the factors serves all of them (``csrc/fc_batch.hip.h``).
+
+What may differ between the runs: the initial condition, the control input of every step (hence the
+controller), and what the host does with the measurements.  Everything a single run logs is logged per run::
+
+    fs = CylinderFlowSolver.make_default(...); fs.load_steady_state()
+    bfs = BatchedFlowSolver(fs, k=8)
+    bfs.initialize_time_stepping(ics=[ParamIC(xloc=x, ...) for x in xs])
+    for _ in range(n):
+        u = np.stack([K[i].step(y=-bfs.y_meas[i][0], dt=dt) for i in range(8)])
+        bfs.step(u_ctrl=u)
+    bfs.timeseries(3)          # DataFrame of run 3, same columns as FlowSolver.timeseries
+"""
+
+from __future__ import annotations
+
+import logging
+import time
+from typing import Sequence
+
+import numpy as np
+import pandas as pd
+
+from ._lib import SLOT_BDF1, SLOT_BDF2, FcDiverged
+from .exporter import FlowExporter
+from .fem.spaces import Function
+from .flowsolverparameters import ParamIC
+
+logger = logging.getLogger(__name__)
+
+
+class BatchedFlowSolver:
+    def __init__(self, fs, k: int) -> None:
+        if not 1 <= int(k) <= 16:
+            raise ValueError(f"k must be in [1, 16], got {k}")
+        if fs.fields.U0 is None:
+            raise RuntimeError("no base flow: call compute_steady_state() or load_steady_state() on the FlowSolver first")
+        if fs.refine_steps or fs.nd_truncate:
+            raise ValueError("batched stepping applies the full factors directly: refine_steps and nd_truncate must be 0")
+        self.fs = fs
+        self.k = int(k)
+        self.params_time = fs.params_time
+        self.params_save = fs.params_save
+        self.residual_tol = fs.residual_tol
+        self._ready = False
+
+    # ── setup ────────────────────────────────────────────────────────────────
+    def _prepare(self) -> None:
+        fs = self.fs
+        if fs.fields._store.get("u_n") is None:
+            fs.initialize_time_stepping(ic=None)  # the operators are assembled from the solver's own (any) state
+        if not fs._systems_ready:
+            fs._prepare_systems(fs.fields._store["u_n"], fs.fields._store["u_nn"])
+        self.dev = fs.th.device()
+        if self.dev.world > 1:
+            raise RuntimeError("batched stepping runs on single-GPU handles (replicas scale across GPUs by themselves)")
+        self.dev.set_batch(self.k)
+        self._ready = True
+
+    def initialize_time_stepping(self, ics: Sequence[ParamIC | Function | None] | None = None, Tstart: float = 0.0) -> None:
+        """Initial condition of every run: a ``ParamIC`` (the solver's default div-free Gaussian vortex with that
+        centre / radius / amplitude, as ``FlowSolver._initialize_with_ic``), a mixed ``Function`` (taken as it is) or
+        ``None`` (the solver's own ``params_ic``)."""
+        if Tstart != 0.0:
+            raise NotImplementedError("batched runs start from initial conditions (restart one run with FlowSolver)")
+        if not self._ready:
+            self._prepare()
+        fs, k = self.fs, self.k
+        ics = list(ics) if ics is not None else [None] * k
+        if len(ics) != k:
+            raise ValueError(f"expected {k} initial conditions, got {len(ics)}")
+        nn2, nv = 2 * fs.th.nn, fs.th.nv
+        u_n = np.zeros((k, nn2))
+        p_n = np.zeros((k, nv))
+        self.y_meas = np.zeros((k, len(fs.params_control.sensor_list)))
+        self.exporters = []
+        for i, ic in enumerate(ics):
+            if isinstance(ic, Function):
+                up = ic.vector().array().copy()
+            else:
+                pic = fs.params_ic if ic is None else ic
+                up = np.zeros(fs.th.N)
+                if pic.amplitude:
+                    up += pic.amplitude * fs._default_initial_perturbation(xloc=pic.xloc, yloc=pic.yloc, radius=pic.radius).vector().array()
+            u_n[i], p_n[i] = up[:nn2], up[nn2:]
+            self.y_meas[i] = fs.make_measurement(up=Function(fs.W, up))
+            ex = FlowExporter(paths=fs.paths, fields=fs.fields, V=fs.V, P=fs.P, Tstart=self.params_time.Tstart, dt=self.params_time.dt, save_every=0)
+            ex.log_ic(t=self.params_time.Tstart, y_meas=self.y_meas[i], dE=0.5 * fs._velocity_l2_norm(u_n[i]) ** 2)
+            self.exporters.append(ex)
+        self.dev.set_state_batch(u_n, u_n, p_n)
+        self.order: int | str = "cn" if fs.params_solver.time_scheme == "cn" else 1
+        self._u_ctrl_prev = None
+        self.iter = 0
+        self.t = self.params_time.Tstart
+        self.diverged = np.zeros(k, dtype=bool)
+
+    # ── stepping ─────────────────────────────────────────────────────────────
+    def step(self, u_ctrl) -> np.ndarray | None:
+        """Advance all k runs by one Δt; ``u_ctrl``: (k, n_act).  Returns y_meas (k, n_sens).  A run whose velocity
+        became non-finite is reported as ``FlowSolver.step`` reports it — ``RuntimeError`` or, with
+        ``params_solver.throw_error = False``, ``None`` — with ``self.diverged`` marking the runs."""
+        fs, k = self.fs, self.k
+        t0 = time.time()
+        n_act = fs.params_control.actuator_number
+        u_ctrl = np.asarray(u_ctrl, dtype=np.float64).reshape(k, n_act)
+        next_iter = self.iter + 1
+        want_energy = fs._niter_multiple_of(next_iter, self.params_save.energy_every)
+        u_force = None
+        if self.order == "cn":
+            prev = np.zeros_like(u_ctrl) if self._u_ctrl_prev is None else self._u_ctrl_prev
+            u_force = 0.5 * (u_ctrl + prev)
+        try:
+            y, dE, info = self.dev.step_batch(SLOT_BDF2 if self.order == 2 else SLOT_BDF1, u_ctrl, compute_energy=want_energy, u_force=u_force)
+        except FcDiverged:
+            self.diverged = self.dev._batch_bufs[4][:, 3] != 0
+            logger.critical("Solver diverged (Inf detected) in runs %s", np.flatnonzero(self.diverged).tolist())
+            if not fs.params_solver.throw_error:
+                return None
+            raise RuntimeError("Failed solving: Inf found in solution")
+        self.solve_info = info
+        if np.any(info[:, 1] > self.residual_tol):
+            msg = f"linear solve residual {info[:, 1].max():.2e} exceeds residual_tol = {self.residual_tol:.1e} at iteration {next_iter}"
+            logger.critical(msg)
+            if fs.params_solver.throw_error:
+                raise RuntimeError(msg)
+            return None
+        self.iter = next_iter
+        self.t = self.params_time.Tstart + self.iter * self.params_time.dt
+        self._u_ctrl_prev = u_ctrl.copy()
+        if fs.params_solver.time_scheme != "cn":
+            self.order = 2
+        self.y_meas = y
+        runtime = (time.time() - t0) / k
+        for i, ex in enumerate(self.exporters):
+            ex.log(u_ctrl=u_ctrl[i], y_meas=y[i], dE=dE[i] if want_energy else np.nan, t=self.t, runtime=runtime)
+        return self.y_meas
+
+    # ── results ──────────────────────────────────────────────────────────────
+    def timeseries(self, i: int) -> pd.DataFrame:
+        return self.exporters[i].to_dataframe()
+
+    def state(self):
+        """(u_n, u_nn, p_n) of all runs, arrays (k, ·) — one download."""
+        return self.dev.get_state_batch()
+
+    def field(self, i: int) -> Function:
+        """Current perturbation (u, p) of run ``i`` as a mixed ``Function`` (downloads the batched state)."""
+        u_n, _, p_n = self.dev.get_state_batch()
+        return Function(self.fs.W, np.r_[u_n[i], p_n[i]])
+
+    def close(self) -> None:
+        if self._ready:
+            self.dev.set_batch(0)
+            self._ready = False
+
+
+__all__ = ["BatchedFlowSolver"]

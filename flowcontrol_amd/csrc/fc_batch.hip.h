@@ -1,0 +1,411 @@
+// Shared-operator batched stepping: k lock-step simulations on ONE handle (gfx950 / CDNA4, wave64).
+// Included by fc_hip.hip only.
+//
+// The reference's outer workloads are k runs of the SAME operator that differ in initial condition, control
+// input or controller (IC sweeps examples/lidcavity/batch_run_lidcavity.py:197-215, controller optimisation
+// utils/optim.py:95-102): the factors (O1: 176 MB) are the same for all of them.  A single run re-reads them
+// every step to advance ONE right-hand side; here every vector becomes a row-major matrix [row][KB]
+// (KB = 4, 8 or 16 simulations side by side, simulation index fastest) and every level of the factor sweep a
+// dense block product  (factor block) x (operand rows x KB)  on the fp64 matrix cores
+// (v_mfma_f64_16x16x4_f64): the factor bytes are streamed once per KB simulated steps.
+//
+//   fc_nd_block_b   one workgroup per task = up to 16 RT rows of ONE dense factor block of one tree node
+//                   ([D^-1 | -U] rows in the down-sweep, -L rows in the up-sweep) times the node's operand rows
+//                   (staged once per workgroup in LDS); the four waves split into RT row tiles x 4/RT column
+//                   groups, the column groups' accumulators are summed through LDS in a fixed order
+//   fc_nd_fold_b    up-sweep: a tree node's -L block writes its products to a private scratch row per
+//                   (node, boundary row); the rows of the next level add the scratch rows of their descendants in
+//                   a fixed order (bit-reproducible, no fp64 atomics)
+//   fc_rhs_elem_b / fc_rhs_gather_b / fc_tail_b / fc_final_b   the step kernels of fc_kernels.hip.h with the
+//                   simulation index as the fastest-running one (cell tables, gather lists, matrix rows and sensor
+//                   rows are read once for all KB simulations)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct __attribute__((aligned(16))) FcBTask {
+  long long val;  // offset of the task's first value (first row, column c0 of the node's block)
+  int ld;         // row stride of the block
+  int nrows;      // rows of this task (<= 16 RT)
+  int ncols;      // columns of this task: operand columns [c0, c0 + ncols) of the node
+  int c0;
+  int i0, ni;     // operand columns [0, ni): buffer rows i0 + c
+  int idx;        // operand columns [ni, ...): buffer rows idxlist[idx + c - ni]
+  int dst;        // first destination buffer row
+  int pad0, pad1;
+};
+
+#define FC_B_TW 256  // operand columns staged per LDS tile
+
+// LDS position of operand column c of a tile: inside every group of 8 columns, the columns a wave's four
+// k-lanes need in ONE matrix instruction (c = 8 j + 2 q + e for q = 0..3, see below) sit in 4 consecutive rows
+__device__ __forceinline__ int fc_b_pos(int c) { return (c & ~7) | ((c & 1) << 2) | ((c >> 1) & 3); }
+
+// v_mfma_f64_16x16x4_f64: lane l holds A[row l & 15][k = l >> 4], B[k = l >> 4][col l & 15];
+// D[row (l >> 4) + 4 r][col l & 15] in register r.  The k index of an instruction is free to stand for any four
+// columns as long as A and B agree: lane (row, q) loads the value PAIR at columns 8 j + 2 q, 8 j + 2 q + 1 of its
+// row (16 contiguous bytes; the four q lanes of a row cover 64 contiguous bytes) and feeds the pair to two
+// consecutive instructions.
+template <int KB>
+__global__ __launch_bounds__(256) void fc_nd_block_b(const FcBTask* __restrict__ tasks, const int* __restrict__ idxlist,
+                                                     const double* __restrict__ val, double* __restrict__ buf, int RT) {
+  __shared__ double Ys[FC_B_TW * KB > 1024 ? FC_B_TW * KB : 1024];
+  const FcBTask tk = tasks[blockIdx.x];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, lr = lane & 15, lq = lane >> 4;
+  const int CG = 4 / RT;                       // column groups
+  const int tile = wave % RT, grp = wave / RT;  // this wave: rows [16 tile, 16 tile + 16), 64-column chunks grp, grp + CG, ...
+  const bool wave_live = 16 * tile < tk.nrows;
+  // rows past the task's last one shadow it (valid addresses, results dropped at the store)
+  const int row = 16 * tile + lr < tk.nrows ? 16 * tile + lr : tk.nrows - 1;
+  const double* __restrict__ vrow = val + tk.val + (long long)row * tk.ld + 2 * lq;
+  fc_d4 acc = {0.0, 0.0, 0.0, 0.0};
+  const int nchunk = (tk.ncols + 63) >> 6;
+  // value chunk ch of this wave's rows: 8 pairs per lane; a pair beyond the task's columns is not loaded (it
+  // may read up to 7 values into the next row / block: finite numbers that meet zero operand rows)
+  double an[16];
+  auto load_chunk = [&](int ch) {
+    const int cb = ch << 6;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool ok = wave_live && cb + 8 * u < tk.ncols;
+      an[2 * u] = ok ? vrow[cb + 8 * u] : 0.0;
+      an[2 * u + 1] = ok ? vrow[cb + 8 * u + 1] : 0.0;
+    }
+  };
+  int ch = grp;  // next chunk of this wave
+  if (ch < nchunk) load_chunk(ch);  // in flight while the first operand tile is staged
+  for (int t0 = 0; t0 < tk.ncols; t0 += FC_B_TW) {
+    const int tl = tk.ncols - t0 < FC_B_TW ? tk.ncols - t0 : FC_B_TW;
+    const int tlp = (tl + 7) & ~7;
+    for (int e = t; e < tlp * KB; e += 256) {
+      const int c = e / KB, n = e % KB;
+      double v = 0.0;
+      if (c < tl) {
+        const int cc = tk.c0 + t0 + c;
+        const int src = cc < tk.ni ? tk.i0 + cc : idxlist[tk.idx + cc - tk.ni];
+        v = buf[(size_t)src * KB + n];
+      }
+      Ys[fc_b_pos(c) * KB + n] = v;
+    }
+    __syncthreads();
+    // this wave's chunks inside the tile
+    while (ch < nchunk && (ch << 6) < t0 + FC_B_TW) {
+      double a[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a[u] = an[u];
+      const int cb = ch << 6;
+      ch += CG;
+      if (ch < nchunk) load_chunk(ch);  // the next chunk streams in behind the matrix instructions of this one
+      const int cl = cb - t0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (wave_live && cb + 8 * u < tk.ncols) {  // wave-uniform
+          const double b0 = lr < KB ? Ys[(cl + 8 * u + lq) * KB + lr] : 0.0;
+          const double b1 = lr < KB ? Ys[(cl + 8 * u + 4 + lq) * KB + lr] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2 * u], b0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2 * u + 1], b1, acc, 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (CG > 1) {
+    // column groups -> one accumulator per row tile, summed in the order of the groups (reproducible)
+    double* red = Ys;  // 4 waves x 64 lanes x 4 doubles = 8 KB
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    if (grp != 0) return;
+    for (int g = 1; g < CG; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] += red[((tile + RT * g) * 4 + r) * 64 + lane];
+  }
+  if (lr < KB) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int orow = 16 * tile + lq + 4 * r;
+      if (orow < tk.nrows) buf[(size_t)(tk.dst + orow) * KB + lr] = acc[r];
+    }
+  }
+}
+
+// rows [row0, row0 + nrows) of the buffer half at dst_off: (+)= the sum of their source rows, in list order
+template <int KB>
+__global__ __launch_bounds__(256) void fc_nd_fold_b(int nrows, int row0, const int* __restrict__ fptr, const int* __restrict__ fsrc,
+                                                    double* __restrict__ buf, int dst_off, int accumulate) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int r = t / KB, s = t % KB;
+  if (r >= nrows) return;
+  const int i = row0 + r;
+  double* d = buf + (size_t)(dst_off + i) * KB + s;
+  const int q0 = fptr[i], q1 = fptr[i + 1];
+  double acc = accumulate ? *d : 0.0;
+  for (int base = q0; base < q1; base += 4) {
+    int id[4];
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) id[u] = base + u < q1 ? fsrc[base + u] : -1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = id[u] >= 0 ? buf[(size_t)id[u] * KB + s] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (id[u] >= 0) acc += v[u];
+  }
+  *d = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// step kernels, simulation index fastest.  State u_n / u_nn [2 nn][KB], p_n [nv][KB], controls
+// uctrl[s * ustride + a] (host-mapped record of simulation s).
+// ---------------------------------------------------------------------------------------------
+// fc_rhs_elem with 8 lanes per (cell, simulation): ev[(slot * nc + cell) * KB + s]
+template <int KB>
+__global__ __launch_bounds__(256) void fc_rhs_elem_b(int nc, int nn, const int* __restrict__ cn, const double* __restrict__ geom,
+                                                     const double* __restrict__ un, const double* __restrict__ unn,
+                                                     const double* __restrict__ fprof, int n_act, const double* __restrict__ uforce,
+                                                     int ustride, double cm_n, double cm_nn, double cc_n, double cc_nn,
+                                                     double* __restrict__ ev) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = t & 7, g = t >> 3;
+  const int s = g % KB, cl = g / KB;
+  const bool active = cl < nc;
+  const int c = active ? cl : 0;
+  const int q = lane < FC_NQ ? lane : FC_NQ - 1;
+  const double j00 = geom[c], j01 = geom[nc + c], j10 = geom[2 * nc + c], j11 = geom[3 * nc + c];
+  const double wq = lane < FC_NQ ? c_qw[q] * 0.5 * geom[4 * nc + c] : 0.0;
+  double ux = 0, uy = 0, uxi = 0, uet = 0, vxi = 0, vet = 0;
+  double wx = 0, wy = 0, wxi = 0, wet = 0, zxi = 0, zet = 0;
+  double gx = 0, gy = 0;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    const int n = cn[a * nc + c];
+    const double ax = un[(size_t)n * KB + s], ay = un[(size_t)(nn + n) * KB + s];
+    const double bx = unn[(size_t)n * KB + s], by = unn[(size_t)(nn + n) * KB + s];
+    double fx = 0.0, fy = 0.0;
+    for (int k = 0; k < n_act; ++k) {
+      const double uk = uforce[s * ustride + k];
+      fx += uk * fprof[(size_t)k * 2 * nn + n];
+      fy += uk * fprof[(size_t)k * 2 * nn + nn + n];
+    }
+    const double ph = c_phi2[q * 6 + a], dx = c_dphi2[(q * 6 + a) * 2], de = c_dphi2[(q * 6 + a) * 2 + 1];
+    ux += ph * ax;
+    uy += ph * ay;
+    uxi += dx * ax;
+    uet += de * ax;
+    vxi += dx * ay;
+    vet += de * ay;
+    wx += ph * bx;
+    wy += ph * by;
+    wxi += dx * bx;
+    wet += de * bx;
+    zxi += dx * by;
+    zet += de * by;
+    gx += ph * fx;
+    gy += ph * fy;
+  }
+  const double ux_x = uxi * j00 + uet * j10, ux_y = uxi * j01 + uet * j11;
+  const double uy_x = vxi * j00 + vet * j10, uy_y = vxi * j01 + vet * j11;
+  const double wx_x = wxi * j00 + wet * j10, wx_y = wxi * j01 + wet * j11;
+  const double wy_x = zxi * j00 + zet * j10, wy_y = zxi * j01 + zet * j11;
+  gx += cm_n * ux + cm_nn * wx + cc_n * (ux * ux_x + uy * ux_y) + cc_nn * (wx * wx_x + wy * wx_y);
+  gy += cm_n * uy + cm_nn * wy + cc_n * (ux * uy_x + uy * uy_y) + cc_nn * (wx * wy_x + wy * wy_y);
+  gx *= wq;
+  gy *= wq;
+  const int a = lane < 6 ? lane : 5;
+  double accx = 0.0, accy = 0.0;
+#pragma unroll
+  for (int p = 0; p < FC_NQ; ++p) {
+    const double pa = c_phi2[p * 6 + a];
+    accx += pa * __shfl(gx, p, 8);
+    accy += pa * __shfl(gy, p, 8);
+  }
+  if (active && lane < 6) {
+    ev[((size_t)lane * nc + c) * KB + s] = accx;
+    ev[((size_t)(6 + lane) * nc + c) * KB + s] = accy;
+  }
+}
+
+// fc_rhs_gather, one thread per (permuted row, simulation)
+template <int KB>
+__global__ __launch_bounds__(256) void fc_rhs_gather_b(int N, const int* __restrict__ gptr, const int* __restrict__ gidx,
+                                                       const double* __restrict__ ev, const int* __restrict__ bcslot,
+                                                       const double* __restrict__ bcprof, const double* __restrict__ lift, int n_act,
+                                                       const double* __restrict__ uctrl, int ustride, double* __restrict__ b,
+                                                       double* __restrict__ y, const int* __restrict__ c_rowptr,
+                                                       const int* __restrict__ c_col, const double* __restrict__ c_val,
+                                                       const double* __restrict__ un) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t / KB, s = t % KB;
+  if (i >= N) return;
+  double acc = 0.0;
+  const int bs = bcslot[i];
+  if (bs >= 0) {
+    for (int k = 0; k < n_act; ++k) acc += uctrl[s * ustride + k] * bcprof[(size_t)bs * n_act + k];
+  } else {
+    const int k0 = gptr[i], k1 = gptr[i + 1];
+    for (int base = k0; base < k1; base += 8) {
+      int id[8];
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) id[u] = base + u < k1 ? gidx[base + u] : -1;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = id[u] >= 0 ? ev[(size_t)id[u] * KB + s] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (id[u] >= 0) acc += v[u];
+    }
+    for (int k = 0; k < n_act; ++k) acc -= uctrl[s * ustride + k] * lift[(size_t)k * N + i];
+    if (c_rowptr)
+      for (int k = c_rowptr[i]; k < c_rowptr[i + 1]; ++k) acc -= c_val[k] * un[(size_t)c_col[k] * KB + s];
+  }
+  b[(size_t)i * KB + s] = acc;
+  y[(size_t)i * KB + s] = acc;
+}
+
+// fc_tail for KB simulations.  Row workgroups: 4 KB lanes per permuted row (lane = j KB + s: simulation s, every
+// fourth matrix entry from j), the matrix row is read once for all simulations.  Cell workgroups (first in the grid):
+// thread = (cell, Radon point, simulation).  partial[(w * G + block) * KB + s], w = 0: sum r^2, 1: sum b^2, 2: sum e.
+template <int KB>
+__global__ __launch_bounds__(256) void fc_tail_b(int N, int nn2, const int* __restrict__ perm, const double* __restrict__ x,
+                                                 const double* __restrict__ b, const int* __restrict__ a_rowptr,
+                                                 const int* __restrict__ a_col, const double* __restrict__ a_val, int n_row_blocks,
+                                                 int reps, int nc, const int* __restrict__ cn, const double* __restrict__ geom,
+                                                 const int* __restrict__ iperm, double* __restrict__ up, double* __restrict__ u_n,
+                                                 double* __restrict__ u_nn, double* __restrict__ p_n, int* __restrict__ flag,
+                                                 double* __restrict__ partial) {
+  constexpr int LPR = 4 * KB, RPB = 256 / LPR;  // lanes per row, rows per workgroup and repetition
+  constexpr int CPB = 256 / (8 * KB);           // cells per cell workgroup and repetition
+  const int t = threadIdx.x, s = t % KB;
+  const int G = gridDim.x;
+  const int n_cell_blocks = G - n_row_blocks;
+  const int rb = (int)blockIdx.x - n_cell_blocks;
+  double r2 = 0.0, b2 = 0.0, e = 0.0;
+  if (rb >= 0) {
+    const int j = (t % LPR) / KB;
+    for (int rep = 0; rep < reps; ++rep) {
+      const int i = (rb * reps + rep) * RPB + t / LPR;
+      double sa = 0.0;
+      if (i < N) {
+        const int k0 = a_rowptr[i], k1 = a_rowptr[i + 1];
+        double s0 = 0.0, s1 = 0.0;
+        for (int base = k0; base < k1; base += 8) {
+          const int ka = base + j, kb = ka + 4;
+          const int ca = ka < k1 ? a_col[ka] : 0, cb = kb < k1 ? a_col[kb] : 0;
+          const double va = ka < k1 ? a_val[ka] : 0.0, vb = kb < k1 ? a_val[kb] : 0.0;
+          s0 += va * x[(size_t)ca * KB + s];
+          s1 += vb * x[(size_t)cb * KB + s];
+        }
+        sa = s0 + s1;
+      }
+      sa += __shfl_down(sa, 2 * KB, LPR);
+      sa += __shfl_down(sa, KB, LPR);
+      if (i < N && j == 0) {
+        const int r = perm[i];
+        const double v = x[(size_t)i * KB + s];
+        const double bb = b[(size_t)i * KB + s], res = bb - sa;
+        r2 += res * res;
+        b2 += bb * bb;
+        up[(size_t)r * KB + s] = v;
+        if (r < nn2) {
+          u_nn[(size_t)r * KB + s] = u_n[(size_t)r * KB + s];
+          u_n[(size_t)r * KB + s] = v;
+          if (!isfinite(v)) atomicOr(flag + s, 1);
+        } else {
+          p_n[(size_t)(r - nn2) * KB + s] = v;
+        }
+      }
+    }
+  } else {
+    const int q = (t / KB) % 8;
+    for (int rep = 0; rep < reps; ++rep) {
+      const int c = ((int)blockIdx.x * reps + rep) * CPB + t / (8 * KB);
+      if (c < nc && q < FC_NQ) {
+        double ux = 0.0, uy = 0.0;
+        const int nn = nn2 >> 1;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          const int n = cn[(size_t)a * nc + c];
+          const double ph = c_phi2[q * 6 + a];
+          ux += ph * x[(size_t)iperm[n] * KB + s];
+          uy += ph * x[(size_t)iperm[nn + n] * KB + s];
+        }
+        e += c_qw[q] * 0.5 * geom[4 * (size_t)nc + c] * (ux * ux + uy * uy);
+      }
+    }
+  }
+  // threads t, t + KB, t + 2 KB, ... belong to the same simulation
+  __shared__ double red[3][256];
+  red[0][t] = r2;
+  red[1][t] = b2;
+  red[2][t] = e;
+  __syncthreads();
+  for (int st = 128; st >= KB; st >>= 1) {
+    if (t < st) {
+      red[0][t] += red[0][t + st];
+      red[1][t] += red[1][t + st];
+      red[2][t] += red[2][t + st];
+    }
+    __syncthreads();
+  }
+  if (t < KB) {
+    partial[((size_t)0 * G + blockIdx.x) * KB + t] = red[0][t];
+    partial[((size_t)1 * G + blockIdx.x) * KB + t] = red[1][t];
+    partial[((size_t)2 * G + blockIdx.x) * KB + t] = red[2][t];
+  }
+}
+
+// fc_final for simulation s = blockIdx.x: folds its partials, evaluates the sensor rows on its column of `up`,
+// publishes its record (fc_publish: checksummed, the host polls it)
+template <int KB>
+__global__ __launch_bounds__(256) void fc_final_b(int G, int n_cell_blocks, const double* __restrict__ partial, int n_sens,
+                                                  const int* __restrict__ s_rowptr, const int* __restrict__ s_idx,
+                                                  const double* __restrict__ s_w, const double* __restrict__ up,
+                                                  const int* __restrict__ flag, double* __restrict__ rec, int rstride, double seq,
+                                                  int compute_energy) {
+  const int s = blockIdx.x, t = threadIdx.x;
+  __shared__ double red[3][256];
+  __shared__ double ysh[64];
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  for (int i = t; i < G; i += 256) {
+    a0 += partial[((size_t)0 * G + i) * KB + s];
+    a1 += partial[((size_t)1 * G + i) * KB + s];
+    if (i < n_cell_blocks) a2 += partial[((size_t)2 * G + i) * KB + s];
+  }
+  const int wave = t >> 6, lane = t & 63;
+  for (int q = wave; q < n_sens; q += 4) {
+    double acc = 0.0;
+    for (int k = s_rowptr[q] + lane; k < s_rowptr[q + 1]; k += 64) acc += s_w[k] * up[(size_t)s_idx[k] * KB + s];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) ysh[q] = acc;
+  }
+  red[0][t] = a0;
+  red[1][t] = a1;
+  red[2][t] = a2;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (t < st) {
+      red[0][t] += red[0][t + st];
+      red[1][t] += red[1][t + st];
+      red[2][t] += red[2][t + st];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    double* r = rec + (size_t)s * rstride;
+    fc_publish(ysh, n_sens, compute_energy ? 0.5 * red[2][0] : 0.0, red[0][0], red[1][0], (double)(flag[s] & 1), r + 64, r + 128, r + 129,
+               r + 136, r + 137, seq);
+  }
+}
+
+// host <-> device layout change of a state block: dev[i * KB + s] <-> host[s * n + i]
+template <int KB>
+__global__ void fc_b_interleave(int n, int k, const double* __restrict__ src, double* __restrict__ dst, int to_device) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t / KB, s = t % KB;
+  if (i >= n) return;
+  if (to_device)
+    dst[(size_t)i * KB + s] = s < k ? src[(size_t)s * n + i] : 0.0;
+  else if (s < k)
+    dst[(size_t)s * n + i] = src[(size_t)i * KB + s];
+}

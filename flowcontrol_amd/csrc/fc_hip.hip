@@ -24,6 +24,7 @@
 #include "fc_kernels.hip.h"
 #include "fc_dag.hip.h"
 #include "fc_front.hip.h"
+#include "fc_batch.hip.h"
 #include "fc_symbolic.hpp"
 
 namespace {
@@ -271,6 +272,27 @@ struct fc_ctx {
   size_t tused = 0;
   double t_ms[2] = {0.0, 0.0};
   int64_t t_cnt[2] = {0, 0};
+  // batched stepping (fc_set_batch): k lock-step simulations that share the operators and the factors of this handle;
+  // every vector is a matrix [row][KB] (fc_batch.hip.h)
+  struct BLaunch {
+    int kind;  // 0: fc_nd_block_b over tasks [first, first + count) with RT row tiles per workgroup; 1: fc_nd_fold_b
+    int first, count, rt;
+    int row0, nrows, dst_off, accumulate;
+  };
+  struct Batch {
+    int k = 0, KB = 0;
+    bool tables = false;
+    DevBuf<double> u_n, u_nn, p_n, up, b, buf, ev, partial;  // buf = [y (N) | x (N) | scratch] rows of KB
+    DevBuf<int> flag;                                        // [KB] non-finite velocity seen, per simulation
+    DevBuf<FcBTask> tasks;
+    DevBuf<int> fptr, fsrc;       // up-sweep fold lists: permuted row -> scratch rows (absolute buffer rows) of its descendants
+    std::vector<BLaunch> launches;
+    int64_t scratch_rows = 0, factor_values = 0;
+    double vec_rows = 0.0;        // operand / result rows moved per apply (x KB x 8 B)
+    bool pending = false;
+    int pend_slot = 0, pend_energy = 0;
+    double pend_seq = 0.0;
+  } bat;
 };
 
 namespace {
@@ -1459,6 +1481,8 @@ int fc_set_bc(fc_handle h, int32_t n_bc, const int32_t* bc_dofs, int32_t n_act, 
     if (a != b && h->sym_ready) {
       h->sym_ready = false;
       h->have_plan = false;
+      h->bat.tables = false;  // and the batched launch tables with it (fc_set_batch rebuilds them)
+      h->bat.k = h->bat.KB = 0;
       for (int o = 0; o < 2; ++o) h->sys[o].structured = h->sys[o].dag_ready = false;
     }
   }
@@ -1745,12 +1769,11 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
   }
   if (n_idx > 0) FCCHK(S.f_idx.upload(idx, (size_t)n_idx, h->stream));
   else FCCHK(S.f_idx.alloc(1));
-  if (vals) {
-    FCCHK(S.f_val.upload(vals, (size_t)n_val, h->stream));
-  } else {  // structure only: the values are computed on the device (fc_refactor)
-    FCCHK(S.f_val.alloc((size_t)n_val));
-    FCCHK(S.f_val.zero(h->stream));
-  }
+  // 64 zero values behind the last block: the batched block kernel (fc_nd_block_b) reads value pairs in groups of 8
+  // columns and may touch up to 7 values past the end of a row (they meet zero operand rows)
+  FCCHK(S.f_val.alloc((size_t)n_val + 64));
+  FCCHK(S.f_val.zero(h->stream));
+  if (vals) HIPCHK(hipMemcpyAsync(S.f_val.p, vals, (size_t)n_val * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   S.truncated = false;
   for (const Stage& st : S.stages) S.truncated = S.truncated || st.kind == 2;
@@ -2481,8 +2504,11 @@ int fc_setup_solver(fc_handle h, int slot, int32_t depth, int32_t merge, int32_t
   if (truncate == 0 && (world == 1 ? !h->partitioned : exchanges(h))) {
     std::vector<double> b((size_t)N), x((size_t)N);
     for (int i = 0; i < N; ++i) b[i] = std::cos(0.37 * i + 0.1);
-    if (h->pn_shift > 0)
-      for (int i = 2 * h->nn; i < N; ++i) b[i] = 0.0;  // compatible with the constant-pressure null space of an enclosed flow
+    // enclosed flow: a right-hand side compatible with the constant-pressure null space.  Decided by the GLOBAL pin
+    // (h->pin_dof), not by pn_shift: on a partitioned handle only the rank that eliminates the pinned dof carries a
+    // shift, and the ranks of a collective fc_solve must all build the same right-hand side.
+    if (h->pin_dof >= 0)
+      for (int i = 2 * h->nn; i < N; ++i) b[i] = 0.0;
     double info[4];
     FCCHK(fc_set_solver_options(h, FC_METHOD_REFINE, 0, 1e-10, 1));
     FCCHK(fc_solve(h, slot, b.data(), x.data(), info));
@@ -3256,6 +3282,8 @@ int fc_comm_unique_id(char* out128) {
 static void forget_solver_structure(fc_ctx* h) {
   h->sym_ready = false;
   h->have_plan = false;
+  h->bat.tables = false;
+  h->bat.k = h->bat.KB = 0;
   for (int o = 0; o < 2; ++o) h->sys[o].ready = h->sys[o].structured = h->sys[o].dag_ready = false;
 }
 
@@ -3313,6 +3341,440 @@ int fc_algorithmic_bytes(fc_handle h, int slot, double* sweep_bytes, double* spm
   // the in-step SpMV runs on the permuted system matrix (same nnz as the slot up to explicit zeros)
   const double nz = h->sys[slot].Ap_nnz > 0 ? (double)h->sys[slot].Ap_nnz : (double)h->nnz;
   if (spmv_bytes) *spmv_bytes = nz * 12.0 + (double)h->N * 16.0 + (double)(h->N + 1) * 4.0;
+  return FC_OK;
+}
+
+// ── shared-operator batched stepping (fc_batch.hip.h): k lock-step simulations per handle ─────────────────────────────
+// Replaces k independent FlowSolver instances stepping the SAME operator (IC sweeps
+// examples/lidcavity/batch_run_lidcavity.py:197-215, controller optimisation utils/optim.py:95-102).
+constexpr int kRecStride = 160;  // doubles per simulation in the host-mapped record: the single-simulation layout, repeated
+
+// launch tables of the batched factor apply from the symbolic phase of fc_setup_solver: per tree level one block launch
+// (-L blocks on the way up, [D^-1 | -U] blocks on the way down) and, on the way up, one fold launch
+static int build_batch_tables(fc_ctx* h) {
+  fc_ctx::Batch& B = h->bat;
+  if (B.tables) return FC_OK;
+  if (!h->sym_ready) return fail(FC_ERR_NOT_READY, "fc_set_batch: fc_setup_solver must have run (batched stepping uses the in-library analysis)");
+  if (h->partitioned || h->sym_truncate > 0) return fail(FC_ERR_INVALID, "fc_set_batch: single-GPU handles with full factors only");
+  const fcsym::Factors& fac = h->sym_fac;
+  const fcsym::Tree& t = h->sym_tree;
+  const int N = h->N;
+  const size_t G = fac.nodes.size() / 7;
+  auto nd = [&](size_t g, int f) { return fac.nodes[g * 7 + (size_t)f]; };  // level, n, i0, ni, nb, voff, ioff
+  std::vector<int64_t> soff(G, 0);
+  int64_t S = 0;
+  for (size_t g = 0; g < G; ++g) {
+    soff[g] = S;
+    S += nd(g, 4);
+  }
+  if (2 * (int64_t)N + S > (int64_t)std::numeric_limits<int>::max() / 16) return fail(FC_ERR_INVALID, "fc_set_batch: mesh too large for int32 buffer rows");
+  // fold lists: destination row -> scratch rows, nodes in elimination order (deepest first): the order of the
+  // single-simulation segment lists
+  std::vector<int> fptr((size_t)N + 1, 0);
+  for (size_t g = 0; g < G; ++g)
+    for (int64_t j = 0; j < nd(g, 4); ++j) fptr[(size_t)(fac.idx[(size_t)(nd(g, 6) + j)] - N) + 1]++;
+  for (int i = 0; i < N; ++i) fptr[(size_t)i + 1] += fptr[(size_t)i];
+  std::vector<int> fsrc((size_t)std::max(1, fptr[(size_t)N]));
+  {
+    std::vector<int> fill(fptr.begin(), fptr.end() - 1);
+    for (size_t g = 0; g < G; ++g)
+      for (int64_t j = 0; j < nd(g, 4); ++j) fsrc[(size_t)fill[(size_t)(fac.idx[(size_t)(nd(g, 6) + j)] - N)]++] = (int)(2 * (int64_t)N + soff[g] + j);
+  }
+  std::vector<FcBTask> tasks;
+  B.launches.clear();
+  B.factor_values = 0;
+  B.vec_rows = 0.0;
+  static const int min_wg = [] { const char* e = std::getenv("FC_BATCH_MIN_WG"); return e ? std::max(1, std::atoi(e)) : 768; }();
+  static const int force_rt = [] { const char* e = std::getenv("FC_BATCH_RT"); return e ? std::atoi(e) : 0; }();
+  // one block launch for all nodes of `level`: up = the -L blocks (nb x ni), else the [D^-1 | -U] rows (ni x nf)
+  auto emit = [&](int level, bool up) {
+    std::vector<size_t> sel;
+    int64_t rows_total = 0;
+    for (size_t g = 0; g < G; ++g)
+      if (nd(g, 0) == level && nd(g, 3) > 0 && (!up || nd(g, 4) > 0)) {
+        sel.push_back(g);
+        rows_total += up ? nd(g, 4) : nd(g, 3);
+      }
+    if (sel.empty()) return;
+    // row tiles per workgroup: as many as keep the grid above min_wg workgroups (fewer operand stagings per value)
+    int rt = 1;
+    for (int cand : {4, 2}) {
+      int64_t wgs = 0;
+      for (size_t g : sel) wgs += ((up ? nd(g, 4) : nd(g, 3)) + 16 * cand - 1) / (16 * cand);
+      const double mean_rows = (double)rows_total / (double)sel.size();
+      if (wgs >= min_wg && mean_rows > 8.0 * cand) {
+        rt = cand;
+        break;
+      }
+    }
+    if (force_rt == 1 || force_rt == 2 || force_rt == 4) rt = force_rt;
+    const int first = (int)tasks.size();
+    for (size_t g : sel) {
+      const int64_t i0 = nd(g, 2), ni = nd(g, 3), nb = nd(g, 4), voff = nd(g, 5), ioff = nd(g, 6), nf = ni + nb;
+      const int64_t rows = up ? nb : ni, ld = up ? ni : nf, base = up ? voff + ni * nf : voff;
+      for (int64_t r0 = 0; r0 < rows; r0 += 16 * rt) {
+        FcBTask tk = {};
+        tk.val = base + r0 * ld;
+        tk.ld = (int)ld;
+        tk.nrows = (int)std::min<int64_t>(16 * rt, rows - r0);
+        tk.ncols = (int)ld;
+        tk.c0 = 0;
+        tk.i0 = (int)i0;
+        tk.ni = (int)ni;
+        tk.idx = (int)ioff;
+        tk.dst = up ? (int)(2 * (int64_t)N + soff[g] + r0) : (int)(N + i0 + r0);
+        tasks.push_back(tk);
+      }
+      B.factor_values += rows * ld;
+      B.vec_rows += (double)ld + (double)rows;
+    }
+    B.launches.push_back({0, first, (int)tasks.size() - first, rt, 0, 0, 0, 0});
+  };
+  for (int k = t.depth; k >= 1; --k) {
+    emit(k, true);
+    const int64_t r0 = t.node_ptr[(size_t)k - 1].front(), r1 = t.node_ptr[(size_t)k - 1].back();
+    if (r1 > r0) {
+      B.launches.push_back({1, 0, 0, 0, (int)r0, (int)(r1 - r0), 0, 1});
+      B.vec_rows += 2.0 * (double)(r1 - r0) + (double)(fptr[(size_t)r1] - fptr[(size_t)r0]);
+    }
+  }
+  for (int k = 0; k <= t.depth; ++k) emit(k, false);
+  if (tasks.empty()) return fail(FC_ERR_INVALID, "fc_set_batch: empty factor structure");
+  B.scratch_rows = S;
+  FCCHK(B.tasks.upload(tasks, h->stream));
+  FCCHK(B.fptr.upload(fptr, h->stream));
+  FCCHK(B.fsrc.upload(fsrc, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  B.tables = true;
+  return FC_OK;
+}
+
+#define FC_KB_DISPATCH(KBV, CALL4, CALL8, CALL16) \
+  do {                                            \
+    if ((KBV) == 4) {                             \
+      CALL4;                                      \
+    } else if ((KBV) == 8) {                      \
+      CALL8;                                      \
+    } else {                                      \
+      CALL16;                                     \
+    }                                             \
+  } while (0)
+
+// x (rows N .. 2N of bat.buf) = M^-1 y (rows 0 .. N) for all KB columns
+static int batch_apply(fc_ctx* h, OrderSys& S) {
+  fc_ctx::Batch& B = h->bat;
+  double* buf = B.buf.p;
+  FCCHK(time_begin(h, 0, (int)B.launches.size()));
+  for (const fc_ctx::BLaunch& L : B.launches) {
+    if (L.kind == 0) {
+      const FcBTask* tp = B.tasks.p + L.first;
+#define FC_BLK(K) hipLaunchKernelGGL((fc_nd_block_b<K>), dim3(L.count), dim3(256), 0, h->stream, tp, S.f_idx.p, S.f_val.p, buf, L.rt)
+      FC_KB_DISPATCH(B.KB, FC_BLK(4), FC_BLK(8), FC_BLK(16));
+#undef FC_BLK
+    } else {
+      const int g = nblocks((int64_t)L.nrows * B.KB, 256);
+#define FC_FOLD(K) hipLaunchKernelGGL((fc_nd_fold_b<K>), dim3(g), dim3(256), 0, h->stream, L.nrows, L.row0, B.fptr.p, B.fsrc.p, buf, L.dst_off, L.accumulate)
+      FC_KB_DISPATCH(B.KB, FC_FOLD(4), FC_FOLD(8), FC_FOLD(16));
+#undef FC_FOLD
+    }
+  }
+  FCCHK(time_end(h));
+  HIPCHK(hipGetLastError());
+  return FC_OK;
+}
+
+int fc_set_batch(fc_handle h, int32_t k) {
+  if (!h || k < 0 || k > 16) return fail(FC_ERR_INVALID, "fc_set_batch: k must be in [0, 16]");
+  if (h->bat.pending || h->step_pending) return fail(FC_ERR_INVALID, "fc_set_batch: a step is in flight");
+  HIPCHK(hipSetDevice(h->device));
+  fc_ctx::Batch& B = h->bat;
+  if (k == 0) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    B.u_n.release(), B.u_nn.release(), B.p_n.release(), B.up.release(), B.b.release(), B.buf.release(), B.ev.release(), B.partial.release();
+    B.flag.release();
+    B.k = B.KB = 0;
+    return FC_OK;
+  }
+  FCCHK(build_batch_tables(h));
+  const int KB = k <= 4 ? 4 : (k <= 8 ? 8 : 16);
+  const size_t N = (size_t)h->N, nn2 = 2 * (size_t)h->nn;
+  if (KB != B.KB) {
+    FCCHK(B.u_n.alloc(nn2 * KB));
+    FCCHK(B.u_nn.alloc(nn2 * KB));
+    FCCHK(B.p_n.alloc((size_t)h->nv * KB));
+    FCCHK(B.up.alloc(N * KB));
+    FCCHK(B.b.alloc(N * KB));
+    FCCHK(B.buf.alloc((2 * N + (size_t)B.scratch_rows) * KB));
+    FCCHK(B.ev.alloc((size_t)12 * h->nc * KB));
+    FCCHK(B.partial.alloc((size_t)3 * 8192 * KB));
+    FCCHK(B.flag.alloc(16));
+  }
+  B.k = k;
+  B.KB = KB;
+  for (DevBuf<double>* d : {&B.u_n, &B.u_nn, &B.p_n, &B.up, &B.b, &B.buf, &B.ev, &B.partial}) FCCHK(d->zero(h->stream));
+  FCCHK(B.flag.zero(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return FC_OK;
+}
+
+static int batch_check(fc_ctx* h, int32_t k, const char* who) {
+  if (!h) return fail(FC_ERR_INVALID, "null handle");
+  if (h->bat.k == 0) return fail(FC_ERR_NOT_READY, std::string(who) + ": fc_set_batch not called");
+  if (k != h->bat.k) return fail(FC_ERR_INVALID, std::string(who) + ": k differs from fc_set_batch");
+  return FC_OK;
+}
+
+// host [k][n] <-> device [n][KB]
+static int batch_copy(fc_ctx* h, int n, double* host, double* dev, bool to_device) {
+  fc_ctx::Batch& B = h->bat;
+  DevBuf<double> stage;
+  FCCHK(stage.alloc((size_t)n * B.k));
+  const int g = nblocks((int64_t)n * B.KB, 256);
+  if (to_device) HIPCHK(hipMemcpyAsync(stage.p, host, (size_t)n * B.k * sizeof(double), hipMemcpyHostToDevice, h->stream));
+#define FC_IL(K) hipLaunchKernelGGL((fc_b_interleave<K>), dim3(g), dim3(256), 0, h->stream, n, B.k, to_device ? stage.p : dev, to_device ? dev : stage.p, to_device ? 1 : 0)
+  FC_KB_DISPATCH(B.KB, FC_IL(4), FC_IL(8), FC_IL(16));
+#undef FC_IL
+  if (!to_device) HIPCHK(hipMemcpyAsync(host, stage.p, (size_t)n * B.k * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return FC_OK;
+}
+
+int fc_set_state_batch(fc_handle h, int32_t k, const double* u_n, const double* u_nn, const double* p_n) {
+  FCCHK(batch_check(h, k, "fc_set_state_batch"));
+  if (!u_n || !u_nn) return fail(FC_ERR_INVALID, "fc_set_state_batch: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  fc_ctx::Batch& B = h->bat;
+  FCCHK(batch_copy(h, 2 * h->nn, const_cast<double*>(u_n), B.u_n.p, true));
+  FCCHK(batch_copy(h, 2 * h->nn, const_cast<double*>(u_nn), B.u_nn.p, true));
+  if (p_n) FCCHK(batch_copy(h, h->nv, const_cast<double*>(p_n), B.p_n.p, true));
+  FCCHK(B.flag.zero(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return FC_OK;
+}
+
+int fc_get_state_batch(fc_handle h, int32_t k, double* u_n, double* u_nn, double* p_n) {
+  FCCHK(batch_check(h, k, "fc_get_state_batch"));
+  HIPCHK(hipSetDevice(h->device));
+  fc_ctx::Batch& B = h->bat;
+  if (u_n) FCCHK(batch_copy(h, 2 * h->nn, u_n, B.u_n.p, false));
+  if (u_nn) FCCHK(batch_copy(h, 2 * h->nn, u_nn, B.u_nn.p, false));
+  if (p_n) FCCHK(batch_copy(h, h->nv, p_n, B.p_n.p, false));
+  return FC_OK;
+}
+
+int fc_get_solution_batch(fc_handle h, int32_t k, double* up) {
+  FCCHK(batch_check(h, k, "fc_get_solution_batch"));
+  if (!up) return fail(FC_ERR_INVALID, "fc_get_solution_batch: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  return batch_copy(h, h->N, up, h->bat.up.p, false);
+}
+
+// the launches of one batched step; controls are read from the host-mapped record (uctrl at s * kRecStride, body-force
+// amplitudes at s * kRecStride + 32), every simulation's outputs go to its own record
+static int batch_enqueue(fc_ctx* h, int order_slot, int compute_energy, double seq) {
+  fc_ctx::Batch& B = h->bat;
+  OrderSys& S = h->sys[order_slot];
+  const StepCoeffs c = coeffs_for(h, order_slot);
+  const int KB = B.KB, N = h->N, nc = h->nc;
+  const double* uc = h->pin_dev;
+  const double* uf = h->pin_dev + 32;
+  const int g_elem = nblocks((int64_t)nc * 8 * KB, 256), g_rows = nblocks((int64_t)N * KB, 256);
+#define FC_ELEM(K) hipLaunchKernelGGL((fc_rhs_elem_b<K>), dim3(g_elem), dim3(256), 0, h->stream, nc, h->nn, h->cn.p, h->geom.p, B.u_n.p, B.u_nn.p, \
+                                      h->have_force ? h->fprof.p : nullptr, h->have_force ? h->n_act : 0, uf, kRecStride, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, B.ev.p)
+  FC_KB_DISPATCH(KB, FC_ELEM(4), FC_ELEM(8), FC_ELEM(16));
+#undef FC_ELEM
+#define FC_GATH(K) hipLaunchKernelGGL((fc_rhs_gather_b<K>), dim3(g_rows), dim3(256), 0, h->stream, N, h->gptr_p.p, h->gidx_p.p, B.ev.p, h->bcslot_p.p, \
+                                      h->bcprof.p, S.lift_p.p, h->n_act, uc, kRecStride, B.b.p, B.buf.p, S.have_c ? S.c_rowptr.p : nullptr, S.c_col.p, \
+                                      S.c_val.p, B.u_n.p)
+  FC_KB_DISPATCH(KB, FC_GATH(4), FC_GATH(8), FC_GATH(16));
+#undef FC_GATH
+  FCCHK(batch_apply(h, S));
+  // tail: residual monitor, scatter / shift, energy; <= ~2000 workgroups per kind
+  const int rpb = 256 / (4 * KB), cpb = 256 / (8 * KB);
+  const int reps = std::max(1, nblocks(nblocks(N, rpb), 2048));
+  const int n_row_blocks = nblocks(N, rpb * reps), n_cell_blocks = compute_energy ? nblocks(nc, cpb * reps) : 0;
+  const int G = n_row_blocks + n_cell_blocks;
+  if ((size_t)3 * G * KB > B.partial.n) return fail(FC_ERR_INVALID, "fc_step_batch: partial buffer too small");
+#define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, B.buf.p + (size_t)N * K, B.b.p, S.Ap_rowptr.p, \
+                                       S.Ap_col.p, S.Ap_val.p, n_row_blocks, reps, nc, h->cn.p, h->geom.p, h->iperm.p, B.up.p, B.u_n.p, B.u_nn.p, B.p_n.p,      \
+                                       B.flag.p, B.partial.p)
+  FC_KB_DISPATCH(KB, FC_TAILB(4), FC_TAILB(8), FC_TAILB(16));
+#undef FC_TAILB
+#define FC_FINB(K) hipLaunchKernelGGL((fc_final_b<K>), dim3(B.k), dim3(256), 0, h->stream, G, n_cell_blocks, B.partial.p, h->n_sens, h->s_rowptr.p, h->s_idx.p, \
+                                      h->s_w.p, B.up.p, B.flag.p, h->pin_dev, kRecStride, seq, compute_energy)
+  FC_KB_DISPATCH(KB, FC_FINB(4), FC_FINB(8), FC_FINB(16));
+#undef FC_FINB
+  HIPCHK(hipGetLastError());
+  return FC_OK;
+}
+
+static int batch_ready(fc_ctx* h, int order_slot, int32_t k, const char* who) {
+  FCCHK(batch_check(h, k, who));
+  FCCHK(check_step_ready(h, order_slot));
+  OrderSys& S = h->sys[order_slot];
+  if (!S.ready) return fail(FC_ERR_NOT_READY, std::string(who) + ": fc_setup_solver not called for this order");
+  if (h->method != FC_METHOD_REFINE || h->max_iter != 0) return fail(FC_ERR_INVALID, std::string(who) + ": batched steps apply the factors directly (FC_METHOD_REFINE, no refinement sweeps)");
+  if (h->partitioned || S.truncated) return fail(FC_ERR_INVALID, std::string(who) + ": single-GPU handles with full factors only");
+  if (h->n_act > 32 || h->n_sens > 64) return fail(FC_ERR_INVALID, std::string(who) + ": at most 32 actuators and 64 sensors");
+  if (kRecStride * 16 > kPinDoubles) return fail(FC_ERR_INVALID, "record too small");
+  return FC_OK;
+}
+
+int fc_step_batch_begin(fc_handle h, int order_slot, int32_t k, const double* u_ctrl, const double* u_force, int compute_energy) {
+  FCCHK(batch_ready(h, order_slot, k, "fc_step_batch"));
+  if (h->n_act > 0 && !u_ctrl) return fail(FC_ERR_INVALID, "fc_step_batch: u_ctrl is null");
+  if (h->bat.pending || h->step_pending) return fail(FC_ERR_INVALID, "fc_step_batch_begin: the previous step was not collected");
+  HIPCHK(hipSetDevice(h->device));
+  h->pre_slot = -1;
+  volatile double* pin = h->pin;
+  for (int s = 0; s < h->bat.KB; ++s)
+    for (int a = 0; a < h->n_act; ++a) {
+      pin[s * kRecStride + a] = s < k ? u_ctrl[(size_t)s * h->n_act + a] : 0.0;
+      pin[s * kRecStride + 32 + a] = s < k ? (u_force ? u_force[(size_t)s * h->n_act + a] : u_ctrl[(size_t)s * h->n_act + a]) : 0.0;
+    }
+  fc_ctx::Batch& B = h->bat;
+  B.pend_slot = order_slot;
+  B.pend_energy = compute_energy;
+  B.pend_seq = (double)(++h->seq);
+  FCCHK(batch_enqueue(h, order_slot, compute_energy, B.pend_seq));
+  B.pending = true;
+  return FC_OK;
+}
+
+int fc_step_batch_end(fc_handle h, int32_t k, double* y_out, double* dE_out, double* info_out) {
+  FCCHK(batch_check(h, k, "fc_step_batch_end"));
+  fc_ctx::Batch& B = h->bat;
+  if (!B.pending) return fail(FC_ERR_INVALID, "fc_step_batch_end: no step in flight");
+  B.pending = false;
+  HIPCHK(hipSetDevice(h->device));
+  volatile double* pin = h->pin;
+  const double seq = B.pend_seq;
+  auto bits = [](double v) {
+    unsigned long long u;
+    std::memcpy(&u, &v, sizeof u);
+    return u;
+  };
+  auto record_ok = [&](int s) {  // the checksummed record of fc_publish, simulation s
+    volatile double* r = pin + (size_t)s * kRecStride;
+    if (r[137] != seq) return false;
+    unsigned long long x = bits(seq), w = x, kk = 3;
+    for (int q = 0; q < h->n_sens; ++q, kk += 2) {
+      const unsigned long long v = bits(r[64 + q]);
+      x ^= v;
+      w += kk * v;
+    }
+    const unsigned long long tail[4] = {bits(r[128]), bits(r[129]), bits(r[130]), bits(r[136])};
+    for (int i = 0; i < 4; ++i, kk += 2) {
+      x ^= tail[i];
+      w += kk * tail[i];
+    }
+    return x == bits(r[138]) && w == bits(r[139]);
+  };
+  auto all_ok = [&]() {
+    for (int s = 0; s < k; ++s)
+      if (!record_ok(s)) return false;
+    return true;
+  };
+  bool seen = false;
+  if (!h->timing) {
+    for (long spin = 0; spin < 20000000L; ++spin) {
+      if (all_ok()) {
+        seen = true;
+        break;
+      }
+      __builtin_ia32_pause();
+    }
+  }
+  if (!seen) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    FCCHK(time_collect(h));
+    if (!all_ok()) return fail(FC_ERR_HIP, "fc_step_batch: a step record failed its checksum after stream synchronisation");
+  }
+  int any = 0;
+  for (int s = 0; s < k; ++s) {
+    volatile double* r = pin + (size_t)s * kRecStride;
+    for (int q = 0; q < h->n_sens; ++q)
+      if (y_out) y_out[(size_t)s * h->n_sens + q] = r[64 + q];
+    if (dE_out) dE_out[s] = B.pend_energy ? r[128] : std::numeric_limits<double>::quiet_NaN();
+    const int flag = ((int)r[136]) % 1024;
+    any |= flag;
+    if (info_out) {
+      const double r2 = r[129], b2 = r[130];
+      info_out[4 * s + 0] = 0.0;
+      info_out[4 * s + 1] = std::sqrt(r2 / (b2 > 0 ? b2 : 1.0));
+      info_out[4 * s + 2] = std::sqrt(b2);
+      info_out[4 * s + 3] = flag;
+    }
+  }
+  if (any) return fail(FC_ERR_DIVERGED, "non-finite velocity after solve (info[s][3] marks the simulations)");
+  return FC_OK;
+}
+
+int fc_step_batch(fc_handle h, int order_slot, int32_t k, const double* u_ctrl, const double* u_force, double* y_out, double* dE_out,
+                  int compute_energy, double* info_out) {
+  FCCHK(fc_step_batch_begin(h, order_slot, k, u_ctrl, u_force, compute_energy));
+  return fc_step_batch_end(h, k, y_out, dE_out, info_out);
+}
+
+int fc_get_batch_info(fc_handle h, double* info) {
+  if (!h || !info) return fail(FC_ERR_INVALID, "fc_get_batch_info: null argument");
+  const fc_ctx::Batch& B = h->bat;
+  int nblk = 0, nfold = 0;
+  for (const fc_ctx::BLaunch& L : B.launches) (L.kind == 0 ? nblk : nfold)++;
+  info[0] = B.k;
+  info[1] = B.KB;
+  info[2] = (double)B.scratch_rows;
+  info[3] = nblk;
+  info[4] = nfold;
+  info[5] = 8.0 * (double)B.factor_values;              // factor bytes of one batched apply (serves KB simulated steps)
+  info[6] = 8.0 * B.vec_rows * (double)std::max(1, B.KB);  // operand / result / fold bytes of one batched apply
+  info[7] = (double)B.tasks.n;
+  return FC_OK;
+}
+
+int fc_bench_batch_apply(fc_handle h, int slot, int reps, double* ms_per_apply) {
+  if (!h || slot < 0 || slot > 1 || reps <= 0 || !ms_per_apply) return fail(FC_ERR_INVALID, "fc_bench_batch_apply: bad argument");
+  if (h->bat.k == 0) return fail(FC_ERR_NOT_READY, "fc_bench_batch_apply: fc_set_batch not called");
+  OrderSys& S = h->sys[slot];
+  if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_setup_solver not called for this slot");
+  HIPCHK(hipSetDevice(h->device));
+  fc_ctx::Batch& B = h->bat;
+  const size_t bytes = (size_t)h->N * B.KB * sizeof(double);
+  for (int i = 0; i < 2; ++i) {
+    HIPCHK(hipMemcpyAsync(B.buf.p, B.b.p, bytes, hipMemcpyDeviceToDevice, h->stream));
+    FCCHK(batch_apply(h, S));
+  }
+  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  for (int i = 0; i < reps; ++i) {
+    HIPCHK(hipMemcpyAsync(B.buf.p, B.b.p, bytes, hipMemcpyDeviceToDevice, h->stream));
+    FCCHK(batch_apply(h, S));
+  }
+  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  HIPCHK(hipEventSynchronize(h->ev1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *ms_per_apply = (double)ms / reps;
+  return FC_OK;
+}
+
+// parity hook: X = A_bc^-1 B for k right-hand sides through the batched factor apply (B, X: [k][N], W numbering)
+int fc_solve_batch(fc_handle h, int slot, int32_t k, const double* b, double* x) {
+  FCCHK(batch_check(h, k, "fc_solve_batch"));
+  if (slot < 0 || slot > 1 || !b || !x) return fail(FC_ERR_INVALID, "fc_solve_batch: bad argument");
+  OrderSys& S = h->sys[slot];
+  if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_setup_solver not called for this slot");
+  HIPCHK(hipSetDevice(h->device));
+  fc_ctx::Batch& B = h->bat;
+  const int N = h->N;
+  // permute on the host (setup-path helper): y_p[i] = b[perm[i]]
+  std::vector<double> bp((size_t)k * N), xp((size_t)k * N);
+  for (int s = 0; s < k; ++s)
+    for (int i = 0; i < N; ++i) bp[(size_t)s * N + i] = b[(size_t)s * N + h->h_perm[i]];
+  FCCHK(batch_copy(h, N, bp.data(), B.buf.p, true));
+  FCCHK(batch_apply(h, S));
+  FCCHK(batch_copy(h, N, xp.data(), B.buf.p + (size_t)N * B.KB, false));
+  for (int s = 0; s < k; ++s)
+    for (int i = 0; i < N; ++i) x[(size_t)s * N + h->h_perm[i]] = xp[(size_t)s * N + i];
   return FC_OK;
 }
 

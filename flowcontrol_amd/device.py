@@ -71,6 +71,8 @@ class DeviceSolver:
         self._pin: int | None = None  # pressure dof of an enclosed flow whose level is fixed (diagonal shift in the factors)
         self._truncate = 0  # > 0: only the tree levels >= this are factorised (memory-lean preconditioner)
         self.device_index = device
+        self.batch_k = 0
+        self._batch_bufs = None
 
     # ── multi-GPU ────────────────────────────────────────────────────────────
     def join(self, rank: int, world: int, broadcast_bytes, host_allreduce=None) -> None:
@@ -531,6 +533,81 @@ class DeviceSolver:
         check(self.lib.fc_run(self._h, first_order_slot, n_steps, ptr(u), is_seq, ptr(yv), ptr(dE), int(compute_energy)))
         del y
         return yv, dE
+
+    # ── shared-operator batched stepping (k lock-step simulations on this handle) ────────────
+    def set_batch(self, k: int) -> None:
+        """Allocate (k > 0) or free (k = 0) the state of k lock-step simulations that share this handle's operators and
+        factors (``fc_set_batch``): IC sweeps / controller sweeps of the reference run k FlowSolver instances instead."""
+        check(self.lib.fc_set_batch(self._h, int(k)))
+        self.batch_k = int(k)
+        self._batch_bufs = None
+
+    def set_state_batch(self, u_n, u_nn, p_n=None) -> None:
+        k = self.batch_k
+        u_n, u_nn = _f64(u_n).reshape(k, 2 * self.nn), _f64(u_nn).reshape(k, 2 * self.nn)
+        p = None if p_n is None else _f64(p_n).reshape(k, self.th.nv)
+        check(self.lib.fc_set_state_batch(self._h, k, u_n, u_nn, ptr(p)))
+
+    def get_state_batch(self):
+        k = self.batch_k
+        u_n, u_nn, p_n = np.empty((k, 2 * self.nn)), np.empty((k, 2 * self.nn)), np.empty((k, self.th.nv))
+        check(self.lib.fc_get_state_batch(self._h, k, ptr(u_n), ptr(u_nn), ptr(p_n)))
+        return u_n, u_nn, p_n
+
+    def get_solution_batch(self) -> np.ndarray:
+        up = np.empty((self.batch_k, self.N))
+        check(self.lib.fc_get_solution_batch(self._h, self.batch_k, up))
+        return up
+
+    def _batch_buffers(self):
+        b = self._batch_bufs
+        if b is None:
+            k = self.batch_k
+            arrs = (np.zeros((k, max(self.n_act, 1))), np.zeros((k, max(self.n_act, 1))), np.empty((k, max(self.n_sens, 1))), np.empty(k),
+                    np.empty((k, 4)))
+            b = self._batch_bufs = arrs + (tuple(ptr(a) for a in arrs),)
+        return b
+
+    def step_batch_begin(self, order_slot: int, u_ctrl, compute_energy: bool = True, u_force=None) -> None:
+        u, uf, y, dE, info, (pu, puf, py, pdE, pinfo) = self._batch_buffers()
+        if self.n_act:
+            u[:, : self.n_act] = np.asarray(u_ctrl, dtype=np.float64).reshape(self.batch_k, self.n_act)
+            if u_force is not None:
+                uf[:, : self.n_act] = np.asarray(u_force, dtype=np.float64).reshape(self.batch_k, self.n_act)
+        code = self.lib.fc_step_batch_begin(self._h, order_slot, self.batch_k, pu if self.n_act else None,
+                                            puf if (self.n_act and u_force is not None) else None, 1 if compute_energy else 0)
+        if code:
+            check(code)
+
+    def step_batch_end(self):
+        """(y [k, n_sens], dE [k], info [k, 4]) of the step in flight; raises :class:`FcDiverged` if any simulation
+        produced a non-finite velocity (``info[:, 3]`` of ``self._batch_bufs`` marks which)."""
+        u, uf, y, dE, info, (pu, puf, py, pdE, pinfo) = self._batch_bufs
+        code = self.lib.fc_step_batch_end(self._h, self.batch_k, py, pdE, pinfo)
+        if code:
+            check(code)
+        return y[:, : self.n_sens].copy(), dE.copy(), info
+
+    def step_batch(self, order_slot: int, u_ctrl, compute_energy: bool = True, u_force=None):
+        self.step_batch_begin(order_slot, u_ctrl, compute_energy, u_force)
+        return self.step_batch_end()
+
+    def batch_info(self) -> dict:
+        a = np.zeros(8)
+        check(self.lib.fc_get_batch_info(self._h, a))
+        return {"k": int(a[0]), "KB": int(a[1]), "scratch_rows": int(a[2]), "block_launches": int(a[3]), "fold_launches": int(a[4]),
+                "factor_bytes": a[5], "vector_bytes": a[6], "tasks": int(a[7])}
+
+    def bench_batch_apply(self, slot: int, reps: int = 200) -> float:
+        ms = C.c_double()
+        check(self.lib.fc_bench_batch_apply(self._h, slot, reps, C.byref(ms)))
+        return ms.value
+
+    def solve_batch(self, slot: int, b) -> np.ndarray:
+        b = _f64(b).reshape(self.batch_k, self.N)
+        x = np.empty_like(b)
+        check(self.lib.fc_solve_batch(self._h, slot, self.batch_k, b, x))
+        return x
 
     # ── parity hooks ─────────────────────────────────────────────────────────
     def assemble_rhs(self, order_slot: int, u_ctrl) -> np.ndarray:

@@ -253,6 +253,37 @@ int fc_step_end(fc_handle h, double* y_out, double* dE_out, double* info_out);
 int fc_run(fc_handle h, int first_order_slot, int32_t n_steps, const double* u_ctrl,
            int u_ctrl_is_sequence, double* y_seq, double* dE_seq, int compute_energy);
 
+/* ── shared-operator batched stepping: k <= 16 lock-step simulations on ONE handle ────────────
+ *    Replaces k independent FlowSolver instances that step the SAME operator with different initial
+ *    conditions / controls / controllers — the reference's outer workloads: IC sweeps
+ *    (examples/lidcavity/batch_run_lidcavity.py:197-215), controller optimisation (utils/optim.py:95-102),
+ *    each of which runs FlowSolver.step (flowsolver.py:703-799) once per simulation and time step.
+ *    All k simulations share the handle's operators, factors, BC / force / sensor tables and time scheme and are
+ *    advanced together: every vector is a matrix [row][KB] on the device (KB = 4, 8 or 16 >= k), every level
+ *    of the factor sweep a dense block product on the fp64 matrix cores, so the factors are read once per
+ *    step for all of them.  Needs fc_setup_solver (full factors, single GPU, no refinement sweeps).
+ *    fc_set_batch(h, k) allocates the batched state (all zero; k = 0 frees it).  Host arrays are [k][...]
+ *    (simulation-major).  The single-simulation state of the handle is independent of the batched one. */
+int fc_set_batch(fc_handle h, int32_t k);
+int fc_set_state_batch(fc_handle h, int32_t k, const double* u_n /* [k][2 nn] */, const double* u_nn /* [k][2 nn] */,
+                       const double* p_n /* [k][nv] or NULL */);
+int fc_get_state_batch(fc_handle h, int32_t k, double* u_n, double* u_nn, double* p_n /* any may be NULL */);
+int fc_get_solution_batch(fc_handle h, int32_t k, double* up /* [k][N] last solve, W layout */);
+/* fc_step for k simulations: u_ctrl [k][n_act], u_force [k][n_act] or NULL (= u_ctrl), y_out [k][n_sens], dE_out [k],
+ * info_out [k][4] = {0, relative residual, |b|, flags}.  FC_ERR_DIVERGED when any simulation produced a non-finite
+ * velocity (info_out[s][3] marks which; the others are unaffected: the columns are independent). */
+int fc_step_batch(fc_handle h, int order_slot, int32_t k, const double* u_ctrl, const double* u_force, double* y_out,
+                  double* dE_out, int compute_energy, double* info_out);
+int fc_step_batch_begin(fc_handle h, int order_slot, int32_t k, const double* u_ctrl, const double* u_force, int compute_energy);
+int fc_step_batch_end(fc_handle h, int32_t k, double* y_out, double* dE_out, double* info_out);
+/* info[8]: k, KB, scratch rows of the up-sweep, block launches and fold launches per apply, factor bytes of one
+ * batched apply (they serve KB simulated steps), vector (operand / result / fold) bytes of one batched apply, tasks */
+int fc_get_batch_info(fc_handle h, double* info /* [8] */);
+/* HIP-event timing of `reps` back-to-back batched factor applies; mean milliseconds per apply */
+int fc_bench_batch_apply(fc_handle h, int slot, int reps, double* ms_per_apply);
+/* parity hook: X = A_bc^{-1} B for k right-hand sides through the batched factor apply; b, x: [k][N] */
+int fc_solve_batch(fc_handle h, int slot, int32_t k, const double* b, double* x);
+
 /* ── parity hooks (tests) ------------------------------------------------------------------- */
 /* RHS of `order_slot` for the current state and u_ctrl, in W layout, BCs lifted and imposed:
  * what SystemAssembler.assemble(rhs) returns (flowsolver.py:728) */
