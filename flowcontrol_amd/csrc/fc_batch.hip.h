@@ -9,10 +9,9 @@
 // dense block product  (factor block) x (operand rows x KB)  on the fp64 matrix cores
 // (v_mfma_f64_16x16x4_f64): the factor bytes are streamed once per KB simulated steps.
 //
-//   fc_nd_block_b   one workgroup per task = up to 16 RT rows of ONE dense factor block of one tree node
-//                   ([D^-1 | -U] rows in the down-sweep, -L rows in the up-sweep) times the node's operand rows
-//                   (staged once per workgroup in LDS); the four waves split into RT row tiles x 4/RT column
-//                   groups, the column groups' accumulators are summed through LDS in a fixed order
+//   fc_nd_block_b   one workgroup per task = a 16-row tile of ONE dense factor block of one tree node
+//                   ([D^-1 | -U] rows in the down-sweep, -L rows in the up-sweep) times the node's operand rows;
+//                   CG waves split the tile's columns, their accumulators are summed through LDS in a fixed order
 //   fc_nd_fold_b    up-sweep: a tree node's -L block writes its products to a private scratch row per
 //                   (node, boundary row); the rows of the next level add the scratch rows of their descendants in
 //                   a fixed order (bit-reproducible, no fp64 atomics)
@@ -24,107 +23,110 @@
 #include <stdint.h>
 
 struct __attribute__((aligned(16))) FcBTask {
-  long long val;  // offset of the task's first value (first row, column c0 of the node's block)
+  long long val;  // offset of the tile's first value (first row, first column of the node's block)
   int ld;         // row stride of the block
-  int nrows;      // rows of this task (<= 16 RT)
-  int ncols;      // columns of this task: operand columns [c0, c0 + ncols) of the node
-  int c0;
-  int i0, ni;     // operand columns [0, ni): buffer rows i0 + c
-  int idx;        // operand columns [ni, ...): buffer rows idxlist[idx + c - ni]
+  int nrows;      // rows of this tile (<= 16)
+  int ncols;      // columns of the block = operand rows of the node
+  int op;         // offset of the node's operand row list (buffer row of every column; even)
   int dst;        // first destination buffer row
-  int pad0, pad1;
+  int pad;
 };
 
-#define FC_B_TW 256  // operand columns staged per LDS tile
+typedef int fc_i2 __attribute__((ext_vector_type(2)));
 
-// LDS position of operand column c of a tile: inside every group of 8 columns, the columns a wave's four
-// k-lanes need in ONE matrix instruction (c = 8 j + 2 q + e for q = 0..3, see below) sit in 4 consecutive rows
-__device__ __forceinline__ int fc_b_pos(int c) { return (c & ~7) | ((c & 1) << 2) | ((c >> 1) & 3); }
-
+// One workgroup per task = one 16-row tile of ONE dense factor block of a tree node, CG <= 8 waves (blockDim = 64 CG): wave g
+// takes the 32-column chunks g, g + CG, ... of the tile's rows, the CG accumulators are summed through LDS in the order
+// of the groups (reproducible).  No barrier before that sum: every wave streams on its own through a three-deep register
+// pipeline  operand-row indices (chunk c + 3) | values + operand rows (chunk c + 2, c + 1 in flight) | matrix
+// instructions (chunk c).  The factor values come from HBM (each exactly once per apply), the operand rows [row][KB] from
+// L2 (a node's rows are shared by all of its tiles).
+//
 // v_mfma_f64_16x16x4_f64: lane l holds A[row l & 15][k = l >> 4], B[k = l >> 4][col l & 15];
-// D[row (l >> 4) + 4 r][col l & 15] in register r.  The k index of an instruction is free to stand for any four
-// columns as long as A and B agree: lane (row, q) loads the value PAIR at columns 8 j + 2 q, 8 j + 2 q + 1 of its
-// row (16 contiguous bytes; the four q lanes of a row cover 64 contiguous bytes) and feeds the pair to two
-// consecutive instructions.
+// D[row (l >> 4) + 4 r][col l & 15] in register r.  The k index of an instruction may stand for any four columns as
+// long as A and B agree: lane (row, q) loads the value PAIR at columns 8 u + 2 q, 8 u + 2 q + 1 of its row (16 contiguous
+// bytes; the four q lanes of a row cover 64 contiguous bytes) and feeds the pair to two consecutive instructions.
 template <int KB>
-__global__ __launch_bounds__(256) void fc_nd_block_b(const FcBTask* __restrict__ tasks, const int* __restrict__ idxlist,
-                                                     const double* __restrict__ val, double* __restrict__ buf, int RT) {
-  __shared__ double Ys[FC_B_TW * KB > 1024 ? FC_B_TW * KB : 1024];
+__global__ __launch_bounds__(512) void fc_nd_block_b(const FcBTask* __restrict__ tasks, const int* __restrict__ olist,
+                                                      const double* __restrict__ val, double* __restrict__ buf, int CG) {
+  extern __shared__ double fc_b_red[];
   const FcBTask tk = tasks[blockIdx.x];
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, lr = lane & 15, lq = lane >> 4;
-  const int CG = 4 / RT;                       // column groups
-  const int tile = wave % RT, grp = wave / RT;  // this wave: rows [16 tile, 16 tile + 16), 64-column chunks grp, grp + CG, ...
-  const bool wave_live = 16 * tile < tk.nrows;
-  // rows past the task's last one shadow it (valid addresses, results dropped at the store)
-  const int row = 16 * tile + lr < tk.nrows ? 16 * tile + lr : tk.nrows - 1;
+  const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+  const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  // rows past the tile's last one shadow it (valid addresses, results dropped at the store)
+  const int row = lr < tk.nrows ? lr : tk.nrows - 1;
   const double* __restrict__ vrow = val + tk.val + (long long)row * tk.ld + 2 * lq;
+  const int* __restrict__ orow = olist + 2 * lq;
+  const int ncols = tk.ncols;
+  const int ls = lr < KB ? lr : 0;  // lanes beyond the batch width shadow simulation 0 (their output columns are never stored)
   fc_d4 acc = {0.0, 0.0, 0.0, 0.0};
-  const int nchunk = (tk.ncols + 63) >> 6;
-  // value chunk ch of this wave's rows: 8 pairs per lane; a pair beyond the task's columns is not loaded (it
-  // may read up to 7 values into the next row / block: finite numbers that meet zero operand rows)
-  double an[16];
-  auto load_chunk = [&](int ch) {
-    const int cb = ch << 6;
+  // chunk c of this wave starts at column 32 (grp + CG c).  The pipeline below has NO branch and no per-lane predicate in
+  // its body (a branch makes the compiler drain the load queue at every join).  Instead:
+  //  * a node's operand list is padded to a multiple of 8 with the index of a buffer row that is always zero, so the
+  //    columns past the block's last one (a lane's value pair may read up to 7 values into the next row / block: finite
+  //    numbers, the allocation is padded) meet a zero operand;
+  //  * a whole group of 8 columns past the end — in the last chunk of a row, or in the up to two chunks by which the
+  //    wave's chunk count is rounded up to the pipeline's period — takes its values from the tile's first columns (valid
+  //    addresses, one cache line per wave) and its operand rows from the "null group" olist[0..8) (the zero row again).
+  // Everything that depends on the chunk index only is wave-uniform (scalar).
+  const int nchunk = (ncols + 31) >> 5;
+  const int nw = nchunk > grp ? (nchunk - grp + CG - 1) / CG : 0;  // chunks of this wave
+  auto I = [&](int c, fc_i2 (&x)[4]) {  // operand-row indices of chunk c
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const bool ok = wave_live && cb + 8 * u < tk.ncols;
-      an[2 * u] = ok ? vrow[cb + 8 * u] : 0.0;
-      an[2 * u + 1] = ok ? vrow[cb + 8 * u + 1] : 0.0;
+    for (int u = 0; u < 4; ++u) {
+      const int col = 32 * (grp + CG * c) + 8 * u;
+      x[u] = *reinterpret_cast<const fc_i2*>(orow + (col < ncols ? tk.op + col : 0));
     }
   };
-  int ch = grp;  // next chunk of this wave
-  if (ch < nchunk) load_chunk(ch);  // in flight while the first operand tile is staged
-  for (int t0 = 0; t0 < tk.ncols; t0 += FC_B_TW) {
-    const int tl = tk.ncols - t0 < FC_B_TW ? tk.ncols - t0 : FC_B_TW;
-    const int tlp = (tl + 7) & ~7;
-    for (int e = t; e < tlp * KB; e += 256) {
-      const int c = e / KB, n = e % KB;
-      double v = 0.0;
-      if (c < tl) {
-        const int cc = tk.c0 + t0 + c;
-        const int src = cc < tk.ni ? tk.i0 + cc : idxlist[tk.idx + cc - tk.ni];
-        v = buf[(size_t)src * KB + n];
-      }
-      Ys[fc_b_pos(c) * KB + n] = v;
-    }
-    __syncthreads();
-    // this wave's chunks inside the tile
-    while (ch < nchunk && (ch << 6) < t0 + FC_B_TW) {
-      double a[16];
+  auto L = [&](int c, const fc_i2 (&x)[4], double (&a)[8], double (&b)[8]) {  // values and operand rows of chunk c
 #pragma unroll
-      for (int u = 0; u < 16; ++u) a[u] = an[u];
-      const int cb = ch << 6;
-      ch += CG;
-      if (ch < nchunk) load_chunk(ch);  // the next chunk streams in behind the matrix instructions of this one
-      const int cl = cb - t0;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (wave_live && cb + 8 * u < tk.ncols) {  // wave-uniform
-          const double b0 = lr < KB ? Ys[(cl + 8 * u + lq) * KB + lr] : 0.0;
-          const double b1 = lr < KB ? Ys[(cl + 8 * u + 4 + lq) * KB + lr] : 0.0;
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2 * u], b0, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2 * u + 1], b1, acc, 0, 0, 0);
-        }
-      }
+    for (int u = 0; u < 4; ++u) {
+      const int col = 32 * (grp + CG * c) + 8 * u;
+      const int o = col < ncols ? col : 0;
+      a[2 * u] = vrow[o];
+      a[2 * u + 1] = vrow[o + 1];
+      b[2 * u] = buf[(size_t)x[u].x * KB + ls];
+      b[2 * u + 1] = buf[(size_t)x[u].y * KB + ls];
     }
-    __syncthreads();
+  };
+  auto M = [&](const double (&a)[8], const double (&b)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+  };
+  if (nw > 0) {
+    fc_i2 x0[4], x1[4], x2[4];
+    double a0[8], b0[8], a1[8], b1[8], a2[8], b2[8];
+    I(0, x0);
+    I(1, x1);
+    I(2, x2);
+    L(0, x0, a0, b0);
+    L(1, x1, a1, b1);
+    for (int c = 0; c < nw; c += 3) {
+      I(c + 3, x0);
+      L(c + 2, x2, a2, b2);
+      M(a0, b0);
+      I(c + 4, x1);
+      L(c + 3, x0, a0, b0);
+      M(a1, b1);
+      I(c + 5, x2);
+      L(c + 4, x1, a1, b1);
+      M(a2, b2);
+    }
   }
   if (CG > 1) {
-    // column groups -> one accumulator per row tile, summed in the order of the groups (reproducible)
-    double* red = Ys;  // 4 waves x 64 lanes x 4 doubles = 8 KB
+    const int wave = (int)threadIdx.x >> 6;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
+    for (int r = 0; r < 4; ++r) fc_b_red[(wave * 4 + r) * 64 + lane] = acc[r];
     __syncthreads();
-    if (grp != 0) return;
+    if (wave != 0) return;
     for (int g = 1; g < CG; ++g)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] += red[((tile + RT * g) * 4 + r) * 64 + lane];
+      for (int r = 0; r < 4; ++r) acc[r] += fc_b_red[(g * 4 + r) * 64 + lane];
   }
   if (lr < KB) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int orow = 16 * tile + lq + 4 * r;
-      if (orow < tk.nrows) buf[(size_t)(tk.dst + orow) * KB + lr] = acc[r];
+      const int o = lq + 4 * r;
+      if (o < tk.nrows) buf[(size_t)(tk.dst + o) * KB + lr] = acc[r];
     }
   }
 }
@@ -158,16 +160,20 @@ __global__ __launch_bounds__(256) void fc_nd_fold_b(int nrows, int row0, const i
 // step kernels, simulation index fastest.  State u_n / u_nn [2 nn][KB], p_n [nv][KB], controls
 // uctrl[s * ustride + a] (host-mapped record of simulation s).
 // ---------------------------------------------------------------------------------------------
-// fc_rhs_elem with 8 lanes per (cell, simulation): ev[(slot * nc + cell) * KB + s]
+// fc_rhs_elem for KB simulations: thread = (cell, Radon point q, simulation s), s fastest — the nodal values of a cell
+// are read as KB contiguous doubles per node; the weighted point values of a cell go through LDS and thread
+// (cell, a = q < 6, s) tests them with phi_a in the fixed order q = 0..6.  ev[(slot * nc + cell) * KB + s]
 template <int KB>
 __global__ __launch_bounds__(256) void fc_rhs_elem_b(int nc, int nn, const int* __restrict__ cn, const double* __restrict__ geom,
                                                      const double* __restrict__ un, const double* __restrict__ unn,
                                                      const double* __restrict__ fprof, int n_act, const double* __restrict__ uforce,
                                                      int ustride, double cm_n, double cm_nn, double cc_n, double cc_nn,
                                                      double* __restrict__ ev) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = t & 7, g = t >> 3;
-  const int s = g % KB, cl = g / KB;
+  constexpr int CPB = 256 / (8 * KB);  // cells per workgroup
+  __shared__ double gs[2][256];
+  const int t = threadIdx.x;
+  const int s = t % KB, lane = (t / KB) % 8, cw = t / (8 * KB);
+  const int cl = blockIdx.x * CPB + cw;
   const bool active = cl < nc;
   const int c = active ? cl : 0;
   const int q = lane < FC_NQ ? lane : FC_NQ - 1;
@@ -209,17 +215,18 @@ __global__ __launch_bounds__(256) void fc_rhs_elem_b(int nc, int nn, const int* 
   const double wy_x = zxi * j00 + zet * j10, wy_y = zxi * j01 + zet * j11;
   gx += cm_n * ux + cm_nn * wx + cc_n * (ux * ux_x + uy * ux_y) + cc_nn * (wx * wx_x + wy * wx_y);
   gy += cm_n * uy + cm_nn * wy + cc_n * (ux * uy_x + uy * uy_y) + cc_nn * (wx * wy_x + wy * wy_y);
-  gx *= wq;
-  gy *= wq;
-  const int a = lane < 6 ? lane : 5;
-  double accx = 0.0, accy = 0.0;
-#pragma unroll
-  for (int p = 0; p < FC_NQ; ++p) {
-    const double pa = c_phi2[p * 6 + a];
-    accx += pa * __shfl(gx, p, 8);
-    accy += pa * __shfl(gy, p, 8);
-  }
+  gs[0][t] = gx * wq;
+  gs[1][t] = gy * wq;
+  __syncthreads();
   if (active && lane < 6) {
+    double accx = 0.0, accy = 0.0;
+    const int base = cw * 8 * KB + s;
+#pragma unroll
+    for (int p = 0; p < FC_NQ; ++p) {
+      const double pa = c_phi2[p * 6 + lane];
+      accx += pa * gs[0][base + p * KB];
+      accy += pa * gs[1][base + p * KB];
+    }
     ev[((size_t)lane * nc + c) * KB + s] = accx;
     ev[((size_t)(6 + lane) * nc + c) * KB + s] = accy;
   }
@@ -266,15 +273,15 @@ __global__ __launch_bounds__(256) void fc_rhs_gather_b(int N, const int* __restr
 // fourth matrix entry from j), the matrix row is read once for all simulations.  Cell workgroups (first in the grid):
 // thread = (cell, Radon point, simulation).  partial[(w * G + block) * KB + s], w = 0: sum r^2, 1: sum b^2, 2: sum e.
 template <int KB>
-__global__ __launch_bounds__(256) void fc_tail_b(int N, int nn2, const int* __restrict__ perm, const double* __restrict__ x,
+__global__ __launch_bounds__(1024) void fc_tail_b(int N, int nn2, const int* __restrict__ perm, const double* __restrict__ x,
                                                  const double* __restrict__ b, const int* __restrict__ a_rowptr,
                                                  const int* __restrict__ a_col, const double* __restrict__ a_val, int n_row_blocks,
                                                  int reps, int nc, const int* __restrict__ cn, const double* __restrict__ geom,
                                                  const int* __restrict__ iperm, double* __restrict__ up, double* __restrict__ u_n,
                                                  double* __restrict__ u_nn, double* __restrict__ p_n, int* __restrict__ flag,
                                                  double* __restrict__ partial) {
-  constexpr int LPR = 4 * KB, RPB = 256 / LPR;  // lanes per row, rows per workgroup and repetition
-  constexpr int CPB = 256 / (8 * KB);           // cells per cell workgroup and repetition
+  constexpr int LPR = 4 * KB, RPB = 1024 / LPR;  // lanes per row, rows per workgroup and repetition
+  constexpr int CPB = 1024 / (8 * KB);           // cells per cell workgroup and repetition
   const int t = threadIdx.x, s = t % KB;
   const int G = gridDim.x;
   const int n_cell_blocks = G - n_row_blocks;
@@ -334,12 +341,12 @@ __global__ __launch_bounds__(256) void fc_tail_b(int N, int nn2, const int* __re
     }
   }
   // threads t, t + KB, t + 2 KB, ... belong to the same simulation
-  __shared__ double red[3][256];
+  __shared__ double red[3][1024];
   red[0][t] = r2;
   red[1][t] = b2;
   red[2][t] = e;
   __syncthreads();
-  for (int st = 128; st >= KB; st >>= 1) {
+  for (int st = 512; st >= KB; st >>= 1) {
     if (t < st) {
       red[0][t] += red[0][t + st];
       red[1][t] += red[1][t + st];

@@ -275,8 +275,8 @@ struct fc_ctx {
   // batched stepping (fc_set_batch): k lock-step simulations that share the operators and the factors of this handle;
   // every vector is a matrix [row][KB] (fc_batch.hip.h)
   struct BLaunch {
-    int kind;  // 0: fc_nd_block_b over tasks [first, first + count) with RT row tiles per workgroup; 1: fc_nd_fold_b
-    int first, count, rt;
+    int kind;  // 0: fc_nd_block_b over tasks [first, first + count) with cg column-group waves per row tile; 1: fc_nd_fold_b
+    int first, count, cg;
     int row0, nrows, dst_off, accumulate;
   };
   struct Batch {
@@ -286,6 +286,7 @@ struct fc_ctx {
     DevBuf<int> flag;                                        // [KB] non-finite velocity seen, per simulation
     DevBuf<FcBTask> tasks;
     DevBuf<int> fptr, fsrc;       // up-sweep fold lists: permuted row -> scratch rows (absolute buffer rows) of its descendants
+    DevBuf<int> olist;            // per tree node: the buffer row of every operand column ([y rows of the node | x rows of its boundary])
     std::vector<BLaunch> launches;
     int64_t scratch_rows = 0, factor_values = 0;
     double vec_rows = 0.0;        // operand / result rows moved per apply (x KB x 8 B)
@@ -3380,55 +3381,66 @@ static int build_batch_tables(fc_ctx* h) {
     for (size_t g = 0; g < G; ++g)
       for (int64_t j = 0; j < nd(g, 4); ++j) fsrc[(size_t)fill[(size_t)(fac.idx[(size_t)(nd(g, 6) + j)] - N)]++] = (int)(2 * (int64_t)N + soff[g] + j);
   }
+  // operand row lists: node g's columns [0, ni) are its own y rows, [ni, nf) the x rows of its boundary; padded to a
+  // multiple of 8 with the index of the buffer's zero row (the row behind the scratch rows: never written); olist[0..8)
+  // is the "null group" the block kernel reads for column groups past the end of a block
+  const int zero_row = (int)(2 * (int64_t)N + S);
+  std::vector<int> olist(8, zero_row);
+  std::vector<int> ooff(G, 0), ooff_up(G, 0);
+  for (size_t g = 0; g < G; ++g) {
+    ooff[g] = (int)olist.size();
+    for (int64_t c = 0; c < nd(g, 3); ++c) olist.push_back((int)(nd(g, 2) + c));
+    for (int64_t j = 0; j < nd(g, 4); ++j) olist.push_back(fac.idx[(size_t)(nd(g, 6) + j)]);
+    while (olist.size() & 7) olist.push_back(zero_row);
+    // the -L block's operand is the node's own y rows only: its list must END with the padding
+    ooff_up[g] = ooff[g];
+    if (nd(g, 4) > 0 && (nd(g, 3) & 7)) {
+      ooff_up[g] = (int)olist.size();
+      for (int64_t c = 0; c < nd(g, 3); ++c) olist.push_back((int)(nd(g, 2) + c));
+      while (olist.size() & 7) olist.push_back(zero_row);
+    }
+  }
   std::vector<FcBTask> tasks;
   B.launches.clear();
   B.factor_values = 0;
   B.vec_rows = 0.0;
-  static const int min_wg = [] { const char* e = std::getenv("FC_BATCH_MIN_WG"); return e ? std::max(1, std::atoi(e)) : 768; }();
-  static const int force_rt = [] { const char* e = std::getenv("FC_BATCH_RT"); return e ? std::atoi(e) : 0; }();
-  // one block launch for all nodes of `level`: up = the -L blocks (nb x ni), else the [D^-1 | -U] rows (ni x nf)
+  static const int force_cg = [] { const char* e = std::getenv("FC_BATCH_CG"); return e ? std::atoi(e) : 0; }();
+  static const double chunks_per_wave = [] { const char* e = std::getenv("FC_BATCH_CPW"); return e ? std::max(0.5, std::atof(e)) : 3.0; }();
+  // one block launch for all nodes of `level`: up = the -L blocks (nb x ni), else the [D^-1 | -U] rows (ni x nf);
+  // one task per 16-row tile, cg waves per tile (about chunks_per_wave 32-column chunks per wave)
   auto emit = [&](int level, bool up) {
     std::vector<size_t> sel;
-    int64_t rows_total = 0;
+    double cols_w = 0.0, w = 0.0;
     for (size_t g = 0; g < G; ++g)
       if (nd(g, 0) == level && nd(g, 3) > 0 && (!up || nd(g, 4) > 0)) {
         sel.push_back(g);
-        rows_total += up ? nd(g, 4) : nd(g, 3);
+        const double rows = (double)(up ? nd(g, 4) : nd(g, 3)), cols = (double)(up ? nd(g, 3) : nd(g, 3) + nd(g, 4));
+        cols_w += rows * cols;  // mean columns, weighted by the values behind them
+        w += rows;
       }
     if (sel.empty()) return;
-    // row tiles per workgroup: as many as keep the grid above min_wg workgroups (fewer operand stagings per value)
-    int rt = 1;
-    for (int cand : {4, 2}) {
-      int64_t wgs = 0;
-      for (size_t g : sel) wgs += ((up ? nd(g, 4) : nd(g, 3)) + 16 * cand - 1) / (16 * cand);
-      const double mean_rows = (double)rows_total / (double)sel.size();
-      if (wgs >= min_wg && mean_rows > 8.0 * cand) {
-        rt = cand;
-        break;
-      }
-    }
-    if (force_rt == 1 || force_rt == 2 || force_rt == 4) rt = force_rt;
+    const double mean_chunks = cols_w / std::max(w, 1.0) / 32.0;
+    int cg = 1;
+    while (cg < 8 && mean_chunks / cg > chunks_per_wave) cg *= 2;
+    if (force_cg == 1 || force_cg == 2 || force_cg == 4 || force_cg == 8) cg = force_cg;
     const int first = (int)tasks.size();
     for (size_t g : sel) {
-      const int64_t i0 = nd(g, 2), ni = nd(g, 3), nb = nd(g, 4), voff = nd(g, 5), ioff = nd(g, 6), nf = ni + nb;
+      const int64_t i0 = nd(g, 2), ni = nd(g, 3), nb = nd(g, 4), voff = nd(g, 5), nf = ni + nb;
       const int64_t rows = up ? nb : ni, ld = up ? ni : nf, base = up ? voff + ni * nf : voff;
-      for (int64_t r0 = 0; r0 < rows; r0 += 16 * rt) {
+      for (int64_t r0 = 0; r0 < rows; r0 += 16) {
         FcBTask tk = {};
         tk.val = base + r0 * ld;
         tk.ld = (int)ld;
-        tk.nrows = (int)std::min<int64_t>(16 * rt, rows - r0);
+        tk.nrows = (int)std::min<int64_t>(16, rows - r0);
         tk.ncols = (int)ld;
-        tk.c0 = 0;
-        tk.i0 = (int)i0;
-        tk.ni = (int)ni;
-        tk.idx = (int)ioff;
+        tk.op = up ? ooff_up[g] : ooff[g];
         tk.dst = up ? (int)(2 * (int64_t)N + soff[g] + r0) : (int)(N + i0 + r0);
         tasks.push_back(tk);
       }
       B.factor_values += rows * ld;
       B.vec_rows += (double)ld + (double)rows;
     }
-    B.launches.push_back({0, first, (int)tasks.size() - first, rt, 0, 0, 0, 0});
+    B.launches.push_back({0, first, (int)tasks.size() - first, cg, 0, 0, 0, 0});
   };
   for (int k = t.depth; k >= 1; --k) {
     emit(k, true);
@@ -3444,6 +3456,7 @@ static int build_batch_tables(fc_ctx* h) {
   FCCHK(B.tasks.upload(tasks, h->stream));
   FCCHK(B.fptr.upload(fptr, h->stream));
   FCCHK(B.fsrc.upload(fsrc, h->stream));
+  FCCHK(B.olist.upload(olist, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   B.tables = true;
   return FC_OK;
@@ -3468,7 +3481,7 @@ static int batch_apply(fc_ctx* h, OrderSys& S) {
   for (const fc_ctx::BLaunch& L : B.launches) {
     if (L.kind == 0) {
       const FcBTask* tp = B.tasks.p + L.first;
-#define FC_BLK(K) hipLaunchKernelGGL((fc_nd_block_b<K>), dim3(L.count), dim3(256), 0, h->stream, tp, S.f_idx.p, S.f_val.p, buf, L.rt)
+#define FC_BLK(K) hipLaunchKernelGGL((fc_nd_block_b<K>), dim3(L.count), dim3(64 * L.cg), L.cg > 1 ? (size_t)L.cg * 2048 : 0, h->stream, tp, B.olist.p, S.f_val.p, buf, L.cg)
       FC_KB_DISPATCH(B.KB, FC_BLK(4), FC_BLK(8), FC_BLK(16));
 #undef FC_BLK
     } else {
@@ -3504,7 +3517,7 @@ int fc_set_batch(fc_handle h, int32_t k) {
     FCCHK(B.p_n.alloc((size_t)h->nv * KB));
     FCCHK(B.up.alloc(N * KB));
     FCCHK(B.b.alloc(N * KB));
-    FCCHK(B.buf.alloc((2 * N + (size_t)B.scratch_rows) * KB));
+    FCCHK(B.buf.alloc((2 * N + (size_t)B.scratch_rows + 1) * KB));  // + the zero row of the operand lists
     FCCHK(B.ev.alloc((size_t)12 * h->nc * KB));
     FCCHK(B.partial.alloc((size_t)3 * 8192 * KB));
     FCCHK(B.flag.alloc(16));
@@ -3578,7 +3591,7 @@ static int batch_enqueue(fc_ctx* h, int order_slot, int compute_energy, double s
   const int KB = B.KB, N = h->N, nc = h->nc;
   const double* uc = h->pin_dev;
   const double* uf = h->pin_dev + 32;
-  const int g_elem = nblocks((int64_t)nc * 8 * KB, 256), g_rows = nblocks((int64_t)N * KB, 256);
+  const int g_elem = nblocks(nc, 256 / (8 * KB)), g_rows = nblocks((int64_t)N * KB, 256);
 #define FC_ELEM(K) hipLaunchKernelGGL((fc_rhs_elem_b<K>), dim3(g_elem), dim3(256), 0, h->stream, nc, h->nn, h->cn.p, h->geom.p, B.u_n.p, B.u_nn.p, \
                                       h->have_force ? h->fprof.p : nullptr, h->have_force ? h->n_act : 0, uf, kRecStride, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, B.ev.p)
   FC_KB_DISPATCH(KB, FC_ELEM(4), FC_ELEM(8), FC_ELEM(16));
@@ -3590,12 +3603,12 @@ static int batch_enqueue(fc_ctx* h, int order_slot, int compute_energy, double s
 #undef FC_GATH
   FCCHK(batch_apply(h, S));
   // tail: residual monitor, scatter / shift, energy; <= ~2000 workgroups per kind
-  const int rpb = 256 / (4 * KB), cpb = 256 / (8 * KB);
-  const int reps = std::max(1, nblocks(nblocks(N, rpb), 2048));
+  const int rpb = 1024 / (4 * KB), cpb = 1024 / (8 * KB);
+  const int reps = std::max(1, nblocks(nblocks(N, rpb), 5000));  // 1 unless the mesh is large: the repetitions of a workgroup run one after the other
   const int n_row_blocks = nblocks(N, rpb * reps), n_cell_blocks = compute_energy ? nblocks(nc, cpb * reps) : 0;
   const int G = n_row_blocks + n_cell_blocks;
   if ((size_t)3 * G * KB > B.partial.n) return fail(FC_ERR_INVALID, "fc_step_batch: partial buffer too small");
-#define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, B.buf.p + (size_t)N * K, B.b.p, S.Ap_rowptr.p, \
+#define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(1024), 0, h->stream, N, 2 * h->nn, h->perm.p, B.buf.p + (size_t)N * K, B.b.p, S.Ap_rowptr.p, \
                                        S.Ap_col.p, S.Ap_val.p, n_row_blocks, reps, nc, h->cn.p, h->geom.p, h->iperm.p, B.up.p, B.u_n.p, B.u_nn.p, B.p_n.p,      \
                                        B.flag.p, B.partial.p)
   FC_KB_DISPATCH(KB, FC_TAILB(4), FC_TAILB(8), FC_TAILB(16));
