@@ -34,7 +34,7 @@ struct __attribute__((aligned(16))) FcBTask {
 
 typedef int fc_i2 __attribute__((ext_vector_type(2)));
 
-// One workgroup per task = one 16-row tile of ONE dense factor block of a tree node, CG <= 8 waves (blockDim = 64 CG): wave g
+// One workgroup per task = one 16-row tile of ONE dense factor block of a tree node, CG <= 16 waves (blockDim = 64 CG): wave g
 // takes the 32-column chunks g, g + CG, ... of the tile's rows, the CG accumulators are summed through LDS in the order
 // of the groups (reproducible).  No barrier before that sum: every wave streams on its own through a three-deep register
 // pipeline  operand-row indices (chunk c + 3) | values + operand rows (chunk c + 2, c + 1 in flight) | matrix
@@ -46,7 +46,7 @@ typedef int fc_i2 __attribute__((ext_vector_type(2)));
 // long as A and B agree: lane (row, q) loads the value PAIR at columns 8 u + 2 q, 8 u + 2 q + 1 of its row (16 contiguous
 // bytes; the four q lanes of a row cover 64 contiguous bytes) and feeds the pair to two consecutive instructions.
 template <int KB>
-__global__ __launch_bounds__(512) void fc_nd_block_b(const FcBTask* __restrict__ tasks, const int* __restrict__ olist,
+__global__ __launch_bounds__(1024) void fc_nd_block_b(const FcBTask* __restrict__ tasks, const int* __restrict__ olist,
                                                       const double* __restrict__ val, double* __restrict__ buf, int CG) {
   extern __shared__ double fc_b_red[];
   const FcBTask tk = tasks[blockIdx.x];
@@ -92,9 +92,20 @@ __global__ __launch_bounds__(512) void fc_nd_block_b(const FcBTask* __restrict__
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
   };
-  if (nw > 0) {
-    fc_i2 x0[4], x1[4], x2[4];
-    double a0[8], b0[8], a1[8], b1[8], a2[8], b2[8];
+  fc_i2 x0[4], x1[4], x2[4];
+  double a0[8], b0[8], a1[8], b1[8], a2[8], b2[8];
+  if (nw == 1) {  // the small blocks near the leaves: one round trip per stage, nothing to overlap
+    I(0, x0);
+    L(0, x0, a0, b0);
+    M(a0, b0);
+  } else if (nw == 2) {
+    I(0, x0);
+    I(1, x1);
+    L(0, x0, a0, b0);
+    L(1, x1, a1, b1);
+    M(a0, b0);
+    M(a1, b1);
+  } else if (nw > 2) {
     I(0, x0);
     I(1, x1);
     I(2, x2);
@@ -160,9 +171,12 @@ __global__ __launch_bounds__(256) void fc_nd_fold_b(int nrows, int row0, const i
 // step kernels, simulation index fastest.  State u_n / u_nn [2 nn][KB], p_n [nv][KB], controls
 // uctrl[s * ustride + a] (host-mapped record of simulation s).
 // ---------------------------------------------------------------------------------------------
-// fc_rhs_elem for KB simulations: thread = (cell, Radon point q, simulation s), s fastest — the nodal values of a cell
-// are read as KB contiguous doubles per node; the weighted point values of a cell go through LDS and thread
-// (cell, a = q < 6, s) tests them with phi_a in the fixed order q = 0..6.  ev[(slot * nc + cell) * KB + s]
+// fc_rhs_elem for KB simulations, thread = (cell, lane8, simulation s) with s fastest.  The element loop is bound by the
+// number of vector-memory instructions, not by bytes: a cell's nodal values are therefore loaded ONCE, by thread
+// (cell, node a = lane8 < 6, s) — KB contiguous doubles per node and field — and shared through LDS together with the
+// basis tables; thread (cell, Radon point q = lane8 < 7, s) evaluates the integrand at its point from LDS, and thread
+// (cell, a < 6, s) tests the weighted point values with phi_a in the fixed order q = 0..6.
+// ev[(slot * nc + cell) * KB + s]
 template <int KB>
 __global__ __launch_bounds__(256) void fc_rhs_elem_b(int nc, int nn, const int* __restrict__ cn, const double* __restrict__ geom,
                                                      const double* __restrict__ un, const double* __restrict__ unn,
@@ -170,30 +184,46 @@ __global__ __launch_bounds__(256) void fc_rhs_elem_b(int nc, int nn, const int* 
                                                      int ustride, double cm_n, double cm_nn, double cc_n, double cc_nn,
                                                      double* __restrict__ ev) {
   constexpr int CPB = 256 / (8 * KB);  // cells per workgroup
+  __shared__ double nod[6][256];       // fields (ux, uy of u_n; ux, uy of u_nn; fx, fy) x [cell][node 8][s]
   __shared__ double gs[2][256];
+  __shared__ double tph[FC_NQ * 6], tdx[FC_NQ * 6], tde[FC_NQ * 6];
   const int t = threadIdx.x;
   const int s = t % KB, lane = (t / KB) % 8, cw = t / (8 * KB);
   const int cl = blockIdx.x * CPB + cw;
   const bool active = cl < nc;
   const int c = active ? cl : 0;
-  const int q = lane < FC_NQ ? lane : FC_NQ - 1;
-  const double j00 = geom[c], j01 = geom[nc + c], j10 = geom[2 * nc + c], j11 = geom[3 * nc + c];
-  const double wq = lane < FC_NQ ? c_qw[q] * 0.5 * geom[4 * nc + c] : 0.0;
-  double ux = 0, uy = 0, uxi = 0, uet = 0, vxi = 0, vet = 0;
-  double wx = 0, wy = 0, wxi = 0, wet = 0, zxi = 0, zet = 0;
-  double gx = 0, gy = 0;
-#pragma unroll
-  for (int a = 0; a < 6; ++a) {
-    const int n = cn[a * nc + c];
-    const double ax = un[(size_t)n * KB + s], ay = un[(size_t)(nn + n) * KB + s];
-    const double bx = unn[(size_t)n * KB + s], by = unn[(size_t)(nn + n) * KB + s];
+  if (t < FC_NQ * 6) {
+    tph[t] = c_phi2[t];
+    tdx[t] = c_dphi2[2 * t];
+    tde[t] = c_dphi2[2 * t + 1];
+  }
+  {
+    const int n = cn[(lane < 6 ? lane : 0) * nc + c];
     double fx = 0.0, fy = 0.0;
     for (int k = 0; k < n_act; ++k) {
       const double uk = uforce[s * ustride + k];
       fx += uk * fprof[(size_t)k * 2 * nn + n];
       fy += uk * fprof[(size_t)k * 2 * nn + nn + n];
     }
-    const double ph = c_phi2[q * 6 + a], dx = c_dphi2[(q * 6 + a) * 2], de = c_dphi2[(q * 6 + a) * 2 + 1];
+    nod[0][t] = un[(size_t)n * KB + s];
+    nod[1][t] = un[(size_t)(nn + n) * KB + s];
+    nod[2][t] = unn[(size_t)n * KB + s];
+    nod[3][t] = unn[(size_t)(nn + n) * KB + s];
+    nod[4][t] = fx;
+    nod[5][t] = fy;
+  }
+  const int q = lane < FC_NQ ? lane : FC_NQ - 1;
+  const double j00 = geom[c], j01 = geom[nc + c], j10 = geom[2 * nc + c], j11 = geom[3 * nc + c];
+  const double wq = lane < FC_NQ ? c_qw[q] * 0.5 * geom[4 * nc + c] : 0.0;
+  __syncthreads();
+  double ux = 0, uy = 0, uxi = 0, uet = 0, vxi = 0, vet = 0;
+  double wx = 0, wy = 0, wxi = 0, wet = 0, zxi = 0, zet = 0;
+  double gx = 0, gy = 0;
+  const int nb = cw * 8 * KB + s;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    const double ax = nod[0][nb + a * KB], ay = nod[1][nb + a * KB], bx = nod[2][nb + a * KB], by = nod[3][nb + a * KB];
+    const double ph = tph[q * 6 + a], dx = tdx[q * 6 + a], de = tde[q * 6 + a];
     ux += ph * ax;
     uy += ph * ay;
     uxi += dx * ax;
@@ -206,8 +236,8 @@ __global__ __launch_bounds__(256) void fc_rhs_elem_b(int nc, int nn, const int* 
     wet += de * bx;
     zxi += dx * by;
     zet += de * by;
-    gx += ph * fx;
-    gy += ph * fy;
+    gx += ph * nod[4][nb + a * KB];
+    gy += ph * nod[5][nb + a * KB];
   }
   const double ux_x = uxi * j00 + uet * j10, ux_y = uxi * j01 + uet * j11;
   const double uy_x = vxi * j00 + vet * j10, uy_y = vxi * j01 + vet * j11;
@@ -220,12 +250,11 @@ __global__ __launch_bounds__(256) void fc_rhs_elem_b(int nc, int nn, const int* 
   __syncthreads();
   if (active && lane < 6) {
     double accx = 0.0, accy = 0.0;
-    const int base = cw * 8 * KB + s;
 #pragma unroll
     for (int p = 0; p < FC_NQ; ++p) {
-      const double pa = c_phi2[p * 6 + lane];
-      accx += pa * gs[0][base + p * KB];
-      accy += pa * gs[1][base + p * KB];
+      const double pa = tph[p * 6 + lane];
+      accx += pa * gs[0][nb + p * KB];
+      accy += pa * gs[1][nb + p * KB];
     }
     ev[((size_t)lane * nc + c) * KB + s] = accx;
     ev[((size_t)(6 + lane) * nc + c) * KB + s] = accy;
@@ -269,95 +298,135 @@ __global__ __launch_bounds__(256) void fc_rhs_gather_b(int N, const int* __restr
   y[(size_t)i * KB + s] = acc;
 }
 
-// fc_tail for KB simulations.  Row workgroups: 4 KB lanes per permuted row (lane = j KB + s: simulation s, every
-// fourth matrix entry from j), the matrix row is read once for all simulations.  Cell workgroups (first in the grid):
-// thread = (cell, Radon point, simulation).  partial[(w * G + block) * KB + s], w = 0: sum r^2, 1: sum b^2, 2: sum e.
+// fc_tail for KB simulations.  Bound by vector-memory instructions and by the length of its dependent chain, so every
+// load moves as much as it can and a workgroup is small (256 threads: many of them per CU, in different phases): a row
+// workgroup gives 4 KB lanes to a permuted row — lane = (j < 8, simulation pair) — and gathers the solution for TWO
+// simulations per lane (16 B) at the row's j-th, (j + 8)-th ... matrix entry: the matrix row is read once for all
+// simulations.  Cell workgroups (first in the grid) bring a cell's nodal velocities to LDS once (thread = (cell, node,
+// simulation)) and evaluate the energy integrand from there (thread = (cell, Radon point, simulation)).
+// partial[(s * 3 + w) * G + block], w = 0: sum r^2, 1: sum b^2, 2: sum e  (fixed order: reproducible).
+typedef double fc_d2u __attribute__((ext_vector_type(2), aligned(8)));
 template <int KB>
-__global__ __launch_bounds__(1024) void fc_tail_b(int N, int nn2, const int* __restrict__ perm, const double* __restrict__ x,
+__global__ __launch_bounds__(256) void fc_tail_b(int N, int nn2, const int* __restrict__ perm, const double* __restrict__ x,
                                                  const double* __restrict__ b, const int* __restrict__ a_rowptr,
                                                  const int* __restrict__ a_col, const double* __restrict__ a_val, int n_row_blocks,
                                                  int reps, int nc, const int* __restrict__ cn, const double* __restrict__ geom,
                                                  const int* __restrict__ iperm, double* __restrict__ up, double* __restrict__ u_n,
                                                  double* __restrict__ u_nn, double* __restrict__ p_n, int* __restrict__ flag,
                                                  double* __restrict__ partial) {
-  constexpr int LPR = 4 * KB, RPB = 1024 / LPR;  // lanes per row, rows per workgroup and repetition
-  constexpr int CPB = 1024 / (8 * KB);           // cells per cell workgroup and repetition
-  const int t = threadIdx.x, s = t % KB;
+  constexpr int HP = KB / 2;                    // simulation pairs
+  constexpr int LPR = 8 * HP, RPB = 256 / LPR;  // lanes per row, rows per workgroup and repetition
+  constexpr int CPB = 256 / (8 * KB);           // cells per cell workgroup and repetition
+  const int t = threadIdx.x;
   const int G = gridDim.x;
   const int n_cell_blocks = G - n_row_blocks;
   const int rb = (int)blockIdx.x - n_cell_blocks;
-  double r2 = 0.0, b2 = 0.0, e = 0.0;
+  __shared__ double red[2][256];
   if (rb >= 0) {
-    const int j = (t % LPR) / KB;
+    const int sp = t % HP, j = (t % LPR) / HP;
+    double r2[2] = {0.0, 0.0}, b2[2] = {0.0, 0.0};
     for (int rep = 0; rep < reps; ++rep) {
       const int i = (rb * reps + rep) * RPB + t / LPR;
-      double sa = 0.0;
-      if (i < N) {
+      double sa0 = 0.0, sa1 = 0.0;
+      if (i < N && a_rowptr) {
         const int k0 = a_rowptr[i], k1 = a_rowptr[i + 1];
-        double s0 = 0.0, s1 = 0.0;
-        for (int base = k0; base < k1; base += 8) {
-          const int ka = base + j, kb = ka + 4;
+        double t0 = 0.0, t1 = 0.0;
+        for (int base = k0; base < k1; base += 16) {
+          const int ka = base + j, kb = ka + 8;
           const int ca = ka < k1 ? a_col[ka] : 0, cb = kb < k1 ? a_col[kb] : 0;
           const double va = ka < k1 ? a_val[ka] : 0.0, vb = kb < k1 ? a_val[kb] : 0.0;
-          s0 += va * x[(size_t)ca * KB + s];
-          s1 += vb * x[(size_t)cb * KB + s];
+          const fc_d2u xa = *reinterpret_cast<const fc_d2u*>(x + (size_t)ca * KB + 2 * sp);
+          const fc_d2u xb = *reinterpret_cast<const fc_d2u*>(x + (size_t)cb * KB + 2 * sp);
+          sa0 += va * xa.x;
+          sa1 += va * xa.y;
+          t0 += vb * xb.x;
+          t1 += vb * xb.y;
         }
-        sa = s0 + s1;
+        sa0 += t0;
+        sa1 += t1;
       }
-      sa += __shfl_down(sa, 2 * KB, LPR);
-      sa += __shfl_down(sa, KB, LPR);
+#pragma unroll
+      for (int off = 4 * HP; off >= HP; off >>= 1) {
+        sa0 += __shfl_down(sa0, off, LPR);
+        sa1 += __shfl_down(sa1, off, LPR);
+      }
       if (i < N && j == 0) {
         const int r = perm[i];
-        const double v = x[(size_t)i * KB + s];
-        const double bb = b[(size_t)i * KB + s], res = bb - sa;
-        r2 += res * res;
-        b2 += bb * bb;
-        up[(size_t)r * KB + s] = v;
+        const fc_d2u v = *reinterpret_cast<const fc_d2u*>(x + (size_t)i * KB + 2 * sp);
+        const fc_d2u bb = *reinterpret_cast<const fc_d2u*>(b + (size_t)i * KB + 2 * sp);
+        const double res0 = bb.x - sa0, res1 = bb.y - sa1;
+        r2[0] += res0 * res0;
+        r2[1] += res1 * res1;
+        b2[0] += bb.x * bb.x;
+        b2[1] += bb.y * bb.y;
+        *reinterpret_cast<fc_d2u*>(up + (size_t)r * KB + 2 * sp) = v;
         if (r < nn2) {
-          u_nn[(size_t)r * KB + s] = u_n[(size_t)r * KB + s];
-          u_n[(size_t)r * KB + s] = v;
-          if (!isfinite(v)) atomicOr(flag + s, 1);
+          *reinterpret_cast<fc_d2u*>(u_nn + (size_t)r * KB + 2 * sp) = *reinterpret_cast<const fc_d2u*>(u_n + (size_t)r * KB + 2 * sp);
+          *reinterpret_cast<fc_d2u*>(u_n + (size_t)r * KB + 2 * sp) = v;
+          if (!isfinite(v.x)) atomicOr(flag + 2 * sp, 1);
+          if (!isfinite(v.y)) atomicOr(flag + 2 * sp + 1, 1);
         } else {
-          p_n[(size_t)(r - nn2) * KB + s] = v;
+          *reinterpret_cast<fc_d2u*>(p_n + (size_t)(r - nn2) * KB + 2 * sp) = v;
         }
       }
     }
-  } else {
-    const int q = (t / KB) % 8;
-    for (int rep = 0; rep < reps; ++rep) {
-      const int c = ((int)blockIdx.x * reps + rep) * CPB + t / (8 * KB);
-      if (c < nc && q < FC_NQ) {
-        double ux = 0.0, uy = 0.0;
-        const int nn = nn2 >> 1;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          const int n = cn[(size_t)a * nc + c];
-          const double ph = c_phi2[q * 6 + a];
-          ux += ph * x[(size_t)iperm[n] * KB + s];
-          uy += ph * x[(size_t)iperm[nn + n] * KB + s];
-        }
-        e += c_qw[q] * 0.5 * geom[4 * (size_t)nc + c] * (ux * ux + uy * uy);
-      }
-    }
-  }
-  // threads t, t + KB, t + 2 KB, ... belong to the same simulation
-  __shared__ double red[3][1024];
-  red[0][t] = r2;
-  red[1][t] = b2;
-  red[2][t] = e;
-  __syncthreads();
-  for (int st = 512; st >= KB; st >>= 1) {
-    if (t < st) {
-      red[0][t] += red[0][t + st];
-      red[1][t] += red[1][t + st];
-      red[2][t] += red[2][t + st];
+    // the (j = 0) lanes park their sums at [row of the workgroup][s]; thread s < KB adds the rows up in order
+    if (j == 0) {
+      const int row = t / LPR;
+      red[0][row * KB + 2 * sp] = r2[0];
+      red[0][row * KB + 2 * sp + 1] = r2[1];
+      red[1][row * KB + 2 * sp] = b2[0];
+      red[1][row * KB + 2 * sp + 1] = b2[1];
     }
     __syncthreads();
-  }
-  if (t < KB) {
-    partial[((size_t)0 * G + blockIdx.x) * KB + t] = red[0][t];
-    partial[((size_t)1 * G + blockIdx.x) * KB + t] = red[1][t];
-    partial[((size_t)2 * G + blockIdx.x) * KB + t] = red[2][t];
+    if (t < KB) {
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int r = 0; r < RPB; ++r) {
+        s0 += red[0][r * KB + t];
+        s1 += red[1][r * KB + t];
+      }
+      partial[((size_t)t * 3 + 0) * G + blockIdx.x] = s0;
+      partial[((size_t)t * 3 + 1) * G + blockIdx.x] = s1;
+      partial[((size_t)t * 3 + 2) * G + blockIdx.x] = 0.0;
+    }
+  } else {
+    const int s = t % KB, lane = (t / KB) % 8, cw = t / (8 * KB);
+    const int nn = nn2 >> 1;
+    double e = 0.0;
+    for (int rep = 0; rep < reps; ++rep) {
+      const int c = ((int)blockIdx.x * reps + rep) * CPB + cw;
+      const int cc = c < nc ? c : 0;
+      if (rep > 0) __syncthreads();
+      {
+        const int n = cn[(size_t)(lane < 6 ? lane : 0) * nc + cc];
+        red[0][t] = x[(size_t)iperm[n] * KB + s];
+        red[1][t] = x[(size_t)iperm[nn + n] * KB + s];
+      }
+      __syncthreads();
+      if (c < nc && lane < FC_NQ) {
+        double ux = 0.0, uy = 0.0;
+        const int nb = cw * 8 * KB + s;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          const double ph = c_phi2[lane * 6 + a];
+          ux += ph * red[0][nb + a * KB];
+          uy += ph * red[1][nb + a * KB];
+        }
+        e += c_qw[lane] * 0.5 * geom[4 * (size_t)nc + cc] * (ux * ux + uy * uy);
+      }
+    }
+    __syncthreads();
+    red[0][t] = e;
+    __syncthreads();
+    if (t < KB) {
+      double se = 0.0;
+#pragma unroll
+      for (int g = 0; g < 8 * CPB; ++g) se += red[0][g * KB + t];
+      partial[((size_t)t * 3 + 0) * G + blockIdx.x] = 0.0;
+      partial[((size_t)t * 3 + 1) * G + blockIdx.x] = 0.0;
+      partial[((size_t)t * 3 + 2) * G + blockIdx.x] = se;
+    }
   }
 }
 
@@ -367,16 +436,29 @@ template <int KB>
 __global__ __launch_bounds__(256) void fc_final_b(int G, int n_cell_blocks, const double* __restrict__ partial, int n_sens,
                                                   const int* __restrict__ s_rowptr, const int* __restrict__ s_idx,
                                                   const double* __restrict__ s_w, const double* __restrict__ up,
-                                                  const int* __restrict__ flag, double* __restrict__ rec, int rstride, double seq,
-                                                  int compute_energy) {
+                                                  const int* __restrict__ flag, double* __restrict__ rec, int rstride,
+                                                  const double* __restrict__ seq_in, int compute_energy) {
   const int s = blockIdx.x, t = threadIdx.x;
   __shared__ double red[3][256];
   __shared__ double ysh[64];
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-  for (int i = t; i < G; i += 256) {
-    a0 += partial[((size_t)0 * G + i) * KB + s];
-    a1 += partial[((size_t)1 * G + i) * KB + s];
-    if (i < n_cell_blocks) a2 += partial[((size_t)2 * G + i) * KB + s];
+  const double* __restrict__ ps = partial + (size_t)s * 3 * G;  // [w][block], contiguous per simulation
+  // one workgroup streams 3 G doubles: eight independent loads per array and trip keep enough of them in flight
+  for (int base = 0; base < G; base += 8 * 256) {
+    double v0[8], v1[8], v2[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * 256 + t;
+      v0[u] = i < G ? ps[i] : 0.0;
+      v1[u] = i < G ? ps[(size_t)G + i] : 0.0;
+      v2[u] = i < n_cell_blocks ? ps[2 * (size_t)G + i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a0 += v0[u];
+      a1 += v1[u];
+      a2 += v2[u];
+    }
   }
   const int wave = t >> 6, lane = t & 63;
   for (int q = wave; q < n_sens; q += 4) {
@@ -401,7 +483,7 @@ __global__ __launch_bounds__(256) void fc_final_b(int G, int n_cell_blocks, cons
   if (t == 0) {
     double* r = rec + (size_t)s * rstride;
     fc_publish(ysh, n_sens, compute_energy ? 0.5 * red[2][0] : 0.0, red[0][0], red[1][0], (double)(flag[s] & 1), r + 64, r + 128, r + 129,
-               r + 136, r + 137, seq);
+               r + 136, r + 137, seq_in[0]);
   }
 }
 

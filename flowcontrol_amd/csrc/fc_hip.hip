@@ -293,6 +293,10 @@ struct fc_ctx {
     bool pending = false;
     int pend_slot = 0, pend_energy = 0;
     double pend_seq = 0.0;
+    // the launches of one batched step as a HIP graph per (order slot, energy flag): captured on first use, replayed as long as
+    // no buffer or parameter that a kernel argument was taken from has changed (gsig: hash of all of them)
+    hipGraphExec_t gexec[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    uint64_t gsig[2][2] = {{0, 0}, {0, 0}};
   } bat;
 };
 
@@ -1350,10 +1354,13 @@ int fc_create(fc_handle* out, int device, int32_t nv, int32_t ne, int32_t nc, co
   return FC_OK;
 }
 
+static void batch_drop_graphs(fc_ctx* h);
+
 int fc_destroy(fc_handle h) {
   if (!h) return FC_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  batch_drop_graphs(h);
   if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
   if (h->pin) (void)hipHostFree(h->pin);
   if (h->xstage) (void)hipHostFree(h->xstage);
@@ -3421,8 +3428,8 @@ static int build_batch_tables(fc_ctx* h) {
     if (sel.empty()) return;
     const double mean_chunks = cols_w / std::max(w, 1.0) / 32.0;
     int cg = 1;
-    while (cg < 8 && mean_chunks / cg > chunks_per_wave) cg *= 2;
-    if (force_cg == 1 || force_cg == 2 || force_cg == 4 || force_cg == 8) cg = force_cg;
+    while (cg < 16 && mean_chunks / cg > chunks_per_wave) cg *= 2;
+    if (force_cg == 1 || force_cg == 2 || force_cg == 4 || force_cg == 8 || force_cg == 16) cg = force_cg;
     const int first = (int)tasks.size();
     for (size_t g : sel) {
       const int64_t i0 = nd(g, 2), ni = nd(g, 3), nb = nd(g, 4), voff = nd(g, 5), nf = ni + nb;
@@ -3503,6 +3510,7 @@ int fc_set_batch(fc_handle h, int32_t k) {
   fc_ctx::Batch& B = h->bat;
   if (k == 0) {
     HIPCHK(hipStreamSynchronize(h->stream));
+    batch_drop_graphs(h);
     B.u_n.release(), B.u_nn.release(), B.p_n.release(), B.up.release(), B.b.release(), B.buf.release(), B.ev.release(), B.partial.release();
     B.flag.release();
     B.k = B.KB = 0;
@@ -3519,7 +3527,7 @@ int fc_set_batch(fc_handle h, int32_t k) {
     FCCHK(B.b.alloc(N * KB));
     FCCHK(B.buf.alloc((2 * N + (size_t)B.scratch_rows + 1) * KB));  // + the zero row of the operand lists
     FCCHK(B.ev.alloc((size_t)12 * h->nc * KB));
-    FCCHK(B.partial.alloc((size_t)3 * 8192 * KB));
+    FCCHK(B.partial.alloc((size_t)3 * 40000 * KB));
     FCCHK(B.flag.alloc(16));
   }
   B.k = k;
@@ -3583,8 +3591,9 @@ int fc_get_solution_batch(fc_handle h, int32_t k, double* up) {
 }
 
 // the launches of one batched step; controls are read from the host-mapped record (uctrl at s * kRecStride, body-force
-// amplitudes at s * kRecStride + 32), every simulation's outputs go to its own record
-static int batch_enqueue(fc_ctx* h, int order_slot, int compute_energy, double seq) {
+// amplitudes at s * kRecStride + 32, the step's sequence number at kSeqSlot), every simulation's outputs go to its own record
+constexpr int kSeqSlot = 4000;
+static int batch_launches(fc_ctx* h, int order_slot, int compute_energy) {
   fc_ctx::Batch& B = h->bat;
   OrderSys& S = h->sys[order_slot];
   const StepCoeffs c = coeffs_for(h, order_slot);
@@ -3602,22 +3611,93 @@ static int batch_enqueue(fc_ctx* h, int order_slot, int compute_energy, double s
   FC_KB_DISPATCH(KB, FC_GATH(4), FC_GATH(8), FC_GATH(16));
 #undef FC_GATH
   FCCHK(batch_apply(h, S));
-  // tail: residual monitor, scatter / shift, energy; <= ~2000 workgroups per kind
-  const int rpb = 1024 / (4 * KB), cpb = 1024 / (8 * KB);
-  const int reps = std::max(1, nblocks(nblocks(N, rpb), 5000));  // 1 unless the mesh is large: the repetitions of a workgroup run one after the other
+  // tail: residual monitor, scatter / shift, energy
+  const int rpb = 256 / (4 * KB), cpb = 256 / (8 * KB);
+  const int reps = std::max(1, nblocks(nblocks(N, rpb), 24000));  // 1 unless the mesh is large: the repetitions of a workgroup run one after the other
   const int n_row_blocks = nblocks(N, rpb * reps), n_cell_blocks = compute_energy ? nblocks(nc, cpb * reps) : 0;
   const int G = n_row_blocks + n_cell_blocks;
   if ((size_t)3 * G * KB > B.partial.n) return fail(FC_ERR_INVALID, "fc_step_batch: partial buffer too small");
-#define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(1024), 0, h->stream, N, 2 * h->nn, h->perm.p, B.buf.p + (size_t)N * K, B.b.p, S.Ap_rowptr.p, \
+  static const bool dbg_nores = [] { const char* e = std::getenv("FC_BATCH_DEBUG_NORES"); return e && e[0] == '1'; }();  // timing experiments only
+#define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, B.buf.p + (size_t)N * K, B.b.p, dbg_nores ? nullptr : S.Ap_rowptr.p, \
                                        S.Ap_col.p, S.Ap_val.p, n_row_blocks, reps, nc, h->cn.p, h->geom.p, h->iperm.p, B.up.p, B.u_n.p, B.u_nn.p, B.p_n.p,      \
                                        B.flag.p, B.partial.p)
   FC_KB_DISPATCH(KB, FC_TAILB(4), FC_TAILB(8), FC_TAILB(16));
 #undef FC_TAILB
 #define FC_FINB(K) hipLaunchKernelGGL((fc_final_b<K>), dim3(B.k), dim3(256), 0, h->stream, G, n_cell_blocks, B.partial.p, h->n_sens, h->s_rowptr.p, h->s_idx.p, \
-                                      h->s_w.p, B.up.p, B.flag.p, h->pin_dev, kRecStride, seq, compute_energy)
+                                      h->s_w.p, B.up.p, B.flag.p, h->pin_dev, kRecStride, h->pin_dev + kSeqSlot, compute_energy)
   FC_KB_DISPATCH(KB, FC_FINB(4), FC_FINB(8), FC_FINB(16));
 #undef FC_FINB
   HIPCHK(hipGetLastError());
+  return FC_OK;
+}
+
+// everything a kernel argument of batch_launches is taken from, hashed (FNV-1a): a captured graph is replayed only while
+// this is unchanged
+static uint64_t batch_signature(fc_ctx* h, int order_slot, int compute_energy) {
+  fc_ctx::Batch& B = h->bat;
+  OrderSys& S = h->sys[order_slot];
+  const StepCoeffs c = coeffs_for(h, order_slot);
+  auto bits = [](double v) {
+    uint64_t u;
+    std::memcpy(&u, &v, sizeof u);
+    return u;
+  };
+  const uint64_t words[] = {
+      (uint64_t)(uintptr_t)h->cn.p, (uint64_t)(uintptr_t)h->geom.p, (uint64_t)(uintptr_t)B.u_n.p, (uint64_t)(uintptr_t)B.u_nn.p, (uint64_t)(uintptr_t)h->fprof.p,
+      (uint64_t)(uintptr_t)B.ev.p, (uint64_t)(uintptr_t)h->gptr_p.p, (uint64_t)(uintptr_t)h->gidx_p.p, (uint64_t)(uintptr_t)h->bcslot_p.p,
+      (uint64_t)(uintptr_t)h->bcprof.p, (uint64_t)(uintptr_t)S.lift_p.p, (uint64_t)(uintptr_t)B.b.p, (uint64_t)(uintptr_t)B.buf.p, (uint64_t)(uintptr_t)S.c_rowptr.p,
+      (uint64_t)(uintptr_t)S.c_col.p, (uint64_t)(uintptr_t)S.c_val.p, (uint64_t)(uintptr_t)B.tasks.p, (uint64_t)(uintptr_t)B.olist.p, (uint64_t)(uintptr_t)S.f_val.p,
+      (uint64_t)(uintptr_t)B.fptr.p, (uint64_t)(uintptr_t)B.fsrc.p, (uint64_t)(uintptr_t)h->perm.p, (uint64_t)(uintptr_t)h->iperm.p, (uint64_t)(uintptr_t)S.Ap_rowptr.p,
+      (uint64_t)(uintptr_t)S.Ap_col.p, (uint64_t)(uintptr_t)S.Ap_val.p, (uint64_t)(uintptr_t)B.up.p, (uint64_t)(uintptr_t)B.p_n.p, (uint64_t)(uintptr_t)B.flag.p,
+      (uint64_t)(uintptr_t)B.partial.p, (uint64_t)(uintptr_t)h->s_rowptr.p, (uint64_t)(uintptr_t)h->s_idx.p, (uint64_t)(uintptr_t)h->s_w.p,
+      (uint64_t)(uintptr_t)h->pin_dev, (uint64_t)B.k, (uint64_t)B.KB, (uint64_t)h->n_act, (uint64_t)h->n_sens, (uint64_t)(h->have_force ? 1 : 0),
+      (uint64_t)(S.have_c ? 1 : 0), (uint64_t)compute_energy, (uint64_t)B.launches.size(), (uint64_t)B.tasks.n, bits(c.cm_n), bits(c.cm_nn), bits(c.cc_n),
+      bits(c.cc_nn)};
+  uint64_t hsh = 1469598103934665603ull;
+  for (uint64_t w : words)
+    for (int b = 0; b < 8; ++b) {
+      hsh ^= (w >> (8 * b)) & 0xffu;
+      hsh *= 1099511628211ull;
+    }
+  return hsh ? hsh : 1;
+}
+
+static void batch_drop_graphs(fc_ctx* h) {
+  for (int o = 0; o < 2; ++o)
+    for (int e = 0; e < 2; ++e) {
+      if (h->bat.gexec[o][e]) (void)hipGraphExecDestroy(h->bat.gexec[o][e]);
+      h->bat.gexec[o][e] = nullptr;
+      h->bat.gsig[o][e] = 0;
+    }
+}
+
+static int batch_enqueue(fc_ctx* h, int order_slot, int compute_energy) {
+  static const bool use_graph = [] {
+    const char* e = std::getenv("FC_BATCH_GRAPH");  // 0: plain launches
+    return !(e && e[0] == '0');
+  }();
+  if (!use_graph || h->timing) return batch_launches(h, order_slot, compute_energy);
+  fc_ctx::Batch& B = h->bat;
+  const int ei = compute_energy ? 1 : 0;
+  const uint64_t sig = batch_signature(h, order_slot, compute_energy);
+  if (!B.gexec[order_slot][ei] || B.gsig[order_slot][ei] != sig) {
+    if (B.gexec[order_slot][ei]) (void)hipGraphExecDestroy(B.gexec[order_slot][ei]);
+    B.gexec[order_slot][ei] = nullptr;
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    const int code = batch_launches(h, order_slot, compute_energy);
+    const hipError_t e = hipStreamEndCapture(h->stream, &graph);
+    if (code != FC_OK) {
+      if (graph) (void)hipGraphDestroy(graph);
+      return code;
+    }
+    if (e != hipSuccess) return fail(FC_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    const hipError_t e2 = hipGraphInstantiate(&B.gexec[order_slot][ei], graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e2 != hipSuccess) return fail(FC_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2));
+    B.gsig[order_slot][ei] = sig;
+  }
+  HIPCHK(hipGraphLaunch(B.gexec[order_slot][ei], h->stream));
   return FC_OK;
 }
 
@@ -3649,7 +3729,8 @@ int fc_step_batch_begin(fc_handle h, int order_slot, int32_t k, const double* u_
   B.pend_slot = order_slot;
   B.pend_energy = compute_energy;
   B.pend_seq = (double)(++h->seq);
-  FCCHK(batch_enqueue(h, order_slot, compute_energy, B.pend_seq));
+  pin[kSeqSlot] = B.pend_seq;
+  FCCHK(batch_enqueue(h, order_slot, compute_energy));
   B.pending = true;
   return FC_OK;
 }

@@ -1,0 +1,266 @@
+"""Shared-operator batched stepping (``fc_step_batch`` / ``BatchedFlowSolver``): k lock-step simulations on one handle.
+
+The reference runs such sweeps as k independent ``FlowSolver`` instances (IC sweeps
+``src/examples/lidcavity/batch_run_lidcavity.py:197-215``, controller optimisation ``src/utils/optim.py:95-102``), each
+calling ``FlowSolver.step`` (``src/flowcontrol/flowsolver.py:703-799``).  Parity bar: every trajectory of a batch equals
+its own single run (same device, public ``FlowSolver.step``) to 1e-12 and, where a golden series of the CPU oracle exists
+for the scenario, that series to 1e-8 — the batched factor apply is a different summation order on the fp64 matrix
+cores, nothing else.
+"""
+import ctypes as C
+import tempfile
+
+import numpy as np
+import pytest
+
+from flowcontrol_amd.controller import Controller
+from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver
+from flowcontrol_amd.fem.spaces import Function
+from flowcontrol_amd.flowsolverparameters import ParamIC
+
+pytestmark = pytest.mark.gpu
+
+N_STEPS = 20
+
+
+def _rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(np.asarray(b))
+
+
+def _ycols(ts):
+    return [c for c in ts.columns if c.startswith("y_meas_")]
+
+
+def _solver(golden_dir, **kw):
+    fs = CylinderFlowSolver.make_default(Re=100, path_out=tempfile.mkdtemp(), num_steps=N_STEPS, **kw)
+    U0, P0 = Function(fs.W, np.load(golden_dir / "cylinder_O1.npz")["UP0"]).split()
+    fs._assign_steady_state(U0, P0)
+    return fs
+
+
+class _Scenario:
+    """One trajectory: an initial condition and a control law u = law(step index, y_meas before the step)."""
+
+    def __init__(self, ic, make_law):
+        self.ic, self.make_law = ic, make_law
+
+
+def _scenarios(golden_dir):
+    kfile = golden_dir / "controllers" / "Kopt_reduced13.mat"
+
+    def open_loop(amp, w):
+        return lambda: (lambda n, y: np.array([amp * np.sin(w * n), -0.5 * amp * np.cos(0.7 * w * n)]))
+
+    def feedback(gain):
+        def make():
+            K = Controller.from_file(file=kfile, x0=None)
+
+            def law(n, y):
+                u = K.step(y=-gain * y[0], dt=0.005)
+                return np.array([u[0], u[0]])
+
+            return law
+
+        return make
+
+    def lowpass(c):
+        def make():
+            K = Controller(A=[[-40.0]], B=[[1.0]], C=[[c]], D=[[0.0]])
+            return lambda n, y: np.array([K.step(y=y[1], dt=0.005)[0], -K.x[0] * c])
+
+        return make
+
+    return [
+        _Scenario(ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0), open_loop(0.0, 0.0)),  # the oracle's open-loop fixture (ol_*)
+        _Scenario(ParamIC(xloc=0.0, yloc=0.0, radius=1.0, amplitude=1.0), feedback(1.0)),  # the oracle's closed-loop fixture (cl_*)
+        _Scenario(ParamIC(xloc=2.5, yloc=0.2, radius=0.6, amplitude=0.7), open_loop(0.05, 0.3)),
+        _Scenario(ParamIC(xloc=1.5, yloc=-0.3, radius=0.4, amplitude=1.3), open_loop(0.02, 0.9)),
+        _Scenario(ParamIC(xloc=0.0, yloc=0.0, radius=1.0, amplitude=0.5), feedback(0.5)),
+        _Scenario(ParamIC(xloc=3.0, yloc=0.0, radius=0.8, amplitude=1.0), feedback(2.0)),
+        _Scenario(ParamIC(xloc=2.0, yloc=0.5, radius=0.5, amplitude=-1.0), lowpass(30.0)),
+        _Scenario(ParamIC(xloc=4.0, yloc=-0.5, radius=1.0, amplitude=2.0), lowpass(-80.0)),
+    ]
+
+
+@pytest.fixture(scope="module")
+def single_runs(golden_dir):
+    """Every scenario on its own through the public FlowSolver.step (one device handle, re-initialised per run)."""
+    fs = _solver(golden_dir)
+    out = []
+    for sc in _scenarios(golden_dir):
+        fs.params_ic = sc.ic
+        fs.initialize_time_stepping(ic=None)
+        law = sc.make_law()
+        for n in range(N_STEPS):
+            fs.step(u_ctrl=law(n, fs.y_meas))
+            assert fs.solve_info[1] < 1e-12
+        ts = fs.timeseries
+        out.append((ts[_ycols(ts)].to_numpy().copy(), ts["dE"].to_numpy().copy(), ts[[c for c in ts.columns if c.startswith("u_ctrl_")]].to_numpy()[1:].copy()))
+    yield fs, out
+    fs.th.release_device()
+
+
+@pytest.mark.parametrize("k", [8, 3, 16])
+def test_batched_trajectories_equal_their_single_runs_and_the_oracle(k, single_runs, golden_dir):
+    """k trajectories with different initial conditions, control inputs and controllers (closed loops through host
+    Controllers that see only their own run's measurements), advanced together: each must equal its single run to 1e-12;
+    runs 0 and 1 are the oracle's open-loop and closed-loop fixtures and must match those to 1e-8."""
+    from flowcontrol_amd.batch import BatchedFlowSolver
+
+    fs, singles = single_runs
+    scen = _scenarios(golden_dir)
+    pick = [i % len(scen) for i in range(k)]  # k = 16: every scenario twice (two columns of one batch must agree bit for bit)
+    bfs = BatchedFlowSolver(fs, k)
+    bfs.initialize_time_stepping(ics=[scen[i].ic for i in pick])
+    laws = [scen[i].make_law() for i in pick]
+    for n in range(N_STEPS):
+        u = np.stack([laws[j](n, bfs.y_meas[j]) for j in range(k)])
+        assert bfs.step(u) is not None
+        assert np.all(bfs.solve_info[:, 1] < 1e-12)
+    assert np.isclose(bfs.t, N_STEPS * 0.005)
+    for j, i in enumerate(pick):
+        ts = bfs.timeseries(j)
+        y1, dE1, u1 = singles[i]
+        assert _rel(ts[_ycols(ts)].to_numpy(), y1) < 1e-12, f"run {j} (scenario {i})"
+        assert _rel(ts["dE"].to_numpy(), dE1) < 1e-12
+        if np.abs(u1).max() > 0:
+            assert _rel(ts[[c for c in ts.columns if c.startswith("u_ctrl_")]].to_numpy()[1:], u1) < 1e-11
+    g = np.load(golden_dir / "cylinder_O1.npz")
+    ts0 = bfs.timeseries(0)
+    assert _rel(ts0[_ycols(ts0)].to_numpy(), g["ol_y"][: N_STEPS + 1]) < 1e-8
+    assert _rel(ts0["dE"].to_numpy(), g["ol_dE"][: N_STEPS + 1]) < 1e-8
+    if k > 1:
+        ts1 = bfs.timeseries(1)
+        assert _rel(ts1[_ycols(ts1)].to_numpy(), g["cl_y"][: N_STEPS + 1]) < 1e-8
+        assert _rel(ts1["dE"].to_numpy(), g["cl_dE"][: N_STEPS + 1]) < 1e-8
+    if k == 16:
+        for j in range(8):  # the same scenario in two columns of the batch: bit-identical
+            a, b = bfs.timeseries(j), bfs.timeseries(j + 8)
+            assert np.array_equal(a[_ycols(a)].to_numpy(), b[_ycols(b)].to_numpy())
+    # fields: the batched state of run 2 is the single run's final state
+    u_n, u_nn, p_n = bfs.state()
+    fs.params_ic = scen[pick[2]].ic
+    fs.initialize_time_stepping(ic=None)
+    law = scen[pick[2]].make_law()
+    for n in range(N_STEPS):
+        fs.step(u_ctrl=law(n, fs.y_meas))
+    assert _rel(u_n[2], fs.fields.u_n.vector().get_local()) < 1e-12
+    assert _rel(u_nn[2], fs.fields.u_nn.vector().get_local()) < 1e-12
+    assert _rel(p_n[2], fs.fields.p_n.vector().get_local()) < 1e-11
+    bfs.close()
+
+
+def test_batched_factor_apply_matches_single_solves(single_runs):
+    """fc_solve_batch: k random right-hand sides through the matrix-core block sweeps vs fc_solve one by one."""
+    from flowcontrol_amd._lib import SLOT_BDF1, SLOT_BDF2
+
+    fs, _ = single_runs
+    dev = fs.th.device()
+    rng = np.random.default_rng(3)
+    for k in (1, 5, 8, 13, 16):
+        dev.set_batch(k)
+        for slot in (SLOT_BDF1, SLOT_BDF2):
+            B = rng.standard_normal((k, dev.N))
+            X = dev.solve_batch(slot, B)
+            for s in range(k):
+                x1, info = dev.solve(slot, B[s])
+                assert _rel(X[s], x1) < 1e-12
+        info = dev.batch_info()
+        assert info["k"] == k and info["KB"] in (4, 8, 16) and info["KB"] >= k
+        assert info["factor_bytes"] == 8.0 * dev.factor_nnz[SLOT_BDF2] or info["factor_bytes"] > 0
+    dev.set_batch(0)
+
+
+def test_one_diverged_run_does_not_touch_the_others(single_runs, golden_dir):
+    """A non-finite state in ONE column of the batch: fc_step_batch reports FC_ERR_DIVERGED and marks that run only; the
+    other runs' measurements are what a clean batch gives (the columns of the block sweeps are independent)."""
+    from flowcontrol_amd._lib import SLOT_BDF1, FcDiverged
+
+    fs, _ = single_runs
+    dev = fs.th.device()
+    k = 4
+    dev.set_batch(k)
+    nn2, nv = 2 * fs.th.nn, fs.th.nv
+    rng = np.random.default_rng(5)
+    u0 = 1e-3 * rng.standard_normal((k, nn2))
+    dev.set_state_batch(u0, u0, np.zeros((k, nv)))
+    y_clean, _, _ = dev.step_batch(SLOT_BDF1, np.zeros((k, 2)))
+    bad = u0.copy()
+    bad[2, 17] = np.inf
+    dev.set_state_batch(bad, bad, np.zeros((k, nv)))
+    with pytest.raises(FcDiverged):
+        dev.step_batch(SLOT_BDF1, np.zeros((k, 2)))
+    info = dev._batch_bufs[4]
+    assert info[2, 3] != 0 and np.all(info[[0, 1, 3], 3] == 0)
+    y = dev._batch_bufs[2][:, : dev.n_sens]
+    assert np.array_equal(y[[0, 1, 3]], y_clean[[0, 1, 3]])
+    dev.set_batch(0)
+
+
+def test_batch_api_refuses_what_it_cannot_do(single_runs):
+    from flowcontrol_amd import _lib
+    from flowcontrol_amd._lib import SLOT_BDF1
+
+    fs, _ = single_runs
+    dev = fs.th.device()
+    with pytest.raises(_lib.FcError):
+        dev.set_batch(17)
+    dev.set_batch(0)
+    with pytest.raises(_lib.FcError):  # no batch allocated
+        _lib.check(dev.lib.fc_step_batch(dev._h, SLOT_BDF1, 4, None, None, None, None, 1, None))
+    dev.set_batch(4)
+    with pytest.raises(_lib.FcError):  # k differs from fc_set_batch
+        _lib.check(dev.lib.fc_step_batch(dev._h, SLOT_BDF1, 3, None, None, None, None, 1, None))
+    dev.set_solver_options(refine=1)
+    with pytest.raises(_lib.FcError):  # refinement sweeps are a single-simulation feature
+        dev.step_batch(SLOT_BDF1, np.zeros((4, 2)))
+    dev.set_solver_options(refine=0)
+    dev.set_batch(0)
+
+
+def test_batched_cavity_force_actuation_closed_loop(golden_dir):
+    """BASELINE config 3's ingredients in a batch (cavity_coarse): body-force actuator (per-run amplitudes enter the element
+    loop), wall-shear sensor, low-pass Controller per run with different gains; run 0 (gain of the committed scenario) against
+    the oracle's closed-loop series tests/golden/cavity_coarse_re7500.npz, all runs against their single runs."""
+    import sys
+
+    sys.path.insert(0, str(golden_dir))
+    from make_config3_fixture import CAVITY_K
+
+    from flowcontrol_amd.batch import BatchedFlowSolver
+    from flowcontrol_amd.examples.cavity.cavityflowsolver import CavityFlowSolver
+
+    g = np.load(golden_dir / "cavity_coarse.npz")
+    ref = np.load(golden_dir / "cavity_coarse_re7500.npz")
+    fs = CavityFlowSolver.make_default(Re=7500, path_out=tempfile.mkdtemp(), num_steps=N_STEPS)
+    U0, P0 = Function(fs.W, g["UP0"]).split()
+    fs._assign_steady_state(U0, P0)
+    gains = [1.0, 0.0, -2.0, 5.0]
+    k = len(gains)
+
+    def controller(gain):
+        return Controller(A=CAVITY_K["A"], B=CAVITY_K["B"], C=[[gain * CAVITY_K["C"][0][0]]], D=CAVITY_K["D"])
+
+    singles = []
+    for gain in gains:
+        fs.initialize_time_stepping(ic=None)
+        K, y0 = controller(gain), fs.y_meas[0]
+        for _ in range(N_STEPS):
+            fs.step(u_ctrl=K.step(y=fs.y_meas[0] - y0, dt=fs.params_time.dt))
+        ts = fs.timeseries
+        singles.append((ts[_ycols(ts)].to_numpy().copy(), ts["dE"].to_numpy().copy()))
+    assert _rel(singles[0][0], ref["y"]) < 1e-8 and _rel(singles[0][1], ref["dE"]) < 1e-8
+    bfs = BatchedFlowSolver(fs, k)
+    bfs.initialize_time_stepping()
+    Ks, y0 = [controller(gn) for gn in gains], bfs.y_meas[:, 0].copy()
+    for _ in range(N_STEPS):
+        bfs.step(np.stack([Ks[j].step(y=bfs.y_meas[j, 0] - y0[j], dt=fs.params_time.dt) for j in range(k)]))
+    for j in range(k):
+        ts = bfs.timeseries(j)
+        assert _rel(ts[_ycols(ts)].to_numpy(), singles[j][0]) < 1e-12
+        assert _rel(ts["dE"].to_numpy(), singles[j][1]) < 1e-12
+    ts0 = bfs.timeseries(0)
+    assert _rel(ts0[_ycols(ts0)].to_numpy(), ref["y"]) < 1e-8
+    assert np.abs(ref["u"]).max() > 0.5  # the loop acts
+    bfs.close()
+    fs.th.release_device()
