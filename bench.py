@@ -16,6 +16,8 @@ One JSON line on rank 0 with the driver's keys plus
   cpu_baseline  compiled single-thread restatement of the reference's per-step work (oracle/cpu_step.cpp element
                 loop + SuperLU triangular solves, 1 core) timed on a bounded sample of the same workload; the numpy
                 oracle's figure is reported next to it
+  replicas      shared-operator batched stepping at N = 1: k = 1, 4, 8, 16 lock-step replicas on one handle
+                (replicas_steps_per_s, bytes per simulated step, roofline of the batched factor sweeps)
   spmv          CSR SpMV probe on the assembled BDF2 matrices of the five shipped meshes (O1: the run's own matrix; the
                 others with a synthetic uniform base flow; cavity_fine is the one beyond the Infinity Cache), % of 8 TB/s
 N > 1 (torchrun, one rank per GPU): the SAME mesh is row-partitioned over the ranks (one sub-tree of the
@@ -177,6 +179,49 @@ def spmv_probe(fs, include_large: bool) -> dict:
     return out
 
 
+def batched_replicas(fs, steps: int, single_rate: float, ks=(1, 4, 8, 16)) -> dict:
+    """Shared-operator batched stepping (fc_step_batch): k lock-step replicas of the headline workload on ONE handle —
+    the reference's IC / controller sweeps run k FlowSolver instances instead (batch_run_lidcavity.py:197-215,
+    utils/optim.py:95-102).  Every batched step is one public BatchedFlowSolver.step() (host-synchronised, measurements and
+    energy of all k runs returned).  The factor sweeps are block products on the fp64 matrix cores; their roofline entry is
+    HBM: (factor bytes + operand / result / fold bytes of one batched apply) / apply time by HIP events."""
+    from flowcontrol_amd._lib import SLOT_BDF2
+    from flowcontrol_amd.batch import BatchedFlowSolver
+
+    dev = fs.th.device()
+    out = {"note": "k replicas of the headline workload advanced together on one handle; replicas_steps_per_s = k x batched steps/s",
+           "single_steps_per_s": single_rate, "per_k": {}}
+    for k in ks:
+        bfs = BatchedFlowSolver(fs, k)
+        bfs.initialize_time_stepping(ics=[fs.params_ic] * k)
+        u = np.zeros((k, 2))
+        for _ in range(20):
+            bfs.step(u)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            bfs.step(u)
+        dt = (time.perf_counter() - t0) / steps
+        ms_apply = dev.bench_batch_apply(SLOT_BDF2, 100)
+        info = dev.batch_info()
+        apply_bytes = info["factor_bytes"] + info["vector_bytes"]
+        # per simulated step, besides the apply: element loop 448 B/cell, gather ~40 B/row, tail: matrix 12 nnz / k + ~100 B/row
+        nnz = dev.nnz
+        other = 448.0 * fs.th.nc + 140.0 * fs.th.N + 12.0 * nnz / k + 170.0 * fs.th.nc
+        out["per_k"][str(k)] = {
+            "k": k, "KB": info["KB"], "replicas_steps_per_s": k / dt, "ms_per_batched_step": dt * 1e3, "x_single": k / dt / single_rate,
+            "bytes_per_simulated_step": apply_bytes / k + other,
+            "y_last_run0": bfs.y_meas[0].tolist(), "residual_max": float(np.max(bfs.solve_info[:, 1])),
+            "roofline": {"bound": "hbm", "kernel": f"fc_nd_block_b<{info['KB']}> + fc_nd_fold_b (batched factor sweeps, v_mfma_f64_16x16x4_f64)",
+                         "achieved": apply_bytes / ms_apply / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": apply_bytes / ms_apply / 1e6 / HBM_PEAK_GBS,
+                         "traffic": None, "apply_us": ms_apply * 1e3, "factor_bytes_per_apply": info["factor_bytes"],
+                         "vector_bytes_per_apply": info["vector_bytes"], "launches_per_apply": info["block_launches"] + info["fold_launches"],
+                         "mfma_tflops": 2.0 * info["factor_bytes"] / 8.0 * info["KB"] / (ms_apply * 1e-3) / 1e12,
+                         "mfma_peak_tflops_f64": 78.6},
+        }
+        bfs.close()
+    return out
+
+
 def dev_index(fs) -> int:
     return int(os.environ.get("LOCAL_RANK", "0"))
 
@@ -292,6 +337,7 @@ def main() -> None:
         roofline = {
             "bound": "hbm", "kernel": "fc_nd_sweep + fc_nd_down_block (factor sweeps)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": "profiles/traffic.json (builder's rocprofv3 --pmc passes of this workload, NOT measured in this run)" if traffic else None,
             "bytes_per_launch": bytes_per_launch, "launches_per_step": tim["sweep_launches"] / args.steps,
             "mean_launch_us": mean_launch_ms * 1e3, "factor_nnz": dev.factor_nnz.get(SLOT_BDF2),
             "applies_per_step": applies / args.steps,
@@ -303,6 +349,9 @@ def main() -> None:
                      if sweep_bytes < 256e6 else
                      f"factors ({sweep_bytes / 1e6:.0f} MB) exceed the 256 MiB Infinity Cache: HBM streaming"),
         }
+        replicas = None
+        if not partitioned and dev.world == 1:
+            replicas = batched_replicas(fs, steps=min(args.steps, 400), single_rate=(1 if partitioned else 1) * args.steps / elapsed)
         phases, nl = dev.profile_steps(SLOT_BDF2, 50, u0)
         spmv = spmv_probe(fs, include_large=not args.no_large_spmv)
         cpu = None
@@ -319,7 +368,7 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "strong" if partitioned else "weak",
+            "scaling": "strong" if partitioned else ("none" if world == 1 else "weak"),
             "vs_baseline": None,
             "dtype": "f64",
             "data": "the reference's shipped mesh O1 (converted data file) + base flow computed by the oracle (golden fixture); "
@@ -335,7 +384,8 @@ def main() -> None:
                 "solver": f"ND selected-inverse depth {dev.depth}, {fs.refine_steps} refinement",
             },
             "batched_steps_per_s": args.steps / t_batched,
-            "replicas_steps_per_s": (world * single_rate) if single_rate else None,
+            "replicas_steps_per_s": (world * single_rate) if single_rate else (replicas["per_k"]["8"]["replicas_steps_per_s"] if replicas else None),
+            "replicas": replicas,
             "roofline": roofline,
             "phase_ms_eager": {k: float(v) for k, v in zip(["rhs_elem", "rhs_gather", "sweeps", "residual_spmv", "finish"], phases)},
             "spmv": spmv,

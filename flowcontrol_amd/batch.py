@@ -81,7 +81,7 @@ class BatchedFlowSolver:
         u_n = np.zeros((k, nn2))
         p_n = np.zeros((k, nv))
         self.y_meas = np.zeros((k, len(fs.params_control.sensor_list)))
-        self.exporters = []
+        dE0 = np.zeros(k)
         for i, ic in enumerate(ics):
             if isinstance(ic, Function):
                 up = ic.vector().array().copy()
@@ -92,9 +92,11 @@ class BatchedFlowSolver:
                     up += pic.amplitude * fs._default_initial_perturbation(xloc=pic.xloc, yloc=pic.yloc, radius=pic.radius).vector().array()
             u_n[i], p_n[i] = up[:nn2], up[nn2:]
             self.y_meas[i] = fs.make_measurement(up=Function(fs.W, up))
-            ex = FlowExporter(paths=fs.paths, fields=fs.fields, V=fs.V, P=fs.P, Tstart=self.params_time.Tstart, dt=self.params_time.dt, save_every=0)
-            ex.log_ic(t=self.params_time.Tstart, y_meas=self.y_meas[i], dE=0.5 * fs._velocity_l2_norm(u_n[i]) ** 2)
-            self.exporters.append(ex)
+            dE0[i] = 0.5 * fs._velocity_l2_norm(u_n[i]) ** 2
+        # the log of all runs as arrays (one append per step, not one dict per run and step); timeseries(i) shapes run i's
+        # rows exactly as FlowExporter does (exporter.py:169-232: IC row without u_ctrl, then one row per step)
+        self._log_ic = (self.params_time.Tstart, self.y_meas.copy(), dE0)
+        self._log: list[tuple] = []
         self.dev.set_state_batch(u_n, u_n, p_n)
         self.order: int | str = "cn" if fs.params_solver.time_scheme == "cn" else 1
         self._u_ctrl_prev = None
@@ -138,14 +140,18 @@ class BatchedFlowSolver:
         if fs.params_solver.time_scheme != "cn":
             self.order = 2
         self.y_meas = y
-        runtime = (time.time() - t0) / k
-        for i, ex in enumerate(self.exporters):
-            ex.log(u_ctrl=u_ctrl[i], y_meas=y[i], dE=dE[i] if want_energy else np.nan, t=self.t, runtime=runtime)
+        self._log.append((self.t, self._u_ctrl_prev, y, dE if want_energy else np.full(k, np.nan), (time.time() - t0) / k))
         return self.y_meas
 
     # ── results ──────────────────────────────────────────────────────────────
     def timeseries(self, i: int) -> pd.DataFrame:
-        return self.exporters[i].to_dataframe()
+        """Log of run ``i``: the columns and rows ``FlowSolver.timeseries`` gives for a single run."""
+        t0, y0, dE0 = self._log_ic
+        ex = FlowExporter(paths=self.fs.paths, fields=self.fs.fields, V=self.fs.V, P=self.fs.P, Tstart=t0, dt=self.params_time.dt, save_every=0)
+        ex.log_ic(t=t0, y_meas=y0[i], dE=dE0[i])
+        for t, u, y, dE, runtime in self._log:
+            ex.log(u_ctrl=u[i], y_meas=y[i], dE=dE[i], t=t, runtime=runtime)
+        return ex.to_dataframe()
 
     def state(self):
         """(u_n, u_nn, p_n) of all runs, arrays (k, ·) — one download."""

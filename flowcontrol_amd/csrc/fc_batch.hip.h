@@ -45,8 +45,11 @@ typedef int fc_i2 __attribute__((ext_vector_type(2)));
 // D[row (l >> 4) + 4 r][col l & 15] in register r.  The k index of an instruction may stand for any four columns as
 // long as A and B agree: lane (row, q) loads the value PAIR at columns 8 u + 2 q, 8 u + 2 q + 1 of its row (16 contiguous
 // bytes; the four q lanes of a row cover 64 contiguous bytes) and feeds the pair to two consecutive instructions.
+#ifndef FC_B_WPE
+#define FC_B_WPE 4  // waves per SIMD the register allocation aims at: 128 VGPRs keep two chunks of a wave in flight
+#endif
 template <int KB>
-__global__ __launch_bounds__(1024) void fc_nd_block_b(const FcBTask* __restrict__ tasks, const int* __restrict__ olist,
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FC_B_WPE, FC_B_WPE))) void fc_nd_block_b(const FcBTask* __restrict__ tasks, const int* __restrict__ olist,
                                                       const double* __restrict__ val, double* __restrict__ buf, int CG) {
   extern __shared__ double fc_b_red[];
   const FcBTask tk = tasks[blockIdx.x];
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(256) void fc_rhs_elem_b(int nc, int nn, const int* 
   }
 }
 
-// fc_rhs_gather, one thread per (permuted row, simulation)
+// fc_rhs_gather, one thread per (permuted row, simulation PAIR): every load moves 16 B
 template <int KB>
 __global__ __launch_bounds__(256) void fc_rhs_gather_b(int N, const int* __restrict__ gptr, const int* __restrict__ gidx,
                                                        const double* __restrict__ ev, const int* __restrict__ bcslot,
@@ -270,151 +273,201 @@ __global__ __launch_bounds__(256) void fc_rhs_gather_b(int N, const int* __restr
                                                        double* __restrict__ y, const int* __restrict__ c_rowptr,
                                                        const int* __restrict__ c_col, const double* __restrict__ c_val,
                                                        const double* __restrict__ un) {
+  typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));
+  constexpr int HP = KB / 2;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = t / KB, s = t % KB;
+  const int i = t / HP, s = 2 * (t % HP);
   if (i >= N) return;
-  double acc = 0.0;
+  double a0 = 0.0, a1 = 0.0;
   const int bs = bcslot[i];
   if (bs >= 0) {
-    for (int k = 0; k < n_act; ++k) acc += uctrl[s * ustride + k] * bcprof[(size_t)bs * n_act + k];
+    for (int k = 0; k < n_act; ++k) {
+      const double p = bcprof[(size_t)bs * n_act + k];
+      a0 += uctrl[s * ustride + k] * p;
+      a1 += uctrl[(s + 1) * ustride + k] * p;
+    }
   } else {
     const int k0 = gptr[i], k1 = gptr[i + 1];
     for (int base = k0; base < k1; base += 8) {
       int id[8];
-      double v[8];
+      d2 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) id[u] = base + u < k1 ? gidx[base + u] : -1;
+      for (int u = 0; u < 8; ++u) id[u] = gidx[base + u < k1 ? base + u : k1 - 1];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = id[u] >= 0 ? ev[(size_t)id[u] * KB + s] : 0.0;
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const d2*>(ev + (size_t)id[u] * KB + s);
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (id[u] >= 0) acc += v[u];
+        if (base + u < k1) {
+          a0 += v[u].x;
+          a1 += v[u].y;
+        }
     }
-    for (int k = 0; k < n_act; ++k) acc -= uctrl[s * ustride + k] * lift[(size_t)k * N + i];
+    for (int k = 0; k < n_act; ++k) {
+      const double l = lift[(size_t)k * N + i];
+      a0 -= uctrl[s * ustride + k] * l;
+      a1 -= uctrl[(s + 1) * ustride + k] * l;
+    }
     if (c_rowptr)
-      for (int k = c_rowptr[i]; k < c_rowptr[i + 1]; ++k) acc -= c_val[k] * un[(size_t)c_col[k] * KB + s];
+      for (int k = c_rowptr[i]; k < c_rowptr[i + 1]; ++k) {
+        const d2 u2 = *reinterpret_cast<const d2*>(un + (size_t)c_col[k] * KB + s);
+        a0 -= c_val[k] * u2.x;
+        a1 -= c_val[k] * u2.y;
+      }
   }
-  b[(size_t)i * KB + s] = acc;
-  y[(size_t)i * KB + s] = acc;
+  const d2 out = {a0, a1};
+  *reinterpret_cast<d2*>(b + (size_t)i * KB + s) = out;
+  *reinterpret_cast<d2*>(y + (size_t)i * KB + s) = out;
 }
 
-// fc_tail for KB simulations.  Bound by vector-memory instructions and by the length of its dependent chain, so every
-// load moves as much as it can and a workgroup is small (256 threads: many of them per CU, in different phases): a row
-// workgroup gives 4 KB lanes to a permuted row — lane = (j < 8, simulation pair) — and gathers the solution for TWO
-// simulations per lane (16 B) at the row's j-th, (j + 8)-th ... matrix entry: the matrix row is read once for all
-// simulations.  Cell workgroups (first in the grid) bring a cell's nodal velocities to LDS once (thread = (cell, node,
-// simulation)) and evaluate the energy integrand from there (thread = (cell, Radon point, simulation)).
+// fc_tail for KB simulations (residual monitor r = b - A x of every simulation, scatter to the W layout, state shift,
+// non-finite flags, energy).  The matrix rows in nested-dissection order come in runs that touch the same few solution
+// rows (a tree node's rows couple to the node and its boundary), so a ROW BLOCK — up to 16 consecutive permuted rows with
+// at most FC_TB_COLS distinct columns, tabulated once per pattern — brings its distinct solution rows [col][KB] to LDS
+// once (coalesced KB-wide rows, instead of one 8 KB-byte gather per matrix entry and simulation pair) and evaluates the
+// 16 rows from there: 16 lanes per row = (j: 16 / HP) x (simulation pair: HP = KB / 2), each lane walks every
+// (16 / HP)-th entry of its row with the entry's LOCAL column (uint16) and reads two simulations (16 B) from LDS.
+// The scatter / shift then uses thread = (row, simulation): all lanes busy.  Cell workgroups (first in the grid) bring
+// a cell's nodal velocities to LDS once and evaluate the energy integrand from there.
 // partial[(s * 3 + w) * G + block], w = 0: sum r^2, 1: sum b^2, 2: sum e  (fixed order: reproducible).
+#define FC_TB_ROWS 16
+#define FC_TB_COLS 192
 typedef double fc_d2u __attribute__((ext_vector_type(2), aligned(8)));
+struct __attribute__((aligned(16))) FcTBlock {
+  int row0, nrows;  // permuted rows [row0, row0 + nrows)
+  int col0, ncols;  // its distinct columns: bcols[col0 .. col0 + ncols)
+};
 template <int KB>
 __global__ __launch_bounds__(256) void fc_tail_b(int N, int nn2, const int* __restrict__ perm, const double* __restrict__ x,
-                                                 const double* __restrict__ b, const int* __restrict__ a_rowptr,
-                                                 const int* __restrict__ a_col, const double* __restrict__ a_val, int n_row_blocks,
-                                                 int reps, int nc, const int* __restrict__ cn, const double* __restrict__ geom,
+                                                 const double* __restrict__ b, const FcTBlock* __restrict__ blocks,
+                                                 const int* __restrict__ bcols, const int* __restrict__ a_rowptr,
+                                                 const unsigned short* __restrict__ a_lidx, const double* __restrict__ a_val,
+                                                 int n_row_blocks, int nc, const int* __restrict__ cn, const double* __restrict__ geom,
                                                  const int* __restrict__ iperm, double* __restrict__ up, double* __restrict__ u_n,
                                                  double* __restrict__ u_nn, double* __restrict__ p_n, int* __restrict__ flag,
-                                                 double* __restrict__ partial) {
-  constexpr int HP = KB / 2;                    // simulation pairs
-  constexpr int LPR = 8 * HP, RPB = 256 / LPR;  // lanes per row, rows per workgroup and repetition
-  constexpr int CPB = 256 / (8 * KB);           // cells per cell workgroup and repetition
+                                                 double* __restrict__ partial, int dbg) {
+  constexpr int HP = KB / 2;           // simulation pairs
+  constexpr int JL = 16 / HP;          // lanes of a row that split its entries
+  constexpr int CPB = 256 / (8 * KB);  // cells per cell workgroup
   const int t = threadIdx.x;
   const int G = gridDim.x;
   const int n_cell_blocks = G - n_row_blocks;
   const int rb = (int)blockIdx.x - n_cell_blocks;
+  __shared__ double xs[FC_TB_COLS * KB];
   __shared__ double red[2][256];
   if (rb >= 0) {
-    const int sp = t % HP, j = (t % LPR) / HP;
-    double r2[2] = {0.0, 0.0}, b2[2] = {0.0, 0.0};
-    for (int rep = 0; rep < reps; ++rep) {
-      const int i = (rb * reps + rep) * RPB + t / LPR;
-      double sa0 = 0.0, sa1 = 0.0;
-      if (i < N && a_rowptr) {
-        const int k0 = a_rowptr[i], k1 = a_rowptr[i + 1];
-        double t0 = 0.0, t1 = 0.0;
-        for (int base = k0; base < k1; base += 16) {
-          const int ka = base + j, kb = ka + 8;
-          const int ca = ka < k1 ? a_col[ka] : 0, cb = kb < k1 ? a_col[kb] : 0;
-          const double va = ka < k1 ? a_val[ka] : 0.0, vb = kb < k1 ? a_val[kb] : 0.0;
-          const fc_d2u xa = *reinterpret_cast<const fc_d2u*>(x + (size_t)ca * KB + 2 * sp);
-          const fc_d2u xb = *reinterpret_cast<const fc_d2u*>(x + (size_t)cb * KB + 2 * sp);
-          sa0 += va * xa.x;
-          sa1 += va * xa.y;
-          t0 += vb * xb.x;
-          t1 += vb * xb.y;
-        }
-        sa0 += t0;
-        sa1 += t1;
-      }
+    const FcTBlock bk = blocks[rb];
+    // the block's solution rows -> LDS, two simulations per lane
+    for (int e = t; e < ((dbg & 4) ? 0 : bk.ncols * HP); e += 256) {
+      const int c = e / HP, sp = e % HP;
+      *reinterpret_cast<fc_d2u*>(xs + c * KB + 2 * sp) = *reinterpret_cast<const fc_d2u*>(x + (size_t)bcols[bk.col0 + c] * KB + 2 * sp);
+    }
+    const int rl = t / 16, j = (t % 16) / HP, sp = t % HP;
+    const int i = bk.row0 + rl;
+    const bool live = rl < bk.nrows;
+    const int k0 = live ? a_rowptr[i] : 0, k1 = live ? a_rowptr[i + 1] : 0;
+    // eight entries per lane and trip, every load of a trip issued before the first use (addresses clamped into the row,
+    // values past its end replaced by zero: no branch in the body); the first trip is in flight while the block's
+    // solution rows are staged
+    int la[8];
+    double va[8];
+    auto fetch = [&](int base) {
 #pragma unroll
-      for (int off = 4 * HP; off >= HP; off >>= 1) {
-        sa0 += __shfl_down(sa0, off, LPR);
-        sa1 += __shfl_down(sa1, off, LPR);
+      for (int u = 0; u < 8; ++u) {
+        const int kk = base + u * JL;
+        const int kc = kk < k1 ? kk : (k1 > k0 ? k1 - 1 : 0);
+        const int l = a_lidx[kc];
+        const double v = a_val[kc];
+        la[u] = l;
+        va[u] = kk < k1 ? v : 0.0;
       }
-      if (i < N && j == 0) {
-        const int r = perm[i];
-        const fc_d2u v = *reinterpret_cast<const fc_d2u*>(x + (size_t)i * KB + 2 * sp);
-        const fc_d2u bb = *reinterpret_cast<const fc_d2u*>(b + (size_t)i * KB + 2 * sp);
-        const double res0 = bb.x - sa0, res1 = bb.y - sa1;
-        r2[0] += res0 * res0;
-        r2[1] += res1 * res1;
-        b2[0] += bb.x * bb.x;
-        b2[1] += bb.y * bb.y;
-        *reinterpret_cast<fc_d2u*>(up + (size_t)r * KB + 2 * sp) = v;
-        if (r < nn2) {
-          *reinterpret_cast<fc_d2u*>(u_nn + (size_t)r * KB + 2 * sp) = *reinterpret_cast<const fc_d2u*>(u_n + (size_t)r * KB + 2 * sp);
-          *reinterpret_cast<fc_d2u*>(u_n + (size_t)r * KB + 2 * sp) = v;
-          if (!isfinite(v.x)) atomicOr(flag + 2 * sp, 1);
-          if (!isfinite(v.y)) atomicOr(flag + 2 * sp + 1, 1);
-        } else {
-          *reinterpret_cast<fc_d2u*>(p_n + (size_t)(r - nn2) * KB + 2 * sp) = v;
-        }
+    };
+    if (!(dbg & 1)) fetch(k0 + j);
+    __syncthreads();
+    double s0 = 0.0, s1 = 0.0;
+    for (int base = k0 + j; base < ((dbg & 1) ? k0 : k1); base += 8 * JL) {
+      int lc[8];
+      double vc[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        lc[u] = la[u];
+        vc[u] = va[u];
+      }
+      if (base + 8 * JL < k1) fetch(base + 8 * JL);  // rows longer than 8 JL entries: the next trip streams in behind this one
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const fc_d2u xa = *reinterpret_cast<const fc_d2u*>(xs + lc[u] * KB + 2 * sp);
+        s0 += vc[u] * xa.x;
+        s1 += vc[u] * xa.y;
       }
     }
-    // the (j = 0) lanes park their sums at [row of the workgroup][s]; thread s < KB adds the rows up in order
+#pragma unroll
+    for (int off = (JL / 2) * HP; off >= HP; off >>= 1) {
+      s0 += __shfl_down(s0, off, 16);
+      s1 += __shfl_down(s1, off, 16);
+    }
+    // (A x)[row][s] -> LDS, then thread = (row, simulation) finishes the row
+    __syncthreads();  // xs is free
     if (j == 0) {
-      const int row = t / LPR;
-      red[0][row * KB + 2 * sp] = r2[0];
-      red[0][row * KB + 2 * sp + 1] = r2[1];
-      red[1][row * KB + 2 * sp] = b2[0];
-      red[1][row * KB + 2 * sp + 1] = b2[1];
+      xs[rl * KB + 2 * sp] = s0;
+      xs[rl * KB + 2 * sp + 1] = s1;
     }
     __syncthreads();
-    if (t < KB) {
-      double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-      for (int r = 0; r < RPB; ++r) {
-        s0 += red[0][r * KB + t];
-        s1 += red[1][r * KB + t];
+    double r2 = 0.0, b2 = 0.0;
+    for (int e = t; e < bk.nrows * KB; e += 256) {  // one trip for KB = 16, fewer threads for smaller KB
+      const int r_l = e / KB, s = e % KB;
+      const int ii = bk.row0 + r_l;
+      const int r = perm[ii];
+      const double v = x[(size_t)ii * KB + s], bb = b[(size_t)ii * KB + s];
+      const double res = bb - xs[r_l * KB + s];
+      r2 += res * res;
+      b2 += bb * bb;
+      if (dbg & 2) continue;
+      up[(size_t)r * KB + s] = v;
+      if (r < nn2) {
+        u_nn[(size_t)r * KB + s] = u_n[(size_t)r * KB + s];
+        u_n[(size_t)r * KB + s] = v;
+        if (!isfinite(v)) atomicOr(flag + s, 1);
+      } else {
+        p_n[(size_t)(r - nn2) * KB + s] = v;
       }
-      partial[((size_t)t * 3 + 0) * G + blockIdx.x] = s0;
-      partial[((size_t)t * 3 + 1) * G + blockIdx.x] = s1;
+    }
+    // threads e = r_l * KB + s: simulation = t % KB for every trip (256 is a multiple of KB)
+    red[0][t] = r2;
+    red[1][t] = b2;
+    __syncthreads();
+    if (t < KB) {
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int g = 0; g < 256 / KB; ++g) {
+        a0 += red[0][g * KB + t];
+        a1 += red[1][g * KB + t];
+      }
+      partial[((size_t)t * 3 + 0) * G + blockIdx.x] = a0;
+      partial[((size_t)t * 3 + 1) * G + blockIdx.x] = a1;
       partial[((size_t)t * 3 + 2) * G + blockIdx.x] = 0.0;
     }
   } else {
     const int s = t % KB, lane = (t / KB) % 8, cw = t / (8 * KB);
     const int nn = nn2 >> 1;
     double e = 0.0;
-    for (int rep = 0; rep < reps; ++rep) {
-      const int c = ((int)blockIdx.x * reps + rep) * CPB + cw;
-      const int cc = c < nc ? c : 0;
-      if (rep > 0) __syncthreads();
-      {
-        const int n = cn[(size_t)(lane < 6 ? lane : 0) * nc + cc];
-        red[0][t] = x[(size_t)iperm[n] * KB + s];
-        red[1][t] = x[(size_t)iperm[nn + n] * KB + s];
-      }
-      __syncthreads();
-      if (c < nc && lane < FC_NQ) {
-        double ux = 0.0, uy = 0.0;
-        const int nb = cw * 8 * KB + s;
+    const int c = (int)blockIdx.x * CPB + cw;
+    const int cc = c < nc ? c : 0;
+    {
+      const int n = cn[(size_t)(lane < 6 ? lane : 0) * nc + cc];
+      red[0][t] = x[(size_t)iperm[n] * KB + s];
+      red[1][t] = x[(size_t)iperm[nn + n] * KB + s];
+    }
+    __syncthreads();
+    if (c < nc && lane < FC_NQ) {
+      double ux = 0.0, uy = 0.0;
+      const int nb = cw * 8 * KB + s;
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          const double ph = c_phi2[lane * 6 + a];
-          ux += ph * red[0][nb + a * KB];
-          uy += ph * red[1][nb + a * KB];
-        }
-        e += c_qw[lane] * 0.5 * geom[4 * (size_t)nc + cc] * (ux * ux + uy * uy);
+      for (int a = 0; a < 6; ++a) {
+        const double ph = c_phi2[lane * 6 + a];
+        ux += ph * red[0][nb + a * KB];
+        uy += ph * red[1][nb + a * KB];
       }
+      e = c_qw[lane] * 0.5 * geom[4 * (size_t)nc + cc] * (ux * ux + uy * uy);
     }
     __syncthreads();
     red[0][t] = e;

@@ -287,6 +287,10 @@ struct fc_ctx {
     DevBuf<FcBTask> tasks;
     DevBuf<int> fptr, fsrc;       // up-sweep fold lists: permuted row -> scratch rows (absolute buffer rows) of its descendants
     DevBuf<int> olist;            // per tree node: the buffer row of every operand column ([y rows of the node | x rows of its boundary])
+    DevBuf<FcTBlock> tblocks;     // row blocks of the batched tail (fc_tail_b): <= 16 consecutive permuted rows, <= FC_TB_COLS distinct columns
+    DevBuf<int> tcols;            // their distinct columns
+    DevBuf<unsigned short> tlidx; // per matrix entry (order of the permuted CSR): position of its column in its block's list
+    int n_tblocks = 0;
     std::vector<BLaunch> launches;
     int64_t scratch_rows = 0, factor_values = 0;
     double vec_rows = 0.0;        // operand / result rows moved per apply (x KB x 8 B)
@@ -3412,7 +3416,7 @@ static int build_batch_tables(fc_ctx* h) {
   B.factor_values = 0;
   B.vec_rows = 0.0;
   static const int force_cg = [] { const char* e = std::getenv("FC_BATCH_CG"); return e ? std::atoi(e) : 0; }();
-  static const double chunks_per_wave = [] { const char* e = std::getenv("FC_BATCH_CPW"); return e ? std::max(0.5, std::atof(e)) : 3.0; }();
+  static const double chunks_per_wave = [] { const char* e = std::getenv("FC_BATCH_CPW"); return e ? std::max(0.5, std::atof(e)) : 1.5; }();
   // one block launch for all nodes of `level`: up = the -L blocks (nb x ni), else the [D^-1 | -U] rows (ni x nf);
   // one task per 16-row tile, cg waves per tile (about chunks_per_wave 32-column chunks per wave)
   auto emit = [&](int level, bool up) {
@@ -3459,6 +3463,50 @@ static int build_batch_tables(fc_ctx* h) {
   }
   for (int k = 0; k <= t.depth; ++k) emit(k, false);
   if (tasks.empty()) return fail(FC_ERR_INVALID, "fc_set_batch: empty factor structure");
+  // row blocks of the batched tail over the permuted pattern (the same for both slots)
+  {
+    const std::vector<int>& rp = h->sym_plan.Ap_rowptr;
+    const std::vector<int>& cl = h->sym_plan.Ap_col;
+    std::vector<FcTBlock> tb;
+    std::vector<int> tcols;
+    std::vector<unsigned short> lidx(cl.size(), 0);
+    std::vector<int> mark((size_t)N, -1), cur;
+    int r0 = 0;
+    while (r0 < N) {
+      cur.clear();
+      int r = r0;
+      for (; r < N && r - r0 < FC_TB_ROWS; ++r) {
+        size_t added = 0;
+        for (int k = rp[(size_t)r]; k < rp[(size_t)r + 1]; ++k)
+          if (mark[(size_t)cl[(size_t)k]] != r0) {
+            mark[(size_t)cl[(size_t)k]] = r0;
+            cur.push_back(cl[(size_t)k]);
+            ++added;
+          }
+        if (cur.size() > FC_TB_COLS && r > r0) {  // this row does not fit any more: it starts the next block
+          for (size_t q = 0; q < added; ++q) mark[(size_t)cur[cur.size() - 1 - q]] = -1;
+          cur.resize(cur.size() - added);
+          break;
+        }
+      }
+      if (cur.size() > FC_TB_COLS) return fail(FC_ERR_INVALID, "fc_set_batch: a matrix row has more than FC_TB_COLS entries");
+      std::sort(cur.begin(), cur.end());
+      const int c0 = (int)tcols.size();
+      for (size_t q = 0; q < cur.size(); ++q) mark[(size_t)cur[q]] = -2 - (int)q;  // local position
+      for (int rr = r0; rr < r; ++rr)
+        for (int k = rp[(size_t)rr]; k < rp[(size_t)rr + 1]; ++k) lidx[(size_t)k] = (unsigned short)(-2 - mark[(size_t)cl[(size_t)k]]);
+      for (int c : cur) mark[(size_t)c] = -1;
+      tcols.insert(tcols.end(), cur.begin(), cur.end());
+      tb.push_back(FcTBlock{r0, r - r0, c0, (int)cur.size()});
+      r0 = r;
+    }
+    if (tcols.empty()) tcols.push_back(0);
+    if (lidx.empty()) lidx.push_back(0);
+    B.n_tblocks = (int)tb.size();
+    FCCHK(B.tblocks.upload(tb, h->stream));
+    FCCHK(B.tcols.upload(tcols, h->stream));
+    FCCHK(B.tlidx.upload(lidx, h->stream));
+  }
   B.scratch_rows = S;
   FCCHK(B.tasks.upload(tasks, h->stream));
   FCCHK(B.fptr.upload(fptr, h->stream));
@@ -3527,7 +3575,7 @@ int fc_set_batch(fc_handle h, int32_t k) {
     FCCHK(B.b.alloc(N * KB));
     FCCHK(B.buf.alloc((2 * N + (size_t)B.scratch_rows + 1) * KB));  // + the zero row of the operand lists
     FCCHK(B.ev.alloc((size_t)12 * h->nc * KB));
-    FCCHK(B.partial.alloc((size_t)3 * 40000 * KB));
+    FCCHK(B.partial.alloc((size_t)3 * ((size_t)B.n_tblocks + (size_t)nblocks(h->nc, 256 / (8 * KB)) + 1) * KB));
     FCCHK(B.flag.alloc(16));
   }
   B.k = k;
@@ -3600,7 +3648,7 @@ static int batch_launches(fc_ctx* h, int order_slot, int compute_energy) {
   const int KB = B.KB, N = h->N, nc = h->nc;
   const double* uc = h->pin_dev;
   const double* uf = h->pin_dev + 32;
-  const int g_elem = nblocks(nc, 256 / (8 * KB)), g_rows = nblocks((int64_t)N * KB, 256);
+  const int g_elem = nblocks(nc, 256 / (8 * KB)), g_rows = nblocks((int64_t)N * (KB / 2), 256);
 #define FC_ELEM(K) hipLaunchKernelGGL((fc_rhs_elem_b<K>), dim3(g_elem), dim3(256), 0, h->stream, nc, h->nn, h->cn.p, h->geom.p, B.u_n.p, B.u_nn.p, \
                                       h->have_force ? h->fprof.p : nullptr, h->have_force ? h->n_act : 0, uf, kRecStride, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, B.ev.p)
   FC_KB_DISPATCH(KB, FC_ELEM(4), FC_ELEM(8), FC_ELEM(16));
@@ -3612,15 +3660,15 @@ static int batch_launches(fc_ctx* h, int order_slot, int compute_energy) {
 #undef FC_GATH
   FCCHK(batch_apply(h, S));
   // tail: residual monitor, scatter / shift, energy
-  const int rpb = 256 / (4 * KB), cpb = 256 / (8 * KB);
-  const int reps = std::max(1, nblocks(nblocks(N, rpb), 24000));  // 1 unless the mesh is large: the repetitions of a workgroup run one after the other
-  const int n_row_blocks = nblocks(N, rpb * reps), n_cell_blocks = compute_energy ? nblocks(nc, cpb * reps) : 0;
+  if ((int64_t)B.tlidx.n != S.Ap_nnz && S.Ap_nnz > 0) return fail(FC_ERR_INVALID, "fc_step_batch: tail tables and system pattern disagree");
+  const int cpb = 256 / (8 * KB);
+  const int n_row_blocks = B.n_tblocks, n_cell_blocks = compute_energy ? nblocks(nc, cpb) : 0;
   const int G = n_row_blocks + n_cell_blocks;
   if ((size_t)3 * G * KB > B.partial.n) return fail(FC_ERR_INVALID, "fc_step_batch: partial buffer too small");
-  static const bool dbg_nores = [] { const char* e = std::getenv("FC_BATCH_DEBUG_NORES"); return e && e[0] == '1'; }();  // timing experiments only
-#define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, B.buf.p + (size_t)N * K, B.b.p, dbg_nores ? nullptr : S.Ap_rowptr.p, \
-                                       S.Ap_col.p, S.Ap_val.p, n_row_blocks, reps, nc, h->cn.p, h->geom.p, h->iperm.p, B.up.p, B.u_n.p, B.u_nn.p, B.p_n.p,      \
-                                       B.flag.p, B.partial.p)
+  static const int dbg_tail = [] { const char* e = std::getenv("FC_BATCH_DEBUG_TAIL"); return e ? std::atoi(e) : 0; }();  // timing experiments only
+#define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, B.buf.p + (size_t)N * K, B.b.p, B.tblocks.p, \
+                                       B.tcols.p, S.Ap_rowptr.p, B.tlidx.p, S.Ap_val.p, n_row_blocks, nc, h->cn.p, h->geom.p, h->iperm.p, B.up.p, B.u_n.p, B.u_nn.p,  \
+                                       B.p_n.p, B.flag.p, B.partial.p, dbg_tail)
   FC_KB_DISPATCH(KB, FC_TAILB(4), FC_TAILB(8), FC_TAILB(16));
 #undef FC_TAILB
 #define FC_FINB(K) hipLaunchKernelGGL((fc_final_b<K>), dim3(B.k), dim3(256), 0, h->stream, G, n_cell_blocks, B.partial.p, h->n_sens, h->s_rowptr.p, h->s_idx.p, \
@@ -3650,7 +3698,7 @@ static uint64_t batch_signature(fc_ctx* h, int order_slot, int compute_energy) {
       (uint64_t)(uintptr_t)B.fptr.p, (uint64_t)(uintptr_t)B.fsrc.p, (uint64_t)(uintptr_t)h->perm.p, (uint64_t)(uintptr_t)h->iperm.p, (uint64_t)(uintptr_t)S.Ap_rowptr.p,
       (uint64_t)(uintptr_t)S.Ap_col.p, (uint64_t)(uintptr_t)S.Ap_val.p, (uint64_t)(uintptr_t)B.up.p, (uint64_t)(uintptr_t)B.p_n.p, (uint64_t)(uintptr_t)B.flag.p,
       (uint64_t)(uintptr_t)B.partial.p, (uint64_t)(uintptr_t)h->s_rowptr.p, (uint64_t)(uintptr_t)h->s_idx.p, (uint64_t)(uintptr_t)h->s_w.p,
-      (uint64_t)(uintptr_t)h->pin_dev, (uint64_t)B.k, (uint64_t)B.KB, (uint64_t)h->n_act, (uint64_t)h->n_sens, (uint64_t)(h->have_force ? 1 : 0),
+      (uint64_t)(uintptr_t)h->pin_dev, (uint64_t)(uintptr_t)B.tblocks.p, (uint64_t)(uintptr_t)B.tcols.p, (uint64_t)(uintptr_t)B.tlidx.p, (uint64_t)B.n_tblocks, (uint64_t)B.k, (uint64_t)B.KB, (uint64_t)h->n_act, (uint64_t)h->n_sens, (uint64_t)(h->have_force ? 1 : 0),
       (uint64_t)(S.have_c ? 1 : 0), (uint64_t)compute_energy, (uint64_t)B.launches.size(), (uint64_t)B.tasks.n, bits(c.cm_n), bits(c.cm_nn), bits(c.cc_n),
       bits(c.cc_nn)};
   uint64_t hsh = 1469598103934665603ull;

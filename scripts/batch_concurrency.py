@@ -30,7 +30,7 @@ def make():
     fs.initialize_time_stepping(ic=None)
     b = BatchedFlowSolver(fs, K)
     import os
-    if os.environ.get('FC_BATCH_DEBUG_NORES') == '1':
+    if os.environ.get('FC_BATCH_DEBUG_TAIL'):
         b.residual_tol = np.inf
     b.initialize_time_stepping(ics=[fs.params_ic] * K)
     for _ in range(3):
