@@ -23,70 +23,86 @@
 #include <stdint.h>
 
 struct __attribute__((aligned(16))) FcBTask {
-  long long val;  // offset of the tile's first value (first row, first column of the node's block)
-  int ld;         // row stride of the block
+  long long src;  // offset of the tile's first value in the factor values as the single-simulation sweeps store them (row-major, stride ld)
+  long long val;  // offset of the tile in the TILED copy the batched kernel streams (fc_b_repack)
+  int ld;         // row stride of the block in the row-major layout
   int nrows;      // rows of this tile (<= 16)
   int ncols;      // columns of the block = operand rows of the node
-  int op;         // offset of the node's operand row list (buffer row of every column; even)
+  int op;         // offset of the node's operand row list (buffer row of every column; multiple of 8)
   int dst;        // first destination buffer row
   int pad;
 };
 
 typedef int fc_i2 __attribute__((ext_vector_type(2)));
+typedef double fc_d2 __attribute__((ext_vector_type(2)));
+
+// Tiled copy of the factor values for the batched kernel: a tile (16 rows of one dense block) is a sequence of 32-column
+// chunks of 4 KB, every chunk stored in the order the matrix instructions consume it — group u of 8 columns, then lane
+// (row = lane & 15, q = lane >> 4), then the value pair at columns 32 c + 8 u + 2 q, + 1 — so that one wave instruction
+// (16 B per lane) reads 1 KB of consecutive memory and a chunk 4 KB.  Rows past the tile's last one and columns past the
+// block's last one hold zeros.  One workgroup per tile; re-run after every numeric factorisation (fc_refactor).
+__global__ __launch_bounds__(256) void fc_b_repack(const FcBTask* __restrict__ tasks, const double* __restrict__ val, double* __restrict__ tiled) {
+  const FcBTask tk = tasks[blockIdx.x];
+  const int nchunk = (tk.ncols + 31) >> 5;
+  for (int e = threadIdx.x; e < nchunk * 256; e += 256) {  // one value pair per trip
+    const int c = e >> 8, u = (e >> 6) & 3, lane = e & 63;
+    const int row = lane & 15, col = 32 * c + 8 * u + 2 * (lane >> 4);
+    fc_d2 v = {0.0, 0.0};
+    if (row < tk.nrows) {
+      const double* __restrict__ p = val + tk.src + (long long)row * tk.ld + col;
+      if (col < tk.ncols) v.x = p[0];
+      if (col + 1 < tk.ncols) v.y = p[1];
+    }
+    *reinterpret_cast<fc_d2*>(tiled + tk.val + 2 * (long long)e) = v;
+  }
+}
 
 // One workgroup per task = one 16-row tile of ONE dense factor block of a tree node, CG <= 16 waves (blockDim = 64 CG): wave g
-// takes the 32-column chunks g, g + CG, ... of the tile's rows, the CG accumulators are summed through LDS in the order
+// takes the 32-column chunks g, g + CG, ... of the tile, the CG accumulators are summed through LDS in the order
 // of the groups (reproducible).  No barrier before that sum: every wave streams on its own through a three-deep register
 // pipeline  operand-row indices (chunk c + 3) | values + operand rows (chunk c + 2, c + 1 in flight) | matrix
-// instructions (chunk c).  The factor values come from HBM (each exactly once per apply), the operand rows [row][KB] from
-// L2 (a node's rows are shared by all of its tiles).
+// instructions (chunk c).  The factor values come from HBM / Infinity Cache (each exactly once per apply, 4 KB of
+// consecutive memory per chunk), the operand rows [row][KB] from L2 (a node's rows are shared by all of its tiles).
 //
 // v_mfma_f64_16x16x4_f64: lane l holds A[row l & 15][k = l >> 4], B[k = l >> 4][col l & 15];
 // D[row (l >> 4) + 4 r][col l & 15] in register r.  The k index of an instruction may stand for any four columns as
-// long as A and B agree: lane (row, q) loads the value PAIR at columns 8 u + 2 q, 8 u + 2 q + 1 of its row (16 contiguous
-// bytes; the four q lanes of a row cover 64 contiguous bytes) and feeds the pair to two consecutive instructions.
+// long as A and B agree: lane (row, q) holds the value PAIR at columns 8 u + 2 q, 8 u + 2 q + 1 of its row and feeds the
+// pair to two consecutive instructions.
 #ifndef FC_B_WPE
 #define FC_B_WPE 4  // waves per SIMD the register allocation aims at: 128 VGPRs keep two chunks of a wave in flight
 #endif
 template <int KB>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FC_B_WPE, FC_B_WPE))) void fc_nd_block_b(const FcBTask* __restrict__ tasks, const int* __restrict__ olist,
-                                                      const double* __restrict__ val, double* __restrict__ buf, int CG) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FC_B_WPE, FC_B_WPE))) void fc_nd_block_b(
+    const FcBTask* __restrict__ tasks, const int* __restrict__ olist, const double* __restrict__ tiled, double* __restrict__ buf, int CG) {
   extern __shared__ double fc_b_red[];
   const FcBTask tk = tasks[blockIdx.x];
   const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
   const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  // rows past the tile's last one shadow it (valid addresses, results dropped at the store)
-  const int row = lr < tk.nrows ? lr : tk.nrows - 1;
-  const double* __restrict__ vrow = val + tk.val + (long long)row * tk.ld + 2 * lq;
+  const double* __restrict__ tv = tiled + tk.val + 2 * lane;
   const int* __restrict__ orow = olist + 2 * lq;
-  const int ncols = tk.ncols;
   const int ls = lr < KB ? lr : 0;  // lanes beyond the batch width shadow simulation 0 (their output columns are never stored)
   fc_d4 acc = {0.0, 0.0, 0.0, 0.0};
-  // chunk c of this wave starts at column 32 (grp + CG c).  The pipeline below has NO branch and no per-lane predicate in
-  // its body (a branch makes the compiler drain the load queue at every join).  Instead:
-  //  * a node's operand list is padded to a multiple of 8 with the index of a buffer row that is always zero, so the
-  //    columns past the block's last one (a lane's value pair may read up to 7 values into the next row / block: finite
-  //    numbers, the allocation is padded) meet a zero operand;
-  //  * a whole group of 8 columns past the end — in the last chunk of a row, or in the up to two chunks by which the
-  //    wave's chunk count is rounded up to the pipeline's period — takes its values from the tile's first columns (valid
-  //    addresses, one cache line per wave) and its operand rows from the "null group" olist[0..8) (the zero row again).
-  // Everything that depends on the chunk index only is wave-uniform (scalar).
-  const int nchunk = (ncols + 31) >> 5;
+  // chunk c of this wave is chunk grp + CG c of the tile.  The pipeline below has NO branch and no per-lane predicate in
+  // its body (a branch makes the compiler drain the load queue at every join): the tiled values are zero past the block's
+  // edges, a node's operand list is padded to a multiple of 32 with the index of a buffer row that is always zero, and the
+  // up to two chunks by which a wave's chunk count is rounded up to the pipeline's period read chunk 0 of the tile (one
+  // valid 4 KB) against the "null group" olist[0..8) (the zero row again).  Everything that depends on the chunk index
+  // only is wave-uniform (scalar).
+  const int nchunk = (tk.ncols + 31) >> 5;
   const int nw = nchunk > grp ? (nchunk - grp + CG - 1) / CG : 0;  // chunks of this wave
   auto I = [&](int c, fc_i2 (&x)[4]) {  // operand-row indices of chunk c
+    const int ch = grp + CG * c;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int col = 32 * (grp + CG * c) + 8 * u;
-      x[u] = *reinterpret_cast<const fc_i2*>(orow + (col < ncols ? tk.op + col : 0));
-    }
+    for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const fc_i2*>(orow + (ch < nchunk ? tk.op + 32 * ch + 8 * u : 0));
   };
   auto L = [&](int c, const fc_i2 (&x)[4], double (&a)[8], double (&b)[8]) {  // values and operand rows of chunk c
+    const int ch = grp + CG * c;
+    const double* __restrict__ p = tv + 512 * (long long)(ch < nchunk ? ch : 0);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int col = 32 * (grp + CG * c) + 8 * u;
-      const int o = col < ncols ? col : 0;
-      a[2 * u] = vrow[o];
-      a[2 * u + 1] = vrow[o + 1];
+      const fc_d2 v = *reinterpret_cast<const fc_d2*>(p + 128 * u);
+      a[2 * u] = v.x;
+      a[2 * u + 1] = v.y;
       b[2 * u] = buf[(size_t)x[u].x * KB + ls];
       b[2 * u + 1] = buf[(size_t)x[u].y * KB + ls];
     }
@@ -344,7 +360,7 @@ __global__ __launch_bounds__(256) void fc_tail_b(int N, int nn2, const int* __re
                                                  int n_row_blocks, int nc, const int* __restrict__ cn, const double* __restrict__ geom,
                                                  const int* __restrict__ iperm, double* __restrict__ up, double* __restrict__ u_n,
                                                  double* __restrict__ u_nn, double* __restrict__ p_n, int* __restrict__ flag,
-                                                 double* __restrict__ partial, int dbg) {
+                                                 double* __restrict__ partial) {
   constexpr int HP = KB / 2;           // simulation pairs
   constexpr int JL = 16 / HP;          // lanes of a row that split its entries
   constexpr int CPB = 256 / (8 * KB);  // cells per cell workgroup
@@ -357,7 +373,7 @@ __global__ __launch_bounds__(256) void fc_tail_b(int N, int nn2, const int* __re
   if (rb >= 0) {
     const FcTBlock bk = blocks[rb];
     // the block's solution rows -> LDS, two simulations per lane
-    for (int e = t; e < ((dbg & 4) ? 0 : bk.ncols * HP); e += 256) {
+    for (int e = t; e < bk.ncols * HP; e += 256) {
       const int c = e / HP, sp = e % HP;
       *reinterpret_cast<fc_d2u*>(xs + c * KB + 2 * sp) = *reinterpret_cast<const fc_d2u*>(x + (size_t)bcols[bk.col0 + c] * KB + 2 * sp);
     }
@@ -381,10 +397,10 @@ __global__ __launch_bounds__(256) void fc_tail_b(int N, int nn2, const int* __re
         va[u] = kk < k1 ? v : 0.0;
       }
     };
-    if (!(dbg & 1)) fetch(k0 + j);
+    fetch(k0 + j);
     __syncthreads();
     double s0 = 0.0, s1 = 0.0;
-    for (int base = k0 + j; base < ((dbg & 1) ? k0 : k1); base += 8 * JL) {
+    for (int base = k0 + j; base < k1; base += 8 * JL) {
       int lc[8];
       double vc[8];
 #pragma unroll
@@ -421,7 +437,6 @@ __global__ __launch_bounds__(256) void fc_tail_b(int N, int nn2, const int* __re
       const double res = bb - xs[r_l * KB + s];
       r2 += res * res;
       b2 += bb * bb;
-      if (dbg & 2) continue;
       up[(size_t)r * KB + s] = v;
       if (r < nn2) {
         u_nn[(size_t)r * KB + s] = u_n[(size_t)r * KB + s];

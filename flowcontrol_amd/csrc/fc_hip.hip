@@ -272,6 +272,9 @@ struct fc_ctx {
   size_t tused = 0;
   double t_ms[2] = {0.0, 0.0};
   int64_t t_cnt[2] = {0, 0};
+  // base-flow iterations inside the library (fc_set_baseflow_bc / fc_picard_step / fc_newton_step): full-field Dirichlet data
+  std::vector<int> ss_dofs;
+  std::vector<double> ss_vals;
   // batched stepping (fc_set_batch): k lock-step simulations that share the operators and the factors of this handle;
   // every vector is a matrix [row][KB] (fc_batch.hip.h)
   struct BLaunch {
@@ -287,6 +290,9 @@ struct fc_ctx {
     DevBuf<FcBTask> tasks;
     DevBuf<int> fptr, fsrc;       // up-sweep fold lists: permuted row -> scratch rows (absolute buffer rows) of its descendants
     DevBuf<int> olist;            // per tree node: the buffer row of every operand column ([y rows of the node | x rows of its boundary])
+    DevBuf<double> ftile[2];      // per slot: the factor values in the tiled layout the batched block kernel streams (fc_b_repack)
+    bool ftile_ok[2] = {false, false};
+    int64_t tiled_values = 0;
     DevBuf<FcTBlock> tblocks;     // row blocks of the batched tail (fc_tail_b): <= 16 consecutive permuted rows, <= FC_TB_COLS distinct columns
     DevBuf<int> tcols;            // their distinct columns
     DevBuf<unsigned short> tlidx; // per matrix entry (order of the permuted CSR): position of its column in its block's list
@@ -1359,6 +1365,7 @@ int fc_create(fc_handle* out, int device, int32_t nv, int32_t ne, int32_t nc, co
 }
 
 static void batch_drop_graphs(fc_ctx* h);
+static int batch_repack(fc_ctx* h, int slot);
 
 int fc_destroy(fc_handle h) {
   if (!h) return FC_OK;
@@ -2331,7 +2338,7 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
   if (ms_out) *ms_out = (double)ms;
   h->refactor_ms[slot] = (double)ms;
   S.ready = true;
-  return FC_OK;
+  return batch_repack(h, slot);  // the batched block kernel streams its own (tiled) copy of the values
 }
 
 int fc_get_refactor_ms(fc_handle h, int slot, double* ms) {
@@ -3356,6 +3363,74 @@ int fc_algorithmic_bytes(fc_handle h, int slot, double* sweep_bytes, double* spm
   return FC_OK;
 }
 
+// ── base-flow (steady-state) iterations behind the C ABI: SteadyStateSolver.picard / .newton (steadystate.py:60-159) ──────
+// Every iteration assembles its operator with the HIP element loop, eliminates the Dirichlet dofs, factorises on the device
+// and solves with the sweep kernels; the host side here only forms the residual and the update (vectors cross the
+// boundary as host arrays: this is the setup path).  Slots used: FC_SLOT_SCRATCH (operator of the residual), FC_SLOT_BDF1
+// (the iteration's system matrix and its factors) — assemble the time-stepping operators afterwards.
+int fc_set_baseflow_bc(fc_handle h, int32_t n_bc, const int32_t* bc_dofs, const double* bc_values) {
+  if (!h || n_bc < 0 || (n_bc > 0 && (!bc_dofs || !bc_values))) return fail(FC_ERR_INVALID, "fc_set_baseflow_bc: bad argument");
+  h->ss_dofs.assign(bc_dofs, bc_dofs + n_bc);
+  h->ss_vals.assign(bc_values, bc_values + n_bc);
+  // the increments of both iterations vanish on the Dirichlet dofs: homogeneous symmetric elimination, no lifting
+  std::vector<double> zero((size_t)std::max(1, n_bc), 0.0);
+  return fc_set_bc(h, n_bc, bc_dofs, 1, zero.data());
+}
+
+static int steady_solve_increment(fc_ctx* h, double nu, const double* adv, const double* lin, const std::vector<double>& rhs, std::vector<double>& delta) {
+  FCCHK(fc_assemble_matrix(h, FC_SLOT_BDF1, 0.0, nu, adv, 1.0, lin, 1.0, -1.0, -1.0));
+  FCCHK(fc_apply_bc(h, FC_SLOT_BDF1));
+  FCCHK(fc_setup_solver(h, FC_SLOT_BDF1, 0, 2, 0, 2, 1));  // first call: + symbolic phase; later: numeric factorisation only
+  double info[4];
+  delta.assign((size_t)h->N, 0.0);
+  FCCHK(fc_solve(h, FC_SLOT_BDF1, rhs.data(), delta.data(), info));
+  if (!(info[1] < 1e-8)) return fail(FC_ERR_NOT_CONVERGED, "base-flow iteration: linear solve residual " + std::to_string(info[1]));
+  return FC_OK;
+}
+
+int fc_picard_step(fc_handle h, double nu, double* up, const double* load, double* rel_change) {
+  if (!h || !up || !(nu > 0.0)) return fail(FC_ERR_INVALID, "fc_picard_step: bad argument");
+  const int N = h->N, nn2 = 2 * h->nn;
+  // Oseen operator with the advecting velocity frozen at the iterate (nsforms.py:149-187); x~ = iterate with the boundary
+  // values imposed; A d = load - A x~ on the free rows, d = 0 on the Dirichlet dofs; next iterate = x~ + d
+  std::vector<double> adv(up, up + nn2), xt(up, up + N), r((size_t)N), d;
+  for (size_t k = 0; k < h->ss_dofs.size(); ++k) xt[(size_t)h->ss_dofs[k]] = h->ss_vals[k];
+  FCCHK(fc_assemble_matrix(h, FC_SLOT_SCRATCH, 0.0, nu, adv.data(), 1.0, nullptr, 1.0, -1.0, -1.0));
+  FCCHK(fc_spmv(h, FC_SLOT_SCRATCH, xt.data(), r.data()));
+  for (int i = 0; i < N; ++i) r[(size_t)i] = (load ? load[i] : 0.0) - r[(size_t)i];
+  for (int dof : h->ss_dofs) r[(size_t)dof] = 0.0;
+  FCCHK(steady_solve_increment(h, nu, adv.data(), nullptr, r, d));
+  double diff = 0.0, base = 0.0;
+  for (int i = 0; i < N; ++i) {
+    const double nw = xt[(size_t)i] + d[(size_t)i];
+    diff += (nw - up[i]) * (nw - up[i]);
+    base += up[i] * up[i];
+    up[i] = nw;
+  }
+  if (rel_change) *rel_change = std::sqrt(diff) / (std::sqrt(base) + 1e-14);
+  return FC_OK;
+}
+
+int fc_newton_step(fc_handle h, double nu, double* up, const double* load, double* res_norm, int update) {
+  if (!h || !up || !(nu > 0.0)) return fail(FC_ERR_INVALID, "fc_newton_step: bad argument");
+  const int N = h->N, nn2 = 2 * h->nn;
+  for (size_t k = 0; k < h->ss_dofs.size(); ++k) up[(size_t)h->ss_dofs[k]] = h->ss_vals[k];
+  // residual of the steady equations: ((U.grad)U, v) + nu (grad U, grad v) - (P, div v) - (q, div U) - load (nsforms.py:116-147)
+  std::vector<double> u(up, up + nn2), F((size_t)N), d;
+  FCCHK(fc_assemble_matrix(h, FC_SLOT_SCRATCH, 0.0, nu, u.data(), 1.0, nullptr, 1.0, -1.0, -1.0));
+  FCCHK(fc_spmv(h, FC_SLOT_SCRATCH, up, F.data()));
+  if (load)
+    for (int i = 0; i < N; ++i) F[(size_t)i] -= load[i];
+  for (int dof : h->ss_dofs) F[(size_t)dof] = 0.0;
+  double r2 = 0.0;
+  for (double v : F) r2 += v * v;
+  if (res_norm) *res_norm = std::sqrt(r2);
+  if (!update) return FC_OK;
+  FCCHK(steady_solve_increment(h, nu, u.data(), u.data(), F, d));  // Jacobian: advecting AND linearised field = the iterate
+  for (int i = 0; i < N; ++i) up[i] -= d[(size_t)i];
+  return FC_OK;
+}
+
 // ── shared-operator batched stepping (fc_batch.hip.h): k lock-step simulations per handle ─────────────────────────────
 // Replaces k independent FlowSolver instances stepping the SAME operator (IC sweeps
 // examples/lidcavity/batch_run_lidcavity.py:197-215, controller optimisation utils/optim.py:95-102).
@@ -3393,25 +3468,26 @@ static int build_batch_tables(fc_ctx* h) {
       for (int64_t j = 0; j < nd(g, 4); ++j) fsrc[(size_t)fill[(size_t)(fac.idx[(size_t)(nd(g, 6) + j)] - N)]++] = (int)(2 * (int64_t)N + soff[g] + j);
   }
   // operand row lists: node g's columns [0, ni) are its own y rows, [ni, nf) the x rows of its boundary; padded to a
-  // multiple of 8 with the index of the buffer's zero row (the row behind the scratch rows: never written); olist[0..8)
+  // multiple of 32 with the index of the buffer's zero row (the row behind the scratch rows: never written); olist[0..8)
   // is the "null group" the block kernel reads for column groups past the end of a block
   const int zero_row = (int)(2 * (int64_t)N + S);
-  std::vector<int> olist(8, zero_row);
+  std::vector<int> olist(32, zero_row);
   std::vector<int> ooff(G, 0), ooff_up(G, 0);
   for (size_t g = 0; g < G; ++g) {
     ooff[g] = (int)olist.size();
     for (int64_t c = 0; c < nd(g, 3); ++c) olist.push_back((int)(nd(g, 2) + c));
     for (int64_t j = 0; j < nd(g, 4); ++j) olist.push_back(fac.idx[(size_t)(nd(g, 6) + j)]);
-    while (olist.size() & 7) olist.push_back(zero_row);
+    while (olist.size() & 31) olist.push_back(zero_row);
     // the -L block's operand is the node's own y rows only: its list must END with the padding
     ooff_up[g] = ooff[g];
-    if (nd(g, 4) > 0 && (nd(g, 3) & 7)) {
+    if (nd(g, 4) > 0 && (nd(g, 3) & 31)) {
       ooff_up[g] = (int)olist.size();
       for (int64_t c = 0; c < nd(g, 3); ++c) olist.push_back((int)(nd(g, 2) + c));
-      while (olist.size() & 7) olist.push_back(zero_row);
+      while (olist.size() & 31) olist.push_back(zero_row);
     }
   }
   std::vector<FcBTask> tasks;
+  int64_t tiled_off = 0;
   B.launches.clear();
   B.factor_values = 0;
   B.vec_rows = 0.0;
@@ -3435,21 +3511,59 @@ static int build_batch_tables(fc_ctx* h) {
     while (cg < 16 && mean_chunks / cg > chunks_per_wave) cg *= 2;
     if (force_cg == 1 || force_cg == 2 || force_cg == 4 || force_cg == 8 || force_cg == 16) cg = force_cg;
     const int first = (int)tasks.size();
+    // XCD placement (speed only): workgroups b and b + 8 share an XCD and its L2 (MI355X_MICROARCH.md, Workgroup dispatch),
+    // and all tiles of a node read the same operand rows — so a node's tiles (for the few big nodes near the root: a run of
+    // them) go to ONE of eight classes, and position p of the launch takes the next task of class p % 8: the node's operand
+    // crosses the fabric once per XCD that hosts it instead of once per tile.  FC_BATCH_XCD=0: node-major order.
+    static const bool xcd_order = [] { const char* e = std::getenv("FC_BATCH_XCD"); return !(e && e[0] == '0'); }();
+    std::vector<FcBTask> cls[8];
+    int64_t tiles_total = 0;
+    for (size_t g : sel) tiles_total += ((up ? nd(g, 4) : nd(g, 3)) + 15) / 16;
+    const int64_t run_max = std::max<int64_t>(1, (tiles_total + 7) / 8);  // a node with more tiles is cut into runs of this many
     for (size_t g : sel) {
       const int64_t i0 = nd(g, 2), ni = nd(g, 3), nb = nd(g, 4), voff = nd(g, 5), nf = ni + nb;
       const int64_t rows = up ? nb : ni, ld = up ? ni : nf, base = up ? voff + ni * nf : voff;
+      int64_t in_run = 0;
+      int c = 0;
       for (int64_t r0 = 0; r0 < rows; r0 += 16) {
         FcBTask tk = {};
-        tk.val = base + r0 * ld;
+        tk.src = base + r0 * ld;
+        tk.val = tiled_off;
+        tiled_off += 512 * ((ld + 31) / 32);
         tk.ld = (int)ld;
         tk.nrows = (int)std::min<int64_t>(16, rows - r0);
         tk.ncols = (int)ld;
         tk.op = up ? ooff_up[g] : ooff[g];
         tk.dst = up ? (int)(2 * (int64_t)N + soff[g] + r0) : (int)(N + i0 + r0);
-        tasks.push_back(tk);
+        if (!xcd_order) {
+          tasks.push_back(tk);
+          continue;
+        }
+        if (in_run == 0) {  // a new run: the class with the fewest tasks so far
+          c = 0;
+          for (int q = 1; q < 8; ++q)
+            if (cls[q].size() < cls[c].size()) c = q;
+        }
+        cls[c].push_back(tk);
+        if (++in_run == run_max) in_run = 0;
       }
       B.factor_values += rows * ld;
       B.vec_rows += (double)ld + (double)rows;
+    }
+    if (xcd_order) {
+      size_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      size_t left = 0;
+      for (int q = 0; q < 8; ++q) left += cls[q].size();
+      for (size_t p = 0; left > 0; ++p) {
+        int c = (int)(p & 7);
+        if (pos[c] >= cls[c].size()) {  // this class is exhausted: take from the one with the most tasks left
+          size_t best = 0;
+          for (int q = 0; q < 8; ++q)
+            if (cls[q].size() - pos[q] > best) best = cls[q].size() - pos[q], c = q;
+        }
+        tasks.push_back(cls[c][pos[c]++]);
+        --left;
+      }
     }
     B.launches.push_back({0, first, (int)tasks.size() - first, cg, 0, 0, 0, 0});
   };
@@ -3508,6 +3622,8 @@ static int build_batch_tables(fc_ctx* h) {
     FCCHK(B.tlidx.upload(lidx, h->stream));
   }
   B.scratch_rows = S;
+  B.tiled_values = tiled_off;
+  B.ftile_ok[0] = B.ftile_ok[1] = false;
   FCCHK(B.tasks.upload(tasks, h->stream));
   FCCHK(B.fptr.upload(fptr, h->stream));
   FCCHK(B.fsrc.upload(fsrc, h->stream));
@@ -3528,15 +3644,30 @@ static int build_batch_tables(fc_ctx* h) {
     }                                             \
   } while (0)
 
-// x (rows N .. 2N of bat.buf) = M^-1 y (rows 0 .. N) for all KB columns
-static int batch_apply(fc_ctx* h, OrderSys& S) {
+// tiled copy of the slot's factor values for the batched block kernel (after every numeric factorisation)
+static int batch_repack(fc_ctx* h, int slot) {
   fc_ctx::Batch& B = h->bat;
+  if (!B.tables || B.tasks.n == 0) return FC_OK;
+  OrderSys& S = h->sys[slot];
+  if (!S.structured || S.f_val.n == 0) return FC_OK;
+  if (B.ftile[slot].n != (size_t)B.tiled_values) FCCHK(B.ftile[slot].alloc((size_t)B.tiled_values));
+  hipLaunchKernelGGL(fc_b_repack, dim3((unsigned)B.tasks.n), dim3(256), 0, h->stream, B.tasks.p, S.f_val.p, B.ftile[slot].p);
+  HIPCHK(hipGetLastError());
+  B.ftile_ok[slot] = true;
+  return FC_OK;
+}
+
+// x (rows N .. 2N of bat.buf) = M^-1 y (rows 0 .. N) for all KB columns
+static int batch_apply(fc_ctx* h, int slot) {
+  fc_ctx::Batch& B = h->bat;
+  if (!B.ftile_ok[slot]) return fail(FC_ERR_NOT_READY, "batched apply: the slot's factors have no tiled copy (fc_set_batch after fc_setup_solver)");
   double* buf = B.buf.p;
+  const double* tiled = B.ftile[slot].p;
   FCCHK(time_begin(h, 0, (int)B.launches.size()));
   for (const fc_ctx::BLaunch& L : B.launches) {
     if (L.kind == 0) {
       const FcBTask* tp = B.tasks.p + L.first;
-#define FC_BLK(K) hipLaunchKernelGGL((fc_nd_block_b<K>), dim3(L.count), dim3(64 * L.cg), L.cg > 1 ? (size_t)L.cg * 2048 : 0, h->stream, tp, B.olist.p, S.f_val.p, buf, L.cg)
+#define FC_BLK(K) hipLaunchKernelGGL((fc_nd_block_b<K>), dim3(L.count), dim3(64 * L.cg), L.cg > 1 ? (size_t)L.cg * 2048 : 0, h->stream, tp, B.olist.p, tiled, buf, L.cg)
       FC_KB_DISPATCH(B.KB, FC_BLK(4), FC_BLK(8), FC_BLK(16));
 #undef FC_BLK
     } else {
@@ -3580,6 +3711,8 @@ int fc_set_batch(fc_handle h, int32_t k) {
   }
   B.k = k;
   B.KB = KB;
+  for (int o = 0; o < 2; ++o)
+    if (h->sys[o].ready && !B.ftile_ok[o]) FCCHK(batch_repack(h, o));
   for (DevBuf<double>* d : {&B.u_n, &B.u_nn, &B.p_n, &B.up, &B.b, &B.buf, &B.ev, &B.partial}) FCCHK(d->zero(h->stream));
   FCCHK(B.flag.zero(h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -3658,17 +3791,16 @@ static int batch_launches(fc_ctx* h, int order_slot, int compute_energy) {
                                       S.c_val.p, B.u_n.p)
   FC_KB_DISPATCH(KB, FC_GATH(4), FC_GATH(8), FC_GATH(16));
 #undef FC_GATH
-  FCCHK(batch_apply(h, S));
+  FCCHK(batch_apply(h, order_slot));
   // tail: residual monitor, scatter / shift, energy
   if ((int64_t)B.tlidx.n != S.Ap_nnz && S.Ap_nnz > 0) return fail(FC_ERR_INVALID, "fc_step_batch: tail tables and system pattern disagree");
   const int cpb = 256 / (8 * KB);
   const int n_row_blocks = B.n_tblocks, n_cell_blocks = compute_energy ? nblocks(nc, cpb) : 0;
   const int G = n_row_blocks + n_cell_blocks;
   if ((size_t)3 * G * KB > B.partial.n) return fail(FC_ERR_INVALID, "fc_step_batch: partial buffer too small");
-  static const int dbg_tail = [] { const char* e = std::getenv("FC_BATCH_DEBUG_TAIL"); return e ? std::atoi(e) : 0; }();  // timing experiments only
 #define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, B.buf.p + (size_t)N * K, B.b.p, B.tblocks.p, \
                                        B.tcols.p, S.Ap_rowptr.p, B.tlidx.p, S.Ap_val.p, n_row_blocks, nc, h->cn.p, h->geom.p, h->iperm.p, B.up.p, B.u_n.p, B.u_nn.p,  \
-                                       B.p_n.p, B.flag.p, B.partial.p, dbg_tail)
+                                       B.p_n.p, B.flag.p, B.partial.p)
   FC_KB_DISPATCH(KB, FC_TAILB(4), FC_TAILB(8), FC_TAILB(16));
 #undef FC_TAILB
 #define FC_FINB(K) hipLaunchKernelGGL((fc_final_b<K>), dim3(B.k), dim3(256), 0, h->stream, G, n_cell_blocks, B.partial.p, h->n_sens, h->s_rowptr.p, h->s_idx.p, \
@@ -3694,7 +3826,7 @@ static uint64_t batch_signature(fc_ctx* h, int order_slot, int compute_energy) {
       (uint64_t)(uintptr_t)h->cn.p, (uint64_t)(uintptr_t)h->geom.p, (uint64_t)(uintptr_t)B.u_n.p, (uint64_t)(uintptr_t)B.u_nn.p, (uint64_t)(uintptr_t)h->fprof.p,
       (uint64_t)(uintptr_t)B.ev.p, (uint64_t)(uintptr_t)h->gptr_p.p, (uint64_t)(uintptr_t)h->gidx_p.p, (uint64_t)(uintptr_t)h->bcslot_p.p,
       (uint64_t)(uintptr_t)h->bcprof.p, (uint64_t)(uintptr_t)S.lift_p.p, (uint64_t)(uintptr_t)B.b.p, (uint64_t)(uintptr_t)B.buf.p, (uint64_t)(uintptr_t)S.c_rowptr.p,
-      (uint64_t)(uintptr_t)S.c_col.p, (uint64_t)(uintptr_t)S.c_val.p, (uint64_t)(uintptr_t)B.tasks.p, (uint64_t)(uintptr_t)B.olist.p, (uint64_t)(uintptr_t)S.f_val.p,
+      (uint64_t)(uintptr_t)S.c_col.p, (uint64_t)(uintptr_t)S.c_val.p, (uint64_t)(uintptr_t)B.tasks.p, (uint64_t)(uintptr_t)B.olist.p, (uint64_t)(uintptr_t)B.ftile[order_slot].p,
       (uint64_t)(uintptr_t)B.fptr.p, (uint64_t)(uintptr_t)B.fsrc.p, (uint64_t)(uintptr_t)h->perm.p, (uint64_t)(uintptr_t)h->iperm.p, (uint64_t)(uintptr_t)S.Ap_rowptr.p,
       (uint64_t)(uintptr_t)S.Ap_col.p, (uint64_t)(uintptr_t)S.Ap_val.p, (uint64_t)(uintptr_t)B.up.p, (uint64_t)(uintptr_t)B.p_n.p, (uint64_t)(uintptr_t)B.flag.p,
       (uint64_t)(uintptr_t)B.partial.p, (uint64_t)(uintptr_t)h->s_rowptr.p, (uint64_t)(uintptr_t)h->s_idx.p, (uint64_t)(uintptr_t)h->s_w.p,
@@ -3868,7 +4000,7 @@ int fc_get_batch_info(fc_handle h, double* info) {
   info[2] = (double)B.scratch_rows;
   info[3] = nblk;
   info[4] = nfold;
-  info[5] = 8.0 * (double)B.factor_values;              // factor bytes of one batched apply (serves KB simulated steps)
+  info[5] = 8.0 * (double)B.tiled_values;               // factor bytes STREAMED by one batched apply (tiled copy incl. zero padding; serves KB simulated steps)
   info[6] = 8.0 * B.vec_rows * (double)std::max(1, B.KB);  // operand / result / fold bytes of one batched apply
   info[7] = (double)B.tasks.n;
   return FC_OK;
@@ -3884,12 +4016,12 @@ int fc_bench_batch_apply(fc_handle h, int slot, int reps, double* ms_per_apply) 
   const size_t bytes = (size_t)h->N * B.KB * sizeof(double);
   for (int i = 0; i < 2; ++i) {
     HIPCHK(hipMemcpyAsync(B.buf.p, B.b.p, bytes, hipMemcpyDeviceToDevice, h->stream));
-    FCCHK(batch_apply(h, S));
+    FCCHK(batch_apply(h, slot));
   }
   HIPCHK(hipEventRecord(h->ev0, h->stream));
   for (int i = 0; i < reps; ++i) {
     HIPCHK(hipMemcpyAsync(B.buf.p, B.b.p, bytes, hipMemcpyDeviceToDevice, h->stream));
-    FCCHK(batch_apply(h, S));
+    FCCHK(batch_apply(h, slot));
   }
   HIPCHK(hipEventRecord(h->ev1, h->stream));
   HIPCHK(hipEventSynchronize(h->ev1));
@@ -3913,7 +4045,7 @@ int fc_solve_batch(fc_handle h, int slot, int32_t k, const double* b, double* x)
   for (int s = 0; s < k; ++s)
     for (int i = 0; i < N; ++i) bp[(size_t)s * N + i] = b[(size_t)s * N + h->h_perm[i]];
   FCCHK(batch_copy(h, N, bp.data(), B.buf.p, true));
-  FCCHK(batch_apply(h, S));
+  FCCHK(batch_apply(h, slot));
   FCCHK(batch_copy(h, N, xp.data(), B.buf.p + (size_t)N * B.KB, false));
   for (int s = 0; s < k; ++s)
     for (int i = 0; i < N; ++i) x[(size_t)s * N + h->h_perm[i]] = xp[(size_t)s * N + i];

@@ -55,11 +55,10 @@ class DeviceSolver:
         self.use_block_kernel = os.environ.get("FC_BLOCK_KERNEL", "1") != "0"  # LDS-tiled down-sweeps
         self.part: ndsolver.RankPartition | None = None
         self._sensor_rows: list | None = None
-        # numeric factorisation on the device (fc_refactor); FC_HOST_FACTOR=1 keeps the numpy multifrontal
-        self.device_factor = os.environ.get("FC_HOST_FACTOR", "0") != "1"
-        # the symbolic phase (tree, factor layout, elimination plan, sweep tables) runs inside the library
-        # (fc_setup_solver); FC_PY_SYMBOLIC=1 keeps the numpy one of :mod:`ndsolver` that it mirrors
-        self.py_symbolic = os.environ.get("FC_PY_SYMBOLIC", "0") == "1" or not self.device_factor
+        # the numeric factorisation always runs on the device (fc_refactor); the symbolic phase (tree, factor layout,
+        # elimination plan, sweep tables) runs inside the library (fc_setup_solver); FC_PY_SYMBOLIC=1 keeps the numpy one of
+        # :mod:`ndsolver` that it mirrors
+        self.py_symbolic = os.environ.get("FC_PY_SYMBOLIC", "0") == "1"
         self._tree_args = None
         self._fac_struct: ndsolver.BlockFactors | None = None
         self._plan: ndsolver.FactorPlan | None = None
@@ -209,7 +208,7 @@ class DeviceSolver:
         The host only lays out the structure (once per tree); the numbers are computed on the device
         (``fc_refactor``; on a partitioned handle every rank repeats it for the whole tree), and a later call
         for the same slot is just that numeric phase (``restructure=True`` uploads the launch geometry
-        again).  ``FC_HOST_FACTOR=1`` uses the numpy multifrontal of :mod:`ndsolver` instead.
+        again).
 
         ``truncate = d > 0`` (memory-lean preconditioner): only the tree levels ≥ d are factorised and stored (the
         sub-domain solves and their couplings to the separators above — memory shrinks towards O(nnz) as d grows); the
@@ -238,45 +237,36 @@ class DeviceSolver:
         t = self._tree
         # partitioned handles: every rank holds the whole (small) matrix but lays out and factorises its own sub-tree
         # and the root only; the root front is summed over the ranks inside fc_refactor
-        on_device = bool(self.device_factor)
         up_split = int(os.environ.get("FC_UP_SPLIT", "0"))
-        if on_device:
-            # structure on the host (index work only, once per tree), numbers on the device
-            if self._fac_struct is None:
-                # a rank of a multi-GPU run lays out, stores and factorises its own sub-tree and the root only
-                keep = ndsolver.rank_keeps(t, self.rank, self.world) if self.world > 1 else None
-                self._truncate = int(truncate)
-                if truncate:
-                    if self.world > 1 or truncate > t.depth:
-                        raise ValueError("truncate needs a single-GPU handle and 0 < truncate <= tree depth")
-                    keep = lambda k, n: k >= truncate  # noqa: E731
-                self._fac_struct = ndsolver.factorize_blocks(None, t, numeric=False, keep=keep)
-                pl = ndsolver.factor_plan(self._fac_struct, self.rowptr, self.colidx, self._skip, keep=keep)
-                check(self.lib.fc_factor_plan(
-                    self._h, int(pl.nodes.shape[0]), pl.nodes, int(pl.level_ptr.size - 1), pl.level_ptr, int(pl.front_size),
-                    int(pl.a_src.size), pl.a_src if pl.a_src.size else np.zeros(1, np.int64), pl.a_dst if pl.a_dst.size else np.zeros(1, np.int64),
-                    pl.a_ptr, pl.ext_off, int(pl.ext_p.size), pl.ext_p, int(pl.ap_src.size), pl.ap_src, int(pl.max_slots)))
-                self._plan = pl
-                if truncate:  # the top levels' down stages become diagonal stages
-                    self._fac_struct.stage_kind[t.depth : t.depth + truncate] = 2
-                if self._pin is not None:
-                    self._upload_pin()
-                tag = sp.csr_matrix((np.ones(self.nnz), self.colidx, self.rowptr), shape=(self.N, self.N))
-                Ap = tag[t.perm][:, t.perm].tocsr()
-                Ap.sort_indices()
-                self._Ap_struct = Ap
-            if slot in self._structured and not restructure:
-                self.refactor(slot)
-                self.set_solver_options(refine, check_residual)
-                return
-            fac, Ap = ndsolver.split_up_segments(self._fac_struct, up_split), self._Ap_struct
-        else:
-            A = self.matrix(slot)
+        # structure on the host (index work only, once per tree), numbers on the device
+        if self._fac_struct is None:
+            # a rank of a multi-GPU run lays out, stores and factorises its own sub-tree and the root only
+            keep = ndsolver.rank_keeps(t, self.rank, self.world) if self.world > 1 else None
+            self._truncate = int(truncate)
+            if truncate:
+                if self.world > 1 or truncate > t.depth:
+                    raise ValueError("truncate needs a single-GPU handle and 0 < truncate <= tree depth")
+                keep = lambda k, n: k >= truncate  # noqa: E731
+            self._fac_struct = ndsolver.factorize_blocks(None, t, numeric=False, keep=keep)
+            pl = ndsolver.factor_plan(self._fac_struct, self.rowptr, self.colidx, self._skip, keep=keep)
+            check(self.lib.fc_factor_plan(
+                self._h, int(pl.nodes.shape[0]), pl.nodes, int(pl.level_ptr.size - 1), pl.level_ptr, int(pl.front_size),
+                int(pl.a_src.size), pl.a_src if pl.a_src.size else np.zeros(1, np.int64), pl.a_dst if pl.a_dst.size else np.zeros(1, np.int64),
+                pl.a_ptr, pl.ext_off, int(pl.ext_p.size), pl.ext_p, int(pl.ap_src.size), pl.ap_src, int(pl.max_slots)))
+            self._plan = pl
+            if truncate:  # the top levels' down stages become diagonal stages
+                self._fac_struct.stage_kind[t.depth : t.depth + truncate] = 2
             if self._pin is not None:
-                A = (A + sp.csr_matrix(([self._pin_shift], ([self._pin], [self._pin])), shape=A.shape)).tocsr()
-            fac = ndsolver.split_up_segments(ndsolver.factorize_blocks(A, t), up_split)
-            Ap = A[t.perm][:, t.perm].tocsr()
+                self._upload_pin()
+            tag = sp.csr_matrix((np.ones(self.nnz), self.colidx, self.rowptr), shape=(self.N, self.N))
+            Ap = tag[t.perm][:, t.perm].tocsr()
             Ap.sort_indices()
+            self._Ap_struct = Ap
+        if slot in self._structured and not restructure:
+            self.refactor(slot)
+            self.set_solver_options(refine, check_residual)
+            return
+        fac, Ap = ndsolver.split_up_segments(self._fac_struct, up_split), self._Ap_struct
         part = ndsolver.partition(fac, self.rank, self.world)
         if getattr(self, "_force_comm", False):
             # single-rank communicator: everything is owned, the root rows are "shared" with nobody
@@ -318,9 +308,8 @@ class DeviceSolver:
         # one-launch factor apply: dependency lists of the elimination tree (the task tables are built in the library)
         nodes, mine, dn_dep, up_ptr, up_idx = ndsolver.dag_dependencies(fac, self.rank, self.world)
         check(self.lib.fc_solver_set_dag(self._h, slot, int(nodes.shape[0]), nodes, mine, dn_dep, up_ptr, up_idx))
-        if on_device:
-            self._structured.add(slot)
-            self.refactor(slot)
+        self._structured.add(slot)
+        self.refactor(slot)
         self.factor_nnz[slot] = int(fac.nnz)
         self._n_factor_values = int(fac.vals.size)
         self.local_factor_nnz = int(part.seg_len.sum())

@@ -476,7 +476,7 @@ class FlowSolver(ABC):
                                 pressure=a.pressure, divergence=a.divergence)
             dev.apply_bc(slot)
             solver = self._make_solver(order=order)
-            solver.set_operator(slot)
+            solver.set_operator(DeviceOperator(dev, slot))  # reference: solver.set_operator(A) (flowsolver.py:697)
             self.solvers[order] = solver
             if F.explicit is not None:
                 from ._lib import SLOT_SCRATCH
@@ -588,7 +588,12 @@ class FlowSolver(ABC):
             prev = np.zeros_like(u_ctrl) if self._u_ctrl_prev is None else self._u_ctrl_prev
             u_force = 0.5 * (u_ctrl + prev)
         try:
-            y, dE, info = self.th.device().step(SLOT_BDF2 if self.order == 2 else SLOT_BDF1, u_ctrl, compute_energy=want_energy, u_force=u_force)
+            solver = self.solvers[self.order]
+            slot = SLOT_BDF2 if self.order == 2 else SLOT_BDF1
+            if isinstance(solver, _DeviceNDSolver):
+                y, dE, info = self.th.device().step(slot, u_ctrl, compute_energy=want_energy, u_force=u_force)
+            else:
+                y, dE, info = self._step_with_plugin_solver(solver, slot, u_ctrl, want_energy)
         except FcDiverged:
             logger.critical("Solver diverged (Inf detected)")
             self.fields._mark_stale()  # the host mirrors no longer describe the device state
@@ -617,6 +622,34 @@ class FlowSolver(ABC):
         if at_checkpoint:
             self._checkpoint()
         return self.y_meas
+
+    def _step_with_plugin_solver(self, solver, slot: int, u_ctrl, want_energy: bool):
+        """A ``_make_solver`` override that returns its own solver object (the reference's documented plug-in point,
+        ``docs/numerical-details.md:44-48``, ``flowsolver.py:812-814``) is honoured as the reference honours it: the
+        right-hand side is assembled on the device, ``solver.solve(x, b)`` runs wherever the plug-in runs, and the result
+        becomes the new state (``flowsolver.py:728-751``).  Vectors cross PCIe every step: this is the compatibility path."""
+        if self.order == "cn":
+            raise NotImplementedError("plug-in solvers with the Crank-Nicolson scheme")
+        dev = self.th.device()
+        if dev.perm is None:
+            # no device factorisation was set up (the plug-in solves): the assembly kernels still want a row ordering
+            from ._lib import check
+
+            dev.perm = np.arange(dev.N, dtype=np.int32)
+            check(dev.lib.fc_set_permutation(dev._h, dev.perm))
+        b = dev.assemble_rhs(slot, u_ctrl)
+        x = np.zeros(dev.N)
+        solver.solve(x, b)
+        nn2 = 2 * self.th.nn
+        if not np.all(np.isfinite(x[:nn2])):
+            from ._lib import FC_ERR_DIVERGED
+
+            raise FcDiverged(FC_ERR_DIVERGED, "non-finite velocity after solve")
+        u_prev, _, _ = dev.get_state()
+        dev.set_state(x[:nn2], u_prev, x[nn2:])
+        y = dev.measure(x)
+        dE = dev.energy(x[:nn2]) if want_energy else float("nan")
+        return y, dE, np.array([0.0, float("nan"), float(np.linalg.norm(b)), 0.0])
 
     def _checkpoint(self) -> None:
         u_n, u_nn, p_n = self.fields.u_n, self.fields.u_nn, self.fields.p_n  # collective on several ranks
@@ -753,18 +786,70 @@ class FlowSolver(ABC):
         ...
 
 
+class DeviceOperator:
+    """The assembled, BC-eliminated system matrix of one time order as ``_make_solver`` products receive it in
+    ``set_operator(A)`` (reference ``flowsolver.py:697``: a ``dolfin.PETScMatrix``).  The values live in a matrix slot of the
+    device handle; a solver written against the reference contract reads them as CSR — ``A.mat().getValuesCSR()`` is what
+    ``as_backend_type(A).mat().getValuesCSR()`` gives in the reference — or as a scipy matrix (``A.tocsr()``)."""
+
+    def __init__(self, dev, slot: int):
+        self.dev, self.slot = dev, int(slot)
+        self.shape = (dev.N, dev.N)
+
+    def tocsr(self):
+        return self.dev.matrix(self.slot)
+
+    def mat(self):
+        return self
+
+    def getValuesCSR(self):
+        A = self.tocsr()
+        return A.indptr, A.indices, A.data
+
+    def array(self) -> np.ndarray:
+        return self.tocsr().toarray()
+
+
 class _DeviceNDSolver:
-    """Default ``_make_solver`` product: factorise-once / apply-many on the device."""
+    """Default ``_make_solver`` product: factorise-once / apply-many on the device.
 
-    def __init__(self, fs: FlowSolver):
+    ``set_operator(A)`` follows the reference contract (``flowsolver.py:697``): ``A`` is the operator — a
+    :class:`DeviceOperator` (what ``FlowSolver`` passes: the values are on the device already, only the numeric
+    factorisation runs), any scipy sparse matrix on (a subset of) the Taylor–Hood pattern (its values are uploaded into the
+    order's slot first), or, as before, a bare slot id."""
+
+    def __init__(self, fs: FlowSolver, slot: int | None = None):
         self.fs = fs
-        self.slot: int | None = None
+        self.slot: int | None = slot
 
-    def set_operator(self, slot: int) -> None:
-        self.slot = slot
+    def set_operator(self, A) -> None:
         fs = self.fs
         dev = fs.th.device()
-        dev.setup_solver(slot, depth=fs.nd_depth, refine=fs.refine_steps, truncate=fs.nd_truncate)
+        if isinstance(A, DeviceOperator):
+            self.slot = A.slot
+        elif isinstance(A, (int, np.integer)):
+            self.slot = int(A)
+        else:
+            import scipy.sparse as sp
+
+            if self.slot is None:
+                raise ValueError("set_operator(matrix): construct the solver with the slot that takes the values")
+            M = sp.csr_matrix(A)
+            if M.shape != (dev.N, dev.N):
+                raise ValueError(f"operator has shape {M.shape}, expected {(dev.N, dev.N)}")
+            # values onto the handle's pattern (an entry outside it cannot be represented: refuse rather than drop it)
+            M.sort_indices()
+            N = dev.N
+            key = np.repeat(np.arange(N, dtype=np.int64), np.diff(M.indptr)) * N + M.indices
+            pkey = np.repeat(np.arange(N, dtype=np.int64), np.diff(dev.rowptr)) * N + dev.colidx
+            pos = np.searchsorted(pkey, key)
+            bad = (pos >= pkey.size) | (pkey[np.minimum(pos, pkey.size - 1)] != key)
+            if np.any(bad & (M.data != 0.0)):
+                raise ValueError("the operator has entries outside the Taylor–Hood pattern of this mesh")
+            vals = np.zeros(dev.nnz)
+            vals[pos[~bad]] = M.data[~bad]
+            dev.set_matrix_values(self.slot, vals)
+        dev.setup_solver(self.slot, depth=fs.nd_depth, refine=fs.refine_steps, truncate=fs.nd_truncate)
         if fs.nd_truncate:
             dev.set_solver_options(refine=fs.krylov_max_iter, method=fs.krylov_method, rtol=fs.krylov_rtol)
 

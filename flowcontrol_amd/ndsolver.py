@@ -18,8 +18,10 @@ a level), which is what the HIP kernels in ``csrc/fc_hip.hip`` execute:
 The Krylov / iterative-refinement wrapper on the device uses this as its preconditioner; with
 fp64 factors it is exact to round-off, so one or two refinement steps reach LU-grade residuals.
 
-This module only does the symbolic analysis and the (dense-block) numeric factorisation on the
-host — the analogue of MUMPS' analysis + factorisation phase, executed at setup.
+This module is the readable specification of the SYMBOLIC analysis (tree, factor layout, elimination plan, partition,
+tiles, dependencies) that the library performs natively (``csrc/fc_symbolic.hpp``; ``FC_PY_SYMBOLIC=1`` routes the setup
+through this module, ``tests/test_symbolic_cabi.py`` compares the two table by table).  The numbers are always computed on
+the device (``fc_refactor``); the numeric host multifrontal used by the tests is ``tests/support/nd_numeric.py``.
 """
 
 from __future__ import annotations
@@ -149,134 +151,9 @@ def build_tree(cell_dofs: np.ndarray, centroids: np.ndarray, N: int, depth: int,
     return tree
 
 
-@dataclass
-class NDFactors:
-    """Level-wise sparse factors in the permuted ordering (CSR arrays, ready for upload)."""
-
-    tree: NDTree
-    N: int
-    up: list[sp.csr_matrix]  # up[i]: rows of level k = depth-1-i, shape (rows_k, N), entries = −L
-    down: list[sp.csr_matrix]  # down[k]: rows of level k, shape (rows_k, 2N): [D⁻¹ on y | −U on x]
-    nnz: int
-
-    def solve(self, b: np.ndarray) -> np.ndarray:
-        """Host reference of the device apply (used by the CPU tests of this module)."""
-        t = self.tree
-        y = b[t.perm].astype(np.float64).copy()
-        row0 = lambda k: int(t.node_ptr[k][0])  # noqa: E731
-        row1 = lambda k: int(t.node_ptr[k][-1])  # noqa: E731
-        for i, k in enumerate(range(t.depth - 1, -1, -1)):
-            y[row0(k) : row1(k)] += self.up[i] @ y
-        buf = np.concatenate([y, np.zeros(self.N)])
-        for k in range(0, t.depth + 1):
-            buf[self.N + row0(k) : self.N + row1(k)] = self.down[k] @ buf
-        x = np.empty(self.N)
-        x[t.perm] = buf[self.N :]
-        return x
+__all__ = ["NDTree", "build_tree"]
 
 
-def factorize(A: sp.csr_matrix, tree: NDTree) -> NDFactors:
-    """Numeric multifrontal factorisation with explicit pivot-block inverses."""
-    N = A.shape[0]
-    t = tree
-    Ap = A[t.perm][:, t.perm].tocsr()
-    Ap.sort_indices()
-    updates: dict[tuple[int, int], tuple[np.ndarray, np.ndarray]] = {}
-    Lr, Lc, Lv = [], [], []  # −L entries (row in B_t, col in I_t)
-    Ur, Uc, Uv = [], [], []  # −U entries (row in I_t, col in B_t)
-    Dr, Dc, Dv = [], [], []
-    for k in range(t.depth, -1, -1):
-        for n in range(t.nnodes(k)):
-            i0, i1 = int(t.node_ptr[k][n]), int(t.node_ptr[k][n + 1])
-            ni = i1 - i0
-            B = t.bnd[k][n]
-            nb = B.size
-            if ni == 0:
-                # nothing owned here: forward children's updates unchanged (merged)
-                if k < t.depth:
-                    idx = B
-                    F = np.zeros((nb, nb))
-                    for ch in t.children(k, n):
-                        cb, cu = updates.pop((k + 1, ch))
-                        if cb.size:
-                            p = np.searchsorted(idx, cb)
-                            F[np.ix_(p, p)] += cu
-                    updates[(k, n)] = (idx, F)
-                else:
-                    updates[(k, n)] = (B, np.zeros((nb, nb)))
-                continue
-            idx = np.concatenate([np.arange(i0, i1), B])
-            nf = ni + nb
-            F = np.zeros((nf, nf))
-            rows = Ap[i0:i1]
-            # original entries: A[I, I ∪ B] and A[B, I]
-            coo = rows.tocoo()
-            later = coo.col >= i0  # columns < i0 belong to deeper nodes: assembled there as A[B, I]
-            coo = sp.coo_matrix((coo.data[later], (coo.row[later], coo.col[later])), shape=coo.shape)
-            pos = np.searchsorted(idx[ni:], coo.col)
-            inI = (coo.col >= i0) & (coo.col < i1)
-            ok = inI.copy()
-            if nb:
-                posc = np.minimum(pos, nb - 1)
-                inB = (~inI) & (idx[ni:][posc] == coo.col)
-            else:
-                posc = pos
-                inB = np.zeros_like(inI)
-            ok |= inB
-            if not np.all(ok | (coo.data == 0.0)):
-                raise RuntimeError("matrix entry outside the front: tree/boundary sets inconsistent")
-            cc = np.where(inI, coo.col - i0, ni + posc)
-            F[coo.row[ok], cc[ok]] += coo.data[ok]
-            if nb:
-                cols = Ap[:, i0:i1].tocsc()[B].tocoo()  # A[B, I]
-                F[ni + cols.row, cols.col] += cols.data
-            if k < t.depth:
-                for ch in t.children(k, n):
-                    cb, cu = updates.pop((k + 1, ch))
-                    if cb.size:
-                        p = np.searchsorted(idx, cb)
-                        if not np.array_equal(idx[p], cb):
-                            raise RuntimeError("child boundary not contained in parent front")
-                        F[np.ix_(p, p)] += cu
-            F11 = F[:ni, :ni]
-            Dinv = np.linalg.inv(F11)
-            rr, cc2 = np.meshgrid(np.arange(i0, i1), np.arange(i0, i1), indexing="ij")
-            Dr.append(rr.ravel()), Dc.append(cc2.ravel()), Dv.append(Dinv.ravel())
-            if nb:
-                F12, F21, F22 = F[:ni, ni:], F[ni:, :ni], F[ni:, ni:]
-                Wt = F21 @ Dinv
-                Vt = Dinv @ F12
-                updates[(k, n)] = (B, F22 - Wt @ F12)
-                rr, cc2 = np.meshgrid(B, np.arange(i0, i1), indexing="ij")
-                Lr.append(rr.ravel()), Lc.append(cc2.ravel()), Lv.append(-Wt.ravel())
-                rr, cc2 = np.meshgrid(np.arange(i0, i1), B, indexing="ij")
-                Ur.append(rr.ravel()), Uc.append(cc2.ravel()), Uv.append(-Vt.ravel())
-            else:
-                updates[(k, n)] = (B, np.zeros((0, 0)))
-
-    def cat(xs, dt):
-        return np.concatenate(xs) if xs else np.zeros(0, dtype=dt)
-
-    Lm = sp.csr_matrix((cat(Lv, float), (cat(Lr, np.int64), cat(Lc, np.int64))), shape=(N, N))
-    Um = sp.csr_matrix((cat(Uv, float), (cat(Ur, np.int64), cat(Uc, np.int64))), shape=(N, N))
-    Dm = sp.csr_matrix((cat(Dv, float), (cat(Dr, np.int64), cat(Dc, np.int64))), shape=(N, N))
-    up, down = [], []
-    for k in range(t.depth - 1, -1, -1):
-        r0, r1 = int(t.node_ptr[k][0]), int(t.node_ptr[k][-1])
-        up.append(Lm[r0:r1].tocsr())
-    DU = sp.hstack([Dm, Um]).tocsr()
-    for k in range(0, t.depth + 1):
-        r0, r1 = int(t.node_ptr[k][0]), int(t.node_ptr[k][-1])
-        down.append(DU[r0:r1].tocsr())
-    nnz = int(Lm.nnz + Um.nnz + Dm.nnz)
-    return NDFactors(t, N, up, down, nnz)
-
-
-__all__ = ["NDTree", "NDFactors", "build_tree", "factorize"]
-
-
-# ──────────────────────────────────────────────────────────────────────────────────────────
-# Block ("segment list") factors: what the device actually consumes.
 # ──────────────────────────────────────────────────────────────────────────────────────────
 @dataclass
 class BlockFactors:
@@ -311,42 +188,6 @@ class BlockFactors:
     # boundary size, offset of its [D⁻¹ | −U] rows in ``vals`` (row stride ni+nb), offset of its index list
     nodes: np.ndarray | None = None  # (n_nodes, 7) int64: level, n, i0, ni, nb, val_off, idx_off
 
-    def to_csr_stages(self):
-        """(up, down) lists of scipy CSR matrices — host reference used by the CPU tests."""
-        mats = []
-        for s in range(len(self.stage_kind)):
-            r0 = int(self.stage_begin[s])
-            nr = int(self.stage_nrows[s])
-            rows, cols, vals = [], [], []
-            for r in range(nr):
-                for q in range(int(self.seg_ptr[r0 + r]), int(self.seg_ptr[r0 + r + 1])):
-                    n = int(self.seg_len[q])
-                    c = int(self.seg_col[q])
-                    cc = np.arange(c, c + n) if c >= 0 else self.idx[-(c + 1) : -(c + 1) + n]
-                    rows.append(np.full(n, r))
-                    cols.append(cc)
-                    vals.append(self.vals[int(self.seg_val[q]) : int(self.seg_val[q]) + n])
-            if rows:
-                M = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nr, 2 * self.N))
-            else:
-                M = sp.csr_matrix((nr, 2 * self.N))
-            mats.append(M)
-        return mats
-
-    def solve(self, b: np.ndarray) -> np.ndarray:
-        """Host reference of the device apply (small meshes only: builds CSR stages)."""
-        t = self.tree
-        buf = np.concatenate([b[t.perm].astype(np.float64), np.zeros(self.N)])
-        for s, M in enumerate(self.to_csr_stages()):
-            r0, nr = int(self.stage_row0[s]), int(self.stage_nrows[s])
-            if self.stage_kind[s] == 0:
-                buf[r0 : r0 + nr] += M @ buf
-            else:
-                buf[self.N + r0 : self.N + r0 + nr] = M @ buf
-        x = np.empty(self.N)
-        x[t.perm] = buf[self.N :]
-        return x
-
 
 def rank_keeps(tree: NDTree, rank: int, world: int):
     """Predicate (level, node) → this rank stores and factorises the node: its own sub-tree of the ``world``-ary
@@ -359,41 +200,16 @@ def rank_keeps(tree: NDTree, rank: int, world: int):
     return keep
 
 
-def factorize_blocks(A: sp.csr_matrix | None, tree: NDTree, numeric: bool = True, keep=None) -> BlockFactors:
-    """Numeric multifrontal factorisation with explicit pivot-block inverses → block factors.
-
-    ``numeric=False`` lays out the structure only (segment lists, index lists, value offsets; ``vals``
-    all zero, ``A`` may be None): the values are then computed on the device (:func:`factor_plan`,
-    ``fc_refactor``).  ``keep(level, node)`` (structure only): nodes for which it is False get no storage at all —
-    a rank of a multi-GPU run lays out its own sub-tree and the root (:func:`rank_keeps`), so its factor array
-    is ~1/world of the whole."""
+def factorize_blocks(A: sp.csr_matrix | None, tree: NDTree, numeric: bool = False, keep=None) -> BlockFactors:
+    """Layout of the block factors along ``tree``: segment lists, index lists, value offsets (``vals`` all zero, ``A`` is
+    ignored and may be None).  The VALUES are computed on the device (:func:`factor_plan`, ``fc_refactor``); the numeric
+    host multifrontal that used to live here is test infrastructure now (``tests/support/nd_numeric.py``).
+    ``keep(level, node)``: nodes for which it is False get no storage at all — a rank of a multi-GPU run lays out its own
+    sub-tree and the root (:func:`rank_keeps`), so its factor array is ~1/world of the whole."""
     t = tree
-    if keep is not None and numeric:
-        raise ValueError("keep= is for the structure-only layout (numeric=False)")
+    if numeric:
+        raise ValueError("the product lays out structure only: the numeric host multifrontal is tests/support/nd_numeric.py")
     N = int(t.perm.size)
-    if not numeric:
-        A = sp.csr_matrix((N, N))
-    Ap = A[t.perm][:, t.perm].tocoo()
-    r_, c_, v_ = Ap.row.astype(np.int64), Ap.col.astype(np.int64), Ap.data
-    nonzero = v_ != 0.0
-    r_, c_, v_ = r_[nonzero], c_[nonzero], v_[nonzero]
-    # node id (global, in elimination order) of every permuted dof
-    starts = np.concatenate([t.node_ptr[k][:-1] for k in range(t.depth, -1, -1)])
-    node_level = np.concatenate([np.full(len(t.node_ptr[k]) - 1, k) for k in range(t.depth, -1, -1)])
-    node_index = np.concatenate([np.arange(len(t.node_ptr[k]) - 1) for k in range(t.depth, -1, -1)])
-    ends = np.concatenate([t.node_ptr[k][1:] for k in range(t.depth, -1, -1)])
-    order_nodes = np.argsort(starts, kind="stable")
-    sorted_starts = starts[order_nodes]
-    nonempty = ends[order_nodes] > sorted_starts
-    sn = sorted_starts[nonempty]
-    sid = order_nodes[nonempty]
-    owner_of_dof = sid[np.searchsorted(sn, np.arange(N), side="right") - 1]
-    own = owner_of_dof[np.minimum(r_, c_)]
-    eorder = np.argsort(own, kind="stable")
-    r_, c_, v_, own = r_[eorder], c_[eorder], v_[eorder], own[eorder]
-    ebeg = np.searchsorted(own, np.arange(len(starts) + 1))
-    gid = {(int(k), int(n)): g for g, (k, n) in enumerate(zip(node_level, node_index))}
-
     vals_chunks: list[np.ndarray] = []
     vpos = 0
     idx_chunks: list[np.ndarray] = []
@@ -402,7 +218,6 @@ def factorize_blocks(A: sp.csr_matrix | None, tree: NDTree, numeric: bool = True
     dn_val = np.zeros((N, 2), dtype=np.int64)
     dn_col = np.zeros((N, 2), dtype=np.int32)
     dn_len = np.zeros((N, 2), dtype=np.int32)
-    updates: dict[tuple[int, int], tuple[np.ndarray, np.ndarray]] = {}
     nnz = 0
     node_rows: list[tuple] = []
     for k in range(t.depth, -1, -1):
@@ -411,53 +226,14 @@ def factorize_blocks(A: sp.csr_matrix | None, tree: NDTree, numeric: bool = True
             ni = i1 - i0
             B = t.bnd[k][n]
             nb = B.size
-            children = t.children(k, n) if k < t.depth else ()
             if keep is not None and not keep(k, n):
                 continue
             if ni == 0:
-                if not numeric:
-                    continue
-                F = np.zeros((nb, nb))
-                for ch in children:
-                    cb, cu = updates.pop((k + 1, ch))
-                    if cb.size:
-                        p = np.searchsorted(B, cb)
-                        F[np.ix_(p, p)] += cu
-                updates[(k, n)] = (B, F)
                 continue
             nf = ni + nb
             rows = np.arange(i0, i1)
-            if numeric:
-                idxs = np.concatenate([np.arange(i0, i1), B])
-                F = np.zeros((nf, nf))
-                g = gid[(k, n)]
-                er, ec, ev = r_[ebeg[g] : ebeg[g + 1]], c_[ebeg[g] : ebeg[g + 1]], v_[ebeg[g] : ebeg[g + 1]]
-                rin, cin = er < i1, ec < i1  # owner = node of min(r, c) ⇒ both ≥ i0
-                pr = np.where(rin, er - i0, ni + np.searchsorted(B, er))
-                pc = np.where(cin, ec - i0, ni + np.searchsorted(B, ec))
-                if nb:
-                    bad = (~rin & (B[np.clip(pr - ni, 0, nb - 1)] != er)) | (~cin & (B[np.clip(pc - ni, 0, nb - 1)] != ec))
-                else:
-                    bad = ~rin | ~cin
-                if np.any(bad):
-                    raise RuntimeError("matrix entry outside the front: tree/boundary sets inconsistent")
-                np.add.at(F, (pr, pc), ev)
-                for ch in children:
-                    cb, cu = updates.pop((k + 1, ch))
-                    if cb.size:
-                        p = np.searchsorted(idxs, cb)
-                        F[np.ix_(p, p)] += cu
-                Dinv = np.linalg.inv(F[:ni, :ni])
             if nb:
-                if numeric:
-                    F12, F21 = F[:ni, ni:], F[ni:, :ni]
-                    Wt = F21 @ Dinv
-                    Vt = Dinv @ F12
-                    updates[(k, n)] = (B, F[ni:, ni:] - Wt @ F12)
-                    vals_chunks.append(np.hstack([Dinv, -Vt]).ravel())  # (ni, ni+nb) row-major: one contiguous row per dof
-                    vals_chunks.append((-Wt).ravel())  # (nb, ni) row-major: row j feeds dof B[j]
-                else:
-                    vals_chunks.append(np.zeros(ni * nf + nb * ni))
+                vals_chunks.append(np.zeros(ni * nf + nb * ni))  # [D^-1 | -U] (ni, ni+nb) row-major, then -L (nb, ni) row-major
                 node_rows.append((k, n, i0, ni, nb, vpos, ipos))
                 dn_val[rows, 0] = vpos + np.arange(ni) * nf
                 dn_val[rows, 1] = vpos + np.arange(ni) * nf + ni
@@ -473,11 +249,7 @@ def factorize_blocks(A: sp.csr_matrix | None, tree: NDTree, numeric: bool = True
                 vpos += nb * ni
                 nnz += ni * ni + 2 * ni * nb
             else:
-                if numeric:
-                    updates[(k, n)] = (B, np.zeros((0, 0)))
-                    vals_chunks.append(Dinv.ravel())
-                else:
-                    vals_chunks.append(np.zeros(ni * ni))
+                vals_chunks.append(np.zeros(ni * ni))
                 node_rows.append((k, n, i0, ni, 0, vpos, 0))
                 dn_val[rows, 0] = vpos + np.arange(ni) * ni
                 vpos += ni * ni
@@ -669,58 +441,6 @@ def front_diagonal_slot(plan: FactorPlan, tree: NDTree, dof: int) -> int:
     return fo + (ip - int(i0[g])) * (nf + 1)
 
 
-def factorize_with_plan(plan: FactorPlan, fac: BlockFactors, values: np.ndarray, lead: bool = True, allreduce=None) -> np.ndarray:
-    """Host replay of exactly what ``fc_refactor`` does on the device (same order of operations): the
-    factor values for the CSR ``values`` (original numbering).  Test reference, not a product path.
-
-    Per-rank plans (``keep=`` of :func:`factor_plan`): ``lead`` — this rank scatters the matrix entries of the root
-    front; ``allreduce(array)`` sums the root front over the ranks before the root is eliminated."""
-    F = np.zeros(plan.front_size)
-    vals = np.zeros(fac.vals.size)
-    nodes = plan.nodes
-    n_lower = int(plan.a_ptr[-2]) if allreduce is not None else int(plan.a_ptr[-1])  # entries below the root level
-    np.add.at(F, plan.a_dst[:n_lower], values[plan.a_src[:n_lower]])
-    if allreduce is not None and lead:
-        np.add.at(F, plan.a_dst[n_lower:], values[plan.a_src[n_lower:]])
-    nlev = plan.level_ptr.size - 1
-    for li in range(nlev):
-        g0, g1 = int(plan.level_ptr[li]), int(plan.level_ptr[li + 1])
-        # children of this level's nodes were finished in the previous round: add their update blocks
-        if li > 0:
-            c0, c1 = int(plan.level_ptr[li - 1]), int(plan.level_ptr[li])
-            for s in range(plan.max_slots):
-                for gc in range(c0, c1):
-                    if plan.ext_off[gc] < 0 or nodes[gc, 6] != s:
-                        continue
-                    _, fo, nf, ni, _, par, _ = nodes[gc]
-                    nbc = nf - ni
-                    S = F[fo : fo + nf * nf].reshape(nf, nf)[ni:, ni:]
-                    pp = plan.ext_p[plan.ext_off[gc] : plan.ext_off[gc] + nbc]
-                    _, pfo, pnf = nodes[par, 0], nodes[par, 1], nodes[par, 2]
-                    P = F[pfo : pfo + pnf * pnf].reshape(pnf, pnf)
-                    P[np.ix_(pp, pp)] += S
-        if allreduce is not None and li == nlev - 1:
-            _, fo, nf = nodes[g0, 0], nodes[g0, 1], nodes[g0, 2]
-            root = F[fo : fo + nf * nf]
-            allreduce(root)  # every rank's sub-tree contributes its Schur complement, the lead the matrix entries
-        for g in range(g0, g1):
-            _, fo, nf, ni, vo, _, _ = nodes[g]
-            if ni == 0:
-                continue
-            Fm = F[fo : fo + nf * nf].reshape(nf, nf)
-            Dinv = np.linalg.inv(Fm[:ni, :ni])
-            nb = nf - ni
-            if nb:
-                mVt = -(Dinv @ Fm[:ni, ni:])
-                mWt = -(Fm[ni:, :ni] @ Dinv)
-                Fm[ni:, ni:] += mWt @ Fm[:ni, ni:]
-                vals[vo : vo + ni * nf] = np.hstack([Dinv, mVt]).ravel()
-                vals[vo + ni * nf : vo + ni * nf + nb * ni] = mWt.ravel()
-            else:
-                vals[vo : vo + ni * ni] = Dinv.ravel()
-    return vals
-
-
 def split_up_segments(fac: BlockFactors, maxlen: int) -> BlockFactors:
     """Cut the up-sweep segments into pieces of ≤ ``maxlen`` values (same values, same order).
 
@@ -881,7 +601,7 @@ def dag_dependencies(fac: BlockFactors, rank: int = 0, world: int = 1):
 
 
 __all__ += ["BlockFactors", "factorize_blocks", "rank_keeps", "schur_diagonal_scaling", "down_blocks", "dag_dependencies", "split_up_segments", "FactorPlan", "factor_plan",
-            "factorize_with_plan", "front_diagonal_slot"]
+            "front_diagonal_slot"]
 
 
 # ──────────────────────────────────────────────────────────────────────────────────────────
@@ -1008,36 +728,4 @@ def partition(fac: BlockFactors, rank: int, world: int) -> RankPartition:
     )
 
 
-def solve_partitioned_reference(fac: BlockFactors, part: RankPartition, b_local_perm: np.ndarray, allreduce) -> np.ndarray:
-    """Host emulation of what one rank's device does (CPU tests with gloo): ``b_local_perm`` holds
-    this rank's share of the permuted right-hand side (owned rows + its partial of the root rows);
-    ``allreduce(array)`` sums an array over the ranks in place.  Returns the x-half of the buffer
-    (valid on owned and root rows)."""
-    N = fac.N
-    buf = np.concatenate([b_local_perm.astype(np.float64), np.zeros(N)])
-    for s in range(len(part.stage_kind)):
-        g0, nr, r0 = int(part.stage_begin[s]), int(part.stage_nrows[s]), int(part.stage_row0[s])
-        acc = np.zeros(nr)
-        for r in range(nr):
-            for q in range(int(part.seg_ptr[g0 + r]), int(part.seg_ptr[g0 + r + 1])):
-                n, c, vo = int(part.seg_len[q]), int(part.seg_col[q]), int(part.seg_val[q])
-                xs = buf[c : c + n] if c >= 0 else buf[fac.idx[-(c + 1) : -(c + 1) + n]]
-                acc[r] += fac.vals[vo : vo + n] @ xs
-        if part.stage_kind[s] == 0:
-            buf[r0 : r0 + nr] += acc
-        else:
-            if s == part.ar2_stage:
-                buf[N + part.ar_row0 : N + part.ar_row0 + part.ar_n] = 0.0  # the other ranks' blocks
-            buf[N + r0 : N + r0 + nr] = acc
-        if s == part.ar_stage and part.ar_n > 0:
-            seg = buf[part.ar_row0 : part.ar_row0 + part.ar_n].copy()
-            allreduce(seg)
-            buf[part.ar_row0 : part.ar_row0 + part.ar_n] = seg
-        if s == part.ar2_stage and part.ar_n > 0:
-            seg = buf[N + part.ar_row0 : N + part.ar_row0 + part.ar_n].copy()
-            allreduce(seg)
-            buf[N + part.ar_row0 : N + part.ar_row0 + part.ar_n] = seg
-    return buf[N:]
-
-
-__all__ += ["RankPartition", "partition", "solve_partitioned_reference"]
+__all__ += ["RankPartition", "partition"]

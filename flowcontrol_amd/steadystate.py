@@ -7,7 +7,7 @@ applied with the same sweep kernels as a time step; the host only forms norms an
 iterate.  On a partitioned (multi-GPU) handle every rank assembles the whole (small) operator, factorises its own
 sub-tree and the root, and the solves are collectives (``fc_solve`` merges the ranks' parts); before time stepping
 starts the handle is not partitioned yet and every rank simply computes the base flow on its own GPU.
-``FC_HOST_FACTOR=1`` keeps the earlier host path (SuperLU with the nested-dissection ordering).
+There is no host solver in here: without the device the first call raises.
 """
 
 from __future__ import annotations
@@ -15,10 +15,8 @@ from __future__ import annotations
 import logging
 
 import numpy as np
-import scipy.sparse as sp
-import scipy.sparse.linalg as spla
 
-from . import _lib, ndsolver
+from . import _lib
 from ._lib import SLOT_BDF1, SLOT_MASS, SLOT_SCRATCH
 from .fem.boundary import combine_bcs, pressure_pin
 from .fem.spaces import Function
@@ -48,43 +46,13 @@ class SteadyStateSolver:
     def _device(self):
         return self.W.th.device()
 
-    def _ordering(self, bc_dofs: np.ndarray) -> np.ndarray:
-        if self._perm is None:
-            th = self.W.th
-            skip = np.zeros(th.N, dtype=bool)
-            skip[bc_dofs] = True
-            depth = max(2, int(np.ceil(np.log2(max(th.nc, 1) / 12.0))))
-            self._perm = ndsolver.build_tree(th.cell_dofs, th.mesh.cell_centroids(), th.N, depth, skip).perm
-        return self._perm
-
-    def _solve(self, A: sp.csr_matrix, b: np.ndarray, bc_dofs: np.ndarray) -> np.ndarray:
-        p = self._ordering(bc_dofs)
-        lu = spla.splu(A[p][:, p].tocsc(), permc_spec="NATURAL", diag_pivot_thresh=0.01)
-        x = np.empty_like(b)
-        x[p] = lu.solve(b[p])
-        return x
-
     def _assemble_on_device(self, coeff, slot=SLOT_SCRATCH) -> None:
         self._device().assemble_matrix(slot, mass=coeff.mass, nu=coeff.nu, adv=coeff.adv, lin=coeff.lin, pressure=coeff.pressure,
                                        divergence=coeff.divergence)
 
-    def _assemble(self, coeff) -> sp.csr_matrix:
-        self._assemble_on_device(coeff)
-        return self._device().matrix(SLOT_SCRATCH)
-
-    def _on_device(self) -> bool:
-        dev = self._device()
-        return bool(dev.device_factor)
-
     def _solve_increment(self, coeff, r: np.ndarray, dofs: np.ndarray) -> np.ndarray:
         """δ with  A δ = r  on the free rows and δ = 0 on the Dirichlet dofs (``r[dofs]`` is 0)."""
         pin = pressure_pin(self.W.th, dofs)  # enclosed flow: the pressure level is fixed at one dof
-        if not self._on_device():
-            rows = dofs if pin is None else np.append(dofs, pin)
-            if pin is not None:
-                r = r.copy()
-                r[pin] = 0.0
-            return self._solve(self._rows_to_identity(self._assemble(coeff), rows), r, rows)
         dev = self._device()
         if not self._bc_set:
             # increments vanish on the Dirichlet dofs: homogeneous symmetric elimination, no lifting
@@ -133,12 +101,6 @@ class SteadyStateSolver:
         x = np.zeros(th.N)
         x[: th.nn], x[th.nn : 2 * th.nn] = nodal[:, 0], nodal[:, 1]
         return dev.spmv(SLOT_MASS, x)
-
-    @staticmethod
-    def _rows_to_identity(A: sp.csr_matrix, dofs: np.ndarray) -> sp.csr_matrix:
-        keep = np.ones(A.shape[0])
-        keep[dofs] = 0.0
-        return (sp.diags(keep) @ A + sp.diags(1.0 - keep)).tocsr()
 
     # ── public API ───────────────────────────────────────────────────────────
     def newton(self, UP0: Function, f=None, max_iter: int = 25, rtol: float = 1e-9, atol: float = 1e-10) -> Function:

@@ -253,6 +253,18 @@ int fc_step_end(fc_handle h, double* y_out, double* dE_out, double* info_out);
 int fc_run(fc_handle h, int first_order_slot, int32_t n_steps, const double* u_ctrl,
            int u_ctrl_is_sequence, double* y_seq, double* dE_seq, int compute_energy);
 
+/* ── base-flow (steady-state) iterations: replace SteadyStateSolver.picard / .newton (steadystate.py:60-159:
+ *    dolfin.solve(F == 0, ...) :95 and the assemble / bc.apply / LUSolver.solve loop :137-145).  A host program drives the
+ *    loop and its stopping rule (picard: relative change < tol, steadystate.py:150-156; newton: dolfin's residual criterion
+ *    rel 1e-9 / abs 1e-10); every iteration's assembly, Dirichlet elimination, factorisation and solve run on the device.
+ *    fc_set_baseflow_bc: the FULL-field Dirichlet data (FlowSolver._make_BCs, flowsolver.py:329-337) — it replaces the
+ *    fc_set_bc tables (call fc_set_bc again before time stepping).  up: mixed vector [N], W layout, in = iterate, out = next
+ *    iterate; load: (f, v) of a body force or NULL; nu = 1 / Re.  Enclosed flows: fc_set_pressure_pin first.
+ *    fc_newton_step returns |F(up_in)| over the free rows in res_norm; update = 0 evaluates the residual only. */
+int fc_set_baseflow_bc(fc_handle h, int32_t n_bc, const int32_t* bc_dofs, const double* bc_values);
+int fc_picard_step(fc_handle h, double nu, double* up, const double* load, double* rel_change);
+int fc_newton_step(fc_handle h, double nu, double* up, const double* load, double* res_norm, int update);
+
 /* ── shared-operator batched stepping: k <= 16 lock-step simulations on ONE handle ────────────
  *    Replaces k independent FlowSolver instances that step the SAME operator with different initial
  *    conditions / controls / controllers — the reference's outer workloads: IC sweeps

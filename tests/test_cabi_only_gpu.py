@@ -119,3 +119,109 @@ def test_setup_and_step_through_the_c_abi_only():
         assert np.linalg.norm(sol - up) < 1e-10 * np.linalg.norm(up)
     finally:
         lib.fc_destroy(h)
+
+
+def test_base_flow_iterations_through_the_c_abi_only():
+    """fc_set_baseflow_bc / fc_picard_step / fc_newton_step: a host program with nothing but ctypes drives the reference's
+    base-flow recipe (Picard, then Newton with dolfin's residual criterion; steadystate.py:60-159) on a channel-like square
+    with a parabolic inflow; every iteration's assembly / elimination / factorisation / solve runs on the device.  Checked
+    against the oracle's Picard and Newton on the same mesh and data."""
+    lib = _lib.load()
+    n = 10
+    coords, cells, cell_edges, edges = _square_mesh(n)
+    nv, ne, nc = len(coords), len(edges), len(cells)
+    nn, N = nv + ne, 2 * (nv + ne) + nv
+    node_xy = np.vstack([coords, 0.5 * (coords[edges[:, 0]] + coords[edges[:, 1]])])
+    x, y = node_xy[:, 0], node_xy[:, 1]
+    wall = (y < 1e-12) | (y > 1 - 1e-12) | (x < 1e-12)  # no-slip bottom / top, inflow on the left, outflow on the right
+    nodes = np.flatnonzero(wall)
+    bc_dofs = np.r_[nodes, nodes + nn].astype(np.int32)
+    bc_vals = np.r_[np.where(x[nodes] < 1e-12, 4.0 * y[nodes] * (1 - y[nodes]), 0.0), np.zeros(nodes.size)]
+    nu = 1.0 / 50.0
+    d = O.Disc(coords, cells, np.hstack([cells, cell_edges + nv]), nn)
+    up0 = np.zeros(N)
+    up0[:nn] = 1.0
+    ref = O.picard(d, nu, up0.copy(), bc_dofs, bc_vals, max_iter=4, tol=1e-12)
+    ref = O.newton(d, nu, ref, bc_dofs, bc_vals, max_iter=10)
+
+    h = C.c_void_p()
+    _check(lib, lib.fc_create(C.byref(h), 0, nv, ne, nc, np.ascontiguousarray(coords), cells, cell_edges))
+    try:
+        _check(lib, lib.fc_set_baseflow_bc(h, bc_dofs.size, bc_dofs.ctypes.data_as(C.c_void_p), bc_vals.ctypes.data_as(C.c_void_p)))
+        up = up0.copy()
+        rel = C.c_double()
+        for _ in range(4):
+            _check(lib, lib.fc_picard_step(h, nu, up, None, C.byref(rel)))
+        assert rel.value < 0.1
+        res, r0 = C.c_double(), None
+        for it in range(11):
+            _check(lib, lib.fc_newton_step(h, nu, up, None, C.byref(res), 0))  # residual only
+            r0 = res.value if r0 is None else r0
+            if res.value < 1e-10 or res.value < 1e-9 * r0:
+                break
+            _check(lib, lib.fc_newton_step(h, nu, up, None, C.byref(res), 1))
+        assert it < 10, "Newton did not converge"
+        assert np.allclose(up[bc_dofs], bc_vals)
+        assert np.linalg.norm(up[: 2 * nn] - ref[: 2 * nn]) < 1e-9 * np.linalg.norm(ref[: 2 * nn])
+        assert np.linalg.norm(up[2 * nn :] - ref[2 * nn :]) < 1e-8 * np.linalg.norm(ref[2 * nn :])
+    finally:
+        lib.fc_destroy(h)
+
+
+def test_batched_steps_through_the_c_abi_only():
+    """fc_set_batch / fc_set_state_batch / fc_step_batch with ctypes + numpy only: four simulations with different states
+    and controls on one handle against the oracle's time stepper, one simulation at a time."""
+    lib = _lib.load()
+    n = 10
+    coords, cells, cell_edges, edges = _square_mesh(n)
+    nv, ne, nc = len(coords), len(edges), len(cells)
+    nn, N = nv + ne, 2 * (nv + ne) + nv
+    node_xy = np.vstack([coords, 0.5 * (coords[edges[:, 0]] + coords[edges[:, 1]])])
+    x, y = node_xy[:, 0], node_xy[:, 1]
+    wall = (y < 1e-12) | (y > 1 - 1e-12) | (x < 1e-12)
+    nodes = np.flatnonzero(wall)
+    bc_dofs = np.r_[nodes, nodes + nn].astype(np.int32)
+    prof = np.zeros((bc_dofs.size, 1))
+    lid = y[nodes] > 1 - 1e-12
+    prof[: nodes.size][lid, 0] = (x[nodes][lid] * (1 - x[nodes][lid])) * 4
+    U0 = np.r_[0.4 * y * (2 - y), np.zeros(nn)]
+    Re, dt, k = 60.0, 0.01, 4
+    h = C.c_void_p()
+    _check(lib, lib.fc_create(C.byref(h), 0, nv, ne, nc, np.ascontiguousarray(coords), cells, cell_edges))
+    try:
+        _check(lib, lib.fc_set_bc(h, bc_dofs.size, bc_dofs.ctypes.data_as(C.c_void_p), 1, prof.ctypes.data_as(C.c_void_p)))
+        _check(lib, lib.fc_set_time_scheme(h, dt, 1))
+        rp = np.array([0, 2], dtype=np.int32)
+        sidx = np.array([7, nn + 9], dtype=np.int32)
+        sw = np.array([1.0, -0.5])
+        _check(lib, lib.fc_set_sensors(h, 1, rp.ctypes.data_as(C.c_void_p), sidx.ctypes.data_as(C.c_void_p), sw.ctypes.data_as(C.c_void_p)))
+        for slot, alpha in ((_lib.SLOT_BDF1, 1.0 / dt), (_lib.SLOT_BDF2, 1.5 / dt)):
+            _check(lib, lib.fc_assemble_matrix(h, slot, alpha, 1.0 / Re, U0.ctypes.data_as(C.c_void_p), 1.0, U0.ctypes.data_as(C.c_void_p), 1.0, -1.0, -1.0))
+            _check(lib, lib.fc_apply_bc(h, slot))
+            _check(lib, lib.fc_setup_solver(h, slot, 0, 2, 0, 0, 1))
+        _check(lib, lib.fc_set_batch(h, k))
+        rng = np.random.default_rng(11)
+        u0 = 0.1 * rng.standard_normal((k, 2 * nn))
+        u0[:, bc_dofs] = 0.0
+        _check(lib, lib.fc_set_state_batch(h, k, u0, u0, None))
+        d = O.Disc(coords, cells, np.hstack([cells, cell_edges + nv]), nn)
+        ts = O.TimeStepper(d, Re, dt, U0, bc_dofs, prof)
+        M = O.velocity_mass(d)
+        u_n, u_nn = u0.copy(), u0.copy()
+        y_out, dE, inf = np.zeros((k, 1)), np.zeros(k), np.zeros((k, 4))
+        for step in range(4):
+            u = np.array([[0.2 * (s + 1) * np.cos(0.4 * step)] for s in range(k)])
+            slot, order = (_lib.SLOT_BDF1, 1) if step == 0 else (_lib.SLOT_BDF2, 2)
+            _check(lib, lib.fc_step_batch(h, slot, k, u.ctypes.data_as(C.c_void_p), None, y_out.ctypes.data_as(C.c_void_p), dE.ctypes.data_as(C.c_void_p), 1,
+                                          inf.ctypes.data_as(C.c_void_p)))
+            for s in range(k):
+                up = ts.step(order, u_n[s], u_nn[s], u[s])
+                u_nn[s], u_n[s] = u_n[s], up[: 2 * nn]
+                assert np.isclose(y_out[s, 0], sw @ up[sidx], rtol=1e-9, atol=1e-12)
+                assert abs(dE[s] - 0.5 * u_n[s] @ (M @ u_n[s])) < 1e-10 * abs(dE[s])
+            assert np.all(inf[:, 1] < 1e-10)
+        got = np.empty((k, 2 * nn))
+        _check(lib, lib.fc_get_state_batch(h, k, got.ctypes.data_as(C.c_void_p), None, None))
+        assert np.linalg.norm(got - u_n) < 1e-10 * np.linalg.norm(u_n)
+    finally:
+        lib.fc_destroy(h)

@@ -4,7 +4,7 @@ The HIP kernels need a GPU; what is exercised here is everything *around* them t
 path correct by construction: the 2**p-ary root split of the elimination tree, the per-rank stage
 tables, the ownership masks / cell lists, and the exchange pattern (per solve: one all-reduce of the root
 right-hand side and one of the root solution, whose rows are split over the ranks).  Each rank runs the host emulation of its device program
-(``ndsolver.solve_partitioned_reference``) and the union of the ranks' results must equal the
+(``nd_numeric.solve_partitioned_reference``) and the union of the ranks' results must equal the
 serial solve of the same system.
 """
 import os
@@ -20,6 +20,7 @@ from flowcontrol_amd import ndsolver
 from flowcontrol_amd.fem.mesh import Mesh
 from flowcontrol_amd.fem.spaces import TaylorHood
 from oracle import ns_oracle as O
+from tests.support import nd_numeric
 
 
 def _free_port():
@@ -52,7 +53,7 @@ def _worker(rank, world, port, out):
         th, d, A, skip = _system()
         p = int(np.log2(world))
         tree = ndsolver.build_tree(th.cell_dofs, th.mesh.cell_centroids(), th.N, 4, skip, merge=2, top_bits=p)
-        fac = ndsolver.factorize_blocks(A, tree)
+        fac = nd_numeric.factorize_blocks(A, tree)
         part = ndsolver.partition(fac, rank, world)
         # right-hand side assembled from this rank's cells only (element loop of the oracle on a sub-mesh)
         rng = np.random.default_rng(7)
@@ -70,7 +71,7 @@ def _worker(rank, world, port, out):
             dist.all_reduce(tns, op=dist.ReduceOp.SUM)
             calls.append(a.size)
 
-        x_perm = ndsolver.solve_partitioned_reference(fac, part, b_perm, allreduce)
+        x_perm = nd_numeric.solve_partitioned_reference(fac, part, b_perm, allreduce)
         x = np.zeros(th.N)
         mine = kind[tree.perm] == 1
         x[tree.perm[mine]] = x_perm[mine]
@@ -81,7 +82,7 @@ def _worker(rank, world, port, out):
         dist.all_reduce(tns, op=dist.ReduceOp.SUM)
         if rank == 0:
             b_full = O.rhs_transient(d, 1, 0.005, u_n, None)
-            x_ref = fac.solve(b_full)
+            x_ref = nd_numeric.block_solve(fac, b_full)
             out["err"] = float(np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref))
             out["res"] = float(np.linalg.norm(A @ x - b_full) / np.linalg.norm(b_full))
             out["calls"] = list(calls)
@@ -111,7 +112,7 @@ def test_partitioned_solve_matches_serial(world):
 def test_partition_covers_everything_once():
     th, d, A, skip = _system()
     tree = ndsolver.build_tree(th.cell_dofs, th.mesh.cell_centroids(), th.N, 4, skip, merge=2, top_bits=2)
-    fac = ndsolver.factorize_blocks(A, tree)
+    fac = nd_numeric.factorize_blocks(A, tree)
     parts = [ndsolver.partition(fac, r, 4) for r in range(4)]
     owned = np.stack([p.rowkind == 1 for p in parts])
     root = parts[0].rowkind == 2
@@ -145,7 +146,7 @@ def _factor_worker(rank, world, port, out):
             tns = torch.from_numpy(a)
             dist.all_reduce(tns, op=dist.ReduceOp.SUM)
 
-        vals = ndsolver.factorize_with_plan(plan, fac, A.data, lead=rank == 0, allreduce=allreduce)
+        vals = nd_numeric.factorize_with_plan(plan, fac, A.data, lead=rank == 0, allreduce=allreduce)
         out[f"nodes{rank}"] = fac.nodes.copy()
         out[f"vals{rank}"] = vals
         out[f"fronts{rank}"] = int(plan.front_size)
@@ -161,7 +162,7 @@ def test_per_rank_factorisation_matches_serial(world):
     th, d, A, skip = _system()
     p = int(np.log2(world))
     tree = ndsolver.build_tree(th.cell_dofs, th.mesh.cell_centroids(), th.N, 4, skip, merge=2, top_bits=p)
-    ref = ndsolver.factorize_blocks(A, tree)
+    ref = nd_numeric.factorize_blocks(A, tree)
     where = {(int(k), int(n)): (int(vo), int(ni), int(nb)) for k, n, _, ni, nb, vo, _ in ref.nodes}
     with mp.Manager() as mgr:
         out = mgr.dict()

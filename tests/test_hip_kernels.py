@@ -222,14 +222,12 @@ def test_block_and_segment_down_sweeps_agree(setup):
 
 def test_device_factorisation_matches_host_multifrontal(setup):
     """fc_refactor (scatter, extend-add, blocked Gauss-Jordan front elimination on the fp64 matrix cores)
-    against the numpy multifrontal of ndsolver.factorize_blocks on the same matrix and tree: factor
+    against the numpy multifrontal of tests/support/nd_numeric.py on the same matrix and tree: factor
     values to round-off, then again after the matrix changed (numeric phase only)."""
     th, dev, d, O = setup
-    from flowcontrol_amd import ndsolver
     from flowcontrol_amd.device import SLOT_BDF2
+    from tests.support import nd_numeric
 
-    if not dev.device_factor:
-        pytest.skip("FC_HOST_FACTOR=1")
     dt, Re = 0.005, 100.0
     dofs, prof = _bc_setup(th)
     dev.set_bc(dofs, prof)
@@ -241,7 +239,7 @@ def test_device_factorisation_matches_host_multifrontal(setup):
         dev.setup_solver(SLOT_BDF2)  # second round: numeric phase only
         assert SLOT_BDF2 in dev._structured and dev.refactor_ms[SLOT_BDF2] > 0
         A = dev.matrix(SLOT_BDF2)
-        host = ndsolver.factorize_blocks(A, dev.tree)
+        host = nd_numeric.factorize_blocks(A, dev.tree)
         got = dev.factor_values(SLOT_BDF2)
         assert got.shape == host.vals.shape
         assert np.abs(got - host.vals).max() <= 1e-10 * np.abs(host.vals).max()
@@ -249,35 +247,6 @@ def test_device_factorisation_matches_host_multifrontal(setup):
         x, info = dev.solve(SLOT_BDF2, b)
         assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-12
         assert info[1] < 1e-12
-
-
-def test_host_factorisation_path_still_agrees(setup):
-    """FC_HOST_FACTOR=1 route (numpy multifrontal uploaded as values) vs the device factorisation: same
-    solve to round-off — keeps the fallback of setup_solver exercised."""
-    th, dev, d, O = setup
-    from flowcontrol_amd.device import SLOT_BDF2
-
-    dt, Re = 0.005, 100.0
-    U0 = _smooth_velocity(th)
-    dofs, prof = _bc_setup(th)
-    dev.set_bc(dofs, prof)
-    dev.set_time_scheme(dt, True)
-    dev.assemble_matrix(SLOT_BDF2, mass=1.5 / dt, nu=1.0 / Re, adv=U0, lin=U0)
-    dev.apply_bc(SLOT_BDF2)
-    b = np.random.default_rng(11).standard_normal(dev.N)
-    was = dev.device_factor
-    try:
-        dev.device_factor = True
-        dev.setup_solver(SLOT_BDF2, restructure=True)
-        x_dev, _ = dev.solve(SLOT_BDF2, b)
-        dev.device_factor = False
-        dev.setup_solver(SLOT_BDF2, restructure=True)
-        x_host, info = dev.solve(SLOT_BDF2, b)
-    finally:
-        dev.device_factor = was
-        dev.setup_solver(SLOT_BDF2, restructure=True)
-    assert _rel(x_host, x_dev) < 1e-11
-    assert info[1] < 1e-12
 
 
 def test_bicgstab_with_exact_and_lagged_factors(setup):

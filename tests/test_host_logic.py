@@ -20,6 +20,7 @@ from flowcontrol_amd.fem.spaces import Function, TaylorHood
 from flowcontrol_amd.flowsolverparameters import ParamIC, ParamTime
 from flowcontrol_amd.sensor import SENSOR_TYPE, SensorHorizontalWallShear, SensorPoint
 from oracle import ns_oracle as O
+from tests.support import nd_numeric
 
 REF = Path("/root/reference/src/examples")
 
@@ -259,10 +260,10 @@ def test_nd_block_factors_solve_saddle_point_system(depth, merge):
     tree = ndsolver.build_tree(th.cell_dofs, m.cell_centroids(), th.N, depth, skip, merge=merge)
     assert sorted(tree.perm) == list(range(th.N))
     b = np.random.default_rng(0).standard_normal(th.N)
-    fb = ndsolver.factorize_blocks(A, tree)
-    xb = fb.solve(b)
+    fb = nd_numeric.factorize_blocks(A, tree)
+    xb = nd_numeric.block_solve(fb, b)
     assert np.linalg.norm(A @ xb - b) / np.linalg.norm(b) < 1e-12
-    fc = ndsolver.factorize(A, tree)
+    fc = nd_numeric.factorize(A, tree)
     assert fc.nnz == fb.nnz and np.allclose(fc.solve(b), xb, rtol=1e-12, atol=1e-14)
     # every stage only reads what earlier stages (or the other half of the buffer) produced
     for s in range(len(fb.stage_kind)):
@@ -450,16 +451,21 @@ def test_factor_plan_replays_the_multifrontal_factorisation():
     skip[dofs] = True
     for top_bits in (0, 1):
         t = nd.build_tree(th.cell_dofs, m.cell_centroids(), th.N, 4, skip, merge=2, top_bits=top_bits)
-        f = nd.factorize_blocks(sp.csr_matrix((vals, indices, indptr), shape=(th.N, th.N)), t)
-        f0 = nd.factorize_blocks(None, t, numeric=False)
-        for name in ("seg_val", "seg_col", "seg_len", "seg_ptr", "idx", "nodes", "stage_begin", "stage_row0", "stage_nrows"):
-            assert np.array_equal(getattr(f, name), getattr(f0, name)), name
-        assert f0.vals.size == f.vals.size and not f0.vals.any()
+        Afull = sp.csr_matrix((vals, indices, indptr), shape=(th.N, th.N))
+        f0 = nd.factorize_blocks(None, t)
+        assert not f0.vals.any()
         plan = nd.factor_plan(f0, indptr, indices, skip)
         assert plan.nodes[:, 5].max() < plan.nodes.shape[0] and plan.a_ptr[-1] == plan.a_src.size
         assert np.unique(plan.a_dst).size == plan.a_dst.size  # one front slot per matrix entry
-        v = nd.factorize_with_plan(plan, f0, vals)
-        assert np.array_equal(v, f.vals)
+        # the plan replayed on the host (what fc_refactor does on the device) against the independent CSR multifrontal
+        f0.vals = nd_numeric.factorize_with_plan(plan, f0, vals)
+        b = np.random.default_rng(top_bits).standard_normal(th.N)
+        x_plan = nd_numeric.block_solve(f0, b)
+        x_csr = nd_numeric.factorize(Afull, t).solve(b)
+        assert np.linalg.norm(x_plan - x_csr) <= 1e-12 * np.linalg.norm(x_csr)
+        assert np.linalg.norm(Afull @ x_plan - b) <= 1e-12 * np.linalg.norm(b)
+        f1 = nd_numeric.factorize_blocks(Afull, t)  # the convenience route used by the GPU parity tests: same numbers
+        assert np.array_equal(f1.vals, f0.vals)
 
 
 def test_pressure_pin_only_for_enclosed_flows():
