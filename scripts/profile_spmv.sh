@@ -5,7 +5,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profile_spmv
 rm -rf "$OUT" && mkdir -p "$OUT"
-export FC_HOST_FACTOR=1
+# (FC_HOST_FACTOR was removed in round 3: the factorisation always runs on the device)
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/err.txt"
 python - <<PY
 import glob, json, pandas as pd
