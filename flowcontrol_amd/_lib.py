@@ -125,6 +125,8 @@ SIGNATURES: dict[str, list] = {
     "fc_set_stage_diag": [_H, C.c_int, _dp],
     "fc_debug_inject_dag_failure": [_H, C.c_int],
     "fc_debug_trace_apply": [_H, C.c_int, C.c_int32, _lp, _ip, _ip],
+    "fc_set_factor_precision": [_H, C.c_int],
+    "fc_get_factor_storage": [_H, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64)],
     "fc_set_baseflow_bc": [_H, C.c_int32, C.c_void_p, C.c_void_p],
     "fc_picard_step": [_H, C.c_double, _dp, C.c_void_p, C.POINTER(C.c_double)],
     "fc_newton_step": [_H, C.c_double, _dp, C.c_void_p, C.POINTER(C.c_double), C.c_int],

@@ -270,20 +270,22 @@ __global__ __launch_bounds__(256) void fc_fe_update(const FcFront* __restrict__ 
   }
 }
 
-// factor rows [D^-1 | -U] (stride nf) and the -L block (nb x ni, stride ni) into the layout the sweeps read
-__global__ __launch_bounds__(256) void fc_fe_export(const FcFront* __restrict__ nodes, const double* __restrict__ fronts, double* __restrict__ fvals) {
+// factor rows [D^-1 | -U] (stride nf) and the -L block (nb x ni, stride ni) into the layout the sweeps read, in the
+// storage type of the slot (double, or rounded once to float / bfloat16: compressed factors, fc_kernels.hip.h)
+template <typename VT>
+__global__ __launch_bounds__(256) void fc_fe_export(const FcFront* __restrict__ nodes, const double* __restrict__ fronts, VT* __restrict__ fvals) {
   const FcFront nd = nodes[blockIdx.y];
   const int nf = nd.nf, ni = nd.ni;
   const int i0 = blockIdx.x * 16;
   if (i0 >= nf || ni == 0) return;
   const double* A = fronts + nd.front;
-  double* dv = fvals + nd.voff;
-  double* mw = dv + (size_t)ni * nf;
+  VT* dv = fvals + nd.voff;
+  VT* mw = dv + (size_t)ni * nf;
   for (int i = i0; i < i0 + 16 && i < nf; ++i) {
     if (i < ni) {
-      for (int j = threadIdx.x; j < nf; j += 256) dv[(size_t)i * nf + j] = j < ni ? A[(size_t)i * nf + j] : -A[(size_t)i * nf + j];
+      for (int j = threadIdx.x; j < nf; j += 256) dv[(size_t)i * nf + j] = fc_pack<VT>(j < ni ? A[(size_t)i * nf + j] : -A[(size_t)i * nf + j]);
     } else {
-      for (int j = threadIdx.x; j < ni; j += 256) mw[(size_t)(i - ni) * ni + j] = A[(size_t)i * nf + j];
+      for (int j = threadIdx.x; j < ni; j += 256) mw[(size_t)(i - ni) * ni + j] = fc_pack<VT>(A[(size_t)i * nf + j]);
     }
   }
 }

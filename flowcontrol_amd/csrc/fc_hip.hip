@@ -104,6 +104,9 @@ struct OrderSys {
   DevBuf<FcBlk> blk;
   DevBuf<int> f_idx;
   DevBuf<double> f_val;
+  DevBuf<float> f_val32;    // compressed factors (fc_set_factor_precision): the values rounded once to fp32 ...
+  DevBuf<FcBf16> f_val16;   // ... or to bfloat16; f_val is then not allocated
+  int bits = 64;            // storage width of this slot's factor values
   int64_t f_nnz = 0;
   DevBuf<double> dscale;  // kind-2 stages (fc_set_stage_diag), permuted numbering
   bool truncated = false;  // the factors are a preconditioner only (some pivot blocks replaced by a diagonal)
@@ -164,6 +167,7 @@ struct fc_ctx {
   bool step_pending = false;  // fc_step_begin without its fc_step_end
   int pend_slot = 0, pend_energy = 0;
   double pend_seq = 0.0;
+  int factor_bits = 64;       // fc_set_factor_precision: storage width of the factor values laid out from now on (64 exact, 32 / 16 compressed)
   int pin_dof = -1;           // fc_set_pressure_pin: pressure dof whose diagonal is shifted inside the factorisation
   double pin_shift = 1.0;
   int64_t sym_local_values[2] = {0, 0};  // factor values this rank sweeps per solve, per slot
@@ -465,6 +469,45 @@ int launch_sweep(fc_ctx* h, const OrderSys& S, const Stage& st) {
     if (S.dscale.n != (size_t)h->N) return fail(FC_ERR_NOT_READY, "fc_set_stage_diag not called for a truncated factorisation");
     hipLaunchKernelGGL(fc_diag_stage, dim3(nblocks(st.nrows, 256)), dim3(256), 0, h->stream, st.nrows, S.dscale.p + st.row0, h->buf.p + st.row0,
                        h->buf.p + h->N + st.row0);
+    HIPCHK(hipGetLastError());
+    return FC_OK;
+  }
+  if (S.bits != 64) {
+    // compressed factors: a reduced set of launch geometries (any geometry is correct for any row; this is the memory-lean
+    // path, not the fast one), values widened to fp64 as they are loaded
+    const bool f32 = S.bits == 32;
+    if (st.kind == 1 && st.blk_count > 0) {
+      const FcBlk* bp = S.blk.p + st.blk_begin;
+      const int lpr = st.blk_lpr <= 16 ? 16 : (st.blk_lpr <= 32 ? 32 : 64);
+#define FC_BLOCK_LP(L, R)                                                                                                                    \
+  do {                                                                                                                                         \
+    if (f32)                                                                                                                                   \
+      hipLaunchKernelGGL((fc_nd_down_block<L, R, float>), dim3(st.blk_count), dim3(256), 0, h->stream, bp, S.f_idx.p, S.f_val32.p, h->buf.p, h->N); \
+    else                                                                                                                                       \
+      hipLaunchKernelGGL((fc_nd_down_block<L, R, FcBf16>), dim3(st.blk_count), dim3(256), 0, h->stream, bp, S.f_idx.p, S.f_val16.p, h->buf.p, h->N); \
+  } while (0)
+      if (lpr == 16) FC_BLOCK_LP(16, 2);
+      else if (lpr == 32) FC_BLOCK_LP(32, 4);
+      else FC_BLOCK_LP(64, 8);
+#undef FC_BLOCK_LP
+      HIPCHK(hipGetLastError());
+      return FC_OK;
+    }
+    const int lanes = st.lanes <= 16 ? 16 : (st.lanes <= 64 ? 64 : 256), sub = lanes == 16 ? 4 : (lanes == 64 ? 16 : 64);
+    dim3 grid(nblocks(st.nrows, 256 / lanes)), block(256);
+    const int64_t* rp = S.seg_ptr.p + st.rp_begin;
+    const int dest0 = st.kind == 0 ? st.row0 : h->N + st.row0, acc = st.kind == 0 ? 1 : 0;
+#define FC_SWEEP_LP(L, SB)                                                                                                                  \
+  do {                                                                                                                                        \
+    if (f32)                                                                                                                                  \
+      hipLaunchKernelGGL((fc_nd_sweep<L, SB, float>), grid, block, 0, h->stream, st.nrows, rp, S.seg.p, S.f_idx.p, S.f_val32.p, h->buf.p, dest0, acc); \
+    else                                                                                                                                      \
+      hipLaunchKernelGGL((fc_nd_sweep<L, SB, FcBf16>), grid, block, 0, h->stream, st.nrows, rp, S.seg.p, S.f_idx.p, S.f_val16.p, h->buf.p, dest0, acc); \
+  } while (0)
+    if (lanes == 16) FC_SWEEP_LP(16, 4);
+    else if (lanes == 64) FC_SWEEP_LP(64, 16);
+    else FC_SWEEP_LP(256, 64);
+#undef FC_SWEEP_LP
     HIPCHK(hipGetLastError());
     return FC_OK;
   }
@@ -1790,11 +1833,25 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
   else FCCHK(S.f_idx.alloc(1));
   // 64 zero values behind the last block: the batched block kernel (fc_nd_block_b) reads value pairs in groups of 8
   // columns and may touch up to 7 values past the end of a row (they meet zero operand rows)
-  FCCHK(S.f_val.alloc((size_t)n_val + 64));
-  FCCHK(S.f_val.zero(h->stream));
-  if (vals) HIPCHK(hipMemcpyAsync(S.f_val.p, vals, (size_t)n_val * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  S.bits = h->factor_bits;
+  S.f_val.release(), S.f_val32.release(), S.f_val16.release();
+  if (S.bits == 64) {
+    FCCHK(S.f_val.alloc((size_t)n_val + 64));
+    FCCHK(S.f_val.zero(h->stream));
+    if (vals) HIPCHK(hipMemcpyAsync(S.f_val.p, vals, (size_t)n_val * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  } else {
+    // compressed factors: only the rounded values are ever stored (fc_fe_export writes them straight from the fronts)
+    if (vals) return fail(FC_ERR_INVALID, "fc_solver_setup: host-supplied factor values need 64-bit storage (fc_set_factor_precision)");
+    if (S.bits == 32) {
+      FCCHK(S.f_val32.alloc((size_t)n_val + 64));
+      HIPCHK(hipMemsetAsync(S.f_val32.p, 0, S.f_val32.n * sizeof(float), h->stream));
+    } else {
+      FCCHK(S.f_val16.alloc((size_t)n_val + 64));
+      HIPCHK(hipMemsetAsync(S.f_val16.p, 0, S.f_val16.n * sizeof(FcBf16), h->stream));
+    }
+  }
   HIPCHK(hipStreamSynchronize(h->stream));
-  S.truncated = false;
+  S.truncated = S.bits != 64;  // compressed factors are a preconditioner, like truncated ones
   for (const Stage& st : S.stages) S.truncated = S.truncated || st.kind == 2;
   S.ready = true;
   S.structured = true;
@@ -1872,7 +1929,7 @@ int fc_solver_set_dag(fc_handle h, int slot, int32_t n_nodes, const int64_t* nod
   if (!S.structured) return fail(FC_ERR_NOT_READY, "fc_solver_setup must be called first");
   HIPCHK(hipSetDevice(h->device));
   S.dag_ready = false;
-  if (S.truncated) return FC_OK;  // truncated (preconditioner-only) factors are applied with the level launches
+  if (S.truncated) return FC_OK;  // truncated / compressed (preconditioner-only) factors are applied with the level launches
   const int N = h->N;
   const int64_t n_idx = (int64_t)S.f_idx.n, n_val = S.f_nnz;
   struct Nd {
@@ -2324,11 +2381,16 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
           hipLaunchKernelGGL(fc_fe_update<FC_FE_KB>, dim3(ct * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
         }
       }
-      hipLaunchKernelGGL(fc_fe_export, dim3((nfmax + 15) / 16, grp.second), dim3(256), 0, h->stream, fp, F, fv);
+      if (S.bits == 64)
+        hipLaunchKernelGGL(fc_fe_export<double>, dim3((nfmax + 15) / 16, grp.second), dim3(256), 0, h->stream, fp, F, fv);
+      else if (S.bits == 32)
+        hipLaunchKernelGGL(fc_fe_export<float>, dim3((nfmax + 15) / 16, grp.second), dim3(256), 0, h->stream, fp, F, S.f_val32.p);
+      else
+        hipLaunchKernelGGL(fc_fe_export<FcBf16>, dim3((nfmax + 15) / 16, grp.second), dim3(256), 0, h->stream, fp, F, S.f_val16.p);
       HIPCHK(hipGetLastError());
     }
   }
-  if (S.dag_ready)  // row-by-row copy of the -L values for the one-launch apply
+  if (S.dag_ready && S.bits == 64)  // row-by-row copy of the -L values for the one-launch apply
     hipLaunchKernelGGL(fc_gather64_pad, dim3(nblocks(S.dag_up_n + 1, 256)), dim3(256), 0, h->stream, S.dag_up_n + 1, S.dag_up_src.p, fv,
                        S.dag_up_val.p);
   HIPCHK(hipEventRecord(h->ev1, h->stream));
@@ -2520,6 +2582,21 @@ int fc_setup_solver(fc_handle h, int slot, int32_t depth, int32_t merge, int32_t
   // end-to-end acceptance of the new factors: one solve with a fixed right-hand side, residual against the matrix itself
   // (partitioned: the probe is a collective, every rank calls fc_setup_solver; truncated factors are a preconditioner:
   // nothing to probe)
+  if (truncate == 0 && h->sys[slot].bits != 64) {
+    // compressed factors: the acceptance solve goes through GMRES (they are a preconditioner): it must converge in a
+    // handful of iterations, or the rounded factors are no good for this operator
+    if (world > 1) return fail(FC_ERR_INVALID, "fc_setup_solver: compressed factors need a single-GPU handle");
+    std::vector<double> b((size_t)N), x((size_t)N);
+    for (int i = 0; i < N; ++i) b[i] = std::cos(0.37 * i + 0.1);
+    if (h->pin_dof >= 0)
+      for (int i = 2 * h->nn; i < N; ++i) b[i] = 0.0;
+    double info[4];
+    FCCHK(fc_set_solver_options(h, FC_METHOD_GMRES, 60, 1e-10, 1));
+    FCCHK(fc_solve(h, slot, b.data(), x.data(), info));
+    if (!(info[1] < 1e-8) || info[0] > 40)
+      return fail(FC_ERR_HIP, "fc_setup_solver: GMRES on the compressed factors needed " + std::to_string((int)info[0]) + " iterations (residual " + std::to_string(info[1]) + ")");
+    return FC_OK;  // the caller chooses the Krylov method and its tolerances (fc_set_solver_options)
+  }
   if (truncate == 0 && (world == 1 ? !h->partitioned : exchanges(h))) {
     std::vector<double> b((size_t)N), x((size_t)N);
     for (int i = 0; i < N; ++i) b[i] = std::cos(0.37 * i + 0.1);
@@ -2744,6 +2821,24 @@ int fc_get_factor_values(fc_handle h, int slot, int64_t n, double* out) {
   OrderSys& S = h->sys[slot];
   if (!S.structured) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this slot");
   if (n != S.f_nnz) return fail(FC_ERR_INVALID, "fc_get_factor_values: size differs from the uploaded factors");
+  if (S.bits != 64) {  // compressed factors: widened back to fp64 on the host
+    HIPCHK(hipSetDevice(h->device));
+    if (S.bits == 32) {
+      std::vector<float> tmp((size_t)n);
+      HIPCHK(hipMemcpy(tmp.data(), S.f_val32.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < n; ++i) out[i] = (double)tmp[(size_t)i];
+    } else {
+      std::vector<unsigned short> tmp((size_t)n);
+      HIPCHK(hipMemcpy(tmp.data(), S.f_val16.p, (size_t)n * sizeof(unsigned short), hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < n; ++i) {
+        const uint32_t u = (uint32_t)tmp[(size_t)i] << 16;
+        float f;
+        std::memcpy(&f, &u, sizeof f);
+        out[i] = (double)f;
+      }
+    }
+    return FC_OK;
+  }
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipMemcpyAsync(out, S.f_val.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -3363,6 +3458,27 @@ int fc_algorithmic_bytes(fc_handle h, int slot, double* sweep_bytes, double* spm
   return FC_OK;
 }
 
+// storage width of the factor values of every slot set up from now on: 64 = exact selected inverse (default), 32 / 16 =
+// COMPRESSED factors (fp32 / bfloat16: 50 % / 25 % of the memory; never materialised in fp64).  Compressed factors are a
+// preconditioner: fc_solve / fc_step then need FC_METHOD_GMRES or FC_METHOD_BICGSTAB.
+int fc_set_factor_precision(fc_handle h, int bits) {
+  if (!h || (bits != 64 && bits != 32 && bits != 16)) return fail(FC_ERR_INVALID, "fc_set_factor_precision: bits must be 64, 32 or 16");
+  if (bits != h->factor_bits) {
+    h->factor_bits = bits;
+    for (int o = 0; o < 2; ++o) h->sys[o].ready = h->sys[o].structured = h->sys[o].dag_ready = false;  // the value arrays are laid out anew
+    h->bat.ftile_ok[0] = h->bat.ftile_ok[1] = false;
+  }
+  return FC_OK;
+}
+
+int fc_get_factor_storage(fc_handle h, int slot, int32_t* bits, int64_t* bytes) {
+  if (!h || slot < 0 || slot > 1) return fail(FC_ERR_INVALID, "fc_get_factor_storage: bad argument");
+  const OrderSys& S = h->sys[slot];
+  if (bits) *bits = S.bits;
+  if (bytes) *bytes = (int64_t)(S.f_val.n * sizeof(double) + S.f_val32.n * sizeof(float) + S.f_val16.n * sizeof(FcBf16));
+  return FC_OK;
+}
+
 // ── base-flow (steady-state) iterations behind the C ABI: SteadyStateSolver.picard / .newton (steadystate.py:60-159) ──────
 // Every iteration assembles its operator with the HIP element loop, eliminates the Dirichlet dofs, factorises on the device
 // and solves with the sweep kernels; the host side here only forms the residual and the update (vectors cross the
@@ -3649,7 +3765,7 @@ static int batch_repack(fc_ctx* h, int slot) {
   fc_ctx::Batch& B = h->bat;
   if (!B.tables || B.tasks.n == 0) return FC_OK;
   OrderSys& S = h->sys[slot];
-  if (!S.structured || S.f_val.n == 0) return FC_OK;
+  if (!S.structured || S.f_val.n == 0 || S.bits != 64) return FC_OK;  // batched steps apply exact (fp64) factors
   if (B.ftile[slot].n != (size_t)B.tiled_values) FCCHK(B.ftile[slot].alloc((size_t)B.tiled_values));
   hipLaunchKernelGGL(fc_b_repack, dim3((unsigned)B.tasks.n), dim3(256), 0, h->stream, B.tasks.p, S.f_val.p, B.ftile[slot].p);
   HIPCHK(hipGetLastError());

@@ -361,6 +361,32 @@ __global__ __launch_bounds__(256) void fc_spmv_csr(int nrows, const int* __restr
 // Rows of one level never read what the same launch writes, so a level is one launch.
 // Values stream at 8 B/nnz; column information is O(1/len) bytes per value.
 // ---------------------------------------------------------------------------------------------
+// Storage type of the factor values.  double: the exact selected inverse (applied directly).  float / FcBf16 (bfloat16: the
+// upper 16 bits of a float, full fp32 range): COMPRESSED factors at 50 % / 25 % of the memory — rounded once after the fp64
+// elimination, accumulated in fp64 — which are a preconditioner for the device Krylov solvers (GMRES: 2 / ~9 iterations to
+// 1e-12 on the cylinder operator).
+struct FcBf16 {
+  unsigned short u;
+};
+__device__ __forceinline__ double fc_val(double v) { return v; }
+__device__ __forceinline__ double fc_val(float v) { return (double)v; }
+__device__ __forceinline__ double fc_val(FcBf16 v) { return (double)__uint_as_float((unsigned)v.u << 16); }
+template <typename VT>
+__device__ __forceinline__ VT fc_pack(double v);
+template <>
+__device__ __forceinline__ double fc_pack<double>(double v) {
+  return v;
+}
+template <>
+__device__ __forceinline__ float fc_pack<float>(double v) {
+  return (float)v;
+}
+template <>
+__device__ __forceinline__ FcBf16 fc_pack<FcBf16>(double v) {
+  const unsigned b = __float_as_uint((float)v);
+  return FcBf16{(unsigned short)((b + 0x7FFFu + ((b >> 16) & 1u)) >> 16)};  // round to nearest even
+}
+
 struct __attribute__((aligned(16))) FcSeg {
   long long val;  // offset of the first value
   int col;        // >= 0: first buffer index; < 0: -(offset into idx) - 1
@@ -372,11 +398,11 @@ struct __attribute__((aligned(16))) FcSeg {
 // of SUB lanes each take every (LANES/SUB)-th segment, so several segments of the row are in flight
 // at once: a row is a *chain* of short dense slices and one slice per memory round trip would leave
 // the launch latency-bound (bytes in flight = rows x slice length) far below the HBM rate.
-template <int LANES, int SUB>
+template <int LANES, int SUB, typename VT = double>
 __global__ __launch_bounds__(256) void fc_nd_sweep(int nrows, const int64_t* __restrict__ seg_ptr,
                                                    const FcSeg* __restrict__ seg,
                                                    const int* __restrict__ idx,
-                                                   const double* __restrict__ val,
+                                                   const VT* __restrict__ val,
                                                    double* __restrict__ buf, int dest0, int accumulate) {
   constexpr int RPB = 256 / LANES;
   constexpr int SW = LANES < 64 ? LANES : 64;  // shuffle width (descriptor broadcast, reduction)
@@ -403,14 +429,15 @@ __global__ __launch_bounds__(256) void fc_nd_sweep(int nrows, const int64_t* __r
       const int c = __shfl(mine.col, src, SW);
       int len = __shfl(mine.len, src, SW);
       if (sidx >= cnt) len = 0;  // this sub-group has no segment in the last round
-      const double* __restrict__ v = val + vo;
+      const VT* __restrict__ v = val + vo;
+      const VT vz = fc_pack<VT>(0.0);
       if (c >= 0) {
         const double* __restrict__ x = buf + c;
         // predicated 4-deep issue: all eight loads of a trip are in flight before the first FMA
         for (int base = 0; base < len; base += 4 * SUB) {
           const int j0 = base + l2, j1 = j0 + SUB, j2 = j1 + SUB, j3 = j2 + SUB;
-          const double v0 = j0 < len ? v[j0] : 0.0, v1 = j1 < len ? v[j1] : 0.0;
-          const double v2 = j2 < len ? v[j2] : 0.0, v3 = j3 < len ? v[j3] : 0.0;
+          const double v0 = fc_val(j0 < len ? v[j0] : vz), v1 = fc_val(j1 < len ? v[j1] : vz);
+          const double v2 = fc_val(j2 < len ? v[j2] : vz), v3 = fc_val(j3 < len ? v[j3] : vz);
           const double x0 = j0 < len ? x[j0] : 0.0, x1 = j1 < len ? x[j1] : 0.0;
           const double x2 = j2 < len ? x[j2] : 0.0, x3 = j3 < len ? x[j3] : 0.0;
           s0 += v0 * x0;
@@ -424,8 +451,8 @@ __global__ __launch_bounds__(256) void fc_nd_sweep(int nrows, const int64_t* __r
           const int j0 = base + l2, j1 = j0 + SUB, j2 = j1 + SUB, j3 = j2 + SUB;
           const int i0 = j0 < len ? ix[j0] : 0, i1 = j1 < len ? ix[j1] : 0;
           const int i2 = j2 < len ? ix[j2] : 0, i3 = j3 < len ? ix[j3] : 0;
-          const double v0 = j0 < len ? v[j0] : 0.0, v1 = j1 < len ? v[j1] : 0.0;
-          const double v2 = j2 < len ? v[j2] : 0.0, v3 = j3 < len ? v[j3] : 0.0;
+          const double v0 = fc_val(j0 < len ? v[j0] : vz), v1 = fc_val(j1 < len ? v[j1] : vz);
+          const double v2 = fc_val(j2 < len ? v[j2] : vz), v3 = fc_val(j3 < len ? v[j3] : vz);
           s0 += v0 * buf[i0];
           s1 += v1 * buf[i1];
           s2 += v2 * buf[i2];
@@ -477,10 +504,10 @@ struct __attribute__((aligned(16))) FcBlk {
 // issued BEFORE the operand gather: descriptor -> {values | index list -> operand} is a chain of
 // three memory round trips instead of five (descriptor, indices, operand, LDS, values).  On the
 // small nodes near the leaves (row width <= 4 x LPR) that first trip is the whole row.
-template <int LPR, int RPS>
+template <int LPR, int RPS, typename VT = double>
 __global__ __launch_bounds__(256) void fc_nd_down_block(const FcBlk* __restrict__ blk,
                                                         const int* __restrict__ idxlist,
-                                                        const double* __restrict__ val,
+                                                        const VT* __restrict__ val,
                                                         double* __restrict__ buf, int N) {
   __shared__ double xs[FC_BLK_TILE];
   constexpr int SLOTS = 256 / LPR;  // rows in flight per workgroup
@@ -493,11 +520,11 @@ __global__ __launch_bounds__(256) void fc_nd_down_block(const FcBlk* __restrict_
   for (int k = 0; k < RPS; ++k) {
     acc[k] = 0.0;
     const int r = slot + k * SLOTS;
-    const double* __restrict__ v = val + b.val + (long long)r * wd;
+    const VT* __restrict__ v = val + b.val + (long long)r * wd;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int j = l + u * LPR;
-      pv[k][u] = (r < b.nrows && j < tl0) ? v[j] : 0.0;
+      pv[k][u] = (r < b.nrows && j < tl0) ? fc_val(v[j]) : 0.0;
     }
   }
   for (int t0 = 0; t0 < wd; t0 += FC_BLK_TILE) {
@@ -511,7 +538,7 @@ __global__ __launch_bounds__(256) void fc_nd_down_block(const FcBlk* __restrict_
     for (int k = 0; k < RPS; ++k) {
       const int r = slot + k * SLOTS;
       if (r < b.nrows) {
-        const double* __restrict__ v = val + b.val + (long long)r * wd + t0;
+        const VT* __restrict__ v = val + b.val + (long long)r * wd + t0;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         int base = 0;
         if (t0 == 0) {
@@ -524,8 +551,8 @@ __global__ __launch_bounds__(256) void fc_nd_down_block(const FcBlk* __restrict_
         }
         for (; base < tl; base += 4 * LPR) {
           const int j0 = base + l, j1 = j0 + LPR, j2 = j1 + LPR, j3 = j2 + LPR;
-          const double v0 = j0 < tl ? v[j0] : 0.0, v1 = j1 < tl ? v[j1] : 0.0;
-          const double v2 = j2 < tl ? v[j2] : 0.0, v3 = j3 < tl ? v[j3] : 0.0;
+          const double v0 = j0 < tl ? fc_val(v[j0]) : 0.0, v1 = j1 < tl ? fc_val(v[j1]) : 0.0;
+          const double v2 = j2 < tl ? fc_val(v[j2]) : 0.0, v3 = j3 < tl ? fc_val(v[j3]) : 0.0;
           s0 += v0 * (j0 < tl ? xs[j0] : 0.0);
           s1 += v1 * (j1 < tl ? xs[j1] : 0.0);
           s2 += v2 * (j2 < tl ? xs[j2] : 0.0);

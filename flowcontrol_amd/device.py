@@ -359,6 +359,22 @@ class DeviceSolver:
             assert np.array_equal(self._tree.perm, self.perm)
         return self._tree
 
+    def set_factor_precision(self, bits: int) -> None:
+        """Storage width of the factor values of every slot set up from now on: 64 = exact selected inverse (default), 32 / 16
+        = compressed factors (fp32 / bfloat16, 50 % / 25 % of the memory; a preconditioner for ``method="gmres" | "bicgstab"``)."""
+        if int(bits) != 64 and self.py_symbolic:
+            raise ValueError("compressed factors are laid out by the in-library analysis (unset FC_PY_SYMBOLIC)")
+        if int(bits) != getattr(self, "_factor_bits", 64):
+            self._structured.clear()
+        check(self.lib.fc_set_factor_precision(self._h, int(bits)))
+        self._factor_bits = int(bits)
+
+    def factor_storage(self, slot: int) -> tuple[int, int]:
+        """(bits per factor value, bytes of factor values held) of ``slot``."""
+        bits, nbytes = C.c_int32(), C.c_int64()
+        check(self.lib.fc_get_factor_storage(self._h, slot, C.byref(bits), C.byref(nbytes)))
+        return bits.value, nbytes.value
+
     def set_pressure_pin(self, dof: int | None, shift: float = 1.0) -> None:
         """Enclosed flows (velocity prescribed on the whole boundary): the monolithic matrix is singular, the
         pressure being defined up to a constant.  A positive shift on the diagonal of ONE pressure dof inside

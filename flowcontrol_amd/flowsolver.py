@@ -82,6 +82,10 @@ class FlowSolver(ABC):
         #: memory-lean mode: factorise only the tree levels >= nd_truncate and solve every step with a Krylov method
         #: preconditioned by those truncated factors (0 = full selected inverse, applied directly)
         self.nd_truncate: int = 0
+        #: compressed factors: 64 = exact selected inverse applied directly (default); 32 / 16 = the factor values are stored in
+        #: fp32 / bfloat16 (50 % / 25 % of the memory) and every step is solved by the device GMRES / BiCGStab preconditioned
+        #: with them (a few iterations)
+        self.factor_bits: int = 64
         self.krylov_method: str = "gmres"
         self.krylov_max_iter: int = 500
         self.krylov_rtol: float = 1e-12
@@ -462,6 +466,7 @@ class FlowSolver(ABC):
         dofs, prof = self._bc_tables()
         dev.set_bc(dofs, prof)
         dev.set_pressure_pin(pressure_pin(self.th, dofs))  # enclosed flows only (lid-driven cavity)
+        dev.set_factor_precision(self.factor_bits)
         dev.set_force(self._force_tables())
         dev.set_sensors([s.row(self) for s in self.params_control.sensor_list])
         dev.set_time_scheme(self.params_time.dt, self.params_solver.is_eq_nonlinear)
@@ -850,7 +855,7 @@ class _DeviceNDSolver:
             vals[pos[~bad]] = M.data[~bad]
             dev.set_matrix_values(self.slot, vals)
         dev.setup_solver(self.slot, depth=fs.nd_depth, refine=fs.refine_steps, truncate=fs.nd_truncate)
-        if fs.nd_truncate:
+        if fs.nd_truncate or fs.factor_bits != 64:
             dev.set_solver_options(refine=fs.krylov_max_iter, method=fs.krylov_method, rtol=fs.krylov_rtol)
 
     def solve(self, x: np.ndarray, b: np.ndarray) -> None:

@@ -120,6 +120,14 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
                     /* and the rows x[ar_row0 .. +ar_n) after stage `ar2_stage` (-1: none): the root's down stage, in which
                      * every rank fills its own block of the root's rows (the others are zeroed before the launch) */
                     int32_t ar2_stage);
+/* COMPRESSED factors, the memory-lean Krylov mode (reference plug-in point flowsolver.py:812-814; north_star: "HIP
+ * BiCGStab/GMRES ... preconditioning"): the selected inverse is computed in fp64 front by front as always, but its values are
+ * STORED rounded to fp32 (bits = 32: 50 % of the memory) or bfloat16 (bits = 16: 25 %) — the fp64 array never exists — and
+ * applied with fp64 accumulation as right preconditioner of the device GMRES / BiCGStab (cylinder operator: 2 / ~9 GMRES
+ * iterations to 1e-12).  Call before fc_setup_solver; a change lays the slots out anew.  fc_setup_solver then accepts the
+ * factors through a GMRES probe (<= 40 iterations); fc_solve / fc_step need FC_METHOD_GMRES or FC_METHOD_BICGSTAB. */
+int fc_set_factor_precision(fc_handle h, int bits /* 64 (default, exact), 32, 16 */);
+int fc_get_factor_storage(fc_handle h, int slot, int32_t* bits, int64_t* bytes /* bytes of factor values held for the slot */);
 /* Truncated factors (memory-lean preconditioner): stages of kind 2 stand for tree levels whose pivot blocks are NOT
  * stored; on their rows x = dscale * y (dscale [N], permuted numbering: a diagonal stand-in for the Schur complement).
  * Such a slot is a preconditioner only: fc_solve / fc_step need FC_METHOD_GMRES or FC_METHOD_BICGSTAB. */

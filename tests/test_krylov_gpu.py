@@ -98,3 +98,48 @@ def test_time_steps_with_truncated_factors(method, tmp_path_factory, golden_dir)
     assert np.linalg.norm(ts["dE"].to_numpy() - g["ol_dE"][:7]) <= 1e-8 * np.linalg.norm(g["ol_dE"][:7])
     print(f"[truncated factors, {method}] stored factor values {dev._n_factor_values} of {full}; iterations per step {its}")
     fs.th.release_device()
+
+
+@pytest.mark.parametrize("case,bits", [("cylinder", 16), ("cylinder", 32), ("cavity", 16)])
+def test_time_steps_with_compressed_factors(case, bits, tmp_path_factory, golden_dir):
+    """The Krylov mode that works without the full fp64 factorisation: the selected inverse is stored in bfloat16 (25 % of
+    the factor memory) or fp32 (50 %) — the fp64 values never exist on the device — and every step is solved by the device
+    GMRES right-preconditioned with those compressed factors.  O1 (cylinder) and cavity_coarse must follow the oracle's
+    series to 1e-8 at a handful of iterations per step (bar: <= 40)."""
+    from flowcontrol_amd._lib import SLOT_BDF2
+    from flowcontrol_amd.fem.spaces import Function
+    from flowcontrol_amd.flowsolverparameters import ParamIC
+
+    if case == "cylinder":
+        from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver as Case
+
+        g = np.load(golden_dir / "cylinder_O1.npz")
+        fs = Case.make_default(Re=100, path_out=tmp_path_factory.mktemp(f"lp_{case}_{bits}"), num_steps=10)
+        fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
+        y_ref, dE_ref, u = g["ol_y"][:11], g["ol_dE"][:11], [0.0, 0.0]
+    else:
+        from flowcontrol_amd.examples.cavity.cavityflowsolver import CavityFlowSolver as Case
+
+        g = np.load(golden_dir / "cavity_coarse.npz")
+        fs = Case.make_default(Re=7500, path_out=tmp_path_factory.mktemp(f"lp_{case}_{bits}"), num_steps=10)
+        y_ref, dE_ref, u = g["y"][:11], g["dE"][:11], [0.0]
+    fs.factor_bits, fs.krylov_method, fs.krylov_max_iter, fs.krylov_rtol = bits, "gmres", 60, 1e-12
+    U0, P0 = Function(fs.W, g["UP0"]).split()
+    fs._assign_steady_state(U0, P0)
+    fs.initialize_time_stepping(ic=None)
+    its = []
+    for _ in range(10):
+        fs.step(u)
+        assert fs.solve_info[1] < 1e-10  # the tail's residual monitor checks the Krylov result against the fp64 operator
+        its.append(int(fs.solve_info[0]))
+    assert 1 <= max(its) <= 40, its
+    dev = fs.th.device()
+    got_bits, nbytes = dev.factor_storage(SLOT_BDF2)
+    values = dev._n_factor_values
+    assert got_bits == bits and nbytes <= (bits / 64.0) * 8.0 * values + 1024  # 25 % / 50 % of the fp64 factor bytes
+    ts = fs.timeseries
+    y = ts[[c for c in ts.columns if c.startswith("y_meas_")]].to_numpy()
+    assert np.linalg.norm(y - y_ref) <= 1e-8 * np.linalg.norm(y_ref)
+    assert np.linalg.norm(ts["dE"].to_numpy() - dE_ref) <= 1e-8 * np.linalg.norm(dE_ref)
+    print(f"[compressed factors, {case}, {bits} bit] {nbytes / 1e6:.1f} MB of factor values ({values} values); GMRES iterations per step {its}")
+    fs.th.release_device()
