@@ -57,22 +57,24 @@ def refined_mesh_file(levels: int) -> Path:
     return refined_cylinder_mesh(levels)
 
 
-def build_solver(device: int, distributed: bool = False):
+def build_solver(device: int, distributed: bool = False, refine: int | None = None):
     from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver
     from flowcontrol_amd.fem.spaces import Function
     from flowcontrol_amd.flowsolverparameters import ParamIC
 
-    meshpath = refined_mesh_file(REFINE) if REFINE else None
+    refine = REFINE if refine is None else refine
+    meshpath = refined_mesh_file(refine) if refine else None
     fs = CylinderFlowSolver.make_default(Re=100, path_out=tempfile.mkdtemp(prefix="fc_bench_"), num_steps=0, save_every=0, meshpath=meshpath)
     fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
     fs.distributed = distributed
     fs.th.device(device)
-    if REFINE:
-        # no golden base flow for the refined mesh: compute it as the reference's scripts do (setup, untimed)
+    golden = {0: "cylinder_O1.npz", 1: "cylinder_O1_refined1.npz"}.get(refine)
+    if golden is None:
+        # no golden base flow for this mesh: compute it as the reference's scripts do (setup, untimed)
         fs.compute_steady_state(method="picard", max_iter=3, tol=1e-7, u_ctrl=[0.0, 0.0])
         fs.compute_steady_state(method="newton", max_iter=25, u_ctrl=[0.0, 0.0], initial_guess=fs.fields.UP0)
     else:
-        up0 = np.load(GOLDEN / "cylinder_O1.npz")["UP0"]
+        up0 = np.load(GOLDEN / golden)["UP0"]  # the oracle's base flow (tests/golden/make_*_fixtures.py)
         U0, P0 = Function(fs.W, up0).split()
         fs._assign_steady_state(U0, P0)
     fs.initialize_time_stepping(ic=None)
@@ -234,6 +236,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-spmv", action="store_true")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent replicas instead of the partitioned run")
+    ap.add_argument("--no-extras", action="store_true", help="skip rank 0's single-GPU extras (roofline replay, SpMV probe, batched replicas, CPU baseline)")
+    ap.add_argument("--no-config4", action="store_true", help="N > 1: skip the strong-scaling run on the BASELINE config-4 mesh (O1 refined once)")
     ap.add_argument("--refine", type=int, default=0, help="red-refine the O1 mesh K times (BASELINE config 4: K=1); not the headline workload")
     args = ap.parse_args()
     global REFINE
@@ -285,16 +289,59 @@ def main() -> None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     y_last = fs.y_meas.copy()
+    mesh_nc, mesh_N, resid_last = fs.th.nc, fs.th.N, float(fs.solve_info[1])
 
+    config4 = None
     if partitioned:
         # collective-free extras below run on rank 0 only with a private single-GPU solver
+        comm = fs.th.device().comm_info()
         part_info = {"local_cells": int(fs.th.device().part.local_cells.size), "root_dofs": int(fs.th.device().part.ar_n),
                      "local_factor_nnz": int(fs.th.device().local_factor_nnz),  # factor values this rank sweeps per solve
                      "stored_factor_nnz": int(fs.th.device()._n_factor_values),  # ... and stores: its sub-tree + the root block
-                     "exchanges_per_step": 3}
+                     "exchanges_per_step": 3,
+                     # read back from the communicator inside the library (ncclCommCount / ncclCommUserRank), not from the environment
+                     "rccl_ranks": comm["nranks"] if comm["transport"] == "rccl" else None, "exchange_transport": comm["transport"]}
         dist.barrier()
-        if rank == 0:
+        if not args.no_config4 and REFINE == 0:
+            # the mesh the row partition is meant for (BASELINE config 4: O1 red-refined once, 222 962 dofs): same protocol,
+            # fewer steps; the headline line stays the O1 figure BASELINE.json's metric names
             fs.th.release_device()
+            steps4 = max(20, min(args.steps, 300))
+            fs4 = build_solver(local, distributed=True, refine=1)
+            fs4.step(u0)
+            for _ in range(10):
+                fs4.step(u0)
+            barrier()
+            t4 = time.perf_counter()
+            for _ in range(steps4):
+                fs4.step(u0)
+            barrier()
+            e4 = torch.tensor([time.perf_counter() - t4], dtype=torch.float64, device="cpu" if same_dev else "cuda")
+            dist.all_reduce(e4, op=dist.ReduceOp.MAX)
+            dev4 = fs4.th.device()
+            config4 = {"workload": f"cylinder Re=100, mesh O1 red-refined x1 ({fs4.th.nc} cells, {fs4.th.N} dofs), same protocol", "steps": steps4,
+                       "steps_per_s": steps4 / float(e4.item()), "scaling": "strong", "n_gpus": world,
+                       "partition": {"local_cells": int(dev4.part.local_cells.size), "root_dofs": int(dev4.part.ar_n),
+                                     "local_factor_nnz": int(dev4.local_factor_nnz), "stored_factor_nnz": int(dev4._n_factor_values)},
+                       "y_last": fs4.y_meas.tolist(), "residual": float(fs4.solve_info[1])}
+            fs4.th.release_device()
+            dist.barrier()
+            if rank == 0 and not args.no_extras:
+                fs4 = build_solver(local, distributed=False, refine=1)
+                fs4.step(u0)
+                for _ in range(10):
+                    fs4.step(u0)
+                t4 = time.perf_counter()
+                for _ in range(steps4):
+                    fs4.step(u0)
+                config4["single_gpu_steps_per_s"] = steps4 / (time.perf_counter() - t4)
+                fs4.th.release_device()
+            fs = None
+        if rank == 0 and args.no_extras:
+            single_rate = None
+        elif rank == 0:
+            if fs is not None:
+                fs.th.release_device()
             fs = build_solver(local, distributed=False)
             fs.step(u0)
             for _ in range(20):
@@ -307,7 +354,10 @@ def main() -> None:
         part_info, single_rate = None, None
 
     result = None
-    if rank == 0:
+    roofline = phases = spmv = cpu = replicas = None
+    t_batched = None
+    depth_str = None
+    if rank == 0 and not args.no_extras:
         from flowcontrol_amd._lib import SLOT_BDF2
 
         dev = fs.th.device()
@@ -358,6 +408,8 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(fs)
             cpu.pop("_y_last"), cpu.pop("_dE_last")
+        depth_str = f"ND selected-inverse depth {dev.depth}, {fs.refine_steps} refinement"
+    if rank == 0:
         value = (1 if partitioned else world) * args.steps / elapsed
         result = {
             "metric": "timesteps/s (cylinder Re=100, fixed mesh)",
@@ -374,24 +426,25 @@ def main() -> None:
             "data": "the reference's shipped mesh O1 (converted data file) + base flow computed by the oracle (golden fixture); "
                     "IC and actuation as run_cylinder_example.py",
             "config": {
-                "workload": f"cylinder Re=100, mesh O1{' red-refined x' + str(REFINE) if REFINE else ''} ({fs.th.nc} cells, {fs.th.N} dofs), "
+                "workload": f"cylinder Re=100, mesh O1{' red-refined x' + str(REFINE) if REFINE else ''} ({mesh_nc} cells, {mesh_N} dofs), "
                 "dt=0.005, BDF2, open loop, IC div-free vortex (2,0) r=0.5, sensors+energy every step",
                 "parallelism": "single GPU" if world == 1 else (
                     f"row-partitioned over {world} GPUs: one elimination sub-tree + its cells per rank, the root's rows split "
                     f"over the ranks, 3 RCCL all-reduces per step" if partitioned
                     else f"{world} independent replicas (no data-path collective)"),
                 "partition": part_info,
-                "solver": f"ND selected-inverse depth {dev.depth}, {fs.refine_steps} refinement",
+                "solver": depth_str,
             },
-            "batched_steps_per_s": args.steps / t_batched,
+            "batched_steps_per_s": (args.steps / t_batched) if t_batched else None,
+            "strong_scaling_config4": config4,
             "replicas_steps_per_s": (world * single_rate) if single_rate else (replicas["per_k"]["8"]["replicas_steps_per_s"] if replicas else None),
             "replicas": replicas,
             "roofline": roofline,
-            "phase_ms_eager": {k: float(v) for k, v in zip(["rhs_elem", "rhs_gather", "sweeps", "residual_spmv", "finish"], phases)},
+            "phase_ms_eager": {k: float(v) for k, v in zip(["rhs_elem", "rhs_gather", "sweeps", "residual_spmv", "finish"], phases)} if phases is not None else None,
             "spmv": spmv,
             "cpu_baseline": cpu,
             "speedup_vs_cpu_baseline": (value / cpu["value"]) if cpu else None,
-            "solve_rel_residual_pre_refine": float(fs.solve_info[1]),
+            "solve_rel_residual_pre_refine": resid_last,
             "y_last": y_last.tolist(),
         }
     if world > 1:

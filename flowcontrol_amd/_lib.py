@@ -103,6 +103,7 @@ SIGNATURES: dict[str, list] = {
     "fc_set_partition": [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_int],
     "fc_comm_unique_id": [C.c_char_p],
     "fc_comm_init": [_H, C.c_int, C.c_int, C.c_char_p],
+    "fc_comm_info": [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "fc_set_host_exchange": [_H, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     "fc_set_timing": [_H, C.c_int],
     "fc_get_timing": [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64)],

@@ -327,6 +327,8 @@ struct Rccl {
   int (*CommInitRank)(void**, int, FcNcclId, int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;
+  int (*CommUserRank)(void*, int*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
 Rccl g_rccl;
@@ -354,6 +356,8 @@ int rccl_load() {
   g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclAllReduce");
   g_rccl.CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
   g_rccl.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+  g_rccl.CommCount = (int (*)(void*, int*))dlsym(lib, "ncclCommCount");
+  g_rccl.CommUserRank = (int (*)(void*, int*))dlsym(lib, "ncclCommUserRank");
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
     return fail(FC_ERR_HIP, "RCCL symbols missing");
   g_rccl.lib = lib;
@@ -3413,6 +3417,27 @@ int fc_comm_init(fc_handle h, int nranks, int rank, const char* id128) {
   h->nranks = nranks;
   h->rank = rank;
   forget_solver_structure(h);
+  return FC_OK;
+}
+
+// what the handle's exchange actually is: transport 0 = none (single GPU), 1 = RCCL communicator — nranks / rank are then READ
+// BACK from the communicator (ncclCommCount / ncclCommUserRank), not echoed from fc_comm_init —, 2 = host callback
+int fc_comm_info(fc_handle h, int32_t* nranks, int32_t* rank, int32_t* transport) {
+  if (!h) return fail(FC_ERR_INVALID, "null handle");
+  int n = 1, r = 0, t = 0;
+  if (h->comm) {
+    t = 1;
+    if (!g_rccl.CommCount || !g_rccl.CommUserRank) return fail(FC_ERR_HIP, "fc_comm_info: ncclCommCount / ncclCommUserRank not found");
+    NCCLCHK(g_rccl.CommCount(h->comm, &n));
+    NCCLCHK(g_rccl.CommUserRank(h->comm, &r));
+  } else if (h->host_xchg) {
+    t = 2;
+    n = h->nranks;
+    r = h->rank;
+  }
+  if (nranks) *nranks = n;
+  if (rank) *rank = r;
+  if (transport) *transport = t;
   return FC_OK;
 }
 

@@ -118,6 +118,12 @@ class DeviceSolver:
         uid = broadcast_bytes(buf.raw if rank == 0 else None)
         check(self.lib.fc_comm_init(self._h, world, rank, C.create_string_buffer(uid, 128)))
 
+    def comm_info(self) -> dict:
+        """Ranks / rank / transport of the handle's exchange as the library sees it (RCCL: read back from the communicator)."""
+        n, r, t = C.c_int32(), C.c_int32(), C.c_int32()
+        check(self.lib.fc_comm_info(self._h, C.byref(n), C.byref(r), C.byref(t)))
+        return {"nranks": n.value, "rank": r.value, "transport": {0: "none", 1: "rccl", 2: "host"}[t.value]}
+
     # ── lifetime ─────────────────────────────────────────────────────────────
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h:

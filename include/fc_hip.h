@@ -341,6 +341,9 @@ int fc_comm_init(fc_handle h, int nranks, int rank, const char* id128);
  * The launch sequence of a step is the one of the RCCL path; only the exchange itself differs (device -> pinned
  * host buffer -> fn -> device instead of an in-stream ncclAllReduce).  Three exchanges per step: the root
  * right-hand side, the root solution (row blocks), the 80-double step record. */
+/* what the handle's exchange is: transport 0 = none, 1 = RCCL (nranks / rank READ BACK from the communicator with
+ * ncclCommCount / ncclCommUserRank), 2 = host callback */
+int fc_comm_info(fc_handle h, int32_t* nranks, int32_t* rank, int32_t* transport);
 typedef void (*fc_exchange_fn)(double* buf, int64_t n, void* user);
 int fc_set_host_exchange(fc_handle h, int nranks, int rank, fc_exchange_fn fn, void* user);
 
