@@ -236,6 +236,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-spmv", action="store_true")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent replicas instead of the partitioned run")
+    ap.add_argument("--no-replicas", action="store_true", help="skip the batched-replicas section (profiling passes of the single-simulation step)")
     ap.add_argument("--no-extras", action="store_true", help="skip rank 0's single-GPU extras (roofline replay, SpMV probe, batched replicas, CPU baseline)")
     ap.add_argument("--no-config4", action="store_true", help="N > 1: skip the strong-scaling run on the BASELINE config-4 mesh (O1 refined once)")
     ap.add_argument("--refine", type=int, default=0, help="red-refine the O1 mesh K times (BASELINE config 4: K=1); not the headline workload")
@@ -400,7 +401,7 @@ def main() -> None:
                      f"factors ({sweep_bytes / 1e6:.0f} MB) exceed the 256 MiB Infinity Cache: HBM streaming"),
         }
         replicas = None
-        if not partitioned and dev.world == 1:
+        if not partitioned and dev.world == 1 and not args.no_replicas:
             replicas = batched_replicas(fs, steps=min(args.steps, 400), single_rate=(1 if partitioned else 1) * args.steps / elapsed)
         phases, nl = dev.profile_steps(SLOT_BDF2, 50, u0)
         spmv = spmv_probe(fs, include_large=not args.no_large_spmv)

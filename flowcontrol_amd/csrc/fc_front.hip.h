@@ -40,10 +40,22 @@ typedef double fc_d4 __attribute__((ext_vector_type(4)));
 // W = A[K,K]^-1 by Gauss-Jordan with partial pivoting among the block's rows (ties -> smallest row: reproducible)
 // (a: KB x (KB + 1) doubles and piv: KB ints of LDS, provided by the caller: the stand-alone kernel below for a front's
 // first step, fc_fe_update for every later one)
+//
+// The KB dependent column steps of this inversion are the critical path of every block step (the trailing update hides
+// behind it, not the other way round): they run on ONE wave out of registers — lane r owns row r (KB doubles), the pivot
+// search is a wave reduction, the pivot row reaches the other lanes as scalar broadcasts (v_readlane), a row swap is a
+// lane permute — with no workgroup barrier and no LDS round trip inside a column step (the LDS version spent 1.4 us per
+// column: 44 us per 32-column block, 46 us measured for the stand-alone kernel).  LDS carries the
+// block in (coalesced load by all threads) and out (the columns of the inverse permuted back).
+// value of `v` in lane `l` (wave-uniform l) as a scalar broadcast
+__device__ __forceinline__ double fc_readlane(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
 template <int KB>
 __device__ __forceinline__ void fc_fe_pivot_block(const FcFront& nd, const double* fronts, double* __restrict__ scratch, int step,
                                                   double (*a)[KB + 1], int* piv) {
-  constexpr int EPT = KB * KB / 256;
   const int k0 = step * KB;
   const int kb = nd.ni - k0 < KB ? nd.ni - k0 : KB;
   const int nf = nd.nf;
@@ -54,77 +66,75 @@ __device__ __forceinline__ void fc_fe_pivot_block(const FcFront& nd, const doubl
     a[r][c] = (r < kb && c < kb) ? A[(size_t)(k0 + r) * nf + k0 + c] : (r == c ? 1.0 : 0.0);
   }
   __syncthreads();
-  for (int k = 0; k < kb; ++k) {
-    // pivot search in column k, rows k .. kb-1 (one wave is enough)
-    if (wave == 0) {
-      double best = -1.0;
-      int bi = k;
-      if (lane >= k && lane < kb) {
-        best = fabs(a[lane][k]);
-        bi = lane;
-      }
+  if (wave == 0) {
+    const int r = lane < KB ? lane : KB - 1;  // lanes beyond the block shadow its last row (KB = 32: half the wave)
+    double x[KB];
+#pragma unroll
+    for (int c = 0; c < KB; ++c) x[c] = a[r][c];
+    // A COMPACT loop over the KB columns (the fully unrolled form is 64 KB of straight-line code: instruction fetch then
+    // costs what the barriers cost before): every step works on register 0 and rotates the row by one position while it
+    // updates it — after KB steps the columns are back in place.  Steps k >= kb meet the identity padding: no-ops.
+#pragma clang loop unroll(disable)
+    for (int k = 0; k < KB; ++k) {
+      // pivot search in the current column over rows k .. kb-1 (k >= kb: the padding row k itself)
+      double best = ((lane >= k && lane < kb) || (k >= kb && lane == k)) ? fabs(x[0]) : -1.0;
+      int bi = lane;
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_down(best, off, 64);
-        const int oi = __shfl_down(bi, off, 64);
+        const double ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
         if (ov > best || (ov == best && oi < bi)) {
           best = ov;
           bi = oi;
         }
       }
-      if (lane == 0) piv[k] = bi;
-    }
-    __syncthreads();
-    const int p = piv[k];
-    if (p != k && t < KB) {
-      const double u = a[k][t], v = a[p][t];
-      a[k][t] = v;
-      a[p][t] = u;
-    }
-    __syncthreads();
-    const double d = 1.0 / a[k][k];
-    // every thread updates its entries: row k scaled, other rows eliminated; column k takes the swept values
-    double nv[EPT];
+      const int p = __builtin_amdgcn_readfirstlane(bi);
+      if (lane == 0) piv[k] = p;
+      if (p != k) {  // exchange rows k and p: a permute between two lanes
+        const int partner = lane == k ? p : (lane == p ? k : lane);
 #pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-      const int e = t + 256 * q, r = e / KB, c = e % KB;
-      const double ark = a[r][k], akc = a[k][c];
-      double v;
-      if (r == k)
-        v = c == k ? d : akc * d;
-      else
-        v = c == k ? -ark * d : a[r][c] - ark * (akc * d);
-      nv[q] = v;
-    }
-    __syncthreads();
+        for (int c = 0; c < KB; ++c) x[c] = __shfl(x[c], partner, 64);
+      }
+      const double d = 1.0 / fc_readlane(x[0], k);
+      const double f = x[0];  // this row's entry in the pivot column
+      const bool isk = lane == k;
 #pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-      const int e = t + 256 * q;
-      a[e / KB][e % KB] = nv[q];
+      for (int c = 1; c < KB; ++c) {
+        const double rk = fc_readlane(x[c], k) * d;  // scaled pivot row: a scalar broadcast from lane k
+        x[c - 1] = isk ? rk : x[c] - f * rk;
+      }
+      x[KB - 1] = isk ? d : -f * d;  // the swept pivot column takes the free slot at the end of the rotation
     }
-    __syncthreads();
-  }
-  // the row swaps act on the columns of the inverse, in reverse order
-  for (int k = kb - 1; k >= 0; --k) {
-    const int p = piv[k];
-    if (p != k && t < KB) {
-      const double u = a[t][k], v = a[t][p];
-      a[t][k] = v;
-      a[t][p] = u;
+    // inverse back to LDS; the row swaps are undone on its columns, in reverse order
+    if (lane < KB) {
+#pragma unroll
+      for (int c = 0; c < KB; ++c) a[lane][c] = x[c];
     }
-    __syncthreads();
+    if (lane == 0) {
+      // col[c] = column of the swept block that is column c of the inverse
+      for (int c = 0; c < KB; ++c) piv[KB + c] = c;
+      for (int k = kb - 1; k >= 0; --k) {
+        const int p = piv[k];
+        if (p != k) {
+          const int u = piv[KB + k];
+          piv[KB + k] = piv[KB + p];
+          piv[KB + p] = u;
+        }
+      }
+    }
   }
+  __syncthreads();
   double* W = scratch + nd.scratch;
   for (int e = t; e < KB * KB; e += 256) {
     const int r = e / KB, c = e % KB;
-    W[e] = (r < kb && c < kb) ? a[r][c] : 0.0;
+    W[e] = (r < kb && c < kb) ? a[r][piv[KB + c]] : 0.0;
   }
 }
 
 template <int KB>
 __global__ __launch_bounds__(256) void fc_fe_pivot(const FcFront* __restrict__ nodes, double* fronts, double* __restrict__ scratch, int step) {
   __shared__ double a[KB][KB + 1];
-  __shared__ int piv[KB];
+  __shared__ int piv[2 * KB];
   const FcFront nd = nodes[blockIdx.x];
   if (step * KB >= nd.ni) return;
   fc_fe_pivot_block<KB>(nd, fronts, scratch, step, a, piv);
@@ -194,7 +204,7 @@ template <int KB>
 __global__ __launch_bounds__(256) void fc_fe_update(const FcFront* __restrict__ nodes, double* fronts, const double* __restrict__ scratch,
                                                     int step, int tiles_per_side) {
   __shared__ double smem[KB * (KB + 1) > KB * 64 ? KB * (KB + 1) : KB * 64];  // the B panel, then (one tile only) the next pivot block
-  __shared__ int piv[KB];
+  __shared__ int piv[2 * KB];
   double (*Bs)[64] = reinterpret_cast<double (*)[64]>(smem);
   const FcFront nd = nodes[blockIdx.y];
   const int k0 = step * KB;

@@ -9,7 +9,7 @@ rm -rf "$OUT" && mkdir -p "$OUT"
 (while true; do sleep 60; echo "[$(date +%T)] still profiling"; done) &
 HB=$!
 trap 'kill $HB 2>/dev/null' EXIT
-ARGS="--warmup 20 --no-cpu-baseline --no-large-spmv"
+ARGS="--warmup 20 --no-cpu-baseline --no-large-spmv --no-replicas"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python bench.py --steps ${STEPS:-1000} $ARGS > "$OUT/bench_stats.json" 2> "$OUT/stats.err"
 echo "stats pass done"
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python bench.py --steps 100 $ARGS > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err"

@@ -223,8 +223,14 @@ def test_plugin_solver_of_the_stub_on_the_gpu():
         assert x.applied
         ref = spla.splu(A_dolfin.tocsc()).solve(b.a)
         assert np.linalg.norm(x.a - ref) < 1e-10 * np.linalg.norm(ref)
-        solver.set_operator(FakeMatrix(2.0 * A_dolfin))  # a new operator: numeric phase only
+        free = np.ones(W.N)
+        free[bc_dolfin] = 0.0  # (Dirichlet rows stay identity rows, as SystemAssembler leaves them)
+        free[to_fc[W.N - len(mesh.coordinates()) :]] = 0.0  # ... and there is no pressure-pressure block to add to
+        A2 = (A_dolfin + sp.diags(25.0 * free)).tocsr()
+        solver.set_operator(FakeMatrix(A2))  # a new operator: numeric phase only
         solver.solve(x, b)
-        assert np.linalg.norm(x.a - 0.5 * ref) < 1e-10 * np.linalg.norm(ref)
+        ref2 = spla.splu(A2.tocsc()).solve(b.a)
+        assert np.linalg.norm(ref2 - ref) > 1e-3 * np.linalg.norm(ref)
+        assert np.linalg.norm(x.a - ref2) < 1e-10 * np.linalg.norm(ref2)
     finally:
         lib.fc_destroy(h)
