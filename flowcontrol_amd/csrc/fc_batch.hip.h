@@ -342,11 +342,10 @@ __global__ __launch_bounds__(256) void fc_rhs_gather_b(int N, const int* __restr
 // once (coalesced KB-wide rows, instead of one 8 KB-byte gather per matrix entry and simulation pair) and evaluates the
 // 16 rows from there: 16 lanes per row = (j: 16 / HP) x (simulation pair: HP = KB / 2), each lane walks every
 // (16 / HP)-th entry of its row with the entry's LOCAL column (uint16) and reads two simulations (16 B) from LDS.
-// The scatter / shift then uses thread = (row, simulation): all lanes busy.  Cell workgroups (first in the grid) bring
-// a cell's nodal velocities to LDS once and evaluate the energy integrand from there.
-// partial[(s * 3 + w) * G + block], w = 0: sum r^2, 1: sum b^2, 2: sum e  (fixed order: reproducible).
+// The scatter / shift then uses thread = (row, simulation): all lanes busy.  (The energy is fc_energy_b's.)
+// partial[(s * 3 + w) * G + block], w = 0: sum r^2, 1: sum b^2 (fc_tail_b), 2: sum e (fc_energy_b)  (fixed order: reproducible).
 #define FC_TB_ROWS 16
-#define FC_TB_COLS 192
+#define FC_TB_COLS 128
 typedef double fc_d2u __attribute__((ext_vector_type(2), aligned(8)));
 struct __attribute__((aligned(16))) FcTBlock {
   int row0, nrows;  // permuted rows [row0, row0 + nrows)
@@ -357,21 +356,15 @@ __global__ __launch_bounds__(256) void fc_tail_b(int N, int nn2, const int* __re
                                                  const double* __restrict__ b, const FcTBlock* __restrict__ blocks,
                                                  const int* __restrict__ bcols, const int* __restrict__ a_rowptr,
                                                  const unsigned short* __restrict__ a_lidx, const double* __restrict__ a_val,
-                                                 int n_row_blocks, int nc, const int* __restrict__ cn, const double* __restrict__ geom,
-                                                 const int* __restrict__ iperm, double* __restrict__ up, double* __restrict__ u_n,
-                                                 double* __restrict__ u_nn, double* __restrict__ p_n, int* __restrict__ flag,
-                                                 double* __restrict__ partial) {
-  constexpr int HP = KB / 2;           // simulation pairs
-  constexpr int JL = 16 / HP;          // lanes of a row that split its entries
-  constexpr int CPB = 256 / (8 * KB);  // cells per cell workgroup
+                                                 double* __restrict__ up, double* __restrict__ u_n, double* __restrict__ u_nn,
+                                                 double* __restrict__ p_n, int* __restrict__ flag, double* __restrict__ partial, int G) {
+  constexpr int HP = KB / 2;   // simulation pairs
+  constexpr int JL = 16 / HP;  // lanes of a row that split its entries
   const int t = threadIdx.x;
-  const int G = gridDim.x;
-  const int n_cell_blocks = G - n_row_blocks;
-  const int rb = (int)blockIdx.x - n_cell_blocks;
   __shared__ double xs[FC_TB_COLS * KB];
   __shared__ double red[2][256];
-  if (rb >= 0) {
-    const FcTBlock bk = blocks[rb];
+  {
+    const FcTBlock bk = blocks[blockIdx.x];
     // the block's solution rows -> LDS, two simulations per lane
     for (int e = t; e < bk.ncols * HP; e += 256) {
       const int c = e / HP, sp = e % HP;
@@ -459,49 +452,59 @@ __global__ __launch_bounds__(256) void fc_tail_b(int N, int nn2, const int* __re
       }
       partial[((size_t)t * 3 + 0) * G + blockIdx.x] = a0;
       partial[((size_t)t * 3 + 1) * G + blockIdx.x] = a1;
-      partial[((size_t)t * 3 + 2) * G + blockIdx.x] = 0.0;
     }
-  } else {
-    const int s = t % KB, lane = (t / KB) % 8, cw = t / (8 * KB);
-    const int nn = nn2 >> 1;
-    double e = 0.0;
-    const int c = (int)blockIdx.x * CPB + cw;
-    const int cc = c < nc ? c : 0;
-    {
-      const int n = cn[(size_t)(lane < 6 ? lane : 0) * nc + cc];
-      red[0][t] = x[(size_t)iperm[n] * KB + s];
-      red[1][t] = x[(size_t)iperm[nn + n] * KB + s];
-    }
-    __syncthreads();
-    if (c < nc && lane < FC_NQ) {
-      double ux = 0.0, uy = 0.0;
-      const int nb = cw * 8 * KB + s;
+  }
+}
+
+// energy of the new velocity, 1/2 int |u|^2 element by element (flowsolver.py:827-829), for KB simulations: a workgroup brings
+// its cells' nodal velocities to LDS once (thread = (cell, node, simulation)) and evaluates the integrand from there
+// (thread = (cell, Radon point, simulation)).  Its own launch (not appended to fc_tail_b's grid): the row blocks keep up to
+// FC_TB_COLS solution rows in LDS, and a shared launch would charge every cell workgroup that footprint too.
+// partial[(s * 3 + 2) * G + first + block]
+template <int KB>
+__global__ __launch_bounds__(256) void fc_energy_b(int nn2, int nc, const int* __restrict__ cn, const double* __restrict__ geom,
+                                                   const int* __restrict__ iperm, const double* __restrict__ x, double* __restrict__ partial,
+                                                   int G, int first) {
+  constexpr int CPB = 256 / (8 * KB);  // cells per workgroup
+  __shared__ double red[2][256];
+  const int t = threadIdx.x;
+  const int s = t % KB, lane = (t / KB) % 8, cw = t / (8 * KB);
+  const int nn = nn2 >> 1;
+  double e = 0.0;
+  const int c = (int)blockIdx.x * CPB + cw;
+  const int cc = c < nc ? c : 0;
+  {
+    const int n = cn[(size_t)(lane < 6 ? lane : 0) * nc + cc];
+    red[0][t] = x[(size_t)iperm[n] * KB + s];
+    red[1][t] = x[(size_t)iperm[nn + n] * KB + s];
+  }
+  __syncthreads();
+  if (c < nc && lane < FC_NQ) {
+    double ux = 0.0, uy = 0.0;
+    const int nb = cw * 8 * KB + s;
 #pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        const double ph = c_phi2[lane * 6 + a];
-        ux += ph * red[0][nb + a * KB];
-        uy += ph * red[1][nb + a * KB];
-      }
-      e = c_qw[lane] * 0.5 * geom[4 * (size_t)nc + cc] * (ux * ux + uy * uy);
+    for (int a = 0; a < 6; ++a) {
+      const double ph = c_phi2[lane * 6 + a];
+      ux += ph * red[0][nb + a * KB];
+      uy += ph * red[1][nb + a * KB];
     }
-    __syncthreads();
-    red[0][t] = e;
-    __syncthreads();
-    if (t < KB) {
-      double se = 0.0;
+    e = c_qw[lane] * 0.5 * geom[4 * (size_t)nc + cc] * (ux * ux + uy * uy);
+  }
+  __syncthreads();
+  red[0][t] = e;
+  __syncthreads();
+  if (t < KB) {
+    double se = 0.0;
 #pragma unroll
-      for (int g = 0; g < 8 * CPB; ++g) se += red[0][g * KB + t];
-      partial[((size_t)t * 3 + 0) * G + blockIdx.x] = 0.0;
-      partial[((size_t)t * 3 + 1) * G + blockIdx.x] = 0.0;
-      partial[((size_t)t * 3 + 2) * G + blockIdx.x] = se;
-    }
+    for (int g = 0; g < 8 * CPB; ++g) se += red[0][g * KB + t];
+    partial[((size_t)t * 3 + 2) * G + first + blockIdx.x] = se;
   }
 }
 
 // fc_final for simulation s = blockIdx.x: folds its partials, evaluates the sensor rows on its column of `up`,
 // publishes its record (fc_publish: checksummed, the host polls it)
 template <int KB>
-__global__ __launch_bounds__(256) void fc_final_b(int G, int n_cell_blocks, const double* __restrict__ partial, int n_sens,
+__global__ __launch_bounds__(256) void fc_final_b(int G, int n_row_blocks, const double* __restrict__ partial, int n_sens,
                                                   const int* __restrict__ s_rowptr, const int* __restrict__ s_idx,
                                                   const double* __restrict__ s_w, const double* __restrict__ up,
                                                   const int* __restrict__ flag, double* __restrict__ rec, int rstride,
@@ -517,9 +520,9 @@ __global__ __launch_bounds__(256) void fc_final_b(int G, int n_cell_blocks, cons
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = base + u * 256 + t;
-      v0[u] = i < G ? ps[i] : 0.0;
-      v1[u] = i < G ? ps[(size_t)G + i] : 0.0;
-      v2[u] = i < n_cell_blocks ? ps[2 * (size_t)G + i] : 0.0;
+      v0[u] = i < n_row_blocks ? ps[i] : 0.0;  // row blocks [0, n_row_blocks): residual sums; cell blocks behind them: energy
+      v1[u] = i < n_row_blocks ? ps[(size_t)G + i] : 0.0;
+      v2[u] = (i >= n_row_blocks && i < G) ? ps[2 * (size_t)G + i] : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {

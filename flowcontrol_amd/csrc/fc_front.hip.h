@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void fc_fe_panels(const FcFront* __restrict__ 
 //   v_mfma_f64_16x16x4_f64: lane l holds A[row l & 15][k = l >> 4], B[k = l >> 4][col l & 15];
 //   D[row (l >> 4) + 4 r][col l & 15] in register r.
 template <int KB>
-__global__ __launch_bounds__(256) void fc_fe_update(const FcFront* __restrict__ nodes, double* fronts, const double* __restrict__ scratch,
+__global__ __launch_bounds__(256) void fc_fe_update(const FcFront* __restrict__ nodes, double* fronts, double* scratch,
                                                     int step, int tiles_per_side) {
   __shared__ double smem[KB * (KB + 1) > KB * 64 ? KB * (KB + 1) : KB * 64];  // the B panel, then (one tile only) the next pivot block
   __shared__ int piv[2 * KB];
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void fc_fe_update(const FcFront* __restrict__ 
   // the other workgroups of the launch are still updating theirs -- the next step then starts with its panels
   if (k1 < nd.ni && ti == tk && tj == tk) {
     __syncthreads();  // the tile's stores are visible to the whole workgroup; Bs is free
-    fc_fe_pivot_block<KB>(nd, fronts, const_cast<double*>(scratch), step + 1, reinterpret_cast<double (*)[KB + 1]>(smem), piv);
+    fc_fe_pivot_block<KB>(nd, fronts, scratch, step + 1, reinterpret_cast<double (*)[KB + 1]>(smem), piv);
   }
 }
 

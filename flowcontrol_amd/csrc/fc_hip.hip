@@ -1020,8 +1020,9 @@ int bicgstab_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
   // report the TRUE residual of the returned x
   FCCHK(matvec(x, t));
   hipLaunchKernelGGL(fc_lin3, dim3(g), dim3(256), 0, h->stream, N, t, 1.0, h->b.p, -1.0, t, 0.0, (const double*)nullptr);
-  hipLaunchKernelGGL(fc_dots2, dim3(gd), dim3(256), 0, h->stream, N, t, t, t, t, h->partial.p);
-  hipLaunchKernelGGL(fc_bicg_phase, dim3(1), dim3(256), 0, h->stream, -1, gd, h->partial.p, ks, h->rtol, 1, 0);
+  // the same masked dot (rows this rank accounts for) and exchange as inside the loop: on a partitioned handle every rank
+  // must report the SAME residual (callers branch on it)
+  FCCHK(dots(-1, t, t, t, t));
   FCCHK(krylov_state(h, kh));
   *relres = std::sqrt(kh[KS_D0]) / bnorm;
   HIPCHK(hipGetLastError());
@@ -2371,7 +2372,10 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
       const int nfmax = h->plevel_max_nf[li];
       const int ct = (nfmax + 63) / 64;  // 64-wide tiles per side of the widest front
       // block step of the level: wide fronts take 64 pivot columns at a time, small ones 32 (fc_front.hip.h)
-      const bool wide = h->plevel_max_nf[li] >= FC_FE_WIDE_NF;
+      // FC_FE_WIDE_NF (environment, read per factorisation): tests run the 64-column kernels on small meshes with it
+      int wide_nf = FC_FE_WIDE_NF;
+      if (const char* e = std::getenv("FC_FE_WIDE_NF")) wide_nf = std::max(1, std::atoi(e));
+      const bool wide = h->plevel_max_nf[li] >= wide_nf;
       const int kbs = wide ? FC_FE_KB_WIDE : FC_FE_KB;
       const int steps = (h->plevel_max_ni[li] + kbs - 1) / kbs;
       for (int k = 0; k < steps; ++k) {
@@ -3939,12 +3943,17 @@ static int batch_launches(fc_ctx* h, int order_slot, int compute_energy) {
   const int n_row_blocks = B.n_tblocks, n_cell_blocks = compute_energy ? nblocks(nc, cpb) : 0;
   const int G = n_row_blocks + n_cell_blocks;
   if ((size_t)3 * G * KB > B.partial.n) return fail(FC_ERR_INVALID, "fc_step_batch: partial buffer too small");
-#define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, B.buf.p + (size_t)N * K, B.b.p, B.tblocks.p, \
-                                       B.tcols.p, S.Ap_rowptr.p, B.tlidx.p, S.Ap_val.p, n_row_blocks, nc, h->cn.p, h->geom.p, h->iperm.p, B.up.p, B.u_n.p, B.u_nn.p,  \
-                                       B.p_n.p, B.flag.p, B.partial.p)
+#define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(n_row_blocks), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, B.buf.p + (size_t)N * K, B.b.p, B.tblocks.p, \
+                                       B.tcols.p, S.Ap_rowptr.p, B.tlidx.p, S.Ap_val.p, B.up.p, B.u_n.p, B.u_nn.p, B.p_n.p, B.flag.p, B.partial.p, G)
   FC_KB_DISPATCH(KB, FC_TAILB(4), FC_TAILB(8), FC_TAILB(16));
 #undef FC_TAILB
-#define FC_FINB(K) hipLaunchKernelGGL((fc_final_b<K>), dim3(B.k), dim3(256), 0, h->stream, G, n_cell_blocks, B.partial.p, h->n_sens, h->s_rowptr.p, h->s_idx.p, \
+  if (n_cell_blocks > 0) {
+#define FC_ENB(K) hipLaunchKernelGGL((fc_energy_b<K>), dim3(n_cell_blocks), dim3(256), 0, h->stream, 2 * h->nn, nc, h->cn.p, h->geom.p, h->iperm.p, \
+                                     B.buf.p + (size_t)N * K, B.partial.p, G, n_row_blocks)
+    FC_KB_DISPATCH(KB, FC_ENB(4), FC_ENB(8), FC_ENB(16));
+#undef FC_ENB
+  }
+#define FC_FINB(K) hipLaunchKernelGGL((fc_final_b<K>), dim3(B.k), dim3(256), 0, h->stream, G, n_row_blocks, B.partial.p, h->n_sens, h->s_rowptr.p, h->s_idx.p, \
                                       h->s_w.p, B.up.p, B.flag.p, h->pin_dev, kRecStride, h->pin_dev + kSeqSlot, compute_energy)
   FC_KB_DISPATCH(KB, FC_FINB(4), FC_FINB(8), FC_FINB(16));
 #undef FC_FINB

@@ -72,6 +72,7 @@ class DeviceSolver:
         self.device_index = device
         self.batch_k = 0
         self._batch_bufs = None
+        self._xchg_error: BaseException | None = None
 
     # ── multi-GPU ────────────────────────────────────────────────────────────
     def join(self, rank: int, world: int, broadcast_bytes, host_allreduce=None) -> None:
@@ -99,7 +100,14 @@ class DeviceSolver:
             # exchange through the host (fc_set_host_exchange): no RCCL communicator; ``host_allreduce(array)`` sums a
             # float64 array over the ranks in place.  The launch sequence is the one of the RCCL path.
             def _cb(ptr, n, _user):
-                host_allreduce(np.ctypeslib.as_array(ptr, shape=(int(n),)))
+                # ctypes swallows an exception raised in a callback: park it, poison the buffer (the residual / divergence
+                # checks of the step then trip instead of continuing on un-reduced sums) and re-raise after the C call
+                arr = np.ctypeslib.as_array(ptr, shape=(int(n),))
+                try:
+                    host_allreduce(arr)
+                except BaseException as err:  # noqa: BLE001
+                    self._xchg_error = err
+                    arr[:] = np.nan
 
             self._xchg_cb = _lib.EXCHANGE_FN(_cb)  # keep the callback object alive as long as the handle
             check(self.lib.fc_set_host_exchange(self._h, world, rank, C.cast(self._xchg_cb, C.c_void_p), None))
@@ -123,6 +131,12 @@ class DeviceSolver:
         n, r, t = C.c_int32(), C.c_int32(), C.c_int32()
         check(self.lib.fc_comm_info(self._h, C.byref(n), C.byref(r), C.byref(t)))
         return {"nranks": n.value, "rank": r.value, "transport": {0: "none", 1: "rccl", 2: "host"}[t.value]}
+
+    def _raise_exchange_error(self) -> None:
+        """An exception inside the host exchange callback (gloo timeout, dead peer) surfaces here, after the C call returned."""
+        err, self._xchg_error = self._xchg_error, None
+        if err is not None:
+            raise _lib.FcError(_lib.FC_ERR_HIP, f"host exchange failed: {err!r}") from err
 
     # ── lifetime ─────────────────────────────────────────────────────────────
     def close(self) -> None:
@@ -325,7 +339,9 @@ class DeviceSolver:
     def _setup_solver_native(self, slot, depth, refine, check_residual, merge, truncate) -> None:
         """``fc_setup_solver``: tree, factor layout, elimination plan, sweep tables, numeric factorisation and its
         acceptance solve all happen inside the library; only sizes come back."""
-        check(self.lib.fc_setup_solver(self._h, slot, int(depth or 0), int(merge), int(truncate), int(refine), int(bool(check_residual))))
+        code = self.lib.fc_setup_solver(self._h, slot, int(depth or 0), int(merge), int(truncate), int(refine), int(bool(check_residual)))
+        self._raise_exchange_error()
+        check(code)
         info = np.zeros(10, dtype=np.int64)
         check(self.lib.fc_get_solver_info(self._h, slot, info))
         self._n_factor_values, self.total_factor_nnz, self.local_factor_nnz = int(info[0]), int(info[1]), int(info[2])
@@ -413,7 +429,9 @@ class DeviceSolver:
         if slot not in self._structured:
             raise RuntimeError("setup_solver(slot) must run once before refactor(slot)")
         ms = C.c_double()
-        check(self.lib.fc_refactor(self._h, slot, C.byref(ms)))
+        code = self.lib.fc_refactor(self._h, slot, C.byref(ms))
+        self._raise_exchange_error()
+        check(code)
         self.refactor_ms[slot] = ms.value
         # end-to-end acceptance of the new factors: one solve with a fixed right-hand side, residual
         # against the matrix itself (block-local pivoting in fc_fe_pivot is not trusted blindly)
@@ -527,6 +545,8 @@ class DeviceSolver:
         """Second half: wait for the step's record; returns (y, dE, info) like :meth:`step`."""
         u, uf, y, info, dE, (pu, puf, py, pinfo), pdE = self._step_bufs
         code = self.lib.fc_step_end(self._h, py, pdE, pinfo)
+        if self._xchg_error is not None:
+            self._raise_exchange_error()
         if code:
             check(code)
         return y[: self.n_sens].copy(), dE.value, info
@@ -630,7 +650,9 @@ class DeviceSolver:
     def solve(self, slot: int, b):
         x = np.empty(self.N)
         info = np.empty(4)
-        check(self.lib.fc_solve(self._h, slot, _f64(b), x, ptr(info)))
+        code = self.lib.fc_solve(self._h, slot, _f64(b), x, ptr(info))
+        self._raise_exchange_error()
+        check(code)
         return x, info
 
     def energy(self, u) -> float:

@@ -220,14 +220,19 @@ def test_block_and_segment_down_sweeps_agree(setup):
         assert info[1] < 1e-9
 
 
-def test_device_factorisation_matches_host_multifrontal(setup):
-    """fc_refactor (scatter, extend-add, blocked Gauss-Jordan front elimination on the fp64 matrix cores)
+@pytest.mark.parametrize("wide", [False, True])
+def test_device_factorisation_matches_host_multifrontal(setup, wide, monkeypatch):
+    """(wide = True: FC_FE_WIDE_NF=64 sends every level of this small mesh through the 64-column kernels — pivot / panels /
+    update<64> with the look-ahead inversion in the 64 x 65 LDS overlay — which cavity_fine alone reaches otherwise.)
+    fc_refactor (scatter, extend-add, blocked Gauss-Jordan front elimination on the fp64 matrix cores)
     against the numpy multifrontal of tests/support/nd_numeric.py on the same matrix and tree: factor
     values to round-off, then again after the matrix changed (numeric phase only)."""
     th, dev, d, O = setup
     from flowcontrol_amd.device import SLOT_BDF2
     from tests.support import nd_numeric
 
+    if wide:
+        monkeypatch.setenv("FC_FE_WIDE_NF", "64")
     dt, Re = 0.005, 100.0
     dofs, prof = _bc_setup(th)
     dev.set_bc(dofs, prof)

@@ -273,3 +273,55 @@ def test_rccl_plumbing_with_a_single_rank_communicator(monkeypatch):
     y_b, dE_b = fs.run(4, np.zeros(2))  # batched path with in-stream collectives
     assert np.all(np.isfinite(y_b)) and np.all(np.isfinite(dE_b))
     fs.th.release_device()
+
+
+def _lidcavity_worker(rank, world, port, out, nsteps):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from flowcontrol_amd.examples.lidcavity.lidcavityflowsolver import LidCavityFlowSolver
+        from flowcontrol_amd.fem.spaces import Function
+
+        g = np.load(ROOT / "tests" / "golden" / "lidcavity_mesh64.npz")
+        fs = LidCavityFlowSolver.make_default(Re=1000, path_out=tempfile.mkdtemp(), num_steps=nsteps)
+        U0, P0 = Function(fs.W, g["UP0"]).split()
+        fs._assign_steady_state(U0, P0)
+        fs.initialize_time_stepping(ic=None)
+        for _ in range(nsteps):
+            fs.step(u_ctrl=[0.0] * fs.params_control.actuator_number)
+        ts = fs.timeseries
+        if rank == 0:
+            out["y"] = ts[[c for c in ts.columns if c.startswith("y_meas_")]].to_numpy()
+            out["dE"] = ts["dE"].to_numpy()
+            out["resid"] = float(fs.solve_info[1])
+        fs.th.release_device()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_enclosed_flow_on_a_partitioned_handle():
+    """Lid-driven cavity (velocity prescribed on the whole boundary: the pressure level is pinned at ONE dof, which only the
+    rank that eliminates it shifts) on two ranks: fc_setup_solver's acceptance solve is a collective, so every rank must
+    build the same null-space-compatible probe right-hand side — decided by the global pin, not by the rank-local shift
+    (round-2 advisor finding).  Setup must pass on both ranks and the steps must be the serial run's."""
+    from flowcontrol_amd.examples.lidcavity.lidcavityflowsolver import LidCavityFlowSolver
+    from flowcontrol_amd.fem.spaces import Function
+
+    nsteps = 4
+    g = np.load(ROOT / "tests" / "golden" / "lidcavity_mesh64.npz")
+    fs = LidCavityFlowSolver.make_default(Re=1000, path_out=tempfile.mkdtemp(), num_steps=nsteps)
+    U0, P0 = Function(fs.W, g["UP0"]).split()
+    fs._assign_steady_state(U0, P0)
+    fs.initialize_time_stepping(ic=None)
+    for _ in range(nsteps):
+        fs.step(u_ctrl=[0.0] * fs.params_control.actuator_number)
+    ts = fs.timeseries
+    y1, dE1 = ts[[c for c in ts.columns if c.startswith("y_meas_")]].to_numpy(), ts["dE"].to_numpy()
+    fs.th.release_device()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_lidcavity_worker, args=(2, _free_port(), out, nsteps), nprocs=2, join=True)
+        assert np.linalg.norm(out["y"] - y1) <= 1e-8 * np.linalg.norm(y1)
+        assert np.linalg.norm(out["dE"] - dE1) <= 1e-8 * np.linalg.norm(dE1)
+        assert out["resid"] < 1e-9
