@@ -96,6 +96,7 @@ __device__ __forceinline__ bool fc_dag_wait(const FcDagDep* __restrict__ deps, i
   return true;
 }
 
+#ifdef FC_WITH_DAG  // the kernel is compiled only into builds that ask for it (hipcc -DFC_WITH_DAG): measured slower than the level launches on every mesh
 // PERSISTENT: workgroup w of G runs tasks w, w + G, w + 2G, ... (topological order: a task's dependencies have
 // smaller numbers, so they belong to workgroups that are resident and get to them first; all G workgroups must be
 // resident, which the launch ensures by its size — and every wait is bounded anyway).  Software pipeline: the
@@ -254,3 +255,4 @@ __global__ __launch_bounds__(256, FC_DAG_WAVES_PER_SIMD) void fc_nd_dag(
   }
 #undef FC_STAMP
 }
+#endif  // FC_WITH_DAG

@@ -617,10 +617,15 @@ int apply_factors_dag(fc_ctx* h, OrderSys& S, int first, int last) {
     if (h->host_xchg) wgs = std::min(wgs, 128);  // ranks sharing one GPU (host exchange): leave room for the other ranks' grids
     const int lds_pad = std::max(0, (160 * 1024) / per_cu - (int)(FC_DAG_TILE * sizeof(double)) - 1024);
     const int n = t1 - t0;
+#ifdef FC_WITH_DAG
     if (n > 0)
       hipLaunchKernelGGL(fc_nd_dag, dim3(std::min(n, wgs)), dim3(256), lds_pad, h->stream, S.dag_tasks.p + t0, n, S.dag_deps.p, S.dag_cnt.p,
                          S.dag_epoch, h->dag_err.p, S.dag_up_col.p, S.dag_up_val.p, S.f_idx.p, S.f_val.p, h->buf.p,
                          h->dag_trace.p ? h->dag_trace.p + (size_t)t0 * 8 : nullptr);
+#else
+    (void)wgs, (void)lds_pad, (void)n;
+    return fail(FC_ERR_INVALID, "the one-launch factor apply is not part of this build (hipcc -DFC_WITH_DAG)");
+#endif
     HIPCHK(hipGetLastError());
     return FC_OK;
   };
@@ -1404,7 +1409,9 @@ int fc_create(fc_handle* out, int device, int32_t nv, int32_t ne, int32_t nc, co
   TRY(h->tail.zero(h->stream));
   TRY(h->dag_err.alloc(2));
   TRY(h->dag_err.zero(h->stream));
-  if (const char* e = std::getenv("FC_DAG")) h->dag_enabled = e[0] != '0';  // 1: one-launch factor apply (fc_dag.hip.h)
+#ifdef FC_WITH_DAG
+  if (const char* e = std::getenv("FC_DAG")) h->dag_enabled = e[0] != '0';  // 1: one-launch factor apply (fc_dag.hip.h; builds with -DFC_WITH_DAG only)
+#endif
   TRYHIP(hipStreamSynchronize(h->stream));
 #undef TRY
 #undef TRYHIP
@@ -1934,6 +1941,9 @@ int fc_solver_set_dag(fc_handle h, int slot, int32_t n_nodes, const int64_t* nod
   if (!S.structured) return fail(FC_ERR_NOT_READY, "fc_solver_setup must be called first");
   HIPCHK(hipSetDevice(h->device));
   S.dag_ready = false;
+#ifndef FC_WITH_DAG
+  return FC_OK;  // the one-launch apply is not part of this build: nothing to tabulate (the level launches are the apply)
+#endif
   if (S.truncated) return FC_OK;  // truncated / compressed (preconditioner-only) factors are applied with the level launches
   const int N = h->N;
   const int64_t n_idx = (int64_t)S.f_idx.n, n_val = S.f_nnz;
@@ -2194,6 +2204,9 @@ int fc_set_dag(fc_handle h, int on) {
   if (!h) return fail(FC_ERR_INVALID, "null handle");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
+#ifndef FC_WITH_DAG
+  if (on) return fail(FC_ERR_INVALID, "fc_set_dag: the one-launch factor apply is not part of this build (hipcc -DFC_WITH_DAG)");
+#endif
   h->dag_enabled = on != 0;
   return FC_OK;
 }

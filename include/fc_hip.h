@@ -178,7 +178,10 @@ int fc_get_rowkind(fc_handle h, uint8_t* rowkind /* [N]: 0 other rank, 1 owned, 
  * the node is swept by this rank.  dn_dep[g]: nearest ancestor that owns dofs (-1: none); up_dep_idx[up_dep_ptr[g]
  * .. up_dep_ptr[g+1]): nearest owners below g, one per branch.  Must follow fc_solver_setup for the slot.
  * Every wait inside the launch is bounded; after a give-up the step is redone with the level launches and the
- * handle stays on them (fc_get_dag_info reports it).  FC_DAG=0 / fc_set_dag(h, 0): level launches throughout. */
+ * handle stays on them (fc_get_dag_info reports it).  FC_DAG=0 / fc_set_dag(h, 0): level launches throughout.
+ * OPTIONAL PART: the kernel is compiled only with hipcc -DFC_WITH_DAG (it is slower than the level launches on
+ * every mesh measured).  A default build keeps these four entry points so that bindings load:
+ * fc_solver_set_dag tabulates nothing, fc_set_dag(h, 1) returns FC_ERR_INVALID, FC_DAG in the environment is ignored. */
 int fc_solver_set_dag(fc_handle h, int slot, int32_t n_nodes, const int64_t* nodes /* [n_nodes][7] */,
                       const uint8_t* mine /* [n_nodes] or NULL */, const int32_t* dn_dep /* [n_nodes] */,
                       const int32_t* up_dep_ptr /* [n_nodes+1] */, const int32_t* up_dep_idx);
