@@ -26,6 +26,9 @@
 #ifndef FC_FE_WIDE_NF
 #define FC_FE_WIDE_NF 3072   // a level is "wide" when its largest front has at least this order (below, the longer pivot chain costs more than the update gains)
 #endif
+#ifndef FC_FE_PIVOT_UNROLL
+#define FC_FE_PIVOT_UNROLL 8  // column steps per trip of the pivot-block loop: the row rotation costs one register move per entry and TRIP
+#endif
 #define FC_FE_KB_MAX 64      // scratch layout: W (KB_MAX x KB_MAX) then Cs (nf x KB_MAX), whatever KB a level uses
 
 struct __attribute__((aligned(16))) FcFront {
@@ -53,6 +56,18 @@ __device__ __forceinline__ double fc_readlane(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
+// max of v over the 16 lanes of a DPP row, left in every lane of the row (0 is the neutral element)
+__device__ __forceinline__ unsigned fc_row_max_u32(unsigned v) {
+  unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1, 0, 3, 2]
+  v = o > v ? o : v;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2, 3, 0, 1]
+  v = o > v ? o : v;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, true);  // row_ror:4
+  v = o > v ? o : v;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);  // row_ror:8
+  return o > v ? o : v;
+}
+
 template <int KB>
 __device__ __forceinline__ void fc_fe_pivot_block(const FcFront& nd, const double* fronts, double* __restrict__ scratch, int step,
                                                   double (*a)[KB + 1], int* piv) {
@@ -74,37 +89,48 @@ __device__ __forceinline__ void fc_fe_pivot_block(const FcFront& nd, const doubl
     // A COMPACT loop over the KB columns (the fully unrolled form is 64 KB of straight-line code: instruction fetch then
     // costs what the barriers cost before): every step works on register 0 and rotates the row by one position while it
     // updates it — after KB steps the columns are back in place.  Steps k >= kb meet the identity padding: no-ops.
-#pragma clang loop unroll(disable)
+    // One wave issues one instruction at a time, so a column step costs its instruction count:
+    //  * pivot search on a 32-bit key (upper word of |x|: exponent + 20 mantissa bits, the lane in the low 6 bits) reduced
+    //    with DPP row operations + one readlane per 16-lane row — no LDS permutes; the diagonal is kept whenever it is
+    //    within 8x of the largest candidate (threshold pivoting: a row exchange is 2 KB permutes), ties -> smallest row;
+    //  * 1 / pivot by v_rcp_f64 + two Newton steps;
+    //  * the pivot row is NOT scaled inside the loop (its lane multiplies by its 1 / pivot once, at the end: a scaled
+    //    row only ever acts on itself afterwards, so the scaling commutes with the later column steps): every entry
+    //    of the rank-1 update is then two scalar broadcasts (v_readlane) and one v_fma_f64 with g = x[0] / pivot.
+    double dsave = 1.0;
+#pragma clang loop unroll_count(FC_FE_PIVOT_UNROLL)
     for (int k = 0; k < KB; ++k) {
-      // pivot search in the current column over rows k .. kb-1 (k >= kb: the padding row k itself)
-      double best = ((lane >= k && lane < kb) || (k >= kb && lane == k)) ? fabs(x[0]) : -1.0;
-      int bi = lane;
+      const unsigned hi = (unsigned)__double2hiint(x[0]) & 0x7fffffffu;
+      const bool cand = k < kb ? (lane >= k && lane < kb) : lane == k;
+      const unsigned key = cand ? ((hi & ~63u) | (unsigned)(63 - lane)) : 0u;
+      unsigned m = fc_row_max_u32(key);
+      unsigned mw = (unsigned)__builtin_amdgcn_readlane((int)m, 0);
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(best, off, 64);
-        const int oi = __shfl_xor(bi, off, 64);
-        if (ov > best || (ov == best && oi < bi)) {
-          best = ov;
-          bi = oi;
-        }
+      for (int rw = 16; rw < KB; rw += 16) {
+        const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)m, rw);
+        mw = o > mw ? o : mw;
       }
-      const int p = __builtin_amdgcn_readfirstlane(bi);
+      const unsigned kd = (unsigned)__builtin_amdgcn_readlane((int)key, k);
+      const int p = (mw >> 20) <= (kd >> 20) + 2u ? k : 63 - (int)(mw & 63u);
       if (lane == 0) piv[k] = p;
       if (p != k) {  // exchange rows k and p: a permute between two lanes
         const int partner = lane == k ? p : (lane == p ? k : lane);
 #pragma unroll
         for (int c = 0; c < KB; ++c) x[c] = __shfl(x[c], partner, 64);
       }
-      const double d = 1.0 / fc_readlane(x[0], k);
-      const double f = x[0];  // this row's entry in the pivot column
+      const double pv = fc_readlane(x[0], k);
+      double d = __builtin_amdgcn_rcp(pv);
+      d = __builtin_fma(__builtin_fma(-pv, d, 1.0), d, d);
+      d = __builtin_fma(__builtin_fma(-pv, d, 1.0), d, d);
       const bool isk = lane == k;
+      const double g = isk ? 0.0 : x[0] * d;  // this row's entry in the pivot column over the pivot
+      if (isk) dsave = d;
 #pragma unroll
-      for (int c = 1; c < KB; ++c) {
-        const double rk = fc_readlane(x[c], k) * d;  // scaled pivot row: a scalar broadcast from lane k
-        x[c - 1] = isk ? rk : x[c] - f * rk;
-      }
-      x[KB - 1] = isk ? d : -f * d;  // the swept pivot column takes the free slot at the end of the rotation
+      for (int c = 1; c < KB; ++c) x[c - 1] = __builtin_fma(-g, fc_readlane(x[c], k), x[c]);
+      x[KB - 1] = isk ? 1.0 : -g;  // the swept pivot column takes the free slot at the end of the rotation
     }
+#pragma unroll
+    for (int c = 0; c < KB; ++c) x[c] *= dsave;
     // inverse back to LDS; the row swaps are undone on its columns, in reverse order
     if (lane < KB) {
 #pragma unroll
