@@ -1058,27 +1058,61 @@ int gmres_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
   double* hcol2 = used_p + 1;
   double* yv = gm + (size_t)(m + 1) * m + 2 * m + (m + 1);
   const double mean = (double)S.Ap_nnz / std::max(1, N);
+  // Partitioned handles: the vectors live in the distributed form of bicgstab_permuted (a rank's own rows, the root's rows
+  // replicated, zeros elsewhere); every inner product runs over the rows a rank accounts for and is summed over the ranks,
+  // so the Hessenberg matrix, the rotations and the convergence state are the same on all ranks.
+  const bool dist = h->partitioned && exchanges(h);
+  const unsigned char* kinds = dist ? h->rowkind_p.p : nullptr;
+  const int lead = h->lead ? 1 : 0;
   auto precond = [&](const double* in, double* out) -> int {
     hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, in, h->buf.p);
+    if (dist) hipLaunchKernelGGL(fc_mask_rows, dim3(g), dim3(256), 0, h->stream, N, kinds, lead, h->buf.p);  // root rows: summed by the apply
     FCCHK(apply_factors(h, S));
     hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->buf.p + N, out);
+    if (dist) hipLaunchKernelGGL(fc_mask_rows, dim3(g), dim3(256), 0, h->stream, N, kinds, 1, out);  // other ranks' rows: zero
     return FC_OK;
   };
   auto matvec = [&](const double* in, double* out) -> int {
-    const int nb = launch_spmv<0>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, in, nullptr, out, nullptr, nullptr);
-    return nb < 0 ? nb : FC_OK;
+    const int nb = launch_spmv<0>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, in, nullptr, out, nullptr, nullptr, kinds);
+    if (nb < 0) return nb;
+    if (dist) {  // the root's rows: every rank's share over the columns it accounts for, summed over the ranks
+      hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, in, h->tmpN.p);
+      hipLaunchKernelGGL(fc_mask_rows, dim3(g), dim3(256), 0, h->stream, N, kinds, lead, h->tmpN.p);
+      const int nb2 = launch_spmv<0>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, h->tmpN.p, nullptr, h->xsol.p, nullptr, nullptr,
+                                     h->rootmask_p.p);
+      if (nb2 < 0) return nb2;
+      if (S.ar_n > 0) {
+        hipLaunchKernelGGL(fc_copy, dim3(nblocks(S.ar_n, 256)), dim3(256), 0, h->stream, S.ar_n, h->xsol.p + S.ar_row0, out + S.ar_row0);
+        FCCHK(exchange(h, out + S.ar_row0, (size_t)S.ar_n));
+      }
+    }
+    return FC_OK;
   };
-  auto begin_cycle = [&](int first) {
-    hipLaunchKernelGGL(fc_dots2, dim3(gd), dim3(256), 0, h->stream, N, r, r, h->b.p, h->b.p, h->partial.p);
+  // |r|^2 -> ks[KS_D0], |b|^2 -> ks[KS_D1]
+  auto norms = [&]() -> int {
+    hipLaunchKernelGGL(fc_dots2, dim3(gd), dim3(256), 0, h->stream, N, r, r, h->b.p, h->b.p, h->partial.p, kinds, lead);
     hipLaunchKernelGGL(fc_bicg_phase, dim3(1), dim3(256), 0, h->stream, -1, gd, h->partial.p, ks, h->rtol, 1, 0);
+    if (dist) FCCHK(exchange(h, ks + KS_D0, 2));
+    return FC_OK;
+  };
+  // out[i] = V_i . w for i < nv (summed over the ranks)
+  auto multidot = [&](int nv, const double* Vv, const double* ww, double* out) -> int {
+    hipLaunchKernelGGL(fc_multidot, dim3(gd, nv), dim3(256), 0, h->stream, N, nv, Vv, ww, h->mdot.p, ks, kinds, lead);
+    hipLaunchKernelGGL(fc_multidot_reduce, dim3(nv), dim3(64), 0, h->stream, nv, gd, h->mdot.p, out, 0, ks);
+    if (dist) FCCHK(exchange(h, out, (size_t)nv));
+    return FC_OK;
+  };
+  auto begin_cycle = [&](int first) -> int {
+    FCCHK(norms());
     hipLaunchKernelGGL(fc_gmres_begin, dim3(1), dim3(1), 0, h->stream, m, gm, ks, h->rtol, first);
     hipLaunchKernelGGL(fc_scale_by_norm, dim3(g), dim3(256), 0, h->stream, N, r, norm2, V, ks);
+    return FC_OK;
   };
   HIPCHK(hipMemsetAsync(ks, 0, KS_SIZE * sizeof(double), h->stream));
   HIPCHK(hipMemsetAsync(gm, 0, gm_n * sizeof(double), h->stream));
   HIPCHK(hipMemsetAsync(x, 0, (size_t)N * sizeof(double), h->stream));
   hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, r);
-  begin_cycle(1);
+  FCCHK(begin_cycle(1));
   double kh[KS_SIZE];
   *iters = 0;
   *relres = 0.0;
@@ -1092,15 +1126,12 @@ int gmres_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
       FCCHK(precond(vj, z));
       FCCHK(matvec(z, w));
       // classical Gram-Schmidt, twice: h = V^T w, w -= V h; h2 = V^T w, w -= V h2; Hessenberg column = h + h2
-      hipLaunchKernelGGL(fc_multidot, dim3(gd, j + 1), dim3(256), 0, h->stream, N, j + 1, V, w, h->mdot.p, ks);
-      hipLaunchKernelGGL(fc_multidot_reduce, dim3(j + 1), dim3(64), 0, h->stream, j + 1, gd, h->mdot.p, hcol, 0, ks);
+      FCCHK(multidot(j + 1, V, w, hcol));
       hipLaunchKernelGGL(fc_gmres_project, dim3(g), dim3(256), 0, h->stream, N, j + 1, V, hcol, w, ks);
-      hipLaunchKernelGGL(fc_multidot, dim3(gd, j + 1), dim3(256), 0, h->stream, N, j + 1, V, w, h->mdot.p, ks);
-      hipLaunchKernelGGL(fc_multidot_reduce, dim3(j + 1), dim3(64), 0, h->stream, j + 1, gd, h->mdot.p, hcol2, 0, ks);
-      hipLaunchKernelGGL(fc_multidot_reduce, dim3(j + 1), dim3(64), 0, h->stream, j + 1, gd, h->mdot.p, hcol, 1, ks);
+      FCCHK(multidot(j + 1, V, w, hcol2));
+      hipLaunchKernelGGL(fc_small_add, dim3(nblocks(j + 1, 64)), dim3(64), 0, h->stream, j + 1, hcol2, hcol, ks);
       hipLaunchKernelGGL(fc_gmres_project, dim3(g), dim3(256), 0, h->stream, N, j + 1, V, hcol2, w, ks);
-      hipLaunchKernelGGL(fc_multidot, dim3(gd, 1), dim3(256), 0, h->stream, N, 1, w, w, h->mdot.p, ks);
-      hipLaunchKernelGGL(fc_multidot_reduce, dim3(1), dim3(64), 0, h->stream, 1, gd, h->mdot.p, norm2, 0, ks);
+      FCCHK(multidot(1, w, w, norm2));
       hipLaunchKernelGGL(fc_gmres_givens, dim3(1), dim3(1), 0, h->stream, j, m, gm, ks, h->rtol);
       hipLaunchKernelGGL(fc_scale_by_norm, dim3(g), dim3(256), 0, h->stream, N, w, norm2, V + (size_t)(j + 1) * N, ks);
       if ((j + 1) % kKrylovCheck == 0 || j + 1 == m || total + 1 == h->max_iter) {
@@ -1135,11 +1166,10 @@ int gmres_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
     } else if (total >= h->max_iter) {
       done = true;
     } else {
-      begin_cycle(0);
+      FCCHK(begin_cycle(0));
     }
   }
-  hipLaunchKernelGGL(fc_dots2, dim3(gd), dim3(256), 0, h->stream, N, r, r, h->b.p, h->b.p, h->partial.p);
-  hipLaunchKernelGGL(fc_bicg_phase, dim3(1), dim3(256), 0, h->stream, -1, gd, h->partial.p, ks, h->rtol, 1, 0);
+  FCCHK(norms());  // the same masked sums and exchange on every rank: all ranks report the same residual
   FCCHK(krylov_state(h, kh));
   *iters = (int)kh[KS_ITERS];
   const double bnorm = std::sqrt(kh[KS_D1]);
@@ -1165,7 +1195,13 @@ int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, 
   if (h->method != FC_METHOD_REFINE) {
     // Krylov solve inside the step (the memory-lean path: truncated factors as preconditioner; or lagged factors):
     // the drivers synchronise with the host every few iterations; the residual monitor of the tail checks the result
-    if (h->partitioned) return fail(FC_ERR_INVALID, "the Krylov drivers are not available on a partitioned handle");
+    if (h->partitioned) {
+      // the assembled right-hand side holds this rank's rows in full and its PARTIAL sums of the root's rows: the Krylov
+      // vectors want the root's rows complete on every rank and zeros on the other ranks' rows
+      if (!exchanges(h)) return fail(FC_ERR_INVALID, "partitioned handle without an exchange");
+      if (S.ar_n > 0) FCCHK(exchange(h, h->b.p + S.ar_row0, (size_t)S.ar_n));
+      hipLaunchKernelGGL(fc_mask_rows, dim3(nblocks(h->N, 256)), dim3(256), 0, h->stream, h->N, h->rowkind_p.p, 1, h->b.p);
+    }
     int iters = 0;
     double relres = 0.0;
     FCCHK(h->method == FC_METHOD_GMRES ? gmres_permuted(h, S, &iters, &relres) : bicgstab_permuted(h, S, &iters, &relres));
@@ -2606,7 +2642,7 @@ int fc_setup_solver(fc_handle h, int slot, int32_t depth, int32_t merge, int32_t
   if (truncate == 0 && h->sys[slot].bits != 64) {
     // compressed factors: the acceptance solve goes through GMRES (they are a preconditioner): it must converge in a
     // handful of iterations, or the rounded factors are no good for this operator
-    if (world > 1) return fail(FC_ERR_INVALID, "fc_setup_solver: compressed factors need a single-GPU handle");
+    if (world > 1 && !exchanges(h)) return fail(FC_ERR_INVALID, "fc_setup_solver: compressed factors on a partitioned handle need its exchange first (the acceptance solve is a collective GMRES)");
     std::vector<double> b((size_t)N), x((size_t)N);
     for (int i = 0; i < N; ++i) b[i] = std::cos(0.37 * i + 0.1);
     if (h->pin_dof >= 0)
@@ -3171,7 +3207,6 @@ static int solve_once(fc_handle h, int slot, const double* b, double* x, double*
     // every rank was handed the whole right-hand side: keep the rows this rank accounts for (its own, and the root's on
     // the lead rank -- the apply sums the root rows over the ranks; the Krylov vectors keep the root rows on every rank),
     // solve, then merge the ranks' parts of the solution
-    if (h->method == FC_METHOD_GMRES) return fail(FC_ERR_INVALID, "fc_solve: GMRES is not available on a partitioned handle (use FC_METHOD_BICGSTAB)");
     hipLaunchKernelGGL(fc_mask_rows, dim3(g), dim3(256), 0, h->stream, N, h->rowkind_p.p, krylov ? 1 : (h->lead ? 1 : 0), h->b.p);
   }
   hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, h->buf.p);

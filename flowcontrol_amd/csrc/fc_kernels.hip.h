@@ -1302,13 +1302,22 @@ __global__ __launch_bounds__(256) void fc_bicg_phase(int phase, int nblk, const 
 }
 
 // GMRES(m): h[i] = V_i . w for i < nv (one block per (vector, chunk); partial[i * gx + blockIdx.x])
+// (multi-GPU: rowkind != nullptr restricts the sums to the rows this rank accounts for, as fc_dots2)
 __global__ __launch_bounds__(256) void fc_multidot(int n, int nv, const double* __restrict__ V, const double* __restrict__ w,
-                                                   double* __restrict__ partial, const double* __restrict__ ks) {
+                                                   double* __restrict__ partial, const double* __restrict__ ks,
+                                                   const unsigned char* __restrict__ rowkind = nullptr, int lead = 1) {
   if (ks[KS_STATE] != 0.0) return;
   const int i = blockIdx.y;
   const double* __restrict__ v = V + (size_t)i * n;
   double s = 0.0;
-  for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) s += v[k] * w[k];
+  if (rowkind) {
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+      const int kind = rowkind[k];
+      if (kind == 1 || (kind == 2 && lead)) s += v[k] * w[k];
+    }
+  } else {
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) s += v[k] * w[k];
+  }
   __shared__ double red[256];
   red[threadIdx.x] = s;
   __syncthreads();
@@ -1327,6 +1336,12 @@ __global__ void fc_multidot_reduce(int nv, int gx, const double* __restrict__ pa
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   if (threadIdx.x == 0 && i < nv) h[i] = accumulate ? h[i] + s : s;
+}
+// h[i] += h2[i]: the second Gram-Schmidt pass joins the Hessenberg column
+__global__ void fc_small_add(int nv, const double* __restrict__ h2, double* __restrict__ h, const double* __restrict__ ks) {
+  if (ks[KS_STATE] != 0.0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nv) h[i] += h2[i];
 }
 // w -= sum_i h[i] V_i
 __global__ void fc_gmres_project(int n, int nv, const double* __restrict__ V, const double* __restrict__ h, double* w,
