@@ -307,19 +307,24 @@ __global__ __launch_bounds__(256) void fc_fe_update(const FcFront* __restrict__ 
 }
 
 // factor rows [D^-1 | -U] (stride nf) and the -L block (nb x ni, stride ni) into the layout the sweeps read, in the
-// storage type of the slot (double, or rounded once to float / bfloat16: compressed factors, fc_kernels.hip.h)
+// storage type of the slot (double, or rounded once to float / bfloat16: compressed factors, fc_kernels.hip.h).
+// Of the pivot rows only [xr0, xr1) are written, row xr0 first (all of them: 0, INT_MAX; the root of a multi-GPU layout: the
+// handle's block, fc_set_root_rows).
 template <typename VT>
-__global__ __launch_bounds__(256) void fc_fe_export(const FcFront* __restrict__ nodes, const double* __restrict__ fronts, VT* __restrict__ fvals) {
+__global__ __launch_bounds__(256) void fc_fe_export(const FcFront* __restrict__ nodes, const double* __restrict__ fronts, VT* __restrict__ fvals,
+                                                    int xr0, int xr1) {
   const FcFront nd = nodes[blockIdx.y];
   const int nf = nd.nf, ni = nd.ni;
   const int i0 = blockIdx.x * 16;
   if (i0 >= nf || ni == 0) return;
   const double* A = fronts + nd.front;
   VT* dv = fvals + nd.voff;
-  VT* mw = dv + (size_t)ni * nf;
+  const int stored = (xr1 < ni ? xr1 : ni) - xr0;  // pivot rows with storage
+  VT* mw = dv + (size_t)stored * nf;
   for (int i = i0; i < i0 + 16 && i < nf; ++i) {
     if (i < ni) {
-      for (int j = threadIdx.x; j < nf; j += 256) dv[(size_t)i * nf + j] = fc_pack<VT>(j < ni ? A[(size_t)i * nf + j] : -A[(size_t)i * nf + j]);
+      if (i < xr0 || i >= xr1) continue;
+      for (int j = threadIdx.x; j < nf; j += 256) dv[(size_t)(i - xr0) * nf + j] = fc_pack<VT>(j < ni ? A[(size_t)i * nf + j] : -A[(size_t)i * nf + j]);
     } else {
       for (int j = threadIdx.x; j < ni; j += 256) mw[(size_t)(i - ni) * ni + j] = fc_pack<VT>(A[(size_t)i * nf + j]);
     }

@@ -255,6 +255,7 @@ struct fc_ctx {
     int level, nf, ni, parent;
   };
   bool have_plan = false;
+  int root_x0 = -1, root_xn = 0;  // multi-GPU: of the root's pivot rows (0-based inside its block) this handle stores [root_x0, root_x0 + root_xn) only (fc_set_root_rows); -1: all
   std::vector<PlanNode> pnodes;
   std::vector<int64_t> plevel_ptr, pa_ptr;
   std::vector<std::vector<std::pair<int64_t, int>>> pext_groups;  // per (level, slot): (first FcExt, count)
@@ -2002,7 +2003,8 @@ int fc_solver_set_dag(fc_handle h, int slot, int32_t n_nodes, const int64_t* nod
     d.voff = r[5];
     d.ioff = r[6];
     if (d.ni <= 0 || d.nb < 0 || d.i0 < 0 || (int64_t)d.i0 + d.ni > N || d.voff < 0 ||
-        d.voff + (int64_t)d.ni * (d.ni + d.nb) > n_val || (d.nb > 0 && (d.ioff < 0 || d.ioff + d.nb > n_idx)))
+        d.voff + (int64_t)((d.level == 0 && d.nb == 0 && h->root_x0 >= 0) ? h->root_xn : d.ni) * (d.ni + d.nb) > n_val ||
+        (d.nb > 0 && (d.ioff < 0 || d.ioff + d.nb > n_idx)))
       return fail(FC_ERR_INVALID, "fc_solver_set_dag: node table out of range");
     if (dn_dep[g] >= n_nodes || up_dep_ptr[g] < 0 || up_dep_ptr[g + 1] < up_dep_ptr[g])
       return fail(FC_ERR_INVALID, "fc_solver_set_dag: dependency table out of range");
@@ -2111,7 +2113,7 @@ int fc_solver_set_dag(fc_handle h, int slot, int32_t n_nodes, const int64_t* nod
           t.nrows = std::min(R, r_hi - r0);
           t.dest0 = N + d.i0 + r0;
           t.stride = wd;
-          t.val = (long long)(d.voff + (int64_t)r0 * wd);
+          t.val = (long long)(d.voff + (int64_t)(r0 - ((d.level == 0 && d.nb == 0 && h->root_x0 >= 0) ? h->root_x0 : 0)) * wd);
           t.i0 = d.i0;
           t.ni = d.ni;
           t.ioff = (int)d.ioff;
@@ -2358,6 +2360,13 @@ int fc_set_front_shifts(fc_handle h, int32_t n, const int64_t* slots, const doub
   return FC_OK;
 }
 
+int fc_set_root_rows(fc_handle h, int32_t first, int32_t count) {
+  if (!h || first < -1 || (first >= 0 && count < 0)) return fail(FC_ERR_INVALID, "fc_set_root_rows: bad argument");
+  h->root_x0 = first;
+  h->root_xn = first >= 0 ? count : 0;
+  return FC_OK;
+}
+
 int fc_refactor(fc_handle h, int slot, double* ms_out) {
   if (!h || slot < 0 || slot > 1) return fail(FC_ERR_INVALID, "fc_refactor: bad argument");
   if (!h->have_plan) return fail(FC_ERR_NOT_READY, "fc_factor_plan not called");
@@ -2365,9 +2374,14 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
   if (!S.structured) return fail(FC_ERR_NOT_READY, "fc_solver_setup (structure) must be called first");
   if ((int64_t)h->pap_src.n != S.Ap_nnz) return fail(FC_ERR_INVALID, "fc_refactor: plan and solver structure disagree (matrix)");
   HIPCHK(hipSetDevice(h->device));
-  for (const fc_ctx::PlanNode& nd : h->pnodes) {
+  for (size_t g = 0; g < h->pnodes.size(); ++g) {
+    const fc_ctx::PlanNode& nd = h->pnodes[g];
     const int nb = nd.nf - nd.ni;
-    if (nd.ni > 0 && nd.voff + (int64_t)nd.ni * nd.nf + (int64_t)nb * nd.ni > S.f_nnz)
+    const bool root_block = h->root_x0 >= 0 && g + 1 == h->pnodes.size();
+    if (root_block && (nd.parent >= 0 || nb != 0 || h->root_x0 + h->root_xn > nd.ni))
+      return fail(FC_ERR_INVALID, "fc_refactor: fc_set_root_rows needs a root without boundary and rows inside its pivot block");
+    const int64_t rows = root_block ? h->root_xn : nd.ni;
+    if (nd.ni > 0 && nd.voff + rows * nd.nf + (int64_t)nb * nd.ni > S.f_nnz)
       return fail(FC_ERR_INVALID, "fc_refactor: plan and solver structure disagree (factor values)");
   }
   HIPCHK(hipEventRecord(h->ev0, h->stream));
@@ -2438,12 +2452,15 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
           hipLaunchKernelGGL(fc_fe_update<FC_FE_KB>, dim3(ct * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
         }
       }
+      // (the root of a multi-GPU layout: only this handle's block of pivot rows has storage)
+      const bool root_block = li == n_levels - 1 && h->root_x0 >= 0;
+      const int xr0 = root_block ? h->root_x0 : 0, xr1 = root_block ? h->root_x0 + h->root_xn : INT_MAX;
       if (S.bits == 64)
-        hipLaunchKernelGGL(fc_fe_export<double>, dim3((nfmax + 15) / 16, grp.second), dim3(256), 0, h->stream, fp, F, fv);
+        hipLaunchKernelGGL(fc_fe_export<double>, dim3((nfmax + 15) / 16, grp.second), dim3(256), 0, h->stream, fp, F, fv, xr0, xr1);
       else if (S.bits == 32)
-        hipLaunchKernelGGL(fc_fe_export<float>, dim3((nfmax + 15) / 16, grp.second), dim3(256), 0, h->stream, fp, F, S.f_val32.p);
+        hipLaunchKernelGGL(fc_fe_export<float>, dim3((nfmax + 15) / 16, grp.second), dim3(256), 0, h->stream, fp, F, S.f_val32.p, xr0, xr1);
       else
-        hipLaunchKernelGGL(fc_fe_export<FcBf16>, dim3((nfmax + 15) / 16, grp.second), dim3(256), 0, h->stream, fp, F, S.f_val16.p);
+        hipLaunchKernelGGL(fc_fe_export<FcBf16>, dim3((nfmax + 15) / 16, grp.second), dim3(256), 0, h->stream, fp, F, S.f_val16.p, xr0, xr1);
       HIPCHK(hipGetLastError());
     }
   }
@@ -2587,7 +2604,14 @@ int fc_setup_solver(fc_handle h, int slot, int32_t depth, int32_t merge, int32_t
       if (truncate > h->sym_tree.depth) return fail(FC_ERR_INVALID, "fc_setup_solver: truncate exceeds the tree depth");
       FCCHK(fc_set_permutation(h, h->sym_tree.perm.data()));
       FCCHK(upload_energy_matrix(h));
-      h->sym_fac = fcsym::layout_factors(h->sym_tree, keep);
+      if (world > 1) {  // of the root's pivot-block inverse a rank stores the rows it applies
+        const auto rr = fcsym::root_row_block(h->sym_tree, rank, world);
+        h->sym_fac = fcsym::layout_factors(h->sym_tree, keep, rr.first, rr.second);
+        FCCHK(fc_set_root_rows(h, (int)(rr.first - h->sym_tree.node_ptr[0].front()), (int)(rr.second - rr.first)));
+      } else {
+        h->sym_fac = fcsym::layout_factors(h->sym_tree, keep);
+        FCCHK(fc_set_root_rows(h, -1, 0));
+      }
       if (truncate > 0)
         for (int k = 0; k < truncate; ++k) h->sym_fac.stage_kind[(size_t)h->sym_tree.depth + k] = 2;
       h->sym_plan = fcsym::factor_plan(h->sym_tree, h->sym_fac, h->h_rowptr, h->h_col, &skip, keep);
@@ -2731,7 +2755,8 @@ int fc_sym_build(int32_t nv, int32_t ne, int32_t nc, const double* coords, const
     fcsym::Keep keep;
     if (world > 1) keep = [&t, rank, top](int k, int n) { return k == 0 || (n >> (t.cum[k] - top)) == rank; };
     if (truncate > 0) keep = [truncate](int k, int) { return k >= truncate; };
-    fcsym::Factors fac = fcsym::layout_factors(t, keep);
+    const auto rr = fcsym::root_row_block(t, rank, world);
+    fcsym::Factors fac = world > 1 && truncate == 0 ? fcsym::layout_factors(t, keep, rr.first, rr.second) : fcsym::layout_factors(t, keep);
     lap("layout_factors", t0);
     if (truncate > 0)
       for (int k = 0; k < truncate; ++k) fac.stage_kind[(size_t)t.depth + k] = 2;

@@ -207,11 +207,23 @@ struct Factors {  // ndsolver.BlockFactors, structure only
   std::vector<int64_t> seg_val, seg_ptr, stage_begin;
   std::vector<int> seg_col, seg_len, stage_row0, stage_nrows, stage_kind;
   std::vector<int64_t> nodes;  // [n][7]: level, n, i0, ni, nb, val_off, idx_off
+  int64_t root_lo = -1, root_hi = -1;  // multi-GPU: the only stored rows of the root's pivot-block inverse (val_off of the root = row root_lo); -1: all
 };
 
-// ndsolver.factorize_blocks(None, tree, numeric=False, keep)
-inline Factors layout_factors(const Tree& t, const Keep& keep) {
+// ndsolver.root_row_block: the rows of the root's pivot-block inverse that rank `rank` applies (and stores)
+inline std::pair<int64_t, int64_t> root_row_block(const Tree& t, int rank, int world) {
+  const int64_t lo = t.node_ptr[0].front(), hi = t.node_ptr[0].back();
+  if (world <= 1) return {lo, hi};
+  const int64_t blk = (hi - lo + world - 1) / world;
+  const int64_t a = std::min(hi, lo + rank * blk);
+  return {a, std::min(hi, a + blk)};
+}
+
+// ndsolver.factorize_blocks(None, tree, numeric=False, keep)  (root_lo >= 0: keep.root_rows = (root_lo, root_hi))
+inline Factors layout_factors(const Tree& t, const Keep& keep, int64_t root_lo = -1, int64_t root_hi = -1) {
   Factors f;
+  f.root_lo = root_lo;
+  f.root_hi = root_hi;
   const int N = (int)t.perm.size();
   f.N = N;
   int64_t vpos = 0, ipos = 0;
@@ -246,14 +258,18 @@ inline Factors layout_factors(const Tree& t, const Keep& keep) {
         vpos += nb * ni;
         f.nnz += ni * ni + 2 * ni * nb;
       } else {
+        // stored rows [a, b): all of them, or (the root of a multi-GPU layout) this rank's block
+        const int64_t a = (k != 0 || root_lo < 0) ? i0 : std::max(i0, root_lo), b = (k != 0 || root_lo < 0) ? i1 : std::min(i1, root_hi);
+        const int64_t nst = std::max<int64_t>(0, b - a);
         f.nodes.insert(f.nodes.end(), {k, n, i0, ni, 0, vpos, 0});
-        for (int64_t r = 0; r < ni; ++r) {
-          dn_val[(size_t)(i0 + r)] = {vpos + r * ni, 0};
-          dn_col[(size_t)(i0 + r)] = {(int)i0, 0};
-          dn_len[(size_t)(i0 + r)] = {(int)ni, 0};
+        for (int64_t r = i0; r < i1; ++r) {
+          const bool stored = r >= a && r < b;
+          dn_val[(size_t)r] = {stored ? vpos + (r - a) * ni : vpos, 0};
+          dn_col[(size_t)r] = {(int)i0, 0};
+          dn_len[(size_t)r] = {stored ? (int)ni : 0, 0};
         }
-        vpos += ni * ni;
-        f.nnz += ni * ni;
+        vpos += nst * ni;
+        f.nnz += nst * ni;
       }
     }
   f.n_val = vpos;
@@ -603,8 +619,9 @@ inline Blocks down_blocks(const Tree& t, const Factors& fac, int rank, int world
       const int64_t i0 = fac.nodes[q * 7 + 2], ni = fac.nodes[q * 7 + 3], nb = fac.nodes[q * 7 + 4], voff = fac.nodes[q * 7 + 5], ioff = fac.nodes[q * 7 + 6];
       const int64_t wd = ni + nb;
       const int64_t first = std::max<int64_t>(0, lo - i0), last = std::min<int64_t>(ni, hi - i0);
+      const int64_t skipped = (k == 0 && fac.root_lo >= 0) ? fac.root_lo - i0 : 0;  // root rows before the stored block
       for (int64_t r0 = first; r0 < last; r0 += rc) {
-        B.val.push_back(voff + r0 * wd);
+        B.val.push_back(voff + (r0 - skipped) * wd);
         B.row0.push_back((int)(i0 + r0));
         B.nrows.push_back((int)std::min<int64_t>(rc, last - r0));
         B.i0.push_back((int)i0);

@@ -273,6 +273,8 @@ class DeviceSolver:
                 self._h, int(pl.nodes.shape[0]), pl.nodes, int(pl.level_ptr.size - 1), pl.level_ptr, int(pl.front_size),
                 int(pl.a_src.size), pl.a_src if pl.a_src.size else np.zeros(1, np.int64), pl.a_dst if pl.a_dst.size else np.zeros(1, np.int64),
                 pl.a_ptr, pl.ext_off, int(pl.ext_p.size), pl.ext_p, int(pl.ap_src.size), pl.ap_src, int(pl.max_slots)))
+            rr = pl.root_rows  # a rank stores only the rows of the root's pivot-block inverse that it applies
+            check(self.lib.fc_set_root_rows(self._h, -1 if rr is None else rr[0] - int(t.node_ptr[0][0]), 0 if rr is None else rr[1] - rr[0]))
             self._plan = pl
             if truncate:  # the top levels' down stages become diagonal stages
                 self._fac_struct.stage_kind[t.depth : t.depth + truncate] = 2

@@ -187,16 +187,32 @@ class BlockFactors:
     # per tree node with rows (for the LDS-tiled down-sweep kernel): level, node id, first row, rows,
     # boundary size, offset of its [D⁻¹ | −U] rows in ``vals`` (row stride ni+nb), offset of its index list
     nodes: np.ndarray | None = None  # (n_nodes, 7) int64: level, n, i0, ni, nb, val_off, idx_off
+    #: multi-GPU: rows [lo, hi) of the root's pivot-block inverse are the only ones stored (val_off of the root = row lo)
+    root_rows: tuple[int, int] | None = None
+
+
+def root_row_block(tree: NDTree, rank: int, world: int) -> tuple[int, int]:
+    """Rows [lo, hi) (permuted numbering) of the root's pivot-block inverse that rank ``rank`` applies — and therefore the
+    only ones it stores: ceil(|root| / world) consecutive rows per rank."""
+    lo, hi = int(tree.node_ptr[0][0]), int(tree.node_ptr[0][-1])
+    if world <= 1:
+        return lo, hi
+    blk = -(-(hi - lo) // world)
+    a = min(hi, lo + rank * blk)
+    return a, min(hi, a + blk)
 
 
 def rank_keeps(tree: NDTree, rank: int, world: int):
     """Predicate (level, node) → this rank stores and factorises the node: its own sub-tree of the ``world``-ary
-    root, and the root itself."""
+    root, and the root itself — of whose pivot-block inverse it STORES only the rows it applies
+    (``keep.root_rows``, :func:`root_row_block`; every rank still eliminates the whole root front)."""
     p = int(np.log2(world)) if world > 1 else 0
 
     def keep(k: int, n: int) -> bool:
         return world == 1 or k == 0 or (n >> (tree.cum[k] - p)) == rank
 
+    if world > 1:
+        keep.root_rows = root_row_block(tree, rank, world)
     return keep
 
 
@@ -205,8 +221,11 @@ def factorize_blocks(A: sp.csr_matrix | None, tree: NDTree, numeric: bool = Fals
     ignored and may be None).  The VALUES are computed on the device (:func:`factor_plan`, ``fc_refactor``); the numeric
     host multifrontal that used to live here is test infrastructure now (``tests/support/nd_numeric.py``).
     ``keep(level, node)``: nodes for which it is False get no storage at all — a rank of a multi-GPU run lays out its own
-    sub-tree and the root (:func:`rank_keeps`), so its factor array is ~1/world of the whole."""
+    sub-tree and the root (:func:`rank_keeps`), so its factor array is ~1/world of the whole.  ``keep.root_rows = (lo, hi)``:
+    of the root's pivot-block inverse only the rows [lo, hi) get storage (at the root's value offset, row ``lo`` first);
+    the other root rows get empty segments."""
     t = tree
+    root_rows = getattr(keep, "root_rows", None)
     if numeric:
         raise ValueError("the product lays out structure only: the numeric host multifrontal is tests/support/nd_numeric.py")
     N = int(t.perm.size)
@@ -249,12 +268,15 @@ def factorize_blocks(A: sp.csr_matrix | None, tree: NDTree, numeric: bool = Fals
                 vpos += nb * ni
                 nnz += ni * ni + 2 * ni * nb
             else:
-                vals_chunks.append(np.zeros(ni * ni))
+                a, b = (i0, i1) if (k != 0 or root_rows is None) else (max(i0, root_rows[0]), min(i1, root_rows[1]))
+                nst = max(0, b - a)  # stored rows: all of them, or this rank's block of the root
+                vals_chunks.append(np.zeros(nst * ni))
                 node_rows.append((k, n, i0, ni, 0, vpos, 0))
-                dn_val[rows, 0] = vpos + np.arange(ni) * ni
-                vpos += ni * ni
-                dn_col[rows, 0], dn_len[rows, 0] = i0, ni
-                nnz += ni * ni
+                stored = (rows >= a) & (rows < b)
+                dn_val[rows, 0] = np.where(stored, vpos + (rows - a) * ni, vpos)
+                vpos += nst * ni
+                dn_col[rows, 0], dn_len[rows, 0] = i0, np.where(stored, ni, 0)
+                nnz += nst * ni
     vals = np.concatenate(vals_chunks) if vals_chunks else np.zeros(0)
     idx = np.concatenate(idx_chunks) if idx_chunks else np.zeros(0, dtype=np.int32)
     # up segments grouped by destination row (stable ⇒ fixed summation order: deeper nodes first)
@@ -296,7 +318,7 @@ def factorize_blocks(A: sp.csr_matrix | None, tree: NDTree, numeric: bool = Fals
         seg_len=np.ascontiguousarray(np.concatenate(seg_len), dtype=np.int32),
         seg_ptr=seg_ptr, stage_row0=np.array(row0, dtype=np.int32), stage_nrows=nrows,
         stage_kind=np.array(kind, dtype=np.int32), stage_begin=begin, nnz=int(nnz),
-        nodes=np.array(node_rows, dtype=np.int64).reshape(-1, 7),
+        nodes=np.array(node_rows, dtype=np.int64).reshape(-1, 7), root_rows=root_rows,
     )
 
 
@@ -323,6 +345,7 @@ class FactorPlan:
     ap_src: np.ndarray  # (nnz of the permuted matrix,) int64
     max_slots: int
     node_i0: np.ndarray | None = None  # (n_nodes,) first permuted dof of every plan node
+    root_rows: tuple[int, int] | None = None  # multi-GPU: stored rows of the root's pivot-block inverse (fc_set_root_rows)
 
 
 def factor_plan(fac: BlockFactors, indptr: np.ndarray, indices: np.ndarray, skip: np.ndarray | None = None, keep=None) -> FactorPlan:
@@ -425,7 +448,7 @@ def factor_plan(fac: BlockFactors, indptr: np.ndarray, indices: np.ndarray, skip
     return FactorPlan(nodes=np.ascontiguousarray(nodes), level_ptr=level_ptr, front_size=int(front_off[-1]),
                       a_src=np.ascontiguousarray(src), a_dst=np.ascontiguousarray(a_dst), a_ptr=np.ascontiguousarray(a_ptr, dtype=np.int64),
                       ext_off=ext_off, ext_p=np.ascontiguousarray(ext_p), ap_src=np.ascontiguousarray(ap_src), max_slots=max_slots,
-                      node_i0=i0s.copy())
+                      node_i0=i0s.copy(), root_rows=fac.root_rows)
 
 
 def front_diagonal_slot(plan: FactorPlan, tree: NDTree, dof: int) -> int:
@@ -525,9 +548,10 @@ def down_blocks(fac: BlockFactors, rank: int = 0, world: int = 1, max_rows: int 
         for _, n, i0, ni, nb, voff, ioff in sel:
             wd = ni + nb
             first, last = max(0, lo - int(i0)), min(int(ni), hi - int(i0))
+            skipped = (fac.root_rows[0] - int(i0)) if (k == 0 and fac.root_rows is not None) else 0  # root rows before the stored block
             for r0 in range(first, last, rc):
                 nr = min(rc, last - r0)
-                for lst, v in zip(cols, (voff + r0 * wd, i0 + r0, nr, i0, ni, ioff, nb)):
+                for lst, v in zip(cols, (voff + (r0 - skipped) * wd, i0 + r0, nr, i0, ni, ioff, nb)):
                     lst.append(int(v))
                 nblk += 1
         count[s] = nblk - begin[s]

@@ -217,6 +217,11 @@ int fc_factor_plan(fc_handle h, int32_t n_nodes, const int64_t* nodes, int32_t n
                    const int64_t* a_ptr, const int64_t* ext_off, int64_t n_ext, const int32_t* ext_p,
                    int64_t n_ap, const int64_t* ap_src, int32_t max_slots);
 int fc_refactor(fc_handle h, int slot, double* ms_out);
+/* Multi-GPU layouts made outside fc_setup_solver: of the ROOT's pivot-block inverse (the last plan node; every rank
+ * eliminates the whole root front) this handle stores only the pivot rows [first, first + count) (0-based inside the
+ * root's block) -- the rows it applies in the root's down stage -- at the root's value offset, row `first` first.
+ * first = -1: all rows (single GPU).  Call before fc_refactor; fc_setup_solver does it itself. */
+int fc_set_root_rows(fc_handle h, int32_t first, int32_t count);
 /* values added to front entries (offsets into the front buffer of fc_factor_plan) after the matrix has
  * been scattered, in every later fc_refactor: a positive shift on ONE pressure diagonal selects the
  * solution with that pressure = 0 of an enclosed flow's singular system (lid-driven cavity; the reference

@@ -197,6 +197,9 @@ def factorize_with_plan(plan: FactorPlan, fac: BlockFactors, values: np.ndarray,
                 Fm[ni:, ni:] += mWt @ Fm[:ni, ni:]
                 vals[vo : vo + ni * nf] = np.hstack([Dinv, mVt]).ravel()
                 vals[vo + ni * nf : vo + ni * nf + nb * ni] = mWt.ravel()
+            elif plan.root_rows is not None and li == nlev - 1:
+                a, b = plan.root_rows[0] - int(plan.node_i0[g]), plan.root_rows[1] - int(plan.node_i0[g])
+                vals[vo : vo + (b - a) * ni] = Dinv[a:b].ravel()  # this rank's rows of the root's pivot-block inverse
             else:
                 vals[vo : vo + ni * ni] = Dinv.ravel()
     return vals
