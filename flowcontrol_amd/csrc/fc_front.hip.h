@@ -6,7 +6,7 @@
 // (= pivot-block inverse D^-1, the U block, the -L block and the Schur complement the parent receives) by block
 // steps of KB pivot columns K = [k0, k0 + kb) (KB = 32 on levels of small fronts, where the pivot inversions' dependent
 // chain dominates; KB = 64 on levels whose largest front has order >= FC_FE_WIDE_NF: half the steps, twice the arithmetic per byte
-// of front touched by the trailing update):
+// of front touched by the trailing update; 128 columns -- the fc_fe_*_huge kernels below -- where that traffic is the bound):
 //     W        = A[K,K]^-1                      fc_fe_pivot   one workgroup per front: Gauss-Jordan in LDS with partial
 //                                                              pivoting inside the block (the inverse of the block
 //                                                              does not depend on the pivoting; it only needs it)
@@ -29,6 +29,13 @@
 #ifndef FC_FE_PIVOT_UNROLL
 #define FC_FE_PIVOT_UNROLL 8  // column steps per trip of the pivot-block loop: the row rotation costs one register move per entry and TRIP
 #endif
+#ifndef FC_FE_HUGE_NF
+#define FC_FE_HUGE_NF 1536   // a level takes 128-column steps (fc_fe_*_huge) when its largest front has at least this order
+#endif
+#ifndef FC_FE_HUGE_MB
+#define FC_FE_HUGE_MB 512.0  // ... or when the fronts of the level together hold at least this many MB (and the largest has order >= FC_FE_HUGE_MIN_NF)
+#endif
+#define FC_FE_HUGE_MIN_NF 256  // ... and never below this one (the scratch of such levels is sized for 64-column steps)
 #define FC_FE_KB_MAX 64      // scratch layout: W (KB_MAX x KB_MAX) then Cs (nf x KB_MAX), whatever KB a level uses
 
 struct __attribute__((aligned(16))) FcFront {
@@ -68,6 +75,69 @@ __device__ __forceinline__ unsigned fc_row_max_u32(unsigned v) {
   return o > v ? o : v;
 }
 
+// One wave inverts a KB x KB block held as lane r = row r (x[c] = its KB entries; lanes >= KB shadow the last row), in
+// place; kb <= KB valid rows / columns, the rest identity padding.  On return x holds the rows of the swept block and
+// piv[KB + c] (written by lane 0) the column of the swept block that is column c of the inverse (row exchanges undone).
+template <int KB>
+__device__ __forceinline__ void fc_fe_gj_wave(double (&x)[KB], int lane, int kb, int* piv) {
+  // A COMPACT loop over the KB columns (the fully unrolled form is 64 KB of straight-line code: instruction fetch then
+  // costs what the barriers cost before): every step works on register 0 and rotates the row by one position while it
+  // updates it — after KB steps the columns are back in place.  Steps k >= kb meet the identity padding: no-ops.
+  // One wave issues one instruction at a time, so a column step costs its instruction count:
+  //  * pivot search on a 32-bit key (upper word of |x|: exponent + 20 mantissa bits, the lane in the low 6 bits) reduced
+  //    with DPP row operations + one readlane per 16-lane row — no LDS permutes; the diagonal is kept whenever it is
+  //    within 8x of the largest candidate (threshold pivoting: a row exchange is 2 KB permutes), ties -> smallest row;
+  //  * 1 / pivot by v_rcp_f64 + two Newton steps;
+  //  * the pivot row is NOT scaled inside the loop (its lane multiplies by its 1 / pivot once, at the end: a scaled
+  //    row only ever acts on itself afterwards, so the scaling commutes with the later column steps): every entry
+  //    of the rank-1 update is then two scalar broadcasts (v_readlane) and one v_fma_f64 with g = x[0] / pivot.
+  double dsave = 1.0;
+#pragma clang loop unroll_count(FC_FE_PIVOT_UNROLL)
+  for (int k = 0; k < KB; ++k) {
+    const unsigned hi = (unsigned)__double2hiint(x[0]) & 0x7fffffffu;
+    const bool cand = k < kb ? (lane >= k && lane < kb) : lane == k;
+    const unsigned key = cand ? ((hi & ~63u) | (unsigned)(63 - lane)) : 0u;
+    unsigned m = fc_row_max_u32(key);
+    unsigned mw = (unsigned)__builtin_amdgcn_readlane((int)m, 0);
+#pragma unroll
+    for (int rw = 16; rw < KB; rw += 16) {
+      const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)m, rw);
+      mw = o > mw ? o : mw;
+    }
+    const unsigned kd = (unsigned)__builtin_amdgcn_readlane((int)key, k);
+    const int p = (mw >> 20) <= (kd >> 20) + 2u ? k : 63 - (int)(mw & 63u);
+    if (lane == 0) piv[k] = p;
+    if (p != k) {  // exchange rows k and p: a permute between two lanes
+      const int partner = lane == k ? p : (lane == p ? k : lane);
+#pragma unroll
+      for (int c = 0; c < KB; ++c) x[c] = __shfl(x[c], partner, 64);
+    }
+    const double pv = fc_readlane(x[0], k);
+    double d = __builtin_amdgcn_rcp(pv);
+    d = __builtin_fma(__builtin_fma(-pv, d, 1.0), d, d);
+    d = __builtin_fma(__builtin_fma(-pv, d, 1.0), d, d);
+    const bool isk = lane == k;
+    const double g = isk ? 0.0 : x[0] * d;  // this row's entry in the pivot column over the pivot
+    if (isk) dsave = d;
+#pragma unroll
+    for (int c = 1; c < KB; ++c) x[c - 1] = __builtin_fma(-g, fc_readlane(x[c], k), x[c]);
+    x[KB - 1] = isk ? 1.0 : -g;  // the swept pivot column takes the free slot at the end of the rotation
+  }
+#pragma unroll
+  for (int c = 0; c < KB; ++c) x[c] *= dsave;
+  if (lane == 0) {
+    for (int c = 0; c < KB; ++c) piv[KB + c] = c;
+    for (int k = kb - 1; k >= 0; --k) {
+      const int p = piv[k];
+      if (p != k) {
+        const int u = piv[KB + k];
+        piv[KB + k] = piv[KB + p];
+        piv[KB + p] = u;
+      }
+    }
+  }
+}
+
 template <int KB>
 __device__ __forceinline__ void fc_fe_pivot_block(const FcFront& nd, const double* fronts, double* __restrict__ scratch, int step,
                                                   double (*a)[KB + 1], int* piv) {
@@ -86,67 +156,11 @@ __device__ __forceinline__ void fc_fe_pivot_block(const FcFront& nd, const doubl
     double x[KB];
 #pragma unroll
     for (int c = 0; c < KB; ++c) x[c] = a[r][c];
-    // A COMPACT loop over the KB columns (the fully unrolled form is 64 KB of straight-line code: instruction fetch then
-    // costs what the barriers cost before): every step works on register 0 and rotates the row by one position while it
-    // updates it — after KB steps the columns are back in place.  Steps k >= kb meet the identity padding: no-ops.
-    // One wave issues one instruction at a time, so a column step costs its instruction count:
-    //  * pivot search on a 32-bit key (upper word of |x|: exponent + 20 mantissa bits, the lane in the low 6 bits) reduced
-    //    with DPP row operations + one readlane per 16-lane row — no LDS permutes; the diagonal is kept whenever it is
-    //    within 8x of the largest candidate (threshold pivoting: a row exchange is 2 KB permutes), ties -> smallest row;
-    //  * 1 / pivot by v_rcp_f64 + two Newton steps;
-    //  * the pivot row is NOT scaled inside the loop (its lane multiplies by its 1 / pivot once, at the end: a scaled
-    //    row only ever acts on itself afterwards, so the scaling commutes with the later column steps): every entry
-    //    of the rank-1 update is then two scalar broadcasts (v_readlane) and one v_fma_f64 with g = x[0] / pivot.
-    double dsave = 1.0;
-#pragma clang loop unroll_count(FC_FE_PIVOT_UNROLL)
-    for (int k = 0; k < KB; ++k) {
-      const unsigned hi = (unsigned)__double2hiint(x[0]) & 0x7fffffffu;
-      const bool cand = k < kb ? (lane >= k && lane < kb) : lane == k;
-      const unsigned key = cand ? ((hi & ~63u) | (unsigned)(63 - lane)) : 0u;
-      unsigned m = fc_row_max_u32(key);
-      unsigned mw = (unsigned)__builtin_amdgcn_readlane((int)m, 0);
-#pragma unroll
-      for (int rw = 16; rw < KB; rw += 16) {
-        const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)m, rw);
-        mw = o > mw ? o : mw;
-      }
-      const unsigned kd = (unsigned)__builtin_amdgcn_readlane((int)key, k);
-      const int p = (mw >> 20) <= (kd >> 20) + 2u ? k : 63 - (int)(mw & 63u);
-      if (lane == 0) piv[k] = p;
-      if (p != k) {  // exchange rows k and p: a permute between two lanes
-        const int partner = lane == k ? p : (lane == p ? k : lane);
-#pragma unroll
-        for (int c = 0; c < KB; ++c) x[c] = __shfl(x[c], partner, 64);
-      }
-      const double pv = fc_readlane(x[0], k);
-      double d = __builtin_amdgcn_rcp(pv);
-      d = __builtin_fma(__builtin_fma(-pv, d, 1.0), d, d);
-      d = __builtin_fma(__builtin_fma(-pv, d, 1.0), d, d);
-      const bool isk = lane == k;
-      const double g = isk ? 0.0 : x[0] * d;  // this row's entry in the pivot column over the pivot
-      if (isk) dsave = d;
-#pragma unroll
-      for (int c = 1; c < KB; ++c) x[c - 1] = __builtin_fma(-g, fc_readlane(x[c], k), x[c]);
-      x[KB - 1] = isk ? 1.0 : -g;  // the swept pivot column takes the free slot at the end of the rotation
-    }
-#pragma unroll
-    for (int c = 0; c < KB; ++c) x[c] *= dsave;
-    // inverse back to LDS; the row swaps are undone on its columns, in reverse order
+    fc_fe_gj_wave<KB>(x, lane, kb, piv);
+    // inverse back to LDS; the row swaps are undone on its columns when it is read
     if (lane < KB) {
 #pragma unroll
       for (int c = 0; c < KB; ++c) a[lane][c] = x[c];
-    }
-    if (lane == 0) {
-      // col[c] = column of the swept block that is column c of the inverse
-      for (int c = 0; c < KB; ++c) piv[KB + c] = c;
-      for (int k = kb - 1; k >= 0; --k) {
-        const int p = piv[k];
-        if (p != k) {
-          const int u = piv[KB + k];
-          piv[KB + k] = piv[KB + p];
-          piv[KB + p] = u;
-        }
-      }
     }
   }
   __syncthreads();
@@ -303,6 +317,255 @@ __global__ __launch_bounds__(256) void fc_fe_update(const FcFront* __restrict__ 
   if (k1 < nd.ni && ti == tk && tj == tk) {
     __syncthreads();  // the tile's stores are visible to the whole workgroup; Bs is free
     fc_fe_pivot_block<KB>(nd, fronts, scratch, step + 1, reinterpret_cast<double (*)[KB + 1]>(smem), piv);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 128-column block steps for the levels of WIDE fronts, where the trailing update is bound by the HBM traffic of the front
+// (read + written once per block step: 4 flop/B at KB = 32, 8 at 64, 16 at 128): half the passes over the front of the
+// 64-column steps.  The pivot block (128 x 128) is inverted by ONE workgroup per front entirely in LDS -- Gauss-Jordan in
+// four sub-steps of 32 columns: the 32 x 32 diagonal sub-block on one wave out of registers (fc_fe_gj_wave), its row panel
+// and the rank-32 update of the other 96 rows by all four waves out of LDS -- so the dependent chain of a 128-column step
+// is one launch.  Scratch of a front: W (128 x 128), then Cs (nf x 128).
+// ---------------------------------------------------------------------------------------------------------------------
+#define FC_FE_KH 128
+#define FC_FE_KH_LD (FC_FE_KH + 1)
+#define FC_FE_KH_LDS_BYTES ((FC_FE_KH * FC_FE_KH_LD + 2 * 32 * 33) * 8 + 64 * 4)
+
+__global__ __launch_bounds__(256) void fc_fe_pivot_huge(const FcFront* __restrict__ nodes, const double* fronts, double* __restrict__ scratch, int step) {
+  extern __shared__ double fc_fe_lds[];
+  constexpr int KH = FC_FE_KH, LD = FC_FE_KH_LD;
+  double* a = fc_fe_lds;                                                   // [KH][LD] the pivot block, swept in place
+  double (*sub)[33] = reinterpret_cast<double (*)[33]>(a + KH * LD);       // rows of the swept 32 x 32 sub-block
+  double (*subp)[33] = sub + 32;                                           // its inverse (columns permuted back)
+  int* piv = reinterpret_cast<int*>(subp + 32);                            // 64 ints
+  const FcFront nd = nodes[blockIdx.x];
+  const int k0 = step * KH;
+  if (k0 >= nd.ni) return;
+  const int kb = nd.ni - k0 < KH ? nd.ni - k0 : KH;
+  const int nf = nd.nf;
+  const double* A = fronts + nd.front;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  for (int e = t; e < KH * KH; e += 256) {
+    const int r = e / KH, c = e % KH;
+    a[r * LD + c] = (r < kb && c < kb) ? A[(size_t)(k0 + r) * nf + k0 + c] : (r == c ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  for (int c0 = 0; c0 < kb; c0 += 32) {  // (sub-steps beyond kb meet the identity padding: nothing to do)
+    const int kbs = kb - c0 < 32 ? kb - c0 : 32;
+    if (wave == 0) {
+      const int r = lane < 32 ? lane : 31;
+      double x[32];
+#pragma unroll
+      for (int c = 0; c < 32; ++c) x[c] = a[(c0 + r) * LD + c0 + c];
+      fc_fe_gj_wave<32>(x, lane, kbs, piv);
+      if (lane < 32) {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) sub[lane][c] = x[c];
+      }
+    }
+    __syncthreads();
+    for (int e = t; e < 32 * 32; e += 256) subp[e / 32][e % 32] = sub[e / 32][piv[32 + e % 32]];
+    __syncthreads();
+    const int lr = lane & 15, lk = lane >> 4;
+    {
+      // row panel on the matrix cores: a[c0 + r, j] = sum_k subp[r, k] a[c0 + k, j]  (j in the sub-block's columns: = subp).  Wave w owns
+      // the columns [32 w, 32 w + 32): it reads and writes only those, so the panel is swept in place without a barrier.
+      fc_d4 acc[2][2];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) acc[rt][cc] = fc_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s4 = 0; s4 < 8; ++s4) {
+        const double b0 = a[(c0 + 4 * s4 + lk) * LD + 32 * wave + lr], b1 = a[(c0 + 4 * s4 + lk) * LD + 32 * wave + 16 + lr];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const double av = subp[16 * rt + lr][4 * s4 + lk];
+          acc[rt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, acc[rt][0], 0, 0, 0);
+          acc[rt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, acc[rt][1], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          const int j = 32 * wave + 16 * cc + lr;
+          const bool inK = j >= c0 && j < c0 + 32;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * rt + lk + 4 * r;
+            a[(c0 + row) * LD + j] = inK ? subp[row][j - c0] : acc[rt][cc][r];
+          }
+        }
+    }
+    __syncthreads();
+    {
+      // the other rows on the matrix cores: a[i, j] = [j in the sub-block's columns ? 0 : a[i, j]] - a[i, c0 .. c0 + 32) a[c0 .. c0 + 32, j].
+      // Wave w owns the row tiles w and w + 4 (16 rows each; the two tiles of the pivot rows are skipped): a row tile is read
+      // and written by its owner only, its old pivot-column entries go to registers before any of it is overwritten.
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int rt = wave + 4 * q;
+        if (16 * rt >= c0 && 16 * rt < c0 + 32) continue;  // (wave-uniform)
+        double cs[8];
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4) cs[s4] = a[(16 * rt + lr) * LD + c0 + 4 * s4 + lk];
+#pragma clang loop unroll_count(2)
+        for (int ct = 0; ct < 8; ++ct) {
+          const int j = 16 * ct + lr;
+          const bool inK = j >= c0 && j < c0 + 32;
+          fc_d4 acc = fc_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int s4 = 0; s4 < 8; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cs[s4], a[(c0 + 4 * s4 + lk) * LD + j], acc, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            double* dst = a + (16 * rt + lk + 4 * r) * LD + j;
+            *dst = (inK ? 0.0 : *dst) - acc[r];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  double* W = scratch + nd.scratch;
+  for (int e = t; e < KH * KH; e += 256) {
+    const int r = e / KH, c = e % KH;
+    W[e] = (r < kb && c < kb) ? a[r * LD + c] : 0.0;
+  }
+}
+
+// blockIdx.x < ct: row panel of 64 columns on the matrix cores:  A[K, j] = sum_c W[., c] A[k0 + c, j]  (j in K: = W); wave w computes
+//                  rows [32 w, 32 w + 32) (its W rows in registers, the 128 x 64 panel of A staged once in LDS)
+// blockIdx.x >= ct: column panel copy, 64 rows per workgroup: Cs[i, c] = A[i, k0 + c]  (zero beyond kb)
+#define FC_FE_KH_PANEL_LDS_BYTES (FC_FE_KH * 64 * 8)
+__global__ __launch_bounds__(256) void fc_fe_panels_huge(const FcFront* __restrict__ nodes, double* fronts, double* __restrict__ scratch, int step, int ct) {
+  extern __shared__ double fc_fe_lds[];
+  constexpr int KH = FC_FE_KH;
+  const FcFront nd = nodes[blockIdx.y];
+  const int k0 = step * KH;
+  if (k0 >= nd.ni) return;
+  const int kb = nd.ni - k0 < KH ? nd.ni - k0 : KH;
+  const int nf = nd.nf;
+  double* A = fronts + nd.front;
+  const double* W = scratch + nd.scratch;
+  double* Cs = scratch + nd.scratch + KH * KH;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  if ((int)blockIdx.x >= ct) {
+    const int i0 = ((int)blockIdx.x - ct) * 64;
+    if (i0 >= nf) return;
+    for (int e = t; e < 64 * KH; e += 256) {
+      const int i = i0 + e / KH, c = e % KH;
+      if (i < nf) Cs[(size_t)i * KH + c] = c < kb ? A[(size_t)i * nf + k0 + c] : 0.0;
+    }
+    return;
+  }
+  const int j0 = blockIdx.x * 64;
+  if (j0 >= nf) return;
+  double (*Bs)[64] = reinterpret_cast<double (*)[64]>(fc_fe_lds);  // [KH][64] the old pivot rows of these columns
+  for (int e = t; e < KH * 64; e += 256) {
+    const int c = e / 64, j = j0 + e % 64;
+    Bs[c][e % 64] = (c < kb && j < nf) ? A[(size_t)(k0 + c) * nf + j] : 0.0;
+  }
+  const int lr = lane & 15, lk = lane >> 4;
+  // the wave's W rows as MFMA A operands: av[rt][s] = W[32 wave + 16 rt + lr][4 s + lk]
+  double av[2][KH / 4];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int s2 = 0; s2 < KH / 4; ++s2) av[rt][s2] = W[(size_t)(32 * wave + 16 * rt + lr) * KH + 4 * s2 + lk];
+  __syncthreads();
+  fc_d4 acc[2][4];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      acc[rt][c] = fc_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s2 = 0; s2 < KH / 4; ++s2) acc[rt][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[rt][s2], Bs[4 * s2 + lk][16 * c + lr], acc[rt][c], 0, 0, 0);
+    }
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int j = j0 + 16 * c + lr;
+      if (j >= nf) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 32 * wave + 16 * rt + lk + 4 * r;  // row of the pivot block
+        if (row >= kb) continue;
+        A[(size_t)(k0 + row) * nf + j] = (j >= k0 && j < k0 + kb) ? W[(size_t)row * KH + (j - k0)] : acc[rt][c][r];
+      }
+    }
+}
+
+// 64 x 64 tile of the trailing update with 128 pivot columns (fc_fe_update without the look-ahead): the B panel (128 x 64) goes
+// through LDS in two halves of 64 pivot rows, the tile's Cs rows stay in registers.
+__global__ __launch_bounds__(256) void fc_fe_update_huge(const FcFront* __restrict__ nodes, double* fronts, const double* __restrict__ scratch,
+                                                         int step, int tiles_per_side) {
+  __shared__ double Bs[64][64];
+  constexpr int KH = FC_FE_KH;
+  const FcFront nd = nodes[blockIdx.y];
+  const int k0 = step * KH;
+  if (k0 >= nd.ni) return;
+  const int kb = nd.ni - k0 < KH ? nd.ni - k0 : KH;
+  const int nf = nd.nf;
+  const int ti = (int)blockIdx.x / tiles_per_side, tj = (int)blockIdx.x % tiles_per_side;
+  const int i0 = ti * 64, j0 = tj * 64;
+  if (i0 >= nf || j0 >= nf) return;
+  double* A = fronts + nd.front;
+  const double* Cs = scratch + nd.scratch + KH * KH;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int arow = i0 + 16 * wave + lr;
+  double av[KH / 4];
+#pragma unroll
+  for (int s2 = 0; s2 < KH / 4; ++s2) av[s2] = arow < nf ? Cs[(size_t)arow * KH + 4 * s2 + lk] : 0.0;  // zero beyond kb (fc_fe_panels_huge)
+  double cv[4][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int col = j0 + 16 * c + lr;
+    const bool inK = col >= k0 && col < k0 + kb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i0 + 16 * wave + lk + 4 * r;
+      const bool live = col < nf && row < nf && !(row >= k0 && row < k0 + kb);
+      cv[c][r] = (live && !inK) ? A[(size_t)row * nf + col] : 0.0;
+    }
+  }
+  fc_d4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = fc_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    double bq[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int e = t + 256 * q, k = 64 * half + e / 64, col = j0 + e % 64;
+      bq[q] = (k < kb && col < nf) ? A[(size_t)(k0 + k) * nf + col] : 0.0;
+    }
+    if (half) __syncthreads();  // the first half's MFMAs have read Bs
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int e = t + 256 * q;
+      Bs[e / 64][e % 64] = bq[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[16 * half + s2], Bs[4 * s2 + lk][16 * c + lr], acc[c], 0, 0, 0);
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int col = j0 + 16 * c + lr;
+    if (col >= nf) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i0 + 16 * wave + lk + 4 * r;
+      if (row >= nf || (row >= k0 && row < k0 + kb)) continue;  // the pivot rows are final (fc_fe_panels_huge)
+      A[(size_t)row * nf + col] = cv[c][r] - acc[c][r];
+    }
   }
 }
 

@@ -255,6 +255,7 @@ struct fc_ctx {
     int level, nf, ni, parent;
   };
   bool have_plan = false;
+  bool huge_lds_ok = false;  // fc_fe_pivot_huge was granted its dynamic LDS
   int root_x0 = -1, root_xn = 0;  // multi-GPU: of the root's pivot rows (0-based inside its block) this handle stores [root_x0, root_x0 + root_xn) only (fc_set_root_rows); -1: all
   std::vector<PlanNode> pnodes;
   std::vector<int64_t> plevel_ptr, pa_ptr;
@@ -267,6 +268,7 @@ struct fc_ctx {
   DevBuf<FcFront> pfront;                              // fronts with a pivot block, grouped per level
   std::vector<std::pair<int64_t, int>> pfront_groups;  // per level: (first, count)
   std::vector<int> plevel_max_ni, plevel_max_nf;       // per level: block steps / tile grid of the elimination kernels
+  std::vector<int64_t> plevel_fsize;                   // per level: doubles in its fronts with a pivot block
   DevBuf<double> pscratch;                             // per front: inverse of the current pivot block + copied column panel
   DevBuf<int> pext_p;
   DevBuf<int64_t> pshift_slot;  // fc_set_front_shifts: added to the fronts after the scatter
@@ -2314,6 +2316,7 @@ int fc_factor_plan(fc_handle h, int32_t n_nodes, const int64_t* nodes, int32_t n
   h->pfront_groups.assign((size_t)n_levels, {0, 0});
   h->plevel_max_ni.assign((size_t)n_levels, 0);
   h->plevel_max_nf.assign((size_t)n_levels, 0);
+  h->plevel_fsize.assign((size_t)n_levels, 0);
   int64_t scratch_max = 1;
   for (int li = 0; li < n_levels; ++li) {
     const int64_t first = (int64_t)fr.size();
@@ -2321,10 +2324,18 @@ int fc_factor_plan(fc_handle h, int32_t n_nodes, const int64_t* nodes, int32_t n
     for (int64_t g = level_ptr[li]; g < level_ptr[li + 1]; ++g) {
       const fc_ctx::PlanNode& nd = h->pnodes[(size_t)g];
       if (nd.ni == 0) continue;
-      fr.push_back(FcFront{(long long)nd.front, (long long)nd.voff, nd.nf, nd.ni, (long long)off});
-      off += (int64_t)FC_FE_KB_MAX * FC_FE_KB_MAX + (int64_t)nd.nf * FC_FE_KB_MAX;
       h->plevel_max_ni[li] = std::max(h->plevel_max_ni[li], nd.ni);
       h->plevel_max_nf[li] = std::max(h->plevel_max_nf[li], nd.nf);
+      h->plevel_fsize[li] += (int64_t)nd.nf * nd.nf;
+    }
+    // scratch of a front: W (KB x KB) then Cs (nf x KB) for the widest block step its level may take (128 columns on levels
+    // whose largest front has order >= FC_FE_HUGE_MIN_NF, 64 elsewhere)
+    const int64_t kbm = h->plevel_max_nf[li] >= FC_FE_HUGE_MIN_NF ? FC_FE_KH : FC_FE_KB_MAX;
+    for (int64_t g = level_ptr[li]; g < level_ptr[li + 1]; ++g) {
+      const fc_ctx::PlanNode& nd = h->pnodes[(size_t)g];
+      if (nd.ni == 0) continue;
+      fr.push_back(FcFront{(long long)nd.front, (long long)nd.voff, nd.nf, nd.ni, (long long)off});
+      off += kbm * kbm + (int64_t)nd.nf * kbm;
     }
     scratch_max = std::max(scratch_max, off);
     h->pfront_groups[li] = {first, (int)((int64_t)fr.size() - first)};
@@ -2438,11 +2449,30 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
       // FC_FE_WIDE_NF (environment, read per factorisation): tests run the 64-column kernels on small meshes with it
       int wide_nf = FC_FE_WIDE_NF;
       if (const char* e = std::getenv("FC_FE_WIDE_NF")) wide_nf = std::max(1, std::atoi(e));
-      const bool wide = h->plevel_max_nf[li] >= wide_nf;
-      const int kbs = wide ? FC_FE_KB_WIDE : FC_FE_KB;
+      // 128-column steps where the update is bound by the traffic of the fronts: very wide fronts, or a level whose fronts together
+      // exceed what the caches hold (many mid-size fronts: the dependent chain of a step is hidden behind the other fronts)
+      int huge_nf = FC_FE_HUGE_NF;
+      double huge_mb = FC_FE_HUGE_MB;
+      if (const char* e = std::getenv("FC_FE_HUGE_NF")) huge_nf = std::atoi(e);
+      if (const char* e = std::getenv("FC_FE_HUGE_MB")) huge_mb = std::atof(e);
+      const bool huge = h->plevel_max_nf[li] >= FC_FE_HUGE_MIN_NF &&  // (the scratch of smaller levels is not sized for it)
+                        (h->plevel_max_nf[li] >= huge_nf || (double)h->plevel_fsize[li] * 8e-6 >= huge_mb);
+      const bool wide = !huge && h->plevel_max_nf[li] >= wide_nf;
+      const int kbs = huge ? FC_FE_KH : (wide ? FC_FE_KB_WIDE : FC_FE_KB);
       const int steps = (h->plevel_max_ni[li] + kbs - 1) / kbs;
+      if (huge && !h->huge_lds_ok) {  // 146 KB of LDS per workgroup: above the 64 KB a kernel gets without asking
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_fe_pivot_huge), hipFuncAttributeMaxDynamicSharedMemorySize, FC_FE_KH_LDS_BYTES));
+        h->huge_lds_ok = true;
+      }
       for (int k = 0; k < steps; ++k) {
-        if (wide) {
+        if (huge) {
+          // (a two-stream look-ahead -- the next pivot block's four tiles first, then its inversion beside the rest of the update -- was
+          // measured: the streams do not overlap on this runtime, 70.5 -> 69.5 ms on cavity_fine, slower on O1; not kept)
+          if (k == 0) hipLaunchKernelGGL(fc_fe_pivot_huge, dim3(grp.second), dim3(256), FC_FE_KH_LDS_BYTES, h->stream, fp, F, h->pscratch.p, k);
+          hipLaunchKernelGGL(fc_fe_panels_huge, dim3(2 * ct, grp.second), dim3(256), FC_FE_KH_PANEL_LDS_BYTES, h->stream, fp, F, h->pscratch.p, k, ct);
+          hipLaunchKernelGGL(fc_fe_update_huge, dim3(ct * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
+          if (k + 1 < steps) hipLaunchKernelGGL(fc_fe_pivot_huge, dim3(grp.second), dim3(256), FC_FE_KH_LDS_BYTES, h->stream, fp, F, h->pscratch.p, k + 1);
+        } else if (wide) {
           if (k == 0) hipLaunchKernelGGL(fc_fe_pivot<FC_FE_KB_WIDE>, dim3(grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k);
           hipLaunchKernelGGL(fc_fe_panels<FC_FE_KB_WIDE>, dim3(2 * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
           hipLaunchKernelGGL(fc_fe_update<FC_FE_KB_WIDE>, dim3(ct * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);

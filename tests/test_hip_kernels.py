@@ -220,10 +220,13 @@ def test_block_and_segment_down_sweeps_agree(setup):
         assert info[1] < 1e-9
 
 
-@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("wide", [False, True, "huge"])
 def test_device_factorisation_matches_host_multifrontal(setup, wide, monkeypatch):
     """(wide = True: FC_FE_WIDE_NF=64 sends every level of this small mesh through the 64-column kernels — pivot / panels /
-    update<64> with the look-ahead inversion in the 64 x 65 LDS overlay — which cavity_fine alone reaches otherwise.)
+    update<64> with the look-ahead inversion in the 64 x 65 LDS overlay — which cavity_fine alone reaches otherwise.
+    wide = "huge": FC_FE_HUGE_NF=256 sends every level whose largest front has order >= 256 — the top four of O1 — through
+    the 128-column kernels, fc_fe_pivot_huge / panels_huge / update_huge, which only the pinball mesh and the cavity
+    meshes reach otherwise.)
     fc_refactor (scatter, extend-add, blocked Gauss-Jordan front elimination on the fp64 matrix cores)
     against the numpy multifrontal of tests/support/nd_numeric.py on the same matrix and tree: factor
     values to round-off, then again after the matrix changed (numeric phase only)."""
@@ -231,8 +234,12 @@ def test_device_factorisation_matches_host_multifrontal(setup, wide, monkeypatch
     from flowcontrol_amd.device import SLOT_BDF2
     from tests.support import nd_numeric
 
-    if wide:
+    if wide == "huge":
+        monkeypatch.setenv("FC_FE_HUGE_NF", "256")
+    elif wide:
         monkeypatch.setenv("FC_FE_WIDE_NF", "64")
+        monkeypatch.setenv("FC_FE_HUGE_NF", "1000000")
+        monkeypatch.setenv("FC_FE_HUGE_MB", "1e9")
     dt, Re = 0.005, 100.0
     dofs, prof = _bc_setup(th)
     dev.set_bc(dofs, prof)
