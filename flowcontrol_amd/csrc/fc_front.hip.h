@@ -29,11 +29,11 @@
 #ifndef FC_FE_PIVOT_UNROLL
 #define FC_FE_PIVOT_UNROLL 8  // column steps per trip of the pivot-block loop: the row rotation costs one register move per entry and TRIP
 #endif
-#ifndef FC_FE_HUGE_NF
-#define FC_FE_HUGE_NF 1536   // a level takes 128-column steps (fc_fe_*_huge) when its largest front has at least this order
-#endif
 #ifndef FC_FE_HUGE_MB
-#define FC_FE_HUGE_MB 512.0  // ... or when the fronts of the level together hold at least this many MB (and the largest has order >= FC_FE_HUGE_MIN_NF)
+#define FC_FE_HUGE_MB 128.0  // a level takes 128-column steps (fc_fe_*_huge) when its fronts together hold at least this many MB: the update is then
+#endif                       // bound by the traffic of the fronts (a level of one or few fronts, however wide -- the root --, is bound by the pivot chain instead)
+#ifndef FC_FE_HUGE_NF
+#define FC_FE_HUGE_NF (1 << 30)  // ... or when its largest front has at least this order (off; tests force the kernels on small meshes with it)
 #endif
 #define FC_FE_HUGE_MIN_NF 256  // ... and never below this one (the scratch of such levels is sized for 64-column steps)
 #define FC_FE_KB_MAX 64      // scratch layout: W (KB_MAX x KB_MAX) then Cs (nf x KB_MAX), whatever KB a level uses
