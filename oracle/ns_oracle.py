@@ -99,6 +99,30 @@ class Disc:
     def from_taylor_hood(cls, th) -> "Disc":
         return cls(th.mesh.coords.copy(), th.mesh.cells.copy(), th.cell_nodes.copy(), th.nn)
 
+    @classmethod
+    def from_mesh_arrays(cls, coords, cells) -> "Disc":
+        """The oracle's OWN numbering, built from the raw mesh arrays alone (nothing of the product's discretisation):
+        cells re-oriented counter-clockwise, P2 edge nodes numbered by the sorted (lower vertex, upper vertex) key of their
+        edge — dolfin's P2 space puts one dof at every vertex and every edge midpoint, the mixed space
+        ``VectorElement(P2) x P1`` (``flowsolver.py:300-306``) then has 2(nv + ne) + nv dofs whatever their order.
+        ``node_coords()`` gives the points of the scalar P2 nodes, by which a test matches this numbering with another."""
+        coords = np.asarray(coords, dtype=np.float64)
+        cells = np.asarray(cells, dtype=np.int64).copy()
+        p = coords[cells]
+        det = (p[:, 1, 0] - p[:, 0, 0]) * (p[:, 2, 1] - p[:, 0, 1]) - (p[:, 1, 1] - p[:, 0, 1]) * (p[:, 2, 0] - p[:, 0, 0])
+        cells[det < 0] = cells[det < 0][:, [0, 2, 1]]
+        nv, nc = coords.shape[0], cells.shape[0]
+        lo = np.stack([np.minimum(cells[:, i], cells[:, j]) for i, j in _EV], axis=1)  # edge k is opposite to vertex k
+        hi = np.stack([np.maximum(cells[:, i], cells[:, j]) for i, j in _EV], axis=1)
+        uniq, inv = np.unique((lo * nv + hi).reshape(-1), return_inverse=True)
+        d = cls(coords, cells, np.hstack([cells, nv + inv.reshape(nc, 3)]), nv + uniq.size)
+        d._edge_lo, d._edge_hi = uniq // nv, uniq % nv
+        return d
+
+    def node_coords(self) -> np.ndarray:
+        """Points of the scalar P2 nodes (vertices, then edge midpoints) of :meth:`from_mesh_arrays`."""
+        return np.vstack([self.coords, 0.5 * (self.coords[self._edge_lo] + self.coords[self._edge_hi])])
+
     # field helpers
     def vel_at_q(self, u: np.ndarray):
         """u (2nn,) → values (nc,7,2) and gradients ∂_i u_j (nc,7,2,2) at quadrature points."""
