@@ -186,7 +186,7 @@ template <int KB>
 __global__ __launch_bounds__(256) void fc_fe_panels(const FcFront* __restrict__ nodes, double* fronts, double* __restrict__ scratch, int step,
                                                     int ct) {
   __shared__ double Ws[KB][KB];  // read as Ws[r][c] with r (nearly) uniform over a wave: broadcast, no padding needed
-  __shared__ double Rs[KB][32 + 1];
+  __shared__ double Rs[KB][KB == 32 ? 2 * 33 : 32 + 1];
   const FcFront nd = nodes[blockIdx.y];
   const int k0 = step * KB;
   if (k0 >= nd.ni) return;
@@ -207,6 +207,39 @@ __global__ __launch_bounds__(256) void fc_fe_panels(const FcFront* __restrict__ 
   }
   const int j0 = blockIdx.x * 64;
   if (j0 >= nf) return;
+  if constexpr (KB == 32) {
+    // both halves at once: every load of the workgroup (W and the 32 x 64 old pivot rows) is in flight before the one barrier --
+    // the panel kernel is on the dependent chain of every block step of the narrow levels, its latency is what counts
+    double (*R2)[64 + 1] = reinterpret_cast<double (*)[64 + 1]>(&Rs[0][0]);  // (Rs is declared [KB][2 * 33] for KB = 32)
+    double wq[4], rq[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wq[q] = W[t + 256 * q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = t + 256 * q, c = e / 64, j = j0 + e % 64;
+      rq[q] = (c < kb && j < nf) ? A[(size_t)(k0 + c) * nf + j] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Ws[(t + 256 * q) / KB][(t + 256 * q) % KB] = wq[q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) R2[(t + 256 * q) / 64][(t + 256 * q) % 64] = rq[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = t + 256 * q, r = e / 64, jj = e % 64, j = j0 + jj;
+      if (r >= kb || j >= nf) continue;
+      double sum;
+      if (j >= k0 && j < k0 + kb) {
+        sum = Ws[r][j - k0];
+      } else {
+        sum = 0.0;
+#pragma unroll 8
+        for (int c = 0; c < KB; ++c) sum += Ws[r][c] * R2[c][jj];
+      }
+      A[(size_t)(k0 + r) * nf + j] = sum;
+    }
+    return;
+  }
   for (int e = t; e < KB * KB; e += 256) Ws[e / KB][e % KB] = W[e];
   for (int half = 0; half < 2; ++half) {
     const int jh = j0 + 32 * half;
