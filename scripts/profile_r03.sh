@@ -29,9 +29,14 @@ python scripts/batch_probe.py --steps 400 > "$OUT/batch_probe_O1.log" 2>&1
 python scripts/batch_probe.py --skip-parity --refine 1 --steps 100 > "$OUT/batch_probe_refined1.log" 2>&1
 echo "batch profile done"
 # 4. numeric factorisation times (every figure DESIGN quotes) + kernel breakdown on O1
-python scripts/refactor_time.py O1 mesh_middle_gmsh cavity_fine > "$OUT/refactor_times.txt" 2>&1
+python scripts/refactor_time.py O1 mesh_middle_gmsh cavity_coarse cavity_fine > "$OUT/refactor_times.txt" 2>&1
 bash scripts/profile_refactor.sh > "$OUT/refactor_kernel_stats.txt" 2>&1 || true
 cp gpurun_out/prof_refactor/kernel_stats.csv "$OUT/refactor_kernel_stats.csv" 2>/dev/null || true
+# per-launch timeline of one factorisation (which launches form the dependent chain): O1 and cavity_fine
+for M in O1 cavity_fine; do
+  MESH=$M bash scripts/trace_refactor.sh > "$OUT/refactor_timeline_$M.txt" 2>&1 || true
+  cp gpurun_out/trace_refactor/timeline.csv "$OUT/refactor_timeline_$M.csv" 2>/dev/null || true
+done
 echo "refactor done"
 # 5. closed-loop throughput runs of configs 5 and 3 + the sweeps' traffic on cavity_fine
 python scripts/bench_case.py pinball --steps 10000 > "$OUT/bench_pinball_10k.json" 2> "$OUT/bench_pinball.err"
