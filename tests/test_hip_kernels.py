@@ -261,6 +261,67 @@ def test_device_factorisation_matches_host_multifrontal(setup, wide, monkeypatch
         assert info[1] < 1e-12
 
 
+def test_pivoting_inside_the_pivot_block(setup):
+    """The pivot blocks are inverted with (threshold) partial pivoting among their own rows.  On the assembled operators the
+    diagonal always passes the threshold, so the exchange path would never run: here the ux- and uy-rows of a few P2 nodes are
+    swapped (both rows have the same column pattern; P A x = P b has the same solution), which puts O(1) convection
+    couplings on the diagonal and the O(mass / dt) entries next to them — without the row exchange the elimination would
+    divide by those small entries (or by zero).  Nodes are taken from leaves of at most 32 pivot rows, so that both rows sit
+    in one pivot block."""
+    th, dev, d, O = setup
+    from flowcontrol_amd.device import SLOT_BDF2
+
+    dt, Re = 0.005, 100.0
+    dofs, prof = _bc_setup(th)
+    dev.set_bc(dofs, prof)
+    dev.set_time_scheme(dt, True)
+    U0 = _smooth_velocity(th)
+    dev.assemble_matrix(SLOT_BDF2, mass=1.5 / dt, nu=1.0 / Re, adv=U0, lin=U0)
+    dev.apply_bc(SLOT_BDF2)
+    dev.setup_solver(SLOT_BDF2)
+    A = dev.matrix(SLOT_BDF2).tocsr()
+    t = dev.tree
+    is_bc = np.zeros(dev.N, dtype=bool)
+    is_bc[dofs] = True
+    K = t.depth
+    swaps = []
+    for n in range(t.nnodes(K)):
+        i0, i1 = int(t.node_ptr[K][n]), int(t.node_ptr[K][n + 1])
+        if not 2 <= i1 - i0 <= 32:
+            continue
+        own = set(t.perm[i0:i1].tolist())
+        for q in sorted(own):
+            if q < th.nn and q + th.nn in own and not is_bc[q] and not is_bc[q + th.nn]:
+                ra, rb = A.indices[A.indptr[q] : A.indptr[q + 1]], A.indices[A.indptr[q + th.nn] : A.indptr[q + th.nn + 1]]
+                if ra.size == rb.size and np.array_equal(ra, rb):
+                    swaps.append((q, q + th.nn))
+                    break
+        if len(swaps) >= 12:
+            break
+    assert len(swaps) >= 3, "no leaf holds both velocity dofs of a free node"
+    vals = A.data.copy()
+    for a, b_ in swaps:
+        sa, sb = slice(A.indptr[a], A.indptr[a + 1]), slice(A.indptr[b_], A.indptr[b_ + 1])
+        vals[sa], vals[sb] = A.data[sb].copy(), A.data[sa].copy()
+        # the swapped diagonal must be far below the column's largest candidate: the exchange is not optional
+        Ad = A[[a, b_]][:, [a, b_]].toarray()
+        assert abs(Ad[1, 0]) < 1e-2 * abs(Ad[0, 0]) and abs(Ad[0, 1]) < 1e-2 * abs(Ad[1, 1])
+    try:
+        dev.set_matrix_values(SLOT_BDF2, vals)
+        dev.refactor(SLOT_BDF2)
+        b = np.random.default_rng(11).standard_normal(dev.N)
+        x, info = dev.solve(SLOT_BDF2, b)
+        Ap = dev.matrix(SLOT_BDF2)
+        assert np.linalg.norm(Ap @ x - b) / np.linalg.norm(b) < 1e-11
+        pb = b.copy()
+        for a, b_ in swaps:
+            pb[a], pb[b_] = b[b_], b[a]
+        assert np.linalg.norm(A @ x - pb) / np.linalg.norm(b) < 1e-11  # the solution of the un-swapped system for the swapped-back right-hand side
+    finally:
+        dev.set_matrix_values(SLOT_BDF2, A.data)
+        dev.refactor(SLOT_BDF2)
+
+
 def test_bicgstab_with_exact_and_lagged_factors(setup):
     """Device BiCGStab (fc_solve, FC_METHOD_BICGSTAB), right-preconditioned by the factor sweeps: one
     iteration with the operator's own factors; a handful with the factors of a different (earlier)
