@@ -265,6 +265,10 @@ struct fc_ctx {
   DevBuf<double> fronts;
   DevBuf<int64_t> pa_src, pa_dst, pap_src;
   DevBuf<FcExt> pext;
+  DevBuf<FcExt> pext2;                                 // the same descriptors grouped by parent (children in slot order): fc_extend_add_parents
+  DevBuf<FcExtPar> pextpar;
+  std::vector<std::pair<int64_t, int>> pextpar_groups;  // per level of the children: (first parent entry, parents)
+  std::vector<int> pextpar_maxnf;                       // ... and the largest parent front
   DevBuf<FcFront> pfront;                              // fronts with a pivot block, grouped per level
   std::vector<std::pair<int64_t, int>> pfront_groups;  // per level: (first, count)
   std::vector<int> plevel_max_ni, plevel_max_nf;       // per level: block steps / tile grid of the elimination kernels
@@ -2311,6 +2315,32 @@ int fc_factor_plan(fc_handle h, int32_t n_nodes, const int64_t* nodes, int32_t n
     }
   }
   if (ext.empty()) ext.push_back(FcExt{0, 0, 0, 0, 0, 0});
+  // ... and grouped by parent, children in slot order (one launch per level: fc_extend_add_parents)
+  std::vector<FcExt> ext2;
+  std::vector<FcExtPar> extpar;
+  h->pextpar_groups.assign((size_t)n_levels, {0, 0});
+  h->pextpar_maxnf.assign((size_t)n_levels, 0);
+  for (int li = 0; li < n_levels; ++li) {
+    std::map<int, std::vector<std::pair<int, FcExt>>> by_parent;  // parent node -> (slot, descriptor)
+    for (int64_t g = level_ptr[li]; g < level_ptr[li + 1]; ++g) {
+      const fc_ctx::PlanNode& c = h->pnodes[(size_t)g];
+      const int nbc = c.nf - c.ni;
+      if (ext_off[g] < 0 || c.parent < 0 || nbc <= 0) continue;
+      const fc_ctx::PlanNode& par = h->pnodes[(size_t)c.parent];
+      by_parent[c.parent].push_back({(int)nodes[(size_t)g * 7 + 6],
+                                     FcExt{(long long)(c.front + (int64_t)c.ni * c.nf + c.ni), (long long)par.front, c.nf, par.nf, nbc, (int)ext_off[g]}});
+    }
+    const int64_t first = (int64_t)extpar.size();
+    for (auto& kv : by_parent) {
+      std::sort(kv.second.begin(), kv.second.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+      extpar.push_back(FcExtPar{(int)ext2.size(), (int)kv.second.size()});
+      for (const auto& e : kv.second) ext2.push_back(e.second);
+      h->pextpar_maxnf[li] = std::max(h->pextpar_maxnf[li], h->pnodes[(size_t)kv.first].nf);
+    }
+    h->pextpar_groups[li] = {first, (int)((int64_t)extpar.size() - first)};
+  }
+  if (ext2.empty()) ext2.push_back(FcExt{0, 0, 0, 0, 0, 0});
+  if (extpar.empty()) extpar.push_back(FcExtPar{0, 0});
   // fronts with a pivot block, level by level, with their scratch (fc_front.hip.h)
   std::vector<FcFront> fr;
   h->pfront_groups.assign((size_t)n_levels, {0, 0});
@@ -2349,6 +2379,8 @@ int fc_factor_plan(fc_handle h, int32_t n_nodes, const int64_t* nodes, int32_t n
   FCCHK(h->pa_dst.upload(a_dst, (size_t)std::max<int64_t>(1, n_a), h->stream));
   FCCHK(h->pap_src.upload(ap_src, (size_t)n_ap, h->stream));
   FCCHK(h->pext.upload(ext, h->stream));
+  FCCHK(h->pext2.upload(ext2, h->stream));
+  FCCHK(h->pextpar.upload(extpar, h->stream));
   FCCHK(h->pext_p.upload(ext_p, (size_t)std::max<int64_t>(1, n_ext), h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->pn_shift = 0;
@@ -2421,7 +2453,18 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
                        h->pshift_val.p, F, skip0, skip1);
   }
   for (int li = 0; li < n_levels; ++li) {
-    if (li > 0) {
+    static const bool ext_by_slot = [] { const char* e = std::getenv("FC_EXTEND_BY_SLOT"); return e && e[0] == '1'; }();  // A/B reference
+    if (li > 0 && !ext_by_slot) {
+      // update blocks of the level below: one launch, a workgroup per 16 rows of a parent front, children in slot order
+      const auto pg = h->pextpar_groups[li - 1];
+      int rows = FC_EXTP_ROWS;  // fewer rows per workgroup on the levels of few, large parents: at least ~2 000 workgroups
+      while (rows > 4 && (int64_t)pg.second * ((h->pextpar_maxnf[li - 1] + rows - 1) / rows) < 2048) rows /= 2;
+      const int gx = (h->pextpar_maxnf[li - 1] + rows - 1) / rows;
+      for (int c0 = 0; c0 < pg.second; c0 += 65535) {  // grid.y limit
+        const int nc_ = std::min(65535, pg.second - c0);
+        hipLaunchKernelGGL(fc_extend_add_parents, dim3(gx, nc_), dim3(256), 0, h->stream, h->pextpar.p + pg.first + c0, h->pext2.p, h->pext_p.p, F, rows);
+      }
+    } else if (li > 0) {
       // update blocks of the level below, one launch per child slot (deterministic, conflict-free)
       for (int sl = 0; sl < h->pmax_slots; ++sl) {
         const auto grp = h->pext_groups[li - 1][sl];

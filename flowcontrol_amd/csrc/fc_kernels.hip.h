@@ -623,6 +623,54 @@ __global__ __launch_bounds__(256) void fc_extend_add(const FcExt* __restrict__ e
   }
 }
 
+// The same sums in ONE launch per level: a workgroup owns `rows` (16, 8 or 4) rows of one PARENT front and adds the update blocks of
+// all its children in slot order -- wave w takes the parent rows r with r % 4 == w, so every parent entry is touched by one wave
+// only, children one after the other (deterministic, no atomics).  A child's position list is ascending; a wave finds the
+// child rows that land in its parent rows with one coalesced pass over the list (ballot), the list itself sits in LDS
+// for the column scatter.  par[q] = {first FcExt of parent q, number of children} (children of a parent are contiguous, in
+// slot order).
+#define FC_EXTP_ROWS 16
+#define FC_EXTP_LDS 8192  // position-list entries held in LDS (longer lists are read from global memory)
+struct __attribute__((aligned(8))) FcExtPar {
+  int first, count;
+};
+__global__ __launch_bounds__(256) void fc_extend_add_parents(const FcExtPar* __restrict__ par, const FcExt* __restrict__ ext,
+                                                             const int* __restrict__ p, double* __restrict__ fronts, int rows) {
+  __shared__ int pl[FC_EXTP_LDS];
+  const FcExtPar pq = par[blockIdx.y];
+  const int r0 = blockIdx.x * rows;  // rows: parent rows per workgroup (a multiple of 4; fewer on levels of few, large parents)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int c = 0; c < pq.count; ++c) {
+    const FcExt d = ext[pq.first + c];
+    if (r0 >= d.nfp) return;  // (all children of a parent carry the parent's order: uniform)
+    const int* __restrict__ pp = p + d.poff;
+    // does any of this child's rows land in [r0, r0 + ROWS)?  The list is ascending: compare its ends first.
+    if (pp[0] >= r0 + rows || pp[d.nbc - 1] < r0) continue;  // uniform
+    const bool in_lds = d.nbc <= FC_EXTP_LDS;
+    __syncthreads();  // the previous child's list is no longer read
+    if (in_lds)
+      for (int j = threadIdx.x; j < d.nbc; j += 256) pl[j] = pp[j];
+    __syncthreads();
+    for (int base = 0; base < d.nbc; base += 64) {
+      const int i = base + lane;
+      const int row = i < d.nbc ? (in_lds ? pl[i] : pp[i]) : -1;
+      if (__builtin_amdgcn_readfirstlane(row) >= r0 + rows) break;  // ascending list: nothing further down lands here
+      unsigned long long mask = __ballot(row >= r0 && row < r0 + rows && ((row - r0) & 3) == wave);
+      while (mask) {
+        const int b = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const int prow = __builtin_amdgcn_readlane(row, b);
+        const double* __restrict__ srow = fronts + d.src + (long long)(base + b) * d.nfc;
+        double* __restrict__ drow = fronts + d.dst + (long long)prow * d.nfp;
+        if (in_lds)
+          for (int j = lane; j < d.nbc; j += 64) drow[pl[j]] += srow[j];
+        else
+          for (int j = lane; j < d.nbc; j += 64) drow[pp[j]] += srow[j];
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // small vector kernels
 // ---------------------------------------------------------------------------------------------
