@@ -26,6 +26,9 @@
 #ifndef FC_FE_WIDE_NF
 #define FC_FE_WIDE_NF 3072   // a level is "wide" when its largest front has at least this order (below, the longer pivot chain costs more than the update gains)
 #endif
+#ifndef FC_FE_GJ_WAVES
+#define FC_FE_GJ_WAVES 4  // waves that invert a pivot block: 4 (columns split over the workgroup's waves, one barrier per column step) or 1
+#endif
 #ifndef FC_FE_PIVOT_UNROLL
 #define FC_FE_PIVOT_UNROLL 8  // column steps per trip of the pivot-block loop: the row rotation costs one register move per entry and TRIP
 #endif
@@ -138,9 +141,105 @@ __device__ __forceinline__ void fc_fe_gj_wave(double (&x)[KB], int lane, int kb,
   }
 }
 
+// The same inversion on FOUR waves: wave w owns the columns [KB/4 w, KB/4 (w + 1)) of every row (lane r = row r, KB/4 entries in
+// registers).  Per column step the owner of the column finds the pivot, forms g_r = x_r[k] / pivot for every row and leaves it in
+// LDS; one workgroup barrier; then every wave updates its own columns (two v_readlane + one v_fmac_f64 per entry).  The rank-1
+// update -- three quarters of a column step on one wave -- is spread over the four SIMDs of the CU; what stays serial is the
+// search, the reciprocal and the barrier.  a: the block (LDS, row stride KB + 1), swept in place; gj: LDS scratch of
+// 2 * 64 + KB doubles; piv: 2 * KB + 2 ints.  All 256 threads call it; ends with a barrier; piv[KB + c] as fc_fe_gj_wave.
+template <int KB>
+__device__ __forceinline__ void fc_fe_gj_block(double (*a)[KB + 1], int kb, double* gj, int* piv) {
+  constexpr int CW = KB / 4;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int r = lane < KB ? lane : KB - 1;  // lanes beyond the block shadow its last row
+  double* dsc = gj + 128;
+  int* pcur = piv + 2 * KB;
+  double x[CW];
+#pragma unroll
+  for (int c = 0; c < CW; ++c) x[c] = a[r][CW * wave + c];
+  if (t < KB) dsc[t] = 1.0;
+#pragma clang loop unroll(disable)
+  for (int ow = 0; ow < 4; ++ow) {
+#pragma unroll
+    for (int kl = 0; kl < CW; ++kl) {
+      const int k = CW * ow + kl;
+      double* gb = gj + 64 * (k & 1);
+      if (wave == ow) {
+        const unsigned hi = (unsigned)__double2hiint(x[kl]) & 0x7fffffffu;
+        const bool cand = k < kb ? (lane >= k && lane < kb) : lane == k;
+        const unsigned key = cand ? ((hi & ~63u) | (unsigned)(63 - lane)) : 0u;
+        unsigned m = fc_row_max_u32(key);
+        unsigned mw = (unsigned)__builtin_amdgcn_readlane((int)m, 0);
+#pragma unroll
+        for (int rw = 16; rw < KB; rw += 16) {
+          const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)m, rw);
+          mw = o > mw ? o : mw;
+        }
+        const unsigned kd = (unsigned)__builtin_amdgcn_readlane((int)key, k);
+        const int p = (mw >> 20) <= (kd >> 20) + 2u ? k : 63 - (int)(mw & 63u);
+        if (p != k) {
+          const int partner = lane == k ? p : (lane == p ? k : lane);
+#pragma unroll
+          for (int c = 0; c < CW; ++c) x[c] = __shfl(x[c], partner, 64);
+        }
+        const double pv = fc_readlane(x[kl], k);
+        double d = __builtin_amdgcn_rcp(pv);
+        d = __builtin_fma(__builtin_fma(-pv, d, 1.0), d, d);
+        d = __builtin_fma(__builtin_fma(-pv, d, 1.0), d, d);
+        const bool isk = lane == k;
+        const double g = isk ? 0.0 : x[kl] * d;
+        if (lane < KB) gb[lane] = g;
+        if (isk) dsc[k] = d;
+        if (lane == 0) {
+          pcur[k & 1] = p;
+          piv[k] = p;
+        }
+        x[kl] = isk ? 1.0 : -g;  // the swept pivot column
+      }
+      __syncthreads();
+      const int p = pcur[k & 1];
+      const double ng = -gb[r];
+      if (wave == ow) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c)
+          if (c != kl) x[c] = __builtin_fma(ng, fc_readlane(x[c], k), x[c]);
+      } else {
+        if (p != k) {
+          const int partner = lane == k ? p : (lane == p ? k : lane);
+#pragma unroll
+          for (int c = 0; c < CW; ++c) x[c] = __shfl(x[c], partner, 64);
+        }
+#pragma unroll
+        for (int c = 0; c < CW; ++c) x[c] = __builtin_fma(ng, fc_readlane(x[c], k), x[c]);
+      }
+    }
+  }
+  __syncthreads();
+  if (lane < KB) {
+    const double ds = dsc[lane];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) a[lane][CW * wave + c] = x[c] * ds;
+  }
+  if (t == 0) {
+    for (int c = 0; c < KB; ++c) piv[KB + c] = c;
+    for (int k = kb - 1; k >= 0; --k) {
+      const int p = piv[k];
+      if (p != k) {
+        const int u = piv[KB + k];
+        piv[KB + k] = piv[KB + p];
+        piv[KB + p] = u;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+template <int KB>
+__device__ __forceinline__ void fc_fe_pivot_finish(const FcFront& nd, double* __restrict__ scratch, int kb, double (*a)[KB + 1], int* piv, double* gj);
+
 template <int KB>
 __device__ __forceinline__ void fc_fe_pivot_block(const FcFront& nd, const double* fronts, double* __restrict__ scratch, int step,
-                                                  double (*a)[KB + 1], int* piv) {
+                                                  double (*a)[KB + 1], int* piv, double* gj) {
   const int k0 = step * KB;
   const int kb = nd.ni - k0 < KB ? nd.ni - k0 : KB;
   const int nf = nd.nf;
@@ -151,6 +250,16 @@ __device__ __forceinline__ void fc_fe_pivot_block(const FcFront& nd, const doubl
     a[r][c] = (r < kb && c < kb) ? A[(size_t)(k0 + r) * nf + k0 + c] : (r == c ? 1.0 : 0.0);
   }
   __syncthreads();
+  fc_fe_pivot_finish<KB>(nd, scratch, kb, a, piv, gj);
+}
+
+// a (LDS, identity-padded beyond kb, visible to the whole workgroup) -> its inverse -> W in the front's scratch
+template <int KB>
+__device__ __forceinline__ void fc_fe_pivot_finish(const FcFront& nd, double* __restrict__ scratch, int kb, double (*a)[KB + 1], int* piv, double* gj) {
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+#if FC_FE_GJ_WAVES == 4
+  fc_fe_gj_block<KB>(a, kb, gj, piv);
+#else
   if (wave == 0) {
     const int r = lane < KB ? lane : KB - 1;  // lanes beyond the block shadow its last row (KB = 32: half the wave)
     double x[KB];
@@ -164,6 +273,7 @@ __device__ __forceinline__ void fc_fe_pivot_block(const FcFront& nd, const doubl
     }
   }
   __syncthreads();
+#endif
   double* W = scratch + nd.scratch;
   for (int e = t; e < KB * KB; e += 256) {
     const int r = e / KB, c = e % KB;
@@ -174,10 +284,11 @@ __device__ __forceinline__ void fc_fe_pivot_block(const FcFront& nd, const doubl
 template <int KB>
 __global__ __launch_bounds__(256) void fc_fe_pivot(const FcFront* __restrict__ nodes, double* fronts, double* __restrict__ scratch, int step) {
   __shared__ double a[KB][KB + 1];
-  __shared__ int piv[2 * KB];
+  __shared__ int piv[2 * KB + 2];
+  __shared__ double gj[128 + KB];
   const FcFront nd = nodes[blockIdx.x];
   if (step * KB >= nd.ni) return;
-  fc_fe_pivot_block<KB>(nd, fronts, scratch, step, a, piv);
+  fc_fe_pivot_block<KB>(nd, fronts, scratch, step, a, piv, gj);
 }
 
 // blockIdx.x < ct: row panel, 64 columns per workgroup (two passes of 32):  A[K, j] = sum_c W[., c] A[k0 + c, j]  (j in K: = W)
@@ -277,25 +388,63 @@ template <int KB>
 __global__ __launch_bounds__(256) void fc_fe_update(const FcFront* __restrict__ nodes, double* fronts, double* scratch,
                                                     int step, int tiles_per_side) {
   __shared__ double smem[KB * (KB + 1) > KB * 64 ? KB * (KB + 1) : KB * 64];  // the B panel, then (one tile only) the next pivot block
-  __shared__ int piv[2 * KB];
+  __shared__ int piv[2 * KB + 2];
+  __shared__ double gj[128 + KB];
   double (*Bs)[64] = reinterpret_cast<double (*)[64]>(smem);
   const FcFront nd = nodes[blockIdx.y];
   const int k0 = step * KB;
   if (k0 >= nd.ni) return;
   const int kb = nd.ni - k0 < KB ? nd.ni - k0 : KB;
   const int nf = nd.nf;
-  // the tile holding the next pivot block goes FIRST (block 0): its workgroup carries on with the inversion (below) and
-  // needs the rest of the launch to hide behind
-  const int k1 = k0 + KB;
-  const int tk = k1 / 64, special = k1 < nd.ni && tk < tiles_per_side ? tk * tiles_per_side + tk : 0;
-  const int tile = (int)blockIdx.x == 0 ? special : ((int)blockIdx.x <= special ? (int)blockIdx.x - 1 : (int)blockIdx.x);
-  const int ti = tile / tiles_per_side, tj = tile % tiles_per_side;
-  const int i0 = ti * 64, j0 = tj * 64;
-  if (i0 >= nf || j0 >= nf) return;
   double* A = fronts + nd.front;
   const double* Cs = scratch + nd.scratch + FC_FE_KB_MAX * FC_FE_KB_MAX;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int lr = lane & 15, lk = lane >> 4;
+  if (blockIdx.x == 0) {
+    // look-ahead workgroup (scheduled first): it updates ONLY the next pivot block -- KB x KB entries, straight from the panels into
+    // the matrix cores and on into LDS -- and inverts it right away, while the other workgroups of the launch update their tiles
+    // (one of them computes the same entries again and stores them; this one stores only the inverse).  The next step then starts
+    // with its panels; the dependent chain of a block step is this workgroup: launch, three loads, KB column steps, one store.
+    const int k1 = k0 + KB;
+    if (k1 >= nd.ni) return;
+    const int kb1 = nd.ni - k1 < KB ? nd.ni - k1 : KB;
+    double (*a)[KB + 1] = reinterpret_cast<double (*)[KB + 1]>(smem);
+    constexpr int NT = KB / 16;
+    for (int tile = wave; tile < NT * NT; tile += 4) {
+      const int rt = tile / NT, ct = tile % NT;
+      const int arow = k1 + 16 * rt + lr, bcol = k1 + 16 * ct + lr;
+      double av[KB / 4], bv[KB / 4], cin[4];
+#pragma unroll
+      for (int s4 = 0; s4 < KB / 4; ++s4) {
+        av[s4] = arow < nf ? Cs[(size_t)arow * KB + 4 * s4 + lk] : 0.0;  // zero beyond kb (fc_fe_panels)
+        bv[s4] = (4 * s4 + lk < kb && bcol < nf) ? A[(size_t)(k0 + 4 * s4 + lk) * nf + bcol] : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * rt + lk + 4 * r, col = 16 * ct + lr;
+        cin[r] = (row < kb1 && col < kb1) ? A[(size_t)(k1 + row) * nf + k1 + col] : 0.0;
+      }
+      fc_d4 acc = fc_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s4 = 0; s4 < KB / 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * rt + lk + 4 * r, col = 16 * ct + lr;
+        const bool in = row < kb1 && col < kb1;
+        const double v = cin[r] - acc[r];
+        a[row][col] = in ? v : (row == col ? 1.0 : 0.0);
+        if (in) A[(size_t)(k1 + row) * nf + k1 + col] = v;  // these entries are this workgroup's alone (the tile that holds them skips them)
+      }
+    }
+    __syncthreads();
+    fc_fe_pivot_finish<KB>(nd, scratch, kb1, a, piv, gj);
+    return;
+  }
+  const int k1 = k0 + KB, k1e = k1 < nd.ni ? (nd.ni < k1 + KB ? nd.ni : k1 + KB) : k1;  // [k1, k1e): the next pivot block (empty after the last step)
+  const int tile = (int)blockIdx.x - 1;
+  const int ti = tile / tiles_per_side, tj = tile % tiles_per_side;
+  const int i0 = ti * 64, j0 = tj * 64;
+  if (i0 >= nf || j0 >= nf) return;
   // B panel: KB x 64, a row of 64 columns per 64 consecutive threads (coalesced)
   constexpr int BPT = KB * 64 / 256;
   double bq[BPT];
@@ -342,14 +491,9 @@ __global__ __launch_bounds__(256) void fc_fe_update(const FcFront* __restrict__ 
     for (int r = 0; r < 4; ++r) {
       const int row = i0 + 16 * wave + lk + 4 * r;
       if (row >= nf || (row >= k0 && row < k0 + kb)) continue;  // the pivot rows are final (fc_fe_panels)
+      if (row >= k1 && row < k1e && col >= k1 && col < k1e) continue;  // the next pivot block: read and written by the look-ahead workgroup only
       A[(size_t)row * nf + col] = cv[c][r] - acc[c][r];
     }
-  }
-  // look-ahead: the tile that holds the NEXT pivot block inverts it right away (its entries are final for this step), while
-  // the other workgroups of the launch are still updating theirs -- the next step then starts with its panels
-  if (k1 < nd.ni && ti == tk && tj == tk) {
-    __syncthreads();  // the tile's stores are visible to the whole workgroup; Bs is free
-    fc_fe_pivot_block<KB>(nd, fronts, scratch, step + 1, reinterpret_cast<double (*)[KB + 1]>(smem), piv);
   }
 }
 

@@ -2518,11 +2518,11 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
         } else if (wide) {
           if (k == 0) hipLaunchKernelGGL(fc_fe_pivot<FC_FE_KB_WIDE>, dim3(grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k);
           hipLaunchKernelGGL(fc_fe_panels<FC_FE_KB_WIDE>, dim3(2 * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
-          hipLaunchKernelGGL(fc_fe_update<FC_FE_KB_WIDE>, dim3(ct * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
+          hipLaunchKernelGGL(fc_fe_update<FC_FE_KB_WIDE>, dim3(ct * ct + 1, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
         } else {
           if (k == 0) hipLaunchKernelGGL(fc_fe_pivot<FC_FE_KB>, dim3(grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k);
           hipLaunchKernelGGL(fc_fe_panels<FC_FE_KB>, dim3(2 * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
-          hipLaunchKernelGGL(fc_fe_update<FC_FE_KB>, dim3(ct * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
+          hipLaunchKernelGGL(fc_fe_update<FC_FE_KB>, dim3(ct * ct + 1, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
         }
       }
       // (the root of a multi-GPU layout: only this handle's block of pivot rows has storage)
