@@ -33,7 +33,7 @@
 #define FC_FE_PIVOT_UNROLL 8  // column steps per trip of the pivot-block loop: the row rotation costs one register move per entry and TRIP
 #endif
 #ifndef FC_FE_HUGE_MB
-#define FC_FE_HUGE_MB 128.0  // a level takes 128-column steps (fc_fe_*_huge) when its fronts together hold at least this many MB: the update is then
+#define FC_FE_HUGE_MB 256.0  // a level takes 128-column steps (fc_fe_*_huge) when its fronts together hold at least this many MB: the update is then
 #endif                       // bound by the traffic of the fronts (a level of one or few fronts, however wide -- the root --, is bound by the pivot chain instead)
 #ifndef FC_FE_HUGE_NF
 #define FC_FE_HUGE_NF (1 << 30)  // ... or when its largest front has at least this order (off; tests force the kernels on small meshes with it)
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void fc_fe_update(const FcFront* __restrict__ 
 // ---------------------------------------------------------------------------------------------------------------------
 #define FC_FE_KH 128
 #define FC_FE_KH_LD (FC_FE_KH + 1)
-#define FC_FE_KH_LDS_BYTES ((FC_FE_KH * FC_FE_KH_LD + 2 * 32 * 33) * 8 + 64 * 4)
+#define FC_FE_KH_LDS_BYTES ((FC_FE_KH * FC_FE_KH_LD + 2 * 32 * 33 + 160) * 8 + 66 * 4)
 
 __global__ __launch_bounds__(256) void fc_fe_pivot_huge(const FcFront* __restrict__ nodes, const double* fronts, double* __restrict__ scratch, int step) {
   extern __shared__ double fc_fe_lds[];
@@ -515,7 +515,8 @@ __global__ __launch_bounds__(256) void fc_fe_pivot_huge(const FcFront* __restric
   double* a = fc_fe_lds;                                                   // [KH][LD] the pivot block, swept in place
   double (*sub)[33] = reinterpret_cast<double (*)[33]>(a + KH * LD);       // rows of the swept 32 x 32 sub-block
   double (*subp)[33] = sub + 32;                                           // its inverse (columns permuted back)
-  int* piv = reinterpret_cast<int*>(subp + 32);                            // 64 ints
+  double* gj = reinterpret_cast<double*>(subp + 32);                       // 128 + 32 doubles: scratch of fc_fe_gj_block
+  int* piv = reinterpret_cast<int*>(gj + 160);                            // 66 ints
   const FcFront nd = nodes[blockIdx.x];
   const int k0 = step * KH;
   if (k0 >= nd.ni) return;
@@ -530,18 +531,10 @@ __global__ __launch_bounds__(256) void fc_fe_pivot_huge(const FcFront* __restric
   __syncthreads();
   for (int c0 = 0; c0 < kb; c0 += 32) {  // (sub-steps beyond kb meet the identity padding: nothing to do)
     const int kbs = kb - c0 < 32 ? kb - c0 : 32;
-    if (wave == 0) {
-      const int r = lane < 32 ? lane : 31;
-      double x[32];
-#pragma unroll
-      for (int c = 0; c < 32; ++c) x[c] = a[(c0 + r) * LD + c0 + c];
-      fc_fe_gj_wave<32>(x, lane, kbs, piv);
-      if (lane < 32) {
-#pragma unroll
-        for (int c = 0; c < 32; ++c) sub[lane][c] = x[c];
-      }
-    }
+    // the 32 x 32 diagonal sub-block, inverted by all four waves (fc_fe_gj_block)
+    for (int e = t; e < 32 * 32; e += 256) sub[e / 32][e % 32] = a[(c0 + e / 32) * LD + c0 + e % 32];
     __syncthreads();
+    fc_fe_gj_block<32>(sub, kbs, gj, piv);
     for (int e = t; e < 32 * 32; e += 256) subp[e / 32][e % 32] = sub[e / 32][piv[32 + e % 32]];
     __syncthreads();
     const int lr = lane & 15, lk = lane >> 4;

@@ -22,4 +22,4 @@ s[["name", "t_us", "dur_us", "gap_us", "wgs", "Workgroup_Size_X", "LDS_Block_Siz
 print(s.groupby("name")["dur_us"].agg(["count", "sum", "mean"]).sort_values("sum", ascending=False).to_string())
 print("total span us", s["t_us"].iloc[-1] + s["dur_us"].iloc[-1], "sum of gaps", s["gap_us"].iloc[1:].sum())
 PY
-rm -rf "$OUT/raw"
+[ -n "$KEEP_RAW" ] && python scripts/trace_refactor_pre.py "$OUT/raw"; rm -rf "$OUT/raw"
