@@ -504,22 +504,23 @@ __global__ __launch_bounds__(256) void fc_energy_b(int nn2, int nc, const int* _
 // fc_final for simulation s = blockIdx.x: folds its partials, evaluates the sensor rows on its column of `up`,
 // publishes its record (fc_publish: checksummed, the host polls it)
 template <int KB>
-__global__ __launch_bounds__(256) void fc_final_b(int G, int n_row_blocks, const double* __restrict__ partial, int n_sens,
-                                                  const int* __restrict__ s_rowptr, const int* __restrict__ s_idx,
-                                                  const double* __restrict__ s_w, const double* __restrict__ up,
-                                                  const int* __restrict__ flag, double* __restrict__ rec, int rstride,
-                                                  const double* __restrict__ seq_in, int compute_energy) {
-  const int s = blockIdx.x, t = threadIdx.x;
-  __shared__ double red[3][256];
+__global__ __launch_bounds__(1024) void fc_final_b(int G, int n_row_blocks, const double* __restrict__ partial, int n_sens,
+                                                   const int* __restrict__ s_rowptr, const int* __restrict__ s_idx,
+                                                   const double* __restrict__ s_w, const double* __restrict__ up,
+                                                   const int* __restrict__ flag, double* __restrict__ rec, int rstride,
+                                                   const double* __restrict__ seq_in, int compute_energy) {
+  // one workgroup of 1024 threads per simulation: the kernel is a chain of dependent round trips over 3 G partial sums, so
+  // what counts is how few trips there are (sixteen waves, eight loads per array and trip: 8 192 partials per trip)
+  const int s = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+  __shared__ double red[3][16];
   __shared__ double ysh[64];
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
   const double* __restrict__ ps = partial + (size_t)s * 3 * G;  // [w][block], contiguous per simulation
-  // one workgroup streams 3 G doubles: eight independent loads per array and trip keep enough of them in flight
-  for (int base = 0; base < G; base += 8 * 256) {
+  for (int base = 0; base < G; base += 8 * nt) {
     double v0[8], v1[8], v2[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int i = base + u * 256 + t;
+      const int i = base + u * nt + t;
       v0[u] = i < n_row_blocks ? ps[i] : 0.0;  // row blocks [0, n_row_blocks): residual sums; cell blocks behind them: energy
       v1[u] = i < n_row_blocks ? ps[(size_t)G + i] : 0.0;
       v2[u] = (i >= n_row_blocks && i < G) ? ps[2 * (size_t)G + i] : 0.0;
@@ -531,30 +532,36 @@ __global__ __launch_bounds__(256) void fc_final_b(int G, int n_row_blocks, const
       a2 += v2[u];
     }
   }
-  const int wave = t >> 6, lane = t & 63;
-  for (int q = wave; q < n_sens; q += 4) {
+  const int wave = t >> 6, lane = t & 63, nw = nt >> 6;
+  for (int q = wave; q < n_sens; q += nw) {
     double acc = 0.0;
     for (int k = s_rowptr[q] + lane; k < s_rowptr[q + 1]; k += 64) acc += s_w[k] * up[(size_t)s_idx[k] * KB + s];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if (lane == 0) ysh[q] = acc;
   }
-  red[0][t] = a0;
-  red[1][t] = a1;
-  red[2][t] = a2;
-  __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
-    if (t < st) {
-      red[0][t] += red[0][t + st];
-      red[1][t] += red[1][t + st];
-      red[2][t] += red[2][t + st];
-    }
-    __syncthreads();
+  // fixed order: lanes of a wave (shuffle tree), then the waves in index order
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a0 += __shfl_down(a0, off, 64);
+    a1 += __shfl_down(a1, off, 64);
+    a2 += __shfl_down(a2, off, 64);
   }
+  if (lane == 0) {
+    red[0][wave] = a0;
+    red[1][wave] = a1;
+    red[2][wave] = a2;
+  }
+  __syncthreads();
   if (t == 0) {
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+    for (int w = 0; w < nw; ++w) {
+      r0 += red[0][w];
+      r1 += red[1][w];
+      r2 += red[2][w];
+    }
     double* r = rec + (size_t)s * rstride;
-    fc_publish(ysh, n_sens, compute_energy ? 0.5 * red[2][0] : 0.0, red[0][0], red[1][0], (double)(flag[s] & 1), r + 64, r + 128, r + 129,
-               r + 136, r + 137, seq_in[0]);
+    fc_publish(ysh, n_sens, compute_energy ? 0.5 * r2 : 0.0, r0, r1, (double)(flag[s] & 1), r + 64, r + 128, r + 129, r + 136, r + 137, seq_in[0]);
   }
 }
 

@@ -4099,7 +4099,7 @@ static int batch_launches(fc_ctx* h, int order_slot, int compute_energy) {
     FC_KB_DISPATCH(KB, FC_ENB(4), FC_ENB(8), FC_ENB(16));
 #undef FC_ENB
   }
-#define FC_FINB(K) hipLaunchKernelGGL((fc_final_b<K>), dim3(B.k), dim3(256), 0, h->stream, G, n_row_blocks, B.partial.p, h->n_sens, h->s_rowptr.p, h->s_idx.p, \
+#define FC_FINB(K) hipLaunchKernelGGL((fc_final_b<K>), dim3(B.k), dim3(1024), 0, h->stream, G, n_row_blocks, B.partial.p, h->n_sens, h->s_rowptr.p, h->s_idx.p, \
                                       h->s_w.p, B.up.p, B.flag.p, h->pin_dev, kRecStride, h->pin_dev + kSeqSlot, compute_energy)
   FC_KB_DISPATCH(KB, FC_FINB(4), FC_FINB(8), FC_FINB(16));
 #undef FC_FINB
