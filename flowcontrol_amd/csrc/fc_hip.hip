@@ -211,6 +211,8 @@ struct fc_ctx {
   double rtol = 1e-10;
   // state + work
   DevBuf<double> u_n, u_nn, p_n, up;
+  DevBuf<double> u_old, p_old;  // what the last step's shift overwrote (u_nn, p_n before it): fc_undo_step
+  bool undo_ok = false;
   DevBuf<double> b, buf, xsol, tmpN, tmpN2;  // buf = [y | x] (2N)
   DevBuf<double> partial, scal;               // reductions; scal: [0]=E [1]=r2 [2]=b2
   DevBuf<double> uctrl, ydev, yseq, Eseq, useq;
@@ -886,7 +888,7 @@ int launch_tail(fc_ctx* h, OrderSys& S, int compute_energy, double* d_y, double*
     }
     fin = FcFin{h->fin_cnt.p, kGroup, n_groups, h->n_sens, h->s_rowptr.p, h->s_idxp.p, h->s_w.p, d_y, d_E, d_r, d_flag_out, d_seq, seq, step_id};
   }
-#define FC_TAIL_ARGS h->N, 2 * h->nn, h->perm.p, h->buf.p + h->N, h->b.p, res ? S.Ap_rowptr.p : nullptr, S.Ap_col.p, S.Ap_val.p, g_rows, reps, h->nc, g_cells > 0 ? h->cn.p : nullptr, h->geom.p, h->iperm.p, part ? h->rowkind_p.p : nullptr, part ? h->cell_list.p : nullptr, ncl, h->up.p, h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p, h->partial.p, h->dag_err.p, fin
+#define FC_TAIL_ARGS h->N, 2 * h->nn, h->perm.p, h->buf.p + h->N, h->b.p, res ? S.Ap_rowptr.p : nullptr, S.Ap_col.p, S.Ap_val.p, g_rows, reps, h->nc, g_cells > 0 ? h->cn.p : nullptr, h->geom.p, h->iperm.p, part ? h->rowkind_p.p : nullptr, part ? h->cell_list.p : nullptr, ncl, h->up.p, h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p, h->partial.p, h->dag_err.p, fin, h->u_old.p, h->p_old.p
   if (fused)
     hipLaunchKernelGGL(fc_tail<true>, dim3(g), dim3(256), 0, h->stream, FC_TAIL_ARGS);
   else
@@ -1226,7 +1228,7 @@ int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, 
   if (!h->partitioned) {
     hipLaunchKernelGGL(fc_finish, dim3(g), dim3(256), 0, h->stream, h->N, 2 * h->nn, h->perm.p, x, dx, h->up.p, h->u_n.p,
                        h->u_nn.p, h->p_n.p, h->flag.p, compute_energy ? h->mp_rowptr.p : nullptr, h->mp_col.p,
-                       h->mp_val.p, compute_energy ? e_partial : nullptr, (const unsigned char*)nullptr, h->dag_err.p);
+                       h->mp_val.p, compute_energy ? e_partial : nullptr, (const unsigned char*)nullptr, h->dag_err.p, h->u_old.p, h->p_old.p);
     hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, g, compute_energy ? e_partial : nullptr,
                        d_E, nrp, nrp > 0 ? h->partial.p : nullptr, d_r, h->n_sens, h->s_rowptr.p, h->s_idx.p,
                        h->s_w.p, h->up.p, d_y, h->flag.p, d_flag_out, d_seq, seq, h->dag_err.p, step_id);
@@ -1235,7 +1237,7 @@ int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, 
     // owned dofs; the partial tail is summed over the ranks with one small all-reduce
     hipLaunchKernelGGL(fc_finish, dim3(g), dim3(256), 0, h->stream, h->N, 2 * h->nn, h->perm.p, x, dx, h->up.p, h->u_n.p,
                        h->u_nn.p, h->p_n.p, h->flag.p, (const int*)nullptr, (const int*)nullptr, (const double*)nullptr,
-                       (double*)nullptr, h->rowkind_p.p, h->dag_err.p);
+                       (double*)nullptr, h->rowkind_p.p, h->dag_err.p, h->u_old.p, h->p_old.p);
     int ne = 0;
     if (compute_energy && h->ncl > 0) {
       ne = nblocks(h->ncl, 256);
@@ -1426,6 +1428,8 @@ int fc_create(fc_handle* out, int device, int32_t nv, int32_t ne, int32_t nc, co
   for (int s = 0; s < FC_NUM_SLOTS; ++s) TRY(h->vals[s].alloc((size_t)h->nnz));
   TRY(h->u_n.alloc(2 * (size_t)nn));
   TRY(h->u_nn.alloc(2 * (size_t)nn));
+  TRY(h->u_old.alloc(2 * (size_t)nn));
+  TRY(h->p_old.alloc((size_t)std::max(1, nv)));
   TRY(h->p_n.alloc(nv));
   TRY(h->up.alloc(N));
   TRY(h->b.alloc(N));
@@ -3058,6 +3062,7 @@ int fc_set_solver_options(fc_handle h, int method, int max_iter, double rtol, in
 int fc_set_state(fc_handle h, const double* u_n, const double* u_nn, const double* p_n) {
   if (!h || !u_n || !u_nn) return fail(FC_ERR_INVALID, "fc_set_state: null argument");
   h->pre_slot = -1;
+  h->undo_ok = false;
   HIPCHK(hipSetDevice(h->device));
   const size_t nv2 = 2 * (size_t)h->nn;
   HIPCHK(hipMemcpyAsync(h->u_n.p, u_n, nv2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -3065,6 +3070,22 @@ int fc_set_state(fc_handle h, const double* u_n, const double* u_nn, const doubl
   if (p_n) HIPCHK(hipMemcpyAsync(h->p_n.p, p_n, (size_t)h->nv * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemsetAsync(h->flag.p, 0, sizeof(int), h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  return FC_OK;
+}
+
+int fc_undo_step(fc_handle h) {
+  if (!h) return fail(FC_ERR_INVALID, "null handle");
+  if (h->step_pending) return fail(FC_ERR_INVALID, "fc_undo_step: collect the step first (fc_step_end)");
+  if (!h->undo_ok) return fail(FC_ERR_NOT_READY, "fc_undo_step: the last state change was not a single fc_step");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t nv2 = 2 * (size_t)h->nn * sizeof(double);
+  HIPCHK(hipMemcpyAsync(h->u_n.p, h->u_nn.p, nv2, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->u_nn.p, h->u_old.p, nv2, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->p_n.p, h->p_old.p, (size_t)h->nv * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemsetAsync(h->flag.p, 0, sizeof(int), h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->pre_slot = -1;  // a speculative element loop of the next step read the state that was just withdrawn
+  h->undo_ok = false;
   return FC_OK;
 }
 
@@ -3115,6 +3136,7 @@ static int step_enqueue(fc_ctx* h) {
   double* dev = h->pin_dev;
   h->pend_seq = (double)(++h->seq);
   FCCHK(enqueue_step(h, h->pend_slot, dev, dev + 64, dev + 128, dev + 129, dev + 136, h->pend_energy, dev + 32, dev + 137, h->pend_seq));
+  h->undo_ok = true;  // the tail kept what its shift overwrote
   speculate_next_rhs(h, h->pend_slot);
   return FC_OK;
 }
@@ -3221,6 +3243,7 @@ int fc_run(fc_handle h, int first_order_slot, int32_t n_steps, const double* u_c
            double* y_seq, double* dE_seq, int compute_energy) {
   FCCHK(check_step_ready(h, first_order_slot));
   if (n_steps <= 0) return fail(FC_ERR_INVALID, "fc_run: n_steps must be positive");
+  h->undo_ok = false;  // (fc_undo_step withdraws a single fc_step)
   if (h->n_act > 0 && !u_ctrl) return fail(FC_ERR_INVALID, "fc_run: u_ctrl is null");
   HIPCHK(hipSetDevice(h->device));
   const int na = std::max(1, h->n_act), ns = std::max(1, h->n_sens);
@@ -3453,7 +3476,7 @@ int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double*
     }
     hipLaunchKernelGGL(fc_finish, dim3(nblocks(N, 32)), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, x, dx, h->up.p, h->u_n.p,
                        h->u_nn.p, h->p_n.p, h->flag.p, h->mp_rowptr.p, h->mp_col.p, h->mp_val.p, e_partial,
-                       (const unsigned char*)nullptr, h->dag_err.p);
+                       (const unsigned char*)nullptr, h->dag_err.p, h->u_old.p, h->p_old.p);
     hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, nblocks(N, 32), e_partial, h->scal.p, nrp,
                        nrp > 0 ? h->partial.p : nullptr, h->scal.p + 1, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p,
                        h->up.p, h->ydev.p, h->flag.p, (double*)nullptr, (double*)nullptr, 0.0, h->dag_err.p, 1);

@@ -751,7 +751,8 @@ __global__ __launch_bounds__(256) void fc_finish(int N, int nn2, const int* __re
                                                  const double* __restrict__ m_val,
                                                  double* __restrict__ e_partial,
                                                  const unsigned char* __restrict__ rowkind,
-                                                 const int* __restrict__ err) {
+                                                 const int* __restrict__ err, double* __restrict__ u_old,
+                                                 double* __restrict__ p_old) {  // u_old / p_old: what the shift overwrites (fc_undo_step)
   if (err && err[0]) return;  // the factor apply gave up (fc_nd_dag): leave the state as it is, the host redoes the step
   // 8 lanes per (permuted) row: they share the mass-matrix row of the energy term (coalesced 8 x 12 B
   // per trip), lane 0 scatters / shifts the row's dof
@@ -773,12 +774,14 @@ __global__ __launch_bounds__(256) void fc_finish(int N, int nn2, const int* __re
       }
       if (lane == 0) {
         up[r] = v;
+        u_old[r] = u_nn[r];
         u_nn[r] = u_n[r];
         u_n[r] = v;
         if (!isfinite(v)) atomicOr(flag, 1);
       }
     } else if (lane == 0) {
       up[r] = v;
+      p_old[r - nn2] = p_n[r - nn2];
       p_n[r - nn2] = v;
     }
   }
@@ -969,7 +972,8 @@ __global__ __launch_bounds__(256) void fc_tail(
     int n_row_blocks, int reps, int nc, const int* __restrict__ cn, const double* __restrict__ geom, const int* __restrict__ iperm,
     const unsigned char* __restrict__ rowkind, const int* __restrict__ cell_list, int ncl,
     double* __restrict__ up, double* __restrict__ u_n, double* __restrict__ u_nn, double* __restrict__ p_n,
-    int* __restrict__ flag, double* __restrict__ partial, int* __restrict__ err, FcFin fin) {
+    int* __restrict__ flag, double* __restrict__ partial, int* __restrict__ err, FcFin fin,
+    double* __restrict__ u_old, double* __restrict__ p_old) {  // u_old / p_old: what the shift overwrites (fc_undo_step)
   if (err && err[0]) {
     // the factor apply gave up (fc_nd_dag): leave the state as it is, the host redoes the step; a fused tail still owes
     // the host its record (flag word + 1024)
@@ -1031,10 +1035,12 @@ __global__ __launch_bounds__(256) void fc_tail(
       }
       up[r] = v;
       if (r < nn2) {
+        u_old[r] = u_nn[r];
         u_nn[r] = u_n[r];
         u_n[r] = v;
         bad |= !isfinite(v);
       } else {
+        p_old[r - nn2] = p_n[r - nn2];
         p_n[r - nn2] = v;
       }
     }

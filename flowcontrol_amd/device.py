@@ -493,6 +493,11 @@ class DeviceSolver:
         p = None if p_n is None else _f64(p_n)
         check(self.lib.fc_set_state(self._h, _f64(u_n), _f64(u_nn), ptr(p)))
 
+    def undo_step(self) -> None:
+        """``fc_undo_step``: (u_n, u_nn, p_n) as they were before the last single step (after FC_ERR_DIVERGED: the reference's
+        state is untouched by a failed step, flowsolver.py:727-751)."""
+        check(self.lib.fc_undo_step(self._h))
+
     def get_state(self):
         u_n, u_nn, p_n = np.empty(2 * self.nn), np.empty(2 * self.nn), np.empty(self.th.nv)
         check(self.lib.fc_get_state(self._h, ptr(u_n), ptr(u_nn), ptr(p_n)))

@@ -601,7 +601,11 @@ class FlowSolver(ABC):
                 y, dE, info = self._step_with_plugin_solver(solver, slot, u_ctrl, want_energy)
         except FcDiverged:
             logger.critical("Solver diverged (Inf detected)")
-            self.fields._mark_stale()  # the host mirrors no longer describe the device state
+            # the reference detects the non-finite velocity BEFORE it shifts the fields (flowsolver.py:727-751): u_n, u_nn, p_n stay
+            # what they were.  The device shifted inside the step's last kernel: withdraw that.
+            if isinstance(solver, _DeviceNDSolver):
+                self.th.device().undo_step()
+            self.fields._mark_stale()  # the host mirrors are re-read from the device
             if not self.params_solver.throw_error:
                 return None
             raise RuntimeError("Failed solving: Inf found in solution")

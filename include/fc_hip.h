@@ -247,6 +247,11 @@ int fc_set_solver_options(fc_handle h, int method, int max_iter, double rtol, in
 /* ── state: FlowFieldCollection u_n, u_nn, p_n (flowfield.py:67-105; flowsolver.py:487-491) ─ */
 int fc_set_state(fc_handle h, const double* u_n /* [2 nn] */, const double* u_nn /* [2 nn] */,
                  const double* p_n /* [nv] */);
+/* Withdraw the last fc_step: (u_n, u_nn, p_n) as they were before it (the step's tail keeps what its shift overwrites).
+ * The reference leaves its state untouched when a step fails (a non-finite velocity is detected BEFORE the fields are
+ * shifted, flowsolver.py:727-751); a host program gets the same by calling this after FC_ERR_DIVERGED -- FlowSolver.step does.
+ * Valid once after a single fc_step / fc_step_end (not after fc_run, fc_set_state or a batched step). */
+int fc_undo_step(fc_handle h);
 int fc_get_state(fc_handle h, double* u_n, double* u_nn, double* p_n);
 int fc_get_solution(fc_handle h, double* up /* [N] last solve, W layout */);
 

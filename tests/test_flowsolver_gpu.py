@@ -422,11 +422,22 @@ def test_non_finite_state_is_reported_as_divergence(tmp_path_factory, golden_dir
             with pytest.raises(FcDiverged) as e:  # the C ABI status itself
                 dev.step(SLOT_BDF2, np.zeros(2))
             assert e.value.code == FC_ERR_DIVERGED
-            dev.set_state(u_bad, u_nn, p_n)
+            # the C-ABI step shifted the (non-finite) solution into the state; fc_undo_step withdraws it
+            dev.undo_step()
+            a, b, c = dev.get_state()
+            assert np.array_equal(np.isinf(a), np.isinf(u_bad)) and np.array_equal(a[np.isfinite(a)], u_bad[np.isfinite(u_bad)])
+            assert np.array_equal(b, u_nn) and np.array_equal(c, p_n)
+            with pytest.raises(Exception, match="not a single fc_step"):
+                dev.undo_step()  # once only
             with pytest.raises(RuntimeError, match="Failed solving"):
                 fs.step([0.0, 0.0])
+            # FlowSolver.step leaves the fields as the reference does: untouched by the failed step (flowsolver.py:727-751)
+            a, b, c = dev.get_state()
+            assert np.array_equal(b, u_nn) and np.array_equal(c, p_n) and np.isinf(a[17])
         else:
             assert fs.step([0.0, 0.0]) is None
+            a, b, c = dev.get_state()
+            assert np.array_equal(b, u_nn) and np.array_equal(c, p_n) and np.isinf(a[17])
             # a pushed finite state makes the solver usable again
             fs.fields.u_n = Function(fs.V, u_n)
             fs.fields.u_nn = Function(fs.V, u_nn)
