@@ -741,15 +741,22 @@ __global__ __launch_bounds__(256) void fc_fe_update_huge(const FcFront* __restri
 
 // factor rows [D^-1 | -U] (stride nf) and the -L block (nb x ni, stride ni) into the layout the sweeps read, in the
 // storage type of the slot (double, or rounded once to float / bfloat16: compressed factors, fc_kernels.hip.h).
-// Of the pivot rows only [xr0, xr1) are written, row xr0 first (all of them: 0, INT_MAX; the root of a multi-GPU layout: the
-// handle's block, fc_set_root_rows).
+// ONE launch for all fronts of all levels at the end of the factorisation (the fronts stay intact: an extend-add only reads a
+// child) over a flat work list.  Of the pivot rows of front `root_front` only [xr0_root, xr1_root) are written, row xr0_root first
+// (the root of a multi-GPU layout: the handle's block, fc_set_root_rows; root_front = -1: every front is written in full).
+// work list of the export: one entry per 16 rows of a front
+struct __attribute__((aligned(8))) FcExpItem {
+  int front;  // index into the front table
+  int i0;     // first row
+};
 template <typename VT>
-__global__ __launch_bounds__(256) void fc_fe_export(const FcFront* __restrict__ nodes, const double* __restrict__ fronts, VT* __restrict__ fvals,
-                                                    int xr0, int xr1) {
-  const FcFront nd = nodes[blockIdx.y];
+__global__ __launch_bounds__(256) void fc_fe_export(const FcFront* __restrict__ nodes, const FcExpItem* __restrict__ items, const double* __restrict__ fronts,
+                                                    VT* __restrict__ fvals, int root_front, int xr0_root, int xr1_root) {
+  const FcExpItem it = items[blockIdx.x];
+  const FcFront nd = nodes[it.front];
   const int nf = nd.nf, ni = nd.ni;
-  const int i0 = blockIdx.x * 16;
-  if (i0 >= nf || ni == 0) return;
+  const int i0 = it.i0;
+  const int xr0 = it.front == root_front ? xr0_root : 0, xr1 = it.front == root_front ? xr1_root : INT_MAX;
   const double* A = fronts + nd.front;
   VT* dv = fvals + nd.voff;
   const int stored = (xr1 < ni ? xr1 : ni) - xr0;  // pivot rows with storage

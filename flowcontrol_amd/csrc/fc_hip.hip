@@ -266,6 +266,8 @@ struct fc_ctx {
   int pmax_slots = 1, pmax_ni = 0;
   DevBuf<double> fronts;
   DevBuf<int64_t> pa_src, pa_dst, pap_src;
+  DevBuf<FcExpItem> pexp;  // work list of fc_fe_export
+  int64_t pexp_n = 0, pfront_total = 0;
   DevBuf<FcExt> pext;
   DevBuf<FcExt> pext2;                                 // the same descriptors grouped by parent (children in slot order): fc_extend_add_parents
   DevBuf<FcExtPar> pextpar;
@@ -2375,6 +2377,13 @@ int fc_factor_plan(fc_handle h, int32_t n_nodes, const int64_t* nodes, int32_t n
     h->pfront_groups[li] = {first, (int)((int64_t)fr.size() - first)};
     if (h->pfront_groups[li].second > 65535) return fail(FC_ERR_INVALID, "fc_factor_plan: more than 65535 fronts in one level");
   }
+  h->pfront_total = (int64_t)fr.size();
+  std::vector<FcExpItem> items;  // work list of the export: 16 rows of a front per workgroup
+  for (size_t f = 0; f < fr.size(); ++f)
+    for (int i0 = 0; i0 < fr[f].nf; i0 += 16) items.push_back(FcExpItem{(int)f, i0});
+  h->pexp_n = (int64_t)items.size();
+  if (items.empty()) items.push_back(FcExpItem{0, 0});
+  FCCHK(h->pexp.upload(items, h->stream));
   if (fr.empty()) fr.push_back(FcFront{0, 0, 0, 0, 0});
   FCCHK(h->pscratch.alloc((size_t)scratch_max));
   FCCHK(h->pfront.upload(fr, h->stream));
@@ -2529,15 +2538,22 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
           hipLaunchKernelGGL(fc_fe_update<FC_FE_KB>, dim3(ct * ct + 1, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
         }
       }
-      // (the root of a multi-GPU layout: only this handle's block of pivot rows has storage)
-      const bool root_block = li == n_levels - 1 && h->root_x0 >= 0;
-      const int xr0 = root_block ? h->root_x0 : 0, xr1 = root_block ? h->root_x0 + h->root_xn : INT_MAX;
+      HIPCHK(hipGetLastError());
+    }
+  }
+  {
+    // all fronts -> the layout the sweeps read, in the storage type of the slot (the root of a multi-GPU layout: only this handle's
+    // block of pivot rows has storage)
+    const int n_items = (int)h->pexp_n;
+    const int root_front = h->root_x0 >= 0 ? (int)h->pfront_total - 1 : -1;
+    const int xr0 = h->root_x0 >= 0 ? h->root_x0 : 0, xr1 = h->root_x0 >= 0 ? h->root_x0 + h->root_xn : INT_MAX;
+    if (n_items > 0) {
       if (S.bits == 64)
-        hipLaunchKernelGGL(fc_fe_export<double>, dim3((nfmax + 15) / 16, grp.second), dim3(256), 0, h->stream, fp, F, fv, xr0, xr1);
+        hipLaunchKernelGGL(fc_fe_export<double>, dim3(n_items), dim3(256), 0, h->stream, h->pfront.p, h->pexp.p, F, fv, root_front, xr0, xr1);
       else if (S.bits == 32)
-        hipLaunchKernelGGL(fc_fe_export<float>, dim3((nfmax + 15) / 16, grp.second), dim3(256), 0, h->stream, fp, F, S.f_val32.p, xr0, xr1);
+        hipLaunchKernelGGL(fc_fe_export<float>, dim3(n_items), dim3(256), 0, h->stream, h->pfront.p, h->pexp.p, F, S.f_val32.p, root_front, xr0, xr1);
       else
-        hipLaunchKernelGGL(fc_fe_export<FcBf16>, dim3((nfmax + 15) / 16, grp.second), dim3(256), 0, h->stream, fp, F, S.f_val16.p, xr0, xr1);
+        hipLaunchKernelGGL(fc_fe_export<FcBf16>, dim3(n_items), dim3(256), 0, h->stream, h->pfront.p, h->pexp.p, F, S.f_val16.p, root_front, xr0, xr1);
       HIPCHK(hipGetLastError());
     }
   }
