@@ -2444,8 +2444,6 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
   const double* av = h->vals[slot].p;
   double* F = h->fronts.p;
   double* fv = S.f_val.p;
-  // permuted copy of the matrix for the residual monitor
-  hipLaunchKernelGGL(fc_gather64, dim3(nblocks(S.Ap_nnz, 256)), dim3(256), 0, h->stream, S.Ap_nnz, h->pap_src.p, av, S.Ap_val.p);
   HIPCHK(hipMemsetAsync(F, 0, h->fronts.n * sizeof(double), h->stream));
   const int n_levels = (int)h->plevel_ptr.size() - 1;
   // multi-GPU: this rank's plan holds its own sub-tree and the root (fc_factor_plan built with keep=): the root front is
@@ -2453,8 +2451,9 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
   const bool dist = h->partitioned && exchanges(h) && h->nranks > 1;
   int64_t n_a = h->pa_ptr.back();
   if (dist && !h->lead) n_a = h->pa_ptr[(size_t)n_levels - 1];  // entries below the root level
-  if (n_a > 0)
-    hipLaunchKernelGGL(fc_front_scatter, dim3(nblocks(n_a, 256)), dim3(256), 0, h->stream, n_a, h->pa_src.p, h->pa_dst.p, av, F);
+  // matrix entries -> fronts, and (same launch) the permuted copy of the matrix for the residual monitor
+  hipLaunchKernelGGL(fc_front_scatter, dim3(nblocks(n_a + S.Ap_nnz, 256)), dim3(256), 0, h->stream, n_a, h->pa_src.p, h->pa_dst.p, av, F,
+                     (int64_t)S.Ap_nnz, h->pap_src.p, S.Ap_val.p);
   if (h->pn_shift > 0) {
     int64_t skip0 = 0, skip1 = 0;  // the root front is summed over the ranks: only the lead rank shifts there
     if (dist && !h->lead) {

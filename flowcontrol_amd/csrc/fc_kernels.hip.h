@@ -577,10 +577,16 @@ __global__ __launch_bounds__(256) void fc_nd_down_block(const FcBlk* __restrict_
 // Device-side numeric factorisation (fc_refactor): index kernels around the dense front elimination (fc_front.hip.h).
 // ---------------------------------------------------------------------------------------------
 // fronts[a_dst[k]] = vals[a_src[k]]: every matrix entry has exactly one slot in exactly one front
+// (threads beyond n: the permuted copy of the matrix for the residual monitor, out2[k2] = vals[src2[k2]] -- the same gather from the
+//  same values, riding in this launch instead of one of its own)
 __global__ void fc_front_scatter(int64_t n, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
-                                 const double* __restrict__ vals, double* __restrict__ fronts) {
+                                 const double* __restrict__ vals, double* __restrict__ fronts, int64_t n2 = 0,
+                                 const int64_t* __restrict__ src2 = nullptr, double* __restrict__ out2 = nullptr) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < n) fronts[dst[k]] = vals[src[k]];
+  if (k < n)
+    fronts[dst[k]] = vals[src[k]];
+  else if (k - n < n2)
+    out2[k - n] = vals[src2[k - n]];
 }
 // fronts[slot[k]] += value[k]: diagonal shifts applied after the scatter (pressure pin of enclosed flows)
 // (multi-GPU: slots in [skip0, skip1) — the root front, which is summed over the ranks — are left to the lead rank)
