@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void fc_fe_update(const FcFront* __restrict__ 
 // 64-column steps.  The pivot block (128 x 128) is inverted by ONE workgroup per front entirely in LDS -- Gauss-Jordan in
 // four sub-steps of 32 columns: the 32 x 32 diagonal sub-block on one wave out of registers (fc_fe_gj_wave), its row panel
 // and the rank-32 update of the other 96 rows by all four waves out of LDS -- so the dependent chain of a 128-column step
-// is one launch.  Scratch of a front: W (128 x 128), then Cs (nf x 128).
+// is one launch.  Scratch of a front: W (128 x 128) then Cs (nf x 128), both stored [k / 4][row][k % 4].
 // ---------------------------------------------------------------------------------------------------------------------
 #define FC_FE_KH 128
 #define FC_FE_KH_LD (FC_FE_KH + 1)
@@ -598,9 +598,11 @@ __global__ __launch_bounds__(256) void fc_fe_pivot_huge(const FcFront* __restric
     }
     __syncthreads();
   }
+  // W goes out in the order fc_fe_panels_huge reads it as MFMA A operands: [k / 4][row][k % 4] (a wave's load of one k-step is then
+  // 16 rows x 32 B back to back instead of sixteen 32-B pieces a row apart)
   double* W = scratch + nd.scratch;
   for (int e = t; e < KH * KH; e += 256) {
-    const int r = e / KH, c = e % KH;
+    const int r = (e / 4) % KH, c = 4 * (e / (4 * KH)) + e % 4;
     W[e] = (r < kb && c < kb) ? a[r * LD + c] : 0.0;
   }
 }
@@ -624,9 +626,10 @@ __global__ __launch_bounds__(256) void fc_fe_panels_huge(const FcFront* __restri
   if ((int)blockIdx.x >= ct) {
     const int i0 = ((int)blockIdx.x - ct) * 64;
     if (i0 >= nf) return;
+    // Cs is stored [k / 4][row][k % 4]: the order fc_fe_update_huge reads it as MFMA A operands (16 rows x 32 B back to back per load)
     for (int e = t; e < 64 * KH; e += 256) {
       const int i = i0 + e / KH, c = e % KH;
-      if (i < nf) Cs[(size_t)i * KH + c] = c < kb ? A[(size_t)i * nf + k0 + c] : 0.0;
+      if (i < nf) Cs[((size_t)(c >> 2) * nf + i) * 4 + (c & 3)] = c < kb ? A[(size_t)i * nf + k0 + c] : 0.0;
     }
     return;
   }
@@ -643,7 +646,7 @@ __global__ __launch_bounds__(256) void fc_fe_panels_huge(const FcFront* __restri
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-    for (int s2 = 0; s2 < KH / 4; ++s2) av[rt][s2] = W[(size_t)(32 * wave + 16 * rt + lr) * KH + 4 * s2 + lk];
+    for (int s2 = 0; s2 < KH / 4; ++s2) av[rt][s2] = W[((size_t)s2 * KH + 32 * wave + 16 * rt + lr) * 4 + lk];  // W[row][4 s2 + lk], k-step major (fc_fe_pivot_huge)
   __syncthreads();
   fc_d4 acc[2][4];
 #pragma unroll
@@ -664,7 +667,7 @@ __global__ __launch_bounds__(256) void fc_fe_panels_huge(const FcFront* __restri
       for (int r = 0; r < 4; ++r) {
         const int row = 32 * wave + 16 * rt + lk + 4 * r;  // row of the pivot block
         if (row >= kb) continue;
-        A[(size_t)(k0 + row) * nf + j] = (j >= k0 && j < k0 + kb) ? W[(size_t)row * KH + (j - k0)] : acc[rt][c][r];
+        A[(size_t)(k0 + row) * nf + j] = (j >= k0 && j < k0 + kb) ? W[((size_t)((j - k0) >> 2) * KH + row) * 4 + ((j - k0) & 3)] : acc[rt][c][r];
       }
     }
 }
@@ -690,7 +693,7 @@ __global__ __launch_bounds__(256) void fc_fe_update_huge(const FcFront* __restri
   const int arow = i0 + 16 * wave + lr;
   double av[KH / 4];
 #pragma unroll
-  for (int s2 = 0; s2 < KH / 4; ++s2) av[s2] = arow < nf ? Cs[(size_t)arow * KH + 4 * s2 + lk] : 0.0;  // zero beyond kb (fc_fe_panels_huge)
+  for (int s2 = 0; s2 < KH / 4; ++s2) av[s2] = arow < nf ? Cs[((size_t)s2 * nf + arow) * 4 + lk] : 0.0;  // Cs[arow][4 s2 + lk], k-step major; zero beyond kb (fc_fe_panels_huge)
   double cv[4][4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
