@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void fc_fe_panels(const FcFront* __restrict__ 
     if (i0 >= nf) return;
     for (int e = t; e < 64 * KB; e += 256) {
       const int i = i0 + e / KB, c = e % KB;
-      if (i < nf) Cs[(size_t)i * KB + c] = c < kb ? A[(size_t)i * nf + k0 + c] : 0.0;
+      if (i < nf) Cs[((size_t)(c >> 2) * nf + i) * 4 + (c & 3)] = c < kb ? A[(size_t)i * nf + k0 + c] : 0.0;  // [k / 4][row][k % 4]: the order the update's MFMA A operands are loaded in
     }
     return;
   }
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void fc_fe_update(const FcFront* __restrict__ 
       double av[KB / 4], bv[KB / 4], cin[4];
 #pragma unroll
       for (int s4 = 0; s4 < KB / 4; ++s4) {
-        av[s4] = arow < nf ? Cs[(size_t)arow * KB + 4 * s4 + lk] : 0.0;  // zero beyond kb (fc_fe_panels)
+        av[s4] = arow < nf ? Cs[((size_t)s4 * nf + arow) * 4 + lk] : 0.0;  // Cs[arow][4 s4 + lk], k-step major; zero beyond kb (fc_fe_panels)
         bv[s4] = (4 * s4 + lk < kb && bcol < nf) ? A[(size_t)(k0 + 4 * s4 + lk) * nf + bcol] : 0.0;
       }
 #pragma unroll
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void fc_fe_update(const FcFront* __restrict__ 
   const int arow = i0 + 16 * wave + lr;
   double av[KB / 4];
 #pragma unroll
-  for (int s = 0; s < KB / 4; ++s) av[s] = arow < nf ? Cs[(size_t)arow * KB + 4 * s + lk] : 0.0;  // zero beyond kb (fc_fe_panels)
+  for (int s = 0; s < KB / 4; ++s) av[s] = arow < nf ? Cs[((size_t)s * nf + arow) * 4 + lk] : 0.0;  // Cs[arow][4 s + lk], k-step major; zero beyond kb (fc_fe_panels)
   // the wave's entries of the C tile (pivot rows and everything outside the front: not touched)
   double cv[4][4];
 #pragma unroll
