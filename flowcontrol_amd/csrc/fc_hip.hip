@@ -258,6 +258,7 @@ struct fc_ctx {
   };
   bool have_plan = false;
   bool huge_lds_ok = false;  // fc_fe_pivot_huge was granted its dynamic LDS
+  bool huge_refused = false;  // ... or was refused it: no 128-column steps on this handle
   int root_x0 = -1, root_xn = 0;  // multi-GPU: of the root's pivot rows (0-based inside its block) this handle stores [root_x0, root_x0 + root_xn) only (fc_set_root_rows); -1: all
   std::vector<PlanNode> pnodes;
   std::vector<int64_t> plevel_ptr, pa_ptr;
@@ -2510,15 +2511,20 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
       double huge_mb = FC_FE_HUGE_MB;
       if (const char* e = std::getenv("FC_FE_HUGE_NF")) huge_nf = std::atoi(e);
       if (const char* e = std::getenv("FC_FE_HUGE_MB")) huge_mb = std::atof(e);
-      const bool huge = h->plevel_max_nf[li] >= FC_FE_HUGE_MIN_NF &&  // (the scratch of smaller levels is not sized for it)
-                        (h->plevel_max_nf[li] >= huge_nf || (double)h->plevel_fsize[li] * 8e-6 >= huge_mb);
+      bool huge = !h->huge_refused && h->plevel_max_nf[li] >= FC_FE_HUGE_MIN_NF &&  // (the scratch of smaller levels is not sized for it)
+                  (h->plevel_max_nf[li] >= huge_nf || (double)h->plevel_fsize[li] * 8e-6 >= huge_mb);
+      if (huge && !h->huge_lds_ok) {  // 148 KB of LDS per workgroup: above the 64 KB a kernel gets without asking
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(fc_fe_pivot_huge), hipFuncAttributeMaxDynamicSharedMemorySize, FC_FE_KH_LDS_BYTES) == hipSuccess) {
+          h->huge_lds_ok = true;
+        } else {  // a runtime that does not grant it: the level takes 64- / 32-column steps (slower, same result)
+          (void)hipGetLastError();
+          h->huge_refused = true;
+          huge = false;
+        }
+      }
       const bool wide = !huge && h->plevel_max_nf[li] >= wide_nf;
       const int kbs = huge ? FC_FE_KH : (wide ? FC_FE_KB_WIDE : FC_FE_KB);
       const int steps = (h->plevel_max_ni[li] + kbs - 1) / kbs;
-      if (huge && !h->huge_lds_ok) {  // 146 KB of LDS per workgroup: above the 64 KB a kernel gets without asking
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_fe_pivot_huge), hipFuncAttributeMaxDynamicSharedMemorySize, FC_FE_KH_LDS_BYTES));
-        h->huge_lds_ok = true;
-      }
       for (int k = 0; k < steps; ++k) {
         if (huge) {
           // (a two-stream look-ahead -- the next pivot block's four tiles first, then its inversion beside the rest of the update -- was
