@@ -264,3 +264,36 @@ def test_batched_cavity_force_actuation_closed_loop(golden_dir):
     assert np.abs(ref["u"]).max() > 0.5  # the loop acts
     bfs.close()
     fs.th.release_device()
+
+
+def test_lidcavity_ic_sweep_example_matches_single_runs(tmp_path_factory):
+    """The reference's IC-sweep script (src/examples/lidcavity/batch_run_lidcavity.py) as ONE batch: an enclosed flow (the pressure
+    pin lives in the factorisation), k = 4 vortex positions, the snapshot files the reference writes — each run against a single
+    ``FlowSolver`` started from the same initial condition."""
+    from flowcontrol_amd.examples.lidcavity.batch_run_lidcavity import run_lidcavity_with_ics
+    from flowcontrol_amd.examples.lidcavity.lidcavityflowsolver import LidCavityFlowSolver
+    from flowcontrol_amd.flowsolverparameters import ParamIC
+
+    out = tmp_path_factory.mktemp("lid_batch")
+    ics = [ParamIC(xloc=x, yloc=y, radius=0.1, amplitude=0.1) for x, y in ((0.2, 0.2), (0.8, 0.2), (0.5, 0.5), (0.2, 0.8))]
+    dirs = [out / f"run{i + 1}" for i in range(len(ics))]
+    bfs = run_lidcavity_with_ics(1000.0, ics, dirs, num_steps=12, save_every=4, picard_iterations=12)
+    fs = bfs.fs
+    U0 = fs.fields.U0.vector().get_local()
+    for i in (0, 2):
+        U = np.load(dirs[i] / "U_field_alldata.npy")
+        assert U.shape == (fs.V.dim(), 3, 1) and np.load(dirs[i] / "UP0_field_data.npy").shape == (fs.W.dim(),)
+        single = LidCavityFlowSolver.make_default(Re=1000.0, path_out=out / f"single{i}", num_steps=12, save_every=0)
+        single._assign_steady_state(fs.fields.U0, fs.fields.P0)
+        single.params_ic = ics[i]
+        single.initialize_time_stepping(ic=None)
+        for n in range(12):
+            single.step([0.0])
+        u_single = single.fields.u_n.vector().get_local() + U0
+        assert np.linalg.norm(U[:, -1, 0] - u_single) <= 1e-10 * np.linalg.norm(u_single)
+        ts, tb = single.timeseries, bfs.timeseries(i)
+        yc = [c for c in ts.columns if c.startswith("y_meas_")]
+        assert np.allclose(tb[yc].to_numpy(), ts[yc].to_numpy(), rtol=1e-9, atol=1e-13)
+        single.th.release_device()
+    bfs.close()
+    fs.th.release_device()
