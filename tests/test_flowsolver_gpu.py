@@ -554,3 +554,27 @@ def test_make_solver_plugin_written_against_the_reference_contract(tmp_path_fact
     y_again = [fs.step(u_ctrl=[0.01, -0.01]).copy() for _ in range(3)]
     assert np.allclose(np.array(y_again), np.array(y_slot), rtol=1e-12, atol=1e-15)
     fs.th.release_device()
+
+
+def test_base_flow_continuation_in_reynolds_number(tmp_path_factory):
+    """The reference's Re-continuation script for the lid-driven cavity (compute_steady_state_increasing_Re.py): each base flow
+    starts from the previous one, read back from the files the script writes; the last one is a converged steady state of ITS
+    Reynolds number (residual of the steady equations) and is what a solver loads with load_steady_state(path_u_p=...)."""
+    from flowcontrol_amd.examples.lidcavity.compute_steady_state_increasing_Re import continuation
+    from flowcontrol_amd.examples.lidcavity.lidcavityflowsolver import LidCavityFlowSolver
+
+    out = tmp_path_factory.mktemp("lid_continuation")
+    found = continuation(re_list=[400, 1000, 2000], path_out=out, picard_iterations=6, newton_iterations=15)
+    assert sorted(found) == [400, 1000, 2000] and (out / "steady" / "U0_Re=2000.xdmf").exists()
+    fs = LidCavityFlowSolver.make_default(Re=2000, path_out=out, num_steps=3)
+    fs.load_steady_state(path_u_p=[out / "steady" / "U0_Re=2000.xdmf", out / "steady" / "P0_Re=2000.xdmf"])
+    assert np.allclose(fs.fields.U0.vector().get_local(), found[2000][0].vector().get_local(), rtol=0, atol=1e-12)
+    # a steady state: the perturbation equations started from zero perturbation stay at zero
+    fs.params_ic = ParamIC(xloc=0.5, yloc=0.5, radius=0.1, amplitude=0.0)  # (the default adds a vortex to whatever ic is passed)
+    fs.initialize_time_stepping(ic=Function(fs.W))
+    for _ in range(3):
+        fs.step([0.0])
+    assert np.abs(fs.fields.u_n.vector().get_local()).max() < 1e-8
+    # ... and not the base flow of a lower Reynolds number
+    assert np.abs(found[2000][0].vector().get_local() - found[1000][0].vector().get_local()).max() > 1e-3
+    fs.th.release_device()
