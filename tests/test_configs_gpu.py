@@ -254,3 +254,19 @@ def test_config3_cavity_fine_closed_loop_vs_oracle(tmp_path_factory, golden_dir)
     b_ref[dofs] = g_[dofs]
     assert _rel(b_dev, b_ref) < 1e-12
     fs.th.release_device()
+
+
+def test_example_scripts_run_end_to_end(tmp_path_factory):
+    """The run scripts a user of the reference starts from (run_lidcavity_example.py, run_pinball_suction_example.py): a few steps of
+    each, finite measurements, the time series file, residuals at round-off."""
+    from flowcontrol_amd.examples.lidcavity import run_lidcavity_example
+    from flowcontrol_amd.examples.pinball import run_pinball_suction_example
+
+    fs = run_lidcavity_example.main(num_steps=5, path_out=tmp_path_factory.mktemp("ex_lid"), Re=1000)
+    assert np.all(np.isfinite(fs.y_meas)) and fs.solve_info[1] < 1e-10 and len(fs.timeseries) == 6
+    assert any(p.suffix == ".csv" for p in Path(fs.params_save.path_out).rglob("*"))
+    fs.th.release_device()
+    fs = run_pinball_suction_example.main(num_steps=4, path_out=tmp_path_factory.mktemp("ex_pinball"))
+    assert np.all(np.isfinite(fs.y_meas)) and fs.solve_info[1] < 1e-10
+    assert np.abs(fs.timeseries[["u_ctrl_1", "u_ctrl_2", "u_ctrl_3"]].to_numpy()[1:]).max() > 0  # the bumps were applied
+    fs.th.release_device()
