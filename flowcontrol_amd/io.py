@@ -236,3 +236,39 @@ def read_xdmf(filename, func: Function, name: str, counter: int = -1) -> float:
 
 
 __all__ = ["write_xdmf", "read_xdmf", "dolfin_tables"]
+
+
+def export_sparse_matrix(A, figname=None) -> bool:
+    """Spy plot of a sparse (or dense) matrix as PNG (reference ``utils/io.py:254-272``).  Needs matplotlib, which this image does
+    not ship: returns False (and writes nothing) when it cannot be imported."""
+    try:
+        import matplotlib
+
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+    except ImportError:
+        return False
+    import scipy.sparse as sp
+
+    M = A if sp.issparse(A) else sp.csr_matrix(np.asarray(A))
+    fig, ax = plt.subplots()
+    ax.spy(M, markersize=1)
+    ax.set_title("Sparse matrix plot")
+    fig.savefig(figname if figname is not None else "spy.png")
+    plt.close(fig)
+    return True
+
+
+def export_square_operators(path, operators, operators_names) -> None:
+    """``<name>.npz`` (CSR) and ``<name>_coo.npz`` (COO) per operator — the files the reference's control-design scripts load
+    (``utils/io.py:237-251``) — plus ``<name>.png`` when matplotlib is available."""
+    import scipy.sparse as sp
+
+    d = Path(path)
+    d.mkdir(parents=True, exist_ok=True)
+    for M, name in zip(operators, operators_names):
+        csr = sp.csr_matrix(M)
+        export_sparse_matrix(csr, d / f"{name}.png")
+        sp.save_npz(d / f"{name}.npz", csr)
+        sp.save_npz(d / f"{name}_coo.npz", csr.tocoo())
+

@@ -70,3 +70,19 @@ def test_mass_B_C(fs_cylinder):
     assert np.allclose(C @ x.vector().get_local(), y, rtol=1e-10)  # reference :238-254
     A, E2, B2, C2 = og.get_all()
     assert A.shape == E2.shape and np.array_equal(B2, B) and np.array_equal(C2, C)
+
+
+def test_operator_files_of_the_example(fs_cylinder, tmp_path):
+    """examples/operators/compute_operators.py writes what the reference writes: A.npz / A_coo.npz / E.npz / E_coo.npz, loadable
+    with scipy and equal to what OperatorGetter returns (reference utils/io.py:237-251)."""
+    import scipy.sparse as sp
+
+    from flowcontrol_amd.examples.operators.compute_operators import compute_operators_flowsolver
+
+    A, E, B, C = compute_operators_flowsolver(fs_cylinder, export=True, path=tmp_path)
+    for name, M in (("A", A), ("E", E)):
+        csr, coo = sp.load_npz(tmp_path / f"{name}.npz"), sp.load_npz(tmp_path / f"{name}_coo.npz")
+        assert csr.format == "csr" and coo.format == "coo"
+        assert abs(csr - sp.csr_matrix(M)).max() == 0.0 and abs(coo.tocsr() - csr).max() == 0.0
+    assert np.sqrt((sp.csr_matrix(A).data ** 2).sum()) == pytest.approx(55.37024024761875, rel=1e-6)  # test_operatorgetter.py:24
+    assert B.shape[0] == A.shape[0] and C.shape[1] == A.shape[0]
