@@ -21,6 +21,7 @@ def main(num_steps: int = 100, path_out: Path | None = None, Re: float = 8000):
     out = Path(path_out) if path_out else Path.cwd() / "data_output"
     fs = LidCavityFlowSolver.make_default(Re=Re, path_out=out, num_steps=num_steps, save_every=20, verbose=10)
     fs.params_ic = ParamIC(xloc=0.1, yloc=0.1, radius=0.1, amplitude=0.1)
+    flu.export_subdomains(fs.mesh, fs.boundaries.subdomain, out / "subdomains.xdmf")
     t0 = time.perf_counter()
     fs.compute_steady_state(method="picard", max_iter=40, tol=1e-7, u_ctrl=[0.0])
     print(f"base flow on {fs.th.N} dofs: {time.perf_counter() - t0:.2f} s")

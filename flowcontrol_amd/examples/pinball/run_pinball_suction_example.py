@@ -12,6 +12,7 @@ import sys
 import time
 from pathlib import Path
 
+from flowcontrol_amd import utils as flu
 from flowcontrol_amd.actuator import CYLINDER_ACTUATION_MODE
 from flowcontrol_amd.examples.pinball.pinballflowsolver import PinballCustomInitialGuess, PinballFlowSolver
 from flowcontrol_amd.examples.pinball.run_pinball_rotation_example import gaussian_bump
@@ -26,6 +27,7 @@ def main(num_steps: int = 20, path_out: Path | None = None):
     fs = PinballFlowSolver.make_default(Re=100, mode_actuation=CYLINDER_ACTUATION_MODE.SUCTION, path_out=out, num_steps=num_steps,
                                         save_every=10, verbose=10)
     fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
+    flu.export_subdomains(fs.mesh, fs.boundaries.subdomain, out / "subdomains.xdmf")
     start = PinballCustomInitialGuess(mode="antisymmetric_bot").as_dolfin_function(function_space=fs.W)
     t0 = time.perf_counter()
     fs.compute_steady_state(method="picard", max_iter=15, tol=1e-7, u_ctrl=[0.0, 0.0, 0.0], initial_guess=start)

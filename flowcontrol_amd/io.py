@@ -31,6 +31,7 @@ verified against dolfin itself: neither dolfin nor h5py exist in this image.
 
 from __future__ import annotations
 
+import logging
 import re
 import xml.etree.ElementTree as ET
 from pathlib import Path
@@ -39,6 +40,8 @@ import numpy as np
 
 from .fem.hdf5_min import MinimalHDF5, write_hdf5
 from .fem.spaces import Function
+
+logger = logging.getLogger(__name__)
 
 _ELEMENT = {"V": ("CG", 2, "Vector"), "P": ("CG", 1, "Scalar"), "W": ("Mixed", 2, "Vector")}
 
@@ -271,4 +274,31 @@ def export_square_operators(path, operators, operators_names) -> None:
         export_sparse_matrix(csr, d / f"{name}.png")
         sp.save_npz(d / f"{name}.npz", csr)
         sp.save_npz(d / f"{name}_coo.npz", csr.tocoo())
+
+
+def export_subdomains(mesh, subdomains_list, filename="subdomains.xdmf") -> np.ndarray:
+    """Facet markers of the boundary sub-domains for visualisation (reference ``utils/io.py:171-185``: a facet
+    ``MeshFunction`` with 0 everywhere and i + 1 on the facets of ``subdomains_list[i]``, later entries overwriting earlier
+    ones), written as an XDMF file over the mesh EDGES (``Polyline`` cells with one integer attribute ``f``; heavy data in
+    ``<stem>.h5``) that ParaView opens.  Usage as in the reference: ``export_subdomains(fs.mesh, fs.boundaries.subdomain, path)``.
+    Returns the marker array (one entry per mesh edge)."""
+    path = Path(filename)
+    path.parent.mkdir(parents=True, exist_ok=True)
+    markers = np.zeros(mesh.edges.shape[0], dtype=np.int64)
+    for i, sub in enumerate(subdomains_list):
+        sub.mark(markers, i + 1, mesh)
+        logger.info("Marking subdomain nr: %d", i + 1)
+    h5 = path.with_suffix(".h5")
+    write_hdf5(h5, {"mesh": {"topology": mesh.edges.astype(np.int64), "geometry": np.asarray(mesh.coords, dtype=np.float64)},
+                    "f": markers.reshape(-1, 1)})
+    ne, nv = mesh.edges.shape[0], mesh.coords.shape[0]
+    path.write_text(
+        '<?xml version="1.0"?>\n<Xdmf Version="3.0"><Domain><Grid Name="subdomains" GridType="Uniform">\n'
+        f'<Topology TopologyType="Polyline" NodesPerElement="2" NumberOfElements="{ne}">'
+        f'<DataItem Dimensions="{ne} 2" NumberType="Int" Precision="8" Format="HDF">{h5.name}:/mesh/topology</DataItem></Topology>\n'
+        f'<Geometry GeometryType="XY"><DataItem Dimensions="{nv} 2" NumberType="Float" Precision="8" Format="HDF">{h5.name}:/mesh/geometry</DataItem></Geometry>\n'
+        f'<Attribute Name="f" AttributeType="Scalar" Center="Cell"><DataItem Dimensions="{ne} 1" NumberType="Int" Precision="8" Format="HDF">{h5.name}:/f</DataItem></Attribute>\n'
+        "</Grid></Domain></Xdmf>\n")
+    logger.info("Writing subdomains file: %s", path)
+    return markers
 

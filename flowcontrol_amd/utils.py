@@ -1,6 +1,8 @@
 """Small helpers user scripts import from the reference's ``utils`` package
 (``utils/utils_flowsolver.py`` aggregator: ``flu.apply_fun``, ``flu.MpiUtils``, ``flu.summarize_timings``,
-``flu.read_xdmf`` / ``flu.write_xdmf`` as the lid-cavity scripts use them, ``flu.boundary_force``)."""
+``flu.read_xdmf`` / ``flu.write_xdmf`` as the lid-cavity scripts use them, ``flu.export_subdomains``, ``flu.export_square_operators``,
+the ``*_cpp`` predicate builders, ``flu.boundary_force``).  The control-design, frequency-response and eigenvalue helpers the
+reference aggregates under the same name need python-control / PETSc / SLEPc and are not part of this package."""
 
 from __future__ import annotations
 
@@ -11,7 +13,8 @@ from typing import Any, Callable
 import numpy as np
 
 from .fem.forces import boundary_force, force_coefficients  # noqa: F401  (flu.* names)
-from .io import read_xdmf, write_xdmf  # noqa: F401
+from .dolfin_compat import and_cpp, between_cpp, near_cpp, on_boundary_cpp, or_cpp  # noqa: F401  (C-string predicates of the case files)
+from .io import export_sparse_matrix, export_square_operators, export_subdomains, read_xdmf, write_xdmf  # noqa: F401
 
 logger = logging.getLogger(__name__)
 

@@ -575,3 +575,27 @@ def test_boundary_force_of_a_linear_flow_on_the_unit_square():
     assert np.isclose(Fx, -(S[0, 0] - 2.375)) and np.isclose(Fy, -S[1, 0])
     Fx, Fy = boundary_force(th, be, nu, u, p)  # closed boundary: ∮ p n ds = ∇p |Ω|
     assert np.isclose(Fx, 0.5, atol=1e-12) and np.isclose(Fy, -0.25, atol=1e-12)
+
+
+def test_export_subdomains_writes_facet_markers(tmp_path):
+    """flu.export_subdomains (reference utils/io.py:171-185): 0 everywhere, i + 1 on the facets of sub-domain i, later entries
+    win; an XDMF file over the mesh edges whose heavy data reads back."""
+    from flowcontrol_amd import utils as flu
+    from flowcontrol_amd.fem.boundary import SubDomain
+    from flowcontrol_amd.fem.hdf5_min import read_dataset
+    from flowcontrol_amd.fem.mesh import Mesh
+
+    m = Mesh.unit_square(4, 4)
+    left = SubDomain(lambda x, ob: ob & (np.abs(x[:, 0]) < 1e-12))
+    walls = SubDomain(lambda x, ob: ob)  # every boundary facet, listed last: overwrites `left`
+    top = SubDomain(lambda x, ob: ob & (np.abs(x[:, 1] - 1.0) < 1e-12))
+    mk = flu.export_subdomains(m, [left, top], tmp_path / "sub.xdmf")
+    assert np.bincount(mk).tolist() == [m.edges.shape[0] - 8, 4, 4]
+    assert np.array_equal(read_dataset(tmp_path / "sub.h5", "/f").ravel(), mk)
+    assert np.array_equal(read_dataset(tmp_path / "sub.h5", "/mesh/topology"), m.edges)
+    xml = (tmp_path / "sub.xdmf").read_text()
+    assert 'TopologyType="Polyline"' in xml and "sub.h5:/f" in xml
+    mk2 = flu.export_subdomains(m, [left, walls], tmp_path / "sub2.xdmf")
+    assert np.bincount(mk2).tolist() == [m.edges.shape[0] - 16, 0, 16]
+    # the aggregator carries the predicate builders the case files use
+    assert flu.near_cpp("x[0]", 1.0) == "near(x[0], 1.0, MESH_TOL)" and flu.on_boundary_cpp() == "on_boundary"
