@@ -211,6 +211,8 @@ struct fc_ctx {
   double rtol = 1e-10;
   // state + work
   DevBuf<double> u_n, u_nn, p_n, up;
+  DevBuf<int> asm_cells;  // multi-GPU: cells whose element matrices this rank assembles (own + touching a root dof)
+  int n_asm = 0;
   DevBuf<double> u_old, p_old;  // what the last step's shift overwrote (u_nn, p_n before it): fc_undo_step
   bool undo_ok = false;
   DevBuf<double> b, buf, xsol, tmpN, tmpN2;  // buf = [y | x] (2N)
@@ -229,7 +231,7 @@ struct fc_ctx {
   std::vector<unsigned char> h_rowkind;  // original numbering: 0 other rank, 1 owned, 2 shared root
   DevBuf<int> cell_list;
   DevBuf<unsigned char> rowkind_p;  // permuted numbering
-  DevBuf<unsigned char> rowkind_w;  // W numbering (columns of an explicit rhs operator)
+  DevBuf<unsigned char> rowkind_w;  // W numbering (columns of an explicit rhs operator; row mask of the collective fc_spmv)
   DevBuf<unsigned char> rootmask_p;  // 1 on the root's rows (permuted numbering): row mask of the partitioned Krylov mat-vec
   void* comm = nullptr;             // ncclComm_t
   int nranks = 1, rank = 0;
@@ -1518,8 +1520,12 @@ int fc_assemble_matrix(fc_handle h, int slot, double mass, double nu, const doub
     HIPCHK(hipMemcpyAsync(h->tmpN2.p, lin, nv2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     d_lin = h->tmpN2.p;
   }
-  hipLaunchKernelGGL(fc_mat_elem, dim3(nblocks(h->nc, 256), 6), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p,
-                     h->geom.p, mass, nu, d_adv, adv_scale, d_lin, lin_scale, pressure, divergence, h->em.p);
+  // (a partitioned handle assembles the element matrices of its own cells and of the cells touching a root dof: the rows it owns and
+  //  the root's rows come out complete, the other ranks' rows -- never read on this rank -- partial)
+  const bool sub = h->partitioned && h->n_asm > 0;
+  hipLaunchKernelGGL(fc_mat_elem, dim3(nblocks(sub ? h->n_asm : h->nc, 256), 6), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p,
+                     h->geom.p, mass, nu, d_adv, adv_scale, d_lin, lin_scale, pressure, divergence, h->em.p,
+                     sub ? h->asm_cells.p : nullptr, sub ? h->n_asm : 0);
   hipLaunchKernelGGL(fc_mat_gather, dim3(nblocks(h->nnz, 256)), dim3(256), 0, h->stream, h->nnz, h->mptr.p, h->midx.p,
                      h->em.p, h->vals[slot].p);
   HIPCHK(hipGetLastError());
@@ -1558,6 +1564,12 @@ int fc_spmv(fc_handle h, int slot, const double* x, double* y) {
   const int nb = launch_spmv<0>(h, h->N, (double)h->nnz / h->N, h->rowptr.p, h->col.p, h->vals[slot].p, h->tmpN.p, nullptr,
                                 h->tmpN2.p, nullptr, nullptr);
   if (nb < 0) return nb;
+  if (h->partitioned && exchanges(h) && h->rowkind_w.n == (size_t)h->N) {
+    // a partitioned handle holds complete rows for the dofs it owns and for the root's only (fc_assemble_matrix): the product is a
+    // collective -- every rank keeps the rows it accounts for (its own; the root's on the lead rank), one all-reduce assembles it
+    hipLaunchKernelGGL(fc_mask_rows, dim3(nblocks(h->N, 256)), dim3(256), 0, h->stream, h->N, h->rowkind_w.p, h->lead ? 1 : 0, h->tmpN2.p);
+    FCCHK(exchange(h, h->tmpN2.p, (size_t)h->N));
+  }
   HIPCHK(hipMemcpyAsync(y, h->tmpN2.p, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return FC_OK;
@@ -2664,6 +2676,15 @@ int fc_set_pressure_pin(fc_handle h, int32_t dof, double shift) {
   return apply_pressure_pin(h);
 }
 
+int fc_get_partition_info(fc_handle h, int32_t* out) {
+  if (!h || !out) return fail(FC_ERR_INVALID, "fc_get_partition_info: null argument");
+  out[0] = h->partitioned ? h->ncl : h->nc;                      // cells whose right-hand side / energy this rank computes
+  out[1] = h->partitioned && h->n_asm > 0 ? h->n_asm : h->nc;    // cells whose element matrices it assembles (own + along the separator)
+  out[2] = h->partitioned ? (h->lead ? 1 : 0) : 1;
+  out[3] = (h->comm || h->host_xchg) ? h->nranks : 1;
+  return FC_OK;
+}
+
 int fc_get_local_cells(fc_handle h, int32_t* cells) {
   if (!h || !cells) return fail(FC_ERR_INVALID, "fc_get_local_cells: null argument");
   if (h->partitioned)
@@ -3554,6 +3575,21 @@ int fc_set_partition(fc_handle h, int32_t n_local_cells, const int32_t* local_ce
   std::vector<int> cl(std::max(1, n_local_cells), 0);
   std::copy(local_cells, local_cells + n_local_cells, cl.begin());
   FCCHK(h->cell_list.upload(cl, h->stream));
+  {
+    // cells whose element MATRICES this rank needs: every cell with a dof it owns or a root dof (its own cells, and the other ranks'
+    // cells along the separator).  The element matrices of all other cells are zeroed once and never written again.
+    std::vector<int> ac;
+    for (int c = 0; c < nc; ++c) {
+      bool need = false;
+      for (int k = 0; k < 15 && !need; ++k) need = rowkind[h->h_cell_dofs[(size_t)c * 15 + k]] != 0;
+      if (need) ac.push_back(c);
+    }
+    h->n_asm = (int)ac.size();
+    if (ac.empty()) ac.push_back(0);
+    FCCHK(h->asm_cells.upload(ac, h->stream));
+    FCCHK(h->rowkind_w.upload(rowkind, (size_t)N, h->stream));
+    FCCHK(h->em.zero(h->stream));
+  }
   // element -> row gather lists restricted to this rank's cells (same fixed order as the serial lists)
   {
     std::vector<int> cnh((size_t)6 * nc);

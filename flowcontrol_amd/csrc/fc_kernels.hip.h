@@ -168,10 +168,14 @@ __global__ __launch_bounds__(256) void fc_mat_elem(int nc, int nn, const int* __
                                                    double nu, const double* __restrict__ adv,
                                                    double adv_scale, const double* __restrict__ lin,
                                                    double lin_scale, double pressure, double divergence,
-                                                   double* __restrict__ em) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+                                                   double* __restrict__ em, const int* __restrict__ cell_list = nullptr,
+                                                   int ncl = 0) {
+  // (multi-GPU: cell_list = the cells whose element matrices this rank needs -- its own and those touching a root dof;
+  //  the element matrices of the others keep their zeros)
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int a = blockIdx.y;  // wave-uniform test node
-  if (c >= nc) return;
+  if (tid >= (cell_list ? ncl : nc)) return;
+  const int c = cell_list ? cell_list[tid] : tid;
   const double j00 = geom[c], j01 = geom[nc + c], j10 = geom[2 * nc + c], j11 = geom[3 * nc + c];
   const double hdet = 0.5 * geom[4 * nc + c];
   double Ux[6], Uy[6], Lx[6], Ly[6];

@@ -493,6 +493,12 @@ class DeviceSolver:
         p = None if p_n is None else _f64(p_n)
         check(self.lib.fc_set_state(self._h, _f64(u_n), _f64(u_nn), ptr(p)))
 
+    def partition_info(self) -> dict:
+        """Cells this rank computes the right-hand side for / assembles element matrices of, lead flag, ranks."""
+        out = np.zeros(4, dtype=np.int32)
+        check(self.lib.fc_get_partition_info(self._h, out))
+        return {"rhs_cells": int(out[0]), "matrix_cells": int(out[1]), "lead": bool(out[2]), "ranks": int(out[3])}
+
     def undo_step(self) -> None:
         """``fc_undo_step``: (u_n, u_nn, p_n) as they were before the last single step (after FC_ERR_DIVERGED: the reference's
         state is untouched by a failed step, flowsolver.py:727-751)."""

@@ -170,6 +170,12 @@ int fc_set_pressure_pin(fc_handle h, int32_t dof, double shift);
 /* device milliseconds of the slot's last numeric factorisation (fc_refactor, also inside fc_setup_solver) */
 int fc_get_refactor_ms(fc_handle h, int slot, double* ms);
 int fc_get_local_cells(fc_handle h, int32_t* cells /* [info[8] of fc_get_solver_info] */);
+/* out[4]: cells of this rank (right-hand side, energy), cells whose element matrices fc_assemble_matrix computes on this handle (its own
+ * and the other ranks' cells that touch a root dof: the rows a rank owns and the root's rows are complete, the other ranks' rows are
+ * never read), lead rank (0 / 1), ranks.  A single-GPU handle: all cells, all cells, 1, 1. */
+int fc_get_partition_info(fc_handle h, int32_t* out);
+/* (On a partitioned handle fc_get_matrix_values returns this rank's view -- complete rows for the dofs it owns and the root's, partial
+ * rows elsewhere -- and fc_spmv is a collective: every rank calls it with the same x and receives the whole product.) */
 int fc_get_rowkind(fc_handle h, uint8_t* rowkind /* [N]: 0 other rank, 1 owned, 2 root (all 1 on a single-GPU handle) */);
 /* One-launch factor apply (replaces the 2*depth+1 level launches of LUSolver.solve, flowsolver.py:729, by ONE
  * grid whose workgroups wait for each other through per-node arrival counters; fc_dag.hip.h).  `nodes` has 7

@@ -68,6 +68,8 @@ def _worker(rank, world, port, out, nsteps, backend="gloo", refine=0, scheme="bd
 
         dev = fs.th.device()
         slot = next(iter(dev.factor_nnz))  # Crank-Nicolson keeps its one operator in the first slot
+        pi = dev.partition_info()
+        out[f"matrix_cells{rank}"] = (pi["rhs_cells"], pi["matrix_cells"], fs.th.nc)
         out[f"values{rank}"] = int(dev.local_factor_nnz)  # factor values this rank sweeps per solve
         out[f"stored{rank}"] = int(dev.factor_nnz[slot])  # ... and stores (its sub-tree + the root's pivot block)
         if rank == 0:
@@ -114,6 +116,10 @@ def test_partitioned_ranks_reproduce_the_serial_run(world, refine, scheme, bits)
         if bits != 64:
             assert 1 <= out["krylov_its"] <= 6, out["krylov_its"]  # the single-GPU count (2-3 with fp32 storage), over two ranks
         assert abs(out["cells"] - 12284 // world) <= 1
+        # a rank assembles the element matrices of its own cells and of the cells along the separator, not of the whole mesh
+        for r in range(world):
+            own, asm, nc = out[f"matrix_cells{r}"]
+            assert own <= asm <= own + 0.15 * nc and asm < 0.8 * nc, (own, asm, nc)
         # no replicated sweep work: the ranks' factor values add up to the serial count, evenly
         shares = [out[f"values{r}"] for r in range(world)]
         assert sum(shares) == out["total_values"]
@@ -123,6 +129,20 @@ def test_partitioned_ranks_reproduce_the_serial_run(world, refine, scheme, bits)
         stored = [out[f"stored{r}"] for r in range(world)]
         assert sum(stored) == out["total_values"]
         assert max(stored) < 1.25 * out["total_values"] / world
+
+
+def _merged_matrix(dev, slot, rank):
+    """A partitioned handle assembles complete rows for the dofs it owns and for the root's only: the whole matrix is the
+    ranks' owned rows (+ the root's rows from rank 0), summed over the ranks."""
+    import scipy.sparse as sp
+    import torch
+
+    A = dev.matrix(slot)
+    kind = np.asarray(dev.part.rowkind)
+    keep = (kind == 1) | ((kind == 2) & (rank == 0))
+    data = torch.from_numpy(A.data * np.repeat(keep, np.diff(A.indptr)))
+    dist.all_reduce(data)
+    return sp.csr_matrix((data.numpy(), A.indices, A.indptr), shape=A.shape)
 
 
 def _steady_worker(rank, world, port, out):
@@ -145,7 +165,9 @@ def _steady_worker(rank, world, port, out):
         b = np.cos(0.37 * np.arange(dev.N) + 0.1)
         dev.refactor(SLOT_BDF1)  # Newton may have finished on lagged factors; the acceptance probe inside is a collective too
         x, info = dev.solve(SLOT_BDF1, b)
-        A = dev.matrix(SLOT_BDF1)
+        A = _merged_matrix(dev, SLOT_BDF1, rank)
+        own_rows_only = float(np.linalg.norm(dev.matrix(SLOT_BDF1) @ x - b) / np.linalg.norm(b))  # this rank's copy alone is NOT the operator
+        Ax_collective = dev.spmv(SLOT_BDF1, x)  # ... fc_spmv on a partitioned handle is a collective and is
         # the operator moves on, the factors stay: BiCGStab over the ranks (dots, root rows of the mat-vec and the
         # preconditioner's two exchanges are all collectives)
         U = 1.3 * fs.fields.UP0.vector().get_local()[: 2 * fs.th.nn]
@@ -156,7 +178,7 @@ def _steady_worker(rank, world, port, out):
         xk, infok = dev.solve(SLOT_BDF1, b)
         dev.set_solver_options(refine=60, method="gmres", rtol=1e-12)  # ... and GMRES(30): its inner products go through the exchange
         xg, infog = dev.solve(SLOT_BDF1, b)
-        A1 = dev.matrix(SLOT_BDF1)
+        A1 = _merged_matrix(dev, SLOT_BDF1, rank)
         # ... and refinement on the lagged factors: two sweeps of a (here slowly converging) Richardson iteration must at
         # least cut the residual of the plain apply
         dev.set_solver_options(refine=0, method="refine")
@@ -168,6 +190,8 @@ def _steady_worker(rank, world, port, out):
 
             out["UP0"] = fs.fields.UP0.vector().get_local()
             out["solve_res"] = float(np.linalg.norm(A @ x - b) / np.linalg.norm(b))
+            out["spmv_res"] = float(np.linalg.norm(Ax_collective - b) / np.linalg.norm(b))
+            out["own_rows_only"] = own_rows_only
             out["info_res"] = float(info[1])
             x1 = spla.splu(A1.tocsc()).solve(b)
             out["krylov_err"] = float(np.linalg.norm(xk - x1) / np.linalg.norm(x1))
@@ -192,7 +216,8 @@ def test_base_flow_on_a_partitioned_handle():
         nn2 = int(np.count_nonzero(np.isfinite(g["UP0"])))  # whole vector
         rel = np.linalg.norm(out["UP0"][:nn2] - g["UP0"][:nn2]) / np.linalg.norm(g["UP0"][:nn2])
         assert rel < 1e-9, rel
-        assert out["solve_res"] < 1e-10 and out["info_res"] < 1e-10
+        assert out["solve_res"] < 1e-10 and out["info_res"] < 1e-10 and out["spmv_res"] < 1e-10
+        assert out["own_rows_only"] > 1e-3  # the rows of the other rank are not assembled on this one
         assert out["moved"] > 1e-3 and out["krylov_err"] < 1e-9 and 1 < out["krylov_its"] <= 60, dict(out)
         assert out["gmres_err"] < 1e-9 and 1 < out["gmres_its"] <= 60, dict(out)
         assert out["refine_gain"] < 0.2, out["refine_gain"]  # three refinement sweeps over the ranks do reduce the residual
