@@ -298,7 +298,8 @@ def main() -> None:
         comm = fs.th.device().comm_info()
         part_info = {"local_cells": int(fs.th.device().part.local_cells.size), "root_dofs": int(fs.th.device().part.ar_n),
                      "local_factor_nnz": int(fs.th.device().local_factor_nnz),  # factor values this rank sweeps per solve
-                     "stored_factor_nnz": int(fs.th.device()._n_factor_values),  # ... and stores: its sub-tree + the root block
+                     "stored_factor_nnz": int(fs.th.device()._n_factor_values),  # ... and stores: its sub-tree + its rows of the root block
+                     "matrix_cells": int(fs.th.device().partition_info()["matrix_cells"]),  # cells whose element matrices it assembles
                      "exchanges_per_step": 3,
                      # read back from the communicator inside the library (ncclCommCount / ncclCommUserRank), not from the environment
                      "rccl_ranks": comm["nranks"] if comm["transport"] == "rccl" else None, "exchange_transport": comm["transport"]}

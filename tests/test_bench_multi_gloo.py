@@ -60,7 +60,9 @@ class _FakeSolver:
         self.exchanges = 0
         part = self.part
         dev = SimpleNamespace(part=part, local_factor_nnz=int(part.seg_len.sum()), _n_factor_values=int(self.fac.vals.size), depth=self.tree.depth,
-                              comm_info=lambda: {"nranks": self.world, "rank": self.rank, "transport": "host" if self.world > 1 else "none"})
+                              comm_info=lambda: {"nranks": self.world, "rank": self.rank, "transport": "host" if self.world > 1 else "none"},
+                              partition_info=lambda: {"rhs_cells": int(part.local_cells.size), "matrix_cells": int(part.local_cells.size), "lead": self.rank == 0,
+                                                      "ranks": self.world})
         self.th = SimpleNamespace(N=th.N, nc=th.nc, device=lambda *_: dev, release_device=lambda: None)
         self.y_meas = np.zeros(2)
         self.solve_info = np.array([0.0, 0.0, 0.0, 0.0])
