@@ -599,3 +599,37 @@ def test_export_subdomains_writes_facet_markers(tmp_path):
     assert np.bincount(mk2).tolist() == [m.edges.shape[0] - 16, 0, 16]
     # the aggregator carries the predicate builders the case files use
     assert flu.near_cpp("x[0]", 1.0) == "near(x[0], 1.0, MESH_TOL)" and flu.on_boundary_cpp() == "on_boundary"
+
+
+def test_signal_helpers():
+    """flowcontrol_amd/signal.py (reference src/utils/signal.py): multisine spectrum, crest factor, dominant frequency."""
+    from flowcontrol_amd import signal as sg
+
+    assert sg.pad_upto([1, 2], 4, v=9) == [1, 2, 9, 9] and sg.pad_upto(np.array([1.0]), 3).tolist() == [1.0, 0.0, 0.0]
+    with pytest.raises(TypeError):
+        sg.pad_upto((1, 2), 3)
+    assert (sg.saturate(5, 0, 1), sg.saturate(-5, 0, 1), sg.saturate(0.5, 0, 1)) == (1, 0, 0.5)
+    assert np.allclose(sg.sample_lco(2.0, 10.0, 4), [10.0, 10.5, 11.0, 11.5])
+    t = np.arange(4000) * 0.005
+    assert sg.crest_factor(np.sin(2 * np.pi * 1.7 * t)) == pytest.approx(np.sqrt(2.0), rel=1e-3)
+    assert sg.compute_signal_frequency(3.0 + np.sin(2 * np.pi * 1.7 * t) + 5 * np.exp(-t), Tf=20.0, dt=0.005) == pytest.approx(1.7, abs=0.02)
+    np.random.seed(0)
+    N, Fs = 256, 64.0
+    y = sg.multisine(N, Fs, fmin=0.1, fmax=0.5)
+    assert y.shape == (N,)
+    # the record spans N - 1 sampling intervals (the reference's time axis), so project on the nominal harmonics directly
+    tt = np.linspace(0.0, (N - 1) / Fs, N)
+    k = np.arange(N // 2)
+    amp = np.abs(np.exp(-2j * np.pi * np.outer(k * Fs / N, tt)) @ y) * 2 / N
+    band = (k * Fs / N >= 0.1 * Fs / 2) & (k * Fs / N <= 0.5 * Fs / 2)
+    assert amp[band].min() > 0.5 * amp[band].max() and amp[~band].max() < 0.2 * amp[band].max()
+    assert np.mean(y * y) == pytest.approx(0.5, rel=0.1)  # nf unit sines / sqrt(nf): rms^2 = 1/2
+    odd = sg.multisine(N, Fs, 0.1, 0.5, skip_even=True)
+    amp_odd = np.abs(np.exp(-2j * np.pi * np.outer(k * Fs / N, tt)) @ odd)
+    assert amp_odd[band & (k % 2 == 0)].max() < 0.2 * amp_odd[band & (k % 2 == 1)].max()
+    np.random.seed(1)
+    plain = np.mean([sg.crest_factor(sg.multisine(N, Fs, 0.1, 0.5)) for _ in range(10)])
+    tuned = np.mean([sg.crest_factor(sg.multisine(N, Fs, 0.1, 0.5, opt_cf=30)) for _ in range(10)])
+    assert tuned < plain
+    mp_ = sg.multisine_MP(3, 2, unwrap=False, N=64, Fs=16.0, fmin=0.2, fmax=0.8)
+    assert mp_.shape == (3, 128) and np.array_equal(mp_[:, :64], mp_[:, 64:]) and sg.multisine_MP(3, 2, N=64, Fs=16.0, fmin=0.2, fmax=0.8).shape == (384,)
