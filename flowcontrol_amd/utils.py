@@ -35,6 +35,19 @@ def get_rank() -> int:
     return 0
 
 
+def print0(*args: Any, **kwargs: Any) -> None:
+    """Log on rank 0 only (``utils/fem.py:30-33``)."""
+    if get_rank() == 0:
+        logger.info(*args, **kwargs)
+
+
+def get_subspace_dofs(W) -> dict[str, np.ndarray]:
+    """Dof indices of the u, v and p sub-spaces of the mixed space (``utils/fem.py:76-86``); in this package's W layout they are
+    the three consecutive blocks [ux | uy | p]."""
+    th = W.th
+    return {"u": np.arange(th.nn), "v": th.nn + np.arange(th.nn), "p": 2 * th.nn + np.arange(th.nv)}
+
+
 def mpi_broadcast(x):
     """Identity on one rank; every rank of a multi-GPU run already holds identical ``y_meas``."""
     return x
