@@ -85,6 +85,8 @@ SIGNATURES: dict[str, list] = {
     "fc_set_front_shifts": [_H, C.c_int32, _lp, _dp],
     "fc_set_root_rows": [_H, C.c_int32, C.c_int32],
     "fc_undo_step": [_H],
+    "fc_accept_factors": [_H, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int32)],
+    "fc_get_factors_inexact": [_H, C.c_int, C.POINTER(C.c_int32)],
     "fc_get_partition_info": [_H, _ip],
     "fc_get_factor_values": [_H, C.c_int, C.c_int64, _dp],
     "fc_solver_set_blocks": [_H, C.c_int, C.c_int32, _lp, _ip, _ip, C.c_int64, _lp, _ip, _ip, _ip, _ip, _ip, _ip, C.c_int64, C.c_int64],

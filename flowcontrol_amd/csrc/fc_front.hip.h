@@ -26,6 +26,9 @@
 #ifndef FC_FE_WIDE_NF
 #define FC_FE_WIDE_NF 3072   // a level is "wide" when its largest front has at least this order (below, the longer pivot chain costs more than the update gains)
 #endif
+#ifndef FC_FE_PIVOT_KEEP_LOG2
+#define FC_FE_PIVOT_KEEP_LOG2 2u  // threshold pivoting: the diagonal is kept while its binary exponent is within this many of the largest candidate's (2: within 8x)
+#endif
 #ifndef FC_FE_GJ_WAVES
 #define FC_FE_GJ_WAVES 4  // waves that invert a pivot block: 4 (columns split over the workgroup's waves, one barrier per column step) or 1
 #endif
@@ -108,7 +111,7 @@ __device__ __forceinline__ void fc_fe_gj_wave(double (&x)[KB], int lane, int kb,
       mw = o > mw ? o : mw;
     }
     const unsigned kd = (unsigned)__builtin_amdgcn_readlane((int)key, k);
-    const int p = (mw >> 20) <= (kd >> 20) + 2u ? k : 63 - (int)(mw & 63u);
+    const int p = (mw >> 20) <= (kd >> 20) + FC_FE_PIVOT_KEEP_LOG2 ? k : 63 - (int)(mw & 63u);
     if (lane == 0) piv[k] = p;
     if (p != k) {  // exchange rows k and p: a permute between two lanes
       const int partner = lane == k ? p : (lane == p ? k : lane);
@@ -176,7 +179,7 @@ __device__ __forceinline__ void fc_fe_gj_block(double (*a)[KB + 1], int kb, doub
           mw = o > mw ? o : mw;
         }
         const unsigned kd = (unsigned)__builtin_amdgcn_readlane((int)key, k);
-        const int p = (mw >> 20) <= (kd >> 20) + 2u ? k : 63 - (int)(mw & 63u);
+        const int p = (mw >> 20) <= (kd >> 20) + FC_FE_PIVOT_KEEP_LOG2 ? k : 63 - (int)(mw & 63u);
         if (p != k) {
           const int partner = lane == k ? p : (lane == p ? k : lane);
 #pragma unroll

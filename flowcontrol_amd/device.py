@@ -7,6 +7,7 @@ reference's ``src/flowcontrol/flowsolver.py``) owns one :class:`DeviceSolver`.
 from __future__ import annotations
 
 import ctypes as C
+import logging
 import os
 
 import numpy as np
@@ -25,6 +26,8 @@ def _f64(a) -> np.ndarray:
 def _i32(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.int32)
 
+
+logger = logging.getLogger(__name__)
 
 class DeviceSolver:
     def __init__(self, th: TaylorHood, device: int = 0):
@@ -64,6 +67,8 @@ class DeviceSolver:
         self._plan: ndsolver.FactorPlan | None = None
         self._structured: set[int] = set()
         self.refactor_ms: dict[int, float] = {}
+        #: slot -> the factors missed the acceptance residual by the direct apply and serve as GMRES preconditioner (fc_accept_factors)
+        self.factors_inexact: dict[int, bool] = {}
         self._probe: np.ndarray | None = None
         self._pin_shift = 1.0
         self._step_bufs = None
@@ -365,6 +370,11 @@ class DeviceSolver:
         ms = C.c_double()
         check(self.lib.fc_get_refactor_ms(self._h, slot, C.byref(ms)))
         self.refactor_ms[slot] = ms.value
+        flag = C.c_int32()
+        check(self.lib.fc_get_factors_inexact(self._h, slot, C.byref(flag)))
+        self.factors_inexact[slot] = bool(flag.value)
+        if flag.value:
+            logger.warning("slot %d: the direct factor apply misses 1e-10 on this operator; its solves run GMRES preconditioned by the factors", slot)
         self._structured.add(slot)
         self._solver_opts = (int(refine), bool(check_residual), "refine", 1e-10)
 
@@ -445,12 +455,13 @@ class DeviceSolver:
             check(self.lib.fc_set_stage_diag(self._h, slot, _f64(ndsolver.schur_diagonal_scaling(self.matrix(slot), self.nn)[self.perm])))
             return ms.value  # a preconditioner: nothing to probe
         # (on a partitioned handle the probe is a collective: every rank refactorises, every rank probes)
-        opts = getattr(self, "_solver_opts", (0, True, "refine", 1e-10))
-        check(self.lib.fc_set_solver_options(self._h, _lib.METHOD_REFINE, 0, 1e-10, 1))
-        _, info = self.solve(slot, self._probe)
-        self.set_solver_options(*opts)
-        if not info[1] < 1e-8:
-            raise _lib.FcError(_lib.FC_ERR_HIP, f"device factorisation of slot {slot} failed its residual check ({info[1]:.2e})")
+        res, inexact = C.c_double(), C.c_int32()
+        code = self.lib.fc_accept_factors(self._h, slot, C.byref(res), C.byref(inexact))
+        self._raise_exchange_error()
+        check(code)
+        self.factors_inexact[slot] = bool(inexact.value)
+        if inexact.value:
+            logger.warning("slot %d: the direct factor apply reaches only %.1e on this operator; its solves run GMRES preconditioned by the factors", slot, res.value)
         return ms.value
 
     def factor_values(self, slot: int) -> np.ndarray:

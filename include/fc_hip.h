@@ -146,7 +146,7 @@ int fc_solver_set_blocks(fc_handle h, int slot, int32_t n_stages, const int64_t*
  * `depth` bisections — 0: leaves of ~12 cells — fused `merge` at a time; on a handle with a communicator / host exchange
  * the root is nranks-ary and this rank lays out its own sub-tree and the root), permutation, segment tables, workgroup
  * tiles, factorisation plan, task dependencies, then the numeric factorisation of the slot's current matrix on the
- * device and a probe solve (error if its relative residual is not < 1e-8).  truncate = d > 0: only the tree levels >= d
+ * device and the acceptance solve of fc_accept_factors (below).  truncate = d > 0: only the tree levels >= d
  * are factorised (memory-lean preconditioner; use FC_METHOD_GMRES / FC_METHOD_BICGSTAB afterwards).  A later call for the
  * same slot redoes only the numeric phase.  Needs: fc_set_bc, fc_assemble_matrix(slot), fc_apply_bc(slot).  The
  * array-level entry points below (fc_set_permutation ... fc_solver_set_dag) remain for tests and for callers that bring
@@ -228,6 +228,17 @@ int fc_refactor(fc_handle h, int slot, double* ms_out);
  * root's block) -- the rows it applies in the root's down stage -- at the root's value offset, row `first` first.
  * first = -1: all rows (single GPU).  Call before fc_refactor; fc_setup_solver does it itself. */
 int fc_set_root_rows(fc_handle h, int32_t first, int32_t count);
+/* Acceptance solve of a slot's freshly computed factors (fc_setup_solver runs it itself; call it after a bare fc_refactor): a fixed
+ * right-hand side, residual against the matrix.  < 1e-10 by the direct apply: exact factors (time-step operators give <= 1e-12).
+ * Between 1e-10 and 1e-2 (pivoting confined to the pivot blocks lost digits on an ill-conditioned operator, e.g. a steady Oseen
+ * operator far beyond the Reynolds number the mesh resolves, where sparse LU with partial pivoting still reaches 1e-12): the factors
+ * are kept as a PRECONDITIONER if GMRES reaches 1e-8 -- or, on a single-device handle, a normwise backward error
+ * |r| / (|A|_F |x| + |b|) < 1e-13 -- within 40 iterations; fc_solve / fc_step on this slot then run GMRES(60, 1e-12, restarted on
+ * the true residual until it stagnates) by themselves whenever FC_METHOD_REFINE is selected (*inexact_out = 1; the batched calls
+ * refuse such a slot).  Anything else is FC_ERR_HIP.  residual_out: the direct apply's relative residual.  A collective on a
+ * partitioned handle.  fc_refactor clears the flag. */
+int fc_accept_factors(fc_handle h, int slot, double* residual_out, int32_t* inexact_out);
+int fc_get_factors_inexact(fc_handle h, int slot, int32_t* inexact /* 1: the slot's factors serve as GMRES preconditioner */);
 /* values added to front entries (offsets into the front buffer of fc_factor_plan) after the matrix has
  * been scattered, in every later fc_refactor: a positive shift on ONE pressure diagonal selects the
  * solution with that pressure = 0 of an enclosed flow's singular system (lid-driven cavity; the reference

@@ -1,0 +1,77 @@
+"""Soak test of the numeric factorisation: many operators (base-flow amplitude and shape varied at random), each factorised on the
+device and checked by a solve with a random right-hand side; the same operator factorised twice must give bit-identical factors.
+
+    python scripts/soak_refactor.py [mesh ...] [--n 200]
+"""
+import argparse
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from flowcontrol_amd.device import SLOT_BDF2, DeviceSolver  # noqa: E402
+from flowcontrol_amd.fem.mesh import read_xdmf_mesh  # noqa: E402
+from flowcontrol_amd.fem.spaces import TaylorHood  # noqa: E402
+
+GOLDEN = Path(__file__).resolve().parents[1] / "tests" / "golden" / "meshes"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("meshes", nargs="*", default=["O1", "cavity_coarse"])
+    ap.add_argument("--n", type=int, default=200)
+    ap.add_argument("--extreme", action="store_true", help="also steady operators at a mesh Reynolds number far beyond what the mesh resolves")
+    a = ap.parse_args()
+    rng = np.random.default_rng(2026)
+    for name in a.meshes:
+        th = TaylorHood(read_xdmf_mesh(GOLDEN / f"{name}.npz"))
+        dev = DeviceSolver(th)
+        x = th.node_coords
+        m = th.mesh
+        be = m.boundary_edges()
+        be = be[m.edge_midpoints()[be, 0] < m.coords[:, 0].max() - 1e-9]
+        nodes = np.unique(np.r_[m.edges[be].reshape(-1), th.nv + be])
+        dofs = np.sort(np.r_[nodes, nodes + th.nn])
+        dev.set_bc(dofs, np.zeros((dofs.size, 1)))
+        worst, repeat_diff, n_inexact = 0.0, 0.0, 0
+        for i in range(a.n):
+            amp, kx, ky, ph = rng.uniform(0.2, 3.0), rng.uniform(0.2, 2.0), rng.uniform(0.2, 2.0), rng.uniform(0, 6.28)
+            U0 = amp * np.r_[1.0 + 0.5 * np.sin(kx * x[:, 0] + ph) * np.cos(ky * x[:, 1]), 0.4 * np.cos(ky * x[:, 0]) * np.sin(kx * x[:, 1] + ph)]
+            mass, nu = float(rng.choice([0.0, 200.0, 3000.0])), float(rng.choice([1e-2, 1e-3, 1.3e-4]))
+            if mass == 0.0 and nu < 1e-3 and not a.extreme:
+                nu = 1e-3  # (--extreme: steady Oseen operators at Re ~ 10^4 on a mesh made for Re ~ 10^2 as well)
+            dev.assemble_matrix(SLOT_BDF2, mass=mass, nu=nu, adv=U0, lin=U0)
+            dev.apply_bc(SLOT_BDF2)
+            try:
+                if i == 0:
+                    dev.setup_solver(SLOT_BDF2)
+                else:
+                    dev.refactor(SLOT_BDF2)
+            except Exception as e:  # the acceptance probe refused the factors: say for which operator
+                print(f"{name}: operator {i}: mass {mass:g} nu {nu:g} amp {amp:.2f}: {str(e)[-60:]}", flush=True)
+                if i == 0:
+                    raise
+                continue
+            b = rng.standard_normal(dev.N)
+            xs, info = dev.solve(SLOT_BDF2, b)
+            A = dev.matrix(SLOT_BDF2)
+            r = float(np.linalg.norm(A @ xs - b))
+            res = r / float(np.linalg.norm(b))
+            if res > 1e-8:  # operators next to singular: the measure is the normwise backward error, as in fc_accept_factors
+                res = min(res, 1e5 * r / (float(np.sqrt((A.data**2).sum())) * float(np.linalg.norm(xs)) + float(np.linalg.norm(b))))
+            worst = max(worst, res)
+            n_inexact += bool(dev.factors_inexact.get(SLOT_BDF2))
+            if not np.isfinite(res) or res > 1e-8:
+                print(f"{name}: operator {i}: residual {res:.3e} (amp {amp:.2f})", flush=True)
+            if i % 25 == 0:
+                f1 = dev.factor_values(SLOT_BDF2)
+                dev.refactor(SLOT_BDF2)
+                repeat_diff = max(repeat_diff, float(np.abs(dev.factor_values(SLOT_BDF2) - f1).max()))
+                print(f"{name}: {i + 1} operators, worst residual so far {worst:.2e}", flush=True)
+        print(f"{name}: {a.n} operators factorised, worst solve residual {worst:.2e}, {n_inexact} of them through GMRES on inexact factors, max |difference| between two factorisations of one operator {repeat_diff:.1e}", flush=True)
+        dev.close()
+
+
+if __name__ == "__main__":
+    main()

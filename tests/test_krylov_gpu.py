@@ -143,3 +143,59 @@ def test_time_steps_with_compressed_factors(case, bits, tmp_path_factory, golden
     assert np.linalg.norm(ts["dE"].to_numpy() - dE_ref) <= 1e-8 * np.linalg.norm(dE_ref)
     print(f"[compressed factors, {case}, {bits} bit] {nbytes / 1e6:.1f} MB of factor values ({values} values); GMRES iterations per step {its}")
     fs.th.release_device()
+
+
+def test_factors_that_miss_the_acceptance_residual_precondition_gmres(golden_dir):
+    """Steady Oseen operators far beyond the mesh's resolution (Re ~ 10^4 on O1): pivoting confined to the pivot blocks loses digits
+    on some of them.  ``fc_accept_factors`` then keeps the factors as a GMRES preconditioner instead of refusing them; the solve is as
+    good as the oracle's sparse LU (same normwise backward error), and the batched API -- which applies factors directly -- says no."""
+    from flowcontrol_amd._lib import FcError
+    from flowcontrol_amd.device import SLOT_BDF2, DeviceSolver
+
+    th = TaylorHood(read_xdmf_mesh(golden_dir / "meshes" / "O1.npz"))
+    dev = DeviceSolver(th)
+    x = th.node_coords
+    dofs = _bc(th)
+    dev.set_bc(dofs, np.zeros((dofs.size, 1)))
+    rng = np.random.default_rng(2026)
+    seen = {False: 0, True: 0}
+    for i in range(16):
+        amp, kx, ky, ph = rng.uniform(0.2, 3.0), rng.uniform(0.2, 2.0), rng.uniform(0.2, 2.0), rng.uniform(0, 6.28)
+        U0 = amp * np.r_[1.0 + 0.5 * np.sin(kx * x[:, 0] + ph) * np.cos(ky * x[:, 1]), 0.4 * np.cos(ky * x[:, 0]) * np.sin(kx * x[:, 1] + ph)]
+        dev.assemble_matrix(SLOT_BDF2, mass=0.0, nu=1.3e-4, adv=U0, lin=U0)
+        dev.apply_bc(SLOT_BDF2)
+        if i == 0:
+            dev.setup_solver(SLOT_BDF2)
+        else:
+            dev.refactor(SLOT_BDF2)
+        inexact = dev.factors_inexact[SLOT_BDF2]
+        seen[inexact] += 1
+        if seen[inexact] > 2:
+            continue  # two of each kind are checked in full
+        A = dev.matrix(SLOT_BDF2).tocsc()
+        b = rng.standard_normal(dev.N)
+        b[dofs] = 0.0
+        xs, info = dev.solve(SLOT_BDF2, b)
+        x_lu = spla.splu(A).solve(b)
+        norm_a = np.sqrt((A.data**2).sum())
+
+        def backward(v):
+            return np.linalg.norm(A @ v - b) / (norm_a * np.linalg.norm(v) + np.linalg.norm(b))
+
+        assert backward(xs) <= max(10.0 * backward(x_lu), 1e-13), (i, inexact, backward(xs), backward(x_lu))
+        assert np.linalg.norm(A @ xs - b) <= 1e-8 * np.linalg.norm(b)
+        assert np.linalg.norm(xs - x_lu) <= 1e-6 * np.linalg.norm(x_lu)
+        if inexact:
+            assert 1 <= info[0] <= 40  # GMRES iterations
+            dev.set_batch(2)
+            with pytest.raises(FcError, match="inexact"):
+                dev.solve_batch(SLOT_BDF2, np.stack([b, b]))
+            dev.set_batch(0)
+    print("inexact / exact operators:", seen)
+    assert seen[True] >= 1, "no operator of this family tripped the acceptance residual: the test lost its subject"
+    # a well-conditioned operator afterwards clears the flag
+    dev.assemble_matrix(SLOT_BDF2, mass=300.0, nu=1e-2, adv=U0, lin=U0)
+    dev.apply_bc(SLOT_BDF2)
+    dev.refactor(SLOT_BDF2)
+    assert not dev.factors_inexact[SLOT_BDF2]
+    dev.close()
