@@ -342,8 +342,8 @@ __global__ __launch_bounds__(256) void fc_rhs_gather_b(int N, const int* __restr
 // once (coalesced KB-wide rows, instead of one 8 KB-byte gather per matrix entry and simulation pair) and evaluates the
 // 16 rows from there: 16 lanes per row = (j: 16 / HP) x (simulation pair: HP = KB / 2), each lane walks every
 // (16 / HP)-th entry of its row with the entry's LOCAL column (uint16) and reads two simulations (16 B) from LDS.
-// The scatter / shift then uses thread = (row, simulation): all lanes busy.  (The energy is fc_energy_b's.)
-// partial[(s * 3 + w) * G + block], w = 0: sum r^2, 1: sum b^2 (fc_tail_b), 2: sum e (fc_energy_b)  (fixed order: reproducible).
+// The scatter / shift then uses thread = (row, simulation): all lanes busy.
+// partial[(s * 3 + w) * G + block], w = 0: sum r^2, 1: sum b^2 (row blocks), 2: sum e (cell blocks)  (fixed order: reproducible).
 #define FC_TB_ROWS 16
 #define FC_TB_COLS 128
 typedef double fc_d2u __attribute__((ext_vector_type(2), aligned(8)));
@@ -351,20 +351,71 @@ struct __attribute__((aligned(16))) FcTBlock {
   int row0, nrows;  // permuted rows [row0, row0 + nrows)
   int col0, ncols;  // its distinct columns: bcols[col0 .. col0 + ncols)
 };
+// energy of the new velocity, 1/2 int |u|^2 element by element (flowsolver.py:827-829), for KB simulations: a workgroup brings
+// its cells' nodal velocities to LDS once (thread = (cell, node, simulation)) and evaluates the integrand from there
+// (thread = (cell, Radon point, simulation)).  The cell workgroups are the FIRST n_cell_blocks of fc_tail_b's grid (their
+// chain of dependent gathers overlaps with the row blocks' streaming; as a launch of their own they cost its ~5 us floor).
+// partial[(s * 3 + 2) * G + first + block]
+template <int KB>
+__device__ __forceinline__ void fc_energy_b_block(int cb, int nn2, int nc, const int* __restrict__ cn, const double* __restrict__ geom,
+                                                  const int* __restrict__ iperm, const double* __restrict__ x, double* __restrict__ partial,
+                                                  int G, int first, double (&red)[2][256]) {
+  constexpr int CPB = 256 / (8 * KB);  // cells per workgroup
+  const int t = threadIdx.x;
+  const int s = t % KB, lane = (t / KB) % 8, cw = t / (8 * KB);
+  const int nn = nn2 >> 1;
+  double e = 0.0;
+  const int c = cb * CPB + cw;
+  const int cc = c < nc ? c : 0;
+  {
+    const int n = cn[(size_t)(lane < 6 ? lane : 0) * nc + cc];
+    red[0][t] = x[(size_t)iperm[n] * KB + s];
+    red[1][t] = x[(size_t)iperm[nn + n] * KB + s];
+  }
+  __syncthreads();
+  if (c < nc && lane < FC_NQ) {
+    double ux = 0.0, uy = 0.0;
+    const int nb = cw * 8 * KB + s;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const double ph = c_phi2[lane * 6 + a];
+      ux += ph * red[0][nb + a * KB];
+      uy += ph * red[1][nb + a * KB];
+    }
+    e = c_qw[lane] * 0.5 * geom[4 * (size_t)nc + cc] * (ux * ux + uy * uy);
+  }
+  __syncthreads();
+  red[0][t] = e;
+  __syncthreads();
+  if (t < KB) {
+    double se = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8 * CPB; ++g) se += red[0][g * KB + t];
+    partial[((size_t)t * 3 + 2) * G + first + cb] = se;
+  }
+}
+
 template <int KB>
 __global__ __launch_bounds__(256) void fc_tail_b(int N, int nn2, const int* __restrict__ perm, const double* __restrict__ x,
                                                  const double* __restrict__ b, const FcTBlock* __restrict__ blocks,
                                                  const int* __restrict__ bcols, const int* __restrict__ a_rowptr,
                                                  const unsigned short* __restrict__ a_lidx, const double* __restrict__ a_val,
                                                  double* __restrict__ up, double* __restrict__ u_n, double* __restrict__ u_nn,
-                                                 double* __restrict__ p_n, int* __restrict__ flag, double* __restrict__ partial, int G) {
+                                                 double* __restrict__ p_n, int* __restrict__ flag, double* __restrict__ partial, int G,
+                                                 int n_cell_blocks, int nc, const int* __restrict__ cn, const double* __restrict__ geom,
+                                                 const int* __restrict__ iperm) {
   constexpr int HP = KB / 2;   // simulation pairs
   constexpr int JL = 16 / HP;  // lanes of a row that split its entries
   const int t = threadIdx.x;
   __shared__ double xs[FC_TB_COLS * KB];
   __shared__ double red[2][256];
+  if ((int)blockIdx.x < n_cell_blocks) {
+    fc_energy_b_block<KB>((int)blockIdx.x, nn2, nc, cn, geom, iperm, x, partial, G, G - n_cell_blocks, red);
+    return;
+  }
+  const int rbk = (int)blockIdx.x - n_cell_blocks;  // row block of this workgroup
   {
-    const FcTBlock bk = blocks[blockIdx.x];
+    const FcTBlock bk = blocks[rbk];
     // the block's solution rows -> LDS, two simulations per lane
     for (int e = t; e < bk.ncols * HP; e += 256) {
       const int c = e / HP, sp = e % HP;
@@ -450,54 +501,9 @@ __global__ __launch_bounds__(256) void fc_tail_b(int N, int nn2, const int* __re
         a0 += red[0][g * KB + t];
         a1 += red[1][g * KB + t];
       }
-      partial[((size_t)t * 3 + 0) * G + blockIdx.x] = a0;
-      partial[((size_t)t * 3 + 1) * G + blockIdx.x] = a1;
+      partial[((size_t)t * 3 + 0) * G + rbk] = a0;
+      partial[((size_t)t * 3 + 1) * G + rbk] = a1;
     }
-  }
-}
-
-// energy of the new velocity, 1/2 int |u|^2 element by element (flowsolver.py:827-829), for KB simulations: a workgroup brings
-// its cells' nodal velocities to LDS once (thread = (cell, node, simulation)) and evaluates the integrand from there
-// (thread = (cell, Radon point, simulation)).  Its own launch (not appended to fc_tail_b's grid): the row blocks keep up to
-// FC_TB_COLS solution rows in LDS, and a shared launch would charge every cell workgroup that footprint too.
-// partial[(s * 3 + 2) * G + first + block]
-template <int KB>
-__global__ __launch_bounds__(256) void fc_energy_b(int nn2, int nc, const int* __restrict__ cn, const double* __restrict__ geom,
-                                                   const int* __restrict__ iperm, const double* __restrict__ x, double* __restrict__ partial,
-                                                   int G, int first) {
-  constexpr int CPB = 256 / (8 * KB);  // cells per workgroup
-  __shared__ double red[2][256];
-  const int t = threadIdx.x;
-  const int s = t % KB, lane = (t / KB) % 8, cw = t / (8 * KB);
-  const int nn = nn2 >> 1;
-  double e = 0.0;
-  const int c = (int)blockIdx.x * CPB + cw;
-  const int cc = c < nc ? c : 0;
-  {
-    const int n = cn[(size_t)(lane < 6 ? lane : 0) * nc + cc];
-    red[0][t] = x[(size_t)iperm[n] * KB + s];
-    red[1][t] = x[(size_t)iperm[nn + n] * KB + s];
-  }
-  __syncthreads();
-  if (c < nc && lane < FC_NQ) {
-    double ux = 0.0, uy = 0.0;
-    const int nb = cw * 8 * KB + s;
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      const double ph = c_phi2[lane * 6 + a];
-      ux += ph * red[0][nb + a * KB];
-      uy += ph * red[1][nb + a * KB];
-    }
-    e = c_qw[lane] * 0.5 * geom[4 * (size_t)nc + cc] * (ux * ux + uy * uy);
-  }
-  __syncthreads();
-  red[0][t] = e;
-  __syncthreads();
-  if (t < KB) {
-    double se = 0.0;
-#pragma unroll
-    for (int g = 0; g < 8 * CPB; ++g) se += red[0][g * KB + t];
-    partial[((size_t)t * 3 + 2) * G + first + blockIdx.x] = se;
   }
 }
 

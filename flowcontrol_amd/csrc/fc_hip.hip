@@ -4284,16 +4284,11 @@ static int batch_launches(fc_ctx* h, int order_slot, int compute_energy) {
   const int n_row_blocks = B.n_tblocks, n_cell_blocks = compute_energy ? nblocks(nc, cpb) : 0;
   const int G = n_row_blocks + n_cell_blocks;
   if ((size_t)3 * G * KB > B.partial.n) return fail(FC_ERR_INVALID, "fc_step_batch: partial buffer too small");
-#define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(n_row_blocks), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, B.buf.p + (size_t)N * K, B.b.p, B.tblocks.p, \
-                                       B.tcols.p, S.Ap_rowptr.p, B.tlidx.p, S.Ap_val.p, B.up.p, B.u_n.p, B.u_nn.p, B.p_n.p, B.flag.p, B.partial.p, G)
+#define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, B.buf.p + (size_t)N * K, B.b.p, B.tblocks.p, \
+                                       B.tcols.p, S.Ap_rowptr.p, B.tlidx.p, S.Ap_val.p, B.up.p, B.u_n.p, B.u_nn.p, B.p_n.p, B.flag.p, B.partial.p, G,   \
+                                       n_cell_blocks, nc, h->cn.p, h->geom.p, h->iperm.p)
   FC_KB_DISPATCH(KB, FC_TAILB(4), FC_TAILB(8), FC_TAILB(16));
 #undef FC_TAILB
-  if (n_cell_blocks > 0) {
-#define FC_ENB(K) hipLaunchKernelGGL((fc_energy_b<K>), dim3(n_cell_blocks), dim3(256), 0, h->stream, 2 * h->nn, nc, h->cn.p, h->geom.p, h->iperm.p, \
-                                     B.buf.p + (size_t)N * K, B.partial.p, G, n_row_blocks)
-    FC_KB_DISPATCH(KB, FC_ENB(4), FC_ENB(8), FC_ENB(16));
-#undef FC_ENB
-  }
 #define FC_FINB(K) hipLaunchKernelGGL((fc_final_b<K>), dim3(B.k), dim3(1024), 0, h->stream, G, n_row_blocks, B.partial.p, h->n_sens, h->s_rowptr.p, h->s_idx.p, \
                                       h->s_w.p, B.up.p, B.flag.p, h->pin_dev, kRecStride, h->pin_dev + kSeqSlot, compute_energy)
   FC_KB_DISPATCH(KB, FC_FINB(4), FC_FINB(8), FC_FINB(16));
