@@ -874,8 +874,10 @@ int launch_tail(fc_ctx* h, OrderSys& S, int compute_energy, double* d_y, double*
   const bool part = h->partitioned;
   const int ncl = part ? h->ncl : h->nc;
   const int reps = std::max(1, nblocks(h->N, 32 * 2048));  // <= ~2048 + ~500 partials per array for fc_final
-  const int g_rows = nblocks(h->N, 32 * reps), g_cells = (compute_energy && ncl > 0) ? nblocks(ncl, 32 * reps) : 0;
-  const int g = g_rows + g_cells;
+  const int g_rows = res ? nblocks(h->N, 32 * reps) : 0, g_cells = (compute_energy && ncl > 0) ? nblocks(ncl, 32 * reps) : 0;
+  const int g_shift = nblocks(h->N, 256 * FC_TAIL_SHIFT);
+  const int g = g_rows + g_shift + g_cells;
+  if (g > h->nblk_N) return fail(FC_ERR_INVALID, "launch_tail: partial buffer too small");
   // FC_FUSED_FINAL=1 (single GPU): the last workgroup to arrive does fc_final's work inside this launch.  Measured equal
   // to the separate launch (24.7 vs 24.2 us for tail + final on O1, identical results): the last arriver's serial chain
   // (sc1 loads of the partials, sensor rows, PCIe publish) is what fc_final costs, the boundary itself is ~1.5 us
@@ -895,7 +897,7 @@ int launch_tail(fc_ctx* h, OrderSys& S, int compute_energy, double* d_y, double*
     }
     fin = FcFin{h->fin_cnt.p, kGroup, n_groups, h->n_sens, h->s_rowptr.p, h->s_idxp.p, h->s_w.p, d_y, d_E, d_r, d_flag_out, d_seq, seq, step_id};
   }
-#define FC_TAIL_ARGS h->N, 2 * h->nn, h->perm.p, h->buf.p + h->N, h->b.p, res ? S.Ap_rowptr.p : nullptr, S.Ap_col.p, S.Ap_val.p, g_rows, reps, h->nc, g_cells > 0 ? h->cn.p : nullptr, h->geom.p, h->iperm.p, part ? h->rowkind_p.p : nullptr, part ? h->cell_list.p : nullptr, ncl, h->up.p, h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p, h->partial.p, h->dag_err.p, fin, h->u_old.p, h->p_old.p
+#define FC_TAIL_ARGS h->N, 2 * h->nn, h->perm.p, h->buf.p + h->N, h->b.p, res ? S.Ap_rowptr.p : nullptr, S.Ap_col.p, S.Ap_val.p, g_rows, g_shift, reps, h->nc, g_cells > 0 ? h->cn.p : nullptr, h->geom.p, h->iperm.p, part ? h->rowkind_p.p : nullptr, part ? h->cell_list.p : nullptr, ncl, h->up.p, h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p, h->partial.p, h->dag_err.p, fin, h->u_old.p, h->p_old.p
   if (fused)
     hipLaunchKernelGGL(fc_tail<true>, dim3(g), dim3(256), 0, h->stream, FC_TAIL_ARGS);
   else

@@ -969,17 +969,18 @@ struct FcFin {
 // ---------------------------------------------------------------------------------------------
 // Fused tail of a single-GPU step (residual monitor + state shift + energy in ONE launch, fc_final
 // follows).  Row workgroups: 8 lanes per permuted row evaluate r_i = b_i - (A x)_i (flowsolver.py:729's
-// solve, checked), lane 0 scatters/shifts the dof.  Cell workgroups (appended to the grid): the energy
+// solve, checked).  Shift workgroups: the new state, dof by dof in the W order.  Cell workgroups: the energy
 // integral of the new velocity, element by element.  Every workgroup leaves (sum r^2 | sum b^2 | sum e)
 // in `partial` (three arrays of gridDim.x) for fc_final.
 // (Folding fc_final in as well, "last workgroup to arrive reduces": with an agent-scope release per workgroup it cost
 // 10x what the launch saves; with sc1 partials + drained two-level arrival counters (FcFin below, FC_FUSED_FINAL=1) it
 // costs exactly what the separate launch costs.  Kept opt-in.)
+#define FC_TAIL_SHIFT 4  // dofs per thread of a shift workgroup
 template <bool FUSED>
 __global__ __launch_bounds__(256) void fc_tail(
     int N, int nn2, const int* __restrict__ perm, const double* __restrict__ x, const double* __restrict__ b,
     const int* __restrict__ a_rowptr, const int* __restrict__ a_col, const double* __restrict__ a_val,
-    int n_row_blocks, int reps, int nc, const int* __restrict__ cn, const double* __restrict__ geom, const int* __restrict__ iperm,
+    int n_row_blocks, int n_shift_blocks, int reps, int nc, const int* __restrict__ cn, const double* __restrict__ geom, const int* __restrict__ iperm,
     const unsigned char* __restrict__ rowkind, const int* __restrict__ cell_list, int ncl,
     double* __restrict__ up, double* __restrict__ u_n, double* __restrict__ u_nn, double* __restrict__ p_n,
     int* __restrict__ flag, double* __restrict__ partial, int* __restrict__ err, FcFin fin,
@@ -1003,20 +1004,44 @@ __global__ __launch_bounds__(256) void fc_tail(
   bool bad = false;
   // the cell workgroups (a chain of three dependent gathers per lane) come FIRST in the grid, so that their latency
   // overlaps with the row workgroups' streaming instead of forming the launch's tail
-  const int n_cell_blocks = G - n_row_blocks;
-  const int rb = (int)blockIdx.x - n_cell_blocks;  // row block of this workgroup (< 0: a cell workgroup)
-  if (rb >= 0) {
-    // rows: residual monitor, scatter to the W layout, state shift (`reps` row groups per workgroup keep
-    // the number of partials that fc_final folds alone <= ~2000 on large meshes)
+  const int n_cell_blocks = G - n_row_blocks - n_shift_blocks;
+  const int sb = (int)blockIdx.x - n_cell_blocks;  // shift block of this workgroup (< 0: a cell workgroup)
+  const int rb = sb - n_shift_blocks;              // row block (>= 0: a row workgroup)
+  if (sb >= 0 && rb < 0) {
+    // state shift in the W ORDER of the state vectors: u_old <- u_nn <- u_n <- x, p_old <- p_n <- x and the W-layout copy `up`
+    // are six coalesced streams and ONE gather (x through the inverse permutation) per dof.  Done from the permuted rows
+    // instead (lane 0 of a row's eight, six 8-byte accesses scattered by perm[]) it moved a cache line per access: on
+    // cavity_fine that was more traffic than the matrix the residual monitor streams.
+#pragma unroll
+    for (int u = 0; u < FC_TAIL_SHIFT; ++u) {
+      const int r = (sb * FC_TAIL_SHIFT + u) * 256 + t;
+      if (r < N) {
+        const int i = iperm[r];
+        // multi-GPU (rowkind != nullptr): 0 = another rank's row (left alone), 1 = owned, 2 = replicated root row
+        if (!rowkind || rowkind[i] != 0) {
+          const double v = x[i];
+          up[r] = v;
+          if (r < nn2) {
+            u_old[r] = u_nn[r];
+            u_nn[r] = u_n[r];
+            u_n[r] = v;
+            bad |= !isfinite(v);
+          } else {
+            p_old[r - nn2] = p_n[r - nn2];
+            p_n[r - nn2] = v;
+          }
+        }
+      }
+    }
+  } else if (rb >= 0) {
+    // rows: residual monitor (`reps` row groups per workgroup keep the number of partials that fc_final folds alone
+    // <= ~2000 on large meshes)
     for (int rep = 0; rep < reps; ++rep) {
     const int i = (rb * reps + rep) * RPB + t / LANES;
     double sa = 0.0;
-    int r = 0;
-    // multi-GPU (rowkind != nullptr): 0 = another rank's row (skipped), 1 = owned (residual + scatter),
-    // 2 = replicated root row (scatter only)
+    // multi-GPU (rowkind != nullptr): only the rows a rank owns (kind 1) enter its residual sums
     const int kind = i < N ? (rowkind ? rowkind[i] : 1) : 0;
     if (kind != 0) {
-      r = perm[i];
       if (a_rowptr && kind == 1) {
         const int k0 = a_rowptr[i], k1 = a_rowptr[i + 1];
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -1036,23 +1061,10 @@ __global__ __launch_bounds__(256) void fc_tail(
     }
 #pragma unroll
     for (int off = LANES / 2; off > 0; off >>= 1) sa += __shfl_down(sa, off, LANES);
-    if (kind != 0 && lane == 0) {
-      const double v = x[i];
-      if (a_rowptr && kind == 1) {
-        const double bb = b[i], res = bb - sa;
-        r2 += res * res;
-        b2 += bb * bb;
-      }
-      up[r] = v;
-      if (r < nn2) {
-        u_old[r] = u_nn[r];
-        u_nn[r] = u_n[r];
-        u_n[r] = v;
-        bad |= !isfinite(v);
-      } else {
-        p_old[r - nn2] = p_n[r - nn2];
-        p_n[r - nn2] = v;
-      }
+    if (kind == 1 && lane == 0 && a_rowptr) {
+      const double bb = b[i], res = bb - sa;
+      r2 += res * res;
+      b2 += bb * bb;
     }
     }
   } else if (cn) {
