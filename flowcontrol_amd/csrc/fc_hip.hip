@@ -138,6 +138,7 @@ struct OrderSys {
 constexpr int kPinDoubles = 4096;
 #ifndef FC_DOWN_DEPTH
 #define FC_DOWN_DEPTH 2  // down-sweep rows: lanes ~ mean segment length / this
+#define FC_UP_THREADS 1048576.0  // up-sweep rows: segments of a row run side by side only while rows x lanes stays below this
 #endif
 
 }  // namespace
@@ -1869,7 +1870,12 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
     if (st.kind == 0) {
       // up: every segment is a contiguous slice -> run G of them side by side
       sub = std::min(64, std::max(4, pow2_ceil(mean_seg / 4.0)));
-      const int grp = std::min(16, std::max(1, pow2_floor(segs_per_row)));
+      // ... as long as the launch is short of threads: with >= FC_UP_THREADS lanes from the rows alone, rows in flight hide the
+      // latency better than segments of one row in flight (cavity_fine, the three deepest up stages: 64 lanes x 4 segments ->
+      // 16 lanes x 1 segment took 45 us off the 1 000 us apply)
+      static const double up_threads = [] { const char* e = std::getenv("FC_UP_THREADS"); return e ? std::atof(e) : FC_UP_THREADS; }();
+      const int grp_fill = std::max(1, pow2_floor(up_threads / std::max(1.0, (double)st.nrows * sub)));
+      const int grp = std::min(grp_fill, std::min(16, std::max(1, pow2_floor(segs_per_row))));
       lanes = sub * grp;
       if (lanes > 64) {
         if (few_long_rows) {
