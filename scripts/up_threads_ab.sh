@@ -1,0 +1,12 @@
+#!/bin/bash
+# A/B of two FC_UP_THREADS values, alternating, factor-apply time only
+out=gpurun_out/up_threads_ab.txt
+: > $out
+for T in ${TS:-1048576 2097152 1048576 2097152}; do
+  a=$(FC_UP_THREADS=$T timeout -k 10 120 python bench.py --no-cpu-baseline --no-large-spmv --no-replicas --steps 3000 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"]), round(d["phase_ms_eager"]["sweeps"]*1e3,2))')
+  b=$(FC_UP_THREADS=$T timeout -k 10 120 python bench.py --refine 1 --no-cpu-baseline --no-large-spmv --no-replicas --steps 1500 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"]), round(d["phase_ms_eager"]["sweeps"]*1e3,2))')
+  c=$(FC_UP_THREADS=$T timeout -k 10 200 python scripts/bench_case.py pinball --steps 2000 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"]), round(d["roofline"]["apply_us"],1))')
+  d=$(FC_UP_THREADS=$T timeout -k 10 200 python scripts/bench_case.py cavity_fine --steps 300 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"],1), round(d["roofline"]["apply_us"],1))')
+  echo "FC_UP_THREADS=$T: O1 $a | refined O1 $b | pinball $c | cavity_fine $d" >> $out
+done
+cat $out
