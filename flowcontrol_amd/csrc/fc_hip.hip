@@ -88,6 +88,7 @@ struct Stage {
   int64_t blk_begin = 0;  // down stages: LDS-tiled block kernel (fc_nd_down_block) when blk_count > 0
   int blk_count = 0, blk_lpr = 64, blk_rps = 1;
   double bytes;  // algorithmic bytes of this launch
+  bool nt = false;  // its values are streamed with nontemporal loads (OrderSys::nt, minus the stages kept cache-resident)
   int dag_task0 = 0, dag_ntasks = 0;  // one-launch apply (fc_nd_dag): this stage's tasks
 };
 
@@ -110,6 +111,7 @@ struct OrderSys {
   int64_t f_nnz = 0;
   DevBuf<double> dscale;  // kind-2 stages (fc_set_stage_diag), permuted numbering
   bool truncated = false;  // the factors are a preconditioner only (some pivot blocks replaced by a diagonal)
+  bool nt = false;         // fp64 factors larger than the Infinity Cache: the sweeps stream them with nontemporal loads
   bool inexact = false;    // full fp64 factors whose direct apply missed the acceptance residual (an ill-conditioned operator): they precondition GMRES
   std::vector<Stage> stages;
   double sweep_bytes = 0.0;
@@ -138,6 +140,8 @@ struct OrderSys {
 constexpr int kPinDoubles = 4096;
 #ifndef FC_DOWN_DEPTH
 #define FC_DOWN_DEPTH 2  // down-sweep rows: lanes ~ mean segment length / this
+#define FC_RESIDENT_BYTES 0.0  // ... except the first stages up to this many bytes (experiment: kept in the Infinity Cache)
+#define FC_NT_BYTES 268435456.0  // fp64 factors beyond this (the Infinity Cache) are streamed with nontemporal loads
 #define FC_UP_THREADS 1048576.0  // up-sweep rows: segments of a row run side by side only while rows x lanes stays below this
 #endif
 
@@ -534,9 +538,15 @@ int launch_sweep(fc_ctx* h, const OrderSys& S, const Stage& st) {
   }
   if (st.kind == 1 && st.blk_count > 0) {
     const FcBlk* bp = S.blk.p + st.blk_begin;
-#define FC_BLOCK(L, R)                                                                                                   \
-  hipLaunchKernelGGL((fc_nd_down_block<L, R>), dim3(st.blk_count), dim3(256), 0, h->stream, bp, S.f_idx.p, S.f_val.p, \
-                     h->buf.p, h->N)
+#define FC_BLOCK(L, R)                                                                                                                   \
+  do {                                                                                                                                   \
+    if (st.nt)                                                                                                                           \
+      hipLaunchKernelGGL((fc_nd_down_block<L, R, double, true>), dim3(st.blk_count), dim3(256), 0, h->stream, bp, S.f_idx.p, S.f_val.p, \
+                         h->buf.p, h->N);                                                                                                \
+    else                                                                                                                                 \
+      hipLaunchKernelGGL((fc_nd_down_block<L, R>), dim3(st.blk_count), dim3(256), 0, h->stream, bp, S.f_idx.p, S.f_val.p, h->buf.p,     \
+                         h->N);                                                                                                          \
+  } while (0)
     switch (st.blk_lpr * 100 + st.blk_rps) {
       case 1601: FC_BLOCK(16, 1); break;
       case 1602: FC_BLOCK(16, 2); break;
@@ -559,9 +569,15 @@ int launch_sweep(fc_ctx* h, const OrderSys& S, const Stage& st) {
   double* buf = h->buf.p;
   const int dest0 = st.kind == 0 ? st.row0 : h->N + st.row0;
   const int acc = st.kind == 0 ? 1 : 0;
-#define FC_SWEEP(L, SB)                                                                                          \
-  hipLaunchKernelGGL((fc_nd_sweep<L, SB>), grid, block, 0, h->stream, st.nrows, rp, S.seg.p, S.f_idx.p, S.f_val.p, buf, \
-                     dest0, acc)
+#define FC_SWEEP(L, SB)                                                                                                          \
+  do {                                                                                                                           \
+    if (st.nt)                                                                                                                   \
+      hipLaunchKernelGGL((fc_nd_sweep<L, SB, double, true>), grid, block, 0, h->stream, st.nrows, rp, S.seg.p, S.f_idx.p,       \
+                         S.f_val.p, buf, dest0, acc);                                                                            \
+    else                                                                                                                         \
+      hipLaunchKernelGGL((fc_nd_sweep<L, SB>), grid, block, 0, h->stream, st.nrows, rp, S.seg.p, S.f_idx.p, S.f_val.p, buf,     \
+                         dest0, acc);                                                                                            \
+  } while (0)
   const int key = st.lanes * 1000 + st.sub;
   switch (key) {
     case 8004: FC_SWEEP(8, 4); break;
@@ -1933,6 +1949,21 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
   S.ar_row0 = ar_row0;
   S.ar_n = ar_n;
   S.f_nnz = n_val;
+  {
+    static const double nt_bytes = [] { const char* e = std::getenv("FC_NT_BYTES"); return e ? std::atof(e) : FC_NT_BYTES; }();
+    S.nt = 8.0 * (double)n_val > nt_bytes;
+    // ... except for the stages that fit a resident budget, taken in launch order (the deepest up levels first: short segments,
+    // latency-bound -- the ones a cache hit helps most)
+    static const double resident = [] { const char* e = std::getenv("FC_RESIDENT_BYTES"); return e ? std::atof(e) : FC_RESIDENT_BYTES; }();
+    double kept = 0.0;
+    for (Stage& st : S.stages) {
+      st.nt = S.nt;
+      if (S.nt && kept + st.bytes <= resident) {
+        st.nt = false;
+        kept += st.bytes;
+      }
+    }
+  }
   FCCHK(S.Ap_rowptr.upload(Ap_rowptr, N + 1, h->stream));
   FCCHK(S.Ap_col.upload(Ap_col, (size_t)S.Ap_nnz, h->stream));
   if (Ap_val) {

@@ -372,6 +372,23 @@ __global__ __launch_bounds__(256) void fc_spmv_csr(int nrows, const int* __restr
 struct FcBf16 {
   unsigned short u;
 };
+// value stream of the factor sweeps: every value is read exactly once per apply.  NT = nontemporal loads, for factors that do
+// not fit the 256 MiB Infinity Cache anyway: streamed past the caches they leave the state vectors, the matrix of the residual
+// monitor and the operand rows resident (refined O1 / pinball: +6 % steps/s; O1, whose 176 MB of factors DO stay in the Infinity
+// Cache from step to step: -12 %, so the handle decides -- fc_solver_setup, FC_NT_BYTES)
+template <bool NT>
+__device__ __forceinline__ double fc_ld(const double* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
+template <bool NT>
+__device__ __forceinline__ float fc_ld(const float* p) {
+  return *p;
+}
+template <bool NT>
+__device__ __forceinline__ FcBf16 fc_ld(const FcBf16* p) {
+  return *p;
+}
 __device__ __forceinline__ double fc_val(double v) { return v; }
 __device__ __forceinline__ double fc_val(float v) { return (double)v; }
 __device__ __forceinline__ double fc_val(FcBf16 v) { return (double)__uint_as_float((unsigned)v.u << 16); }
@@ -402,7 +419,7 @@ struct __attribute__((aligned(16))) FcSeg {
 // of SUB lanes each take every (LANES/SUB)-th segment, so several segments of the row are in flight
 // at once: a row is a *chain* of short dense slices and one slice per memory round trip would leave
 // the launch latency-bound (bytes in flight = rows x slice length) far below the HBM rate.
-template <int LANES, int SUB, typename VT = double>
+template <int LANES, int SUB, typename VT = double, bool NT = false>
 __global__ __launch_bounds__(256) void fc_nd_sweep(int nrows, const int64_t* __restrict__ seg_ptr,
                                                    const FcSeg* __restrict__ seg,
                                                    const int* __restrict__ idx,
@@ -440,8 +457,8 @@ __global__ __launch_bounds__(256) void fc_nd_sweep(int nrows, const int64_t* __r
         // predicated 4-deep issue: all eight loads of a trip are in flight before the first FMA
         for (int base = 0; base < len; base += 4 * SUB) {
           const int j0 = base + l2, j1 = j0 + SUB, j2 = j1 + SUB, j3 = j2 + SUB;
-          const double v0 = fc_val(j0 < len ? v[j0] : vz), v1 = fc_val(j1 < len ? v[j1] : vz);
-          const double v2 = fc_val(j2 < len ? v[j2] : vz), v3 = fc_val(j3 < len ? v[j3] : vz);
+          const double v0 = fc_val(j0 < len ? fc_ld<NT>(v + j0) : vz), v1 = fc_val(j1 < len ? fc_ld<NT>(v + j1) : vz);
+          const double v2 = fc_val(j2 < len ? fc_ld<NT>(v + j2) : vz), v3 = fc_val(j3 < len ? fc_ld<NT>(v + j3) : vz);
           const double x0 = j0 < len ? x[j0] : 0.0, x1 = j1 < len ? x[j1] : 0.0;
           const double x2 = j2 < len ? x[j2] : 0.0, x3 = j3 < len ? x[j3] : 0.0;
           s0 += v0 * x0;
@@ -455,8 +472,8 @@ __global__ __launch_bounds__(256) void fc_nd_sweep(int nrows, const int64_t* __r
           const int j0 = base + l2, j1 = j0 + SUB, j2 = j1 + SUB, j3 = j2 + SUB;
           const int i0 = j0 < len ? ix[j0] : 0, i1 = j1 < len ? ix[j1] : 0;
           const int i2 = j2 < len ? ix[j2] : 0, i3 = j3 < len ? ix[j3] : 0;
-          const double v0 = fc_val(j0 < len ? v[j0] : vz), v1 = fc_val(j1 < len ? v[j1] : vz);
-          const double v2 = fc_val(j2 < len ? v[j2] : vz), v3 = fc_val(j3 < len ? v[j3] : vz);
+          const double v0 = fc_val(j0 < len ? fc_ld<NT>(v + j0) : vz), v1 = fc_val(j1 < len ? fc_ld<NT>(v + j1) : vz);
+          const double v2 = fc_val(j2 < len ? fc_ld<NT>(v + j2) : vz), v3 = fc_val(j3 < len ? fc_ld<NT>(v + j3) : vz);
           s0 += v0 * buf[i0];
           s1 += v1 * buf[i1];
           s2 += v2 * buf[i2];
@@ -508,7 +525,7 @@ struct __attribute__((aligned(16))) FcBlk {
 // issued BEFORE the operand gather: descriptor -> {values | index list -> operand} is a chain of
 // three memory round trips instead of five (descriptor, indices, operand, LDS, values).  On the
 // small nodes near the leaves (row width <= 4 x LPR) that first trip is the whole row.
-template <int LPR, int RPS, typename VT = double>
+template <int LPR, int RPS, typename VT = double, bool NT = false>
 __global__ __launch_bounds__(256) void fc_nd_down_block(const FcBlk* __restrict__ blk,
                                                         const int* __restrict__ idxlist,
                                                         const VT* __restrict__ val,
@@ -528,7 +545,7 @@ __global__ __launch_bounds__(256) void fc_nd_down_block(const FcBlk* __restrict_
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int j = l + u * LPR;
-      pv[k][u] = (r < b.nrows && j < tl0) ? fc_val(v[j]) : 0.0;
+      pv[k][u] = (r < b.nrows && j < tl0) ? fc_val(fc_ld<NT>(v + j)) : 0.0;
     }
   }
   for (int t0 = 0; t0 < wd; t0 += FC_BLK_TILE) {
@@ -555,8 +572,8 @@ __global__ __launch_bounds__(256) void fc_nd_down_block(const FcBlk* __restrict_
         }
         for (; base < tl; base += 4 * LPR) {
           const int j0 = base + l, j1 = j0 + LPR, j2 = j1 + LPR, j3 = j2 + LPR;
-          const double v0 = j0 < tl ? fc_val(v[j0]) : 0.0, v1 = j1 < tl ? fc_val(v[j1]) : 0.0;
-          const double v2 = j2 < tl ? fc_val(v[j2]) : 0.0, v3 = j3 < tl ? fc_val(v[j3]) : 0.0;
+          const double v0 = j0 < tl ? fc_val(fc_ld<NT>(v + j0)) : 0.0, v1 = j1 < tl ? fc_val(fc_ld<NT>(v + j1)) : 0.0;
+          const double v2 = j2 < tl ? fc_val(fc_ld<NT>(v + j2)) : 0.0, v3 = j3 < tl ? fc_val(fc_ld<NT>(v + j3)) : 0.0;
           s0 += v0 * (j0 < tl ? xs[j0] : 0.0);
           s1 += v1 * (j1 < tl ? xs[j1] : 0.0);
           s2 += v2 * (j2 < tl ? xs[j2] : 0.0);
