@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void fc_b_repack(const FcBTask* __restrict__ t
 #ifndef FC_B_WPE
 #define FC_B_WPE 4  // waves per SIMD the register allocation aims at: 128 VGPRs keep two chunks of a wave in flight
 #endif
-template <int KB>
+template <int KB, bool NT = false>  // NT: the tiled factors exceed the Infinity Cache and are streamed with nontemporal loads (fc_ld in fc_kernels.hip.h)
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FC_B_WPE, FC_B_WPE))) void fc_nd_block_b(
     const FcBTask* __restrict__ tasks, const int* __restrict__ olist, const double* __restrict__ tiled, double* __restrict__ buf, int CG) {
   extern __shared__ double fc_b_red[];
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FC_B_WPE, 
     const double* __restrict__ p = tv + 512 * (long long)(ch < nchunk ? ch : 0);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const fc_d2 v = *reinterpret_cast<const fc_d2*>(p + 128 * u);
+      const fc_d2 v = NT ? __builtin_nontemporal_load(reinterpret_cast<const fc_d2*>(p + 128 * u)) : *reinterpret_cast<const fc_d2*>(p + 128 * u);
       a[2 * u] = v.x;
       a[2 * u + 1] = v.y;
       b[2 * u] = buf[(size_t)x[u].x * KB + ls];

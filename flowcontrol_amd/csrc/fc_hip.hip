@@ -4188,11 +4188,18 @@ static int batch_apply(fc_ctx* h, int slot) {
   if (!B.ftile_ok[slot]) return fail(FC_ERR_NOT_READY, "batched apply: the slot's factors have no tiled copy (fc_set_batch after fc_setup_solver)");
   double* buf = B.buf.p;
   const double* tiled = B.ftile[slot].p;
+  const bool nt = h->sys[slot].nt;
   FCCHK(time_begin(h, 0, (int)B.launches.size()));
   for (const fc_ctx::BLaunch& L : B.launches) {
     if (L.kind == 0) {
       const FcBTask* tp = B.tasks.p + L.first;
-#define FC_BLK(K) hipLaunchKernelGGL((fc_nd_block_b<K>), dim3(L.count), dim3(64 * L.cg), L.cg > 1 ? (size_t)L.cg * 2048 : 0, h->stream, tp, B.olist.p, tiled, buf, L.cg)
+#define FC_BLK(K)                                                                                                                                              \
+  do {                                                                                                                                                         \
+    if (nt)                                                                                                                                                    \
+      hipLaunchKernelGGL((fc_nd_block_b<K, true>), dim3(L.count), dim3(64 * L.cg), L.cg > 1 ? (size_t)L.cg * 2048 : 0, h->stream, tp, B.olist.p, tiled, buf, L.cg); \
+    else                                                                                                                                                       \
+      hipLaunchKernelGGL((fc_nd_block_b<K>), dim3(L.count), dim3(64 * L.cg), L.cg > 1 ? (size_t)L.cg * 2048 : 0, h->stream, tp, B.olist.p, tiled, buf, L.cg);   \
+  } while (0)
       FC_KB_DISPATCH(B.KB, FC_BLK(4), FC_BLK(8), FC_BLK(16));
 #undef FC_BLK
     } else {
