@@ -88,6 +88,7 @@ struct Stage {
   int64_t blk_begin = 0;  // down stages: LDS-tiled block kernel (fc_nd_down_block) when blk_count > 0
   int blk_count = 0, blk_lpr = 64, blk_rps = 1;
   double bytes;  // algorithmic bytes of this launch
+  int64_t wg_begin = -1;  // offset of this launch's workgroup order (OrderSys::wg_order), -1: launch order = row order
   bool nt = false;  // its values are streamed with nontemporal loads (OrderSys::nt, minus the stages kept cache-resident)
   int dag_task0 = 0, dag_ntasks = 0;  // one-launch apply (fc_nd_dag): this stage's tasks
 };
@@ -103,6 +104,7 @@ struct OrderSys {
   DevBuf<int64_t> seg_ptr;  // per-row segment lists of all stages, concatenated
   DevBuf<FcSeg> seg;
   DevBuf<FcBlk> blk;
+  DevBuf<int> wg_order;  // per sweep launch: row groups by decreasing work
   DevBuf<int> f_idx;
   DevBuf<double> f_val;
   DevBuf<float> f_val32;    // compressed factors (fc_set_factor_precision): the values rounded once to fp32 ...
@@ -569,14 +571,15 @@ int launch_sweep(fc_ctx* h, const OrderSys& S, const Stage& st) {
   double* buf = h->buf.p;
   const int dest0 = st.kind == 0 ? st.row0 : h->N + st.row0;
   const int acc = st.kind == 0 ? 1 : 0;
+  const int* wgo = st.wg_begin >= 0 ? S.wg_order.p + st.wg_begin : nullptr;
 #define FC_SWEEP(L, SB)                                                                                                          \
   do {                                                                                                                           \
     if (st.nt)                                                                                                                   \
       hipLaunchKernelGGL((fc_nd_sweep<L, SB, double, true>), grid, block, 0, h->stream, st.nrows, rp, S.seg.p, S.f_idx.p,       \
-                         S.f_val.p, buf, dest0, acc);                                                                            \
+                         S.f_val.p, buf, dest0, acc, wgo);                                                                       \
     else                                                                                                                         \
       hipLaunchKernelGGL((fc_nd_sweep<L, SB>), grid, block, 0, h->stream, st.nrows, rp, S.seg.p, S.f_idx.p, S.f_val.p, buf,     \
-                         dest0, acc);                                                                                            \
+                         dest0, acc, wgo);                                                                                       \
   } while (0)
   const int key = st.lanes * 1000 + st.sub;
   switch (key) {
@@ -1856,6 +1859,7 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
   int64_t total_rows = 0;
   S.stages.clear();
   S.sweep_bytes = 0.0;
+  std::vector<int> wg_order;  // workgroup order of every sweep launch, one after the other
   for (int s = 0; s < n_stages; ++s) {
     Stage st;
     st.rp_begin = stage_begin[s];
@@ -1936,9 +1940,24 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
     st.bytes = 8.0 * (double)nz + 16.0 * (double)(q1 - q0) + 4.0 * (double)nz_idx +
                (double)st.nrows * (8.0 + 8.0 + (st.kind == 0 ? 8.0 : 0.0));
     S.sweep_bytes += st.bytes;
+    // row groups of this launch by decreasing work (values behind their rows); FC_WG_SORT=0: row order
+    static const bool wg_sort = [] { const char* e = std::getenv("FC_WG_SORT"); return !(e && e[0] == '0'); }();
+    if (wg_sort && st.kind != 2 && st.nrows > 0) {
+      const int rpb = 256 / st.lanes, ng = (st.nrows + rpb - 1) / rpb;
+      std::vector<int64_t> work((size_t)ng, 0);
+      for (int r = 0; r < st.nrows; ++r)
+        for (int64_t q = seg_ptr[total_rows + r]; q < seg_ptr[total_rows + r + 1]; ++q) work[(size_t)(r / rpb)] += seg_len[q];
+      std::vector<int> order((size_t)ng);
+      for (int g = 0; g < ng; ++g) order[(size_t)g] = g;
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return work[(size_t)a] > work[(size_t)b]; });
+      st.wg_begin = (int64_t)wg_order.size();
+      wg_order.insert(wg_order.end(), order.begin(), order.end());
+    }
     S.stages.push_back(st);
     total_rows += st.nrows;
   }
+  if (wg_order.empty()) wg_order.push_back(0);
+  FCCHK(S.wg_order.upload(wg_order, h->stream));
   if (ar_stage >= n_stages || ar_row0 < 0 || ar_n < 0 || (int64_t)ar_row0 + ar_n > N)
     return fail(FC_ERR_INVALID, "fc_solver_setup: bad all-reduce range");
   if (ar2_stage >= n_stages || (ar2_stage >= 0 && (ar2_stage <= ar_stage || S.stages[ar2_stage].kind != 1 || S.stages[ar2_stage].row0 < ar_row0 ||
@@ -2059,6 +2078,12 @@ int fc_solver_set_blocks(fc_handle h, int slot, int32_t n_stages, const int64_t*
       }
       if (rows != st.nrows) return fail(FC_ERR_INVALID, "fc_solver_set_blocks: blocks do not cover the stage rows");
     }
+    // launch order = decreasing work: the workgroups of the widest blocks start first instead of forming the launch's tail
+    // (blocks are independent of one another; FC_BLK_SORT=0: tree order)
+    static const bool blk_sort = [] { const char* e = std::getenv("FC_BLK_SORT"); return !(e && e[0] == '0'); }();
+    if (blk_sort && stage_blk_count[s] > 1)
+      std::stable_sort(packed.begin() + stage_blk_begin[s], packed.begin() + stage_blk_begin[s] + stage_blk_count[s],
+                       [](const FcBlk& a, const FcBlk& b) { return (int64_t)a.nrows * (a.ni + a.nb) > (int64_t)b.nrows * (b.ni + b.nb); });
     st.blk_begin = stage_blk_begin[s];
     st.blk_count = stage_blk_count[s];
     st.blk_lpr = stage_lpr[s];

@@ -424,7 +424,10 @@ __global__ __launch_bounds__(256) void fc_nd_sweep(int nrows, const int64_t* __r
                                                    const FcSeg* __restrict__ seg,
                                                    const int* __restrict__ idx,
                                                    const VT* __restrict__ val,
-                                                   double* __restrict__ buf, int dest0, int accumulate) {
+                                                   double* __restrict__ buf, int dest0, int accumulate,
+                                                   const int* __restrict__ wg_order = nullptr) {
+  // wg_order: launch position -> row group, by decreasing work (the long rows start first instead of forming the launch's tail)
+  const int wg = wg_order ? wg_order[blockIdx.x] : (int)blockIdx.x;
   constexpr int RPB = 256 / LANES;
   constexpr int SW = LANES < 64 ? LANES : 64;  // shuffle width (descriptor broadcast, reduction)
   constexpr int G = LANES / SUB;               // segments processed concurrently per row
@@ -432,7 +435,7 @@ __global__ __launch_bounds__(256) void fc_nd_sweep(int nrows, const int64_t* __r
   const int sl = threadIdx.x % SW;             // lane inside the shuffle group
   const int g = lane / SUB;                    // sub-group of this lane
   const int l2 = lane % SUB;
-  const int row = blockIdx.x * RPB + threadIdx.x / LANES;
+  const int row = wg * RPB + threadIdx.x / LANES;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   // rows beyond nrows still take part in the shuffles below (q0 == q1: zero trips)
   const int64_t q0 = row < nrows ? seg_ptr[row] : 0, q1 = row < nrows ? seg_ptr[row + 1] : 0;
