@@ -19,8 +19,8 @@ __constant__ double c_qw[FC_NQ];             // weights (sum = 1; times |detJ|/2
 // ---------------------------------------------------------------------------------------------
 // RHS element loop: the `rhs` of NSForms._order1/_order2 (reference nsforms.py:238-305)
 //   g = cm_n u_n + cm_nn u_nn + cc_n (u_n.grad)u_n + cc_nn (u_nn.grad)u_nn + f ;  L_e[a,j] = ∫ g_j φ_a
-// EIGHT lanes per cell: lane q < 7 evaluates g at Radon point q (the nodal values of the cell are
-// loaded by all eight lanes from the same addresses: one broadcast transaction), the weighted point
+// EIGHT lanes per cell: lane q < 7 evaluates g at Radon point q (the nodal values of the cell come
+// through LDS, fetched once by lanes a < 6), the weighted point
 // values are exchanged inside the group and lane a < 6 sums the contribution to test function a in
 // the fixed order q = 0..6.  With a thread per cell the launch had 12 k threads (< 1 wave per CU) and
 // ran ~1 000 dependent FMAs each; this way it is two memory round trips and ~150 FMAs deep.
@@ -41,22 +41,37 @@ __global__ __launch_bounds__(256) void fc_rhs_elem(int nc, int nn, const int* __
   const int cl = t >> 3, lane = t & 7;
   const bool active = cl < ncl;
   const int c = active ? (cell_list ? cell_list[cl] : cl) : 0;
-  const int q = lane < FC_NQ ? lane : FC_NQ - 1;  // lane 7 shadows point 6 with zero weight
-  const double j00 = geom[c], j01 = geom[nc + c], j10 = geom[2 * nc + c], j11 = geom[3 * nc + c];
-  const double wq = lane < FC_NQ ? c_qw[q] * 0.5 * geom[4 * nc + c] : 0.0;
-  double ux = 0, uy = 0, uxi = 0, uet = 0, vxi = 0, vet = 0;  // field n: value, d/dxi, d/deta of (ux, uy)
-  double wx = 0, wy = 0, wxi = 0, wet = 0, zxi = 0, zet = 0;  // field nn
-  double gx = 0, gy = 0;
-#pragma unroll
-  for (int a = 0; a < 6; ++a) {
-    const int n = cn[a * nc + c];
-    const double ax = un[n], ay = un[nn + n], bx = unn[n], by = unn[nn + n];
+  // The loop is bound by the number of vector-memory instructions, not by bytes (the nodal values sit in the caches): lane
+  // a < 6 fetches node a of its cell ONCE -- its two velocity fields and the force profile -- and the eight lanes of the cell
+  // read the six nodes back from LDS (broadcast reads; row stride 9 keeps the eight cells of a wave on different banks).
+  __shared__ double sh[6][32 * 9];
+  const int cb = (threadIdx.x >> 3) * 9;
+  if (lane < 6) {
+    const int n = cn[lane * nc + c];
     double fx = 0.0, fy = 0.0;
     for (int k = 0; k < n_act; ++k) {
       const double uk = uctrl[k];
       fx += uk * fprof[(size_t)k * 2 * nn + n];
       fy += uk * fprof[(size_t)k * 2 * nn + nn + n];
     }
+    sh[0][cb + lane] = un[n];
+    sh[1][cb + lane] = un[nn + n];
+    sh[2][cb + lane] = unn[n];
+    sh[3][cb + lane] = unn[nn + n];
+    sh[4][cb + lane] = fx;
+    sh[5][cb + lane] = fy;
+  }
+  const int q = lane < FC_NQ ? lane : FC_NQ - 1;  // lane 7 shadows point 6 with zero weight
+  const double j00 = geom[c], j01 = geom[nc + c], j10 = geom[2 * nc + c], j11 = geom[3 * nc + c];
+  const double wq = lane < FC_NQ ? c_qw[q] * 0.5 * geom[4 * nc + c] : 0.0;
+  double ux = 0, uy = 0, uxi = 0, uet = 0, vxi = 0, vet = 0;  // field n: value, d/dxi, d/deta of (ux, uy)
+  double wx = 0, wy = 0, wxi = 0, wet = 0, zxi = 0, zet = 0;  // field nn
+  double gx = 0, gy = 0;
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    const double ax = sh[0][cb + a], ay = sh[1][cb + a], bx = sh[2][cb + a], by = sh[3][cb + a];
+    const double fx = sh[4][cb + a], fy = sh[5][cb + a];
     const double ph = c_phi2[q * 6 + a], dx = c_dphi2[(q * 6 + a) * 2], de = c_dphi2[(q * 6 + a) * 2 + 1];
     ux += ph * ax;
     uy += ph * ay;
