@@ -193,6 +193,8 @@ struct fc_ctx {
   DevBuf<int> bcslot_p;
   DevBuf<double> bcprof, fprof;
   bool have_force = false;
+  DevBuf<double> fvec;   // [n_act][N] permuted: assembled load vector of every body-force profile (build_force_vectors)
+  bool fvec_ok = false;  // ... valid for the present profiles, permutation, Dirichlet rows and partition
   DevBuf<int> s_rowptr, s_idx;
   DevBuf<int> s_idxp;        // sensor dofs as positions in the sweep buffer's x half (N + permuted index): fused final of fc_tail
   bool have_sidxp = false;
@@ -777,6 +779,7 @@ int solve_permuted(fc_ctx* h, OrderSys& S, const double** x_out, const double** 
 }
 
 int refresh_permuted(fc_ctx* h) {
+  h->fvec_ok = false;  // load vectors of the body-force profiles: permuted rows, Dirichlet rows
   if (!h->have_perm) return FC_OK;
   const int N = h->N;
   // vector-scatter lists and BC slots in permuted row order
@@ -840,31 +843,63 @@ StepCoeffs coeffs_for(const fc_ctx* h, int order_slot) {
   return {2.0 / h->dt, -0.5 / h->dt, -2.0 * nl, nl};
 }
 
+int build_force_vectors(fc_ctx* h);
 int check_step_ready(fc_ctx* h, int order_slot) {
   if (!h) return fail(FC_ERR_INVALID, "null handle");
   if (order_slot != FC_SLOT_BDF1 && order_slot != FC_SLOT_BDF2) return fail(FC_ERR_INVALID, "order_slot must be BDF1/BDF2");
   if (h->dt <= 0) return fail(FC_ERR_NOT_READY, "fc_set_time_scheme not called");
   if (!h->have_perm) return fail(FC_ERR_NOT_READY, "fc_set_permutation not called");
   if (!h->sys[order_slot].have_lift) return fail(FC_ERR_NOT_READY, "fc_apply_bc not called for this order");
-  return FC_OK;
+  return build_force_vectors(h);  // (no-op unless body-force profiles changed: outside any graph capture, before the step is enqueued)
 }
 
 // enqueue RHS assembly for the current state into h->b (permuted numbering)
+// Body-force actuators enter the right-hand side linearly: b += sum_k u_k F_k with F_k the load vector of profile k.  F_k is
+// assembled once per profile (same element kernel, state terms off, unit amplitude on actuator k), so that the element loop of a
+// time step depends on the state only -- it runs ahead of u_ctrl like that of a boundary-actuated flow (speculate_next_rhs).
+int build_force_vectors(fc_ctx* h) {
+  if (!h->have_force || h->fvec_ok) return FC_OK;
+  HIPCHK(hipSetDevice(h->device));
+  const int N = h->N, ncl = h->partitioned ? h->ncl : h->nc;
+  FCCHK(h->fvec.alloc((size_t)std::max(1, h->n_act) * N));
+  std::vector<double> unit((size_t)std::max(1, h->n_act), 0.0);
+  DevBuf<double> amp;
+  FCCHK(amp.alloc(unit.size()));
+  for (int k = 0; k < h->n_act; ++k) {
+    std::fill(unit.begin(), unit.end(), 0.0);
+    unit[(size_t)k] = 1.0;
+    HIPCHK(hipMemcpyAsync(amp.p, unit.data(), unit.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (ncl > 0)
+      hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks((int64_t)ncl * 8, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
+                         h->u_n.p, h->u_nn.p, h->fprof.p, h->n_act, amp.p, 0.0, 0.0, 0.0, 0.0, h->ev.p,
+                         h->partitioned ? h->cell_list.p : nullptr, ncl);
+    hipLaunchKernelGGL(fc_force_rows, dim3(nblocks(N, 256)), dim3(256), 0, h->stream, N, h->gptr_p.p, h->gidx_p.p, h->ev.p,
+                       h->bcslot_p.p, h->partitioned ? h->rowkind_p.p : nullptr, h->fvec.p + (size_t)k * N);
+    HIPCHK(hipStreamSynchronize(h->stream));  // `unit` is rewritten for the next actuator
+  }
+  HIPCHK(hipGetLastError());
+  h->pre_slot = -1;  // ev was used as scratch
+  h->fvec_ok = true;
+  return FC_OK;
+}
+
 int enqueue_rhs(fc_ctx* h, int order_slot, const double* d_uctrl, const double* d_uforce = nullptr) {
   const StepCoeffs c = coeffs_for(h, order_slot);
   OrderSys& S = h->sys[order_slot];
   if (!d_uforce) d_uforce = d_uctrl;
   const int ncl = h->partitioned ? h->ncl : h->nc;
-  const bool have_ev = h->pre_slot == order_slot && !h->have_force;
+  if (h->have_force && !h->fvec_ok) return fail(FC_ERR_NOT_READY, "enqueue_rhs: force vectors not built");
+  const bool have_ev = h->pre_slot == order_slot;
   h->pre_slot = -1;
   if (ncl > 0 && !have_ev)
     hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks((int64_t)ncl * 8, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
-                       h->u_n.p, h->u_nn.p, h->have_force ? h->fprof.p : nullptr, h->have_force ? h->n_act : 0, d_uforce,
-                       c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p, h->partitioned ? h->cell_list.p : nullptr, ncl);
+                       h->u_n.p, h->u_nn.p, (const double*)nullptr, 0, d_uforce, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p,
+                       h->partitioned ? h->cell_list.p : nullptr, ncl);
   hipLaunchKernelGGL(fc_rhs_gather, dim3(nblocks(h->N, 256)), dim3(256), 0, h->stream, h->N, h->gptr_p.p, h->gidx_p.p,
                      h->ev.p, h->bcslot_p.p, h->bcprof.p, S.lift_p.p, h->n_act, d_uctrl, h->b.p, h->buf.p,
                      h->partitioned ? h->rowkind_p.p : nullptr, h->lead ? 1 : 0, S.have_c ? S.c_rowptr.p : nullptr,
-                     S.c_col.p, S.c_val.p, h->u_n.p, h->partitioned ? h->rowkind_w.p : nullptr);
+                     S.c_col.p, S.c_val.p, h->u_n.p, h->partitioned ? h->rowkind_w.p : nullptr,
+                     h->have_force ? h->fvec.p : nullptr, d_uforce);
   HIPCHK(hipGetLastError());
   return FC_OK;
 }
@@ -1702,6 +1737,7 @@ int fc_set_bc(fc_handle h, int32_t n_bc, const int32_t* bc_dofs, int32_t n_act, 
 int fc_set_force(fc_handle h, int32_t n_act, const double* profiles) {
   if (!h) return fail(FC_ERR_INVALID, "null handle");
   HIPCHK(hipSetDevice(h->device));
+  h->fvec_ok = false;
   if (!profiles || n_act == 0) {
     h->have_force = false;
     return FC_OK;
@@ -3331,7 +3367,7 @@ int fc_get_solution(fc_handle h, double* up) {
 // Behind a synchronous step: the element loop of the next right-hand side reads the state only (BC
 // actuation enters in fc_rhs_gather), so it is enqueued now and runs while the host is between two
 // fc_step calls; enqueue_rhs skips its own launch when the prediction (same scheme, BDF2 after BDF1)
-// holds and nothing touched the state in between.  Body-force actuators need u_ctrl: no speculation.
+// holds and nothing touched the state in between.  (Body forces enter in fc_rhs_gather too: build_force_vectors.)
 void speculate_next_rhs(fc_ctx* h, int order_slot) {
   static const bool enabled = [] {
     const char* e = std::getenv("FC_SPECULATE");
@@ -3339,7 +3375,7 @@ void speculate_next_rhs(fc_ctx* h, int order_slot) {
   }();
   h->pre_slot = -1;
   const int ncl = h->partitioned ? h->ncl : h->nc;
-  if (!enabled || h->have_force || ncl <= 0) return;
+  if (!enabled || ncl <= 0) return;
   const int next = h->sys[order_slot].have_c ? order_slot : FC_SLOT_BDF2;
   if (!h->sys[next].ready || !h->sys[next].have_lift) return;
   const StepCoeffs c = coeffs_for(h, next);
@@ -3659,12 +3695,13 @@ int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double*
     launches = 0;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks((int64_t)h->nc * 8, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
-                       h->u_n.p, h->u_nn.p, h->have_force ? h->fprof.p : nullptr, h->have_force ? h->n_act : 0,
-                       h->uctrl.p, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p, (const int*)nullptr, h->nc);
+                       h->u_n.p, h->u_nn.p, (const double*)nullptr, 0, h->uctrl.p, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p,
+                       (const int*)nullptr, h->nc);
     FCCHK(lap(0));
     hipLaunchKernelGGL(fc_rhs_gather, dim3(g), dim3(256), 0, h->stream, N, h->gptr_p.p, h->gidx_p.p, h->ev.p,
                        h->bcslot_p.p, h->bcprof.p, S.lift_p.p, h->n_act, h->uctrl.p, h->b.p, h->buf.p,
-                       (const unsigned char*)nullptr, 1, S.have_c ? S.c_rowptr.p : nullptr, S.c_col.p, S.c_val.p, h->u_n.p);
+                       (const unsigned char*)nullptr, 1, S.have_c ? S.c_rowptr.p : nullptr, S.c_col.p, S.c_val.p, h->u_n.p,
+                       (const unsigned char*)nullptr, h->have_force ? h->fvec.p : nullptr, h->uctrl.p);
     FCCHK(lap(1));
     FCCHK(apply_factors(h, S));
     launches += (int)S.stages.size();
@@ -3735,6 +3772,7 @@ int fc_bench_sweeps(fc_handle h, int slot, int reps, double* ms_per_apply, int32
 }
 
 int fc_set_partition(fc_handle h, int32_t n_local_cells, const int32_t* local_cells, const uint8_t* rowkind, int lead) {
+  if (h) h->fvec_ok = false;
   if (!h || n_local_cells < 0 || (n_local_cells > 0 && !local_cells) || !rowkind)
     return fail(FC_ERR_INVALID, "fc_set_partition: bad argument");
   HIPCHK(hipSetDevice(h->device));

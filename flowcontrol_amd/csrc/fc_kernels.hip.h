@@ -126,7 +126,9 @@ __global__ __launch_bounds__(256) void fc_rhs_gather(int N, const int* __restric
                                                      const int* __restrict__ c_col,
                                                      const double* __restrict__ c_val,
                                                      const double* __restrict__ un,
-                                                     const unsigned char* __restrict__ colkind = nullptr) {
+                                                     const unsigned char* __restrict__ colkind = nullptr,
+                                                     const double* __restrict__ fvec = nullptr,
+                                                     const double* __restrict__ uforce = nullptr) {
   // rowkind (multi-GPU): 0 = another rank's row, 1 = owned, 2 = root separator shared by all ranks
   // (every rank adds its cells' share; the BC value / lifting is added once, by the lead rank; of an explicit operator's
   // root rows every rank takes the columns it accounts for -- colkind: the dof kinds in the W numbering of `un`)
@@ -158,6 +160,10 @@ __global__ __launch_bounds__(256) void fc_rhs_gather(int N, const int* __restric
     }
     if (once)
       for (int k = 0; k < n_act; ++k) s -= uctrl[k] * lift[(size_t)k * N + i];
+    // body-force actuators: + sum_k u_k F_k[row], F_k the assembled load vector of actuator k's profile (fc_force_rows: once per
+    // profile -- the element loop then depends on the state only and can run ahead of u_ctrl); every rank adds its cells' share
+    if (fvec)
+      for (int k = 0; k < n_act; ++k) s += uforce[k] * fvec[(size_t)k * N + i];
     // explicit half of the linear terms of Crank-Nicolson (nsforms.py:212-216): -(C u_n)[row]
     if (c_rowptr)
       for (int k = c_rowptr[i]; k < c_rowptr[i + 1]; ++k) {
@@ -171,6 +177,19 @@ __global__ __launch_bounds__(256) void fc_rhs_gather(int N, const int* __restric
   }
   b[i] = s;
   y[i] = s;  // y-half of the solver work buffer: the first factor sweep starts from b
+}
+
+// load vector of ONE body-force profile from its element vectors (fc_rhs_elem with the state terms switched off and a unit
+// amplitude on that actuator): out[row] = sum of the row's element contributions, 0 on Dirichlet rows and on other ranks' rows
+__global__ __launch_bounds__(256) void fc_force_rows(int N, const int* __restrict__ gptr, const int* __restrict__ gidx,
+                                                     const double* __restrict__ ev, const int* __restrict__ bcslot,
+                                                     const unsigned char* __restrict__ rowkind, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  double s = 0.0;
+  if (bcslot[i] < 0 && !(rowkind && rowkind[i] == 0))
+    for (int k = gptr[i]; k < gptr[i + 1]; ++k) s += ev[gidx[k]];
+  out[i] = s;
 }
 
 // ---------------------------------------------------------------------------------------------
