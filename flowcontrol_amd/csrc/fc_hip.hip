@@ -2838,6 +2838,16 @@ int fc_get_local_cells(fc_handle h, int32_t* cells) {
 
 int fc_accept_factors(fc_handle h, int slot, double* residual_out, int32_t* inexact_out);
 
+// Binary bisections of the default tree: leaves of about 12 cells, i.e. log2(nc / 12) levels, taken to the NEAREST count the
+// fused levels allow (top + a multiple of merge).  Rounding up instead (rounds 1-2) gave the pinball (66 668 cells) and
+// cavity_coarse 16 384 leaves of 3-4 cells: two more launches of blocks too small to fill a workgroup, 7 % slower steps.
+// flowcontrol_amd/device.py::_default_depth is the same rule.
+static int default_depth(int nc, int merge, int top) {
+  const double levels = std::log2(std::max(nc, 1) / 12.0);
+  if (top > 0) return std::max(merge + top, (int)std::ceil(levels));  // partitioned handles: as before (build_tree rounds up)
+  return merge * std::max(1, (int)std::floor(levels / merge + 0.5));
+}
+
 int fc_setup_solver(fc_handle h, int slot, int32_t depth, int32_t merge, int32_t truncate, int32_t refine, int32_t check_residual) {
   if (!h || slot < 0 || slot > 1 || merge < 1 || merge > 4 || depth < 0 || truncate < 0 || refine < 0)
     return fail(FC_ERR_INVALID, "fc_setup_solver: bad argument");
@@ -2860,7 +2870,7 @@ int fc_setup_solver(fc_handle h, int slot, int32_t depth, int32_t merge, int32_t
     }
     if (!h->sym_ready) {
       int d = depth;
-      if (d == 0) d = std::max(merge + top, (int)std::ceil(std::log2(std::max(h->nc, 1) / 12.0)));
+      if (d == 0) d = default_depth(h->nc, merge, top);
       std::vector<unsigned char> skip((size_t)N, 0);
       for (int k = 0; k < h->n_bc; ++k) skip[(size_t)h->h_bc_dofs[k]] = 1;
       h->sym_tree = fcsym::build_tree(h->h_cell_dofs, 15, h->h_cent, h->nc, N, d, &skip, merge, top);
@@ -3075,7 +3085,7 @@ int fc_sym_build(int32_t nv, int32_t ne, int32_t nc, const double* coords, const
     int top = 0;
     while ((1 << top) < world) ++top;
     int d = depth;
-    if (d == 0) d = std::max(merge + top, (int)std::ceil(std::log2(std::max(nc, 1) / 12.0)));
+    if (d == 0) d = default_depth(nc, merge, top);
     const bool timing = getenv("FC_SYM_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto lap = [&](const char* what, std::chrono::steady_clock::time_point& t0) {

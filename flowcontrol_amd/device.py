@@ -29,6 +29,15 @@ def _i32(a) -> np.ndarray:
 
 logger = logging.getLogger(__name__)
 
+def _default_depth(nc: int, merge: int, top: int) -> int:
+    """Binary bisections of the default elimination tree: leaves of about 12 cells, to the nearest count the fused levels allow
+    (``csrc/fc_hip.hip::default_depth`` is the same rule)."""
+    levels = float(np.log2(max(nc, 1) / 12.0))
+    if top > 0:  # partitioned handles: as before (build_tree rounds up)
+        return max(merge + top, int(np.ceil(levels)))
+    return merge * max(1, int(np.floor(levels / merge + 0.5)))
+
+
 class DeviceSolver:
     def __init__(self, th: TaylorHood, device: int = 0):
         self.lib = _lib.load()
@@ -250,7 +259,7 @@ class DeviceSolver:
             th = self.th
             top = int(np.log2(self.world)) if self.world > 1 else 0
             if depth is None:
-                depth = max(merge + top, int(np.ceil(np.log2(max(th.nc, 1) / 12.0))))
+                depth = _default_depth(th.nc, merge, top)
             skip = np.zeros(self.N, dtype=bool)
             skip[self.bc_dofs] = True
             self._skip = skip
@@ -386,7 +395,7 @@ class DeviceSolver:
             depth, merge = self._tree_args
             top = int(np.log2(self.world)) if self.world > 1 else 0
             if depth == 0:
-                depth = max(merge + top, int(np.ceil(np.log2(max(self.th.nc, 1) / 12.0))))
+                depth = _default_depth(self.th.nc, merge, top)
             skip = np.zeros(self.N, dtype=bool)
             skip[self.bc_dofs] = True
             self._tree = ndsolver.build_tree(self.th.cell_dofs, self.th.mesh.cell_centroids(), self.N, depth, skip, merge=merge, top_bits=top)
