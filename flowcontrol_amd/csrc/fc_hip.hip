@@ -334,8 +334,10 @@ struct fc_ctx {
     double pend_seq = 0.0;
     // the launches of one batched step as a HIP graph per (order slot, energy flag): captured on first use, replayed as long as
     // no buffer or parameter that a kernel argument was taken from has changed (gsig: hash of all of them)
-    hipGraphExec_t gexec[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-    uint64_t gsig[2][2] = {{0, 0}, {0, 0}};
+    // (third index: 1 = the graph starts with the element loop, 0 = the previous step's graph already ran it -- pre_slot)
+    hipGraphExec_t gexec[2][2][2] = {{{nullptr, nullptr}, {nullptr, nullptr}}, {{nullptr, nullptr}, {nullptr, nullptr}}};
+    uint64_t gsig[2][2][2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}};
+    int pre_slot = -1;  // order slot whose element vectors (ev) the LAST launch of the previous step left behind, -1: none
   } bat;
 };
 
@@ -1806,6 +1808,7 @@ int fc_set_time_scheme(fc_handle h, double dt, int nonlinear) {
   h->dt = dt;
   h->nonlinear = nonlinear ? 1 : 0;
   h->pre_slot = -1;
+  h->bat.pre_slot = -1;
   return FC_OK;
 }
 
@@ -4301,6 +4304,7 @@ int fc_set_batch(fc_handle h, int32_t k) {
     return FC_OK;
   }
   FCCHK(build_batch_tables(h));
+  h->bat.pre_slot = -1;  // the state below is zeroed
   const int KB = k <= 4 ? 4 : (k <= 8 ? 8 : 16);
   const size_t N = (size_t)h->N, nn2 = 2 * (size_t)h->nn;
   if (KB != B.KB) {
@@ -4351,6 +4355,7 @@ int fc_set_state_batch(fc_handle h, int32_t k, const double* u_n, const double* 
   if (!u_n || !u_nn) return fail(FC_ERR_INVALID, "fc_set_state_batch: null argument");
   HIPCHK(hipSetDevice(h->device));
   fc_ctx::Batch& B = h->bat;
+  B.pre_slot = -1;  // element vectors of the old state
   FCCHK(batch_copy(h, 2 * h->nn, const_cast<double*>(u_n), B.u_n.p, true));
   FCCHK(batch_copy(h, 2 * h->nn, const_cast<double*>(u_nn), B.u_nn.p, true));
   if (p_n) FCCHK(batch_copy(h, h->nv, const_cast<double*>(p_n), B.p_n.p, true));
@@ -4379,18 +4384,23 @@ int fc_get_solution_batch(fc_handle h, int32_t k, double* up) {
 // the launches of one batched step; controls are read from the host-mapped record (uctrl at s * kRecStride, body-force
 // amplitudes at s * kRecStride + 32, the step's sequence number at kSeqSlot), every simulation's outputs go to its own record
 constexpr int kSeqSlot = 4000;
-static int batch_launches(fc_ctx* h, int order_slot, int compute_energy) {
+// lead_elem: the step starts with its element loop; spec_slot >= 0: it ENDS with the element loop of the next step (scheme of
+// that slot) -- the loop depends on the state only, so it runs while the host is between two fc_step_batch calls, as
+// speculate_next_rhs does for the single simulation
+static int batch_launches(fc_ctx* h, int order_slot, int compute_energy, bool lead_elem = true, int spec_slot = -1) {
   fc_ctx::Batch& B = h->bat;
   OrderSys& S = h->sys[order_slot];
-  const StepCoeffs c = coeffs_for(h, order_slot);
   const int KB = B.KB, N = h->N, nc = h->nc;
   const double* uc = h->pin_dev;
   const double* uf = h->pin_dev + 32;
   const int g_elem = nblocks(nc, 256 / (8 * KB)), g_rows = nblocks((int64_t)N * (KB / 2), 256);
+  auto element_loop = [&](const StepCoeffs& c) {
 #define FC_ELEM(K) hipLaunchKernelGGL((fc_rhs_elem_b<K>), dim3(g_elem), dim3(256), 0, h->stream, nc, h->nn, h->cn.p, h->geom.p, B.u_n.p, B.u_nn.p, \
                                       h->have_force ? h->fprof.p : nullptr, h->have_force ? h->n_act : 0, uf, kRecStride, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, B.ev.p)
-  FC_KB_DISPATCH(KB, FC_ELEM(4), FC_ELEM(8), FC_ELEM(16));
+    FC_KB_DISPATCH(KB, FC_ELEM(4), FC_ELEM(8), FC_ELEM(16));
 #undef FC_ELEM
+  };
+  if (lead_elem) element_loop(coeffs_for(h, order_slot));
 #define FC_GATH(K) hipLaunchKernelGGL((fc_rhs_gather_b<K>), dim3(g_rows), dim3(256), 0, h->stream, N, h->gptr_p.p, h->gidx_p.p, B.ev.p, h->bcslot_p.p, \
                                       h->bcprof.p, S.lift_p.p, h->n_act, uc, kRecStride, B.b.p, B.buf.p, S.have_c ? S.c_rowptr.p : nullptr, S.c_col.p, \
                                       S.c_val.p, B.u_n.p)
@@ -4412,13 +4422,14 @@ static int batch_launches(fc_ctx* h, int order_slot, int compute_energy) {
                                       h->s_w.p, B.up.p, B.flag.p, h->pin_dev, kRecStride, h->pin_dev + kSeqSlot, compute_energy)
   FC_KB_DISPATCH(KB, FC_FINB(4), FC_FINB(8), FC_FINB(16));
 #undef FC_FINB
+  if (spec_slot >= 0) element_loop(coeffs_for(h, spec_slot));
   HIPCHK(hipGetLastError());
   return FC_OK;
 }
 
 // everything a kernel argument of batch_launches is taken from, hashed (FNV-1a): a captured graph is replayed only while
 // this is unchanged
-static uint64_t batch_signature(fc_ctx* h, int order_slot, int compute_energy) {
+static uint64_t batch_signature(fc_ctx* h, int order_slot, int compute_energy, bool lead_elem, int spec_slot) {
   fc_ctx::Batch& B = h->bat;
   OrderSys& S = h->sys[order_slot];
   const StepCoeffs c = coeffs_for(h, order_slot);
@@ -4437,7 +4448,9 @@ static uint64_t batch_signature(fc_ctx* h, int order_slot, int compute_energy) {
       (uint64_t)(uintptr_t)B.partial.p, (uint64_t)(uintptr_t)h->s_rowptr.p, (uint64_t)(uintptr_t)h->s_idx.p, (uint64_t)(uintptr_t)h->s_w.p,
       (uint64_t)(uintptr_t)h->pin_dev, (uint64_t)(uintptr_t)B.tblocks.p, (uint64_t)(uintptr_t)B.tcols.p, (uint64_t)(uintptr_t)B.tlidx.p, (uint64_t)B.n_tblocks, (uint64_t)B.k, (uint64_t)B.KB, (uint64_t)h->n_act, (uint64_t)h->n_sens, (uint64_t)(h->have_force ? 1 : 0),
       (uint64_t)(S.have_c ? 1 : 0), (uint64_t)compute_energy, (uint64_t)B.launches.size(), (uint64_t)B.tasks.n, bits(c.cm_n), bits(c.cm_nn), bits(c.cc_n),
-      bits(c.cc_nn)};
+      bits(c.cc_nn), (uint64_t)(lead_elem ? 1 : 0), (uint64_t)(spec_slot + 1), spec_slot >= 0 ? bits(coeffs_for(h, spec_slot).cm_n) : 0,
+      spec_slot >= 0 ? bits(coeffs_for(h, spec_slot).cm_nn) : 0, spec_slot >= 0 ? bits(coeffs_for(h, spec_slot).cc_n) : 0,
+      spec_slot >= 0 ? bits(coeffs_for(h, spec_slot).cc_nn) : 0};
   uint64_t hsh = 1469598103934665603ull;
   for (uint64_t w : words)
     for (int b = 0; b < 8; ++b) {
@@ -4449,11 +4462,13 @@ static uint64_t batch_signature(fc_ctx* h, int order_slot, int compute_energy) {
 
 static void batch_drop_graphs(fc_ctx* h) {
   for (int o = 0; o < 2; ++o)
-    for (int e = 0; e < 2; ++e) {
-      if (h->bat.gexec[o][e]) (void)hipGraphExecDestroy(h->bat.gexec[o][e]);
-      h->bat.gexec[o][e] = nullptr;
-      h->bat.gsig[o][e] = 0;
-    }
+    for (int e = 0; e < 2; ++e)
+      for (int l = 0; l < 2; ++l) {
+        if (h->bat.gexec[o][e][l]) (void)hipGraphExecDestroy(h->bat.gexec[o][e][l]);
+        h->bat.gexec[o][e][l] = nullptr;
+        h->bat.gsig[o][e][l] = 0;
+      }
+  h->bat.pre_slot = -1;
 }
 
 static int batch_enqueue(fc_ctx* h, int order_slot, int compute_energy) {
@@ -4461,28 +4476,46 @@ static int batch_enqueue(fc_ctx* h, int order_slot, int compute_energy) {
     const char* e = std::getenv("FC_BATCH_GRAPH");  // 0: plain launches
     return !(e && e[0] == '0');
   }();
-  if (!use_graph || h->timing) return batch_launches(h, order_slot, compute_energy);
   fc_ctx::Batch& B = h->bat;
-  const int ei = compute_energy ? 1 : 0;
-  const uint64_t sig = batch_signature(h, order_slot, compute_energy);
-  if (!B.gexec[order_slot][ei] || B.gsig[order_slot][ei] != sig) {
-    if (B.gexec[order_slot][ei]) (void)hipGraphExecDestroy(B.gexec[order_slot][ei]);
-    B.gexec[order_slot][ei] = nullptr;
+  // element loop of the NEXT step behind this one (same prediction as speculate_next_rhs: BDF2 follows, or the same CN slot);
+  // body forces make the loop depend on u_ctrl: no speculation then
+  static const bool speculate = [] {
+    const char* e = std::getenv("FC_SPECULATE");
+    return !(e && e[0] == '0');
+  }();
+  int spec_slot = -1;
+  if (speculate && !h->have_force) {
+    const int next = h->sys[order_slot].have_c ? order_slot : FC_SLOT_BDF2;
+    if (h->sys[next].ready && h->sys[next].have_lift) spec_slot = next;
+  }
+  const bool lead = B.pre_slot != order_slot || h->have_force;
+  B.pre_slot = -1;
+  if (!use_graph || h->timing) {
+    FCCHK(batch_launches(h, order_slot, compute_energy, lead, spec_slot));
+    B.pre_slot = spec_slot;
+    return FC_OK;
+  }
+  const int ei = compute_energy ? 1 : 0, li = lead ? 1 : 0;
+  const uint64_t sig = batch_signature(h, order_slot, compute_energy, lead, spec_slot);
+  if (!B.gexec[order_slot][ei][li] || B.gsig[order_slot][ei][li] != sig) {
+    if (B.gexec[order_slot][ei][li]) (void)hipGraphExecDestroy(B.gexec[order_slot][ei][li]);
+    B.gexec[order_slot][ei][li] = nullptr;
     hipGraph_t graph = nullptr;
     HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    const int code = batch_launches(h, order_slot, compute_energy);
+    const int code = batch_launches(h, order_slot, compute_energy, lead, spec_slot);
     const hipError_t e = hipStreamEndCapture(h->stream, &graph);
     if (code != FC_OK) {
       if (graph) (void)hipGraphDestroy(graph);
       return code;
     }
     if (e != hipSuccess) return fail(FC_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-    const hipError_t e2 = hipGraphInstantiate(&B.gexec[order_slot][ei], graph, nullptr, nullptr, 0);
+    const hipError_t e2 = hipGraphInstantiate(&B.gexec[order_slot][ei][li], graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (e2 != hipSuccess) return fail(FC_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2));
-    B.gsig[order_slot][ei] = sig;
+    B.gsig[order_slot][ei][li] = sig;
   }
-  HIPCHK(hipGraphLaunch(B.gexec[order_slot][ei], h->stream));
+  HIPCHK(hipGraphLaunch(B.gexec[order_slot][ei][li], h->stream));
+  B.pre_slot = spec_slot;
   return FC_OK;
 }
 
