@@ -197,6 +197,42 @@ def test_one_diverged_run_does_not_touch_the_others(single_runs, golden_dir):
     dev.set_batch(0)
 
 
+def test_speculative_element_loop_is_dropped_when_the_state_or_the_scheme_changes(single_runs):
+    """A batched step ends with the element loop of the NEXT step (predicted scheme, the state as it stands).  Replacing the state,
+    or asking for another scheme than predicted, must make the next step redo that loop: the same three steps from the same state
+    give the same bits, whatever ran in between."""
+    from flowcontrol_amd._lib import SLOT_BDF1, SLOT_BDF2
+
+    fs, _ = single_runs
+    dev = fs.th.device()
+    k = 5
+    dev.set_batch(k)
+    nn2, nv = 2 * fs.th.nn, fs.th.nv
+    rng = np.random.default_rng(11)
+    u0 = 1e-3 * rng.standard_normal((k, nn2))
+    u_ctrl = 1e-2 * rng.standard_normal((3, k, 2))
+
+    def three_steps():
+        dev.set_state_batch(u0, u0, np.zeros((k, nv)))
+        out = []
+        for n, slot in enumerate((SLOT_BDF1, SLOT_BDF2, SLOT_BDF2)):
+            y, dE, _ = dev.step_batch(slot, u_ctrl[n])
+            out.append((y.copy(), dE.copy()))
+        return out
+
+    ref = three_steps()
+    # (a) straight again: the state is replaced while the speculative loop of a fourth step is on the device
+    again = three_steps()
+    # (b) a BDF1 step where BDF2 was predicted, then the three steps
+    dev.step_batch(SLOT_BDF1, u_ctrl[0])
+    dev.step_batch(SLOT_BDF1, u_ctrl[1])
+    third = three_steps()
+    for a, b, c in zip(ref, again, third):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+    dev.set_batch(0)
+
+
 def test_batch_api_refuses_what_it_cannot_do(single_runs):
     from flowcontrol_amd import _lib
     from flowcontrol_amd._lib import SLOT_BDF1

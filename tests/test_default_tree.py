@@ -1,0 +1,35 @@
+"""Default shape of the elimination tree (``fc_setup_solver`` with depth 0): leaves of about 12 cells, to the NEAREST level the
+fused levels allow on single-GPU handles.  The library rule (``csrc/fc_hip.hip::default_depth``, reached through ``fc_sym_build``)
+and the Python one (``device._default_depth``, which rebuilds the tree for the host-side helpers) must agree."""
+import numpy as np
+import pytest
+
+from flowcontrol_amd import ndsolver
+from flowcontrol_amd.device import _default_depth
+from flowcontrol_amd.fem.mesh import read_xdmf_mesh
+from flowcontrol_amd.fem.spaces import TaylorHood
+
+
+def test_default_depth_rule():
+    # cells -> bisections (merge 2): O1, O1 refined, pinball, cavity_coarse, cavity_fine, lid cavity 64 x 64
+    for nc, want in ((12284, 10), (49136, 12), (66668, 12), (51883, 12), (193916, 14), (8192, 10)):
+        assert _default_depth(nc, 2, 0) == want
+    # partitioned handles keep the rule of rounds 1-2 (build_tree rounds up to top + a multiple of merge)
+    assert _default_depth(49136, 2, 3) == 12 and _default_depth(12284, 2, 1) == 10
+
+
+@pytest.mark.parametrize("mesh", ["O1", "mesh_middle_gmsh"])
+def test_library_default_tree_is_the_python_default_tree(mesh, golden_dir):
+    from test_symbolic_cabi import _bc, _tables
+
+    th = TaylorHood(read_xdmf_mesh(golden_dir / "meshes" / f"{mesh}.npz"))
+    dofs = _bc(th)
+    skip = np.zeros(th.N, bool)
+    skip[dofs] = True
+    tree = ndsolver.build_tree(th.cell_dofs, th.mesh.cell_centroids(), th.N, _default_depth(th.nc, 2, 0), skip, merge=2, top_bits=0)
+    get, free = _tables(th, dofs, 0, 2, 1, 0, 0)
+    try:
+        assert np.array_equal(get("perm"), tree.perm)
+        assert np.array_equal(get("leaf_of_cell"), tree.leaf_of_cell)
+    finally:
+        free()
