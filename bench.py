@@ -20,11 +20,19 @@ One JSON line on rank 0 with the driver's keys plus
                 (replicas_steps_per_s, bytes per simulated step, roofline of the batched factor sweeps)
   spmv          CSR SpMV probe on the assembled BDF2 matrices of the five shipped meshes (O1: the run's own matrix; the
                 others with a synthetic uniform base flow; cavity_fine is the one beyond the Infinity Cache), % of 8 TB/s
+  other_configs N = 1: BASELINE configs 4 / 5 / 3 (refined cylinder, pinball closed loop, cavity_fine closed loop) on this GPU —
+                steps/s of the synchronous public loop, the factor sweeps' roofline from their own bytes and HIP-event time (cavity_fine
+                streams 4.7 GB of factors per step from HBM: the true HBM-streaming evidence), phase split, fc_refactor ms
 N > 1 (torchrun, one rank per GPU): the SAME mesh is row-partitioned over the ranks (one sub-tree of the
 elimination tree and its cells per GPU, the root's rows split over the ranks; three small RCCL all-reduces per step) —
 total work fixed, "scaling": "strong", value = steps ÷ max time.  The shipped mesh is tiny (56 k
 DoFs), so this is latency-bound; ``replicas_steps_per_s`` (N × the single-GPU rate measured on rank 0
-in the same run) is reported next to it.  ``--replicas`` times N independent simulations instead.
+in the same run) is reported next to it, and the meshes the partition is meant for run as further legs of the same protocol:
+``strong_scaling_config4`` / ``_config5`` / ``_config3`` (steps/s over the N GPUs, the single-GPU rate of the same loop, and
+``phase_us``: every rank's mean microseconds per step in {rhs, up-sweeps, exchange 1, root, exchange 2, down-sweeps, tail,
+exchange 3, publish} from HIP-event marks inside fc_step).  ``--replicas`` times N independent simulations instead.
+Rehearsals of the N > 1 path on ONE GPU (not measurements): ``FC_BENCH_THREAD_RANKS=8 python bench.py --gpus 8`` (ranks =
+threads of one process) or ``FC_BENCH_SAME_DEVICE=1 torchrun --nproc-per-node 4 bench.py --gpus 4`` (process ranks over gloo).
 """
 from __future__ import annotations
 
@@ -225,126 +233,254 @@ def batched_replicas(fs, steps: int, single_rate: float, ks=(1, 4, 8, 16)) -> di
 
 
 def dev_index(fs) -> int:
-    return int(os.environ.get("LOCAL_RANK", "0"))
+    return int(fs.th.device().device_index)
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-large-spmv", action="store_true")
-    ap.add_argument("--replicas", action="store_true", help="N > 1: independent replicas instead of the partitioned run")
-    ap.add_argument("--no-replicas", action="store_true", help="skip the batched-replicas section (profiling passes of the single-simulation step)")
-    ap.add_argument("--no-extras", action="store_true", help="skip rank 0's single-GPU extras (roofline replay, SpMV probe, batched replicas, CPU baseline)")
-    ap.add_argument("--no-config4", action="store_true", help="N > 1: skip the strong-scaling run on the BASELINE config-4 mesh (O1 refined once)")
-    ap.add_argument("--refine", type=int, default=0, help="red-refine the O1 mesh K times (BASELINE config 4: K=1); not the headline workload")
-    args = ap.parse_args()
-    global REFINE
-    REFINE = args.refine
+# ── the workloads: BASELINE configs[1] (headline), [3] (refined cylinder), [4] (pinball), [2] (open cavity) ─────────────────
+class Case:
+    """One workload: ``prepare(comm, device)`` → data every rank needs (e.g. a base flow computed once and broadcast),
+    ``make(device, shared)`` → a FlowSolver ready to step, ``controller(fs)`` → ``fs -> u_ctrl`` of the loop."""
 
+    def __init__(self, key, workload, make, controller=None, prepare=None, steps_cap=300, warm=10):
+        self.key, self.workload, self.make, self.steps_cap, self.warm = key, workload, make, steps_cap, warm
+        self._controller, self._prepare = controller, prepare
+
+    def prepare(self, comm, device):
+        return self._prepare(comm, device) if self._prepare else None
+
+    def controller(self, fs):
+        if self._controller:
+            return self._controller(fs)
+        u0 = np.zeros(fs.params_control.actuator_number)
+        return lambda: u0
+
+
+def _make_cylinder(refine):
+    def make(device, shared):
+        return build_solver(device, distributed=True, refine=refine)
+
+    return make
+
+
+def _make_pinball(device, shared):
+    from flowcontrol_amd.actuator import CYLINDER_ACTUATION_MODE
+    from flowcontrol_amd.examples.pinball.pinballflowsolver import PinballFlowSolver
+    from flowcontrol_amd.fem.spaces import Function
+    from flowcontrol_amd.flowsolverparameters import ParamIC
+
+    g = np.load(GOLDEN / "pinball_re100_rotation.npz")
+    fs = PinballFlowSolver.make_default(Re=100, mode_actuation=CYLINDER_ACTUATION_MODE.ROTATION, path_out=tempfile.mkdtemp(prefix="fc_bench_"), num_steps=0,
+                                        save_every=0)
+    fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
+    fs.th.device(device)
+    U0, P0 = Function(fs.W, g["UP0"]).split()
+    fs._assign_steady_state(U0, P0)
+    fs.initialize_time_stepping(ic=None)
+    return fs
+
+
+def _pinball_controller(fs):
+    """Three sensors → 3-in / 3-out LTI controller → three rotating cylinders (tests/golden/make_config45_fixtures.py's system; its
+    output gain, sized for the first 50 steps, is scaled down so that a long run stays a small-amplitude closed loop)."""
+    sys.path.insert(0, str(GOLDEN))
+    from make_config45_fixtures import PINBALL_K
+
+    from flowcontrol_amd.controller import Controller
+
+    K = Controller(A=PINBALL_K["A"], B=PINBALL_K["B"], C=PINBALL_K["C"] / 2.0e6, D=PINBALL_K["D"])
+    y0, dt = fs.y_meas.copy(), fs.params_time.dt
+    return lambda: np.asarray(K.step(y=(fs.y_meas - y0)[:3], dt=dt)).reshape(-1)
+
+
+def _cavity_fs(device):
+    from flowcontrol_amd.examples.cavity.cavityflowsolver import CavityFlowSolver
+
+    fs = CavityFlowSolver.make_default(Re=7500, path_out=tempfile.mkdtemp(prefix="fc_bench_"), num_steps=0, save_every=0,
+                                       meshpath=GOLDEN / "meshes" / "cavity_fine.npz")
+    fs.th.device(device)
+    return fs
+
+
+def _prepare_cavity(comm, device):
+    """cavity_fine ships no base flow: rank 0 runs a few Picard sweeps on its own GPU (a throughput run, not a converged
+    base flow — every iteration assembled / factorised / solved on the device) and the field is broadcast."""
+    up0 = None
+    if comm.rank == 0:
+        fs = _cavity_fs(device)
+        fs.distributed = False
+        fs.compute_steady_state(method="picard", max_iter=4, tol=1e-7, u_ctrl=[0.0])
+        up0 = fs.fields.UP0.vector().get_local().copy()
+        fs.th.release_device()
+    return comm.bcast(up0, src=0)
+
+
+def _make_cavity(device, shared):
+    from flowcontrol_amd.fem.spaces import Function
+
+    fs = _cavity_fs(device)
+    U0, P0 = Function(fs.W, shared).split()
+    fs._assign_steady_state(U0, P0)
+    fs.initialize_time_stepping(ic=None)
+    return fs
+
+
+def _cavity_controller(fs):
+    from flowcontrol_amd.controller import Controller
+
+    K = Controller(A=[[-100.0]], B=[[1.0]], C=[[0.5]], D=[[0.0]])  # first-order low-pass on the wall-shear sensor
+    y0, dt = fs.y_meas.copy(), fs.params_time.dt
+    return lambda: np.asarray(K.step(y=(fs.y_meas - y0)[:1], dt=dt)).reshape(-1)
+
+
+CASES = {
+    "config4": Case("config4", "cylinder Re=100, mesh O1 red-refined x1, open loop, same protocol as the headline", _make_cylinder(1), steps_cap=300),
+    "config5": Case("config5", "fluidic pinball Re=100, ROTATION, 3 actuators <- 3-in/3-out LTI Controller <- 3 sensors (closed loop)", _make_pinball,
+                    _pinball_controller, steps_cap=300),
+    "config3": Case("config3", "open cavity Re=7500 on cavity_fine, Gaussian FORCE actuator <- low-pass Controller <- wall-shear sensor (closed loop); "
+                    "base flow = 4 device Picard sweeps (throughput run)", _make_cavity, _cavity_controller, _prepare_cavity, steps_cap=100),
+}
+
+
+def run_case(case, comm, device, steps, with_roofline):
+    """One workload on the ranks of ``comm`` (world 1: the single-GPU run): synchronous public loop  y -> controller ->
+    FlowSolver.step, timed between barriers, max over ranks; then an instrumented replay for the per-rank phase split
+    (HIP-event marks inside fc_step) and, single GPU, the factor sweeps' roofline."""
+    from flowcontrol_amd._lib import SLOT_BDF2
+
+    shared = case.prepare(comm, device)
+    fs = case.make(device, shared)
+    fs.comm = comm if comm.world > 1 else None
+    fs.distributed = comm.world > 1
+    ctrl = case.controller(fs)
+    t0 = time.time()
+    fs.step(ctrl())  # assembles and factorises both operators (partitioned: joins the ranks first)
+    setup_s = time.time() - t0
+    for _ in range(case.warm):
+        fs.step(ctrl())
+    steps = max(10, min(steps, case.steps_cap))
+    comm.barrier()
+    t1 = time.perf_counter()
+    worst = 0.0
+    for _ in range(steps):
+        fs.step(ctrl())
+        worst = max(worst, float(fs.solve_info[1]))
+    comm.barrier()
+    elapsed = comm.allreduce_max(time.perf_counter() - t1)
+    dev = fs.th.device()
+    out = {"workload": f"{case.workload}; {fs.th.nc} cells, {fs.th.N} dofs, dt={fs.params_time.dt}", "n_gpus": comm.world, "steps": steps,
+           "steps_per_s": steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "scaling": "strong" if comm.world > 1 else "none",
+           "worst_relative_residual": worst, "y_last": np.asarray(fs.y_meas).tolist(), "setup_s": setup_s,
+           "refactor_ms": {str(k): float(v) for k, v in dev.refactor_ms.items()}}
+    # per-rank phase split (instrumented replay: event marks at the phase boundaries of every step)
+    n_rep = max(5, min(steps, 50))
+    dev.set_phase_timing(True)
+    for _ in range(n_rep):
+        fs.step(ctrl())
+    ph = dev.get_phase_timing()
+    dev.set_phase_timing(False)
+    names = list(dev.PHASES)
+    rows = comm.gather_rows(np.array([ph[k] for k in names]))
+    out["phase_us"] = {"phases": names, "per_rank": [[round(float(v), 2) for v in r] for r in rows],
+                       "note": "mean microseconds per step and rank from HIP-event marks inside fc_step (instrumented replay of "
+                               f"{n_rep} steps; exchange phases include the wait for the slowest rank)"}
+    if comm.world > 1:
+        part = dev.part
+        info = comm.gather_rows(np.array([part.local_cells.size, dev.local_factor_nnz, dev._n_factor_values, dev.partition_info()["matrix_cells"]], dtype=float))
+        ci = dev.comm_info()
+        out["partition"] = {"root_dofs": int(part.ar_n), "exchanges_per_step": 3, "exchange_transport": ci["transport"],
+                            "rccl_ranks": ci["nranks"] if ci["transport"] == "rccl" else None,
+                            "local_cells": [int(v) for v in info[:, 0]], "local_factor_nnz": [int(v) for v in info[:, 1]],
+                            "stored_factor_nnz": [int(v) for v in info[:, 2]], "matrix_cells": [int(v) for v in info[:, 3]]}
+    elif with_roofline:
+        dev.set_timing(True)
+        for _ in range(n_rep):
+            fs.step(ctrl())
+        tim = dev.get_timing()
+        dev.set_timing(False)
+        sweep_bytes, _ = dev.algorithmic_bytes(SLOT_BDF2)
+        apply_ms = tim["sweep_ms"] / n_rep
+        out["roofline"] = {"bound": "hbm", "kernel": "fc_nd_sweep + fc_nd_down_block (factor sweeps)", "achieved": sweep_bytes / apply_ms / 1e6, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": sweep_bytes / apply_ms / 1e6 / HBM_PEAK_GBS, "traffic": None, "bytes_per_apply": sweep_bytes,
+                           "apply_us": 1e3 * apply_ms, "launches_per_apply": tim["sweep_launches"] / n_rep, "factor_values": int(dev._n_factor_values),
+                           "note": ("factors exceed the 256 MiB Infinity Cache: HBM streaming" if sweep_bytes > 256 * 2**20 else "factors fit the 256 MiB Infinity Cache")}
+        out["tail_us"] = out["phase_us"]["per_rank"][0][names.index("tail")]
+    fs.th.release_device()
+    return out
+
+
+def headline(comm, device, args):
+    """The driver's contract: W untimed warm-up steps, EXACTLY K timed steps between barrier + synchronize, max over ranks."""
     import torch
-    import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
-    same_dev = os.environ.get("FC_BENCH_SAME_DEVICE", "0") == "1"  # rehearsal on a 1-GPU box: all ranks on GPU 0, gloo
-    if same_dev:
-        local = 0
-    torch.cuda.set_device(local)
-    if world > 1:
-        if same_dev:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        comm.barrier()
         torch.cuda.synchronize()
 
-    partitioned = world > 1 and not args.replicas
+    partitioned = comm.world > 1 and not args.replicas
     t_setup = time.time()
     u0 = np.zeros(2)
     # a failure of the partitioned path is a failure of the run: no silent fall-back to replicas
-    fs = build_solver(local, distributed=partitioned)
-    fs.step(u0)  # BDF1 step: assembles, factorises (partitioned: creates the RCCL communicator); setup, untimed
-    log(f"[rank {rank}] setup {time.time() - t_setup:.1f}s; N={fs.th.N}; partitioned={partitioned}")
+    fs = build_solver(device, distributed=partitioned)
+    fs.comm = comm if partitioned else None
+    fs.step(u0)  # BDF1 step: assembles, factorises (partitioned: creates the RCCL communicator, runs its pre-flight); setup, untimed
+    log(f"[rank {comm.rank}] setup {time.time() - t_setup:.1f}s; N={fs.th.N}; partitioned={partitioned}")
     for _ in range(max(args.warmup - 1, 0)):
         fs.step(u0)
-
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         fs.step(u0)
     barrier()
-    elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if same_dev else "cuda")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+    elapsed = comm.allreduce_max(time.perf_counter() - t0)
+    return fs, elapsed, partitioned
+
+
+def run_rank(comm, args, device):
+    """Everything one rank does; rank 0 returns the result dictionary."""
+    world, rank = comm.world, comm.rank
+    u0 = np.zeros(2)
+    fs, elapsed, partitioned = headline(comm, device, args)
     y_last = fs.y_meas.copy()
     mesh_nc, mesh_N, resid_last = fs.th.nc, fs.th.N, float(fs.solve_info[1])
 
-    config4 = None
+    part_info, single_rate, headline_phases, strong = None, None, None, {}
     if partitioned:
-        # collective-free extras below run on rank 0 only with a private single-GPU solver
-        comm = fs.th.device().comm_info()
-        part_info = {"local_cells": int(fs.th.device().part.local_cells.size), "root_dofs": int(fs.th.device().part.ar_n),
-                     "local_factor_nnz": int(fs.th.device().local_factor_nnz),  # factor values this rank sweeps per solve
-                     "stored_factor_nnz": int(fs.th.device()._n_factor_values),  # ... and stores: its sub-tree + its rows of the root block
-                     "matrix_cells": int(fs.th.device().partition_info()["matrix_cells"]),  # cells whose element matrices it assembles
+        dev = fs.th.device()
+        ci = dev.comm_info()
+        part_info = {"local_cells": int(dev.part.local_cells.size), "root_dofs": int(dev.part.ar_n),
+                     "local_factor_nnz": int(dev.local_factor_nnz),  # factor values this rank sweeps per solve
+                     "stored_factor_nnz": int(dev._n_factor_values),  # ... and stores: its sub-tree + its rows of the root block
+                     "matrix_cells": int(dev.partition_info()["matrix_cells"]),  # cells whose element matrices it assembles
                      "exchanges_per_step": 3,
                      # read back from the communicator inside the library (ncclCommCount / ncclCommUserRank), not from the environment
-                     "rccl_ranks": comm["nranks"] if comm["transport"] == "rccl" else None, "exchange_transport": comm["transport"]}
-        dist.barrier()
-        if not args.no_config4 and REFINE == 0:
-            # the mesh the row partition is meant for (BASELINE config 4: O1 red-refined once, 222 962 dofs): same protocol,
-            # fewer steps; the headline line stays the O1 figure BASELINE.json's metric names
-            fs.th.release_device()
-            steps4 = max(20, min(args.steps, 300))
-            fs4 = build_solver(local, distributed=True, refine=1)
-            fs4.step(u0)
-            for _ in range(10):
-                fs4.step(u0)
-            barrier()
-            t4 = time.perf_counter()
-            for _ in range(steps4):
-                fs4.step(u0)
-            barrier()
-            e4 = torch.tensor([time.perf_counter() - t4], dtype=torch.float64, device="cpu" if same_dev else "cuda")
-            dist.all_reduce(e4, op=dist.ReduceOp.MAX)
-            dev4 = fs4.th.device()
-            config4 = {"workload": f"cylinder Re=100, mesh O1 red-refined x1 ({fs4.th.nc} cells, {fs4.th.N} dofs), same protocol", "steps": steps4,
-                       "steps_per_s": steps4 / float(e4.item()), "scaling": "strong", "n_gpus": world,
-                       "partition": {"local_cells": int(dev4.part.local_cells.size), "root_dofs": int(dev4.part.ar_n),
-                                     "local_factor_nnz": int(dev4.local_factor_nnz), "stored_factor_nnz": int(dev4._n_factor_values)},
-                       "y_last": fs4.y_meas.tolist(), "residual": float(fs4.solve_info[1])}
-            fs4.th.release_device()
-            dist.barrier()
-            if rank == 0 and not args.no_extras:
-                fs4 = build_solver(local, distributed=False, refine=1)
-                fs4.step(u0)
-                for _ in range(10):
-                    fs4.step(u0)
-                t4 = time.perf_counter()
-                for _ in range(steps4):
-                    fs4.step(u0)
-                config4["single_gpu_steps_per_s"] = steps4 / (time.perf_counter() - t4)
-                fs4.th.release_device()
-            fs = None
-        if rank == 0 and args.no_extras:
-            single_rate = None
-        elif rank == 0:
-            if fs is not None:
-                fs.th.release_device()
-            fs = build_solver(local, distributed=False)
+                     "rccl_ranks": ci["nranks"] if ci["transport"] == "rccl" else None, "exchange_transport": ci["transport"]}
+        n_rep = max(5, min(args.steps, 50))
+        dev.set_phase_timing(True)
+        for _ in range(n_rep):
+            fs.step(u0)
+        ph = dev.get_phase_timing()
+        dev.set_phase_timing(False)
+        rows = comm.gather_rows(np.array([ph[k] for k in dev.PHASES]))
+        headline_phases = {"phases": list(dev.PHASES), "per_rank": [[round(float(v), 2) for v in r] for r in rows]}
+        fs.th.release_device()
+        fs = None
+        comm.barrier()
+        # the meshes the row partition is meant for, same protocol, fewer steps; the headline stays the O1 figure BASELINE.json names
+        for key in ([] if REFINE else [k for k in ("config4", "config5", "config3") if k not in args.skip]):
+            try:
+                leg = run_case(CASES[key], comm, device, args.steps, with_roofline=False)
+            except Exception as err:  # a leg that fails is reported, the run and the other legs go on
+                leg = {"error": repr(err)}
+                log(f"[rank {rank}] strong-scaling leg {key} failed: {err!r}")
+            strong[key] = leg
+            comm.barrier()
+        if rank == 0 and not args.no_extras:
+            # single-GPU rates of the same workloads, measured in this run on rank 0's GPU (the other ranks wait)
+            one = SingleCommProxy()
+            for key, leg in strong.items():
+                if "error" not in leg:
+                    leg["single_gpu_steps_per_s"] = run_case(CASES[key], one, device, args.steps, with_roofline=False)["steps_per_s"]
+            fs = build_solver(device, distributed=False)
             fs.step(u0)
             for _ in range(20):
                 fs.step(u0)
@@ -352,11 +488,10 @@ def main() -> None:
             for _ in range(args.steps):
                 fs.step(u0)
             single_rate = args.steps / (time.perf_counter() - t1)
-    else:
-        part_info, single_rate = None, None
+        comm.barrier()
 
     result = None
-    roofline = phases = spmv = cpu = replicas = None
+    roofline = phases = spmv = cpu = replicas = other = None
     t_batched = None
     depth_str = None
     if rank == 0 and not args.no_extras:
@@ -379,17 +514,19 @@ def main() -> None:
         mean_launch_ms = tim["sweep_ms"] / max(tim["sweep_launches"], 1)
         bytes_per_launch = sweep_bytes / n_stage
         achieved = bytes_per_launch / mean_launch_ms / 1e6  # GB/s
-        traffic = None
+        traffic, traffic_commit = None, None
         tfile = ROOT / "profiles" / "traffic.json"  # PMC passes of the DEFAULT workload (scripts/profile_gpu.sh)
         if tfile.exists() and REFINE == 0 and not partitioned:
             try:
-                traffic = json.loads(tfile.read_text()).get("fc_nd_sweep_bytes_per_launch")
+                tj = json.loads(tfile.read_text())
+                traffic, traffic_commit = tj.get("fc_nd_sweep_bytes_per_launch"), tj.get("commit")
             except Exception:
                 traffic = None
         roofline = {
             "bound": "hbm", "kernel": "fc_nd_sweep + fc_nd_down_block (factor sweeps)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_source": "profiles/traffic.json (builder's rocprofv3 --pmc passes of this workload, NOT measured in this run)" if traffic else None,
+            "traffic_source": (f"profiles/traffic.json (builder's rocprofv3 --pmc passes of this workload at commit {traffic_commit}, NOT measured in this run)"
+                               if traffic else None),
             "bytes_per_launch": bytes_per_launch, "launches_per_step": tim["sweep_launches"] / args.steps,
             "mean_launch_us": mean_launch_ms * 1e3, "factor_nnz": dev.factor_nnz.get(SLOT_BDF2),
             "applies_per_step": applies / args.steps,
@@ -401,18 +538,31 @@ def main() -> None:
                      if sweep_bytes < 256e6 else
                      f"factors ({sweep_bytes / 1e6:.0f} MB) exceed the 256 MiB Infinity Cache: HBM streaming"),
         }
-        replicas = None
         if not partitioned and dev.world == 1 and not args.no_replicas:
-            replicas = batched_replicas(fs, steps=min(args.steps, 400), single_rate=(1 if partitioned else 1) * args.steps / elapsed)
+            replicas = batched_replicas(fs, steps=min(args.steps, 400), single_rate=args.steps / elapsed)
         phases, nl = dev.profile_steps(SLOT_BDF2, 50, u0)
         spmv = spmv_probe(fs, include_large=not args.no_large_spmv)
-        cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(fs)
             cpu.pop("_y_last"), cpu.pop("_dE_last")
         depth_str = f"ND selected-inverse depth {dev.depth}, {fs.refine_steps} refinement"
+        fs.th.release_device()
+        if world == 1 and not args.no_other_configs and REFINE == 0:
+            # BASELINE configs 3 / 4 / 5 on this GPU, in the driver-timed run: closed-loop steps/s, the factor sweeps' roofline from
+            # their own bytes and HIP-event time, the step's phase split (tail = fc_tail + fc_final), fc_refactor milliseconds
+            other = {}
+            one = SingleCommProxy()
+            for key in ("config4", "config5", "config3"):
+                if key in args.skip:
+                    continue
+                try:
+                    other[key] = run_case(CASES[key], one, device, args.steps, with_roofline=True)
+                except Exception as err:
+                    other[key] = {"error": repr(err)}
+                    log(f"other_configs {key} failed: {err!r}")
     if rank == 0:
         value = (1 if partitioned else world) * args.steps / elapsed
+        c4 = strong.get("config4")
         result = {
             "metric": "timesteps/s (cylinder Re=100, fixed mesh)",
             "value": value,
@@ -436,9 +586,14 @@ def main() -> None:
                     else f"{world} independent replicas (no data-path collective)"),
                 "partition": part_info,
                 "solver": depth_str,
+                "ranks_are": args.ranks_are,
             },
             "batched_steps_per_s": (args.steps / t_batched) if t_batched else None,
-            "strong_scaling_config4": config4,
+            "phase_us": headline_phases,
+            "strong_scaling_config4": c4,
+            "strong_scaling_config5": strong.get("config5"),
+            "strong_scaling_config3": strong.get("config3"),
+            "other_configs": other,
             "replicas_steps_per_s": (world * single_rate) if single_rate else (replicas["per_k"]["8"]["replicas_steps_per_s"] if replicas else None),
             "replicas": replicas,
             "roofline": roofline,
@@ -449,10 +604,79 @@ def main() -> None:
             "solve_rel_residual_pre_refine": resid_last,
             "y_last": y_last.tolist(),
         }
+    comm.barrier()
+    return result
+
+
+def SingleCommProxy():
+    from flowcontrol_amd.comm import SingleComm
+
+    return SingleComm()
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large-spmv", action="store_true")
+    ap.add_argument("--replicas", action="store_true", help="N > 1: independent replicas instead of the partitioned run")
+    ap.add_argument("--no-replicas", action="store_true", help="skip the batched-replicas section (profiling passes of the single-simulation step)")
+    ap.add_argument("--no-extras", action="store_true", help="skip rank 0's single-GPU extras (roofline replay, SpMV probe, batched replicas, CPU baseline)")
+    ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the BASELINE config 3 / 4 / 5 section")
+    ap.add_argument("--skip", default="", help="comma-separated legs to leave out: config3,config4,config5")
+    ap.add_argument("--no-config4", action="store_true", help="N > 1: skip the strong-scaling leg on the BASELINE config-4 mesh (same as --skip config4)")
+    ap.add_argument("--refine", type=int, default=0, help="red-refine the O1 mesh K times (BASELINE config 4: K=1); not the headline workload")
+    args = ap.parse_args()
+    args.skip = {k for k in args.skip.split(",") if k} | ({"config4"} if args.no_config4 else set())
+    global REFINE
+    REFINE = args.refine
+
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    thread_ranks = int(os.environ.get("FC_BENCH_THREAD_RANKS", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if thread_ranks > 1:
+        # rehearsal of an N-GPU run on ONE GPU: the ranks are threads of this process, every rank its own handle on GPU 0, the
+        # exchanges staged through the host (a box admits only a few processes on its card, so eight process ranks cannot share it)
+        from flowcontrol_amd.comm import run_threaded
+
+        if world > 1:
+            raise SystemExit("FC_BENCH_THREAD_RANKS is a single-process rehearsal: do not combine it with torchrun")
+        torch.cuda.set_device(0)
+        args.ranks_are = f"{thread_ranks} threads of one process sharing GPU 0, exchanges through the host (rehearsal, NOT a multi-GPU measurement)"
+        result = run_threaded(thread_ranks, run_rank, args, 0, timeout=1800.0)[0]
+        print(json.dumps(result), flush=True)
+        return
+    import torch.distributed as dist
+
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}")
+    same_dev = os.environ.get("FC_BENCH_SAME_DEVICE", "0") == "1"  # rehearsal on a 1-GPU box: all ranks on GPU 0, gloo
+    if same_dev:
+        local = 0
+    torch.cuda.set_device(local)
     if world > 1:
-        dist.barrier()
+        from flowcontrol_amd.comm import TorchComm
+
+        if same_dev:
+            dist.init_process_group(backend="gloo")
+            args.ranks_are = f"{world} processes sharing GPU 0, exchanges through the host over gloo (rehearsal, NOT a multi-GPU measurement)"
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+            args.ranks_are = "one process per GPU, RCCL"
+        comm = TorchComm(local if not same_dev else None)
+    else:
+        comm = SingleCommProxy()
+        args.ranks_are = "one process, one GPU"
+    result = run_rank(comm, args, local)
+    if world > 1:
         dist.destroy_process_group()
-    if rank == 0:
+    if comm.rank == 0:
         print(json.dumps(result), flush=True)
 
 

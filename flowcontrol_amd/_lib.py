@@ -1,4 +1,5 @@
-"""ctypes binding of ``libfc_hip.so`` (C ABI in ``include/fc_hip.h``) and its in-tree build.
+"""ctypes binding of ``libfc_hip.so`` (C ABI in ``include/fc_hip.h``; array-level / bench / debug hooks in
+``include/fc_hip_internal.h``) and its in-tree build.
 
 The product path has no CPU fallback: if the library is missing or no MI355X is visible,
 :class:`FcError` is raised — nothing silently degrades to numpy.
@@ -17,7 +18,8 @@ import numpy as np
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = Path(os.environ["FC_LIB_PATH"]) if os.environ.get("FC_LIB_PATH") else CSRC / "libfc_hip.so"  # FC_LIB_PATH: tuning builds
-SOURCES = [CSRC / "fc_hip.hip", *sorted(CSRC.glob("*.hip.h")), *sorted(CSRC.glob("*.hpp")), CSRC.parent.parent / "include" / "fc_hip.h"]
+SOURCES = [CSRC / "fc_hip.hip", *sorted(CSRC.glob("*.hip.h")), *sorted(CSRC.glob("*.hpp")), CSRC.parent.parent / "include" / "fc_hip.h",
+           CSRC.parent.parent / "include" / "fc_hip_internal.h"]
 
 FC_OK = 0
 FC_ERR_INVALID, FC_ERR_HIP, FC_ERR_DIVERGED, FC_ERR_NOT_CONVERGED, FC_ERR_NOT_READY = -1, -2, -3, -4, -5
@@ -59,7 +61,7 @@ _ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _lp = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 _H = C.c_void_p
 
-#: name → argtypes; every entry point of include/fc_hip.h (restype is int unless noted)
+#: name → argtypes; every entry point of include/fc_hip.h and include/fc_hip_internal.h (restype is int unless noted)
 SIGNATURES: dict[str, list] = {
     "fc_device_count": [C.POINTER(C.c_int)],
     "fc_create": [C.POINTER(_H), C.c_int, C.c_int32, C.c_int32, C.c_int32, _dp, _ip, _ip],
@@ -110,6 +112,9 @@ SIGNATURES: dict[str, list] = {
     "fc_comm_init": [_H, C.c_int, C.c_int, C.c_char_p],
     "fc_comm_info": [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "fc_set_host_exchange": [_H, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
+    "fc_comm_selftest": [_H, C.POINTER(C.c_double)],
+    "fc_set_phase_timing": [_H, C.c_int],
+    "fc_get_phase_timing": [_H, _dp, C.POINTER(C.c_int64)],
     "fc_set_timing": [_H, C.c_int],
     "fc_get_timing": [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "fc_algorithmic_bytes": [_H, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)],

@@ -5,7 +5,7 @@
 // nested-dissection selected-inverse factors) and all work vectors.  All work is enqueued on one
 // HIP stream per handle; the only host synchronisation in the per-step path is the final copy of
 // (y, dE, info) to pinned memory.
-#include "../../include/fc_hip.h"
+#include "../../include/fc_hip_internal.h"
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -140,6 +140,8 @@ struct OrderSys {
 };
 
 constexpr int kPinDoubles = 4096;
+constexpr int FC_N_PHASES = 9;  // fc_get_phase_timing
+enum { PH_RHS = 0, PH_UP, PH_X1, PH_ROOT, PH_X2, PH_DOWN, PH_TAIL, PH_X3, PH_PUBLISH };
 #ifndef FC_DOWN_DEPTH
 #define FC_DOWN_DEPTH 2  // down-sweep rows: lanes ~ mean segment length / this
 #define FC_RESIDENT_BYTES 0.0  // ... except the first stages up to this many bytes (experiment: kept in the Infinity Cache)
@@ -296,6 +298,13 @@ struct fc_ctx {
   DevBuf<int64_t> pshift_slot;  // fc_set_front_shifts: added to the fronts after the scatter
   DevBuf<double> pshift_val;
   int pn_shift = 0;
+  // per-phase timing of fc_step (fc_set_phase_timing): event marks at the phase boundaries, folded after the step's synchronisation
+  bool phase_timing = false;
+  std::vector<hipEvent_t> pev;   // pool
+  std::vector<int> pid;          // phase that ENDS at mark i (-1: start of a step)
+  size_t pused = 0;
+  double ph_us[FC_N_PHASES] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t ph_steps = 0;
   std::vector<int> tkind;        // 0 sweep, 1 spmv (per recorded pair)
   std::vector<int> tcount;       // kernel launches bracketed by the pair
   size_t tused = 0;
@@ -473,6 +482,34 @@ int time_collect(fc_ctx* h) {
   h->tused = 0;
   h->tkind.clear();
   h->tcount.clear();
+  return FC_OK;
+}
+
+// phase marks of fc_step (fc_set_phase_timing): `phase` is the phase that ends here, -1 opens a step
+int phase_mark(fc_ctx* h, int phase) {
+  if (!h->phase_timing) return FC_OK;
+  if (h->pused >= h->pev.size()) {
+    for (int i = 0; i < 32; ++i) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreate(&e));
+      h->pev.push_back(e);
+    }
+  }
+  HIPCHK(hipEventRecord(h->pev[h->pused], h->stream));
+  if (h->pid.size() <= h->pused) h->pid.resize(h->pused + 1);
+  h->pid[h->pused++] = phase;
+  return FC_OK;
+}
+int phase_collect(fc_ctx* h) {
+  if (!h->phase_timing) return FC_OK;
+  for (size_t i = 1; i < h->pused; ++i) {
+    if (h->pid[i] < 0) continue;
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->pev[i - 1], h->pev[i]));
+    h->ph_us[h->pid[i]] += 1e3 * ms;
+  }
+  for (size_t i = 0; i < h->pused; ++i) h->ph_steps += h->pid[i] < 0 ? 1 : 0;
+  h->pused = 0;
   return FC_OK;
 }
 
@@ -705,10 +742,20 @@ int apply_factors(fc_ctx* h, OrderSys& S, int first = 0, int last = -1) {
     if (st.nrows > 0) FCCHK(launch_sweep(h, S, st));
     // multi-GPU: (1) the root separator's right-hand side is the sum of every rank's element and sub-tree
     // contributions; (2) the root solution is assembled from the ranks' row blocks — the two exchange steps of a solve
-    if (ex && (int)i == S.ar_stage) FCCHK(exchange(h, h->buf.p + S.ar_row0, (size_t)S.ar_n));
-    if (ex && (int)i == S.ar2_stage) FCCHK(exchange(h, h->buf.p + h->N + S.ar_row0, (size_t)S.ar_n));
+    if (ex && (int)i == S.ar_stage) {
+      FCCHK(phase_mark(h, PH_UP));
+      FCCHK(exchange(h, h->buf.p + S.ar_row0, (size_t)S.ar_n));
+      FCCHK(phase_mark(h, PH_X1));
+    }
+    if (ex && (int)i == S.ar2_stage) {
+      FCCHK(phase_mark(h, PH_ROOT));
+      FCCHK(exchange(h, h->buf.p + h->N + S.ar_row0, (size_t)S.ar_n));
+      FCCHK(phase_mark(h, PH_X2));
+    }
+    if (!ex && st.kind == 1 && i > 0 && S.stages[i - 1].kind == 0) FCCHK(phase_mark(h, PH_UP));  // single GPU: up-sweeps | root + down-sweeps
   }
   FCCHK(time_end(h));
+  FCCHK(phase_mark(h, PH_DOWN));
   return FC_OK;
 }
 
@@ -962,10 +1009,11 @@ int launch_tail(fc_ctx* h, OrderSys& S, int compute_energy, double* d_y, double*
 #undef FC_TAIL_ARGS
   const double* e_part = g_cells > 0 ? h->partial.p + 2 * (size_t)g : nullptr;
   if (fused) {
-    // nothing more to launch
+    FCCHK(phase_mark(h, PH_TAIL));
   } else if (!part) {
     hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, g, e_part, d_E, res ? g : 0, res ? h->partial.p : nullptr, d_r,
                        h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p, h->up.p, d_y, h->flag.p, d_flag_out, d_seq, seq, h->dag_err.p, step_id);
+    FCCHK(phase_mark(h, PH_TAIL));
   } else {
     // partitioned: this rank's share (owned rows, its cells, its part of every sensor row) goes to the 80-double
     // tail record, ONE all-reduce sums the ranks' records, the result is published (fc_final rewrites every
@@ -973,8 +1021,11 @@ int launch_tail(fc_ctx* h, OrderSys& S, int compute_energy, double* d_y, double*
     hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, g, e_part, h->tail.p + 64, res ? g : 0,
                        res ? h->partial.p : nullptr, h->tail.p + 65, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p, h->up.p,
                        h->tail.p, h->flag.p, h->tail.p + 72, (double*)nullptr, 0.0, h->dag_err.p, step_id);
+    FCCHK(phase_mark(h, PH_TAIL));
     FCCHK(exchange(h, h->tail.p, 80));  // the third exchange of a step: 80 doubles
+    FCCHK(phase_mark(h, PH_X3));
     hipLaunchKernelGGL(fc_publish_tail, dim3(1), dim3(64), 0, h->stream, h->tail.p, d_y, h->n_sens, d_E, d_r, d_flag_out, d_seq, seq);
+    FCCHK(phase_mark(h, PH_PUBLISH));
   }
   HIPCHK(hipGetLastError());
   return FC_OK;
@@ -1302,7 +1353,9 @@ int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, 
   if (S.truncated && h->method == FC_METHOD_REFINE)
     return fail(FC_ERR_INVALID, "truncated factors are a preconditioner: set FC_METHOD_GMRES or FC_METHOD_BICGSTAB");
   if (compute_energy && !h->partitioned && !h->have_mp) return fail(FC_ERR_NOT_READY, "fc_set_energy_matrix not called");
+  FCCHK(phase_mark(h, -1));
   FCCHK(enqueue_rhs(h, order_slot, d_uctrl, d_uforce));
+  FCCHK(phase_mark(h, PH_RHS));
   const double *x = nullptr, *dx = nullptr;
   int nrp = 0;
   KrylovOverride inexact_factors(h, S);
@@ -1353,10 +1406,14 @@ int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, 
     hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, ne, ne > 0 ? e_partial : nullptr,
                        h->tail.p + 64, nrp, nrp > 0 ? h->partial.p : nullptr, h->tail.p + 65, h->n_sens, h->s_rowptr.p,
                        h->s_idx.p, h->s_w.p, h->up.p, h->tail.p, h->flag.p, h->tail.p + 72, (double*)nullptr, 0.0, h->dag_err.p, step_id);
+    FCCHK(phase_mark(h, PH_TAIL));
     FCCHK(exchange(h, h->tail.p, 80));
+    FCCHK(phase_mark(h, PH_X3));
     hipLaunchKernelGGL(fc_publish_tail, dim3(1), dim3(64), 0, h->stream, h->tail.p, d_y, h->n_sens, d_E, d_r, d_flag_out,
                        d_seq, seq);
+    FCCHK(phase_mark(h, PH_PUBLISH));
   }
+  if (!h->partitioned) FCCHK(phase_mark(h, PH_TAIL));
   HIPCHK(hipGetLastError());
   return FC_OK;
 }
@@ -1585,6 +1642,7 @@ int fc_destroy(fc_handle h) {
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   for (hipEvent_t e : h->tev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->pev) (void)hipEventDestroy(e);
   hipStream_t s = h->stream;
   delete h;
   if (s) (void)hipStreamDestroy(s);
@@ -3388,7 +3446,7 @@ void speculate_next_rhs(fc_ctx* h, int order_slot) {
   }();
   h->pre_slot = -1;
   const int ncl = h->partitioned ? h->ncl : h->nc;
-  if (!enabled || ncl <= 0) return;
+  if (!enabled || ncl <= 0 || h->phase_timing) return;  // (phase timing: the element loop is charged to the step it belongs to)
   const int next = h->sys[order_slot].have_c ? order_slot : FC_SLOT_BDF2;
   if (!h->sys[next].ready || !h->sys[next].have_lift) return;
   const StepCoeffs c = coeffs_for(h, next);
@@ -3463,7 +3521,7 @@ int fc_step_end(fc_handle h, double* y_out, double* dE_out, double* info_out) {
       return x == bits(pin[138]) && w == bits(pin[139]);
     };
     bool seen = false;
-    if (!h->timing) {
+    if (!h->timing && !h->phase_timing) {
       for (long spin = 0; spin < 20000000L; ++spin) {
         if (record_ok()) {
           seen = true;
@@ -3475,6 +3533,7 @@ int fc_step_end(fc_handle h, double* y_out, double* dE_out, double* info_out) {
     if (!seen) {
       HIPCHK(hipStreamSynchronize(h->stream));
       FCCHK(time_collect(h));
+      FCCHK(phase_collect(h));
       if (!record_ok()) return fail(FC_ERR_HIP, "fc_step: the step record failed its checksum after stream synchronisation");
     }
     if (pin[136] >= 1024.0) {
@@ -3785,7 +3844,10 @@ int fc_bench_sweeps(fc_handle h, int slot, int reps, double* ms_per_apply, int32
 }
 
 int fc_set_partition(fc_handle h, int32_t n_local_cells, const int32_t* local_cells, const uint8_t* rowkind, int lead) {
-  if (h) h->fvec_ok = false;
+  if (h) {
+    h->fvec_ok = false;
+    h->pre_slot = h->bat.pre_slot = -1;  // a speculated element loop filled ev for the OLD cell list
+  }
   if (!h || n_local_cells < 0 || (n_local_cells > 0 && !local_cells) || !rowkind)
     return fail(FC_ERR_INVALID, "fc_set_partition: bad argument");
   HIPCHK(hipSetDevice(h->device));
@@ -3909,6 +3971,60 @@ int fc_set_host_exchange(fc_handle h, int nranks, int rank, fc_exchange_fn fn, v
   h->nranks = nranks;
   h->rank = rank;
   forget_solver_structure(h);
+  return FC_OK;
+}
+
+int fc_comm_selftest(fc_handle h, double* max_err_out) {
+  if (!h) return fail(FC_ERR_INVALID, "null handle");
+  if (max_err_out) *max_err_out = 0.0;
+  if (!exchanges(h)) return FC_OK;  // a single-GPU handle has nothing to test
+  HIPCHK(hipSetDevice(h->device));
+  constexpr int n = 256;
+  std::vector<double> v(n);
+  for (int i = 0; i < n; ++i) v[i] = (double)(h->rank + 1) * (double)(i + 1);
+  DevBuf<double> d;
+  FCCHK(d.upload(v, h->stream));
+  FCCHK(exchange(h, d.p, (size_t)n));
+  HIPCHK(hipMemcpyAsync(v.data(), d.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  int nr = h->nranks;
+  if (h->comm && g_rccl.CommCount) NCCLCHK(g_rccl.CommCount(h->comm, &nr));
+  if (nr != h->nranks)
+    return fail(FC_ERR_HIP, "fc_comm_selftest: the communicator holds " + std::to_string(nr) + " ranks, the handle was told " + std::to_string(h->nranks));
+  const double tri = 0.5 * (double)nr * (double)(nr + 1);
+  double worst = 0.0;
+  int bad = -1;
+  for (int i = 0; i < n; ++i) {
+    const double e = std::fabs(v[i] - tri * (double)(i + 1));
+    if (!(e <= worst)) {  // (a NaN lands here too)
+      worst = e;
+      if (bad < 0 && !(e == 0.0)) bad = i;
+    }
+  }
+  if (max_err_out) *max_err_out = worst;
+  if (bad >= 0)
+    return fail(FC_ERR_HIP, "fc_comm_selftest: rank " + std::to_string(h->rank) + " of " + std::to_string(nr) + ": all-reduce of a known vector is wrong at entry " +
+                                std::to_string(bad) + " (got " + std::to_string(v[bad]) + ", expected " + std::to_string(tri * (bad + 1)) + ")");
+  return FC_OK;
+}
+
+int fc_set_phase_timing(fc_handle h, int on) {
+  if (!h) return fail(FC_ERR_INVALID, "null handle");
+  if (h->step_pending) return fail(FC_ERR_INVALID, "fc_set_phase_timing: a step is in flight");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->phase_timing = on != 0;
+  h->pused = 0;
+  h->pre_slot = h->phase_timing ? -1 : h->pre_slot;  // a speculated element loop would fall outside the marks
+  for (int p = 0; p < FC_N_PHASES; ++p) h->ph_us[p] = 0.0;
+  h->ph_steps = 0;
+  return FC_OK;
+}
+
+int fc_get_phase_timing(fc_handle h, double* us, int64_t* steps) {
+  if (!h || !us) return fail(FC_ERR_INVALID, "fc_get_phase_timing: null argument");
+  for (int p = 0; p < FC_N_PHASES; ++p) us[p] = h->ph_us[p];
+  if (steps) *steps = h->ph_steps;
   return FC_OK;
 }
 

@@ -125,6 +125,7 @@ class DeviceSolver:
 
             self._xchg_cb = _lib.EXCHANGE_FN(_cb)  # keep the callback object alive as long as the handle
             check(self.lib.fc_set_host_exchange(self._h, world, rank, C.cast(self._xchg_cb, C.c_void_p), None))
+            self.comm_selftest()
             return
         import sys
 
@@ -139,6 +140,16 @@ class DeviceSolver:
             check(self.lib.fc_comm_unique_id(buf))
         uid = broadcast_bytes(buf.raw if rank == 0 else None)
         check(self.lib.fc_comm_init(self._h, world, rank, C.create_string_buffer(uid, 128)))
+        self.comm_selftest()
+
+    def comm_selftest(self) -> float:
+        """Pre-flight of the exchange (``fc_comm_selftest``, every rank): one all-reduce of a known vector through the path
+        the time steps use, checked on this rank; raises :class:`FcError` naming the first wrong entry."""
+        err = C.c_double()
+        code = self.lib.fc_comm_selftest(self._h, C.byref(err))
+        self._raise_exchange_error()
+        check(code)
+        return err.value
 
     def comm_info(self) -> dict:
         """Ranks / rank / transport of the handle's exchange as the library sees it (RCCL: read back from the communicator)."""
@@ -710,6 +721,20 @@ class DeviceSolver:
         ms, nl = C.c_double(), C.c_int32()
         check(self.lib.fc_bench_sweeps(self._h, slot, reps, C.byref(ms), C.byref(nl)))
         return ms.value, nl.value
+
+    PHASES = ("rhs", "up_sweeps", "exchange1", "root", "exchange2", "down_sweeps", "tail", "exchange3", "publish")
+
+    def set_phase_timing(self, on: bool) -> None:
+        """HIP-event marks at the phase boundaries of every ``fc_step`` from now on (an instrumented replay, see fc_hip_internal.h)."""
+        check(self.lib.fc_set_phase_timing(self._h, int(bool(on))))
+
+    def get_phase_timing(self) -> dict:
+        """Mean microseconds per step of every phase since :meth:`set_phase_timing`, keyed by :attr:`PHASES`, plus ``steps``."""
+        us, n = np.zeros(len(self.PHASES)), C.c_int64()
+        check(self.lib.fc_get_phase_timing(self._h, us, C.byref(n)))
+        d = {k: float(v) / max(n.value, 1) for k, v in zip(self.PHASES, us)}
+        d["steps"] = int(n.value)
+        return d
 
     def set_timing(self, on: bool) -> None:
         check(self.lib.fc_set_timing(self._h, int(bool(on))))

@@ -89,6 +89,8 @@ class FlowSolver(ABC):
         self.krylov_method: str = "gmres"
         self.krylov_max_iter: int = 500
         self.krylov_rtol: float = 1e-12
+        #: multi-GPU: who the ranks are (flowcontrol_amd.comm.Comm); None = the torch.distributed process group of this process, if any
+        self.comm = None
         self._setup()
 
     # ── validation (reference :108-165) ──────────────────────────────────────
@@ -496,36 +498,20 @@ class FlowSolver(ABC):
 
     def _join_process_group(self, dev) -> None:
         """One process per GPU: when ``torch.distributed`` is initialised with more than one rank the
-        solver partitions the elimination tree over the ranks (RCCL inside the library)."""
+        solver partitions the elimination tree over the ranks (RCCL inside the library).  ``self.comm`` (a
+        :class:`flowcontrol_amd.comm.Comm`) overrides the detection — e.g. ranks that are threads of one process."""
         if getattr(self, "_joined", False):
             return
         self._joined = True
-        import sys
+        from .comm import default_comm
 
-        if "torch" not in sys.modules:
-            return  # nobody in this process can have initialised torch.distributed: do not pay the import
-        try:
-            import torch.distributed as dist
-        except Exception:  # pragma: no cover
+        comm = self.comm if self.comm is not None else default_comm()
+        if comm is None or comm.world == 1 or not getattr(self, "distributed", True):
             return
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or not getattr(self, "distributed", True):
-            return
-
-        def bcast(b):
-            box = [b]
-            dist.broadcast_object_list(box, src=0)
-            return box[0]
-
-        host_allreduce = None
-        if dist.get_backend() != "nccl":
-            # no RCCL process group (CPU collectives, or several ranks sharing one GPU): the two
-            # exchange steps of a time step are staged through the host; the arithmetic stays on the GPU
-            import torch
-
-            def host_allreduce(a: np.ndarray) -> None:
-                dist.all_reduce(torch.from_numpy(a))
-
-        dev.join(dist.get_rank(), dist.get_world_size(), bcast, host_allreduce)
+        self.comm = comm
+        # no RCCL process group (CPU collectives, or several ranks sharing one GPU): the exchange steps of a time step are
+        # staged through the host; the arithmetic stays on the GPU
+        dev.join(comm.rank, comm.world, comm.bcast, None if comm.in_stream else comm.allreduce)
 
     def _upload_state(self) -> None:
         f = self.fields
@@ -548,6 +534,8 @@ class FlowSolver(ABC):
 
     def _is_writer(self) -> bool:
         """Files (checkpoints, sidecars, CSV) are written by rank 0 only, as the reference does (exporter.py:260,266)."""
+        if self.comm is not None:
+            return self.comm.rank == 0
         from .utils import get_rank
 
         return get_rank() == 0
@@ -557,17 +545,10 @@ class FlowSolver(ABC):
         u_n, u_nn, p_n = dev.get_state()
         if dev.world > 1:
             # every rank holds its own dofs (+ the replicated root): merge by masked sum
-            import torch
-            import torch.distributed as dist
-
             m = dev.owned_mask()
             nn2 = 2 * self.th.nn
             flat = np.concatenate([np.where(m[:nn2], u_n, 0.0), np.where(m[:nn2], u_nn, 0.0), np.where(m[nn2:], p_n, 0.0)])
-            tns = torch.from_numpy(flat)
-            if dist.get_backend() == "nccl":
-                tns = tns.to(torch.device("cuda", dev.device_index))  # the GPU this rank's handle lives on
-            dist.all_reduce(tns)
-            flat = tns.cpu().numpy()
+            self.comm.allreduce(flat)
             u_n, u_nn, p_n = flat[:nn2], flat[nn2 : 2 * nn2], flat[2 * nn2 :]
         st = self.fields._store
         st["u_n"].vector().set_local(u_n)

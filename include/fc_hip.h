@@ -76,9 +76,6 @@ int fc_set_matrix_values(fc_handle h, int slot, const double* vals /* [nnz] */);
 
 /* y = A_slot x on the device (original numbering); parity hook + SpMV roofline probe */
 int fc_spmv(fc_handle h, int slot, const double* x /* [N] */, double* y /* [N] */);
-/* time `reps` back-to-back launches of the CSR SpMV kernel with HIP events on the handle's
- * stream; returns the mean milliseconds per launch */
-int fc_bench_spmv(fc_handle h, int slot, int reps, double* ms_per_launch);
 
 /* ── Dirichlet data: replaces the DirichletBC list handed to SystemAssembler
  *    (flowsolver.py:693; case files' _make_bcs).  Every actuator expression is linear in u_ctrl
@@ -99,27 +96,6 @@ int fc_set_time_scheme(fc_handle h, double dt, int nonlinear);
  * diagonal. */
 int fc_apply_bc(fc_handle h, int slot);
 
-/* ── solver setup: replaces LUSolver.set_operator(A) + the factorisation MUMPS performs at the
- *    first solve (flowsolver.py:697,729).  The host side (flowcontrol_amd/ndsolver.py) supplies
- *    the nested-dissection permutation and the level-wise selected-inverse factors. ---------- */
-int fc_set_permutation(fc_handle h, const int32_t* perm /* [N] new -> old */);
-int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32_t* Ap_col,
-                    const double* Ap_val, /* permuted system matrix (N rows) */
-                    int32_t n_stages, const int64_t* stage_begin /* [n_stages] first row in seg_ptr */,
-                    const int32_t* stage_row0 /* [n_stages] first destination row */,
-                    const int32_t* stage_nrows /* [n_stages] */,
-                    const int32_t* stage_kind /* [n_stages] 0 = up (y += ..), 1 = down (x = ..), 2 = diagonal (x = dscale y) */,
-                    const int64_t* seg_ptr /* [total_rows + 1] */, int64_t n_seg,
-                    const int64_t* seg_val /* [n_seg] offset into vals */,
-                    const int32_t* seg_col /* [n_seg] >=0: first buffer index; <0: -(offset into idx)-1 */,
-                    const int32_t* seg_len /* [n_seg] */, int64_t n_idx, const int32_t* idx,
-                    int64_t n_val, const double* vals,
-                    /* multi-GPU: after stage `ar_stage` (-1: none) the rows [ar_row0, ar_row0+ar_n) of the
-                     * work buffer are summed over the ranks (RCCL all-reduce) */
-                    int32_t ar_stage, int32_t ar_row0, int32_t ar_n,
-                    /* and the rows x[ar_row0 .. +ar_n) after stage `ar2_stage` (-1: none): the root's down stage, in which
-                     * every rank fills its own block of the root's rows (the others are zeroed before the launch) */
-                    int32_t ar2_stage);
 /* COMPRESSED factors, the memory-lean Krylov mode (reference plug-in point flowsolver.py:812-814; north_star: "HIP
  * BiCGStab/GMRES ... preconditioning"): the selected inverse is computed in fp64 front by front as always, but its values are
  * STORED rounded to fp32 (bits = 32: 50 % of the memory) or bfloat16 (bits = 16: 25 %) — the fp64 array never exists — and
@@ -128,19 +104,6 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
  * factors through a GMRES probe (<= 40 iterations); fc_solve / fc_step need FC_METHOD_GMRES or FC_METHOD_BICGSTAB. */
 int fc_set_factor_precision(fc_handle h, int bits /* 64 (default, exact), 32, 16 */);
 int fc_get_factor_storage(fc_handle h, int slot, int32_t* bits, int64_t* bytes /* bytes of factor values held for the slot */);
-/* Truncated factors (memory-lean preconditioner): stages of kind 2 stand for tree levels whose pivot blocks are NOT
- * stored; on their rows x = dscale * y (dscale [N], permuted numbering: a diagonal stand-in for the Schur complement).
- * Such a slot is a preconditioner only: fc_solve / fc_step need FC_METHOD_GMRES or FC_METHOD_BICGSTAB. */
-int fc_set_stage_diag(fc_handle h, int slot, const double* dscale /* [N] */);
-/* optional: hand the down-sweep stages to the LDS-tiled block kernel.  Every block is up to 32
- * consecutive rows of ONE tree node, whose rows all read the same operand
- * [ y[i0..i0+ni) | x[idx[idx_off..+nb)] ] and whose values lie row-major (stride ni+nb) at blk_val.
- * stage_* arrays have one entry per stage of fc_solver_setup (count 0 = keep the segment kernel). */
-int fc_solver_set_blocks(fc_handle h, int slot, int32_t n_stages, const int64_t* stage_blk_begin,
-                         const int32_t* stage_blk_count, const int32_t* stage_lpr, int64_t n_blk,
-                         const int64_t* blk_val, const int32_t* blk_row0, const int32_t* blk_nrows,
-                         const int32_t* blk_i0, const int32_t* blk_ni, const int32_t* blk_idx,
-                         const int32_t* blk_nb, int64_t n_idx, int64_t n_val);
 /* THE solver setup in one call (what LUSolver.set_operator + the first solve cost the reference, flowsolver.py:697,729):
  * symbolic analysis inside the library from the mesh the handle holds (element-based nested-dissection tree of
  * `depth` bisections — 0: leaves of ~12 cells — fused `merge` at a time; on a handle with a communicator / host exchange
@@ -148,19 +111,11 @@ int fc_solver_set_blocks(fc_handle h, int slot, int32_t n_stages, const int64_t*
  * tiles, factorisation plan, task dependencies, then the numeric factorisation of the slot's current matrix on the
  * device and the acceptance solve of fc_accept_factors (below).  truncate = d > 0: only the tree levels >= d
  * are factorised (memory-lean preconditioner; use FC_METHOD_GMRES / FC_METHOD_BICGSTAB afterwards).  A later call for the
- * same slot redoes only the numeric phase.  Needs: fc_set_bc, fc_assemble_matrix(slot), fc_apply_bc(slot).  The
- * array-level entry points below (fc_set_permutation ... fc_solver_set_dag) remain for tests and for callers that bring
- * their own analysis (flowcontrol_amd/ndsolver.py is the readable specification of the in-library one). */
+ * same slot redoes only the numeric phase.  Needs: fc_set_bc, fc_assemble_matrix(slot), fc_apply_bc(slot).  (The
+ * array-level entry points a caller with an analysis of its own would use -- fc_set_permutation, fc_solver_setup,
+ * fc_factor_plan ... -- are declared in fc_hip_internal.h with the bench / debug hooks; the boundary is this file.) */
 int fc_setup_solver(fc_handle h, int slot, int32_t depth, int32_t merge, int32_t truncate, int32_t refine, int32_t check_residual);
 int fc_get_permutation(fc_handle h, int32_t* perm /* [N] new -> old */);
-/* the symbolic phase on its own, no device involved: every table fc_setup_solver derives, by name, widened to int64
- * (tests compare them with flowcontrol_amd/ndsolver.py entry by entry) */
-int fc_sym_build(int32_t nv, int32_t ne, int32_t nc, const double* coords, const int32_t* cells, const int32_t* cell_edges,
-                 int32_t n_bc, const int32_t* bc_dofs, int32_t depth, int32_t merge, int32_t world, int32_t rank, int32_t truncate,
-                 void** out);
-int fc_sym_size(void* sym, const char* name, int64_t* n);
-int fc_sym_get(void* sym, const char* name, int64_t* out);
-int fc_sym_free(void* sym);
 /* info[10]: factor values stored on this rank, of the whole tree, swept by this rank per solve; stages; tree depth;
  * exchanged rows, the two exchange stages; cells assembled by this rank; truncate */
 int fc_get_solver_info(fc_handle h, int slot, int64_t* info /* [10] */);
@@ -177,57 +132,13 @@ int fc_get_partition_info(fc_handle h, int32_t* out);
 /* (On a partitioned handle fc_get_matrix_values returns this rank's view -- complete rows for the dofs it owns and the root's, partial
  * rows elsewhere -- and fc_spmv is a collective: every rank calls it with the same x and receives the whole product.) */
 int fc_get_rowkind(fc_handle h, uint8_t* rowkind /* [N]: 0 other rank, 1 owned, 2 root (all 1 on a single-GPU handle) */);
-/* One-launch factor apply (replaces the 2*depth+1 level launches of LUSolver.solve, flowsolver.py:729, by ONE
- * grid whose workgroups wait for each other through per-node arrival counters; fc_dag.hip.h).  `nodes` has 7
- * int64 per tree node that owns dofs, elimination order: level, index in level, first row i0, rows ni, boundary
- * size nb, offset of its [D^-1 | -U] rows in the factor values, offset of its index list.  mine[g] (NULL = all):
- * the node is swept by this rank.  dn_dep[g]: nearest ancestor that owns dofs (-1: none); up_dep_idx[up_dep_ptr[g]
- * .. up_dep_ptr[g+1]): nearest owners below g, one per branch.  Must follow fc_solver_setup for the slot.
- * Every wait inside the launch is bounded; after a give-up the step is redone with the level launches and the
- * handle stays on them (fc_get_dag_info reports it).  FC_DAG=0 / fc_set_dag(h, 0): level launches throughout.
- * OPTIONAL PART: the kernel is compiled only with hipcc -DFC_WITH_DAG (it is slower than the level launches on
- * every mesh measured).  A default build keeps these four entry points so that bindings load:
- * fc_solver_set_dag tabulates nothing, fc_set_dag(h, 1) returns FC_ERR_INVALID, FC_DAG in the environment is ignored. */
-int fc_solver_set_dag(fc_handle h, int slot, int32_t n_nodes, const int64_t* nodes /* [n_nodes][7] */,
-                      const uint8_t* mine /* [n_nodes] or NULL */, const int32_t* dn_dep /* [n_nodes] */,
-                      const int32_t* up_dep_ptr /* [n_nodes+1] */, const int32_t* up_dep_idx);
-int fc_get_dag_info(fc_handle h, int slot, int32_t* n_tasks, int32_t* enabled, int32_t* failures);
-int fc_set_dag(fc_handle h, int on);
-/* test aid: behind the n-th factor apply from now (0 = the next one) the give-up word is raised as a workgroup
- * that timed out would raise it, so that the redo path can be exercised; -1 disarms */
-int fc_debug_inject_dag_failure(fc_handle h, int after_n_applies);
-/* diagnostic: one traced factor apply; stamps[task][8] = 100 MHz wall-clock ticks of the task's workgroup at
- * entry / value loads issued / dependencies met / products done / stores drained (rest 0) */
-int fc_debug_trace_apply(fc_handle h, int slot, int32_t n_tasks, int64_t* stamps /* [n_tasks][8] */,
-                         int32_t* task_stage /* [n_tasks] or NULL */, int32_t* task_kind /* [n_tasks] or NULL */);
-/* Numeric factorisation ON THE DEVICE (what `solver.set_operator(A)` costs in the reference,
- * flowsolver.py:697,812-814 -> PETSc/MUMPS numeric phase; also every Newton/Picard iteration of
- * steadystate.py:60-159).  fc_factor_plan uploads the symbolic side once per (tree, pattern): all
- * fronts of the elimination tree live in one row-major buffer; `nodes` has 7 int64 per tree node in
- * elimination order (level, front offset, front order nf, pivot order ni, offset of the node's
- * [D^-1 | -U] rows in the factor values or -1, parent row or -1, child slot), `level_ptr`/`a_ptr` give
- * node and matrix-entry ranges per level (deepest first), (a_src, a_dst) scatter the CSR values of a slot
- * into the fronts, ext_p[ext_off[g] ...] are the positions of child g's update block in its parent's
- * front, ap_src maps the permuted matrix of the residual monitor to CSR value indices.
- * fc_refactor(slot) then recomputes the factor values and the permuted matrix of `slot` from the
- * slot's current CSR values (after fc_assemble_matrix + fc_apply_bc): scatter, per level extend-add of
- * the children's Schur complements, then the in-place elimination of all fronts of the level together by blocked
- * Gauss-Jordan steps of 32 pivot columns (pivot block inverted in LDS with partial pivoting inside the block, panels,
- * trailing update on the fp64 matrix cores, v_mfma_f64_16x16x4_f64: csrc/fc_front.hip.h), exported straight into the
- * layout the sweeps read.  No vendor BLAS / LAPACK is involved.
- * The structure (fc_solver_setup / fc_solver_set_blocks) must have been uploaded before, with any
- * values.  ms_out (optional): device time of the numeric phase.  On a partitioned handle every rank factorises its own
- * sub-tree and the root (plan built with keep=); the root front is summed over the ranks once (exchange). */
-int fc_factor_plan(fc_handle h, int32_t n_nodes, const int64_t* nodes, int32_t n_levels, const int64_t* level_ptr,
-                   int64_t front_size, int64_t n_a, const int64_t* a_src, const int64_t* a_dst,
-                   const int64_t* a_ptr, const int64_t* ext_off, int64_t n_ext, const int32_t* ext_p,
-                   int64_t n_ap, const int64_t* ap_src, int32_t max_slots);
+/* Numeric factorisation ON THE DEVICE of the slot's current matrix values (after fc_assemble_matrix + fc_apply_bc) with the
+ * structure of the first fc_setup_solver: what `solver.set_operator(A)` costs in the reference (flowsolver.py:697,812-814 ->
+ * PETSc/MUMPS numeric phase; every Newton / Picard iteration of steadystate.py:60-159).  Multifrontal, all fronts of a tree
+ * level together, blocked Gauss-Jordan steps with threshold partial pivoting, trailing updates on the fp64 matrix cores
+ * (csrc/fc_front.hip.h); no vendor BLAS / LAPACK.  ms_out (optional): device time.  On a partitioned handle every rank
+ * factorises its own sub-tree; the root front is summed over the ranks once (exchange). */
 int fc_refactor(fc_handle h, int slot, double* ms_out);
-/* Multi-GPU layouts made outside fc_setup_solver: of the ROOT's pivot-block inverse (the last plan node; every rank
- * eliminates the whole root front) this handle stores only the pivot rows [first, first + count) (0-based inside the
- * root's block) -- the rows it applies in the root's down stage -- at the root's value offset, row `first` first.
- * first = -1: all rows (single GPU).  Call before fc_refactor; fc_setup_solver does it itself. */
-int fc_set_root_rows(fc_handle h, int32_t first, int32_t count);
 /* Acceptance solve of a slot's freshly computed factors (fc_setup_solver runs it itself; call it after a bare fc_refactor): a fixed
  * right-hand side, residual against the matrix.  < 1e-10 by the direct apply: exact factors (time-step operators give <= 1e-12).
  * Between 1e-10 and 1e-2 (pivoting confined to the pivot blocks lost digits on an ill-conditioned operator, e.g. a steady Oseen
@@ -239,21 +150,10 @@ int fc_set_root_rows(fc_handle h, int32_t first, int32_t count);
  * partitioned handle.  fc_refactor clears the flag. */
 int fc_accept_factors(fc_handle h, int slot, double* residual_out, int32_t* inexact_out);
 int fc_get_factors_inexact(fc_handle h, int slot, int32_t* inexact /* 1: the slot's factors serve as GMRES preconditioner */);
-/* values added to front entries (offsets into the front buffer of fc_factor_plan) after the matrix has
- * been scattered, in every later fc_refactor: a positive shift on ONE pressure diagonal selects the
- * solution with that pressure = 0 of an enclosed flow's singular system (lid-driven cavity; the reference
- * leaves that system to MUMPS, examples/lidcavity/lidcavityflowsolver.py:57-72).  n = 0 clears. */
-int fc_set_front_shifts(fc_handle h, int32_t n, const int64_t* slots, const double* values);
-/* download the factor values of a slot (n = the n_val given to fc_solver_setup): parity checks */
-int fc_get_factor_values(fc_handle h, int slot, int64_t n, double* out);
 /* optional explicit operator C of the right-hand side, b -= C u_n (rows in the solver's permuted
  * numbering, columns = velocity dofs in W numbering): the explicit half of the linear terms of the
  * Crank-Nicolson form (NSForms._cn, nsforms.py:191-236).  rowptr == NULL removes it. */
 int fc_set_rhs_operator(fc_handle h, int slot, const int32_t* rowptr, const int32_t* col, const double* val);
-/* velocity mass matrix (u,v) in the solver's permuted numbering, CSR with N rows (pressure rows
- * empty): the matrix behind compute_perturbation_energy (flowsolver.py:827-829), used by the
- * fused step tail */
-int fc_set_energy_matrix(fc_handle h, const int32_t* rowptr, const int32_t* col, const double* val);
 /* the slot's matrix changed (fc_assemble_matrix + fc_apply_bc) but its factors are kept as they are: only the
  * permuted copy that SpMV / residuals use is refreshed.  With FC_METHOD_BICGSTAB the old factors then act as
  * preconditioner of the new operator (Picard / Newton iterations of steadystate.py:60-159 between two
@@ -326,11 +226,6 @@ int fc_step_batch(fc_handle h, int order_slot, int32_t k, const double* u_ctrl, 
                   double* dE_out, int compute_energy, double* info_out);
 int fc_step_batch_begin(fc_handle h, int order_slot, int32_t k, const double* u_ctrl, const double* u_force, int compute_energy);
 int fc_step_batch_end(fc_handle h, int32_t k, double* y_out, double* dE_out, double* info_out);
-/* info[8]: k, KB, scratch rows of the up-sweep, block launches and fold launches per apply, factor bytes of one
- * batched apply (they serve KB simulated steps), vector (operand / result / fold) bytes of one batched apply, tasks */
-int fc_get_batch_info(fc_handle h, double* info /* [8] */);
-/* HIP-event timing of `reps` back-to-back batched factor applies; mean milliseconds per apply */
-int fc_bench_batch_apply(fc_handle h, int slot, int reps, double* ms_per_apply);
 /* parity hook: X = A_bc^{-1} B for k right-hand sides through the batched factor apply; b, x: [k][N] */
 int fc_solve_batch(fc_handle h, int slot, int32_t k, const double* b, double* x);
 
@@ -345,16 +240,6 @@ int fc_solve(fc_handle h, int slot, const double* b /* [N] */, double* x /* [N] 
 int fc_energy(fc_handle h, const double* u /* [2 nn] */, double* E);
 int fc_measure(fc_handle h, const double* up /* [N] */, double* y /* [n_sens] */);
 
-/* ── measurement: HIP-event timing of the phases of fc_step on the handle's stream.
- *    phase ids: 0 rhs element loop, 1 rhs gather+BC, 2 factor sweeps (all launches of one
- *    apply), 3 residual SpMV, 4 finish (scatter/shift/sensors/energy).
- *    ms[5] = mean ms per step of each phase over `n_steps` profiled steps; sweep_launches =
- *    number of sweep-kernel launches per step. */
-int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double* u_ctrl,
-                     double* ms /* [5] */, int32_t* sweep_launches);
-/* time `reps` back-to-back factor applies (all sweep launches of one M^-1 application) with HIP
- * events on the handle's stream; mean milliseconds per apply and launches per apply */
-int fc_bench_sweeps(fc_handle h, int slot, int reps, double* ms_per_apply, int32_t* launches_per_apply);
 /* ── multi-GPU (one process per GPU): replaces dolfin's MPI mesh partitioning
  *    (flowsolver.py:236-238) and PETSc/MUMPS' internal MPI.  Each rank holds the whole (small)
  *    discretisation but assembles only its cells and sweeps only its sub-tree of the elimination
@@ -362,8 +247,6 @@ int fc_bench_sweeps(fc_handle h, int slot, int reps, double* ms_per_apply, int32
  *    Exchange steps per step (all-reduces over RCCL/xGMI, or fc_set_host_exchange): the root right-hand side and the
  *    root solution (every rank applies its block of the root's rows) inside the solve, and the 80-double step
  *    tail (sensor partials, energy, residual norms, divergence flag). */
-int fc_set_partition(fc_handle h, int32_t n_local_cells, const int32_t* local_cells,
-                     const uint8_t* rowkind /* [N] */, int lead);
 int fc_comm_unique_id(char* out128 /* ncclUniqueId bytes, made on rank 0 and broadcast by the host */);
 int fc_comm_init(fc_handle h, int nranks, int rank, const char* id128);
 /* Exchange through the host for a partitioned handle that has NO RCCL communicator (several ranks on one GPU,
@@ -376,16 +259,14 @@ int fc_comm_init(fc_handle h, int nranks, int rank, const char* id128);
 int fc_comm_info(fc_handle h, int32_t* nranks, int32_t* rank, int32_t* transport);
 typedef void (*fc_exchange_fn)(double* buf, int64_t n, void* user);
 int fc_set_host_exchange(fc_handle h, int nranks, int rank, fc_exchange_fn fn, void* user);
+/* Pre-flight of the handle's exchange (call on EVERY rank after fc_comm_init / fc_set_host_exchange, before any setup): one
+ * all-reduce of a known vector (entry i of rank r = (r + 1) * (i + 1), 256 doubles) through the very path the time steps use
+ * (in-stream ncclAllReduce, or the host callback), checked entry by entry against nranks (nranks + 1) / 2 * (i + 1).
+ * FC_ERR_HIP with the first wrong entry in fc_last_error() on a mismatch: a communicator that connects the wrong ranks, a
+ * callback that does not sum, a second HIP runtime in the process.  max_err_out (optional): largest deviation seen.
+ * Replaces nothing in the reference (MPI_Init's own checks, src/utils/mpi.py:22-37). */
+int fc_comm_selftest(fc_handle h, double* max_err_out);
 
-/* HIP-event timing inside fc_step / fc_run: when on, the back-to-back factor-sweep launches of
- * every apply are bracketed by ONE event pair on the handle's stream (sweep_ms / sweep_launches =
- * mean launch duration including the inter-launch gap) and every in-step CSR SpMV launch by its own
- * pair; totals are accumulated after the step's synchronisation.  fc_set_timing resets them. */
-int fc_set_timing(fc_handle h, int on);
-int fc_get_timing(fc_handle h, double* sweep_ms, int64_t* sweep_launches, double* spmv_ms,
-                  int64_t* spmv_launches);
-/* algorithmic bytes of one factor apply (sum over sweep launches) and of one CSR SpMV */
-int fc_algorithmic_bytes(fc_handle h, int slot, double* sweep_bytes, double* spmv_bytes);
 
 #ifdef __cplusplus
 }

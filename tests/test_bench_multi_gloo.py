@@ -1,5 +1,5 @@
-"""bench.py's N > 1 code path (argument plumbing, barriers, max-over-ranks timing, part_info, the config-4 strong-scaling leg,
-the JSON line) under two gloo ranks on the CPU, with the device layer replaced by a stand-in: every rank runs the host
+"""bench.py's N > 1 code path (argument plumbing, barriers, max-over-ranks timing, part_info, the strong-scaling legs of configs
+4 / 5 / 3 with their per-rank phase split, the JSON line) under two gloo ranks on the CPU, with the device layer replaced by a stand-in: every rank runs the host
 emulation of its device program (``tests/support/nd_numeric.solve_partitioned_reference``: its own sub-tree, the two root
 exchanges) plus the third, small all-reduce of a step.  No GPU is involved; what an 8-GPU driver run would exercise besides
 is ncclAllReduce itself and the kernels, which the ``-m gpu`` tests cover."""
@@ -59,7 +59,10 @@ class _FakeSolver:
         self.b[dofs] = 0.0
         self.exchanges = 0
         part = self.part
+        phases = ("rhs", "up_sweeps", "exchange1", "root", "exchange2", "down_sweeps", "tail", "exchange3", "publish")
         dev = SimpleNamespace(part=part, local_factor_nnz=int(part.seg_len.sum()), _n_factor_values=int(self.fac.vals.size), depth=self.tree.depth,
+                              PHASES=phases, refactor_ms={0: 1.0, 1: 1.0}, set_phase_timing=lambda on: None,
+                              get_phase_timing=lambda: {**{k: 1.0 + self.rank for k in phases}, "steps": 5},
                               comm_info=lambda: {"nranks": self.world, "rank": self.rank, "transport": "host" if self.world > 1 else "none"},
                               partition_info=lambda: {"rhs_cells": int(part.local_cells.size), "matrix_cells": int(part.local_cells.size), "lead": self.rank == 0,
                                                       "ranks": self.world})
@@ -67,6 +70,9 @@ class _FakeSolver:
         self.y_meas = np.zeros(2)
         self.solve_info = np.array([0.0, 0.0, 0.0, 0.0])
         self.refine_steps = 0
+        self.comm, self.distributed = None, distributed
+        self.params_control = SimpleNamespace(actuator_number=2)
+        self.params_time = SimpleNamespace(dt=0.005)
 
     def _allreduce(self, a):
         if self.world > 1:
@@ -106,6 +112,9 @@ def _worker(rank, world, port, out):
         return _FakeSolver(12 if refine else 8, distributed)
 
     bench.build_solver = fake_build
+    for key in ("config5", "config3"):  # the pinball and cavity legs: the same stand-in behind the real leg driver (run_case)
+        bench.CASES[key] = bench.Case(key, f"stand-in for {key}", lambda device, shared, key=key: fake_build(device, True, key),
+                                      prepare=(lambda comm, device: comm.bcast("base flow" if comm.rank == 0 else None)) if key == "config3" else None)
     sys.argv = ["bench.py", "--gpus", str(world), "--steps", "3", "--warmup", "2", "--no-extras"]
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
@@ -128,7 +137,16 @@ def test_bench_n2_code_path_under_gloo():
         assert part["exchanges_per_step"] == 3 and part["local_cells"] > 0 and part["root_dofs"] > 0
         assert part["exchange_transport"] == "host" and part["rccl_ranks"] is None  # no RCCL on the CPU: reported as such
         assert part["local_factor_nnz"] < part["stored_factor_nnz"]
-        c4 = res["strong_scaling_config4"]
-        assert c4 is not None and c4["n_gpus"] == world and c4["steps_per_s"] > 0 and c4["residual"] < 1e-10
+        for key in ("strong_scaling_config4", "strong_scaling_config5", "strong_scaling_config3"):
+            leg = res[key]
+            assert leg is not None and "error" not in leg, leg
+            assert leg["n_gpus"] == world and leg["steps_per_s"] > 0 and leg["worst_relative_residual"] < 1e-10 and leg["scaling"] == "strong"
+            ph = leg["phase_us"]
+            assert ph["phases"][:3] == ["rhs", "up_sweeps", "exchange1"] and len(ph["per_rank"]) == world
+            assert ph["per_rank"][0][0] == 1.0 and ph["per_rank"][1][0] == 2.0  # every rank's own figures, gathered
+            lp = leg["partition"]
+            assert lp["exchanges_per_step"] == 3 and len(lp["local_cells"]) == world and lp["exchange_transport"] == "host"
+        assert len(res["phase_us"]["per_rank"]) == world
         assert res["solve_rel_residual_pre_refine"] < 1e-10  # the partitioned emulation really solved the system
-        assert (True, None) in [tuple(b) for b in out["built"]] and (True, 1) in [tuple(b) for b in out["built"]]
+        built = [tuple(b) for b in out["built"]]
+        assert (True, None) in built and (True, 1) in built and (True, "config5") in built and (True, "config3") in built

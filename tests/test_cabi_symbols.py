@@ -1,4 +1,4 @@
-"""The C-ABI library builds for gfx950, loads, and exports every symbol include/fc_hip.h declares
+"""The C-ABI library builds for gfx950, loads, and exports every symbol include/fc_hip.h and include/fc_hip_internal.h declare
 (no compute calls: this runs without a GPU)."""
 import ctypes
 import re
@@ -9,17 +9,28 @@ import pytest
 ROOT = Path(__file__).resolve().parents[1]
 
 
-def _declared_symbols():
-    text = (ROOT / "include" / "fc_hip.h").read_text()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|const char\*)\s+(fc_[a-z0-9_]+)\s*\(", text)))
+def _declared_symbols(headers=("fc_hip.h", "fc_hip_internal.h")):
+    out = set()
+    for name in headers:
+        text = (ROOT / "include" / name).read_text()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        out |= set(re.findall(r"\b(?:int|const char\*)\s+(fc_[a-z0-9_]+)\s*\(", text))
+    return sorted(out)
 
 
 def test_header_declares_the_expected_surface():
-    syms = _declared_symbols()
-    for must in ("fc_create", "fc_destroy", "fc_step", "fc_run", "fc_assemble_matrix", "fc_assemble_rhs", "fc_spmv",
-                 "fc_solver_setup", "fc_set_bc", "fc_set_sensors", "fc_set_force", "fc_solve", "fc_last_error"):
+    """The boundary header holds what a simulation needs; array-level setup, bench and debug hooks live in fc_hip_internal.h."""
+    syms = _declared_symbols(("fc_hip.h",))
+    for must in ("fc_create", "fc_destroy", "fc_step", "fc_run", "fc_assemble_matrix", "fc_assemble_rhs", "fc_spmv", "fc_setup_solver",
+                 "fc_refactor", "fc_set_bc", "fc_set_sensors", "fc_set_force", "fc_solve", "fc_last_error", "fc_step_batch",
+                 "fc_picard_step", "fc_newton_step", "fc_comm_init", "fc_set_host_exchange", "fc_comm_selftest"):
         assert must in syms
+    internal = set(_declared_symbols(("fc_hip_internal.h",)))
+    assert not internal & set(syms), internal & set(syms)
+    for name in syms:
+        assert not name.startswith(("fc_debug_", "fc_bench_", "fc_sym_", "fc_profile_")), name
+    for must in ("fc_solver_setup", "fc_factor_plan", "fc_sym_build", "fc_bench_spmv", "fc_set_timing", "fc_set_phase_timing"):
+        assert must in internal
 
 
 def test_library_builds_and_exports_every_declared_symbol():
@@ -29,7 +40,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert path.exists()
     lib = ctypes.CDLL(str(path))
     missing = [s for s in _declared_symbols() if not hasattr(lib, s)]
-    assert not missing, f"declared in fc_hip.h but not exported: {missing}"
+    assert not missing, f"declared in include/*.h but not exported: {missing}"
 
 
 def test_python_binding_covers_the_header():

@@ -1,0 +1,205 @@
+"""The 8-rank partition — what BASELINE configs 4 and 5 are defined on — exercised on ONE MI355X.
+
+Eight ranks are eight threads of this process (``flowcontrol_amd.comm.ThreadComm``), every rank with its own solver handle
+on GPU 0 and the three exchange steps of a time step staged through the host (``fc_set_host_exchange``).  Launch sequence,
+per-rank cell lists, row ownership, sweep tables, the root's row blocks, restricted sensor rows and element-wise energy are
+those of the 8-GPU RCCL run; only the all-reduce call differs.  (A GPU box admits six processes on its card, so eight
+process ranks cannot share it; 2- and 4-process runs are in test_partitioned_gpu.py / test_configs_gpu.py.)
+
+Per mesh: the merged series against the CPU oracle's fixture at 1e-8, every rank's residual at round-off, and the
+"no replicated work" bookkeeping — the ranks' cells tile the mesh, their swept and stored factor values tile the tree.
+"""
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "tests" / "golden"))
+WORLD = 8
+
+
+def _rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(np.asarray(b))
+
+
+def _ycols(ts):
+    return [c for c in ts.columns if c.startswith("y_meas_")]
+
+
+def _bookkeeping(fs, out):
+    dev = fs.th.device()
+    assert dev.world == WORLD and dev.part is not None and dev.part.ar_n > 0
+    assert dev.comm_info() == {"nranks": WORLD, "rank": fs.comm.rank, "transport": "host"}
+    slot = next(iter(dev.factor_nnz))
+    pi = dev.partition_info()
+    out.update(cells=int(dev.part.local_cells.size), swept=int(dev.local_factor_nnz), stored=int(dev.factor_nnz[slot]),
+               total=int(dev.total_factor_nnz), matrix_cells=pi["matrix_cells"], nc=fs.th.nc, root=int(dev.part.ar_n),
+               resid=float(fs.solve_info[1]))
+
+
+def _check_bookkeeping(outs, nc):
+    cells = [o["cells"] for o in outs]
+    assert sum(cells) == nc and max(cells) - min(cells) <= 1
+    total = outs[0]["total"]
+    assert sum(o["swept"] for o in outs) == total  # no replicated sweep work ...
+    assert sum(o["stored"] for o in outs) == total  # ... and no replicated storage: the ranks tile the tree
+    assert max(o["stored"] for o in outs) < 1.35 * total / WORLD, [o["stored"] * WORLD / total for o in outs]
+    assert all(o["resid"] < 1e-9 for o in outs)
+    assert all(o["matrix_cells"] < 0.5 * nc for o in outs)  # own cells + the cells along the separators, not the mesh
+
+
+def _config4_rank(comm, nsteps):
+    from make_config45_fixtures import config4_actuation
+
+    from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver, refined_cylinder_mesh
+    from flowcontrol_amd.fem.spaces import Function
+    from flowcontrol_amd.flowsolverparameters import ParamIC
+
+    g = np.load(ROOT / "tests" / "golden" / "cylinder_O1_refined1.npz")
+    fs = CylinderFlowSolver.make_default(Re=100, path_out=tempfile.mkdtemp(), num_steps=nsteps, meshpath=refined_cylinder_mesh(1))
+    fs.comm = comm
+    fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
+    U0, P0 = Function(fs.W, g["UP0"]).split()
+    fs._assign_steady_state(U0, P0)
+    fs.initialize_time_stepping(ic=None)
+    u = config4_actuation(nsteps)
+    for k in range(nsteps):
+        fs.step(u[k])
+    ts = fs.timeseries
+    out = {"y": ts[_ycols(ts)].to_numpy(), "dE": ts["dE"].to_numpy(), "u": fs.fields.u_.vector().get_local()}  # the field read is a collective
+    _bookkeeping(fs, out)
+    fs.th.release_device()
+    return out
+
+
+def test_config4_refined_cylinder_on_eight_ranks():
+    from flowcontrol_amd.comm import run_threaded
+
+    nsteps = 12
+    g = np.load(ROOT / "tests" / "golden" / "cylinder_O1_refined1.npz")
+    outs = run_threaded(WORLD, _config4_rank, nsteps)
+    for o in outs:  # every rank holds the merged record
+        assert _rel(o["y"], g["y"][: nsteps + 1]) < 1e-8 and _rel(o["dE"], g["dE"][: nsteps + 1]) < 1e-8
+        assert np.array_equal(o["u"], outs[0]["u"])
+    _check_bookkeeping(outs, 49136)
+
+
+def _pinball_rank(comm, nsteps):
+    from make_config45_fixtures import PINBALL_K
+
+    from flowcontrol_amd.actuator import CYLINDER_ACTUATION_MODE
+    from flowcontrol_amd.controller import Controller
+    from flowcontrol_amd.examples.pinball.pinballflowsolver import PinballFlowSolver
+    from flowcontrol_amd.fem.spaces import Function
+    from flowcontrol_amd.flowsolverparameters import ParamIC
+
+    g = np.load(ROOT / "tests" / "golden" / "pinball_re100_rotation.npz")
+    fs = PinballFlowSolver.make_default(Re=100, mode_actuation=CYLINDER_ACTUATION_MODE.ROTATION, path_out=tempfile.mkdtemp(), num_steps=nsteps)
+    fs.comm = comm
+    fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
+    U0, P0 = Function(fs.W, g["UP0"]).split()
+    fs._assign_steady_state(U0, P0)
+    fs.initialize_time_stepping(ic=None)
+    K = Controller(A=PINBALL_K["A"], B=PINBALL_K["B"], C=PINBALL_K["C"], D=PINBALL_K["D"])  # every rank runs the (host) controller on the merged y
+    us = []
+    for _ in range(nsteps):
+        u = np.asarray(K.step(y=fs.y_meas, dt=fs.params_time.dt)).reshape(-1)
+        us.append(u)
+        fs.step(u_ctrl=u)
+    ts = fs.timeseries
+    out = {"y": ts[_ycols(ts)].to_numpy(), "dE": ts["dE"].to_numpy(), "us": np.array(us)}
+    _bookkeeping(fs, out)
+    fs.th.release_device()
+    return out
+
+
+def test_config5_pinball_closed_loop_on_eight_ranks():
+    """Three rotating cylinders (their Dirichlet rows cut by the partition), three sensors, the 3-in / 3-out controller in
+    the loop: the oracle's closed-loop series."""
+    from flowcontrol_amd.comm import run_threaded
+
+    nsteps = 16
+    g = np.load(ROOT / "tests" / "golden" / "pinball_re100_rotation.npz")
+    outs = run_threaded(WORLD, _pinball_rank, nsteps)
+    for o in outs:
+        assert _rel(o["us"], g["cl_u"][:nsteps]) < 1e-8
+        assert _rel(o["y"], g["cl_y"][: nsteps + 1]) < 1e-8 and _rel(o["dE"], g["cl_dE"][: nsteps + 1]) < 1e-8
+    assert np.abs(outs[0]["us"]).max() > 1e-3  # the loop acts
+    _check_bookkeeping(outs, 66668)
+
+
+def _cavity_rank(comm, nsteps):
+    from make_config3_fixture import CAVITY_K
+
+    from flowcontrol_amd.controller import Controller
+    from flowcontrol_amd.examples.cavity.cavityflowsolver import CavityFlowSolver
+    from flowcontrol_amd.fem.spaces import Function
+
+    g = np.load(ROOT / "tests" / "golden" / "cavity_coarse.npz")
+    fs = CavityFlowSolver.make_default(Re=7500, path_out=tempfile.mkdtemp(), num_steps=nsteps)
+    fs.comm = comm
+    U0, P0 = Function(fs.W, g["UP0"]).split()
+    fs._assign_steady_state(U0, P0)
+    fs.initialize_time_stepping(ic=None)
+    K = Controller(A=CAVITY_K["A"], B=CAVITY_K["B"], C=CAVITY_K["C"], D=CAVITY_K["D"])
+    y0 = fs.y_meas[0]
+    us = []
+    for _ in range(nsteps):
+        u = K.step(y=fs.y_meas[0] - y0, dt=fs.params_time.dt)
+        us.append(float(u[0]))
+        fs.step(u_ctrl=[u[0]])
+    ts = fs.timeseries
+    out = {"y": ts[_ycols(ts)].to_numpy(), "dE": ts["dE"].to_numpy(), "us": np.array(us)}
+    _bookkeeping(fs, out)
+    fs.th.release_device()
+    return out
+
+
+def test_config3_cavity_force_actuator_and_wall_shear_sensor_on_eight_ranks():
+    """cavity_coarse (235 374 dofs), config 3's ingredients over the partition: the Gaussian body force as per-rank load vectors
+    (root rows as partial sums), the wall-shear integral sensor as row pieces on the ranks that own its dofs, low-pass
+    controller in the loop: the oracle's closed-loop series (tests/golden/make_config3_fixture.py cavity_coarse)."""
+    from flowcontrol_amd.comm import run_threaded
+
+    nsteps = 20
+    ref = np.load(ROOT / "tests" / "golden" / "cavity_coarse_re7500.npz")
+    outs = run_threaded(WORLD, _cavity_rank, nsteps)
+    for o in outs:
+        assert _rel(o["us"], ref["u"][:nsteps, 0]) < 1e-8
+        assert _rel(o["y"], ref["y"][: nsteps + 1]) < 1e-8 and _rel(o["dE"], ref["dE"][: nsteps + 1]) < 1e-8
+    assert np.abs(ref["u"]).max() > 0.5
+    _check_bookkeeping(outs, int(ref["ncells"]))
+
+
+def test_exchange_selftest_catches_a_wrong_all_reduce():
+    """fc_comm_selftest (run by DeviceSolver.join on every rank): a callback that does not sum — here rank 1's contribution
+    is dropped — is refused before any setup, with the wrong entry named."""
+    from flowcontrol_amd import _lib
+    from flowcontrol_amd.comm import run_threaded
+    from flowcontrol_amd.device import DeviceSolver
+    from flowcontrol_amd.fem.mesh import Mesh
+    from flowcontrol_amd.fem.spaces import TaylorHood
+
+    def rank_body(comm, broken):
+        dev = DeviceSolver(TaylorHood(Mesh.unit_square(4, 4)), 0)
+
+        def allreduce(a):
+            if broken and comm.rank == 1:
+                a[:] = 0.0
+            comm.allreduce(a)
+
+        try:
+            dev.join(comm.rank, comm.world, comm.bcast, allreduce)
+            return "ok"
+        except _lib.FcError as err:
+            return str(err)
+        finally:
+            dev.close()
+
+    assert run_threaded(2, rank_body, False) == ["ok", "ok"]
+    msgs = run_threaded(2, rank_body, True)
+    assert all("fc_comm_selftest" in m and "entry 0" in m for m in msgs), msgs
