@@ -977,7 +977,8 @@ int launch_tail(fc_ctx* h, OrderSys& S, int compute_energy, double* d_y, double*
   const bool res = h->check_residual != 0;
   const bool part = h->partitioned;
   const int ncl = part ? h->ncl : h->nc;
-  const int reps = std::max(1, nblocks(h->N, 32 * 2048));  // <= ~2048 + ~500 partials per array for fc_final
+  static const int reps_env = [] { const char* e = std::getenv("FC_TAIL_REPS"); return e ? std::max(1, std::atoi(e)) : 0; }();  // tuning aid
+  const int reps = reps_env ? reps_env : std::max(1, nblocks(h->N, 32 * 2048));  // <= ~2048 + ~500 partials per array for fc_final
   const int g_rows = res ? nblocks(h->N, 32 * reps) : 0, g_cells = (compute_energy && ncl > 0) ? nblocks(ncl, 32 * reps) : 0;
   const int g_shift = nblocks(h->N, 256 * FC_TAIL_SHIFT);
   const int g = g_rows + g_shift + g_cells;
