@@ -48,6 +48,7 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+from flowcontrol_amd.examples.data import mesh_file  # noqa: E402
 GOLDEN = ROOT / "tests" / "golden"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -172,8 +173,8 @@ def spmv_probe(fs, include_large: bool) -> dict:
         from flowcontrol_amd.fem.mesh import read_xdmf_mesh
         from flowcontrol_amd.fem.spaces import TaylorHood
 
-        cases = [("O1_refined1_bdf2", refined_cylinder_mesh(1), 300.0, 0.01), ("cavity_coarse_bdf2", GOLDEN / "meshes" / "cavity_coarse.npz", 3750.0, 1.0 / 7500.0),
-                 ("pinball_bdf2", GOLDEN / "meshes" / "mesh_middle_gmsh.npz", 300.0, 0.01), ("cavity_fine_bdf2", GOLDEN / "meshes" / "cavity_fine.npz", 3750.0, 1.0 / 7500.0)]
+        cases = [("O1_refined1_bdf2", refined_cylinder_mesh(1), 300.0, 0.01), ("cavity_coarse_bdf2", mesh_file("cavity_coarse"), 3750.0, 1.0 / 7500.0),
+                 ("pinball_bdf2", mesh_file("mesh_middle_gmsh"), 300.0, 0.01), ("cavity_fine_bdf2", mesh_file("cavity_fine"), 3750.0, 1.0 / 7500.0)]
         for key, path, mass, nu in cases:
             th = TaylorHood(read_xdmf_mesh(path))
             big = DeviceSolver(th, dev_index(fs))
@@ -296,7 +297,7 @@ def _cavity_fs(device):
     from flowcontrol_amd.examples.cavity.cavityflowsolver import CavityFlowSolver
 
     fs = CavityFlowSolver.make_default(Re=7500, path_out=tempfile.mkdtemp(prefix="fc_bench_"), num_steps=0, save_every=0,
-                                       meshpath=GOLDEN / "meshes" / "cavity_fine.npz")
+                                       meshpath=mesh_file("cavity_fine"))
     fs.th.device(device)
     return fs
 
@@ -540,7 +541,11 @@ def run_rank(comm, args, device):
         }
         if not partitioned and dev.world == 1 and not args.no_replicas:
             replicas = batched_replicas(fs, steps=min(args.steps, 400), single_rate=args.steps / elapsed)
-        phases, nl = dev.profile_steps(SLOT_BDF2, 50, u0)
+        dev.set_phase_timing(True)  # the step's phase split from HIP-event marks inside fc_step (instrumented replay)
+        for _ in range(200):
+            fs.step(u0)
+        phases = dev.get_phase_timing()
+        dev.set_phase_timing(False)
         spmv = spmv_probe(fs, include_large=not args.no_large_spmv)
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(fs)
@@ -589,7 +594,6 @@ def run_rank(comm, args, device):
                 "ranks_are": args.ranks_are,
             },
             "batched_steps_per_s": (args.steps / t_batched) if t_batched else None,
-            "phase_us": headline_phases,
             "strong_scaling_config4": c4,
             "strong_scaling_config5": strong.get("config5"),
             "strong_scaling_config3": strong.get("config3"),
@@ -597,7 +601,8 @@ def run_rank(comm, args, device):
             "replicas_steps_per_s": (world * single_rate) if single_rate else (replicas["per_k"]["8"]["replicas_steps_per_s"] if replicas else None),
             "replicas": replicas,
             "roofline": roofline,
-            "phase_ms_eager": {k: float(v) for k, v in zip(["rhs_elem", "rhs_gather", "sweeps", "residual_spmv", "finish"], phases)} if phases is not None else None,
+            "phase_us": headline_phases if headline_phases is not None else (
+                {"phases": [k for k in phases if k != "steps"], "per_rank": [[round(v, 2) for k, v in phases.items() if k != "steps"]]} if phases else None),
             "spmv": spmv,
             "cpu_baseline": cpu,
             "speedup_vs_cpu_baseline": (value / cpu["value"]) if cpu else None,

@@ -105,7 +105,6 @@ SIGNATURES: dict[str, list] = {
     "fc_solve": [_H, C.c_int, _dp, _dp, C.c_void_p],
     "fc_energy": [_H, _dp, C.POINTER(C.c_double)],
     "fc_measure": [_H, _dp, C.c_void_p],
-    "fc_profile_steps": [_H, C.c_int, C.c_int32, C.c_void_p, _dp, C.POINTER(C.c_int32)],
     "fc_bench_sweeps": [_H, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int32)],
     "fc_set_partition": [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_int],
     "fc_comm_unique_id": [C.c_char_p],
@@ -118,9 +117,6 @@ SIGNATURES: dict[str, list] = {
     "fc_set_timing": [_H, C.c_int],
     "fc_get_timing": [_H, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "fc_algorithmic_bytes": [_H, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)],
-    "fc_solver_set_dag": [_H, C.c_int, C.c_int32, _lp, np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS"), _ip, _ip, _ip],
-    "fc_get_dag_info": [_H, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
-    "fc_set_dag": [_H, C.c_int],
     "fc_setup_solver": [_H, C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32],
     "fc_get_permutation": [_H, _ip],
     "fc_set_pressure_pin": [_H, C.c_int32, C.c_double],
@@ -134,8 +130,6 @@ SIGNATURES: dict[str, list] = {
     "fc_get_solver_info": [_H, C.c_int, _lp],
     "fc_get_rowkind": [_H, np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")],
     "fc_set_stage_diag": [_H, C.c_int, _dp],
-    "fc_debug_inject_dag_failure": [_H, C.c_int],
-    "fc_debug_trace_apply": [_H, C.c_int, C.c_int32, _lp, _ip, _ip],
     "fc_set_factor_precision": [_H, C.c_int],
     "fc_get_factor_storage": [_H, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64)],
     "fc_set_baseflow_bc": [_H, C.c_int32, C.c_void_p, C.c_void_p],
@@ -148,6 +142,7 @@ SIGNATURES: dict[str, list] = {
     "fc_step_batch": [_H, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
     "fc_step_batch_begin": [_H, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_int],
     "fc_step_batch_end": [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
+    "fc_reset_sim_batch": [_H, C.c_int32],
     "fc_get_batch_info": [_H, _dp],
     "fc_bench_batch_apply": [_H, C.c_int, C.c_int, C.POINTER(C.c_double)],
     "fc_solve_batch": [_H, C.c_int, C.c_int32, _dp, _dp],

@@ -106,9 +106,15 @@ class BatchedFlowSolver:
 
     # ── stepping ─────────────────────────────────────────────────────────────
     def step(self, u_ctrl) -> np.ndarray | None:
-        """Advance all k runs by one Δt; ``u_ctrl``: (k, n_act).  Returns y_meas (k, n_sens).  A run whose velocity
-        became non-finite is reported as ``FlowSolver.step`` reports it — ``RuntimeError`` or, with
-        ``params_solver.throw_error = False``, ``None`` — with ``self.diverged`` marking the runs."""
+        """Advance all k runs by one Δt; ``u_ctrl``: (k, n_act).  Returns y_meas (k, n_sens).
+
+        A run whose velocity becomes non-finite ENDS there, as a single ``FlowSolver`` run does (flowsolver.py:727-737): it is
+        marked in ``self.diverged``, taken out of the batch's dynamics (``fc_reset_sim_batch``) and from then on its rows of
+        ``y_meas`` / its log entries are NaN.  The other runs are not affected — the columns are independent — and keep stepping:
+        with ``params_solver.throw_error = False`` this call returns ``y_meas`` as usual (NaN rows for the diverged runs); with
+        ``throw_error = True`` it raises ``RuntimeError`` once, after the step has been booked, and may be called again for the
+        remaining runs.  Only a linear-solve residual above ``residual_tol`` — broken factors, which all runs share — stops
+        the batch (``None`` / ``RuntimeError``)."""
         fs, k = self.fs, self.k
         t0 = time.time()
         n_act = fs.params_control.actuator_number
@@ -119,16 +125,23 @@ class BatchedFlowSolver:
         if self.order == "cn":
             prev = np.zeros_like(u_ctrl) if self._u_ctrl_prev is None else self._u_ctrl_prev
             u_force = 0.5 * (u_ctrl + prev)
+        newly = np.zeros(k, dtype=bool)
         try:
             y, dE, info = self.dev.step_batch(SLOT_BDF2 if self.order == 2 else SLOT_BDF1, u_ctrl, compute_energy=want_energy, u_force=u_force)
         except FcDiverged:
-            self.diverged = self.dev._batch_bufs[4][:, 3] != 0
-            logger.critical("Solver diverged (Inf detected) in runs %s", np.flatnonzero(self.diverged).tolist())
-            if not fs.params_solver.throw_error:
-                return None
-            raise RuntimeError("Failed solving: Inf found in solution")
+            # the records of all runs were filled before the status came back: the healthy runs' step stands
+            bufs = self.dev._batch_bufs
+            y, dE, info = bufs[2][:, : self.dev.n_sens].copy(), bufs[3].copy(), bufs[4]
+            newly = (info[:, 3] != 0) & ~self.diverged
+            for s in np.flatnonzero(info[:, 3] != 0):
+                self.dev.reset_sim_batch(int(s))  # zero state: the column stops producing non-finite values
+            logger.critical("Solver diverged (Inf detected) in runs %s", np.flatnonzero(newly).tolist())
+            self.diverged |= info[:, 3] != 0
+        if np.any(self.diverged):
+            y = np.where(self.diverged[:, None], np.nan, y)
+            dE = np.where(self.diverged, np.nan, dE)
         self.solve_info = info
-        if np.any(info[:, 1] > self.residual_tol):
+        if np.any(info[~self.diverged, 1] > self.residual_tol):
             msg = f"linear solve residual {info[:, 1].max():.2e} exceeds residual_tol = {self.residual_tol:.1e} at iteration {next_iter}"
             logger.critical(msg)
             if fs.params_solver.throw_error:
@@ -141,6 +154,8 @@ class BatchedFlowSolver:
             self.order = 2
         self.y_meas = y
         self._log.append((self.t, self._u_ctrl_prev, y, dE if want_energy else np.full(k, np.nan), (time.time() - t0) / k))
+        if np.any(newly) and fs.params_solver.throw_error:
+            raise RuntimeError(f"Failed solving: Inf found in solution (runs {np.flatnonzero(newly).tolist()}; the other runs go on)")
         return self.y_meas
 
     # ── results ──────────────────────────────────────────────────────────────

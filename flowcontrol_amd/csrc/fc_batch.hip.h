@@ -196,8 +196,11 @@ __global__ __launch_bounds__(256) void fc_nd_fold_b(int nrows, int row0, const i
 // basis tables; thread (cell, Radon point q = lane8 < 7, s) evaluates the integrand at its point from LDS, and thread
 // (cell, a < 6, s) tests the weighted point values with phi_a in the fixed order q = 0..6.
 // ev[(slot * nc + cell) * KB + s]
+// (un / unn: the batched state in the solver's permuted numbering -- solution halves of the batched work buffers, "state ring";
+//  cnp[a][c] / cnp[6 + a][c] = permuted position of the x- / y-velocity dof of node a of cell c; cn only addresses fprof)
 template <int KB>
-__global__ __launch_bounds__(256) void fc_rhs_elem_b(int nc, int nn, const int* __restrict__ cn, const double* __restrict__ geom,
+__global__ __launch_bounds__(256) void fc_rhs_elem_b(int nc, int nn, const int* __restrict__ cn, const int* __restrict__ cnp,
+                                                     const double* __restrict__ geom,
                                                      const double* __restrict__ un, const double* __restrict__ unn,
                                                      const double* __restrict__ fprof, int n_act, const double* __restrict__ uforce,
                                                      int ustride, double cm_n, double cm_nn, double cc_n, double cc_nn,
@@ -217,17 +220,21 @@ __global__ __launch_bounds__(256) void fc_rhs_elem_b(int nc, int nn, const int* 
     tde[t] = c_dphi2[2 * t + 1];
   }
   {
-    const int n = cn[(lane < 6 ? lane : 0) * nc + c];
+    const int a = lane < 6 ? lane : 0;
+    const int ix = cnp[a * nc + c], iy = cnp[(6 + a) * nc + c];
     double fx = 0.0, fy = 0.0;
-    for (int k = 0; k < n_act; ++k) {
-      const double uk = uforce[s * ustride + k];
-      fx += uk * fprof[(size_t)k * 2 * nn + n];
-      fy += uk * fprof[(size_t)k * 2 * nn + nn + n];
+    if (n_act > 0) {
+      const int n = cn[a * nc + c];
+      for (int k = 0; k < n_act; ++k) {
+        const double uk = uforce[s * ustride + k];
+        fx += uk * fprof[(size_t)k * 2 * nn + n];
+        fy += uk * fprof[(size_t)k * 2 * nn + nn + n];
+      }
     }
-    nod[0][t] = un[(size_t)n * KB + s];
-    nod[1][t] = un[(size_t)(nn + n) * KB + s];
-    nod[2][t] = unn[(size_t)n * KB + s];
-    nod[3][t] = unn[(size_t)(nn + n) * KB + s];
+    nod[0][t] = un[(size_t)ix * KB + s];
+    nod[1][t] = un[(size_t)iy * KB + s];
+    nod[2][t] = unn[(size_t)ix * KB + s];
+    nod[3][t] = unn[(size_t)iy * KB + s];
     nod[4][t] = fx;
     nod[5][t] = fy;
   }
@@ -335,14 +342,15 @@ __global__ __launch_bounds__(256) void fc_rhs_gather_b(int N, const int* __restr
   *reinterpret_cast<d2*>(y + (size_t)i * KB + s) = out;
 }
 
-// fc_tail for KB simulations (residual monitor r = b - A x of every simulation, scatter to the W layout, state shift,
-// non-finite flags, energy).  The matrix rows in nested-dissection order come in runs that touch the same few solution
+// fc_tail for KB simulations: residual monitor r = b - A x of every simulation, non-finite flags, energy.  The new state needs
+// no work -- the solution half of the batched work buffer IS the new state (permuted numbering, rotating buffers: fc_hip.hip
+// "state ring"); rounds up to 3 scattered it to W-layout arrays and shifted three time levels here, 20 of the kernel's 50 us at
+// KB = 16.  The matrix rows in nested-dissection order come in runs that touch the same few solution
 // rows (a tree node's rows couple to the node and its boundary), so a ROW BLOCK — up to 16 consecutive permuted rows with
 // at most FC_TB_COLS distinct columns, tabulated once per pattern — brings its distinct solution rows [col][KB] to LDS
 // once (coalesced KB-wide rows, instead of one 8 KB-byte gather per matrix entry and simulation pair) and evaluates the
 // 16 rows from there: 16 lanes per row = (j: 16 / HP) x (simulation pair: HP = KB / 2), each lane walks every
 // (16 / HP)-th entry of its row with the entry's LOCAL column (uint16) and reads two simulations (16 B) from LDS.
-// The scatter / shift then uses thread = (row, simulation): all lanes busy.
 // partial[(s * 3 + w) * G + block], w = 0: sum r^2, 1: sum b^2 (row blocks), 2: sum e (cell blocks)  (fixed order: reproducible).
 #define FC_TB_ROWS 16
 #define FC_TB_COLS 128
@@ -357,20 +365,19 @@ struct __attribute__((aligned(16))) FcTBlock {
 // chain of dependent gathers overlaps with the row blocks' streaming; as a launch of their own they cost its ~5 us floor).
 // partial[(s * 3 + 2) * G + first + block]
 template <int KB>
-__device__ __forceinline__ void fc_energy_b_block(int cb, int nn2, int nc, const int* __restrict__ cn, const double* __restrict__ geom,
-                                                  const int* __restrict__ iperm, const double* __restrict__ x, double* __restrict__ partial,
+__device__ __forceinline__ void fc_energy_b_block(int cb, int nc, const int* __restrict__ cnp, const double* __restrict__ geom,
+                                                  const double* __restrict__ x, double* __restrict__ partial,
                                                   int G, int first, double (&red)[2][256]) {
   constexpr int CPB = 256 / (8 * KB);  // cells per workgroup
   const int t = threadIdx.x;
   const int s = t % KB, lane = (t / KB) % 8, cw = t / (8 * KB);
-  const int nn = nn2 >> 1;
   double e = 0.0;
   const int c = cb * CPB + cw;
   const int cc = c < nc ? c : 0;
   {
-    const int n = cn[(size_t)(lane < 6 ? lane : 0) * nc + cc];
-    red[0][t] = x[(size_t)iperm[n] * KB + s];
-    red[1][t] = x[(size_t)iperm[nn + n] * KB + s];
+    const int a = lane < 6 ? lane : 0;
+    red[0][t] = x[(size_t)cnp[(size_t)a * nc + cc] * KB + s];
+    red[1][t] = x[(size_t)cnp[(size_t)(6 + a) * nc + cc] * KB + s];
   }
   __syncthreads();
   if (c < nc && lane < FC_NQ) {
@@ -396,21 +403,19 @@ __device__ __forceinline__ void fc_energy_b_block(int cb, int nn2, int nc, const
 }
 
 template <int KB>
-__global__ __launch_bounds__(256) void fc_tail_b(int N, int nn2, const int* __restrict__ perm, const double* __restrict__ x,
+__global__ __launch_bounds__(256) void fc_tail_b(int N, const unsigned char* __restrict__ velrow, const double* __restrict__ x,
                                                  const double* __restrict__ b, const FcTBlock* __restrict__ blocks,
                                                  const int* __restrict__ bcols, const int* __restrict__ a_rowptr,
                                                  const unsigned short* __restrict__ a_lidx, const double* __restrict__ a_val,
-                                                 double* __restrict__ up, double* __restrict__ u_n, double* __restrict__ u_nn,
-                                                 double* __restrict__ p_n, int* __restrict__ flag, double* __restrict__ partial, int G,
-                                                 int n_cell_blocks, int nc, const int* __restrict__ cn, const double* __restrict__ geom,
-                                                 const int* __restrict__ iperm) {
+                                                 int* __restrict__ flag, double* __restrict__ partial, int G,
+                                                 int n_cell_blocks, int nc, const int* __restrict__ cnp, const double* __restrict__ geom) {
   constexpr int HP = KB / 2;   // simulation pairs
   constexpr int JL = 16 / HP;  // lanes of a row that split its entries
   const int t = threadIdx.x;
   __shared__ double xs[FC_TB_COLS * KB];
   __shared__ double red[2][256];
   if ((int)blockIdx.x < n_cell_blocks) {
-    fc_energy_b_block<KB>((int)blockIdx.x, nn2, nc, cn, geom, iperm, x, partial, G, G - n_cell_blocks, red);
+    fc_energy_b_block<KB>((int)blockIdx.x, nc, cnp, geom, x, partial, G, G - n_cell_blocks, red);
     return;
   }
   const int rbk = (int)blockIdx.x - n_cell_blocks;  // row block of this workgroup
@@ -476,19 +481,11 @@ __global__ __launch_bounds__(256) void fc_tail_b(int N, int nn2, const int* __re
     for (int e = t; e < bk.nrows * KB; e += 256) {  // one trip for KB = 16, fewer threads for smaller KB
       const int r_l = e / KB, s = e % KB;
       const int ii = bk.row0 + r_l;
-      const int r = perm[ii];
       const double v = x[(size_t)ii * KB + s], bb = b[(size_t)ii * KB + s];
       const double res = bb - xs[r_l * KB + s];
       r2 += res * res;
       b2 += bb * bb;
-      up[(size_t)r * KB + s] = v;
-      if (r < nn2) {
-        u_nn[(size_t)r * KB + s] = u_n[(size_t)r * KB + s];
-        u_n[(size_t)r * KB + s] = v;
-        if (!isfinite(v)) atomicOr(flag + s, 1);
-      } else {
-        p_n[(size_t)(r - nn2) * KB + s] = v;
-      }
+      if (velrow[ii] && !isfinite(v)) atomicOr(flag + s, 1);  // (reference flowsolver.py:731,816-819: the velocity is tested)
     }
     // threads e = r_l * KB + s: simulation = t % KB for every trip (256 is a multiple of KB)
     red[0][t] = r2;
@@ -507,13 +504,15 @@ __global__ __launch_bounds__(256) void fc_tail_b(int N, int nn2, const int* __re
   }
 }
 
-// fc_final for simulation s = blockIdx.x: folds its partials, evaluates the sensor rows on its column of `up`,
-// publishes its record (fc_publish: checksummed, the host polls it)
+// fc_final for simulation s = blockIdx.x: folds its partials, evaluates the sensor rows on its column of the new solution x
+// (permuted numbering; s_idxp = the sensor dofs' permuted positions), publishes its record (fc_publish: checksummed, the host
+// polls it) and clears its non-finite flag for the next step (the flags are per step: one diverged run does not mark the later
+// steps of the batch)
 template <int KB>
 __global__ __launch_bounds__(1024) void fc_final_b(int G, int n_row_blocks, const double* __restrict__ partial, int n_sens,
                                                    const int* __restrict__ s_rowptr, const int* __restrict__ s_idx,
                                                    const double* __restrict__ s_w, const double* __restrict__ up,
-                                                   const int* __restrict__ flag, double* __restrict__ rec, int rstride,
+                                                   int* __restrict__ flag, double* __restrict__ rec, int rstride,
                                                    const double* __restrict__ seq_in, int compute_energy) {
   // one workgroup of 1024 threads per simulation: the kernel is a chain of dependent round trips over 3 G partial sums, so
   // what counts is how few trips there are (sixteen waves, eight loads per array and trip: 8 192 partials per trip)
@@ -567,18 +566,30 @@ __global__ __launch_bounds__(1024) void fc_final_b(int G, int n_row_blocks, cons
       r2 += red[2][w];
     }
     double* r = rec + (size_t)s * rstride;
-    fc_publish(ysh, n_sens, compute_energy ? 0.5 * r2 : 0.0, r0, r1, (double)(flag[s] & 1), r + 64, r + 128, r + 129, r + 136, r + 137, seq_in[0]);
+    const int fl = flag[s] & 1;
+    flag[s] = 0;
+    fc_publish(ysh, n_sens, compute_energy ? 0.5 * r2 : 0.0, r0, r1, (double)fl, r + 64, r + 128, r + 129, r + 136, r + 137, seq_in[0]);
   }
 }
 
-// host <-> device layout change of a state block: dev[i * KB + s] <-> host[s * n + i]
+// host <-> device layout change of a state block: dev[i * KB + s] <-> host[s * n + p(i)], p = perm (device rows are in the
+// solver's permuted numbering, host vectors in the W layout) or the identity (perm == nullptr)
 template <int KB>
-__global__ void fc_b_interleave(int n, int k, const double* __restrict__ src, double* __restrict__ dst, int to_device) {
+__global__ void fc_b_interleave(int n, int k, const double* __restrict__ src, double* __restrict__ dst, int to_device,
+                                const int* __restrict__ perm) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = t / KB, s = t % KB;
   if (i >= n) return;
+  const int j = perm ? perm[i] : i;
   if (to_device)
-    dst[(size_t)i * KB + s] = s < k ? src[(size_t)s * n + i] : 0.0;
+    dst[(size_t)i * KB + s] = s < k ? src[(size_t)s * n + j] : 0.0;
   else if (s < k)
-    dst[(size_t)s * n + i] = src[(size_t)i * KB + s];
+    dst[(size_t)s * n + j] = src[(size_t)i * KB + s];
+}
+
+// one simulation's column of a [rows][KB] block <- 0 (fc_reset_sim_batch: a diverged run is taken out of the batch)
+template <int KB>
+__global__ void fc_b_zero_column(int n, int s, double* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[(size_t)i * KB + s] = 0.0;
 }

@@ -22,7 +22,6 @@
 #include <vector>
 
 #include "fc_kernels.hip.h"
-#include "fc_dag.hip.h"
 #include "fc_front.hip.h"
 #include "fc_batch.hip.h"
 #include "fc_symbolic.hpp"
@@ -90,7 +89,6 @@ struct Stage {
   double bytes;  // algorithmic bytes of this launch
   int64_t wg_begin = -1;  // offset of this launch's workgroup order (OrderSys::wg_order), -1: launch order = row order
   bool nt = false;  // its values are streamed with nontemporal loads (OrderSys::nt, minus the stages kept cache-resident)
-  int dag_task0 = 0, dag_ntasks = 0;  // one-launch apply (fc_nd_dag): this stage's tasks
 };
 
 struct OrderSys {
@@ -119,20 +117,6 @@ struct OrderSys {
   double sweep_bytes = 0.0;
   int ar_stage = -1, ar_row0 = 0, ar_n = 0;  // all-reduce buf[ar_row0 .. +ar_n) after this stage
   int ar2_stage = -1;  // the root's down stage (this rank's block of rows): x[ar_row0 .. +ar_n) is zeroed before, summed after
-  // one-launch apply (fc_solver_set_dag): tasks in topological order, dependency records, arrival counters
-  bool dag_ready = false;
-  DevBuf<FcDagTask> dag_tasks;
-  DevBuf<FcDagDep> dag_deps;
-  DevBuf<unsigned> dag_cnt;
-  unsigned dag_epoch = 0;
-  // up-sweep rows of the one-launch apply: the -L values re-laid out row by row with explicit columns
-  // (dag_up_src: where each value sits in f_val; refreshed after every numeric factorisation)
-  DevBuf<int64_t> dag_up_src;
-  DevBuf<int> dag_up_col;
-  DevBuf<double> dag_up_val;
-  int64_t dag_up_n = 0;
-  std::vector<int64_t> h_seg_ptr, h_seg_val;  // host copies of the segment lists (fc_solver_set_dag expands them)
-  std::vector<int> h_seg_col, h_seg_len;
   // optional explicit operator of the rhs (Crank-Nicolson): rows permuted, columns index u_n (W layout)
   DevBuf<int> c_rowptr, c_col;
   DevBuf<double> c_val;
@@ -176,6 +160,7 @@ struct fc_ctx {
   double refactor_ms[2] = {0.0, 0.0};  // device time of the last fc_refactor per slot
   bool step_pending = false;  // fc_step_begin without its fc_step_end
   int pend_slot = 0, pend_energy = 0;
+  bool pend_checked = true;
   double pend_seq = 0.0;
   int factor_bits = 64;       // fc_set_factor_precision: storage width of the factor values laid out from now on (64 exact, 32 / 16 compressed)
   int pin_dof = -1;           // fc_set_pressure_pin: pressure dof whose diagonal is shifted inside the factorisation
@@ -198,7 +183,7 @@ struct fc_ctx {
   DevBuf<double> fvec;   // [n_act][N] permuted: assembled load vector of every body-force profile (build_force_vectors)
   bool fvec_ok = false;  // ... valid for the present profiles, permutation, Dirichlet rows and partition
   DevBuf<int> s_rowptr, s_idx;
-  DevBuf<int> s_idxp;        // sensor dofs as positions in the sweep buffer's x half (N + permuted index): fused final of fc_tail
+  DevBuf<int> s_idxp;        // sensor dofs as positions in the permuted solution (what fc_final reads: the state ring holds no W-layout copy)
   bool have_sidxp = false;
   DevBuf<unsigned> fin_cnt;  // arrival counters of the fused final (self-resetting)
   DevBuf<double> s_w;
@@ -223,12 +208,27 @@ struct fc_ctx {
   int last_krylov_iters = 0;
   double rtol = 1e-10;
   // state + work
-  DevBuf<double> u_n, u_nn, p_n, up;
+  // THE STATE RING: four work buffers [y | x] of 2 N doubles in the solver's permuted numbering.  A solve writes its solution into the
+  // x half of the buffer it works in; for a time step that half IS the new (v, p): the step then just moves `cur` on, nothing is
+  // copied, scattered or shifted.  Slot cur: (u_n, p_n); cur - 1: u_nn; cur - 2: what fc_undo_step restores; cur + 1 (= h->buf): the
+  // work buffer of the next solve.  Host-facing vectors (fc_set_state / fc_get_state / fc_get_solution) are in the W layout and are
+  // permuted on the way in and out.
+  DevBuf<double> ring;
+  int cur = 0;
+  bool state_live = false;                     // the ring holds a state (fc_set_state with a permutation, or a step)
+  std::vector<double> hs_n, hs_nn;             // W-layout state handed over before any permutation existed (N doubles each: [u | p])
+  DevBuf<int> cnp;                             // [12][nc] permuted position of the x- / y-velocity dof of every cell node
+  DevBuf<unsigned char> velrow_p;              // 1 on the velocity rows (permuted numbering): the non-finite test
   DevBuf<int> asm_cells;  // multi-GPU: cells whose element matrices this rank assembles (own + touching a root dof)
   int n_asm = 0;
-  DevBuf<double> u_old, p_old;  // what the last step's shift overwrote (u_nn, p_n before it): fc_undo_step
   bool undo_ok = false;
-  DevBuf<double> b, buf, xsol, tmpN, tmpN2;  // buf = [y | x] (2N)
+  uint64_t step_count = 0;   // steps enqueued on this handle (the residual monitor's cadence counts them)
+  bool last_checked = true;  // the last enqueued step formed its residual
+  struct BufView {
+    double* p = nullptr;
+    size_t n = 0;
+  } buf;  // = ring slot cur + 1: [y | x] (2N)
+  DevBuf<double> b, xsol, tmpN, tmpN2;
   DevBuf<double> partial, scal;               // reductions; scal: [0]=E [1]=r2 [2]=b2
   DevBuf<double> uctrl, ydev, yseq, Eseq, useq;
   DevBuf<int> flag;
@@ -260,12 +260,6 @@ struct fc_ctx {
   // element vectors of the NEXT step's right-hand side, enqueued behind a synchronous step while the host
   // is busy (they depend on the state only): slot whose coefficients they were computed with, or -1
   int pre_slot = -1;
-  // one-launch factor apply: [0] != 0 when a workgroup of fc_nd_dag gave up waiting, [1] = id of the first step that saw it
-  DevBuf<int> dag_err;
-  bool dag_enabled = false;  // FC_DAG=1 / fc_set_dag turn the one-launch apply on; a give-up turns it off again
-  int dag_failures = 0;
-  int dag_inject = -1;
-  DevBuf<fc_u64> dag_trace;  // fc_debug_trace_apply: 8 stamps per task of the traced apply  // test aid (fc_debug_inject_dag_failure): raise the give-up word behind the n-th apply from now
   // device-side numeric factorisation (fc_factor_plan / fc_refactor)
   struct PlanNode {
     int64_t front, voff;
@@ -323,7 +317,13 @@ struct fc_ctx {
   struct Batch {
     int k = 0, KB = 0;
     bool tables = false;
-    DevBuf<double> u_n, u_nn, p_n, up, b, buf, ev, partial;  // buf = [y (N) | x (N) | scratch] rows of KB
+    // the batched state ring: four work buffers [y (N) | x (N) | scratch | zero row] of KB columns, permuted numbering; the x half a
+    // batched step writes IS the new state of all KB simulations (slot cur: (u_n, p_n); cur - 1: u_nn; cur + 1 = buf: the next solve)
+    DevBuf<double> ring;
+    int cur = 0;
+    size_t slot_doubles = 0;
+    fc_ctx::BufView buf;
+    DevBuf<double> b, ev, partial;
     DevBuf<int> flag;                                        // [KB] non-finite velocity seen, per simulation
     DevBuf<FcBTask> tasks;
     DevBuf<int> fptr, fsrc;       // up-sweep fold lists: permuted row -> scratch rows (absolute buffer rows) of its descendants
@@ -344,8 +344,9 @@ struct fc_ctx {
     // the launches of one batched step as a HIP graph per (order slot, energy flag): captured on first use, replayed as long as
     // no buffer or parameter that a kernel argument was taken from has changed (gsig: hash of all of them)
     // (third index: 1 = the graph starts with the element loop, 0 = the previous step's graph already ran it -- pre_slot)
-    hipGraphExec_t gexec[2][2][2] = {{{nullptr, nullptr}, {nullptr, nullptr}}, {{nullptr, nullptr}, {nullptr, nullptr}}};
-    uint64_t gsig[2][2][2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}};
+    // (first index: the ring phase `cur` the step starts from -- the buffers a step reads and writes rotate with period four)
+    hipGraphExec_t gexec[4][2][2][2] = {};
+    uint64_t gsig[4][2][2][2] = {};
     int pre_slot = -1;  // order slot whose element vectors (ev) the LAST launch of the previous step left behind, -1: none
   } bat;
 };
@@ -674,61 +675,43 @@ int exchange(fc_ctx* h, double* dptr, size_t n) {
 }
 bool exchanges(const fc_ctx* h) { return h->comm != nullptr || h->host_xchg != nullptr; }
 
-// one-launch apply: the tasks of stages [first, last] as ONE grid whose workgroups wait on per-node
-// counters (fc_dag.hip.h); with an RCCL communicator the grid is cut at the exchange stage
-int apply_factors_dag(fc_ctx* h, OrderSys& S, int first, int last) {
-  if (first == 0) ++S.dag_epoch;
-  const bool ex = exchanges(h) && S.ar_n > 0;
-  int nl = 1;
-  for (int s = first; s < last; ++s) nl += ex && (s == S.ar_stage || s == S.ar2_stage) ? 1 : 0;
-  FCCHK(time_begin(h, 0, nl));
-  auto launch = [&](int s0, int s1) -> int {
-    const int t0 = S.stages[s0].dag_task0, t1 = S.stages[s1].dag_task0 + S.stages[s1].dag_ntasks;
-    // persistent grid: every workgroup must be resident (static task assignment).  FC_DAG_WGS workgroups, kept to
-    // FC_DAG_PER_CU per CU by a dynamic-LDS pad: more resident workgroups only deepen the queue of value loads in
-    // front of the dependency-critical loads (measured on the 56 k-dof cylinder mesh, non-persistent version:
-    // 6 / 4 / 3 / 2 / 1 workgroups per CU -> 101 / 93 / 85 / 108 / 168 us per apply)
-    static const int per_cu = [] { const char* e = std::getenv("FC_DAG_PER_CU"); return e ? std::min(6, std::max(1, std::atoi(e))) : 3; }();
-    static const int wgs_env = [] { const char* e = std::getenv("FC_DAG_WGS"); return e ? std::max(1, std::atoi(e)) : 0; }();
-    int wgs = wgs_env ? wgs_env : per_cu * h->n_cu;
-    if (h->host_xchg) wgs = std::min(wgs, 128);  // ranks sharing one GPU (host exchange): leave room for the other ranks' grids
-    const int lds_pad = std::max(0, (160 * 1024) / per_cu - (int)(FC_DAG_TILE * sizeof(double)) - 1024);
-    const int n = t1 - t0;
-#ifdef FC_WITH_DAG
-    if (n > 0)
-      hipLaunchKernelGGL(fc_nd_dag, dim3(std::min(n, wgs)), dim3(256), lds_pad, h->stream, S.dag_tasks.p + t0, n, S.dag_deps.p, S.dag_cnt.p,
-                         S.dag_epoch, h->dag_err.p, S.dag_up_col.p, S.dag_up_val.p, S.f_idx.p, S.f_val.p, h->buf.p,
-                         h->dag_trace.p ? h->dag_trace.p + (size_t)t0 * 8 : nullptr);
-#else
-    (void)wgs, (void)lds_pad, (void)n;
-    return fail(FC_ERR_INVALID, "the one-launch factor apply is not part of this build (hipcc -DFC_WITH_DAG)");
-#endif
-    HIPCHK(hipGetLastError());
-    return FC_OK;
-  };
-  // the grid is cut behind every exchange stage inside the range
-  int s0 = first;
-  for (int s = first; s <= last; ++s) {
-    const bool cut = ex && (s == S.ar_stage || s == S.ar2_stage);
-    if (!cut && s != last) continue;
-    if (ex && S.ar2_stage >= s0 && S.ar2_stage <= s)
-      HIPCHK(hipMemsetAsync(h->buf.p + h->N + S.ar_row0, 0, (size_t)S.ar_n * sizeof(double), h->stream));  // the other ranks' blocks
-    FCCHK(launch(s0, s));
-    if (cut) FCCHK(exchange(h, h->buf.p + (s == S.ar_stage ? 0 : h->N) + S.ar_row0, (size_t)S.ar_n));
-    s0 = s + 1;
+// the state ring (fc_ctx::ring)
+inline double* ring_slot(const fc_ctx* h, int k) { return h->ring.p + (size_t)(((k % 4) + 4) % 4) * 2 * (size_t)h->N; }
+inline double* st_n(const fc_ctx* h) { return ring_slot(h, h->cur) + h->N; }       // (u_n, p_n), permuted numbering
+inline double* st_nn(const fc_ctx* h) { return ring_slot(h, h->cur + 3) + h->N; }  // u_nn
+inline void ring_point(fc_ctx* h) { h->buf.p = ring_slot(h, h->cur + 1); }
+inline void ring_advance(fc_ctx* h) {  // the solution in h->buf becomes the state
+  h->cur = (h->cur + 1) % 4;
+  ring_point(h);
+}
+// W-layout host vectors [u (2 nn) | p (nv)] <-> ring slots (needs a permutation)
+int state_upload(fc_ctx* h, const double* wn, const double* wnn) {
+  const int N = h->N, g = nblocks(N, 256);
+  const double* src[2] = {wn, wnn};
+  double* dst[2] = {st_n(h), st_nn(h)};
+  for (int k = 0; k < 2; ++k) {
+    HIPCHK(hipMemcpyAsync(h->tmpN.p, src[k], (size_t)N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(fc_gather_perm, dim3(g), dim3(256), 0, h->stream, N, h->perm.p, h->tmpN.p, dst[k]);
+    HIPCHK(hipStreamSynchronize(h->stream));
   }
-  FCCHK(time_end(h));
-  if (h->dag_inject >= 0 && h->dag_inject-- == 0) {
-    // test aid: what a workgroup that gave up waiting leaves behind (the results of this apply are then ignored)
-    static const int one = 1;
-    HIPCHK(hipMemcpyAsync(h->dag_err.p, &one, sizeof(int), hipMemcpyHostToDevice, h->stream));
+  h->state_live = true;
+  return FC_OK;
+}
+int state_download(fc_ctx* h, double* wn, double* wnn) {
+  const int N = h->N, g = nblocks(N, 256);
+  double* dst[2] = {wn, wnn};
+  const double* src[2] = {st_n(h), st_nn(h)};
+  for (int k = 0; k < 2; ++k) {
+    if (!dst[k]) continue;
+    hipLaunchKernelGGL(fc_scatter_perm, dim3(g), dim3(256), 0, h->stream, N, h->perm.p, src[k], (const double*)nullptr, h->tmpN.p);
+    HIPCHK(hipMemcpyAsync(dst[k], h->tmpN.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
   }
   return FC_OK;
 }
 
 int apply_factors(fc_ctx* h, OrderSys& S, int first = 0, int last = -1) {
   if (last < 0) last = (int)S.stages.size() - 1;
-  if (h->dag_enabled && S.dag_ready) return apply_factors_dag(h, S, first, last);
   // timing: ONE event pair around the back-to-back sweep launches of this apply (a pair per launch
   // would serialise the short kernels and read ~2 us high); the launch count is recorded with it
   int nlaunch = 0;
@@ -845,6 +828,18 @@ int refresh_permuted(fc_ctx* h) {
   for (int k = 0; k < h->n_bc; ++k) slot_of[h->h_bc_dofs[k]] = k;
   for (int i = 0; i < N; ++i) bs[i] = slot_of[h->h_perm[i]];
   FCCHK(h->bcslot_p.upload(bs, h->stream));
+  {
+    // the cells' node table and the velocity-row mask in the permuted numbering (the state vectors live there)
+    std::vector<int> ip((size_t)N);
+    for (int i = 0; i < N; ++i) ip[(size_t)h->h_perm[i]] = i;
+    std::vector<int> cp((size_t)12 * h->nc);
+    for (int c = 0; c < h->nc; ++c)
+      for (int k = 0; k < 12; ++k) cp[(size_t)k * h->nc + c] = ip[(size_t)h->h_cell_dofs[(size_t)c * 15 + k]];
+    FCCHK(h->cnp.upload(cp, h->stream));
+    std::vector<unsigned char> vr((size_t)N);
+    for (int i = 0; i < N; ++i) vr[(size_t)i] = h->h_perm[i] < 2 * h->nn ? 1 : 0;
+    FCCHK(h->velrow_p.upload(vr.data(), vr.size(), h->stream));
+  }
   if (h->partitioned) {
     std::vector<unsigned char> rk(N);
     for (int i = 0; i < N; ++i) rk[i] = h->h_rowkind[h->h_perm[i]];
@@ -862,24 +857,6 @@ int refresh_permuted(fc_ctx* h) {
                          S.lift.p + (size_t)k * N, S.lift_p.p + (size_t)k * N);
   }
   HIPCHK(hipStreamSynchronize(h->stream));
-  return FC_OK;
-}
-
-// A workgroup of the one-launch apply gave up waiting (fc_dag.hip.h): the step's tail left the state
-// untouched.  Drain the stream, clear the error word and the arrival counters, and use the level launches
-// for the rest of this handle's life; the caller then redoes the step.
-int dag_recover(fc_ctx* h) {
-  HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipMemsetAsync(h->dag_err.p, 0, 2 * sizeof(int), h->stream));
-  for (int o = 0; o < 2; ++o) {
-    OrderSys& S = h->sys[o];
-    if (S.dag_cnt.n) HIPCHK(hipMemsetAsync(S.dag_cnt.p, 0, S.dag_cnt.n * sizeof(unsigned), h->stream));
-    S.dag_epoch = 0;
-  }
-  HIPCHK(hipStreamSynchronize(h->stream));
-  h->dag_enabled = false;
-  ++h->dag_failures;
-  h->pre_slot = -1;
   return FC_OK;
 }
 
@@ -914,13 +891,14 @@ int build_force_vectors(fc_ctx* h) {
   std::vector<double> unit((size_t)std::max(1, h->n_act), 0.0);
   DevBuf<double> amp;
   FCCHK(amp.alloc(unit.size()));
+  FCCHK(h->tmpN2.zero(h->stream));  // a zero "state" (its terms are switched off; 0 x a non-finite state entry would still poison the load vector)
   for (int k = 0; k < h->n_act; ++k) {
     std::fill(unit.begin(), unit.end(), 0.0);
     unit[(size_t)k] = 1.0;
     HIPCHK(hipMemcpyAsync(amp.p, unit.data(), unit.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (ncl > 0)
-      hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks((int64_t)ncl * 8, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
-                         h->u_n.p, h->u_nn.p, h->fprof.p, h->n_act, amp.p, 0.0, 0.0, 0.0, 0.0, h->ev.p,
+      hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks((int64_t)ncl * 8, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->cnp.p, h->geom.p,
+                         h->tmpN2.p, h->tmpN2.p, h->fprof.p, h->n_act, amp.p, 0.0, 0.0, 0.0, 0.0, h->ev.p,
                          h->partitioned ? h->cell_list.p : nullptr, ncl);
     hipLaunchKernelGGL(fc_force_rows, dim3(nblocks(N, 256)), dim3(256), 0, h->stream, N, h->gptr_p.p, h->gidx_p.p, h->ev.p,
                        h->bcslot_p.p, h->partitioned ? h->rowkind_p.p : nullptr, h->fvec.p + (size_t)k * N);
@@ -941,13 +919,13 @@ int enqueue_rhs(fc_ctx* h, int order_slot, const double* d_uctrl, const double* 
   const bool have_ev = h->pre_slot == order_slot;
   h->pre_slot = -1;
   if (ncl > 0 && !have_ev)
-    hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks((int64_t)ncl * 8, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
-                       h->u_n.p, h->u_nn.p, (const double*)nullptr, 0, d_uforce, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p,
+    hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks((int64_t)ncl * 8, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->cnp.p, h->geom.p,
+                       st_n(h), st_nn(h), (const double*)nullptr, 0, d_uforce, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p,
                        h->partitioned ? h->cell_list.p : nullptr, ncl);
   hipLaunchKernelGGL(fc_rhs_gather, dim3(nblocks(h->N, 256)), dim3(256), 0, h->stream, h->N, h->gptr_p.p, h->gidx_p.p,
                      h->ev.p, h->bcslot_p.p, h->bcprof.p, S.lift_p.p, h->n_act, d_uctrl, h->b.p, h->buf.p,
                      h->partitioned ? h->rowkind_p.p : nullptr, h->lead ? 1 : 0, S.have_c ? S.c_rowptr.p : nullptr,
-                     S.c_col.p, S.c_val.p, h->u_n.p, h->partitioned ? h->rowkind_w.p : nullptr,
+                     S.c_col.p, S.c_val.p, st_n(h), h->partitioned ? h->rowkind_p.p : nullptr,
                      h->have_force ? h->fvec.p : nullptr, d_uforce);
   HIPCHK(hipGetLastError());
   return FC_OK;
@@ -972,16 +950,22 @@ bool use_fused_tail(const fc_ctx* h) {
   return enabled && h->max_iter == 0;
 }
 
+// the solution of this step sits in the x half of h->buf (the ring slot that becomes the state): residual monitor, non-finite
+// test, energy, then fc_final (sensors, record)
 int launch_tail(fc_ctx* h, OrderSys& S, int compute_energy, double* d_y, double* d_E, double* d_r, double* d_flag_out,
-                double* d_seq, double seq, int step_id = 1) {
-  const bool res = h->check_residual != 0;
+                double* d_seq, double seq) {
+  // check_residual = n >= 1: the monitor runs on every n-th step of the handle (the reference never forms this residual,
+  // flowsolver.py:728-737 tests finiteness only; n > 1 amortises the matrix pass); the steps in between report NaN
+  const bool res = h->check_residual != 0 && (h->step_count % (uint64_t)h->check_residual) == 0;
+  h->last_checked = res;
   const bool part = h->partitioned;
   const int ncl = part ? h->ncl : h->nc;
+  const double* x = h->buf.p + h->N;
   static const int reps_env = [] { const char* e = std::getenv("FC_TAIL_REPS"); return e ? std::max(1, std::atoi(e)) : 0; }();  // tuning aid
   const int reps = reps_env ? reps_env : std::max(1, nblocks(h->N, 32 * 2048));  // <= ~2048 + ~500 partials per array for fc_final
   const int g_rows = res ? nblocks(h->N, 32 * reps) : 0, g_cells = (compute_energy && ncl > 0) ? nblocks(ncl, 32 * reps) : 0;
-  const int g_shift = nblocks(h->N, 256 * FC_TAIL_SHIFT);
-  const int g = g_rows + g_shift + g_cells;
+  const int g_check = res ? 0 : nblocks(h->N, 256 * FC_TAIL_CHECK);  // the row workgroups test finiteness themselves
+  const int g = g_rows + g_check + g_cells;
   if (g > h->nblk_N) return fail(FC_ERR_INVALID, "launch_tail: partial buffer too small");
   // FC_FUSED_FINAL=1 (single GPU): the last workgroup to arrive does fc_final's work inside this launch.  Measured equal
   // to the separate launch (24.7 vs 24.2 us for tail + final on O1, identical results): the last arriver's serial chain
@@ -991,7 +975,7 @@ int launch_tail(fc_ctx* h, OrderSys& S, int compute_energy, double* d_y, double*
     return e && e[0] == '1';
   }();
   FcFin fin = {};
-  const bool fused = fuse_final && !part && (h->n_sens == 0 || h->have_sidxp);
+  const bool fused = fuse_final && !part;
   if (fused) {
     constexpr int kGroup = 32;
     const int n_groups = nblocks(g, kGroup);
@@ -1000,9 +984,9 @@ int launch_tail(fc_ctx* h, OrderSys& S, int compute_energy, double* d_y, double*
       FCCHK(h->fin_cnt.alloc(std::max(need, (size_t)32 * 4096)));
       FCCHK(h->fin_cnt.zero(h->stream));
     }
-    fin = FcFin{h->fin_cnt.p, kGroup, n_groups, h->n_sens, h->s_rowptr.p, h->s_idxp.p, h->s_w.p, d_y, d_E, d_r, d_flag_out, d_seq, seq, step_id};
+    fin = FcFin{h->fin_cnt.p, kGroup, n_groups, h->n_sens, h->s_rowptr.p, h->s_idxp.p, h->s_w.p, d_y, d_E, d_r, d_flag_out, d_seq, seq};
   }
-#define FC_TAIL_ARGS h->N, 2 * h->nn, h->perm.p, h->buf.p + h->N, h->b.p, res ? S.Ap_rowptr.p : nullptr, S.Ap_col.p, S.Ap_val.p, g_rows, g_shift, reps, h->nc, g_cells > 0 ? h->cn.p : nullptr, h->geom.p, h->iperm.p, part ? h->rowkind_p.p : nullptr, part ? h->cell_list.p : nullptr, ncl, h->up.p, h->u_n.p, h->u_nn.p, h->p_n.p, h->flag.p, h->partial.p, h->dag_err.p, fin, h->u_old.p, h->p_old.p
+#define FC_TAIL_ARGS h->N, h->velrow_p.p, x, h->b.p, res ? S.Ap_rowptr.p : nullptr, S.Ap_col.p, S.Ap_val.p, g_rows, g_check, reps, h->nc, g_cells > 0 ? h->cnp.p : nullptr, h->geom.p, part ? h->rowkind_p.p : nullptr, part ? h->cell_list.p : nullptr, ncl, h->flag.p, h->partial.p, fin
   if (fused)
     hipLaunchKernelGGL(fc_tail<true>, dim3(g), dim3(256), 0, h->stream, FC_TAIL_ARGS);
   else
@@ -1013,15 +997,15 @@ int launch_tail(fc_ctx* h, OrderSys& S, int compute_energy, double* d_y, double*
     FCCHK(phase_mark(h, PH_TAIL));
   } else if (!part) {
     hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, g, e_part, d_E, res ? g : 0, res ? h->partial.p : nullptr, d_r,
-                       h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p, h->up.p, d_y, h->flag.p, d_flag_out, d_seq, seq, h->dag_err.p, step_id);
+                       h->n_sens, h->s_rowptr.p, h->s_idxp.p, h->s_w.p, x, d_y, h->flag.p, d_flag_out, d_seq, seq);
     FCCHK(phase_mark(h, PH_TAIL));
   } else {
     // partitioned: this rank's share (owned rows, its cells, its part of every sensor row) goes to the 80-double
     // tail record, ONE all-reduce sums the ranks' records, the result is published (fc_final rewrites every
     // used word of the record each step)
     hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, g, e_part, h->tail.p + 64, res ? g : 0,
-                       res ? h->partial.p : nullptr, h->tail.p + 65, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p, h->up.p,
-                       h->tail.p, h->flag.p, h->tail.p + 72, (double*)nullptr, 0.0, h->dag_err.p, step_id);
+                       res ? h->partial.p : nullptr, h->tail.p + 65, h->n_sens, h->s_rowptr.p, h->s_idxp.p, h->s_w.p, x,
+                       h->tail.p, h->flag.p, h->tail.p + 72, (double*)nullptr, 0.0);
     FCCHK(phase_mark(h, PH_TAIL));
     FCCHK(exchange(h, h->tail.p, 80));  // the third exchange of a step: 80 doubles
     FCCHK(phase_mark(h, PH_X3));
@@ -1346,9 +1330,8 @@ struct KrylovOverride {
 };
 
 // enqueue one full step; y -> d_y, E -> d_E; residual norms -> scal[1], scal[2]
-int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, double* d_E, double* d_r,
-                 double* d_flag_out, int compute_energy, const double* d_uforce = nullptr, double* d_seq = nullptr,
-                 double seq = 0.0, int step_id = 1) {
+int enqueue_step_launches(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, double* d_E, double* d_r,
+                          double* d_flag_out, int compute_energy, const double* d_uforce, double* d_seq, double seq) {
   OrderSys& S = h->sys[order_slot];
   if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this order");
   if (S.truncated && h->method == FC_METHOD_REFINE)
@@ -1375,38 +1358,39 @@ int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, 
     FCCHK(h->method == FC_METHOD_GMRES ? gmres_permuted(h, S, &iters, &relres) : bicgstab_permuted(h, S, &iters, &relres));
     h->last_krylov_iters = iters;
     hipLaunchKernelGGL(fc_copy, dim3(nblocks(h->N, 256)), dim3(256), 0, h->stream, h->N, h->kry.p, h->buf.p + h->N);
-    return launch_tail(h, S, compute_energy, d_y, d_E, d_r, d_flag_out, d_seq, seq, step_id);
+    return launch_tail(h, S, compute_energy, d_y, d_E, d_r, d_flag_out, d_seq, seq);
   }
   if (use_fused_tail(h)) {
     FCCHK(apply_factors(h, S));
-    return launch_tail(h, S, compute_energy, d_y, d_E, d_r, d_flag_out, d_seq, seq, step_id);
+    return launch_tail(h, S, compute_energy, d_y, d_E, d_r, d_flag_out, d_seq, seq);
   }
   FCCHK(solve_permuted(h, S, &x, &dx, &nrp));
+  h->last_checked = nrp > 0;
+  // the new state = the x half of the work buffer: after refinement sweeps that half holds the last correction, x the sum so far
+  if (dx) hipLaunchKernelGGL(fc_axpy, dim3(nblocks(h->N, 256)), dim3(256), 0, h->stream, h->N, 1.0, x, h->buf.p + h->N);
+  const double* xn = h->buf.p + h->N;
   const int g = nblocks(h->N, 32);  // fc_finish: 8 lanes per row, 32 rows per workgroup
   double* e_partial = h->partial.p + 2 * (size_t)h->nblk_N;  // energy partials live after the residual ones
   if (!h->partitioned) {
-    hipLaunchKernelGGL(fc_finish, dim3(g), dim3(256), 0, h->stream, h->N, 2 * h->nn, h->perm.p, x, dx, h->up.p, h->u_n.p,
-                       h->u_nn.p, h->p_n.p, h->flag.p, compute_energy ? h->mp_rowptr.p : nullptr, h->mp_col.p,
-                       h->mp_val.p, compute_energy ? e_partial : nullptr, (const unsigned char*)nullptr, h->dag_err.p, h->u_old.p, h->p_old.p);
+    hipLaunchKernelGGL(fc_finish, dim3(g), dim3(256), 0, h->stream, h->N, h->velrow_p.p, xn, h->flag.p, compute_energy ? h->mp_rowptr.p : nullptr,
+                       h->mp_col.p, h->mp_val.p, compute_energy ? e_partial : nullptr, (const unsigned char*)nullptr);
     hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, g, compute_energy ? e_partial : nullptr,
-                       d_E, nrp, nrp > 0 ? h->partial.p : nullptr, d_r, h->n_sens, h->s_rowptr.p, h->s_idx.p,
-                       h->s_w.p, h->up.p, d_y, h->flag.p, d_flag_out, d_seq, seq, h->dag_err.p, step_id);
+                       d_E, nrp, nrp > 0 ? h->partial.p : nullptr, d_r, h->n_sens, h->s_rowptr.p, h->s_idxp.p,
+                       h->s_w.p, xn, d_y, h->flag.p, d_flag_out, d_seq, seq);
   } else {
-    // partitioned: scatter owned + root rows, energy from this rank's cells, sensor rows restricted to
+    // partitioned: owned + root rows, energy from this rank's cells, sensor rows restricted to
     // owned dofs; the partial tail is summed over the ranks with one small all-reduce
-    hipLaunchKernelGGL(fc_finish, dim3(g), dim3(256), 0, h->stream, h->N, 2 * h->nn, h->perm.p, x, dx, h->up.p, h->u_n.p,
-                       h->u_nn.p, h->p_n.p, h->flag.p, (const int*)nullptr, (const int*)nullptr, (const double*)nullptr,
-                       (double*)nullptr, h->rowkind_p.p, h->dag_err.p, h->u_old.p, h->p_old.p);
+    hipLaunchKernelGGL(fc_finish, dim3(g), dim3(256), 0, h->stream, h->N, h->velrow_p.p, xn, h->flag.p, (const int*)nullptr, (const int*)nullptr,
+                       (const double*)nullptr, (double*)nullptr, h->rowkind_p.p);
     int ne = 0;
     if (compute_energy && h->ncl > 0) {
       ne = nblocks(h->ncl, 256);
-      hipLaunchKernelGGL(fc_energy_elem, dim3(ne), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p, h->u_n.p,
-                         h->cell_list.p, h->ncl, e_partial);
+      hipLaunchKernelGGL(fc_energy_elem, dim3(ne), dim3(256), 0, h->stream, h->nc, h->cnp.p, h->geom.p, xn, h->cell_list.p, h->ncl, e_partial);
     }
     HIPCHK(hipMemsetAsync(h->tail.p, 0, 128 * sizeof(double), h->stream));
     hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, ne, ne > 0 ? e_partial : nullptr,
                        h->tail.p + 64, nrp, nrp > 0 ? h->partial.p : nullptr, h->tail.p + 65, h->n_sens, h->s_rowptr.p,
-                       h->s_idx.p, h->s_w.p, h->up.p, h->tail.p, h->flag.p, h->tail.p + 72, (double*)nullptr, 0.0, h->dag_err.p, step_id);
+                       h->s_idxp.p, h->s_w.p, xn, h->tail.p, h->flag.p, h->tail.p + 72, (double*)nullptr, 0.0);
     FCCHK(phase_mark(h, PH_TAIL));
     FCCHK(exchange(h, h->tail.p, 80));
     FCCHK(phase_mark(h, PH_X3));
@@ -1416,6 +1400,18 @@ int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, 
   }
   if (!h->partitioned) FCCHK(phase_mark(h, PH_TAIL));
   HIPCHK(hipGetLastError());
+  return FC_OK;
+}
+
+// enqueue one full step; y -> d_y, E -> d_E; residual norms -> scal[1], scal[2].  On return the state ring has moved on: the
+// solution the launches write IS the new (u_n, p_n), the old u_n is u_nn (nothing is copied)
+int enqueue_step(fc_ctx* h, int order_slot, const double* d_uctrl, double* d_y, double* d_E, double* d_r,
+                 double* d_flag_out, int compute_energy, const double* d_uforce = nullptr, double* d_seq = nullptr,
+                 double seq = 0.0) {
+  FCCHK(enqueue_step_launches(h, order_slot, d_uctrl, d_y, d_E, d_r, d_flag_out, compute_energy, d_uforce, d_seq, seq));
+  ring_advance(h);
+  h->state_live = true;
+  ++h->step_count;
   return FC_OK;
 }
 
@@ -1589,14 +1585,12 @@ int fc_create(fc_handle* out, int device, int32_t nv, int32_t ne, int32_t nc, co
   TRY(h->em.alloc((size_t)225 * nc));
   TRY(h->ev.alloc((size_t)12 * nc));
   for (int s = 0; s < FC_NUM_SLOTS; ++s) TRY(h->vals[s].alloc((size_t)h->nnz));
-  TRY(h->u_n.alloc(2 * (size_t)nn));
-  TRY(h->u_nn.alloc(2 * (size_t)nn));
-  TRY(h->u_old.alloc(2 * (size_t)nn));
-  TRY(h->p_old.alloc((size_t)std::max(1, nv)));
-  TRY(h->p_n.alloc(nv));
-  TRY(h->up.alloc(N));
+  TRY(h->ring.alloc(8 * (size_t)N));  // the state ring: four work buffers [y | x]
+  TRY(h->ring.zero(h->stream));
+  h->cur = 0;
+  h->buf.n = 2 * (size_t)N;
+  ring_point(h);
   TRY(h->b.alloc(N));
-  TRY(h->buf.alloc(2 * (size_t)N));
   TRY(h->xsol.alloc(N));
   TRY(h->tmpN.alloc(N));
   TRY(h->tmpN2.alloc(N));
@@ -1605,10 +1599,6 @@ int fc_create(fc_handle* out, int device, int32_t nv, int32_t ne, int32_t nc, co
   TRY(h->scal.alloc(8));
   TRY(h->flag.alloc(1));
   TRY(h->isbc.alloc(N));
-  TRY(h->u_n.zero(h->stream));
-  TRY(h->u_nn.zero(h->stream));
-  TRY(h->p_n.zero(h->stream));
-  TRY(h->up.zero(h->stream));
   TRY(h->scal.zero(h->stream));
   TRY(h->flag.zero(h->stream));
   TRY(h->isbc.zero(h->stream));
@@ -1617,11 +1607,6 @@ int fc_create(fc_handle* out, int device, int32_t nv, int32_t ne, int32_t nc, co
   TRY(h->ydev.alloc(64));
   TRY(h->tail.alloc(128));
   TRY(h->tail.zero(h->stream));
-  TRY(h->dag_err.alloc(2));
-  TRY(h->dag_err.zero(h->stream));
-#ifdef FC_WITH_DAG
-  if (const char* e = std::getenv("FC_DAG")) h->dag_enabled = e[0] != '0';  // 1: one-launch factor apply (fc_dag.hip.h; builds with -DFC_WITH_DAG only)
-#endif
   TRYHIP(hipStreamSynchronize(h->stream));
 #undef TRY
 #undef TRYHIP
@@ -1740,13 +1725,13 @@ int fc_bench_spmv(fc_handle h, int slot, int reps, double* ms_per_launch) {
   if (!h->slot_ok[slot]) return fail(FC_ERR_NOT_READY, "slot not assembled");
   HIPCHK(hipSetDevice(h->device));
   for (int i = 0; i < 3; ++i) {
-    const int nb = launch_spmv<0>(h, h->N, (double)h->nnz / h->N, h->rowptr.p, h->col.p, h->vals[slot].p, h->up.p,
+    const int nb = launch_spmv<0>(h, h->N, (double)h->nnz / h->N, h->rowptr.p, h->col.p, h->vals[slot].p, h->tmpN.p,
                                   nullptr, h->tmpN2.p, nullptr, nullptr);
     if (nb < 0) return nb;
   }
   HIPCHK(hipEventRecord(h->ev0, h->stream));
   for (int i = 0; i < reps; ++i) {
-    const int nb = launch_spmv<0>(h, h->N, (double)h->nnz / h->N, h->rowptr.p, h->col.p, h->vals[slot].p, h->up.p,
+    const int nb = launch_spmv<0>(h, h->N, (double)h->nnz / h->N, h->rowptr.p, h->col.p, h->vals[slot].p, h->tmpN.p,
                                   nullptr, h->tmpN2.p, nullptr, nullptr);
     if (nb < 0) return nb;
   }
@@ -1778,7 +1763,7 @@ int fc_set_bc(fc_handle h, int32_t n_bc, const int32_t* bc_dofs, int32_t n_act, 
       h->have_plan = false;
       h->bat.tables = false;  // and the batched launch tables with it (fc_set_batch rebuilds them)
       h->bat.k = h->bat.KB = 0;
-      for (int o = 0; o < 2; ++o) h->sys[o].structured = h->sys[o].dag_ready = false;
+      for (int o = 0; o < 2; ++o) h->sys[o].structured = false;
     }
   }
   h->n_bc = n_bc;
@@ -1840,7 +1825,7 @@ static int upload_sensors(fc_ctx* h) {
   if (h->have_perm) {
     std::vector<int> ip((size_t)h->N), idxp(idx.size());
     for (int i = 0; i < h->N; ++i) ip[(size_t)h->h_perm[i]] = i;
-    for (size_t k = 0; k < idx.size(); ++k) idxp[k] = h->N + ip[(size_t)idx[k]];
+    for (size_t k = 0; k < idx.size(); ++k) idxp[k] = ip[(size_t)idx[k]];
     FCCHK(h->s_idxp.upload(idxp, h->stream));
     h->have_sidxp = true;
   }
@@ -1909,6 +1894,14 @@ int fc_set_permutation(fc_handle h, const int32_t* perm) {
     if (perm[i] < 0 || perm[i] >= h->N || seen[perm[i]]) return fail(FC_ERR_INVALID, "fc_set_permutation: not a permutation");
     seen[perm[i]] = 1;
   }
+  // the state vectors live in the permuted numbering: carry them over (W layout on the host in between)
+  std::vector<double> wn, wnn;
+  if (h->have_perm && h->state_live) {
+    wn.resize((size_t)h->N), wnn.resize((size_t)h->N);
+    FCCHK(state_download(h, wn.data(), wnn.data()));
+  } else if (!h->hs_n.empty()) {
+    wn.swap(h->hs_n), wnn.swap(h->hs_nn);
+  }
   h->h_perm.assign(perm, perm + h->N);
   FCCHK(h->perm.upload(h->h_perm, h->stream));
   {
@@ -1918,9 +1911,13 @@ int fc_set_permutation(fc_handle h, const int32_t* perm) {
   }
   h->have_perm = true;
   h->have_mp = false;
+  h->pre_slot = -1;
+  h->undo_ok = false;
   for (int o = 0; o < 2; ++o) h->sys[o].ready = h->sys[o].structured = false;
   FCCHK(upload_sensors(h));  // sensor positions in the permuted numbering
-  return refresh_permuted(h);
+  FCCHK(refresh_permuted(h));
+  if (!wn.empty()) FCCHK(state_upload(h, wn.data(), wnn.data()));
+  return FC_OK;
 }
 
 int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32_t* Ap_col, const double* Ap_val,
@@ -2089,10 +2086,6 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
     FCCHK(S.Ap_val.alloc((size_t)S.Ap_nnz));
     FCCHK(S.Ap_val.zero(h->stream));
   }
-  S.h_seg_ptr.assign(seg_ptr, seg_ptr + total_rows + 1);
-  S.h_seg_val.assign(seg_val, seg_val + n_seg);
-  S.h_seg_col.assign(seg_col, seg_col + n_seg);
-  S.h_seg_len.assign(seg_len, seg_len + n_seg);
   FCCHK(S.seg_ptr.upload(seg_ptr, (size_t)total_rows + 1, h->stream));
   {
     std::vector<FcSeg> packed((size_t)std::max<int64_t>(1, n_seg));
@@ -2126,7 +2119,6 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
   for (const Stage& st : S.stages) S.truncated = S.truncated || st.kind == 2;
   S.ready = true;
   S.structured = true;
-  S.dag_ready = false;  // fc_solver_set_dag must follow
   return FC_OK;
 }
 
@@ -2195,285 +2187,6 @@ int fc_solver_set_blocks(fc_handle h, int slot, int32_t n_stages, const int64_t*
   }
   FCCHK(S.blk.upload(packed, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  return FC_OK;
-}
-
-int fc_solver_set_dag(fc_handle h, int slot, int32_t n_nodes, const int64_t* nodes, const uint8_t* mine, const int32_t* dn_dep,
-                      const int32_t* up_dep_ptr, const int32_t* up_dep_idx) {
-  if (!h || slot < 0 || slot > 1 || n_nodes <= 0 || !nodes || !dn_dep || !up_dep_ptr || (up_dep_ptr[n_nodes] > 0 && !up_dep_idx))
-    return fail(FC_ERR_INVALID, "fc_solver_set_dag: bad argument");
-  OrderSys& S = h->sys[slot];
-  if (!S.structured) return fail(FC_ERR_NOT_READY, "fc_solver_setup must be called first");
-  HIPCHK(hipSetDevice(h->device));
-  S.dag_ready = false;
-#ifndef FC_WITH_DAG
-  return FC_OK;  // the one-launch apply is not part of this build: nothing to tabulate (the level launches are the apply)
-#endif
-  if (S.truncated) return FC_OK;  // truncated / compressed (preconditioner-only) factors are applied with the level launches
-  const int N = h->N;
-  const int64_t n_idx = (int64_t)S.f_idx.n, n_val = S.f_nnz;
-  struct Nd {
-    int level, i0, ni, nb;
-    int64_t voff, ioff;
-    int up_stage = -1, dn_stage = -1;
-    int up_n = 0, dn_n = 0;                          // tasks
-    int up_base = 0, up_sh = 1, dn_base = 0, dn_sh = 1;  // counters
-    int up_dep0 = 0, up_ndep = 0, dn_dep0 = 0, dn_ndep = 0;
-  };
-  std::vector<Nd> nd((size_t)n_nodes);
-  for (int g = 0; g < n_nodes; ++g) {
-    const int64_t* r = nodes + (size_t)g * 7;  // level, index in level, i0, ni, nb, value offset, index-list offset
-    Nd& d = nd[g];
-    d.level = (int)r[0];
-    d.i0 = (int)r[2];
-    d.ni = (int)r[3];
-    d.nb = (int)r[4];
-    d.voff = r[5];
-    d.ioff = r[6];
-    if (d.ni <= 0 || d.nb < 0 || d.i0 < 0 || (int64_t)d.i0 + d.ni > N || d.voff < 0 ||
-        d.voff + (int64_t)((d.level == 0 && d.nb == 0 && h->root_x0 >= 0) ? h->root_xn : d.ni) * (d.ni + d.nb) > n_val ||
-        (d.nb > 0 && (d.ioff < 0 || d.ioff + d.nb > n_idx)))
-      return fail(FC_ERR_INVALID, "fc_solver_set_dag: node table out of range");
-    if (dn_dep[g] >= n_nodes || up_dep_ptr[g] < 0 || up_dep_ptr[g + 1] < up_dep_ptr[g])
-      return fail(FC_ERR_INVALID, "fc_solver_set_dag: dependency table out of range");
-  }
-  for (int k = 0; k < up_dep_ptr[n_nodes]; ++k)
-    if (up_dep_idx[k] < 0 || up_dep_idx[k] >= n_nodes) return fail(FC_ERR_INVALID, "fc_solver_set_dag: dependency index out of range");
-  auto is_mine = [&](int g) { return !mine || mine[g] != 0; };
-  // the stage every node's rows belong to; a stage must be tiled exactly by its nodes
-  const int nst = (int)S.stages.size();
-  std::vector<std::vector<int>> stage_nodes((size_t)nst);
-  for (int g = 0; g < n_nodes; ++g) {
-    if (!is_mine(g)) continue;
-    for (int s = 0; s < nst; ++s) {
-      const Stage& st = S.stages[s];
-      // (a rank's root down stage holds only its block of the root's rows: overlap is enough there)
-      const bool inside = st.row0 <= nd[g].i0 && nd[g].i0 + nd[g].ni <= st.row0 + st.nrows;
-      const bool overlap = st.kind == 1 && s == S.ar2_stage && nd[g].i0 < st.row0 + st.nrows && st.row0 < nd[g].i0 + nd[g].ni;
-      if (inside || overlap) {
-        (st.kind == 0 ? nd[g].up_stage : nd[g].dn_stage) = s;
-        stage_nodes[s].push_back(g);
-      }
-    }
-    if (nd[g].dn_stage < 0) return fail(FC_ERR_INVALID, "fc_solver_set_dag: a node's rows lie in no down stage");
-  }
-  for (int s = 0; s < nst; ++s) {
-    std::sort(stage_nodes[s].begin(), stage_nodes[s].end(), [&](int a, int b) { return nd[a].i0 < nd[b].i0; });
-    int64_t rows = 0;
-    int next = S.stages[s].row0;
-    for (int g : stage_nodes[s]) {
-      const int lo = std::max(nd[g].i0, S.stages[s].row0), hi = std::min(nd[g].i0 + nd[g].ni, S.stages[s].row0 + S.stages[s].nrows);
-      if (lo != next) return fail(FC_ERR_INVALID, "fc_solver_set_dag: the nodes do not tile their stage");
-      next = hi;
-      rows += hi - lo;
-    }
-    if (rows != S.stages[s].nrows) return fail(FC_ERR_INVALID, "fc_solver_set_dag: the nodes do not cover their stage");
-  }
-  // length of every up-sweep row (= concatenation of its segments)
-  int64_t n_up_rows = 0;
-  for (int s = 0; s < nst; ++s)
-    if (S.stages[s].kind == 0) {
-      if (S.stages[s].rp_begin != n_up_rows) return fail(FC_ERR_INVALID, "fc_solver_set_dag: up stages must come first");
-      n_up_rows += S.stages[s].nrows;
-    }
-  if ((int64_t)S.h_seg_ptr.size() < n_up_rows + 1) return fail(FC_ERR_INVALID, "fc_solver_set_dag: segment tables missing");
-  std::vector<int64_t> row_len((size_t)n_up_rows, 0);
-  for (int64_t r = 0; r < n_up_rows; ++r)
-    for (int64_t q = S.h_seg_ptr[r]; q < S.h_seg_ptr[r + 1]; ++q) row_len[r] += S.h_seg_len[q];
-  // tasks, stage by stage (= topological order).  Up tasks are ELL tiles: the rows of a tile are padded to the tile's
-  // longest row (value 0, column = the row itself), so that a lane finds its values from the task record alone.
-  std::vector<FcDagTask> tasks;
-  std::vector<int> task_node;
-  std::vector<int64_t> up_src;  // per expanded entry: index into f_val, -1 = padding
-  std::vector<int> up_col;
-  auto pow2_ceil = [](int v) { int p = 1; while (p < v) p <<= 1; return p; };
-  for (int s = 0; s < nst; ++s) {
-    Stage& st = S.stages[s];
-    st.dag_task0 = (int)tasks.size();
-    for (int g : stage_nodes[s]) {
-      Nd& d = nd[g];
-      if (st.kind == 0) {
-        // lanes per row from the node's longest row (a lane holds <= FC_DAG_PV of its values in registers)
-        const int64_t row_first = st.rp_begin + (d.i0 - st.row0);
-        int64_t maxlen = 1;
-        for (int r = 0; r < d.ni; ++r) maxlen = std::max(maxlen, row_len[row_first + r]);
-        const int lpr = std::min(256, std::max(8, pow2_ceil((int)((maxlen + FC_DAG_PV - 1) / FC_DAG_PV))));
-        const int R = 256 / lpr;
-        for (int r0 = 0; r0 < d.ni; r0 += R) {
-          const int nr = std::min(R, d.ni - r0);
-          int64_t stride = 1;
-          for (int r = 0; r < nr; ++r) stride = std::max(stride, row_len[row_first + r0 + r]);
-          if (stride > std::numeric_limits<int>::max()) return fail(FC_ERR_INVALID, "fc_solver_set_dag: row too long");
-          FcDagTask t{};
-          t.kind = 0;
-          t.lpr = lpr;
-          t.nrows = nr;
-          t.dest0 = d.i0 + r0;
-          t.stride = (int)stride;
-          t.val = (long long)up_src.size();
-          for (int r = 0; r < nr; ++r) {
-            const int64_t row = row_first + r0 + r;
-            int64_t k = 0;
-            for (int64_t q = S.h_seg_ptr[row]; q < S.h_seg_ptr[row + 1]; ++q)
-              for (int j = 0; j < S.h_seg_len[q]; ++j, ++k) {
-                up_src.push_back(S.h_seg_val[q] + j);
-                up_col.push_back(S.h_seg_col[q] + j);  // up segments are contiguous slices of y (checked in fc_solver_setup)
-              }
-            for (; k < stride; ++k) {
-              up_src.push_back(-1);
-              up_col.push_back(d.i0 + r0 + r);
-            }
-          }
-          tasks.push_back(t);
-          task_node.push_back(g);
-          ++d.up_n;
-        }
-      } else {
-        // tile of R = 256 / LPR rows; a lane holds <= FC_DAG_PV values of its row in registers
-        const int wd = d.ni + d.nb;
-        const int lpr = std::min(256, std::max(8, pow2_ceil((wd + FC_DAG_PV - 1) / FC_DAG_PV)));
-        const int R = 256 / lpr;
-        const int r_lo = std::max(0, st.row0 - d.i0), r_hi = std::min(d.ni, st.row0 + st.nrows - d.i0);  // this rank's rows of the node
-        for (int r0 = r_lo; r0 < r_hi; r0 += R) {
-          FcDagTask t{};
-          t.kind = 1;
-          t.lpr = lpr;
-          t.nrows = std::min(R, r_hi - r0);
-          t.dest0 = N + d.i0 + r0;
-          t.stride = wd;
-          t.val = (long long)(d.voff + (int64_t)(r0 - ((d.level == 0 && d.nb == 0 && h->root_x0 >= 0) ? h->root_x0 : 0)) * wd);
-          t.i0 = d.i0;
-          t.ni = d.ni;
-          t.ioff = (int)d.ioff;
-          t.nb = d.nb;
-          tasks.push_back(t);
-          task_node.push_back(g);
-          ++d.dn_n;
-        }
-      }
-    }
-    st.dag_ntasks = (int)tasks.size() - st.dag_task0;
-  }
-  const int64_t n_up = (int64_t)up_src.size();
-  up_src.push_back(-1);
-  up_col.push_back(0);
-  // arrival counters: one 128-byte line per shard
-  int words = 0;
-  auto shards = [](int ntasks) { return ntasks <= 12 ? 1 : std::min(FC_DAG_MAX_SHARDS, (ntasks + 11) / 12); };
-  for (int g = 0; g < n_nodes; ++g) {
-    Nd& d = nd[g];
-    d.up_sh = shards(d.up_n);
-    d.up_base = words;
-    words += d.up_sh * FC_DAG_SHARD_STRIDE;
-    d.dn_sh = shards(d.dn_n);
-    d.dn_base = words;
-    words += d.dn_sh * FC_DAG_SHARD_STRIDE;
-  }
-  // dependency records, shared by all tasks of a node
-  std::vector<FcDagDep> deps;
-  for (int g = 0; g < n_nodes; ++g) {
-    Nd& d = nd[g];
-    if (!is_mine(g)) continue;
-    d.up_dep0 = (int)deps.size();
-    for (int k = up_dep_ptr[g]; k < up_dep_ptr[g + 1]; ++k) {
-      const Nd& c = nd[up_dep_idx[k]];
-      if (!is_mine(up_dep_idx[k]) || c.up_n == 0) continue;  // leaves: y = b is complete before the launch
-      if (c.level <= d.level) return fail(FC_ERR_INVALID, "fc_solver_set_dag: an up dependency is not deeper in the tree");
-      deps.push_back(FcDagDep{c.up_base, c.up_sh, (unsigned)c.up_n, 0});
-    }
-    d.up_ndep = (int)deps.size() - d.up_dep0;
-    d.dn_dep0 = (int)deps.size();
-    if (dn_dep[g] >= 0) {
-      const Nd& a = nd[dn_dep[g]];
-      if (!is_mine(dn_dep[g]) || a.level >= d.level) return fail(FC_ERR_INVALID, "fc_solver_set_dag: a down dependency is not an ancestor of this rank");
-      deps.push_back(FcDagDep{a.dn_base, a.dn_sh, (unsigned)a.dn_n, 0});
-    } else if (d.up_n > 0) {
-      deps.push_back(FcDagDep{d.up_base, d.up_sh, (unsigned)d.up_n, 0});  // the root: its own up rows
-    }
-    d.dn_ndep = (int)deps.size() - d.dn_dep0;
-  }
-  if (deps.empty()) deps.push_back(FcDagDep{0, 0, 0u, 0});
-  std::vector<int> seen_up((size_t)n_nodes, 0), seen_dn((size_t)n_nodes, 0);
-  for (size_t i = 0; i < tasks.size(); ++i) {
-    FcDagTask& t = tasks[i];
-    Nd& d = nd[task_node[i]];
-    if (t.kind == 0) {
-      t.dep0 = d.up_dep0;
-      t.ndep = d.up_ndep;
-      t.sig = d.up_base + (seen_up[task_node[i]]++ % d.up_sh) * FC_DAG_SHARD_STRIDE;
-    } else {
-      t.dep0 = d.dn_dep0;
-      t.ndep = d.dn_ndep;
-      t.sig = d.dn_base + (seen_dn[task_node[i]]++ % d.dn_sh) * FC_DAG_SHARD_STRIDE;
-    }
-  }
-  if (tasks.empty()) return fail(FC_ERR_INVALID, "fc_solver_set_dag: no tasks");
-  FCCHK(S.dag_tasks.upload(tasks, h->stream));
-  FCCHK(S.dag_deps.upload(deps, h->stream));
-  FCCHK(S.dag_cnt.alloc((size_t)std::max(words, FC_DAG_SHARD_STRIDE)));
-  FCCHK(S.dag_cnt.zero(h->stream));
-  FCCHK(S.dag_up_src.upload(up_src, h->stream));
-  FCCHK(S.dag_up_col.upload(up_col, h->stream));
-  FCCHK(S.dag_up_val.alloc((size_t)n_up + 1));
-  S.dag_up_n = n_up;
-  // values as they stand now (host factorisation: final; device factorisation: refreshed by fc_refactor)
-  hipLaunchKernelGGL(fc_gather64_pad, dim3(nblocks(n_up + 1, 256)), dim3(256), 0, h->stream, n_up + 1, S.dag_up_src.p, S.f_val.p, S.dag_up_val.p);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(h->stream));
-  S.dag_epoch = 0;
-  S.dag_ready = true;
-  return FC_OK;
-}
-
-int fc_get_dag_info(fc_handle h, int slot, int32_t* n_tasks, int32_t* enabled, int32_t* failures) {
-  if (!h || slot < 0 || slot > 1) return fail(FC_ERR_INVALID, "fc_get_dag_info: bad argument");
-  if (n_tasks) *n_tasks = h->sys[slot].dag_ready ? (int32_t)h->sys[slot].dag_tasks.n : 0;
-  if (enabled) *enabled = (h->dag_enabled && h->sys[slot].dag_ready) ? 1 : 0;
-  if (failures) *failures = h->dag_failures;
-  return FC_OK;
-}
-
-int fc_debug_trace_apply(fc_handle h, int slot, int32_t n_tasks, int64_t* stamps, int32_t* task_stage, int32_t* task_kind) {
-  if (!h || slot < 0 || slot > 1 || !stamps) return fail(FC_ERR_INVALID, "fc_debug_trace_apply: bad argument");
-  OrderSys& S = h->sys[slot];
-  if (!S.ready || !S.dag_ready || !h->dag_enabled) return fail(FC_ERR_NOT_READY, "fc_debug_trace_apply: one-launch apply not set up");
-  if (n_tasks != (int32_t)S.dag_tasks.n) return fail(FC_ERR_INVALID, "fc_debug_trace_apply: n_tasks differs from fc_get_dag_info");
-  HIPCHK(hipSetDevice(h->device));
-  const int N = h->N, g = nblocks(N, 256);
-  for (int i = 0; i < 3; ++i) {
-    hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, h->buf.p);
-    FCCHK(apply_factors(h, S));
-  }
-  FCCHK(h->dag_trace.alloc((size_t)n_tasks * 8));
-  FCCHK(h->dag_trace.zero(h->stream));
-  hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, h->buf.p);
-  const int code = apply_factors(h, S);
-  HIPCHK(hipMemcpyAsync(stamps, h->dag_trace.p, (size_t)n_tasks * 8 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  h->dag_trace.release();
-  if (code != FC_OK) return code;
-  for (size_t s = 0; s < S.stages.size(); ++s)
-    for (int i = 0; i < S.stages[s].dag_ntasks; ++i) {
-      if (task_stage) task_stage[S.stages[s].dag_task0 + i] = (int32_t)s;
-      if (task_kind) task_kind[S.stages[s].dag_task0 + i] = S.stages[s].kind;
-    }
-  return FC_OK;
-}
-
-int fc_debug_inject_dag_failure(fc_handle h, int after_n_applies) {
-  if (!h) return fail(FC_ERR_INVALID, "null handle");
-  h->dag_inject = after_n_applies;
-  return FC_OK;
-}
-
-int fc_set_dag(fc_handle h, int on) {
-  if (!h) return fail(FC_ERR_INVALID, "null handle");
-  HIPCHK(hipSetDevice(h->device));
-  HIPCHK(hipStreamSynchronize(h->stream));
-#ifndef FC_WITH_DAG
-  if (on) return fail(FC_ERR_INVALID, "fc_set_dag: the one-launch factor apply is not part of this build (hipcc -DFC_WITH_DAG)");
-#endif
-  h->dag_enabled = on != 0;
   return FC_OK;
 }
 
@@ -2777,9 +2490,6 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
       HIPCHK(hipGetLastError());
     }
   }
-  if (S.dag_ready && S.bits == 64)  // row-by-row copy of the -L values for the one-launch apply
-    hipLaunchKernelGGL(fc_gather64_pad, dim3(nblocks(S.dag_up_n + 1, 256)), dim3(256), 0, h->stream, S.dag_up_n + 1, S.dag_up_src.p, fv,
-                       S.dag_up_val.p);
   HIPCHK(hipEventRecord(h->ev1, h->stream));
   HIPCHK(hipEventSynchronize(h->ev1));
   float ms = 0.f;
@@ -2987,8 +2697,6 @@ int fc_setup_solver(fc_handle h, int slot, int32_t depth, int32_t merge, int32_t
                                  B.nrows.empty() ? &zero32 : B.nrows.data(), B.i0.empty() ? &zero32 : B.i0.data(),
                                  B.ni.empty() ? &zero32 : B.ni.data(), B.idx.empty() ? &zero32 : B.idx.data(),
                                  B.nb.empty() ? &zero32 : B.nb.data(), (int64_t)fac.idx.size(), std::max<int64_t>(1, fac.n_val)));
-      const fcsym::Dag D = fcsym::dag_dependencies(t, fac, rank, world);
-      FCCHK(fc_solver_set_dag(h, slot, (int)(fac.nodes.size() / 7), fac.nodes.data(), D.mine.data(), D.dn_dep.data(), D.up_ptr.data(), D.up_idx.data()));
     }
     if (truncate > 0) FCCHK(upload_stage_diag(h, slot));
   } catch (const std::exception& e) {
@@ -3056,8 +2764,14 @@ int fc_accept_factors(fc_handle h, int slot, double* residual_out, int32_t* inex
   // shift, and the ranks of a collective fc_solve must all build the same right-hand side.
   if (h->pin_dof >= 0)
     for (int i = 2 * h->nn; i < N; ++i) b[i] = 0.0;
-  const int method = h->method, max_iter = h->max_iter, check = h->check_residual;
-  const double rtol = h->rtol;
+  // the probe runs with options of its own; the caller's come back on EVERY exit (an early HIPCHK return kept the probe's)
+  struct OptionsGuard {
+    fc_ctx* h;
+    int method, max_iter, check;
+    double rtol;
+    explicit OptionsGuard(fc_ctx* h_) : h(h_), method(h_->method), max_iter(h_->max_iter), check(h_->check_residual), rtol(h_->rtol) {}
+    ~OptionsGuard() { h->method = method, h->max_iter = max_iter, h->rtol = rtol, h->check_residual = check; }
+  } restore(h);
   double info[4] = {0, 0, 0, 0};
   S.inexact = false;
   h->method = FC_METHOD_REFINE, h->max_iter = 0, h->rtol = 1e-10, h->check_residual = 1;
@@ -3085,14 +2799,12 @@ int fc_accept_factors(fc_handle h, int slot, double* residual_out, int32_t* inex
     }
     if (code != FC_OK || !(info[1] < 1e-8 || backward_ok) || info[0] > 40) {
       S.inexact = false;
-      h->method = method, h->max_iter = max_iter, h->rtol = rtol, h->check_residual = check;
       return fail(FC_ERR_HIP, "the factorisation failed its residual check (" + sci(direct) + " by the direct apply, " + sci(info[1]) + " after " + std::to_string((int)info[0]) + " GMRES iterations, backward error " + sci(eta) + ")");
     }
     info[1] = direct;
   } else if (code == FC_OK && !(info[1] < kExactFactors)) {
     code = fail(FC_ERR_HIP, "the factorisation failed its residual check (" + sci(info[1]) + ")");
   }
-  h->method = method, h->max_iter = max_iter, h->rtol = rtol, h->check_residual = check;
   if (code != FC_OK) return code;
   if (residual_out) *residual_out = info[1];
   if (inexact_out) *inexact_out = S.inexact ? 1 : 0;
@@ -3171,8 +2883,6 @@ int fc_sym_build(int32_t nv, int32_t ne, int32_t nc, const double* coords, const
     lap("partition", t0);
     fcsym::Blocks B = fcsym::down_blocks(t, fac, rank, world);
     lap("down_blocks", t0);
-    fcsym::Dag D = fcsym::dag_dependencies(t, fac, rank, world);
-    lap("dag_dependencies", t0);
     fc_sym* sy = new fc_sym();
     auto put = [&](const char* name, auto const& vec) { sy->v[name].assign(vec.begin(), vec.end()); };
     put("perm", t.perm);
@@ -3223,10 +2933,6 @@ int fc_sym_build(int32_t nv, int32_t ne, int32_t nc, const double* coords, const
     put("blk_ni", B.ni);
     put("blk_idx", B.idx);
     put("blk_nb", B.nb);
-    put("dag_mine", D.mine);
-    put("dag_dn_dep", D.dn_dep);
-    put("dag_up_ptr", D.up_ptr);
-    put("dag_up_idx", D.up_idx);
     *out = sy;
   } catch (const std::exception& e) {
     return fail(FC_ERR_INVALID, std::string("fc_sym_build: ") + e.what());
@@ -3348,8 +3054,13 @@ int fc_set_rhs_operator(fc_handle h, int slot, const int32_t* rowptr, const int3
     if (rowptr[i + 1] < rowptr[i]) return fail(FC_ERR_INVALID, "fc_set_rhs_operator: bad row pointers");
   for (int k = 0; k < nz; ++k)
     if (col[k] < 0 || col[k] >= 2 * h->nn) return fail(FC_ERR_INVALID, "fc_set_rhs_operator: column is not a velocity dof");
+  if (!h->have_perm) return fail(FC_ERR_NOT_READY, "fc_set_rhs_operator: the rows are in the solver's permuted numbering (fc_setup_solver / fc_set_permutation first)");
+  // the columns address u_n, which lives in the permuted numbering on the device: W dof -> permuted position
+  std::vector<int> ip((size_t)N), colp((size_t)std::max(1, nz), 0);
+  for (int i = 0; i < N; ++i) ip[(size_t)h->h_perm[i]] = i;
+  for (int k = 0; k < nz; ++k) colp[(size_t)k] = ip[(size_t)col[k]];
   FCCHK(S.c_rowptr.upload(rowptr, (size_t)N + 1, h->stream));
-  FCCHK(S.c_col.upload(col, (size_t)std::max(1, nz), h->stream));
+  FCCHK(S.c_col.upload(colp, h->stream));
   FCCHK(S.c_val.upload(val, (size_t)std::max(1, nz), h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   S.have_c = true;
@@ -3375,7 +3086,7 @@ int fc_set_energy_matrix(fc_handle h, const int32_t* rowptr, const int32_t* col,
 }
 
 int fc_set_solver_options(fc_handle h, int method, int max_iter, double rtol, int check_residual) {
-  if (!h || max_iter < 0 || max_iter > 1000) return fail(FC_ERR_INVALID, "fc_set_solver_options: bad argument");
+  if (!h || max_iter < 0 || max_iter > 1000 || check_residual < 0) return fail(FC_ERR_INVALID, "fc_set_solver_options: bad argument");
   if (method != FC_METHOD_REFINE && method != FC_METHOD_BICGSTAB && method != FC_METHOD_GMRES)
     return fail(FC_ERR_INVALID, "fc_set_solver_options: unknown method (REFINE, BICGSTAB, GMRES)");
   if (method != FC_METHOD_REFINE && (max_iter < 1 || !(rtol > 0.0)))
@@ -3392,12 +3103,25 @@ int fc_set_state(fc_handle h, const double* u_n, const double* u_nn, const doubl
   h->pre_slot = -1;
   h->undo_ok = false;
   HIPCHK(hipSetDevice(h->device));
-  const size_t nv2 = 2 * (size_t)h->nn;
-  HIPCHK(hipMemcpyAsync(h->u_n.p, u_n, nv2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->u_nn.p, u_nn, nv2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  if (p_n) HIPCHK(hipMemcpyAsync(h->p_n.p, p_n, (size_t)h->nv * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  const size_t nv2 = 2 * (size_t)h->nn, N = (size_t)h->N;
+  // W-layout vectors [u | p] of both time levels (p_n = NULL keeps the present pressure)
+  std::vector<double> wn(N, 0.0), wnn(N, 0.0);
+  if (!p_n) {
+    if (h->have_perm && h->state_live) FCCHK(state_download(h, wn.data(), nullptr));
+    else if (!h->hs_n.empty()) wn = h->hs_n;
+  }
+  std::copy(u_n, u_n + nv2, wn.begin());
+  std::copy(u_nn, u_nn + nv2, wnn.begin());
+  if (p_n) std::copy(p_n, p_n + h->nv, wn.begin() + (std::ptrdiff_t)nv2);
+  std::copy(wn.begin() + (std::ptrdiff_t)nv2, wn.end(), wnn.begin() + (std::ptrdiff_t)nv2);
   HIPCHK(hipMemsetAsync(h->flag.p, 0, sizeof(int), h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->have_perm) {
+    FCCHK(state_upload(h, wn.data(), wnn.data()));
+    h->hs_n.clear(), h->hs_nn.clear();
+  } else {  // no numbering to store it in yet: fc_set_permutation takes it from here
+    h->hs_n.swap(wn), h->hs_nn.swap(wnn);
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
   return FC_OK;
 }
 
@@ -3406,10 +3130,10 @@ int fc_undo_step(fc_handle h) {
   if (h->step_pending) return fail(FC_ERR_INVALID, "fc_undo_step: collect the step first (fc_step_end)");
   if (!h->undo_ok) return fail(FC_ERR_NOT_READY, "fc_undo_step: the last state change was not a single fc_step");
   HIPCHK(hipSetDevice(h->device));
-  const size_t nv2 = 2 * (size_t)h->nn * sizeof(double);
-  HIPCHK(hipMemcpyAsync(h->u_n.p, h->u_nn.p, nv2, hipMemcpyDeviceToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->u_nn.p, h->u_old.p, nv2, hipMemcpyDeviceToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->p_n.p, h->p_old.p, (size_t)h->nv * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));  // (a speculated element loop may still be reading the withdrawn state)
+  // the step wrote its solution into a ring slot of its own: the three older levels are still where they were
+  h->cur = (h->cur + 3) % 4;
+  ring_point(h);
   HIPCHK(hipMemsetAsync(h->flag.p, 0, sizeof(int), h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->pre_slot = -1;  // a speculative element loop of the next step read the state that was just withdrawn
@@ -3420,19 +3144,23 @@ int fc_undo_step(fc_handle h) {
 int fc_get_state(fc_handle h, double* u_n, double* u_nn, double* p_n) {
   if (!h) return fail(FC_ERR_INVALID, "null handle");
   HIPCHK(hipSetDevice(h->device));
-  const size_t nv2 = 2 * (size_t)h->nn;
-  if (u_n) HIPCHK(hipMemcpyAsync(u_n, h->u_n.p, nv2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (u_nn) HIPCHK(hipMemcpyAsync(u_nn, h->u_nn.p, nv2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (p_n) HIPCHK(hipMemcpyAsync(p_n, h->p_n.p, (size_t)h->nv * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  const size_t nv2 = 2 * (size_t)h->nn, N = (size_t)h->N;
+  std::vector<double> wn(N, 0.0), wnn(N, 0.0);
+  if (h->have_perm && h->state_live) FCCHK(state_download(h, wn.data(), u_nn ? wnn.data() : nullptr));
+  else if (!h->hs_n.empty()) wn = h->hs_n, wnn = h->hs_nn;
+  if (u_n) std::copy(wn.begin(), wn.begin() + (std::ptrdiff_t)nv2, u_n);
+  if (u_nn) std::copy(wnn.begin(), wnn.begin() + (std::ptrdiff_t)nv2, u_nn);
+  if (p_n) std::copy(wn.begin() + (std::ptrdiff_t)nv2, wn.end(), p_n);
   return FC_OK;
 }
 
 int fc_get_solution(fc_handle h, double* up) {
   if (!h || !up) return fail(FC_ERR_INVALID, "fc_get_solution: null argument");
   HIPCHK(hipSetDevice(h->device));
-  HIPCHK(hipMemcpyAsync(up, h->up.p, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  // the last step's solution IS the state (u_n, p_n)
+  if (h->have_perm && h->state_live) return state_download(h, up, nullptr);
+  std::fill(up, up + h->N, 0.0);
+  if (!h->hs_n.empty()) std::copy(h->hs_n.begin(), h->hs_n.end(), up);
   return FC_OK;
 }
 
@@ -3451,8 +3179,8 @@ void speculate_next_rhs(fc_ctx* h, int order_slot) {
   const int next = h->sys[order_slot].have_c ? order_slot : FC_SLOT_BDF2;
   if (!h->sys[next].ready || !h->sys[next].have_lift) return;
   const StepCoeffs c = coeffs_for(h, next);
-  hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks((int64_t)ncl * 8, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
-                     h->u_n.p, h->u_nn.p, (const double*)nullptr, 0, h->pin_dev, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p,
+  hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks((int64_t)ncl * 8, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->cnp.p, h->geom.p,
+                     st_n(h), st_nn(h), (const double*)nullptr, 0, h->pin_dev, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p,
                      h->partitioned ? h->cell_list.p : nullptr, ncl);
   if (hipGetLastError() == hipSuccess) h->pre_slot = next;
 }
@@ -3464,7 +3192,8 @@ static int step_enqueue(fc_ctx* h) {
   double* dev = h->pin_dev;
   h->pend_seq = (double)(++h->seq);
   FCCHK(enqueue_step(h, h->pend_slot, dev, dev + 64, dev + 128, dev + 129, dev + 136, h->pend_energy, dev + 32, dev + 137, h->pend_seq));
-  h->undo_ok = true;  // the tail kept what its shift overwrote
+  h->pend_checked = h->last_checked;
+  h->undo_ok = true;  // the step wrote into a ring slot of its own: the older levels are intact
   speculate_next_rhs(h, h->pend_slot);
   return FC_OK;
 }
@@ -3495,7 +3224,7 @@ int fc_step_end(fc_handle h, double* y_out, double* dE_out, double* info_out) {
   HIPCHK(hipSetDevice(h->device));
   volatile double* pin = h->pin;
   const int compute_energy = h->pend_energy;
-  for (int attempt = 0;; ++attempt) {
+  {
     const double seq = h->pend_seq;
     // the last kernel publishes the record and `seq` with no fence: poll the host-mapped words (bounded), then fall
     // back to a stream synchronisation — which is also what reports a faulted kernel.
@@ -3537,15 +3266,6 @@ int fc_step_end(fc_handle h, double* y_out, double* dE_out, double* info_out) {
       FCCHK(phase_collect(h));
       if (!record_ok()) return fail(FC_ERR_HIP, "fc_step: the step record failed its checksum after stream synchronisation");
     }
-    if (pin[136] >= 1024.0) {
-      // the one-launch factor apply gave up (bounded wait): nothing was written to the state; redo with level launches
-      if (h->partitioned) return fail(FC_ERR_HIP, "fc_step: the one-launch factor apply gave up waiting on a partitioned handle (set FC_DAG=0)");
-      if (attempt > 0) return fail(FC_ERR_HIP, "fc_step: factor apply failed twice");
-      FCCHK(dag_recover(h));
-      FCCHK(step_enqueue(h));
-      continue;
-    }
-    break;
   }
   for (int s = 0; s < h->n_sens; ++s)
     if (y_out) y_out[s] = pin[64 + s];
@@ -3553,9 +3273,10 @@ int fc_step_end(fc_handle h, double* y_out, double* dE_out, double* info_out) {
   const int flag = ((int)pin[136]) % 1024;
   if (info_out) {
     const double r2 = pin[129], b2 = pin[130];
+    const bool checked = h->pend_checked;  // (check_residual = n > 1: the monitor ran on every n-th step only)
     info_out[0] = h->method == FC_METHOD_REFINE ? h->max_iter : h->last_krylov_iters;  // refinement sweeps / Krylov iterations
-    info_out[1] = h->check_residual ? std::sqrt(r2 / (b2 > 0 ? b2 : 1.0)) : std::numeric_limits<double>::quiet_NaN();
-    info_out[2] = h->check_residual ? std::sqrt(b2) : std::numeric_limits<double>::quiet_NaN();
+    info_out[1] = checked ? std::sqrt(r2 / (b2 > 0 ? b2 : 1.0)) : std::numeric_limits<double>::quiet_NaN();
+    info_out[2] = checked ? std::sqrt(b2) : std::numeric_limits<double>::quiet_NaN();
     info_out[3] = flag;
   }
   if (flag) return fail(FC_ERR_DIVERGED, "non-finite velocity after solve");
@@ -3584,28 +3305,17 @@ int fc_run(fc_handle h, int first_order_slot, int32_t n_steps, const double* u_c
   FCCHK(h->Eseq.alloc((size_t)n_steps));
   std::vector<double> yh((size_t)n_steps * ns), Eh(n_steps);
   int flag = 0;
-  for (int s_begin = 0, attempt = 0;; ++attempt) {
-    for (int s = s_begin; s < n_steps; ++s) {
-      const int order = s == 0 ? first_order_slot : FC_SLOT_BDF2;
-      const double* du = h->useq.p + (u_ctrl_is_sequence ? (size_t)s * h->n_act : 0);
-      FCCHK(enqueue_step(h, order, du, h->yseq.p + (size_t)s * ns, h->Eseq.p + s, h->scal.p + 1, nullptr, compute_energy, nullptr,
-                         nullptr, 0.0, s + 1));
-    }
-    int derr[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(yh.data(), h->yseq.p, yh.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(Eh.data(), h->Eseq.p, Eh.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(&flag, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(derr, h->dag_err.p, sizeof(derr), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    FCCHK(time_collect(h));
-    if (!derr[0]) break;
-    // the one-launch factor apply gave up in step derr[1]: that step and all later ones left the state untouched
-    // (fc_tail / fc_finish return early); redo them with the level launches
-    if (h->partitioned || attempt > 0 || derr[1] < 1 || derr[1] > n_steps)
-      return fail(FC_ERR_HIP, "fc_run: the one-launch factor apply gave up waiting (set FC_DAG=0)");
-    FCCHK(dag_recover(h));
-    s_begin = derr[1] - 1;
+  for (int s = 0; s < n_steps; ++s) {
+    const int order = s == 0 ? first_order_slot : FC_SLOT_BDF2;
+    const double* du = h->useq.p + (u_ctrl_is_sequence ? (size_t)s * h->n_act : 0);
+    FCCHK(enqueue_step(h, order, du, h->yseq.p + (size_t)s * ns, h->Eseq.p + s, h->scal.p + 1, nullptr, compute_energy));
   }
+  HIPCHK(hipMemcpyAsync(yh.data(), h->yseq.p, yh.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(Eh.data(), h->Eseq.p, Eh.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(&flag, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  FCCHK(time_collect(h));
+  FCCHK(phase_collect(h));
   if (y_seq)
     for (int s = 0; s < n_steps; ++s)
       for (int k = 0; k < h->n_sens; ++k) y_seq[(size_t)s * h->n_sens + k] = yh[(size_t)s * ns + k];
@@ -3632,15 +3342,6 @@ static int solve_once(fc_handle h, int slot, const double* b, double* x, double*
 
 int fc_solve(fc_handle h, int slot, const double* b, double* x, double* info_out) {
   if (!h || slot < 0 || slot > 1 || !b || !x) return fail(FC_ERR_INVALID, "fc_solve: bad argument");
-  int code = solve_once(h, slot, b, x, info_out);
-  if (code == FC_ERR_INVALID || code == FC_ERR_NOT_READY || !(h->dag_enabled && h->sys[slot].dag_ready)) return code;
-  int derr[2] = {0, 0};
-  HIPCHK(hipMemcpyAsync(derr, h->dag_err.p, sizeof(derr), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  if (!derr[0]) return code;
-  // the one-launch factor apply gave up waiting somewhere in this solve: redo it with the level launches
-  if (h->partitioned) return fail(FC_ERR_HIP, "fc_solve: the one-launch factor apply gave up waiting on a partitioned handle (set FC_DAG=0)");
-  FCCHK(dag_recover(h));
   return solve_once(h, slot, b, x, info_out);
 }
 
@@ -3735,87 +3436,6 @@ int fc_measure(fc_handle h, const double* up, double* y) {
   HIPCHK(hipMemcpyAsync(h->pin, h->ydev.p, h->n_sens * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   for (int s = 0; s < h->n_sens; ++s) y[s] = h->pin[s];
-  return FC_OK;
-}
-
-int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double* u_ctrl, double* ms,
-                     int32_t* sweep_launches) {
-  FCCHK(check_step_ready(h, order_slot));
-  if (n_steps <= 0 || !ms) return fail(FC_ERR_INVALID, "fc_profile_steps: bad argument");
-  OrderSys& S = h->sys[order_slot];
-  if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this order");
-  if (!h->have_mp) return fail(FC_ERR_NOT_READY, "fc_set_energy_matrix not called");
-  if (h->partitioned) return fail(FC_ERR_INVALID, "fc_profile_steps: single-GPU handles only");
-  h->pre_slot = -1;  // the steps below advance the state with their own launches
-  HIPCHK(hipSetDevice(h->device));
-  if (h->n_act) HIPCHK(hipMemcpyAsync(h->uctrl.p, u_ctrl, h->n_act * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  const int N = h->N, g = nblocks(N, 256);
-  const StepCoeffs c = coeffs_for(h, order_slot);
-  const double mean = (double)S.Ap_nnz / std::max(1, N);
-  double acc[5] = {0, 0, 0, 0, 0};
-  int launches = 0;
-  auto lap = [&](int phase) -> int {
-    HIPCHK(hipEventRecord(h->ev1, h->stream));
-    HIPCHK(hipEventSynchronize(h->ev1));
-    float t = 0.f;
-    HIPCHK(hipEventElapsedTime(&t, h->ev0, h->ev1));
-    acc[phase] += t;
-    HIPCHK(hipEventRecord(h->ev0, h->stream));
-    return FC_OK;
-  };
-  double* e_partial = h->partial.p + 2 * (size_t)h->nblk_N;
-  for (int s = 0; s < n_steps; ++s) {
-    launches = 0;
-    HIPCHK(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks((int64_t)h->nc * 8, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->geom.p,
-                       h->u_n.p, h->u_nn.p, (const double*)nullptr, 0, h->uctrl.p, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p,
-                       (const int*)nullptr, h->nc);
-    FCCHK(lap(0));
-    hipLaunchKernelGGL(fc_rhs_gather, dim3(g), dim3(256), 0, h->stream, N, h->gptr_p.p, h->gidx_p.p, h->ev.p,
-                       h->bcslot_p.p, h->bcprof.p, S.lift_p.p, h->n_act, h->uctrl.p, h->b.p, h->buf.p,
-                       (const unsigned char*)nullptr, 1, S.have_c ? S.c_rowptr.p : nullptr, S.c_col.p, S.c_val.p, h->u_n.p,
-                       (const unsigned char*)nullptr, h->have_force ? h->fvec.p : nullptr, h->uctrl.p);
-    FCCHK(lap(1));
-    FCCHK(apply_factors(h, S));
-    launches += (int)S.stages.size();
-    FCCHK(lap(2));
-    const double* x = h->buf.p + N;
-    const double* dx = nullptr;
-    int nrp = 0;
-    if (use_fused_tail(h)) {
-      FCCHK(launch_tail(h, S, 1, h->ydev.p, h->scal.p, h->scal.p + 1, nullptr, nullptr, 0.0));
-      FCCHK(lap(4));
-      continue;
-    }
-    if (h->max_iter == 0 && h->check_residual) {
-      nrp = launch_spmv<1>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, x, h->b.p, h->tmpN.p, nullptr, h->partial.p);
-      if (nrp < 0) return nrp;
-      FCCHK(lap(3));
-    }
-    for (int it = 0; it < h->max_iter; ++it) {
-      if (it > 0) hipLaunchKernelGGL(fc_axpy, dim3(g), dim3(256), 0, h->stream, N, 1.0, h->buf.p + N, h->xsol.p);
-      const int nb = launch_spmv<1>(h, N, mean, S.Ap_rowptr.p, S.Ap_col.p, S.Ap_val.p, it > 0 ? h->xsol.p : x, h->b.p,
-                                    h->buf.p, it > 0 ? nullptr : h->xsol.p, it == 0 && h->check_residual ? h->partial.p : nullptr);
-      if (nb < 0) return nb;
-      if (it == 0 && h->check_residual) nrp = nb;
-      x = h->xsol.p;
-      FCCHK(lap(3));
-      FCCHK(apply_factors(h, S));
-      launches += (int)S.stages.size();
-      dx = h->buf.p + N;
-      FCCHK(lap(2));
-    }
-    hipLaunchKernelGGL(fc_finish, dim3(nblocks(N, 32)), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, x, dx, h->up.p, h->u_n.p,
-                       h->u_nn.p, h->p_n.p, h->flag.p, h->mp_rowptr.p, h->mp_col.p, h->mp_val.p, e_partial,
-                       (const unsigned char*)nullptr, h->dag_err.p, h->u_old.p, h->p_old.p);
-    hipLaunchKernelGGL(fc_final, dim3(1), dim3(256), 0, h->stream, nblocks(N, 32), e_partial, h->scal.p, nrp,
-                       nrp > 0 ? h->partial.p : nullptr, h->scal.p + 1, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p,
-                       h->up.p, h->ydev.p, h->flag.p, (double*)nullptr, (double*)nullptr, 0.0, h->dag_err.p, 1);
-    FCCHK(lap(4));
-  }
-  HIPCHK(hipStreamSynchronize(h->stream));
-  for (int p = 0; p < 5; ++p) ms[p] = acc[p] / n_steps;
-  if (sweep_launches) *sweep_launches = launches;
   return FC_OK;
 }
 
@@ -3925,7 +3545,7 @@ static void forget_solver_structure(fc_ctx* h) {
   h->have_plan = false;
   h->bat.tables = false;
   h->bat.k = h->bat.KB = 0;
-  for (int o = 0; o < 2; ++o) h->sys[o].ready = h->sys[o].structured = h->sys[o].dag_ready = false;
+  for (int o = 0; o < 2; ++o) h->sys[o].ready = h->sys[o].structured = false;
 }
 
 int fc_comm_init(fc_handle h, int nranks, int rank, const char* id128) {
@@ -4067,7 +3687,7 @@ int fc_set_factor_precision(fc_handle h, int bits) {
   if (!h || (bits != 64 && bits != 32 && bits != 16)) return fail(FC_ERR_INVALID, "fc_set_factor_precision: bits must be 64, 32 or 16");
   if (bits != h->factor_bits) {
     h->factor_bits = bits;
-    for (int o = 0; o < 2; ++o) h->sys[o].ready = h->sys[o].structured = h->sys[o].dag_ready = false;  // the value arrays are laid out anew
+    for (int o = 0; o < 2; ++o) h->sys[o].ready = h->sys[o].structured = false;  // the value arrays are laid out anew
     h->bat.ftile_ok[0] = h->bat.ftile_ok[1] = false;
   }
   return FC_OK;
@@ -4156,6 +3776,11 @@ constexpr int kRecStride = 160;  // doubles per simulation in the host-mapped re
 
 // launch tables of the batched factor apply from the symbolic phase of fc_setup_solver: per tree level one block launch
 // (-L blocks on the way up, [D^-1 | -U] blocks on the way down) and, on the way up, one fold launch
+static inline double* bat_slot(const fc_ctx* h, int k) { return h->bat.ring.p + (size_t)(((k % 4) + 4) % 4) * h->bat.slot_doubles; }
+static inline double* bat_n(const fc_ctx* h) { return bat_slot(h, h->bat.cur) + (size_t)h->N * h->bat.KB; }       // (u_n, p_n) of all simulations
+static inline double* bat_nn(const fc_ctx* h) { return bat_slot(h, h->bat.cur + 3) + (size_t)h->N * h->bat.KB; }  // u_nn
+static inline void bat_point(fc_ctx* h) { h->bat.buf.p = bat_slot(h, h->bat.cur + 1); }
+
 static int build_batch_tables(fc_ctx* h) {
   fc_ctx::Batch& B = h->bat;
   if (B.tables) return FC_OK;
@@ -4415,22 +4040,29 @@ int fc_set_batch(fc_handle h, int32_t k) {
   if (k == 0) {
     HIPCHK(hipStreamSynchronize(h->stream));
     batch_drop_graphs(h);
-    B.u_n.release(), B.u_nn.release(), B.p_n.release(), B.up.release(), B.b.release(), B.buf.release(), B.ev.release(), B.partial.release();
+    B.ring.release(), B.b.release(), B.ev.release(), B.partial.release();
+    B.buf = fc_ctx::BufView{};
     B.flag.release();
+    // ... and everything fc_set_batch(k > 0) tabulates: the tiled copies of both slots' factors (each >= the factor size), task
+    // lists, fold lists, tail blocks -- a handle that goes back to single-run stepping must not keep holding them, nor pay a
+    // repack per fc_refactor
+    B.ftile[0].release(), B.ftile[1].release();
+    B.ftile_ok[0] = B.ftile_ok[1] = false;
+    B.tasks.release(), B.olist.release(), B.fptr.release(), B.fsrc.release(), B.tblocks.release(), B.tcols.release(), B.tlidx.release();
+    B.launches.clear();
+    B.tables = false;
     B.k = B.KB = 0;
     return FC_OK;
   }
   FCCHK(build_batch_tables(h));
   h->bat.pre_slot = -1;  // the state below is zeroed
   const int KB = k <= 4 ? 4 : (k <= 8 ? 8 : 16);
-  const size_t N = (size_t)h->N, nn2 = 2 * (size_t)h->nn;
-  if (KB != B.KB) {
-    FCCHK(B.u_n.alloc(nn2 * KB));
-    FCCHK(B.u_nn.alloc(nn2 * KB));
-    FCCHK(B.p_n.alloc((size_t)h->nv * KB));
-    FCCHK(B.up.alloc(N * KB));
+  const size_t N = (size_t)h->N;
+  if (KB != B.KB || !B.ring.p) {
+    B.slot_doubles = (2 * N + (size_t)B.scratch_rows + 1) * KB;  // + the zero row of the operand lists
+    FCCHK(B.ring.alloc(4 * B.slot_doubles));
+    B.buf.n = B.slot_doubles;
     FCCHK(B.b.alloc(N * KB));
-    FCCHK(B.buf.alloc((2 * N + (size_t)B.scratch_rows + 1) * KB));  // + the zero row of the operand lists
     FCCHK(B.ev.alloc((size_t)12 * h->nc * KB));
     FCCHK(B.partial.alloc((size_t)3 * ((size_t)B.n_tblocks + (size_t)nblocks(h->nc, 256 / (8 * KB)) + 1) * KB));
     FCCHK(B.flag.alloc(16));
@@ -4439,7 +4071,9 @@ int fc_set_batch(fc_handle h, int32_t k) {
   B.KB = KB;
   for (int o = 0; o < 2; ++o)
     if (h->sys[o].ready && !B.ftile_ok[o]) FCCHK(batch_repack(h, o));
-  for (DevBuf<double>* d : {&B.u_n, &B.u_nn, &B.p_n, &B.up, &B.b, &B.buf, &B.ev, &B.partial}) FCCHK(d->zero(h->stream));
+  for (DevBuf<double>* d : {&B.ring, &B.b, &B.ev, &B.partial}) FCCHK(d->zero(h->stream));
+  B.cur = 0;
+  bat_point(h);
   FCCHK(B.flag.zero(h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return FC_OK;
@@ -4453,13 +4087,14 @@ static int batch_check(fc_ctx* h, int32_t k, const char* who) {
 }
 
 // host [k][n] <-> device [n][KB]
-static int batch_copy(fc_ctx* h, int n, double* host, double* dev, bool to_device) {
+// (perm != nullptr: device rows are in the solver's permuted numbering, host vectors in the W layout)
+static int batch_copy(fc_ctx* h, int n, double* host, double* dev, bool to_device, const int* perm = nullptr) {
   fc_ctx::Batch& B = h->bat;
   DevBuf<double> stage;
   FCCHK(stage.alloc((size_t)n * B.k));
   const int g = nblocks((int64_t)n * B.KB, 256);
   if (to_device) HIPCHK(hipMemcpyAsync(stage.p, host, (size_t)n * B.k * sizeof(double), hipMemcpyHostToDevice, h->stream));
-#define FC_IL(K) hipLaunchKernelGGL((fc_b_interleave<K>), dim3(g), dim3(256), 0, h->stream, n, B.k, to_device ? stage.p : dev, to_device ? dev : stage.p, to_device ? 1 : 0)
+#define FC_IL(K) hipLaunchKernelGGL((fc_b_interleave<K>), dim3(g), dim3(256), 0, h->stream, n, B.k, to_device ? stage.p : dev, to_device ? dev : stage.p, to_device ? 1 : 0, perm)
   FC_KB_DISPATCH(B.KB, FC_IL(4), FC_IL(8), FC_IL(16));
 #undef FC_IL
   if (!to_device) HIPCHK(hipMemcpyAsync(host, stage.p, (size_t)n * B.k * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -4467,15 +4102,30 @@ static int batch_copy(fc_ctx* h, int n, double* host, double* dev, bool to_devic
   return FC_OK;
 }
 
+// W-layout host vectors [k][N] = [u (2 nn) | p (nv)] of every simulation from the caller's split arrays
+static void batch_pack_w(const fc_ctx* h, int k, const double* u, const double* p, std::vector<double>& w) {
+  const size_t N = (size_t)h->N, nv2 = 2 * (size_t)h->nn;
+  for (int s = 0; s < k; ++s) {
+    if (u) std::copy(u + (size_t)s * nv2, u + (size_t)(s + 1) * nv2, w.begin() + (std::ptrdiff_t)(s * N));
+    if (p) std::copy(p + (size_t)s * h->nv, p + (size_t)(s + 1) * h->nv, w.begin() + (std::ptrdiff_t)(s * N + nv2));
+  }
+}
+
 int fc_set_state_batch(fc_handle h, int32_t k, const double* u_n, const double* u_nn, const double* p_n) {
   FCCHK(batch_check(h, k, "fc_set_state_batch"));
   if (!u_n || !u_nn) return fail(FC_ERR_INVALID, "fc_set_state_batch: null argument");
+  if (!h->have_perm) return fail(FC_ERR_NOT_READY, "fc_set_state_batch: no permutation (fc_setup_solver)");
   HIPCHK(hipSetDevice(h->device));
   fc_ctx::Batch& B = h->bat;
   B.pre_slot = -1;  // element vectors of the old state
-  FCCHK(batch_copy(h, 2 * h->nn, const_cast<double*>(u_n), B.u_n.p, true));
-  FCCHK(batch_copy(h, 2 * h->nn, const_cast<double*>(u_nn), B.u_nn.p, true));
-  if (p_n) FCCHK(batch_copy(h, h->nv, const_cast<double*>(p_n), B.p_n.p, true));
+  const size_t N = (size_t)h->N;
+  std::vector<double> wn((size_t)k * N, 0.0), wnn((size_t)k * N, 0.0);
+  if (!p_n) FCCHK(batch_copy(h, h->N, wn.data(), bat_n(h), false, h->perm.p));  // keeps the present pressure
+  batch_pack_w(h, k, u_n, p_n, wn);
+  for (int s = 0; s < k; ++s) std::copy(wn.begin() + (std::ptrdiff_t)(s * N), wn.begin() + (std::ptrdiff_t)((s + 1) * N), wnn.begin() + (std::ptrdiff_t)(s * N));
+  batch_pack_w(h, k, u_nn, nullptr, wnn);
+  FCCHK(batch_copy(h, h->N, wn.data(), bat_n(h), true, h->perm.p));
+  FCCHK(batch_copy(h, h->N, wnn.data(), bat_nn(h), true, h->perm.p));
   FCCHK(B.flag.zero(h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return FC_OK;
@@ -4484,10 +4134,19 @@ int fc_set_state_batch(fc_handle h, int32_t k, const double* u_n, const double* 
 int fc_get_state_batch(fc_handle h, int32_t k, double* u_n, double* u_nn, double* p_n) {
   FCCHK(batch_check(h, k, "fc_get_state_batch"));
   HIPCHK(hipSetDevice(h->device));
-  fc_ctx::Batch& B = h->bat;
-  if (u_n) FCCHK(batch_copy(h, 2 * h->nn, u_n, B.u_n.p, false));
-  if (u_nn) FCCHK(batch_copy(h, 2 * h->nn, u_nn, B.u_nn.p, false));
-  if (p_n) FCCHK(batch_copy(h, h->nv, p_n, B.p_n.p, false));
+  const size_t N = (size_t)h->N, nv2 = 2 * (size_t)h->nn;
+  std::vector<double> w((size_t)k * N);
+  if (u_n || p_n) {
+    FCCHK(batch_copy(h, h->N, w.data(), bat_n(h), false, h->perm.p));
+    for (int s = 0; s < k; ++s) {
+      if (u_n) std::copy(w.begin() + (std::ptrdiff_t)(s * N), w.begin() + (std::ptrdiff_t)(s * N + nv2), u_n + (size_t)s * nv2);
+      if (p_n) std::copy(w.begin() + (std::ptrdiff_t)(s * N + nv2), w.begin() + (std::ptrdiff_t)((s + 1) * N), p_n + (size_t)s * h->nv);
+    }
+  }
+  if (u_nn) {
+    FCCHK(batch_copy(h, h->N, w.data(), bat_nn(h), false, h->perm.p));
+    for (int s = 0; s < k; ++s) std::copy(w.begin() + (std::ptrdiff_t)(s * N), w.begin() + (std::ptrdiff_t)(s * N + nv2), u_nn + (size_t)s * nv2);
+  }
   return FC_OK;
 }
 
@@ -4495,7 +4154,29 @@ int fc_get_solution_batch(fc_handle h, int32_t k, double* up) {
   FCCHK(batch_check(h, k, "fc_get_solution_batch"));
   if (!up) return fail(FC_ERR_INVALID, "fc_get_solution_batch: null argument");
   HIPCHK(hipSetDevice(h->device));
-  return batch_copy(h, h->N, up, h->bat.up.p, false);
+  return batch_copy(h, h->N, up, bat_n(h), false, h->perm.p);  // the last step's solution IS the state (u_n, p_n)
+}
+
+// Take simulation s out of the batch's dynamics: its state (both time levels) becomes zero and its non-finite flag is cleared.
+// What a host does with a run that diverged (FC_ERR_DIVERGED, info[s][3]): the columns are independent, so the other runs are
+// unaffected either way, but a column full of Inf / NaN would raise the flag again on every later step.
+int fc_reset_sim_batch(fc_handle h, int32_t s) {
+  if (!h || h->bat.k == 0) return fail(FC_ERR_NOT_READY, "fc_reset_sim_batch: fc_set_batch not called");
+  if (s < 0 || s >= h->bat.k) return fail(FC_ERR_INVALID, "fc_reset_sim_batch: no such simulation");
+  if (h->bat.pending) return fail(FC_ERR_INVALID, "fc_reset_sim_batch: a step is in flight");
+  HIPCHK(hipSetDevice(h->device));
+  fc_ctx::Batch& B = h->bat;
+  B.pre_slot = -1;
+  const int g = nblocks(h->N, 256);
+  for (double* d : {bat_n(h), bat_nn(h)}) {
+#define FC_ZC(K) hipLaunchKernelGGL((fc_b_zero_column<K>), dim3(g), dim3(256), 0, h->stream, h->N, s, d)
+    FC_KB_DISPATCH(B.KB, FC_ZC(4), FC_ZC(8), FC_ZC(16));
+#undef FC_ZC
+  }
+  const int zero = 0;
+  HIPCHK(hipMemcpyAsync(B.flag.p + s, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return FC_OK;
 }
 
 // the launches of one batched step; controls are read from the host-mapped record (uctrl at s * kRecStride, body-force
@@ -4511,35 +4192,39 @@ static int batch_launches(fc_ctx* h, int order_slot, int compute_energy, bool le
   const double* uc = h->pin_dev;
   const double* uf = h->pin_dev + 32;
   const int g_elem = nblocks(nc, 256 / (8 * KB)), g_rows = nblocks((int64_t)N * (KB / 2), 256);
-  auto element_loop = [&](const StepCoeffs& c) {
-#define FC_ELEM(K) hipLaunchKernelGGL((fc_rhs_elem_b<K>), dim3(g_elem), dim3(256), 0, h->stream, nc, h->nn, h->cn.p, h->geom.p, B.u_n.p, B.u_nn.p, \
+  // the state ring: this step reads (u_n, u_nn) from slots cur, cur - 1 and writes its solution -- the new state -- into the x
+  // half of slot cur + 1 (= B.buf); the caller moves `cur` on afterwards
+  const double* un = bat_n(h);
+  const double* unn = bat_nn(h);
+  double* xnew = B.buf.p + (size_t)N * KB;
+  auto element_loop = [&](const StepCoeffs& c, const double* u1, const double* u2) {
+#define FC_ELEM(K) hipLaunchKernelGGL((fc_rhs_elem_b<K>), dim3(g_elem), dim3(256), 0, h->stream, nc, h->nn, h->cn.p, h->cnp.p, h->geom.p, u1, u2, \
                                       h->have_force ? h->fprof.p : nullptr, h->have_force ? h->n_act : 0, uf, kRecStride, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, B.ev.p)
     FC_KB_DISPATCH(KB, FC_ELEM(4), FC_ELEM(8), FC_ELEM(16));
 #undef FC_ELEM
   };
-  if (lead_elem) element_loop(coeffs_for(h, order_slot));
+  if (lead_elem) element_loop(coeffs_for(h, order_slot), un, unn);
 #define FC_GATH(K) hipLaunchKernelGGL((fc_rhs_gather_b<K>), dim3(g_rows), dim3(256), 0, h->stream, N, h->gptr_p.p, h->gidx_p.p, B.ev.p, h->bcslot_p.p, \
                                       h->bcprof.p, S.lift_p.p, h->n_act, uc, kRecStride, B.b.p, B.buf.p, S.have_c ? S.c_rowptr.p : nullptr, S.c_col.p, \
-                                      S.c_val.p, B.u_n.p)
+                                      S.c_val.p, un)
   FC_KB_DISPATCH(KB, FC_GATH(4), FC_GATH(8), FC_GATH(16));
 #undef FC_GATH
   FCCHK(batch_apply(h, order_slot));
-  // tail: residual monitor, scatter / shift, energy
+  // tail: residual monitor, non-finite flags, energy (the solution stays where it is: it is the new state)
   if ((int64_t)B.tlidx.n != S.Ap_nnz && S.Ap_nnz > 0) return fail(FC_ERR_INVALID, "fc_step_batch: tail tables and system pattern disagree");
   const int cpb = 256 / (8 * KB);
   const int n_row_blocks = B.n_tblocks, n_cell_blocks = compute_energy ? nblocks(nc, cpb) : 0;
   const int G = n_row_blocks + n_cell_blocks;
   if ((size_t)3 * G * KB > B.partial.n) return fail(FC_ERR_INVALID, "fc_step_batch: partial buffer too small");
-#define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(256), 0, h->stream, N, 2 * h->nn, h->perm.p, B.buf.p + (size_t)N * K, B.b.p, B.tblocks.p, \
-                                       B.tcols.p, S.Ap_rowptr.p, B.tlidx.p, S.Ap_val.p, B.up.p, B.u_n.p, B.u_nn.p, B.p_n.p, B.flag.p, B.partial.p, G,   \
-                                       n_cell_blocks, nc, h->cn.p, h->geom.p, h->iperm.p)
+#define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(256), 0, h->stream, N, h->velrow_p.p, xnew, B.b.p, B.tblocks.p, \
+                                       B.tcols.p, S.Ap_rowptr.p, B.tlidx.p, S.Ap_val.p, B.flag.p, B.partial.p, G, n_cell_blocks, nc, h->cnp.p, h->geom.p)
   FC_KB_DISPATCH(KB, FC_TAILB(4), FC_TAILB(8), FC_TAILB(16));
 #undef FC_TAILB
-#define FC_FINB(K) hipLaunchKernelGGL((fc_final_b<K>), dim3(B.k), dim3(1024), 0, h->stream, G, n_row_blocks, B.partial.p, h->n_sens, h->s_rowptr.p, h->s_idx.p, \
-                                      h->s_w.p, B.up.p, B.flag.p, h->pin_dev, kRecStride, h->pin_dev + kSeqSlot, compute_energy)
+#define FC_FINB(K) hipLaunchKernelGGL((fc_final_b<K>), dim3(B.k), dim3(1024), 0, h->stream, G, n_row_blocks, B.partial.p, h->n_sens, h->s_rowptr.p, h->s_idxp.p, \
+                                      h->s_w.p, xnew, B.flag.p, h->pin_dev, kRecStride, h->pin_dev + kSeqSlot, compute_energy)
   FC_KB_DISPATCH(KB, FC_FINB(4), FC_FINB(8), FC_FINB(16));
 #undef FC_FINB
-  if (spec_slot >= 0) element_loop(coeffs_for(h, spec_slot));
+  if (spec_slot >= 0) element_loop(coeffs_for(h, spec_slot), xnew, un);  // the NEXT step's loop: its (u_n, u_nn) = (this solution, this u_n)
   HIPCHK(hipGetLastError());
   return FC_OK;
 }
@@ -4556,12 +4241,12 @@ static uint64_t batch_signature(fc_ctx* h, int order_slot, int compute_energy, b
     return u;
   };
   const uint64_t words[] = {
-      (uint64_t)(uintptr_t)h->cn.p, (uint64_t)(uintptr_t)h->geom.p, (uint64_t)(uintptr_t)B.u_n.p, (uint64_t)(uintptr_t)B.u_nn.p, (uint64_t)(uintptr_t)h->fprof.p,
+      (uint64_t)(uintptr_t)h->cn.p, (uint64_t)(uintptr_t)h->geom.p, (uint64_t)(uintptr_t)bat_n(h), (uint64_t)(uintptr_t)bat_nn(h), (uint64_t)(uintptr_t)h->cnp.p, (uint64_t)(uintptr_t)h->fprof.p,
       (uint64_t)(uintptr_t)B.ev.p, (uint64_t)(uintptr_t)h->gptr_p.p, (uint64_t)(uintptr_t)h->gidx_p.p, (uint64_t)(uintptr_t)h->bcslot_p.p,
       (uint64_t)(uintptr_t)h->bcprof.p, (uint64_t)(uintptr_t)S.lift_p.p, (uint64_t)(uintptr_t)B.b.p, (uint64_t)(uintptr_t)B.buf.p, (uint64_t)(uintptr_t)S.c_rowptr.p,
       (uint64_t)(uintptr_t)S.c_col.p, (uint64_t)(uintptr_t)S.c_val.p, (uint64_t)(uintptr_t)B.tasks.p, (uint64_t)(uintptr_t)B.olist.p, (uint64_t)(uintptr_t)B.ftile[order_slot].p,
       (uint64_t)(uintptr_t)B.fptr.p, (uint64_t)(uintptr_t)B.fsrc.p, (uint64_t)(uintptr_t)h->perm.p, (uint64_t)(uintptr_t)h->iperm.p, (uint64_t)(uintptr_t)S.Ap_rowptr.p,
-      (uint64_t)(uintptr_t)S.Ap_col.p, (uint64_t)(uintptr_t)S.Ap_val.p, (uint64_t)(uintptr_t)B.up.p, (uint64_t)(uintptr_t)B.p_n.p, (uint64_t)(uintptr_t)B.flag.p,
+      (uint64_t)(uintptr_t)S.Ap_col.p, (uint64_t)(uintptr_t)S.Ap_val.p, (uint64_t)(uintptr_t)h->velrow_p.p, (uint64_t)(uintptr_t)h->s_idxp.p, (uint64_t)(uintptr_t)B.flag.p,
       (uint64_t)(uintptr_t)B.partial.p, (uint64_t)(uintptr_t)h->s_rowptr.p, (uint64_t)(uintptr_t)h->s_idx.p, (uint64_t)(uintptr_t)h->s_w.p,
       (uint64_t)(uintptr_t)h->pin_dev, (uint64_t)(uintptr_t)B.tblocks.p, (uint64_t)(uintptr_t)B.tcols.p, (uint64_t)(uintptr_t)B.tlidx.p, (uint64_t)B.n_tblocks, (uint64_t)B.k, (uint64_t)B.KB, (uint64_t)h->n_act, (uint64_t)h->n_sens, (uint64_t)(h->have_force ? 1 : 0),
       (uint64_t)(S.have_c ? 1 : 0), (uint64_t)compute_energy, (uint64_t)B.launches.size(), (uint64_t)B.tasks.n, bits(c.cm_n), bits(c.cm_nn), bits(c.cc_n),
@@ -4578,13 +4263,14 @@ static uint64_t batch_signature(fc_ctx* h, int order_slot, int compute_energy, b
 }
 
 static void batch_drop_graphs(fc_ctx* h) {
-  for (int o = 0; o < 2; ++o)
-    for (int e = 0; e < 2; ++e)
-      for (int l = 0; l < 2; ++l) {
-        if (h->bat.gexec[o][e][l]) (void)hipGraphExecDestroy(h->bat.gexec[o][e][l]);
-        h->bat.gexec[o][e][l] = nullptr;
-        h->bat.gsig[o][e][l] = 0;
-      }
+  for (int ph = 0; ph < 4; ++ph)
+    for (int o = 0; o < 2; ++o)
+      for (int e = 0; e < 2; ++e)
+        for (int l = 0; l < 2; ++l) {
+          if (h->bat.gexec[ph][o][e][l]) (void)hipGraphExecDestroy(h->bat.gexec[ph][o][e][l]);
+          h->bat.gexec[ph][o][e][l] = nullptr;
+          h->bat.gsig[ph][o][e][l] = 0;
+        }
   h->bat.pre_slot = -1;
 }
 
@@ -4607,16 +4293,22 @@ static int batch_enqueue(fc_ctx* h, int order_slot, int compute_energy) {
   }
   const bool lead = B.pre_slot != order_slot || h->have_force;
   B.pre_slot = -1;
+  auto advance = [&]() {  // the solution this step writes is the state from here on
+    B.cur = (B.cur + 1) % 4;
+    bat_point(h);
+    B.pre_slot = spec_slot;
+  };
   if (!use_graph || h->timing) {
     FCCHK(batch_launches(h, order_slot, compute_energy, lead, spec_slot));
-    B.pre_slot = spec_slot;
+    advance();
     return FC_OK;
   }
-  const int ei = compute_energy ? 1 : 0, li = lead ? 1 : 0;
+  const int ph = B.cur, ei = compute_energy ? 1 : 0, li = lead ? 1 : 0;  // one graph per ring phase: the buffers rotate with period four
   const uint64_t sig = batch_signature(h, order_slot, compute_energy, lead, spec_slot);
-  if (!B.gexec[order_slot][ei][li] || B.gsig[order_slot][ei][li] != sig) {
-    if (B.gexec[order_slot][ei][li]) (void)hipGraphExecDestroy(B.gexec[order_slot][ei][li]);
-    B.gexec[order_slot][ei][li] = nullptr;
+  hipGraphExec_t& gx = B.gexec[ph][order_slot][ei][li];
+  if (!gx || B.gsig[ph][order_slot][ei][li] != sig) {
+    if (gx) (void)hipGraphExecDestroy(gx);
+    gx = nullptr;
     hipGraph_t graph = nullptr;
     HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     const int code = batch_launches(h, order_slot, compute_energy, lead, spec_slot);
@@ -4626,13 +4318,13 @@ static int batch_enqueue(fc_ctx* h, int order_slot, int compute_energy) {
       return code;
     }
     if (e != hipSuccess) return fail(FC_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-    const hipError_t e2 = hipGraphInstantiate(&B.gexec[order_slot][ei][li], graph, nullptr, nullptr, 0);
+    const hipError_t e2 = hipGraphInstantiate(&gx, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (e2 != hipSuccess) return fail(FC_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2));
-    B.gsig[order_slot][ei][li] = sig;
+    B.gsig[ph][order_slot][ei][li] = sig;
   }
-  HIPCHK(hipGraphLaunch(B.gexec[order_slot][ei][li], h->stream));
-  B.pre_slot = spec_slot;
+  HIPCHK(hipGraphLaunch(gx, h->stream));
+  advance();
   return FC_OK;
 }
 

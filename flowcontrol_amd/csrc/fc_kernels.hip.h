@@ -27,7 +27,10 @@ __constant__ double c_qw[FC_NQ];             // weights (sum = 1; times |detJ|/2
 // Element vectors go to ev[slot][cell] (slot = a + 6 j), summed per dof by fc_rhs_gather
 // (wavefront-independent, deterministic).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fc_rhs_elem(int nc, int nn, const int* __restrict__ cn,
+// un / unn: the velocity-pressure state vectors in the solver's PERMUTED numbering (they are solution halves of the
+// sweep work buffer, never copied: fc_hip.hip "state ring"); cnp[a][c] / cnp[6 + a][c] = permuted position of the x- / y-
+// velocity dof of node a of cell c.  cn (node ids) is only needed to address a body-force profile (fprof, W layout).
+__global__ __launch_bounds__(256) void fc_rhs_elem(int nc, int nn, const int* __restrict__ cn, const int* __restrict__ cnp,
                                                    const double* __restrict__ geom,
                                                    const double* __restrict__ un,
                                                    const double* __restrict__ unn,
@@ -47,17 +50,20 @@ __global__ __launch_bounds__(256) void fc_rhs_elem(int nc, int nn, const int* __
   __shared__ double sh[6][32 * 9];
   const int cb = (threadIdx.x >> 3) * 9;
   if (lane < 6) {
-    const int n = cn[lane * nc + c];
+    const int ix = cnp[lane * nc + c], iy = cnp[(6 + lane) * nc + c];
     double fx = 0.0, fy = 0.0;
-    for (int k = 0; k < n_act; ++k) {
-      const double uk = uctrl[k];
-      fx += uk * fprof[(size_t)k * 2 * nn + n];
-      fy += uk * fprof[(size_t)k * 2 * nn + nn + n];
+    if (n_act > 0) {
+      const int n = cn[lane * nc + c];
+      for (int k = 0; k < n_act; ++k) {
+        const double uk = uctrl[k];
+        fx += uk * fprof[(size_t)k * 2 * nn + n];
+        fy += uk * fprof[(size_t)k * 2 * nn + nn + n];
+      }
     }
-    sh[0][cb + lane] = un[n];
-    sh[1][cb + lane] = un[nn + n];
-    sh[2][cb + lane] = unn[n];
-    sh[3][cb + lane] = unn[nn + n];
+    sh[0][cb + lane] = un[ix];
+    sh[1][cb + lane] = un[iy];
+    sh[2][cb + lane] = unn[ix];
+    sh[3][cb + lane] = unn[iy];
     sh[4][cb + lane] = fx;
     sh[5][cb + lane] = fy;
   }
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(256) void fc_rhs_gather(int N, const int* __restric
                                                      const double* __restrict__ uforce = nullptr) {
   // rowkind (multi-GPU): 0 = another rank's row, 1 = owned, 2 = root separator shared by all ranks
   // (every rank adds its cells' share; the BC value / lifting is added once, by the lead rank; of an explicit operator's
-  // root rows every rank takes the columns it accounts for -- colkind: the dof kinds in the W numbering of `un`)
+  // root rows every rank takes the columns it accounts for -- colkind: the dof kinds in the numbering of `un`, the permuted one)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   double s = 0.0;
@@ -801,53 +807,28 @@ __global__ void fc_lin3(int n, double* out, double c0, const double* v0, double 
   }
 }
 
-// x (permuted) [+ dx] -> up (W layout); shift u_nn <- u_n <- u, p_n <- p; non-finite flag
-// (reference flowsolver.py:730-731,746-751,816-819).  Fused: per-row share of the perturbation
-// energy 1/2 u^T M u (flowsolver.py:827-829) with the velocity mass matrix in permuted numbering
-// (Mp rows of pressure dofs are empty) -> one partial per block, summed by fc_final.
-__global__ __launch_bounds__(256) void fc_finish(int N, int nn2, const int* __restrict__ perm,
-                                                 const double* __restrict__ x,
-                                                 const double* __restrict__ dx, double* __restrict__ up,
-                                                 double* __restrict__ u_n, double* __restrict__ u_nn,
-                                                 double* __restrict__ p_n, int* __restrict__ flag,
-                                                 const int* __restrict__ m_rowptr,
-                                                 const int* __restrict__ m_col,
-                                                 const double* __restrict__ m_val,
-                                                 double* __restrict__ e_partial,
-                                                 const unsigned char* __restrict__ rowkind,
-                                                 const int* __restrict__ err, double* __restrict__ u_old,
-                                                 double* __restrict__ p_old) {  // u_old / p_old: what the shift overwrites (fc_undo_step)
-  if (err && err[0]) return;  // the factor apply gave up (fc_nd_dag): leave the state as it is, the host redoes the step
-  // 8 lanes per (permuted) row: they share the mass-matrix row of the energy term (coalesced 8 x 12 B
-  // per trip), lane 0 scatters / shifts the row's dof
+// The un-fused end of a step (iterative refinement, Krylov solves): x is the new (v, p) in the permuted numbering, already in
+// place in the state ring (nothing is copied or shifted: fc_hip.hip "state ring").  Non-finite flag over the velocity rows
+// (reference flowsolver.py:730-731,816-819) and, fused, the per-row share of the perturbation energy 1/2 u^T M u
+// (flowsolver.py:827-829) with the velocity mass matrix in permuted numbering (Mp rows of pressure dofs are empty) -> one
+// partial per block, summed by fc_final.
+__global__ __launch_bounds__(256) void fc_finish(int N, const unsigned char* __restrict__ velrow, const double* __restrict__ x,
+                                                 int* __restrict__ flag, const int* __restrict__ m_rowptr,
+                                                 const int* __restrict__ m_col, const double* __restrict__ m_val,
+                                                 double* __restrict__ e_partial, const unsigned char* __restrict__ rowkind) {
+  // 8 lanes per (permuted) row: they share the mass-matrix row of the energy term (coalesced 8 x 12 B per trip)
   constexpr int LANES = 8, RPB = 256 / LANES;
   const int lane = threadIdx.x % LANES;
   const int i = blockIdx.x * RPB + threadIdx.x / LANES;
   double e = 0.0;
-  if (i < N && (!rowkind || rowkind[i] != 0)) {
-    const int r = perm[i];
-    const double v = dx ? x[i] + dx[i] : x[i];
-    if (r < nn2) {
-      if (m_rowptr) {
-        double s = 0.0;
-        for (int k = m_rowptr[i] + lane; k < m_rowptr[i + 1]; k += LANES) {
-          const int j = m_col[k];
-          s += m_val[k] * (dx ? x[j] + dx[j] : x[j]);
-        }
-        e = v * s;
-      }
-      if (lane == 0) {
-        up[r] = v;
-        u_old[r] = u_nn[r];
-        u_nn[r] = u_n[r];
-        u_n[r] = v;
-        if (!isfinite(v)) atomicOr(flag, 1);
-      }
-    } else if (lane == 0) {
-      up[r] = v;
-      p_old[r - nn2] = p_n[r - nn2];
-      p_n[r - nn2] = v;
+  if (i < N && velrow[i] && (!rowkind || rowkind[i] != 0)) {
+    const double v = x[i];
+    if (m_rowptr) {
+      double s = 0.0;
+      for (int k = m_rowptr[i] + lane; k < m_rowptr[i + 1]; k += LANES) s += m_val[k] * x[m_col[k]];
+      e = v * s;
     }
+    if (lane == 0 && !isfinite(v)) atomicOr(flag, 1);
   }
   if (e_partial) {
     __shared__ double red[256];
@@ -913,8 +894,8 @@ __device__ inline void fc_publish(const double* ysrc, int n_sens, double E, doub
 }
 
 // tail of a step, ONE workgroup: folds the energy partials (-> E = 1/2 sum) and, if present, the
-// residual partials (sum r^2, sum b^2), evaluates the sensor rows (y_s = sum_k w[k] up[idx[k]],
-// sensor.py:96-98,166-197) and publishes everything to the (host-mapped) record with its checksums
+// residual partials (sum r^2, sum b^2), evaluates the sensor rows (y_s = sum_k w[k] x[idxp[k]]: the new solution in the
+// permuted numbering, idxp = the sensor dofs' permuted positions; sensor.py:96-98,166-197) and publishes everything to the (host-mapped) record with its checksums
 // (fc_publish: no fence, the host validates what it reads), so the host can poll it instead of
 // synchronising the stream.  Fixed summation order => reproducible.
 // SC1: the partials were written by other workgroups of the SAME launch (fc_tail's last arriver) and are read at
@@ -925,10 +906,9 @@ __device__ __forceinline__ void fc_final_body(int n_e, const double* __restrict_
                                               const int* __restrict__ s_rowptr, const int* __restrict__ s_idx,
                                               const double* __restrict__ s_w, const double* __restrict__ up, double* __restrict__ y,
                                               const int* __restrict__ flag, double* __restrict__ flag_out,
-                                              double* __restrict__ seq_out, double seq, int* err, int step_id) {
+                                              double* __restrict__ seq_out, double seq) {
   auto ld = [](const double* q) -> double { return SC1 ? fc_ld_sc1(q) : *q; };
-  // flag word of the record: bit 0 = non-finite velocity, + 1024 when the one-launch factor apply gave up
-  // (err[0]; the first step that sees it leaves its id in err[1]) -- partitioned runs sum the word over the ranks
+  // flag word of the record: bit 0 = non-finite velocity -- partitioned runs sum the word over the ranks
   __shared__ double red[3][256];
   const int t = threadIdx.x;
   // a single workgroup is pure latency: issue every load up front (8 partials per thread and array,
@@ -979,11 +959,7 @@ __device__ __forceinline__ void fc_final_body(int n_e, const double* __restrict_
     __syncthreads();
   }
   if (t == 0) {
-    double fl = flag ? (double)((SC1 ? __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : flag[0]) & 1) : 0.0;
-    if (err && err[0]) {
-      fl += 1024.0;
-      if (err[1] == 0) err[1] = step_id;
-    }
+    const double fl = flag ? (double)((SC1 ? __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : flag[0]) & 1) : 0.0;
     fc_publish(ysh, n_sens, e_partial ? 0.5 * red[0][0] : 0.0, r_partial ? red[1][0] : 0.0, r_partial ? red[2][0] : 0.0,
                fl, y, E_out, r_out, flag_out, seq_out, seq);
   }
@@ -998,9 +974,8 @@ __global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restric
                                                 const double* __restrict__ s_w,
                                                 const double* __restrict__ up, double* __restrict__ y,
                                                 const int* __restrict__ flag, double* __restrict__ flag_out,
-                                                double* __restrict__ seq_out, double seq, int* err, int step_id) {
-  fc_final_body<false>(n_e, e_partial, E_out, n_r, r_partial, r_out, n_sens, s_rowptr, s_idx, s_w, up, y, flag, flag_out, seq_out, seq,
-                       err, step_id);
+                                                double* __restrict__ seq_out, double seq) {
+  fc_final_body<false>(n_e, e_partial, E_out, n_r, r_partial, r_out, n_sens, s_rowptr, s_idx, s_w, up, y, flag, flag_out, seq_out, seq);
 }
 
 // what the LAST workgroup of a fused fc_tail does instead of a separate fc_final launch (enabled: cnt != nullptr)
@@ -1009,7 +984,7 @@ struct FcFin {
   int group, n_groups;   // workgroups per group; groups
   int n_sens;
   const int* s_rowptr;
-  const int* s_idxp;     // sensor dofs as positions in the sweep buffer (N + permuted index: its x half)
+  const int* s_idxp;     // sensor dofs as positions in the permuted solution
   const double* s_w;
   double* y;
   double* E_out;
@@ -1017,86 +992,54 @@ struct FcFin {
   double* flag_out;
   double* seq_out;
   double seq;
-  int step_id;
 };
 
 // ---------------------------------------------------------------------------------------------
-// Fused tail of a single-GPU step (residual monitor + state shift + energy in ONE launch, fc_final
-// follows).  Row workgroups: 8 lanes per permuted row evaluate r_i = b_i - (A x)_i (flowsolver.py:729's
-// solve, checked).  Shift workgroups: the new state, dof by dof in the W order.  Cell workgroups: the energy
-// integral of the new velocity, element by element.  Every workgroup leaves (sum r^2 | sum b^2 | sum e)
-// in `partial` (three arrays of gridDim.x) for fc_final.
+// Tail of a step in ONE launch (fc_final follows).  The new state needs no work: the solution half of the sweep buffer IS
+// the new (v, p) -- state vectors live in the solver's permuted numbering and the work buffers rotate (fc_hip.hip "state
+// ring"), so nothing is scattered, copied or shifted (rounds 1-3 moved ~60 B per dof here, 52 MB per step on cavity_fine).
+// Row workgroups: 8 lanes per permuted row evaluate r_i = b_i - (A x)_i (flowsolver.py:729's solve, checked) and test the
+// row's own entry for finiteness (velocity rows: flowsolver.py:731,816-819).  Check workgroups (only when the residual monitor
+// is off for this step): the finiteness test alone, one row per thread.  Cell workgroups: the energy integral of the new
+// velocity, element by element.  Every workgroup leaves (sum r^2 | sum b^2 | sum e) in `partial` (three arrays of gridDim.x)
+// for fc_final.
 // (Folding fc_final in as well, "last workgroup to arrive reduces": with an agent-scope release per workgroup it cost
-// 10x what the launch saves; with sc1 partials + drained two-level arrival counters (FcFin below, FC_FUSED_FINAL=1) it
+// 10x what the launch saves; with sc1 partials + drained two-level arrival counters (FcFin, FC_FUSED_FINAL=1) it
 // costs exactly what the separate launch costs.  Kept opt-in.)
-#define FC_TAIL_SHIFT 4  // dofs per thread of a shift workgroup
+#define FC_TAIL_CHECK 4  // rows per thread of a check workgroup
 template <bool FUSED>
 __global__ __launch_bounds__(256) void fc_tail(
-    int N, int nn2, const int* __restrict__ perm, const double* __restrict__ x, const double* __restrict__ b,
+    int N, const unsigned char* __restrict__ velrow, const double* __restrict__ x, const double* __restrict__ b,
     const int* __restrict__ a_rowptr, const int* __restrict__ a_col, const double* __restrict__ a_val,
-    int n_row_blocks, int n_shift_blocks, int reps, int nc, const int* __restrict__ cn, const double* __restrict__ geom, const int* __restrict__ iperm,
+    int n_row_blocks, int n_check_blocks, int reps, int nc, const int* __restrict__ cnp, const double* __restrict__ geom,
     const unsigned char* __restrict__ rowkind, const int* __restrict__ cell_list, int ncl,
-    double* __restrict__ up, double* __restrict__ u_n, double* __restrict__ u_nn, double* __restrict__ p_n,
-    int* __restrict__ flag, double* __restrict__ partial, int* __restrict__ err, FcFin fin,
-    double* __restrict__ u_old, double* __restrict__ p_old) {  // u_old / p_old: what the shift overwrites (fc_undo_step)
-  if (err && err[0]) {
-    // the factor apply gave up (fc_nd_dag): leave the state as it is, the host redoes the step; a fused tail still owes
-    // the host its record (flag word + 1024)
-    if (FUSED && blockIdx.x == 0 && threadIdx.x == 0) {
-      if (err[1] == 0) err[1] = fin.step_id;
-      double none[64];
-      for (int k = 0; k < 64; ++k) none[k] = 0.0;
-      fc_publish(none, fin.n_sens, 0.0, 0.0, 0.0, (double)(flag[0] & 1) + 1024.0, fin.y, fin.E_out, fin.r_out, fin.flag_out, fin.seq_out,
-                 fin.seq);
-    }
-    return;
-  }
+    int* __restrict__ flag, double* __restrict__ partial, FcFin fin) {
   constexpr int LANES = 8, RPB = 256 / LANES;
   const int t = threadIdx.x, lane = t % LANES;
   const int G = gridDim.x;
   double r2 = 0.0, b2 = 0.0, e = 0.0;
   bool bad = false;
-  // the cell workgroups (a chain of three dependent gathers per lane) come FIRST in the grid, so that their latency
+  // the cell workgroups (a chain of two dependent gathers per lane) come FIRST in the grid, so that their latency
   // overlaps with the row workgroups' streaming instead of forming the launch's tail
-  const int n_cell_blocks = G - n_row_blocks - n_shift_blocks;
-  const int sb = (int)blockIdx.x - n_cell_blocks;  // shift block of this workgroup (< 0: a cell workgroup)
-  const int rb = sb - n_shift_blocks;              // row block (>= 0: a row workgroup)
-  if (sb >= 0 && rb < 0) {
-    // state shift in the W ORDER of the state vectors: u_old <- u_nn <- u_n <- x, p_old <- p_n <- x and the W-layout copy `up`
-    // are six coalesced streams and ONE gather (x through the inverse permutation) per dof.  Done from the permuted rows
-    // instead (lane 0 of a row's eight, six 8-byte accesses scattered by perm[]) it moved a cache line per access: on
-    // cavity_fine that was more traffic than the matrix the residual monitor streams.
+  const int n_cell_blocks = G - n_row_blocks - n_check_blocks;
+  const int kb = (int)blockIdx.x - n_cell_blocks;  // check block of this workgroup (< 0: a cell workgroup)
+  const int rb = kb - n_check_blocks;              // row block (>= 0: a row workgroup)
+  if (kb >= 0 && rb < 0) {
 #pragma unroll
-    for (int u = 0; u < FC_TAIL_SHIFT; ++u) {
-      const int r = (sb * FC_TAIL_SHIFT + u) * 256 + t;
-      if (r < N) {
-        const int i = iperm[r];
-        // multi-GPU (rowkind != nullptr): 0 = another rank's row (left alone), 1 = owned, 2 = replicated root row
-        if (!rowkind || rowkind[i] != 0) {
-          const double v = x[i];
-          up[r] = v;
-          if (r < nn2) {
-            u_old[r] = u_nn[r];
-            u_nn[r] = u_n[r];
-            u_n[r] = v;
-            bad |= !isfinite(v);
-          } else {
-            p_old[r - nn2] = p_n[r - nn2];
-            p_n[r - nn2] = v;
-          }
-        }
-      }
+    for (int u = 0; u < FC_TAIL_CHECK; ++u) {
+      const int i = (kb * FC_TAIL_CHECK + u) * 256 + t;
+      // multi-GPU (rowkind != nullptr): 0 = another rank's row (never computed here), 1 = owned, 2 = replicated root row
+      if (i < N && velrow[i] && (!rowkind || rowkind[i] != 0)) bad |= !isfinite(x[i]);
     }
   } else if (rb >= 0) {
     // rows: residual monitor (`reps` row groups per workgroup keep the number of partials that fc_final folds alone
     // <= ~2000 on large meshes)
     for (int rep = 0; rep < reps; ++rep) {
-    const int i = (rb * reps + rep) * RPB + t / LANES;
-    double sa = 0.0;
-    // multi-GPU (rowkind != nullptr): only the rows a rank owns (kind 1) enter its residual sums
-    const int kind = i < N ? (rowkind ? rowkind[i] : 1) : 0;
-    if (kind != 0) {
-      if (a_rowptr && kind == 1) {
+      const int i = (rb * reps + rep) * RPB + t / LANES;
+      double sa = 0.0;
+      // multi-GPU (rowkind != nullptr): only the rows a rank owns (kind 1) enter its residual sums
+      const int kind = i < N ? (rowkind ? rowkind[i] : 1) : 0;
+      if (kind == 1) {
         const int k0 = a_rowptr[i], k1 = a_rowptr[i + 1];
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         for (int base = k0; base < k1; base += 4 * LANES) {
@@ -1112,38 +1055,38 @@ __global__ __launch_bounds__(256) void fc_tail(
         }
         sa = (s0 + s1) + (s2 + s3);
       }
-    }
 #pragma unroll
-    for (int off = LANES / 2; off > 0; off >>= 1) sa += __shfl_down(sa, off, LANES);
-    if (kind == 1 && lane == 0 && a_rowptr) {
-      const double bb = b[i], res = bb - sa;
-      r2 += res * res;
-      b2 += bb * bb;
+      for (int off = LANES / 2; off > 0; off >>= 1) sa += __shfl_down(sa, off, LANES);
+      if (lane == 0 && kind != 0) {
+        if (velrow[i]) bad |= !isfinite(x[i]);
+        if (kind == 1) {
+          const double bb = b[i], res = bb - sa;
+          r2 += res * res;
+          b2 += bb * bb;
+        }
+      }
     }
-    }
-  } else if (cn) {
-    // cells: perturbation energy  ∫|u|^2  of the NEW velocity (utils_flowsolver.py:195-203 / flowsolver.py:827-829),
-    // read from the permuted solution through the inverse permutation; lane q = Radon point q (degree-4
+  } else if (cnp) {
+    // cells: perturbation energy  int |u|^2  of the NEW velocity (utils_flowsolver.py:195-203 / flowsolver.py:827-829),
+    // read from the permuted solution through the cells' permuted node table; lane q = Radon point q (degree-4
     // integrand: the 7-point rule is exact), 32 cells per workgroup.  2 MB instead of the 11 MB of mass-matrix rows.
     for (int rep = 0; rep < reps; ++rep) {
-    const int cl = ((int)blockIdx.x * reps + rep) * RPB + t / LANES;
-    const int c = cl < ncl ? (cell_list ? cell_list[cl] : cl) : 0;  // multi-GPU: this rank's cells
-    double w = 0.0;
-    if (cl < ncl && lane < FC_NQ) {
-      double ux = 0.0, uy = 0.0;
-      const int nn = nn2 >> 1;
+      const int cl = ((int)blockIdx.x * reps + rep) * RPB + t / LANES;
+      const int c = cl < ncl ? (cell_list ? cell_list[cl] : cl) : 0;  // multi-GPU: this rank's cells
+      double w = 0.0;
+      if (cl < ncl && lane < FC_NQ) {
+        double ux = 0.0, uy = 0.0;
 #pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        const int n = cn[(size_t)a * nc + c];
-        const double ph = c_phi2[lane * 6 + a];
-        ux += ph * x[iperm[n]];
-        uy += ph * x[iperm[nn + n]];
+        for (int a = 0; a < 6; ++a) {
+          const double ph = c_phi2[lane * 6 + a];
+          ux += ph * x[cnp[(size_t)a * nc + c]];
+          uy += ph * x[cnp[(size_t)(6 + a) * nc + c]];
+        }
+        w = c_qw[lane] * 0.5 * geom[4 * (size_t)nc + c] * (ux * ux + uy * uy);
       }
-      w = c_qw[lane] * 0.5 * geom[4 * (size_t)nc + c] * (ux * ux + uy * uy);
-    }
 #pragma unroll
-    for (int off = LANES / 2; off > 0; off >>= 1) w += __shfl_down(w, off, LANES);
-    if (lane == 0) e += w;
+      for (int off = LANES / 2; off > 0; off >>= 1) w += __shfl_down(w, off, LANES);
+      if (lane == 0) e += w;
     }
   }
   __shared__ double red[3][256];
@@ -1172,7 +1115,7 @@ __global__ __launch_bounds__(256) void fc_tail(
   // fused final: partials and the flag go to the coherence point (sc1), are drained, then the workgroup arrives on its
   // group's counter and the group's last arriver on the top counter (two levels: ~12 ns per same-address atomic would
   // serialise thousands of arrivals on one word).  The last arriver of all folds the partials in fc_final's fixed order,
-  // evaluates the sensors from the sweep buffer (complete before this launch) and publishes; counters reset themselves.
+  // evaluates the sensors from the solution (complete before this launch) and publishes; counters reset themselves.
   __shared__ int last;
   if (t == 0) {
     if (any_bad) atomicOr(flag, 1);
@@ -1197,13 +1140,13 @@ __global__ __launch_bounds__(256) void fc_tail(
   __syncthreads();
   if (!last) return;
   const bool res = a_rowptr != nullptr;
-  fc_final_body<true>(G, cn ? partial + 2 * (size_t)G : nullptr, fin.E_out, res ? G : 0, res ? partial : nullptr, fin.r_out, fin.n_sens,
-                      fin.s_rowptr, fin.s_idxp, fin.s_w, x - N, fin.y, flag, fin.flag_out, fin.seq_out, fin.seq, err, fin.step_id);
+  fc_final_body<true>(G, cnp ? partial + 2 * (size_t)G : nullptr, fin.E_out, res ? G : 0, res ? partial : nullptr, fin.r_out, fin.n_sens,
+                      fin.s_rowptr, fin.s_idxp, fin.s_w, x, fin.y, flag, fin.flag_out, fin.seq_out, fin.seq);
 }
 
 // multi-GPU: energy share of this rank's cells, 1/2 ∫ |u|^2 (degree-4 integrand: exact with the 7-pt rule);
 // one partial per block
-__global__ __launch_bounds__(256) void fc_energy_elem(int nc, int nn, const int* __restrict__ cn,
+__global__ __launch_bounds__(256) void fc_energy_elem(int nc, const int* __restrict__ cnp,
                                                       const double* __restrict__ geom,
                                                       const double* __restrict__ u,
                                                       const int* __restrict__ cell_list, int ncl,
@@ -1216,9 +1159,8 @@ __global__ __launch_bounds__(256) void fc_energy_elem(int nc, int nn, const int*
     double ax[6], ay[6];
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-      const int n = cn[(size_t)a * nc + c];
-      ax[a] = u[n];
-      ay[a] = u[nn + n];
+      ax[a] = u[cnp[(size_t)a * nc + c]];  // u: permuted state, cnp: the cells' permuted node table
+      ay[a] = u[cnp[(size_t)(6 + a) * nc + c]];
     }
 #pragma unroll
     for (int q = 0; q < FC_NQ; ++q) {

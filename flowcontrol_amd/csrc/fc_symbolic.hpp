@@ -636,54 +636,4 @@ inline Blocks down_blocks(const Tree& t, const Factors& fac, int rank, int world
   return B;
 }
 
-struct Dag {  // ndsolver.dag_dependencies
-  std::vector<unsigned char> mine;
-  std::vector<int> dn_dep, up_ptr, up_idx;
-};
-
-inline Dag dag_dependencies(const Tree& t, const Factors& fac, int rank, int world) {
-  Dag D;
-  const size_t G = fac.nodes.size() / 7;
-  std::map<std::pair<int, int>, int> gid;
-  for (size_t g = 0; g < G; ++g) gid[{(int)fac.nodes[g * 7], (int)fac.nodes[g * 7 + 1]}] = (int)g;
-  int p = 0;
-  while ((1 << p) < world) ++p;
-  D.mine.assign(G, 1);
-  D.dn_dep.assign(G, -1);
-  D.up_ptr.assign(G + 1, 0);
-  std::function<void(int, int, std::vector<int>&)> owners_below = [&](int k, int n, std::vector<int>& out) {
-    if (k >= t.depth) return;
-    const int b = t.child_bits(k);
-    for (int c = 0; c < (1 << b); ++c) {
-      const int ch = (n << b) + c;
-      const auto it = gid.find({k + 1, ch});
-      if (it != gid.end())
-        out.push_back(it->second);
-      else
-        owners_below(k + 1, ch, out);
-    }
-  };
-  for (size_t g = 0; g < G; ++g) {
-    const int k = (int)fac.nodes[g * 7], n = (int)fac.nodes[g * 7 + 1];
-    if (world > 1 && k >= 1) D.mine[g] = (n >> (t.cum[k] - p)) == rank ? 1 : 0;
-    int kk = k, nn_ = n;
-    while (kk > 0) {
-      const int b = t.cum[kk] - t.cum[kk - 1];
-      kk -= 1;
-      nn_ >>= b;
-      const auto it = gid.find({kk, nn_});
-      if (it != gid.end()) {
-        D.dn_dep[g] = it->second;
-        break;
-      }
-    }
-    std::vector<int> ch;
-    owners_below(k, n, ch);
-    D.up_idx.insert(D.up_idx.end(), ch.begin(), ch.end());
-    D.up_ptr[g + 1] = (int)D.up_idx.size();
-  }
-  if (D.up_idx.empty()) D.up_idx.push_back(0);
-  return D;
-}
-
 }  // namespace fcsym

@@ -241,7 +241,7 @@ class DeviceSolver:
         check(self.lib.fc_apply_bc(self._h, slot))
 
     # ── solver setup (host analysis + factorisation, device upload) ──────────
-    def setup_solver(self, slot: int, depth: int | None = None, refine: int = 0, check_residual: bool = True, merge: int = 2,
+    def setup_solver(self, slot: int, depth: int | None = None, refine: int = 0, check_residual: bool | int = True, merge: int = 2,
                      restructure: bool = False, truncate: int = 0) -> None:
         """Factorise the (BC-eliminated) matrix of ``slot`` and hand the factors to the device.
 
@@ -352,9 +352,6 @@ class DeviceSolver:
             )
         if getattr(self, "_truncate", 0):
             check(self.lib.fc_set_stage_diag(self._h, slot, _f64(ndsolver.schur_diagonal_scaling(self.matrix(slot), self.nn)[t.perm])))
-        # one-launch factor apply: dependency lists of the elimination tree (the task tables are built in the library)
-        nodes, mine, dn_dep, up_ptr, up_idx = ndsolver.dag_dependencies(fac, self.rank, self.world)
-        check(self.lib.fc_solver_set_dag(self._h, slot, int(nodes.shape[0]), nodes, mine, dn_dep, up_ptr, up_idx))
         self._structured.add(slot)
         self.refactor(slot)
         self.factor_nnz[slot] = int(fac.nnz)
@@ -366,7 +363,7 @@ class DeviceSolver:
     def _setup_solver_native(self, slot, depth, refine, check_residual, merge, truncate) -> None:
         """``fc_setup_solver``: tree, factor layout, elimination plan, sweep tables, numeric factorisation and its
         acceptance solve all happen inside the library; only sizes come back."""
-        code = self.lib.fc_setup_solver(self._h, slot, int(depth or 0), int(merge), int(truncate), int(refine), int(bool(check_residual)))
+        code = self.lib.fc_setup_solver(self._h, slot, int(depth or 0), int(merge), int(truncate), int(refine), int(check_residual))
         self._raise_exchange_error()
         check(code)
         info = np.zeros(10, dtype=np.int64)
@@ -396,7 +393,7 @@ class DeviceSolver:
         if flag.value:
             logger.warning("slot %d: the direct factor apply misses 1e-10 on this operator; its solves run GMRES preconditioned by the factors", slot)
         self._structured.add(slot)
-        self._solver_opts = (int(refine), bool(check_residual), "refine", 1e-10)
+        self._solver_opts = (int(refine), int(check_residual), "refine", 1e-10)
 
     @property
     def tree(self) -> "ndsolver.NDTree | None":
@@ -491,12 +488,14 @@ class DeviceSolver:
         check(self.lib.fc_get_factor_values(self._h, slot, n, out))
         return out
 
-    def set_solver_options(self, refine: int = 0, check_residual: bool = True, method: str = "refine", rtol: float = 1e-10) -> None:
-        """``method="refine"``: factor sweeps (+ ``refine`` iterative-refinement sweeps) — what the time steps use.
+    def set_solver_options(self, refine: int = 0, check_residual: bool | int = True, method: str = "refine", rtol: float = 1e-10) -> None:
+        """``check_residual``: 0 / False = no residual monitor, n >= 1 = the time steps form ``|b - A x| / |b|`` on every n-th step
+        (``info[1]``; NaN on the steps in between).
+        ``method="refine"``: factor sweeps (+ ``refine`` iterative-refinement sweeps) — what the time steps use.
         ``method="bicgstab"`` / ``"gmres"``: right-preconditioned BiCGStab / restarted GMRES(30), device-resident
         (``refine`` = iteration cap, ``rtol`` = relative residual target), with the slot's current factors as
         preconditioner; for :meth:`solve` only."""
-        self._solver_opts = (int(refine), bool(check_residual), method, float(rtol))
+        self._solver_opts = (int(refine), int(check_residual), method, float(rtol))
         m = {"refine": _lib.METHOD_REFINE, "bicgstab": _lib.METHOD_BICGSTAB, "gmres": _lib.METHOD_GMRES}[method]
         check(self.lib.fc_set_solver_options(self._h, m, int(refine), float(rtol), int(check_residual)))
 
@@ -667,6 +666,10 @@ class DeviceSolver:
         self.step_batch_begin(order_slot, u_ctrl, compute_energy, u_force)
         return self.step_batch_end()
 
+    def reset_sim_batch(self, s: int) -> None:
+        """``fc_reset_sim_batch``: take simulation ``s`` (e.g. one that diverged) out of the batch's dynamics — zero state, flag cleared."""
+        check(self.lib.fc_reset_sim_batch(self._h, int(s)))
+
     def batch_info(self) -> dict:
         a = np.zeros(8)
         check(self.lib.fc_get_batch_info(self._h, a))
@@ -710,13 +713,6 @@ class DeviceSolver:
         return y[: self.n_sens]
 
     # ── measurement ──────────────────────────────────────────────────────────
-    def profile_steps(self, order_slot: int, n_steps: int, u_ctrl):
-        u = _f64(np.atleast_1d(u_ctrl)) if self.n_act else None
-        ms = np.empty(5)
-        nl = C.c_int32()
-        check(self.lib.fc_profile_steps(self._h, order_slot, n_steps, ptr(u), ms, C.byref(nl)))
-        return ms, nl.value
-
     def bench_sweeps(self, slot: int, reps: int = 200):
         ms, nl = C.c_double(), C.c_int32()
         check(self.lib.fc_bench_sweeps(self._h, slot, reps, C.byref(ms), C.byref(nl)))
@@ -744,16 +740,6 @@ class DeviceSolver:
         na, nb = C.c_int64(), C.c_int64()
         check(self.lib.fc_get_timing(self._h, C.byref(a), C.byref(na), C.byref(b), C.byref(nb)))
         return {"sweep_ms": a.value, "sweep_launches": na.value, "spmv_ms": b.value, "spmv_launches": nb.value}
-
-    def dag_info(self, slot: int) -> dict:
-        """One-launch factor apply of ``slot``: number of tasks, whether it is in use, give-ups so far."""
-        n, on, bad = C.c_int32(), C.c_int32(), C.c_int32()
-        check(self.lib.fc_get_dag_info(self._h, slot, C.byref(n), C.byref(on), C.byref(bad)))
-        return {"tasks": n.value, "enabled": bool(on.value), "failures": bad.value}
-
-    def set_dag(self, on: bool) -> None:
-        """Switch between the one-launch factor apply and one launch per tree level (A/B, tests)."""
-        check(self.lib.fc_set_dag(self._h, int(bool(on))))
 
     def algorithmic_bytes(self, slot: int):
         a, b = C.c_double(), C.c_double()

@@ -17,7 +17,7 @@ from ... import flowsolver
 from ...fem.boundary import DOLFIN_EPS, Constant, DirichletBC, SubDomain, between, near
 from ...flowfield import BoundaryConditions
 
-DEFAULT_MESH = Path(__file__).resolve().parents[3] / "tests" / "golden" / "meshes" / "cavity_coarse.npz"
+DEFAULT_MESH = Path(__file__).resolve().parent / "data_input" / "cavity_coarse.npz"
 
 
 class CavityFlowSolver(flowsolver.FlowSolver):

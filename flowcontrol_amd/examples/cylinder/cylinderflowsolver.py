@@ -18,7 +18,7 @@ from ...fem.boundary import DOLFIN_EPS, Constant, DirichletBC, SubDomain, betwee
 from ...flowfield import BoundaryConditions
 
 #: mesh fixture shipped with this repository (converted from the reference's O1.xdmf data file)
-DEFAULT_MESH = Path(__file__).resolve().parents[3] / "tests" / "golden" / "meshes" / "O1.npz"
+DEFAULT_MESH = Path(__file__).resolve().parent / "data_input" / "O1.npz"
 
 
 def refined_cylinder_mesh(levels: int = 1, path: str | Path | None = None, source: str | Path | None = None) -> Path:

@@ -18,7 +18,7 @@ from flowcontrol_amd.controller import Controller
 from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver
 from flowcontrol_amd.flowsolverparameters import ParamIC
 
-CONTROLLER = Path(__file__).resolve().parents[3] / "tests" / "golden" / "controllers" / "Kopt_reduced13.mat"
+CONTROLLER = Path(__file__).resolve().parent / "data_input" / "Kopt_reduced13.mat"
 DT = 0.005
 SAVE_EVERY = 25
 

@@ -18,7 +18,7 @@ from ... import flowsolver
 from ...fem.boundary import DOLFIN_EPS, Constant, DirichletBC, SubDomain, near
 from ...flowfield import BoundaryConditions
 
-DEFAULT_MESH = Path(__file__).resolve().parents[3] / "tests" / "golden" / "meshes" / "lidcavity_mesh64.npz"
+DEFAULT_MESH = Path(__file__).resolve().parent / "data_input" / "lidcavity_mesh64.npz"
 
 
 class LidCavityFlowSolver(flowsolver.FlowSolver):

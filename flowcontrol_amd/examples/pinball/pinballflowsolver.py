@@ -17,7 +17,7 @@ from ...actuator import CYLINDER_ACTUATION_MODE
 from ...fem.boundary import DOLFIN_EPS, Constant, DirichletBC, SubDomain, between, near
 from ...flowfield import BoundaryConditions
 
-DEFAULT_MESH = Path(__file__).resolve().parents[3] / "tests" / "golden" / "meshes" / "mesh_middle_gmsh.npz"
+DEFAULT_MESH = Path(__file__).resolve().parent / "data_input" / "mesh_middle_gmsh.npz"
 
 
 class PinballCustomInitialGuess:

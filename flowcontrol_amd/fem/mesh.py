@@ -209,7 +209,7 @@ def read_xdmf_mesh(path: str | Path, reorder: bool = True) -> Mesh:
     Handles both the meshio layout (``/data0``, ``/data1``) and the dolfin layout
     (``/Mesh/mesh/{geometry,topology}``) — the item paths are taken from the XML.
     ``.npz`` files with ``coords`` / ``cells`` arrays (the committed fixtures under
-    ``tests/golden/meshes``) are accepted as well.
+    ``flowcontrol_amd/examples/*/data_input``) are accepted as well.
     """
     path = Path(path)
     if path.suffix == ".npz":

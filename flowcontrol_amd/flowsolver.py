@@ -79,6 +79,10 @@ class FlowSolver(ABC):
         # every step's solve is monitored: relative residual of the linear system above this → error (the
         # factor apply is exact to round-off, ~1e-16; a larger value means broken factors or a singular system)
         self.residual_tol: float = 1e-8
+        #: ... on every n-th step (1: every step; 0: never).  The reference forms no such residual (flowsolver.py:728-737 tests finiteness
+        #: only): the monitor is this solver's own check and costs one pass over the system matrix per monitored step.  On the steps
+        #: in between ``solve_info[1]`` is NaN; the non-finite test runs on every step regardless.
+        self.check_residual_every: int = 1
         #: memory-lean mode: factorise only the tree levels >= nd_truncate and solve every step with a Krylov method
         #: preconditioned by those truncated factors (0 = full selected inverse, applied directly)
         self.nd_truncate: int = 0
@@ -560,8 +564,9 @@ class FlowSolver(ABC):
 
     def step(self, u_ctrl: NDArray[np.float64]) -> NDArray[np.float64] | None:
         """Advance by one Δt; returns the measurement vector, or ``None`` if the solver diverged and
-        ``params_solver.throw_error`` is False (reference ``:703-799``).  After a divergence the device state holds
-        the non-finite field (the reference leaves ``u_n`` untouched): re-initialise or ``fields.push()`` a state."""
+        ``params_solver.throw_error`` is False (reference ``:703-799``).  A failed step leaves ``u_n``, ``u_nn``, ``p_n`` as they
+        were, as in the reference (which detects the non-finite velocity before it shifts its fields, ``:727-751``): the step's
+        solution sits in a buffer of its own and is simply not adopted (``fc_undo_step``)."""
         self._begin_stepping()
         t0 = time.time()
         u_ctrl = np.atleast_1d(np.asarray(u_ctrl, dtype=np.float64))
@@ -839,9 +844,9 @@ class _DeviceNDSolver:
             vals = np.zeros(dev.nnz)
             vals[pos[~bad]] = M.data[~bad]
             dev.set_matrix_values(self.slot, vals)
-        dev.setup_solver(self.slot, depth=fs.nd_depth, refine=fs.refine_steps, truncate=fs.nd_truncate)
+        dev.setup_solver(self.slot, depth=fs.nd_depth, refine=fs.refine_steps, truncate=fs.nd_truncate, check_residual=fs.check_residual_every)
         if fs.nd_truncate or fs.factor_bits != 64:
-            dev.set_solver_options(refine=fs.krylov_max_iter, method=fs.krylov_method, rtol=fs.krylov_rtol)
+            dev.set_solver_options(refine=fs.krylov_max_iter, check_residual=fs.check_residual_every, method=fs.krylov_method, rtol=fs.krylov_rtol)
 
     def solve(self, x: np.ndarray, b: np.ndarray) -> None:
         sol, _ = self.fs.th.device().solve(self.slot, b)

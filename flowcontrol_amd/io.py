@@ -238,9 +238,6 @@ def read_xdmf(filename, func: Function, name: str, counter: int = -1) -> float:
     return time
 
 
-__all__ = ["write_xdmf", "read_xdmf", "dolfin_tables"]
-
-
 def export_sparse_matrix(A, figname=None) -> bool:
     """Spy plot of a sparse (or dense) matrix as PNG (reference ``utils/io.py:254-272``).  Needs matplotlib, which this image does
     not ship: returns False (and writes nothing) when it cannot be imported."""
@@ -302,3 +299,5 @@ def export_subdomains(mesh, subdomains_list, filename="subdomains.xdmf") -> np.n
     logger.info("Writing subdomains file: %s", path)
     return markers
 
+
+__all__ = ["write_xdmf", "read_xdmf", "dolfin_tables", "export_sparse_matrix", "export_square_operators", "export_subdomains"]

@@ -575,56 +575,7 @@ def schur_diagonal_scaling(A: sp.csr_matrix, nn: int) -> np.ndarray:
     return out
 
 
-def dag_dependencies(fac: BlockFactors, rank: int = 0, world: int = 1):
-    """Dependency lists of the one-launch factor apply (``fc_solver_set_dag``), over the rows of
-    ``fac.nodes`` (the tree nodes that own dofs, elimination order).
-
-    * ``dn_dep[g]``: the nearest ancestor that owns dofs (−1: none — the root): a node's down-sweep rows
-      read x of its ancestors only, and an ancestor is complete once ITS ancestors are;
-    * ``up_dep_ptr / up_dep_idx``: the nearest descendants that own dofs, one per branch: a node's
-      up-sweep rows read y of its whole sub-tree, which is complete once those nodes are;
-    * ``mine[g]``: the node is swept by this rank (its sub-tree of a ``world``-ary root, or the root)."""
-    t = fac.tree
-    nodes = np.ascontiguousarray(fac.nodes, dtype=np.int64).reshape(-1, 7)
-    gid = {(int(k), int(n)): g for g, (k, n) in enumerate(zip(nodes[:, 0], nodes[:, 1]))}
-    p = int(np.log2(world)) if world > 1 else 0
-    G = nodes.shape[0]
-    dn_dep = np.full(G, -1, dtype=np.int32)
-    mine = np.ones(G, dtype=np.uint8)
-    up_ptr = np.zeros(G + 1, dtype=np.int32)
-    up_idx: list[int] = []
-
-    def owners_below(k: int, n: int) -> list[int]:
-        out = []
-        if k >= t.depth:
-            return out
-        for ch in t.children(k, n):
-            g = gid.get((k + 1, int(ch)))
-            if g is not None:
-                out.append(g)
-            else:
-                out += owners_below(k + 1, int(ch))
-        return out
-
-    for g in range(G):
-        k, n = int(nodes[g, 0]), int(nodes[g, 1])
-        if world > 1 and k >= 1:
-            mine[g] = 1 if (n >> (t.cum[k] - p)) == rank else 0
-        kk, nn_ = k, n
-        while kk > 0:
-            b = t.cum[kk] - t.cum[kk - 1]
-            kk, nn_ = kk - 1, nn_ >> b
-            a = gid.get((kk, nn_))
-            if a is not None:
-                dn_dep[g] = a
-                break
-        ch = owners_below(k, n)
-        up_idx += ch
-        up_ptr[g + 1] = len(up_idx)
-    return nodes, mine, dn_dep, up_ptr, np.ascontiguousarray(up_idx if up_idx else [0], dtype=np.int32)
-
-
-__all__ += ["BlockFactors", "factorize_blocks", "rank_keeps", "schur_diagonal_scaling", "down_blocks", "dag_dependencies", "split_up_segments", "FactorPlan", "factor_plan",
+__all__ += ["BlockFactors", "factorize_blocks", "rank_keeps", "schur_diagonal_scaling", "down_blocks", "split_up_segments", "FactorPlan", "factor_plan",
             "front_diagonal_slot"]
 
 

@@ -34,8 +34,10 @@ def cummin(y: np.ndarray, return_index: bool = True):
     best = np.minimum.accumulate(y, axis=0)
     if not return_index:
         return best
-    idx = np.array([int(np.flatnonzero(np.isclose(y[: i + 1, 0], best[i, 0]))[0]) for i in range(y.shape[0])])
-    return best, idx
+    # first position (up to step i) whose value equals the running minimum of step i; a NaN cost (a run that was stopped early)
+    # propagates through the running minimum and matches nothing: index 0 then, as the reference's argmax over an all-False row gives
+    hit = np.isclose(best, y.T) & np.tri(y.shape[0], dtype=bool)
+    return best, hit.argmax(1)
 
 
 def write_results(x_data, y_data, optim_path, verbose: bool = True) -> None:
@@ -119,22 +121,24 @@ def closed_loop_costs(fs, controllers: Sequence, num_steps: int, u_penalty: floa
         for _ in range(num_steps):
             u = np.zeros((k, n_act))
             for i, K in enumerate(controllers):
+                if bfs.diverged[i]:
+                    continue  # that run has ended (its measurements are NaN): no command
                 cmd = np.atleast_1d(np.asarray(K.step(y=fb(bfs.y_meas[i]), dt=dt), dtype=float)).ravel()
                 u[i] = cmd if cmd.size == n_act else cmd[0]
-            if bfs.step(u) is None:
+            if bfs.step(u) is None:  # a residual breach: the factors all candidates share are broken
                 alive = False
                 break
         series = [bfs.timeseries(i) for i in range(k)]
         J = np.empty(k)
         for i, ts in enumerate(series):
-            if not alive and bool(bfs.diverged[i]):
+            if bool(bfs.diverged[i]):  # a diverging candidate ends there; the others run to the end
                 J[i] = diverged_cost
                 continue
             t_end = float(ts["time"].iloc[-1])
             Tnorm = dt / max(t_end - Tc, dt)
             ucols = [c for c in ts.columns if c.startswith("u_ctrl_")]
             J[i] = compute_signal_cost(ts[signal].dropna(), Tnorm, criterion) + u_penalty * compute_control_cost(ts[ucols], Tnorm)
-        if not alive:  # the runs that stayed finite stopped early with the batch: mark them as unevaluated rather than rank them
+        if not alive:  # stopped early: mark the finite runs as unevaluated rather than rank them
             J[~np.asarray(bfs.diverged, dtype=bool)] = np.nan
         return J, series
     finally:

@@ -159,6 +159,10 @@ int fc_set_rhs_operator(fc_handle h, int slot, const int32_t* rowptr, const int3
  * preconditioner of the new operator (Picard / Newton iterations of steadystate.py:60-159 between two
  * refactorisations; the reference re-factorises with MUMPS at every iteration). */
 int fc_update_operator(fc_handle h, int slot);
+/* method: FC_METHOD_*; max_iter: refinement sweeps (REFINE) or the Krylov iteration cap; rtol: Krylov target;
+ * check_residual: 0 = no residual monitor, n >= 1 = fc_step / fc_run form |b - A x| / |b| on every n-th step of the handle (info[1];
+ * NaN on the steps in between) -- the reference never forms it (flowsolver.py:728-737 tests finiteness only), n > 1 amortises the
+ * pass over the system matrix it costs.  The non-finite test runs on every step regardless. */
 int fc_set_solver_options(fc_handle h, int method, int max_iter, double rtol, int check_residual);
 
 /* ── state: FlowFieldCollection u_n, u_nn, p_n (flowfield.py:67-105; flowsolver.py:487-491) ─ */
@@ -224,6 +228,10 @@ int fc_get_solution_batch(fc_handle h, int32_t k, double* up /* [k][N] last solv
  * velocity (info_out[s][3] marks which; the others are unaffected: the columns are independent). */
 int fc_step_batch(fc_handle h, int order_slot, int32_t k, const double* u_ctrl, const double* u_force, double* y_out,
                   double* dE_out, int compute_energy, double* info_out);
+/* (the flags are per step: after FC_ERR_DIVERGED the other simulations simply go on; fc_reset_sim_batch(h, s) takes a diverged
+ * run out of the dynamics -- its state becomes zero, so that its column stops producing non-finite values -- the host then ignores
+ * its outputs.  The reference's per-run equivalent: FlowSolver.step returns None / raises and that run ends, flowsolver.py:727-737.) */
+int fc_reset_sim_batch(fc_handle h, int32_t s);
 int fc_step_batch_begin(fc_handle h, int order_slot, int32_t k, const double* u_ctrl, const double* u_force, int compute_energy);
 int fc_step_batch_end(fc_handle h, int32_t k, double* y_out, double* dE_out, double* info_out);
 /* parity hook: X = A_bc^{-1} B for k right-hand sides through the batched factor apply; b, x: [k][N] */

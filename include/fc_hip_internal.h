@@ -60,29 +60,6 @@ int fc_sym_build(int32_t nv, int32_t ne, int32_t nc, const double* coords, const
 int fc_sym_size(void* sym, const char* name, int64_t* n);
 int fc_sym_get(void* sym, const char* name, int64_t* out);
 int fc_sym_free(void* sym);
-/* One-launch factor apply (replaces the 2*depth+1 level launches of LUSolver.solve, flowsolver.py:729, by ONE
- * grid whose workgroups wait for each other through per-node arrival counters; fc_dag.hip.h).  `nodes` has 7
- * int64 per tree node that owns dofs, elimination order: level, index in level, first row i0, rows ni, boundary
- * size nb, offset of its [D^-1 | -U] rows in the factor values, offset of its index list.  mine[g] (NULL = all):
- * the node is swept by this rank.  dn_dep[g]: nearest ancestor that owns dofs (-1: none); up_dep_idx[up_dep_ptr[g]
- * .. up_dep_ptr[g+1]): nearest owners below g, one per branch.  Must follow fc_solver_setup for the slot.
- * Every wait inside the launch is bounded; after a give-up the step is redone with the level launches and the
- * handle stays on them (fc_get_dag_info reports it).  FC_DAG=0 / fc_set_dag(h, 0): level launches throughout.
- * OPTIONAL PART: the kernel is compiled only with hipcc -DFC_WITH_DAG (it is slower than the level launches on
- * every mesh measured).  A default build keeps these four entry points so that bindings load:
- * fc_solver_set_dag tabulates nothing, fc_set_dag(h, 1) returns FC_ERR_INVALID, FC_DAG in the environment is ignored. */
-int fc_solver_set_dag(fc_handle h, int slot, int32_t n_nodes, const int64_t* nodes /* [n_nodes][7] */,
-                      const uint8_t* mine /* [n_nodes] or NULL */, const int32_t* dn_dep /* [n_nodes] */,
-                      const int32_t* up_dep_ptr /* [n_nodes+1] */, const int32_t* up_dep_idx);
-int fc_get_dag_info(fc_handle h, int slot, int32_t* n_tasks, int32_t* enabled, int32_t* failures);
-int fc_set_dag(fc_handle h, int on);
-/* test aid: behind the n-th factor apply from now (0 = the next one) the give-up word is raised as a workgroup
- * that timed out would raise it, so that the redo path can be exercised; -1 disarms */
-int fc_debug_inject_dag_failure(fc_handle h, int after_n_applies);
-/* diagnostic: one traced factor apply; stamps[task][8] = 100 MHz wall-clock ticks of the task's workgroup at
- * entry / value loads issued / dependencies met / products done / stores drained (rest 0) */
-int fc_debug_trace_apply(fc_handle h, int slot, int32_t n_tasks, int64_t* stamps /* [n_tasks][8] */,
-                         int32_t* task_stage /* [n_tasks] or NULL */, int32_t* task_kind /* [n_tasks] or NULL */);
 /* Numeric factorisation ON THE DEVICE (what `solver.set_operator(A)` costs in the reference,
  * flowsolver.py:697,812-814 -> PETSc/MUMPS numeric phase; also every Newton/Picard iteration of
  * steadystate.py:60-159).  fc_factor_plan uploads the symbolic side once per (tree, pattern): all
@@ -126,13 +103,6 @@ int fc_set_energy_matrix(fc_handle h, const int32_t* rowptr, const int32_t* col,
 int fc_get_batch_info(fc_handle h, double* info /* [8] */);
 /* HIP-event timing of `reps` back-to-back batched factor applies; mean milliseconds per apply */
 int fc_bench_batch_apply(fc_handle h, int slot, int reps, double* ms_per_apply);
-/* ── measurement: HIP-event timing of the phases of fc_step on the handle's stream.
- *    phase ids: 0 rhs element loop, 1 rhs gather+BC, 2 factor sweeps (all launches of one
- *    apply), 3 residual SpMV, 4 finish (scatter/shift/sensors/energy).
- *    ms[5] = mean ms per step of each phase over `n_steps` profiled steps; sweep_launches =
- *    number of sweep-kernel launches per step. */
-int fc_profile_steps(fc_handle h, int order_slot, int32_t n_steps, const double* u_ctrl,
-                     double* ms /* [5] */, int32_t* sweep_launches);
 /* time `reps` back-to-back factor applies (all sweep launches of one M^-1 application) with HIP
  * events on the handle's stream; mean milliseconds per apply and launches per apply */
 int fc_bench_sweeps(fc_handle h, int slot, int reps, double* ms_per_apply, int32_t* launches_per_apply);

@@ -9,9 +9,9 @@ from flowcontrol_amd.device import SLOT_BDF2, DeviceSolver  # noqa: E402
 from flowcontrol_amd.fem.mesh import read_xdmf_mesh  # noqa: E402
 from flowcontrol_amd.fem.spaces import TaylorHood  # noqa: E402
 
-GOLDEN = Path(__file__).resolve().parents[1] / "tests" / "golden" / "meshes"
+from flowcontrol_amd.examples.data import mesh_file  # noqa: E402
 for name in sys.argv[1:] or ["O1", "cavity_fine"]:
-    th = TaylorHood(read_xdmf_mesh(GOLDEN / f"{name}.npz"))
+    th = TaylorHood(read_xdmf_mesh(mesh_file(name)))
     dev = DeviceSolver(th)
     x = th.node_coords
     U0 = np.r_[1.0 + 0.3 * np.sin(x[:, 0]) * np.cos(0.7 * x[:, 1]), 0.2 * np.cos(0.5 * x[:, 0] + 0.1) * np.sin(x[:, 1])]

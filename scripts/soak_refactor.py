@@ -14,7 +14,7 @@ from flowcontrol_amd.device import SLOT_BDF2, DeviceSolver  # noqa: E402
 from flowcontrol_amd.fem.mesh import read_xdmf_mesh  # noqa: E402
 from flowcontrol_amd.fem.spaces import TaylorHood  # noqa: E402
 
-GOLDEN = Path(__file__).resolve().parents[1] / "tests" / "golden" / "meshes"
+from flowcontrol_amd.examples.data import mesh_file  # noqa: E402
 
 
 def main():
@@ -25,7 +25,7 @@ def main():
     a = ap.parse_args()
     rng = np.random.default_rng(2026)
     for name in a.meshes:
-        th = TaylorHood(read_xdmf_mesh(GOLDEN / f"{name}.npz"))
+        th = TaylorHood(read_xdmf_mesh(mesh_file(name)))
         dev = DeviceSolver(th)
         x = th.node_coords
         m = th.mesh

@@ -17,6 +17,7 @@ from flowcontrol_amd.controller import Controller
 from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver
 from flowcontrol_amd.fem.spaces import Function
 from flowcontrol_amd.flowsolverparameters import ParamIC
+from flowcontrol_amd.examples.data import controller_file  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -46,7 +47,7 @@ class _Scenario:
 
 
 def _scenarios(golden_dir):
-    kfile = golden_dir / "controllers" / "Kopt_reduced13.mat"
+    kfile = controller_file()
 
     def open_loop(amp, w):
         return lambda: (lambda n, y: np.array([amp * np.sin(w * n), -0.5 * amp * np.cos(0.7 * w * n)]))

@@ -24,6 +24,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT / "tests" / "golden"))
+from flowcontrol_amd.examples.data import mesh_file  # noqa: E402
 
 
 def _rel(a, b):
@@ -209,7 +210,7 @@ def test_config3_cavity_fine_closed_loop_vs_oracle(tmp_path_factory, golden_dir)
 
     g = np.load(golden_dir / "cavity_fine_re7500.npz")
     fs = CavityFlowSolver.make_default(Re=7500, path_out=tmp_path_factory.mktemp("config3"), num_steps=N_STEPS,
-                                       meshpath=golden_dir / "meshes" / "cavity_fine.npz")
+                                       meshpath=mesh_file("cavity_fine"))
     assert fs.th.N == int(g["ndofs"]) == 876645 and fs.th.nc == int(g["ncells"])
     fs.compute_steady_state(method="picard", max_iter=10, tol=1e-7, u_ctrl=[0.0])
     fs.compute_steady_state(method="newton", max_iter=10, u_ctrl=[0.0], initial_guess=fs.fields.UP0)

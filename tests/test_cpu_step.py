@@ -5,10 +5,11 @@ from flowcontrol_amd.fem.mesh import read_xdmf_mesh
 from flowcontrol_amd.fem.spaces import TaylorHood
 from oracle import cpu_step
 from oracle import ns_oracle as O
+from flowcontrol_amd.examples.data import mesh_file  # noqa: E402
 
 
 def test_compiled_step_matches_the_numpy_oracle(golden_dir):
-    th = TaylorHood(read_xdmf_mesh(golden_dir / "meshes" / "O1.npz"))
+    th = TaylorHood(read_xdmf_mesh(mesh_file("O1")))
     d = O.Disc.from_taylor_hood(th)
     rng = np.random.default_rng(0)
     x = th.node_coords

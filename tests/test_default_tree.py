@@ -8,6 +8,7 @@ from flowcontrol_amd import ndsolver
 from flowcontrol_amd.device import _default_depth
 from flowcontrol_amd.fem.mesh import read_xdmf_mesh
 from flowcontrol_amd.fem.spaces import TaylorHood
+from flowcontrol_amd.examples.data import mesh_file  # noqa: E402
 
 
 def test_default_depth_rule():
@@ -22,7 +23,7 @@ def test_default_depth_rule():
 def test_library_default_tree_is_the_python_default_tree(mesh, golden_dir):
     from test_symbolic_cabi import _bc, _tables
 
-    th = TaylorHood(read_xdmf_mesh(golden_dir / "meshes" / f"{mesh}.npz"))
+    th = TaylorHood(read_xdmf_mesh(mesh_file(mesh)))
     dofs = _bc(th)
     skip = np.zeros(th.N, bool)
     skip[dofs] = True

@@ -8,6 +8,7 @@ import pytest
 
 from flowcontrol_amd.fem.mesh import Mesh, read_xdmf_mesh
 from flowcontrol_amd.fem.spaces import TaylorHood
+from flowcontrol_amd.examples.data import mesh_file  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -31,7 +32,7 @@ def setup(request, golden_dir):
     if request.param == "square8":
         mesh = Mesh.unit_square(8, 8)
     else:
-        mesh = read_xdmf_mesh(golden_dir / "meshes" / "O1.npz")
+        mesh = read_xdmf_mesh(mesh_file("O1"))
     th = TaylorHood(mesh)
     dev = DeviceSolver(th)
     d = O.Disc.from_taylor_hood(th)

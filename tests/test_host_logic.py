@@ -21,6 +21,7 @@ from flowcontrol_amd.flowsolverparameters import ParamIC, ParamTime
 from flowcontrol_amd.sensor import SENSOR_TYPE, SensorHorizontalWallShear, SensorPoint
 from oracle import ns_oracle as O
 from tests.support import nd_numeric
+from flowcontrol_amd.examples.data import mesh_file, controller_file  # noqa: E402
 
 REF = Path("/root/reference/src/examples")
 
@@ -32,7 +33,7 @@ REF = Path("/root/reference/src/examples")
 def test_xdmf_hdf5_reader_matches_fixture(rel, name, golden_dir):
     """Chunked+deflate, int64/int32 topology and big-endian f8 geometry (cavity_fine) all decode."""
     a = read_xdmf_mesh(REF / rel)
-    b = read_xdmf_mesh(golden_dir / "meshes" / f"{name}.npz")
+    b = read_xdmf_mesh(mesh_file(name))
     assert np.array_equal(a.coords, b.coords) and np.array_equal(a.cells, b.cells)
 
 
@@ -43,7 +44,7 @@ def test_dolfin_layout_hdf5_contiguous():
 
 
 def test_o1_sizes_match_survey(golden_dir):
-    m = read_xdmf_mesh(golden_dir / "meshes" / "O1.npz")
+    m = read_xdmf_mesh(mesh_file("O1"))
     th = TaylorHood(m)
     assert (m.num_vertices, m.num_cells, m.num_edges, len(m.boundary_edges())) == (6327, 12284, 18611, 370)
     assert (2 * th.nn, th.nv, th.N) == (49876, 6327, 56203)
@@ -181,7 +182,7 @@ def test_controller_zoh_matches_scipy_and_forced_response():
 
 
 def test_controller_from_file_and_algebra(golden_dir):
-    K = Controller.from_file(golden_dir / "controllers" / "Kopt_reduced13.mat")
+    K = Controller.from_file(controller_file())
     assert (K.nstates, K.ninputs, K.noutputs) == (13, 1, 1) and K.file is not None
     assert np.max(np.linalg.eigvals(K.A).real) < 0
     G = Controller(-np.eye(2), np.ones((2, 1)), np.ones((1, 2)), np.array([[2.0]]))
@@ -396,7 +397,7 @@ def test_checkpoints_follow_dolfins_write_checkpoint_layout(mesh, tmp_path, gold
         base = Mesh.unit_square(5, 4, reorder=False)
         coords_o, cells_o = base.coords.copy(), base.cells.copy()
     else:
-        z = np.load(golden_dir / "meshes" / "O1.npz")
+        z = np.load(mesh_file("O1"))
         coords_o, cells_o = z["coords"], z["cells"]
     th = TaylorHood(Mesh.from_arrays(coords_o, cells_o, reorder=True))  # Morton-ordered cells, renumbered vertices
     f = lambda xy, c: np.sin(1.3 * xy[:, 0] + 0.2 * c) * np.cos(0.7 * xy[:, 1]) + 0.1 * c * xy[:, 0]  # noqa: E731

@@ -8,6 +8,7 @@ import scipy.sparse.linalg as spla
 
 from flowcontrol_amd.fem.mesh import read_xdmf_mesh
 from flowcontrol_amd.fem.spaces import TaylorHood
+from flowcontrol_amd.examples.data import mesh_file  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -25,7 +26,7 @@ def test_krylov_methods_match_the_direct_solve(mesh, golden_dir):
     from flowcontrol_amd.device import SLOT_BDF2, DeviceSolver
     from oracle import ns_oracle as O
 
-    th = TaylorHood(read_xdmf_mesh(golden_dir / "meshes" / f"{mesh}.npz"))
+    th = TaylorHood(read_xdmf_mesh(mesh_file(mesh)))
     dev = DeviceSolver(th)
     d = O.Disc.from_taylor_hood(th)
     x = th.node_coords
@@ -152,7 +153,7 @@ def test_factors_that_miss_the_acceptance_residual_precondition_gmres(golden_dir
     from flowcontrol_amd._lib import FcError
     from flowcontrol_amd.device import SLOT_BDF2, DeviceSolver
 
-    th = TaylorHood(read_xdmf_mesh(golden_dir / "meshes" / "O1.npz"))
+    th = TaylorHood(read_xdmf_mesh(mesh_file("O1")))
     dev = DeviceSolver(th)
     x = th.node_coords
     dofs = _bc(th)

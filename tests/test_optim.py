@@ -7,6 +7,7 @@ import pandas as pd
 import pytest
 
 from flowcontrol_amd import optim
+from flowcontrol_amd.examples.data import controller_file  # noqa: E402
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
 
@@ -30,6 +31,11 @@ def test_cost_functions_and_bookkeeping(tmp_path):
     assert run["J"].tolist() == [3.0, 1.0, 1.0] and run["x0"].tolist() == [0.0, 2.0, 2.0]
     optim.write_optim_csv(all_, tmp_path, diverged=True, iteration=7)
     assert (tmp_path / "timeseries" / "timeseries_iter_0007_DIVERGED.csv").exists()
+    # NaN costs (closed_loop_costs marks runs that were stopped early so): the bookkeeping still writes its files
+    best, idx = optim.cummin(np.array([[3.0], [1.0], [np.nan], [0.5]]))
+    assert best.ravel()[:2].tolist() == [3.0, 1.0] and idx.tolist()[:2] == [0, 1] and idx.shape == (4,)
+    optim.write_results(np.array([[0.0], [1.0], [2.0]]), [2.0, np.nan, np.inf], tmp_path, verbose=False)
+    assert pd.read_csv(tmp_path / "J_costfun.csv").shape == (3, 2) and pd.read_csv(tmp_path / "J_costfun_cummin.csv").shape == (3, 2)
 
 
 def test_sobol_sample_is_the_low_discrepancy_sequence_in_its_box():
@@ -54,7 +60,7 @@ def test_batched_candidates_cost_what_their_single_runs_cost(tmp_path_factory):
     from flowcontrol_amd.flowsolverparameters import ParamIC
 
     g = np.load(GOLDEN / "cylinder_O1.npz")
-    K0 = Controller.from_file(file=GOLDEN / "controllers" / "Kopt_reduced13.mat", x0=None)
+    K0 = Controller.from_file(file=controller_file(), x0=None)
     gains = [0.0, 0.5, 1.0, 2.0]
     make = lambda a: Controller(A=K0.A, B=K0.B, C=a * K0.C, D=a * K0.D)  # noqa: E731
     n, pen = 10, 0.3
@@ -85,3 +91,36 @@ def test_batched_candidates_cost_what_their_single_runs_cost(tmp_path_factory):
         assert np.allclose(series[i]["y_meas_1"].to_numpy(), ts["y_meas_1"].to_numpy(), rtol=1e-9, atol=1e-13)
         one.th.release_device()
     assert J[0] != J[2]  # the controller does change the cost
+
+
+@pytest.mark.gpu
+def test_a_diverging_candidate_ends_alone(tmp_path_factory):
+    """One of four candidates is driven to a non-finite state: it gets ``diverged_cost`` from the step it diverges at, the
+    other three run to the end and cost exactly what they cost in a clean batch (one diverging run used to end the
+    whole batch and leave the healthy candidates unevaluated)."""
+    from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver
+    from flowcontrol_amd.fem.spaces import Function
+    from flowcontrol_amd.flowsolverparameters import ParamIC
+
+    g = np.load(GOLDEN / "cylinder_O1.npz")
+    fs = CylinderFlowSolver.make_default(Re=100, path_out=tmp_path_factory.mktemp("diverge_batch"), num_steps=8)
+    fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
+    U0, P0 = Function(fs.W, g["UP0"]).split()
+    fs._assign_steady_state(U0, P0)
+
+    class Gain:
+        def __init__(self, a, blow_at=None):
+            self.a, self.n, self.blow_at = a, 0, blow_at
+
+        def step(self, y, dt):
+            self.n += 1
+            return np.array([np.inf if self.n == self.blow_at else self.a * y])
+
+    gains = [0.0, 0.3, -0.2, 0.1]
+    J_clean, _ = optim.closed_loop_costs(fs, [Gain(a) for a in gains], 8)
+    J, series = optim.closed_loop_costs(fs, [Gain(a, blow_at=4 if i == 2 else None) for i, a in enumerate(gains)], 8, diverged_cost=1e9)
+    assert J[2] == 1e9 and np.all(np.isfinite(J[[0, 1, 3]]))
+    assert np.allclose(J[[0, 1, 3]], J_clean[[0, 1, 3]], rtol=1e-13)
+    assert len(series[0]) == 9 and np.isnan(series[2]["y_meas_1"].to_numpy()[-1]) and np.isfinite(series[2]["y_meas_1"].to_numpy()[3])
+    optim.write_results(np.array(gains)[:, None], J, tmp_path_factory.mktemp("diverge_out"), verbose=False)
+    fs.th.release_device()

@@ -17,6 +17,7 @@ import scipy.sparse as sp
 from flowcontrol_amd.fem.mesh import Mesh, read_xdmf_mesh
 from flowcontrol_amd.fem.spaces import TaylorHood
 from oracle import ns_oracle as O
+from flowcontrol_amd.examples.data import mesh_file  # noqa: E402
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
 
@@ -31,7 +32,7 @@ def _raw(name):
         cells = inv[m.cells]
         cells[::3] = cells[::3][:, [0, 2, 1]]
         return m.coords[order], cells
-    z = np.load(GOLDEN / "meshes" / f"{name}.npz")
+    z = np.load(mesh_file(name))
     return z["coords"], z["cells"]
 
 

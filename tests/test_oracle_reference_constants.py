@@ -16,6 +16,7 @@ from flowcontrol_amd import ndsolver
 from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver
 from flowcontrol_amd.fem.boundary import combine_bcs
 from oracle import ns_oracle as O
+from flowcontrol_amd.examples.data import controller_file  # noqa: E402
 
 # reference tests/integration/test_cylinder.py:66-74
 U0_MAX_REF = 1.1921615450014942
@@ -80,7 +81,7 @@ def test_oracle_closed_loop_reproduces_reference(case, golden_dir):
     ts = O.TimeStepper(d, 100.0, 0.005, U0, dofs, prof, perm=perm)
     M = O.velocity_mass(d)
     rows = [s.row(fs) for s in fs.params_control.sensor_list]
-    K = sio.loadmat(golden_dir / "controllers" / "Kopt_reduced13.mat")
+    K = sio.loadmat(controller_file())
     Ad, Bd, Cd, Dd = O.zoh_discretize(K["A"], K["B"], K["C"], K["D"], 0.005)
     uic = O.div0_gaussian_nodal(th.node_coords, 0.0, 0.0, 1.0)  # default ParamIC()
     u_n = np.r_[uic[:, 0], uic[:, 1]]
