@@ -19,9 +19,10 @@ tail = t[t["k"] == "fc_tail"]["us"].to_numpy()
 lines = [open(out + "/probe.log").read().strip()]
 n = len(tail)
 lines.append(f"fc_tail launches {n}: with energy cells median {pd.Series(tail[n - 2 * steps : n - steps]).median():.1f} us, without {pd.Series(tail[n - steps :]).median():.1f} us")
-for k in ("fc_final", "fc_rhs_elem", "fc_rhs_gather", "fc_nd_sweep", "fc_nd_down_block"):
-    u = t[t["k"] == k]["us"]
-    if len(u):
+t["kk"] = t["Kernel_Name"].str.extract(r"((?:void )?fc_[a-z_0-9]+(?:<[^>]*>)?)")[0].str.replace("void ", "")
+last = t.iloc[-(len(t) // 3):]  # the stepping part of the run (setup kernels come first)
+for k, u in last.groupby("kk")["us"]:
+    if len(u) >= 10:
         lines.append(f"{k}: {len(u)} launches, median {u.median():.1f} us, mean {u.mean():.1f} us")
 open(out + "/summary.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
