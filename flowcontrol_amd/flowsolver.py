@@ -97,6 +97,27 @@ class FlowSolver(ABC):
         self.comm = None
         self._setup()
 
+    # ── the exporter, with the last step's log row possibly still pending (step() books a step's row while the NEXT step runs
+    #    on the GPU: the host work of a step is hidden behind the device's) ──────────────────────────────────────────────
+    @property
+    def exporter(self) -> "FlowExporter":
+        self._flush_log()
+        return self._exporter
+
+    @exporter.setter
+    def exporter(self, value) -> None:
+        self._pending_log = None
+        self._exporter = value
+
+    def _flush_log(self) -> None:
+        row = getattr(self, "_pending_log", None)
+        if row is not None:
+            self._pending_log = None
+            it, t, u_ctrl, y, dE, runtime = row
+            if self._niter_multiple_of(it, self.verbose):
+                self._exporter.log_progress(it, self.params_time.num_steps, t, self.params_time.Tfinal + self.params_time.Tstart, runtime)
+            self._exporter.log(u_ctrl=u_ctrl, y_meas=y, dE=dE, t=t, runtime=runtime)
+
     # ── validation (reference :108-165) ──────────────────────────────────────
     @staticmethod
     def _validate_params(params_flow, params_time, params_save, params_solver, params_mesh, params_control, params_ic, params_restart=None) -> None:
@@ -570,7 +591,6 @@ class FlowSolver(ABC):
         self._begin_stepping()
         t0 = time.time()
         u_ctrl = np.atleast_1d(np.asarray(u_ctrl, dtype=np.float64))
-        self.set_actuators_u_ctrl(u_ctrl)
         next_iter = self.iter + 1
         want_energy = self._niter_multiple_of(next_iter, self.params_save.energy_every)
         u_force = None
@@ -582,13 +602,21 @@ class FlowSolver(ABC):
             solver = self.solvers[self.order]
             slot = SLOT_BDF2 if self.order == 2 else SLOT_BDF1
             if isinstance(solver, _DeviceNDSolver):
-                y, dE, info = self.th.device().step(slot, u_ctrl, compute_energy=want_energy, u_force=u_force)
+                dev = self.th.device()
+                dev.step_begin(slot, u_ctrl, compute_energy=want_energy, u_force=u_force)  # the GPU works from here on ...
+                # ... while the host does what does not depend on this step's result: the previous step's log row and progress
+                # line, the actuators' bookkeeping (the reference does all of it inside the step, flowsolver.py:721-799)
+                self._flush_log()
+                self.set_actuators_u_ctrl(u_ctrl)
+                y, dE, info = dev.step_end()
             else:
+                self._flush_log()
+                self.set_actuators_u_ctrl(u_ctrl)
                 y, dE, info = self._step_with_plugin_solver(solver, slot, u_ctrl, want_energy)
         except FcDiverged:
             logger.critical("Solver diverged (Inf detected)")
             # the reference detects the non-finite velocity BEFORE it shifts the fields (flowsolver.py:727-751): u_n, u_nn, p_n stay
-            # what they were.  The device shifted inside the step's last kernel: withdraw that.
+            # what they were.  On the device the step's solution sits in a buffer of its own: it is simply not adopted.
             if isinstance(solver, _DeviceNDSolver):
                 self.th.device().undo_step()
             self.fields._mark_stale()  # the host mirrors are re-read from the device
@@ -609,12 +637,9 @@ class FlowSolver(ABC):
             self.order = 2
         self.fields._mark_stale()
         self.y_meas = y
-        runtime = time.time() - t0
-        if self._niter_multiple_of(self.iter, self.verbose):
-            self.exporter.log_progress(self.iter, self.params_time.num_steps, self.t, self.params_time.Tfinal + self.params_time.Tstart, runtime)
-        at_checkpoint = self._niter_multiple_of(self.iter, self.params_save.save_every)
-        self.exporter.log(u_ctrl=u_ctrl, y_meas=self.y_meas, dE=dE if want_energy else np.nan, t=self.t, runtime=runtime)
-        if at_checkpoint:
+        # this step's log row is booked while the next step runs (or as soon as anybody looks at the exporter)
+        self._pending_log = (self.iter, self.t, self._u_ctrl_prev, y, dE if want_energy else np.nan, time.time() - t0)
+        if self._niter_multiple_of(self.iter, self.params_save.save_every):
             self._checkpoint()
         return self.y_meas
 
