@@ -96,9 +96,10 @@ SIGNATURES: dict[str, list] = {
     "fc_set_state": [_H, _dp, _dp, C.c_void_p],
     "fc_get_state": [_H, C.c_void_p, C.c_void_p, C.c_void_p],
     "fc_get_solution": [_H, _dp],
-    "fc_step": [_H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_void_p],
+    "fc_step": [_H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
     "fc_step_begin": [_H, C.c_int, C.c_void_p, C.c_void_p, C.c_int],
-    "fc_step_end": [_H, C.c_void_p, C.POINTER(C.c_double), C.c_void_p],
+    "fc_step_end": [_H, C.c_void_p, C.c_void_p, C.c_void_p],
+    "fc_step_collect": [_H, C.c_void_p, C.c_void_p],
     "fc_set_rhs_operator": [_H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "fc_run": [_H, C.c_int, C.c_int32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int],
     "fc_assemble_rhs": [_H, C.c_int, C.c_void_p, _dp],

@@ -221,6 +221,28 @@ struct fc_ctx {
   DevBuf<unsigned char> velrow_p;              // 1 on the velocity rows (permuted numbering): the non-finite test
   DevBuf<int> asm_cells;  // multi-GPU: cells whose element matrices this rank assembles (own + touching a root dof)
   int n_asm = 0;
+  // OVERLAPPED TAIL (single GPU, direct factor apply): the host waits only for the sensors + non-finite flag, published right behind
+  // the last sweep launch (fc_early; the down-sweep launches test finiteness as they write).  Residual monitor, energy and the next
+  // step's element loop run on a second stream while the host and the next step's sweeps go on; their results (dE, |r|, |b|) land in
+  // a late record that fc_step_end collects only if the caller asks for them, else fc_step_collect / the next step does.
+  hipStream_t stream2 = nullptr;
+  DevBuf<fc_u64> solved;    // sequence number of the last step whose solve has finished (fc_early -> fc_wait_solved)
+  DevBuf<int> side_err;     // fc_wait_solved gave up
+  bool side_busy = false;   // stream2 has work that has not been synchronised with
+  bool overlap = true;      // FC_OVERLAP_TAIL=0: everything on one stream, one record
+  bool sweep_check = false; // the down-sweep launches of the apply being enqueued test the solution for finiteness
+  // late records, by step parity: two steps' tails may be in flight (the host makes sure that of step n - 2 has arrived before it enqueues step n,
+  // which is what frees b(n - 2) and, two steps later, the ring slot)
+  struct Late {
+    bool pending = false;
+    double seq = 0.0;
+    int energy = 0;
+    bool checked = false;
+  } late[2];
+  int last_par = 0, pend_par = 0;  // parity of the last step that ended / of the step in flight
+  bool pend_overlapped = false;
+  bool want_all = false;    // fc_step with dE_out / info_out: the caller waits for everything anyway -- one stream, one record
+  double last_dE = 0.0, last_info[4] = {0.0, 0.0, 0.0, 0.0};
   bool undo_ok = false;
   uint64_t step_count = 0;   // steps enqueued on this handle (the residual monitor's cadence counts them)
   bool last_checked = true;  // the last enqueued step formed its residual
@@ -228,10 +250,13 @@ struct fc_ctx {
     double* p = nullptr;
     size_t n = 0;
   } buf;  // = ring slot cur + 1: [y | x] (2N)
-  DevBuf<double> b, xsol, tmpN, tmpN2;
+  DevBuf<double> bstore;  // two right-hand sides: the late tail of step n reads b(n) while step n + 1 assembles b(n + 1)
+  BufView b;
+  DevBuf<double> xsol, tmpN, tmpN2;
   DevBuf<double> partial, scal;               // reductions; scal: [0]=E [1]=r2 [2]=b2
   DevBuf<double> uctrl, ydev, yseq, Eseq, useq;
   DevBuf<int> flag;
+  DevBuf<int> flag2;  // the late tail's row workgroups test finiteness too: into a word nobody reads
   double* pin = nullptr;    // pinned, device-mapped host record: [0..63] u_ctrl in, [64..] outputs
   double* pin_dev = nullptr;  // device address of the same memory
   uint64_t seq = 0;           // step sequence number published by the last kernel of a step
@@ -582,14 +607,15 @@ int launch_sweep(fc_ctx* h, const OrderSys& S, const Stage& st) {
   }
   if (st.kind == 1 && st.blk_count > 0) {
     const FcBlk* bp = S.blk.p + st.blk_begin;
+    const unsigned char* vr = h->sweep_check ? h->velrow_p.p : nullptr;  // (overlapped tail: finiteness tested as the solution is written)
 #define FC_BLOCK(L, R)                                                                                                                   \
   do {                                                                                                                                   \
     if (st.nt)                                                                                                                           \
       hipLaunchKernelGGL((fc_nd_down_block<L, R, double, true>), dim3(st.blk_count), dim3(256), 0, h->stream, bp, S.f_idx.p, S.f_val.p, \
-                         h->buf.p, h->N);                                                                                                \
+                         h->buf.p, h->N, vr, h->flag.p);                                                                                 \
     else                                                                                                                                 \
       hipLaunchKernelGGL((fc_nd_down_block<L, R>), dim3(st.blk_count), dim3(256), 0, h->stream, bp, S.f_idx.p, S.f_val.p, h->buf.p,     \
-                         h->N);                                                                                                          \
+                         h->N, vr, h->flag.p);                                                                                           \
   } while (0)
     switch (st.blk_lpr * 100 + st.blk_rps) {
       case 1601: FC_BLOCK(16, 1); break;
@@ -614,14 +640,15 @@ int launch_sweep(fc_ctx* h, const OrderSys& S, const Stage& st) {
   const int dest0 = st.kind == 0 ? st.row0 : h->N + st.row0;
   const int acc = st.kind == 0 ? 1 : 0;
   const int* wgo = st.wg_begin >= 0 ? S.wg_order.p + st.wg_begin : nullptr;
+  const unsigned char* vr = (h->sweep_check && st.kind == 1) ? h->velrow_p.p + st.row0 : nullptr;
 #define FC_SWEEP(L, SB)                                                                                                          \
   do {                                                                                                                           \
     if (st.nt)                                                                                                                   \
       hipLaunchKernelGGL((fc_nd_sweep<L, SB, double, true>), grid, block, 0, h->stream, st.nrows, rp, S.seg.p, S.f_idx.p,       \
-                         S.f_val.p, buf, dest0, acc, wgo);                                                                       \
+                         S.f_val.p, buf, dest0, acc, wgo, vr, h->flag.p);                                                        \
     else                                                                                                                         \
       hipLaunchKernelGGL((fc_nd_sweep<L, SB>), grid, block, 0, h->stream, st.nrows, rp, S.seg.p, S.f_idx.p, S.f_val.p, buf,     \
-                         dest0, acc, wgo);                                                                                       \
+                         dest0, acc, wgo, vr, h->flag.p);                                                                        \
   } while (0)
   const int key = st.lanes * 1000 + st.sub;
   switch (key) {
@@ -683,6 +710,15 @@ inline void ring_point(fc_ctx* h) { h->buf.p = ring_slot(h, h->cur + 1); }
 inline void ring_advance(fc_ctx* h) {  // the solution in h->buf becomes the state
   h->cur = (h->cur + 1) % 4;
   ring_point(h);
+}
+// the second stream (overlapped tail) idle: before anything but a time step touches the buffers its kernels read or write
+int quiesce(fc_ctx* h) {
+  if (h->side_busy) {
+    HIPCHK(hipStreamSynchronize(h->stream));   // (the side stream's gate waits for the main stream's last solve)
+    HIPCHK(hipStreamSynchronize(h->stream2));
+    h->side_busy = false;
+  }
+  return FC_OK;
 }
 // W-layout host vectors [u (2 nn) | p (nv)] <-> ring slots (needs a permutation)
 int state_upload(fc_ctx* h, const double* wn, const double* wnn) {
@@ -1467,6 +1503,8 @@ int fc_create(fc_handle* out, int device, int32_t nv, int32_t ne, int32_t nc, co
     h->n_cu = std::max(1, prop.multiProcessorCount);
   }
   TRYHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  TRYHIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+  if (const char* e = std::getenv("FC_OVERLAP_TAIL")) h->overlap = e[0] != '0';
   TRYHIP(hipEventCreate(&h->ev0));
   TRYHIP(hipEventCreate(&h->ev1));
   TRYHIP(hipHostMalloc((void**)&h->pin, kPinDoubles * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
@@ -1590,7 +1628,10 @@ int fc_create(fc_handle* out, int device, int32_t nv, int32_t ne, int32_t nc, co
   h->cur = 0;
   h->buf.n = 2 * (size_t)N;
   ring_point(h);
-  TRY(h->b.alloc(N));
+  TRY(h->bstore.alloc(2 * (size_t)N));
+  TRY(h->bstore.zero(h->stream));
+  h->b.p = h->bstore.p;
+  h->b.n = (size_t)N;
   TRY(h->xsol.alloc(N));
   TRY(h->tmpN.alloc(N));
   TRY(h->tmpN2.alloc(N));
@@ -1598,6 +1639,12 @@ int fc_create(fc_handle* out, int device, int32_t nv, int32_t ne, int32_t nc, co
   TRY(h->partial.alloc(3 * (size_t)h->nblk_N));
   TRY(h->scal.alloc(8));
   TRY(h->flag.alloc(1));
+  TRY(h->flag2.alloc(1));
+  TRY(h->flag2.zero(h->stream));
+  TRY(h->solved.alloc(1));
+  TRY(h->solved.zero(h->stream));
+  TRY(h->side_err.alloc(1));
+  TRY(h->side_err.zero(h->stream));
   TRY(h->isbc.alloc(N));
   TRY(h->scal.zero(h->stream));
   TRY(h->flag.zero(h->stream));
@@ -1620,8 +1667,10 @@ static int batch_repack(fc_ctx* h, int slot);
 int fc_destroy(fc_handle h) {
   if (!h) return FC_OK;
   (void)hipSetDevice(h->device);
+  if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   batch_drop_graphs(h);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
   if (h->pin) (void)hipHostFree(h->pin);
   if (h->xstage) (void)hipHostFree(h->xstage);
@@ -1654,6 +1703,7 @@ int fc_assemble_matrix(fc_handle h, int slot, double mass, double nu, const doub
                        const double* lin, double lin_scale, double pressure, double divergence) {
   if (!h || slot < 0 || slot >= FC_NUM_SLOTS) return fail(FC_ERR_INVALID, "fc_assemble_matrix: bad slot");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   const size_t nv2 = 2 * (size_t)h->nn;
   double *d_adv = nullptr, *d_lin = nullptr;
   if (adv) {
@@ -1704,6 +1754,7 @@ int fc_spmv(fc_handle h, int slot, const double* x, double* y) {
   if (!h || slot < 0 || slot >= FC_NUM_SLOTS || !x || !y) return fail(FC_ERR_INVALID, "fc_spmv: bad argument");
   if (!h->slot_ok[slot]) return fail(FC_ERR_NOT_READY, "slot not assembled");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   HIPCHK(hipMemcpyAsync(h->tmpN.p, x, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
   const int nb = launch_spmv<0>(h, h->N, (double)h->nnz / h->N, h->rowptr.p, h->col.p, h->vals[slot].p, h->tmpN.p, nullptr,
                                 h->tmpN2.p, nullptr, nullptr);
@@ -1724,6 +1775,7 @@ int fc_bench_spmv(fc_handle h, int slot, int reps, double* ms_per_launch) {
     return fail(FC_ERR_INVALID, "fc_bench_spmv: bad argument");
   if (!h->slot_ok[slot]) return fail(FC_ERR_NOT_READY, "slot not assembled");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   for (int i = 0; i < 3; ++i) {
     const int nb = launch_spmv<0>(h, h->N, (double)h->nnz / h->N, h->rowptr.p, h->col.p, h->vals[slot].p, h->tmpN.p,
                                   nullptr, h->tmpN2.p, nullptr, nullptr);
@@ -1747,6 +1799,7 @@ int fc_set_bc(fc_handle h, int32_t n_bc, const int32_t* bc_dofs, int32_t n_act, 
   if (!h || n_bc < 0 || n_act < 0 || n_act > 64 || (n_bc > 0 && !bc_dofs) || (n_bc > 0 && n_act > 0 && !profiles))
     return fail(FC_ERR_INVALID, "fc_set_bc: bad argument");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   std::vector<unsigned char> isbc(h->N, 0);
   for (int k = 0; k < n_bc; ++k) {
     if (bc_dofs[k] < 0 || bc_dofs[k] >= 2 * h->nn) return fail(FC_ERR_INVALID, "fc_set_bc: dof is not a velocity dof");
@@ -1783,6 +1836,7 @@ int fc_set_bc(fc_handle h, int32_t n_bc, const int32_t* bc_dofs, int32_t n_act, 
 int fc_set_force(fc_handle h, int32_t n_act, const double* profiles) {
   if (!h) return fail(FC_ERR_INVALID, "null handle");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   h->fvec_ok = false;
   if (!profiles || n_act == 0) {
     h->have_force = false;
@@ -1837,6 +1891,7 @@ int fc_set_sensors(fc_handle h, int32_t n_sens, const int32_t* rowptr, const int
   if (!h || n_sens < 0 || n_sens > 64 || (n_sens > 0 && (!rowptr || !idx || !w)))
     return fail(FC_ERR_INVALID, "fc_set_sensors: bad argument");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   const int nz = n_sens ? rowptr[n_sens] : 0;
   for (int k = 0; k < nz; ++k)
     if (idx[k] < 0 || idx[k] >= h->N) return fail(FC_ERR_INVALID, "fc_set_sensors: index out of range");
@@ -1860,6 +1915,7 @@ int fc_apply_bc(fc_handle h, int slot) {
   if (!h || slot < 0 || slot >= FC_NUM_SLOTS) return fail(FC_ERR_INVALID, "fc_apply_bc: bad slot");
   if (!h->slot_ok[slot]) return fail(FC_ERR_NOT_READY, "slot not assembled");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   const int N = h->N;
   if (slot < 2) {
     OrderSys& S = h->sys[slot];
@@ -1889,6 +1945,7 @@ int fc_apply_bc(fc_handle h, int slot) {
 int fc_set_permutation(fc_handle h, const int32_t* perm) {
   if (!h || !perm) return fail(FC_ERR_INVALID, "fc_set_permutation: null argument");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   std::vector<unsigned char> seen(h->N, 0);
   for (int i = 0; i < h->N; ++i) {
     if (perm[i] < 0 || perm[i] >= h->N || seen[perm[i]]) return fail(FC_ERR_INVALID, "fc_set_permutation: not a permutation");
@@ -1932,6 +1989,7 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
     return fail(FC_ERR_INVALID, "fc_solver_setup: bad argument");
   if (!h->have_perm) return fail(FC_ERR_NOT_READY, "fc_set_permutation not called");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   const int N = h->N;
   OrderSys& S = h->sys[slot];
   S.ready = false;
@@ -2125,6 +2183,7 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
 int fc_set_stage_diag(fc_handle h, int slot, const double* dscale) {
   if (!h || slot < 0 || slot > 1 || !dscale) return fail(FC_ERR_INVALID, "fc_set_stage_diag: bad argument");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   FCCHK(h->sys[slot].dscale.upload(dscale, (size_t)h->N, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return FC_OK;
@@ -2142,6 +2201,7 @@ int fc_solver_set_blocks(fc_handle h, int slot, int32_t n_stages, const int64_t*
   if (n_stages != (int)S.stages.size()) return fail(FC_ERR_INVALID, "fc_solver_set_blocks: stage count differs from fc_solver_setup");
   if (n_val != S.f_nnz) return fail(FC_ERR_INVALID, "fc_solver_set_blocks: value count differs from fc_solver_setup");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   const int N = h->N;
   std::vector<FcBlk> packed((size_t)std::max<int64_t>(1, n_blk));
   for (int64_t q = 0; q < n_blk; ++q) {
@@ -2198,6 +2258,7 @@ int fc_factor_plan(fc_handle h, int32_t n_nodes, const int64_t* nodes, int32_t n
       !ext_off || n_ext < 0 || !ext_p || n_ap <= 0 || !ap_src || max_slots < 1 || max_slots > 64)
     return fail(FC_ERR_INVALID, "fc_factor_plan: bad argument");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   if (level_ptr[0] != 0 || level_ptr[n_levels] != n_nodes || a_ptr[0] != 0 || a_ptr[n_levels] != n_a)
     return fail(FC_ERR_INVALID, "fc_factor_plan: level pointers do not cover the nodes / entries");
   h->have_plan = false;
@@ -2359,6 +2420,7 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
   if (!S.structured) return fail(FC_ERR_NOT_READY, "fc_solver_setup (structure) must be called first");
   if ((int64_t)h->pap_src.n != S.Ap_nnz) return fail(FC_ERR_INVALID, "fc_refactor: plan and solver structure disagree (matrix)");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   for (size_t g = 0; g < h->pnodes.size(); ++g) {
     const fc_ctx::PlanNode& nd = h->pnodes[g];
     const int nb = nd.nf - nd.ni;
@@ -3002,6 +3064,7 @@ int fc_update_operator(fc_handle h, int slot) {
   if (!S.structured) return fail(FC_ERR_NOT_READY, "fc_solver_setup (structure) must be called first");
   if ((int64_t)h->pap_src.n != S.Ap_nnz) return fail(FC_ERR_INVALID, "fc_update_operator: plan and solver structure disagree");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   hipLaunchKernelGGL(fc_gather64, dim3(nblocks(S.Ap_nnz, 256)), dim3(256), 0, h->stream, S.Ap_nnz, h->pap_src.p, h->vals[slot].p, S.Ap_val.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -3041,6 +3104,7 @@ int fc_get_factor_values(fc_handle h, int slot, int64_t n, double* out) {
 int fc_set_rhs_operator(fc_handle h, int slot, const int32_t* rowptr, const int32_t* col, const double* val) {
   if (!h || slot < 0 || slot > 1) return fail(FC_ERR_INVALID, "fc_set_rhs_operator: bad argument");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   OrderSys& S = h->sys[slot];
   if (!rowptr) {
     S.have_c = false;
@@ -3070,6 +3134,7 @@ int fc_set_rhs_operator(fc_handle h, int slot, const int32_t* rowptr, const int3
 int fc_set_energy_matrix(fc_handle h, const int32_t* rowptr, const int32_t* col, const double* val) {
   if (!h || !rowptr || !col || !val) return fail(FC_ERR_INVALID, "fc_set_energy_matrix: null argument");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   const int N = h->N;
   const int nz = rowptr[N];
   if (rowptr[0] != 0 || nz < 0) return fail(FC_ERR_INVALID, "fc_set_energy_matrix: bad row pointers");
@@ -3103,6 +3168,7 @@ int fc_set_state(fc_handle h, const double* u_n, const double* u_nn, const doubl
   h->pre_slot = -1;
   h->undo_ok = false;
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   const size_t nv2 = 2 * (size_t)h->nn, N = (size_t)h->N;
   // W-layout vectors [u | p] of both time levels (p_n = NULL keeps the present pressure)
   std::vector<double> wn(N, 0.0), wnn(N, 0.0);
@@ -3130,6 +3196,7 @@ int fc_undo_step(fc_handle h) {
   if (h->step_pending) return fail(FC_ERR_INVALID, "fc_undo_step: collect the step first (fc_step_end)");
   if (!h->undo_ok) return fail(FC_ERR_NOT_READY, "fc_undo_step: the last state change was not a single fc_step");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   HIPCHK(hipStreamSynchronize(h->stream));  // (a speculated element loop may still be reading the withdrawn state)
   // the step wrote its solution into a ring slot of its own: the three older levels are still where they were
   h->cur = (h->cur + 3) % 4;
@@ -3144,6 +3211,7 @@ int fc_undo_step(fc_handle h) {
 int fc_get_state(fc_handle h, double* u_n, double* u_nn, double* p_n) {
   if (!h) return fail(FC_ERR_INVALID, "null handle");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   const size_t nv2 = 2 * (size_t)h->nn, N = (size_t)h->N;
   std::vector<double> wn(N, 0.0), wnn(N, 0.0);
   if (h->have_perm && h->state_live) FCCHK(state_download(h, wn.data(), u_nn ? wnn.data() : nullptr));
@@ -3157,6 +3225,7 @@ int fc_get_state(fc_handle h, double* u_n, double* u_nn, double* p_n) {
 int fc_get_solution(fc_handle h, double* up) {
   if (!h || !up) return fail(FC_ERR_INVALID, "fc_get_solution: null argument");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   // the last step's solution IS the state (u_n, p_n)
   if (h->have_perm && h->state_live) return state_download(h, up, nullptr);
   std::fill(up, up + h->N, 0.0);
@@ -3168,7 +3237,8 @@ int fc_get_solution(fc_handle h, double* up) {
 // actuation enters in fc_rhs_gather), so it is enqueued now and runs while the host is between two
 // fc_step calls; enqueue_rhs skips its own launch when the prediction (same scheme, BDF2 after BDF1)
 // holds and nothing touched the state in between.  (Body forces enter in fc_rhs_gather too: build_force_vectors.)
-void speculate_next_rhs(fc_ctx* h, int order_slot) {
+void speculate_next_rhs(fc_ctx* h, int order_slot, hipStream_t stream = nullptr) {
+  if (!stream) stream = h->stream;
   static const bool enabled = [] {
     const char* e = std::getenv("FC_SPECULATE");
     return !(e && e[0] == '0');
@@ -3179,7 +3249,7 @@ void speculate_next_rhs(fc_ctx* h, int order_slot) {
   const int next = h->sys[order_slot].have_c ? order_slot : FC_SLOT_BDF2;
   if (!h->sys[next].ready || !h->sys[next].have_lift) return;
   const StepCoeffs c = coeffs_for(h, next);
-  hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks((int64_t)ncl * 8, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->cnp.p, h->geom.p,
+  hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks((int64_t)ncl * 8, 256)), dim3(256), 0, stream, h->nc, h->nn, h->cn.p, h->cnp.p, h->geom.p,
                      st_n(h), st_nn(h), (const double*)nullptr, 0, h->pin_dev, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p,
                      h->partitioned ? h->cell_list.p : nullptr, ncl);
   if (hipGetLastError() == hipSuccess) h->pre_slot = next;
@@ -3188,9 +3258,76 @@ void speculate_next_rhs(fc_ctx* h, int order_slot) {
 // fc_step in two halves: fc_step_begin writes the controls into the mapped record and enqueues the step's launches (the GPU
 // works from here on), fc_step_end waits for the record.  A host program can do its own per-step bookkeeping in between
 // (FlowSolver.step appends the previous step's log row there); fc_step is begin + end.
+constexpr int kLateRec = 160;  // late record of the overlapped tail in the pinned page: [E, sum r^2, sum b^2, seq, checksum, checksum]
+
+// the overlapped form of a step (fc_ctx::stream2): see the comment there
+static bool step_can_overlap(const fc_ctx* h, int order_slot) {
+  const OrderSys& S = h->sys[order_slot];
+  return h->overlap && !h->want_all && !h->partitioned && h->method == FC_METHOD_REFINE && !S.inexact && !S.truncated && S.bits == 64 && use_fused_tail(h) && !h->timing &&
+         !h->phase_timing;
+}
+
+static int collect_late(fc_ctx* h, int par);
+
+static int step_enqueue_overlapped(fc_ctx* h) {
+  double* dev = h->pin_dev;
+  const int order_slot = h->pend_slot, compute_energy = h->pend_energy;
+  OrderSys& S = h->sys[order_slot];
+  if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this order");
+  const int par = (int)(h->step_count & 1);
+  // the late tail of step n - 2 read b(n - 2) -- the buffer this step assembles into -- and, two steps on, its ring slot would be
+  // overwritten: make sure it has finished (it did, a step ago; this is a read of a host-mapped word)
+  FCCHK(collect_late(h, par));
+  h->b.p = h->bstore.p + (size_t)par * (size_t)h->N;
+  FCCHK(enqueue_rhs(h, order_slot, dev, dev + 32));
+  h->sweep_check = true;  // the down-sweep launches raise h->flag on a non-finite velocity entry as they write it
+  const int code = apply_factors(h, S);
+  h->sweep_check = false;
+  FCCHK(code);
+  const double* x = h->buf.p + h->N;
+  const double* b_now = h->b.p;
+  hipLaunchKernelGGL(fc_early, dim3(1), dim3(256), 0, h->stream, h->n_sens, h->s_rowptr.p, h->s_idxp.p, h->s_w.p, x, dev + 64, h->flag.p, dev + 136, dev + 137,
+                     h->pend_seq, h->solved.p);
+  ring_advance(h);  // the solution just written is the state from here on
+  h->state_live = true;
+  const bool res = h->check_residual != 0 && (h->step_count % (uint64_t)h->check_residual) == 0;
+  h->last_checked = res;
+  ++h->step_count;
+  speculate_next_rhs(h, order_slot);  // the next step's element loop, on the main stream behind fc_early as ever
+  // ---- side stream: [gate: this step's solve has finished] residual monitor + energy -> this step's late record
+  hipLaunchKernelGGL(fc_wait_solved, dim3(1), dim3(1), 0, h->stream2, h->solved.p, (fc_u64)h->pend_seq, h->side_err.p);
+  const int reps = std::max(1, nblocks(h->N, 32 * 2048));
+  const int g_rows = res ? nblocks(h->N, 32 * reps) : 0, g_cells = (compute_energy && h->nc > 0) ? nblocks(h->nc, 32 * reps) : 0;
+  const int g = g_rows + g_cells;
+  if (g > h->nblk_N) return fail(FC_ERR_INVALID, "step: partial buffer too small");
+  if (g > 0)
+    hipLaunchKernelGGL(fc_tail<false>, dim3(g), dim3(256), 0, h->stream2, h->N, h->velrow_p.p, x, b_now, res ? S.Ap_rowptr.p : nullptr, S.Ap_col.p, S.Ap_val.p, g_rows,
+                       0, reps, h->nc, g_cells > 0 ? h->cnp.p : nullptr, h->geom.p, (const unsigned char*)nullptr, (const int*)nullptr, h->nc, h->flag2.p,
+                       h->partial.p, FcFin{});
+  hipLaunchKernelGGL(fc_final_late, dim3(1), dim3(256), 0, h->stream2, g_cells > 0 ? g : 0, g_cells > 0 ? h->partial.p + 2 * (size_t)g : nullptr, res ? g : 0,
+                     res ? h->partial.p : nullptr, dev + kLateRec + 8 * par, h->pend_seq);
+  HIPCHK(hipGetLastError());
+  h->late[par].pending = true;
+  h->late[par].seq = h->pend_seq;
+  h->late[par].energy = compute_energy;
+  h->late[par].checked = res;
+  h->side_busy = true;
+  return FC_OK;
+}
+
 static int step_enqueue(fc_ctx* h) {
   double* dev = h->pin_dev;
   h->pend_seq = (double)(++h->seq);
+  h->pend_overlapped = step_can_overlap(h, h->pend_slot);
+  if (h->pend_overlapped) {
+    h->pend_par = (int)(h->step_count & 1);
+    FCCHK(step_enqueue_overlapped(h));
+    h->pend_checked = h->last_checked;
+    h->undo_ok = true;
+    return FC_OK;
+  }
+  FCCHK(quiesce(h));
+  h->b.p = h->bstore.p;
   FCCHK(enqueue_step(h, h->pend_slot, dev, dev + 64, dev + 128, dev + 129, dev + 136, h->pend_energy, dev + 32, dev + 137, h->pend_seq));
   h->pend_checked = h->last_checked;
   h->undo_ok = true;  // the step wrote into a ring slot of its own: the older levels are intact
@@ -3215,6 +3352,50 @@ int fc_step_begin(fc_handle h, int order_slot, const double* u_ctrl, const doubl
   h->pend_energy = compute_energy;
   FCCHK(step_enqueue(h));
   h->step_pending = true;
+  return FC_OK;
+}
+
+// the late record of an overlapped step (fc_final_late on the side stream): [E, sum r^2, sum b^2, seq, checksum, checksum], one per step parity
+static int collect_late(fc_ctx* h, int par) {
+  fc_ctx::Late& L = h->late[par];
+  if (!L.pending) return FC_OK;
+  volatile double* rec = h->pin + kLateRec + 8 * par;
+  const double seq = L.seq;
+  auto bits = [](double v) {
+    unsigned long long u;
+    std::memcpy(&u, &v, sizeof u);
+    return u;
+  };
+  auto ok = [&]() {
+    if (rec[3] != seq) return false;
+    unsigned long long x = bits(seq), w = x, k = 3;
+    for (int i = 0; i < 3; ++i, k += 2) {
+      const unsigned long long v = bits(rec[i]);
+      x ^= v;
+      w += k * v;
+    }
+    return x == bits(rec[4]) && w == bits(rec[5]);
+  };
+  bool seen = false;
+  for (long spin = 0; spin < 20000000L; ++spin) {
+    if (ok()) {
+      seen = true;
+      break;
+    }
+    __builtin_ia32_pause();
+  }
+  if (!seen) {
+    HIPCHK(hipStreamSynchronize(h->stream2));
+    if (!ok()) return fail(FC_ERR_HIP, "fc_step: the late record (residual monitor, energy) never arrived or failed its checksum");
+  }
+  L.pending = false;
+  if (par == h->last_par) {  // the values fc_step_collect hands out are those of the LAST step that ended
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    const double r2 = rec[1], b2 = rec[2];
+    h->last_dE = L.energy ? rec[0] : nan;
+    h->last_info[1] = L.checked ? std::sqrt(r2 / (b2 > 0 ? b2 : 1.0)) : nan;
+    h->last_info[2] = L.checked ? std::sqrt(b2) : nan;
+  }
   return FC_OK;
 }
 
@@ -3269,23 +3450,45 @@ int fc_step_end(fc_handle h, double* y_out, double* dE_out, double* info_out) {
   }
   for (int s = 0; s < h->n_sens; ++s)
     if (y_out) y_out[s] = pin[64 + s];
-  if (dE_out) *dE_out = compute_energy ? pin[128] : std::numeric_limits<double>::quiet_NaN();
   const int flag = ((int)pin[136]) % 1024;
-  if (info_out) {
+  const double nan = std::numeric_limits<double>::quiet_NaN();
+  h->last_info[0] = h->method == FC_METHOD_REFINE ? h->max_iter : h->last_krylov_iters;  // refinement sweeps / Krylov iterations
+  h->last_info[3] = flag;
+  if (h->pend_overlapped) {
+    h->last_par = h->pend_par;
+    // energy and residual norms follow in the late record: wait for it only if the caller wants them now
+    if (dE_out || info_out) FCCHK(collect_late(h, h->last_par));
+  } else {
     const double r2 = pin[129], b2 = pin[130];
     const bool checked = h->pend_checked;  // (check_residual = n > 1: the monitor ran on every n-th step only)
-    info_out[0] = h->method == FC_METHOD_REFINE ? h->max_iter : h->last_krylov_iters;  // refinement sweeps / Krylov iterations
-    info_out[1] = checked ? std::sqrt(r2 / (b2 > 0 ? b2 : 1.0)) : std::numeric_limits<double>::quiet_NaN();
-    info_out[2] = checked ? std::sqrt(b2) : std::numeric_limits<double>::quiet_NaN();
-    info_out[3] = flag;
+    h->last_dE = compute_energy ? pin[128] : nan;
+    h->last_info[1] = checked ? std::sqrt(r2 / (b2 > 0 ? b2 : 1.0)) : nan;
+    h->last_info[2] = checked ? std::sqrt(b2) : nan;
   }
+  if (dE_out) *dE_out = h->last_dE;
+  if (info_out) std::copy(h->last_info, h->last_info + 4, info_out);
   if (flag) return fail(FC_ERR_DIVERGED, "non-finite velocity after solve");
+  return FC_OK;
+}
+
+// energy and solve info of the last fc_step_end that was called WITHOUT dE_out / info_out (the overlapped tail computes them while the host
+// is already busy with the next step): blocks until they are there.  Always valid after any fc_step_end.
+int fc_step_collect(fc_handle h, double* dE_out, double* info_out) {
+  if (!h) return fail(FC_ERR_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  FCCHK(collect_late(h, h->last_par));
+  if (dE_out) *dE_out = h->last_dE;
+  if (info_out) std::copy(h->last_info, h->last_info + 4, info_out);
   return FC_OK;
 }
 
 int fc_step(fc_handle h, int order_slot, const double* u_ctrl, const double* u_force, double* y_out, double* dE_out,
             int compute_energy, double* info_out) {
-  FCCHK(fc_step_begin(h, order_slot, u_ctrl, u_force, compute_energy));
+  if (!h) return fail(FC_ERR_INVALID, "null handle");
+  h->want_all = dE_out != nullptr || info_out != nullptr;
+  const int code = fc_step_begin(h, order_slot, u_ctrl, u_force, compute_energy);
+  h->want_all = false;
+  FCCHK(code);
   return fc_step_end(h, y_out, dE_out, info_out);
 }
 
@@ -3294,8 +3497,10 @@ int fc_run(fc_handle h, int first_order_slot, int32_t n_steps, const double* u_c
   FCCHK(check_step_ready(h, first_order_slot));
   if (n_steps <= 0) return fail(FC_ERR_INVALID, "fc_run: n_steps must be positive");
   h->undo_ok = false;  // (fc_undo_step withdraws a single fc_step)
+  h->b.p = h->bstore.p;
   if (h->n_act > 0 && !u_ctrl) return fail(FC_ERR_INVALID, "fc_run: u_ctrl is null");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   const int na = std::max(1, h->n_act), ns = std::max(1, h->n_sens);
   const size_t nu = u_ctrl_is_sequence ? (size_t)n_steps * na : (size_t)na;
   std::vector<double> uh(nu, 0.0);
@@ -3329,6 +3534,7 @@ int fc_assemble_rhs(fc_handle h, int order_slot, const double* u_ctrl, double* b
   FCCHK(check_step_ready(h, order_slot));
   if (!b_out || (h->n_act > 0 && !u_ctrl)) return fail(FC_ERR_INVALID, "fc_assemble_rhs: null argument");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   if (h->n_act) HIPCHK(hipMemcpyAsync(h->uctrl.p, u_ctrl, h->n_act * sizeof(double), hipMemcpyHostToDevice, h->stream));
   FCCHK(enqueue_rhs(h, order_slot, h->uctrl.p));
   hipLaunchKernelGGL(fc_scatter_perm, dim3(nblocks(h->N, 256)), dim3(256), 0, h->stream, h->N, h->perm.p, h->b.p,
@@ -3349,6 +3555,8 @@ static int solve_once(fc_handle h, int slot, const double* b, double* x, double*
   OrderSys& S = h->sys[slot];
   if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this slot");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
+  h->b.p = h->bstore.p;
   const int N = h->N, g = nblocks(N, 256);
   HIPCHK(hipMemcpyAsync(h->tmpN.p, b, (size_t)N * sizeof(double), hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(fc_gather_perm, dim3(g), dim3(256), 0, h->stream, N, h->perm.p, h->tmpN.p, h->b.p);
@@ -3417,6 +3625,7 @@ int fc_energy(fc_handle h, const double* u, double* E) {
   if (!h || !u || !E) return fail(FC_ERR_INVALID, "fc_energy: null argument");
   if (!h->slot_ok[FC_SLOT_MASS]) return fail(FC_ERR_NOT_READY, "FC_SLOT_MASS not assembled");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   HIPCHK(hipMemcpyAsync(h->tmpN.p, u, 2 * (size_t)h->nn * sizeof(double), hipMemcpyHostToDevice, h->stream));
   FCCHK(enqueue_energy(h, h->tmpN.p, h->scal.p + 3));
   HIPCHK(hipMemcpyAsync(h->pin, h->scal.p + 3, sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -3428,6 +3637,7 @@ int fc_energy(fc_handle h, const double* u, double* E) {
 int fc_measure(fc_handle h, const double* up, double* y) {
   if (!h || !up || (h->n_sens > 0 && !y)) return fail(FC_ERR_INVALID, "fc_measure: null argument");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   if (h->n_sens == 0) return FC_OK;
   HIPCHK(hipMemcpyAsync(h->tmpN.p, up, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(fc_sensors, dim3(h->n_sens), dim3(64), 0, h->stream, h->n_sens, h->s_rowptr.p, h->s_idx.p, h->s_w.p,
@@ -3444,6 +3654,7 @@ int fc_bench_sweeps(fc_handle h, int slot, int reps, double* ms_per_apply, int32
   OrderSys& S = h->sys[slot];
   if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this slot");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   const int N = h->N, g = nblocks(N, 256);
   // rhs = last assembled b (any finite data); re-copied each rep so values stay bounded
   for (int i = 0; i < 2; ++i) {
@@ -3472,6 +3683,7 @@ int fc_set_partition(fc_handle h, int32_t n_local_cells, const int32_t* local_ce
   if (!h || n_local_cells < 0 || (n_local_cells > 0 && !local_cells) || !rowkind)
     return fail(FC_ERR_INVALID, "fc_set_partition: bad argument");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   const int N = h->N, nc = h->nc;
   std::vector<unsigned char> mine(nc, 0);
   for (int k = 0; k < n_local_cells; ++k) {
@@ -3633,6 +3845,7 @@ int fc_set_phase_timing(fc_handle h, int on) {
   if (!h) return fail(FC_ERR_INVALID, "null handle");
   if (h->step_pending) return fail(FC_ERR_INVALID, "fc_set_phase_timing: a step is in flight");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->phase_timing = on != 0;
   h->pused = 0;
@@ -3652,6 +3865,7 @@ int fc_get_phase_timing(fc_handle h, double* us, int64_t* steps) {
 int fc_set_timing(fc_handle h, int on) {
   if (!h) return fail(FC_ERR_INVALID, "null handle");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->timing = on != 0;
   h->tused = 0;
@@ -4036,6 +4250,7 @@ int fc_set_batch(fc_handle h, int32_t k) {
   if (!h || k < 0 || k > 16) return fail(FC_ERR_INVALID, "fc_set_batch: k must be in [0, 16]");
   if (h->bat.pending || h->step_pending) return fail(FC_ERR_INVALID, "fc_set_batch: a step is in flight");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   fc_ctx::Batch& B = h->bat;
   if (k == 0) {
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -4116,6 +4331,7 @@ int fc_set_state_batch(fc_handle h, int32_t k, const double* u_n, const double* 
   if (!u_n || !u_nn) return fail(FC_ERR_INVALID, "fc_set_state_batch: null argument");
   if (!h->have_perm) return fail(FC_ERR_NOT_READY, "fc_set_state_batch: no permutation (fc_setup_solver)");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   fc_ctx::Batch& B = h->bat;
   B.pre_slot = -1;  // element vectors of the old state
   const size_t N = (size_t)h->N;
@@ -4346,6 +4562,7 @@ int fc_step_batch_begin(fc_handle h, int order_slot, int32_t k, const double* u_
   if (h->n_act > 0 && !u_ctrl) return fail(FC_ERR_INVALID, "fc_step_batch: u_ctrl is null");
   if (h->bat.pending || h->step_pending) return fail(FC_ERR_INVALID, "fc_step_batch_begin: the previous step was not collected");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   h->pre_slot = -1;
   volatile double* pin = h->pin;
   for (int s = 0; s < h->bat.KB; ++s)
@@ -4460,6 +4677,7 @@ int fc_bench_batch_apply(fc_handle h, int slot, int reps, double* ms_per_apply) 
   OrderSys& S = h->sys[slot];
   if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_setup_solver not called for this slot");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   fc_ctx::Batch& B = h->bat;
   const size_t bytes = (size_t)h->N * B.KB * sizeof(double);
   for (int i = 0; i < 2; ++i) {
@@ -4487,6 +4705,7 @@ int fc_solve_batch(fc_handle h, int slot, int32_t k, const double* b, double* x)
   if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_setup_solver not called for this slot");
   if (S.inexact) return fail(FC_ERR_INVALID, "fc_solve_batch: this slot's factors are inexact (a preconditioner for GMRES): the batched path applies them directly");
   HIPCHK(hipSetDevice(h->device));
+  FCCHK(quiesce(h));
   fc_ctx::Batch& B = h->bat;
   const int N = h->N;
   // permute on the host (setup-path helper): y_p[i] = b[perm[i]]

@@ -465,8 +465,12 @@ __global__ __launch_bounds__(256) void fc_nd_sweep(int nrows, const int64_t* __r
                                                    const int* __restrict__ idx,
                                                    const VT* __restrict__ val,
                                                    double* __restrict__ buf, int dest0, int accumulate,
-                                                   const int* __restrict__ wg_order = nullptr) {
+                                                   const int* __restrict__ wg_order = nullptr,
+                                                   const unsigned char* __restrict__ velrow = nullptr, int* __restrict__ flag = nullptr) {
   // wg_order: launch position -> row group, by decreasing work (the long rows start first instead of forming the launch's tail)
+  // velrow (down stages of a time step, overlapped tail): the stage's slice of the velocity-row mask; a non-finite solution entry on
+  // such a row raises *flag -- every solution row is written by exactly one down-stage launch, so the reference's finiteness test
+  // (flowsolver.py:731,816-819) costs no pass of its own
   const int wg = wg_order ? wg_order[blockIdx.x] : (int)blockIdx.x;
   constexpr int RPB = 256 / LANES;
   constexpr int SW = LANES < 64 ? LANES : 64;  // shuffle width (descriptor broadcast, reduction)
@@ -535,11 +539,15 @@ __global__ __launch_bounds__(256) void fc_nd_sweep(int nrows, const int64_t* __r
     if (threadIdx.x == 0 && row < nrows) {
       const double t = (part[0] + part[1]) + (part[2] + part[3]);
       const int d = dest0 + row;
-      buf[d] = accumulate ? buf[d] + t : t;
+      const double o = accumulate ? buf[d] + t : t;
+      buf[d] = o;
+      if (velrow && velrow[row] && !isfinite(o)) atomicOr(flag, 1);
     }
   } else if (row < nrows && lane == 0) {
     const int d = dest0 + row;
-    buf[d] = accumulate ? buf[d] + s : s;
+    const double o = accumulate ? buf[d] + s : s;
+    buf[d] = o;
+    if (velrow && velrow[row] && !isfinite(o)) atomicOr(flag, 1);
   }
 }
 
@@ -572,7 +580,9 @@ template <int LPR, int RPS, typename VT = double, bool NT = false>
 __global__ __launch_bounds__(256) void fc_nd_down_block(const FcBlk* __restrict__ blk,
                                                         const int* __restrict__ idxlist,
                                                         const VT* __restrict__ val,
-                                                        double* __restrict__ buf, int N) {
+                                                        double* __restrict__ buf, int N,
+                                                        const unsigned char* __restrict__ velrow = nullptr, int* __restrict__ flag = nullptr) {
+  // velrow / flag: as in fc_nd_sweep (here the whole mask, indexed by the permuted row)
   __shared__ double xs[FC_BLK_TILE];
   constexpr int SLOTS = 256 / LPR;  // rows in flight per workgroup
   const FcBlk b = blk[blockIdx.x];
@@ -633,7 +643,10 @@ __global__ __launch_bounds__(256) void fc_nd_down_block(const FcBlk* __restrict_
 #pragma unroll
     for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_down(s, off, LPR);
     const int r = slot + k * SLOTS;
-    if (l == 0 && r < b.nrows) buf[N + b.row0 + r] = s;
+    if (l == 0 && r < b.nrows) {
+      buf[N + b.row0 + r] = s;
+      if (velrow && velrow[b.row0 + r] && !isfinite(s)) atomicOr(flag, 1);
+    }
   }
 }
 
@@ -976,6 +989,96 @@ __global__ __launch_bounds__(256) void fc_final(int n_e, const double* __restric
                                                 const int* __restrict__ flag, double* __restrict__ flag_out,
                                                 double* __restrict__ seq_out, double seq) {
   fc_final_body<false>(n_e, e_partial, E_out, n_r, r_partial, r_out, n_sens, s_rowptr, s_idx, s_w, up, y, flag, flag_out, seq_out, seq);
+}
+
+// Overlapped tail (single GPU): what the host WAITS for is only this -- the sensor rows on the new solution and the non-finite flag
+// (raised by the down-sweep launches themselves), published right behind the last sweep launch.  Residual monitor and energy follow on
+// a second stream while the host and the next step go on (fc_final_late publishes them to a record of their own).
+__global__ __launch_bounds__(256) void fc_early(int n_sens, const int* __restrict__ s_rowptr, const int* __restrict__ s_idxp,
+                                                const double* __restrict__ s_w, const double* __restrict__ x, double* __restrict__ y,
+                                                int* __restrict__ flag, double* __restrict__ flag_out, double* __restrict__ seq_out, double seq,
+                                                fc_u64* __restrict__ solved) {
+  __shared__ double ysh[64];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  for (int s = wave; s < n_sens; s += 4) {
+    double acc = 0.0;
+    for (int k = s_rowptr[s] + lane; k < s_rowptr[s + 1]; k += 64) acc += s_w[k] * x[s_idxp[k]];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) ysh[s] = acc;
+  }
+  __syncthreads();
+  if (t == 0) {
+    const int fl = flag[0] & 1;
+    flag[0] = 0;  // per step (the next step's sweeps raise it again if need be)
+    fc_publish(ysh, n_sens, 0.0, 0.0, 0.0, (double)fl, y, y + 64, y + 65, flag_out, seq_out, seq);
+    // the side stream's gate (fc_wait_solved): every kernel of this step's solve finished before this one started
+    __hip_atomic_store(solved, (fc_u64)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// first kernel of a step's side-stream batch: one thread waits until the main stream's fc_early of step `seq` has run (bounded: a solve
+// that never arrives -- a failed launch -- ends the wait after ~50 ms and leaves *gave_up = 1; the late record then never matches and the
+// host reports it).  HIP events would do the same across streams, but cost the host ~7 us per record / wait pair on this runtime.
+__global__ void fc_wait_solved(const fc_u64* __restrict__ solved, fc_u64 seq, int* __restrict__ gave_up) {
+  for (long spin = 0; spin < 2000000L; ++spin) {
+    if (__hip_atomic_load(solved, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= seq) return;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  *gave_up = 1;
+}
+// the late record: rec[0] = E, rec[1] = sum r^2, rec[2] = sum b^2, rec[3] = seq, rec[4], rec[5] = checksums (as fc_publish)
+__global__ __launch_bounds__(256) void fc_final_late(int n_e, const double* __restrict__ e_partial, int n_r, const double* __restrict__ r_partial,
+                                                     double* __restrict__ rec, double seq) {
+  __shared__ double red[3][256];
+  const int t = threadIdx.x;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  constexpr int U = 8;
+  double pe[U], pr[U], pb[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int i = t + 256 * u;
+    pe[u] = (e_partial && i < n_e) ? e_partial[i] : 0.0;
+    pr[u] = (r_partial && i < n_r) ? r_partial[i] : 0.0;
+    pb[u] = (r_partial && i < n_r) ? r_partial[n_r + i] : 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    a0 += pe[u];
+    a1 += pr[u];
+    a2 += pb[u];
+  }
+  if (e_partial)
+    for (int i = t + 256 * U; i < n_e; i += 256) a0 += e_partial[i];
+  if (r_partial)
+    for (int i = t + 256 * U; i < n_r; i += 256) {
+      a1 += r_partial[i];
+      a2 += r_partial[n_r + i];
+    }
+  red[0][t] = a0;
+  red[1][t] = a1;
+  red[2][t] = a2;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (t < st) {
+      red[0][t] += red[0][t + st];
+      red[1][t] += red[1][t + st];
+      red[2][t] += red[2][t + st];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    typedef unsigned long long u64;
+    const double v[3] = {e_partial ? 0.5 * red[0][0] : 0.0, r_partial ? red[1][0] : 0.0, r_partial ? red[2][0] : 0.0};
+    u64 x = (u64)__double_as_longlong(seq), w = x, k = 3;
+    for (int i = 0; i < 3; ++i, k += 2) {
+      rec[i] = v[i];
+      x ^= (u64)__double_as_longlong(v[i]);
+      w += k * (u64)__double_as_longlong(v[i]);
+    }
+    rec[4] = __longlong_as_double((long long)x);
+    rec[5] = __longlong_as_double((long long)w);
+    rec[3] = seq;
+  }
 }
 
 // what the LAST workgroup of a fused fc_tail does instead of a separate fc_final launch (enabled: cnt != nullptr)

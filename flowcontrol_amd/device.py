@@ -584,19 +584,42 @@ class DeviceSolver:
         if code:
             check(code)
 
-    def step_end(self):
-        """Second half: wait for the step's record; returns (y, dE, info) like :meth:`step`."""
+    def step_end(self, early: bool = False):
+        """Second half: wait for the step's record; returns (y, dE, info) like :meth:`step`.
+
+        ``early=True``: return as soon as the measurements (and the non-finite flag) are there — ``(y, None, None)`` — and leave
+        energy / solve info to :meth:`step_collect`; on a single-GPU handle they are computed on a second stream while the host and
+        the next step go on (``fc_step_collect`` in fc_hip.h)."""
         u, uf, y, info, dE, (pu, puf, py, pinfo), pdE = self._step_bufs
-        code = self.lib.fc_step_end(self._h, py, pdE, pinfo)
+        code = self.lib.fc_step_end(self._h, py, None if early else pdE, None if early else pinfo)
+        if self._xchg_error is not None:
+            self._raise_exchange_error()
+        if code:
+            check(code)
+        if early:
+            return y[: self.n_sens].copy(), None, None
+        return y[: self.n_sens].copy(), dE.value, info
+
+    def step_collect(self):
+        """(dE, info) of the last step collected with ``step_end(early=True)``; blocks until they exist."""
+        u, uf, y, info, dE, (pu, puf, py, pinfo), pdE = self._step_bufs
+        check(self.lib.fc_step_collect(self._h, pdE, pinfo))
+        return dE.value, info
+
+    def step(self, order_slot: int, u_ctrl, compute_energy: bool = True, u_force=None):
+        """One blocking ``fc_step``: (y, dE, info) of this step, all waited for."""
+        u, uf, y, info, dE, (pu, puf, py, pinfo), pdE = self._step_buffers()
+        if self.n_act:
+            u[:] = u_ctrl
+            if u_force is not None:
+                uf[:] = u_force
+        code = self.lib.fc_step(self._h, order_slot, pu if self.n_act else None, puf if (self.n_act and u_force is not None) else None, py, pdE,
+                                1 if compute_energy else 0, pinfo)
         if self._xchg_error is not None:
             self._raise_exchange_error()
         if code:
             check(code)
         return y[: self.n_sens].copy(), dE.value, info
-
-    def step(self, order_slot: int, u_ctrl, compute_energy: bool = True, u_force=None):
-        self.step_begin(order_slot, u_ctrl, compute_energy, u_force)
-        return self.step_end()
 
     def run(self, first_order_slot: int, n_steps: int, u_ctrl, compute_energy: bool = True):
         u = _f64(u_ctrl)

@@ -97,6 +97,12 @@ class FlowSolver(ABC):
         self.comm = None
         self._setup()
 
+    _pending_log = None        # (iter, t, u_ctrl, y, dE | None, runtime) of the last step, not yet in the exporter
+    _late_pending = False      # the last device step's (dE, info) have not been fetched yet
+    _solve_info = None
+    _last_dE = float("nan")
+    _residual_breach = None
+
     # ── the exporter, with the last step's log row possibly still pending (step() books a step's row while the NEXT step runs
     #    on the GPU: the host work of a step is hidden behind the device's) ──────────────────────────────────────────────
     @property
@@ -109,11 +115,36 @@ class FlowSolver(ABC):
         self._pending_log = None
         self._exporter = value
 
+    def _collect(self) -> None:
+        """Energy and solve info of the last step, which the device computes on a second stream while the host and the next step go on
+        (``fc_step_collect``): fetched once, when somebody needs them — the log row, ``solve_info``, the residual check."""
+        if getattr(self, "_late_pending", False):
+            self._late_pending = False
+            dE, info = self.th.device().step_collect()
+            self._last_dE = dE
+            self._solve_info = info
+            if info[1] > self.residual_tol:  # NaN (monitor off / not this step) compares False
+                self._residual_breach = (float(info[1]), self.iter)
+
+    @property
+    def solve_info(self):
+        """(refinement sweeps / Krylov iterations, relative residual, |b|, flag) of the last step (the device's buffer, reused by the next)."""
+        self._collect()
+        return self._solve_info
+
+    @solve_info.setter
+    def solve_info(self, value) -> None:
+        self._late_pending = False
+        self._solve_info = value
+
     def _flush_log(self) -> None:
         row = getattr(self, "_pending_log", None)
         if row is not None:
             self._pending_log = None
             it, t, u_ctrl, y, dE, runtime = row
+            if dE is None:  # energy of an overlapped step: it has arrived by now
+                self._collect()
+                dE = self._last_dE
             if self._niter_multiple_of(it, self.verbose):
                 self._exporter.log_progress(it, self.params_time.num_steps, t, self.params_time.Tfinal + self.params_time.Tstart, runtime)
             self._exporter.log(u_ctrl=u_ctrl, y_meas=y, dE=dE, t=t, runtime=runtime)
@@ -608,11 +639,14 @@ class FlowSolver(ABC):
                 # line, the actuators' bookkeeping (the reference does all of it inside the step, flowsolver.py:721-799)
                 self._flush_log()
                 self.set_actuators_u_ctrl(u_ctrl)
-                y, dE, info = dev.step_end()
+                # back as soon as the measurements are: energy and residual of this step follow (self._collect)
+                y, dE, info = dev.step_end(early=True)
+                self._late_pending = True
             else:
                 self._flush_log()
                 self.set_actuators_u_ctrl(u_ctrl)
                 y, dE, info = self._step_with_plugin_solver(solver, slot, u_ctrl, want_energy)
+                self.solve_info = info
         except FcDiverged:
             logger.critical("Solver diverged (Inf detected)")
             # the reference detects the non-finite velocity BEFORE it shifts the fields (flowsolver.py:727-751): u_n, u_nn, p_n stay
@@ -623,13 +657,8 @@ class FlowSolver(ABC):
             if not self.params_solver.throw_error:
                 return None
             raise RuntimeError("Failed solving: Inf found in solution")
-        self.solve_info = info  # (refinement sweeps, relative residual, |b|, flag) of this step; buffer reused by the next
-        if info[1] > self.residual_tol:  # NaN (monitor off) compares False
-            msg = f"linear solve residual {info[1]:.2e} exceeds residual_tol = {self.residual_tol:.1e} at iteration {next_iter}"
-            logger.critical(msg)
-            if self.params_solver.throw_error:
-                raise RuntimeError(msg)
-            return None  # as a divergence: the factors (or the system) are broken, do not keep stepping silently
+        if info is not None and info[1] > self.residual_tol:  # (plug-in solvers report none: NaN compares False)
+            self._residual_breach = (float(info[1]), next_iter)
         self.iter = next_iter
         self.t = self.params_time.Tstart + self.iter * self.params_time.dt
         self._u_ctrl_prev = u_ctrl.copy()
@@ -637,10 +666,20 @@ class FlowSolver(ABC):
             self.order = 2
         self.fields._mark_stale()
         self.y_meas = y
-        # this step's log row is booked while the next step runs (or as soon as anybody looks at the exporter)
+        # this step's log row is booked while the next step runs (or as soon as anybody looks at the exporter); dE = None: to be collected
         self._pending_log = (self.iter, self.t, self._u_ctrl_prev, y, dE if want_energy else np.nan, time.time() - t0)
         if self._niter_multiple_of(self.iter, self.params_save.save_every):
             self._checkpoint()
+        breach = getattr(self, "_residual_breach", None)
+        if breach is not None:
+            # the residual monitor is this solver's own check (the reference makes none): its verdict on a step arrives with the NEXT step
+            # at the latest -- the factors (or the system) are broken, do not keep stepping silently
+            self._residual_breach = None
+            msg = f"linear solve residual {breach[0]:.2e} exceeds residual_tol = {self.residual_tol:.1e} at iteration {breach[1]}"
+            logger.critical(msg)
+            if self.params_solver.throw_error:
+                raise RuntimeError(msg)
+            return None
         return self.y_meas
 
     def _step_with_plugin_solver(self, solver, slot: int, u_ctrl, want_energy: bool):

@@ -190,6 +190,13 @@ int fc_step(fc_handle h, int order_slot, const double* u_ctrl /* [n_act] */,
  * reference's exporter.log / progress / checkpoint work of the previous step).  fc_step = begin + end. */
 int fc_step_begin(fc_handle h, int order_slot, const double* u_ctrl, const double* u_force, int compute_energy);
 int fc_step_end(fc_handle h, double* y_out, double* dE_out, double* info_out);
+/* What the controller of a closed loop waits for is y: on a single-GPU handle with the direct factor apply the step publishes the sensors
+ * and the non-finite flag right behind the last sweep launch and computes residual monitor and energy on a second stream, overlapped with
+ * the host's work and the next step's sweeps.  fc_step_end with dE_out == NULL and info_out == NULL returns as soon as y (and the flag:
+ * FC_ERR_DIVERGED) is there; fc_step_collect hands over (dE, info) of that step later -- it blocks until they exist; the next
+ * fc_step_begin keeps them if nobody asked.  With non-NULL dE_out / info_out fc_step_end (and fc_step) wait for everything, as before.
+ * The reference's loop wants exactly this order: y_meas back to the controller at once, dE into the log (flowsolver.py:760-799). */
+int fc_step_collect(fc_handle h, double* dE_out, double* info_out);
 /* n_steps open-loop steps without host synchronisation in between (u_ctrl constant or a
  * sequence [n_steps][n_act]); y_seq [n_steps][n_sens], dE_seq [n_steps] (may be NULL). */
 int fc_run(fc_handle h, int first_order_slot, int32_t n_steps, const double* u_ctrl,

@@ -160,6 +160,50 @@ def test_residual_monitor_cadence_leaves_the_series_bit_identical(tmp_path_facto
     assert not np.any(np.isfinite(runs[0][3]))
 
 
+def test_overlapped_tail_gives_the_blocking_steps_bits(tmp_path_factory, golden_dir, monkeypatch):
+    """fc_step_end(early) + fc_step_collect: the measurements come back right behind the last sweep launch, residual monitor and
+    energy run on a second stream and are collected a step later -- the log (y, dE), the solve info and the state are bit for
+    bit those of FC_OVERLAP_TAIL=0 (one stream, one record) and of the blocking C-ABI fc_step; a residual breach is reported with
+    the following step at the latest."""
+    from flowcontrol_amd._lib import SLOT_BDF1, SLOT_BDF2
+
+    def run(overlap):
+        monkeypatch.setenv("FC_OVERLAP_TAIL", "1" if overlap else "0")
+        fs = CylinderFlowSolver.make_default(Re=100, path_out=tmp_path_factory.mktemp(f"overlap{int(overlap)}"), num_steps=30)
+        fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
+        fs.params_save.energy_every = 3
+        _load_baseflow(fs, golden_dir)
+        fs.initialize_time_stepping(ic=None)
+        infos = []
+        for k in range(30):
+            y = fs.step(u_ctrl=[0.08 * np.sin(0.5 * k), 0.03])
+            if k % 7 == 0:
+                infos.append(np.array(fs.solve_info).copy())  # forces the collection now and then; the log collects the rest
+        ts = fs.timeseries
+        out = (ts[["y_meas_1", "y_meas_2", "y_meas_3"]].to_numpy().copy(), ts["dE"].to_numpy().copy(), fs.fields.u_.vector().get_local().copy(), np.array(infos), y)
+        return fs, out
+
+    fs0, a = run(False)
+    fs0.th.release_device()
+    fs1, b = run(True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1], equal_nan=True) and np.array_equal(a[2], b[2])
+    assert np.array_equal(a[3], b[3]) and np.all(b[3][:, 1] < 1e-12)
+    assert np.count_nonzero(np.isfinite(b[1])) == 11  # IC + every third of 30 steps
+    # the blocking C-ABI step continues both trajectories identically
+    dev = fs1.th.device()
+    y_c, dE_c, info_c = dev.step(SLOT_BDF2, np.array([0.01, -0.02]))
+    assert np.all(np.isfinite(y_c)) and np.isfinite(dE_c) and info_c[1] < 1e-12
+    # a residual breach (here: an absurd tolerance) surfaces with the next step at the latest
+    fs1.params_solver.throw_error = False
+    fs1.fields._mark_stale()
+    fs1.residual_tol = 1e-30
+    r1 = fs1.step(u_ctrl=[0.0, 0.0])
+    r2 = fs1.step(u_ctrl=[0.0, 0.0]) if r1 is not None else None
+    assert r1 is None or r2 is None
+    fs1.th.release_device()
+    assert SLOT_BDF1 == 0
+
+
 def test_missing_baseflow_and_bad_inputs(tmp_path_factory):
     fs = CylinderFlowSolver.make_default(path_out=tmp_path_factory.mktemp("cyl_err"))
     with pytest.raises(ValueError):
