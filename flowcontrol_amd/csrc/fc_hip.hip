@@ -3263,7 +3263,9 @@ constexpr int kLateRec = 160;  // late record of the overlapped tail in the pinn
 // the overlapped form of a step (fc_ctx::stream2): see the comment there
 static bool step_can_overlap(const fc_ctx* h, int order_slot) {
   const OrderSys& S = h->sys[order_slot];
-  return h->overlap && !h->want_all && !h->partitioned && h->method == FC_METHOD_REFINE && !S.inexact && !S.truncated && S.bits == 64 && use_fused_tail(h) && !h->timing &&
+  // (factors that stream from HBM -- S.nt -- leave no slack for a concurrent matrix pass: measured on the refined cylinder, the pinball and
+  //  cavity_fine the overlapped tail costs 6-8 % of the step rate where the cache-resident O1 gains 10 %; profiles/r04_overlap.txt)
+  return h->overlap && !h->want_all && !S.nt && !h->partitioned && h->method == FC_METHOD_REFINE && !S.inexact && !S.truncated && S.bits == 64 && use_fused_tail(h) && !h->timing &&
          !h->phase_timing;
 }
 

@@ -142,8 +142,8 @@ class FlowSolver(ABC):
         if row is not None:
             self._pending_log = None
             it, t, u_ctrl, y, dE, runtime = row
-            if dE is None:  # energy of an overlapped step: it has arrived by now
-                self._collect()
+            self._collect()  # energy / residual of that step (an overlapped step computed them behind the host's back): here by now
+            if dE is None:
                 dE = self._last_dE
             if self._niter_multiple_of(it, self.verbose):
                 self._exporter.log_progress(it, self.params_time.num_steps, t, self.params_time.Tfinal + self.params_time.Tstart, runtime)
