@@ -144,6 +144,8 @@ SIGNATURES: dict[str, list] = {
     "fc_step_batch_begin": [_H, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_int],
     "fc_step_batch_end": [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
     "fc_reset_sim_batch": [_H, C.c_int32],
+    "fc_step_batch_end_early": [_H, C.c_int32, C.c_void_p, C.c_void_p],
+    "fc_step_batch_collect": [_H, C.c_int32, C.c_void_p, C.c_void_p],
     "fc_get_batch_info": [_H, _dp],
     "fc_bench_batch_apply": [_H, C.c_int, C.c_int, C.POINTER(C.c_double)],
     "fc_solve_batch": [_H, C.c_int, C.c_int32, _dp, _dp],

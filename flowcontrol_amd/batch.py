@@ -103,6 +103,7 @@ class BatchedFlowSolver:
         self.iter = 0
         self.t = self.params_time.Tstart
         self.diverged = np.zeros(k, dtype=bool)
+        self._pending, self._breach, self._solve_info = None, None, None
 
     # ── stepping ─────────────────────────────────────────────────────────────
     def step(self, u_ctrl) -> np.ndarray | None:
@@ -125,42 +126,72 @@ class BatchedFlowSolver:
         if self.order == "cn":
             prev = np.zeros_like(u_ctrl) if self._u_ctrl_prev is None else self._u_ctrl_prev
             u_force = 0.5 * (u_ctrl + prev)
+        dev = self.dev
+        dev.step_batch_begin(SLOT_BDF2 if self.order == 2 else SLOT_BDF1, u_ctrl, compute_energy=want_energy, u_force=u_force)
+        self._flush()  # the previous step's energies / residuals arrive behind the host's back: book its log row while this step runs
         newly = np.zeros(k, dtype=bool)
         try:
-            y, dE, info = self.dev.step_batch(SLOT_BDF2 if self.order == 2 else SLOT_BDF1, u_ctrl, compute_energy=want_energy, u_force=u_force)
+            y, flags = dev.step_batch_end_early()
         except FcDiverged:
             # the records of all runs were filled before the status came back: the healthy runs' step stands
-            bufs = self.dev._batch_bufs
-            y, dE, info = bufs[2][:, : self.dev.n_sens].copy(), bufs[3].copy(), bufs[4]
-            newly = (info[:, 3] != 0) & ~self.diverged
-            for s in np.flatnonzero(info[:, 3] != 0):
-                self.dev.reset_sim_batch(int(s))  # zero state: the column stops producing non-finite values
+            y, flags = dev._batch_bufs[2][:, : dev.n_sens].copy(), dev._batch_flags
+            newly = (flags != 0) & ~self.diverged
+            for s in np.flatnonzero(flags != 0):
+                dev.reset_sim_batch(int(s))  # zero state: the column stops producing non-finite values
             logger.critical("Solver diverged (Inf detected) in runs %s", np.flatnonzero(newly).tolist())
-            self.diverged |= info[:, 3] != 0
+            self.diverged |= flags != 0
         if np.any(self.diverged):
             y = np.where(self.diverged[:, None], np.nan, y)
-            dE = np.where(self.diverged, np.nan, dE)
-        self.solve_info = info
-        if np.any(info[~self.diverged, 1] > self.residual_tol):
-            msg = f"linear solve residual {info[:, 1].max():.2e} exceeds residual_tol = {self.residual_tol:.1e} at iteration {next_iter}"
-            logger.critical(msg)
-            if fs.params_solver.throw_error:
-                raise RuntimeError(msg)
-            return None
         self.iter = next_iter
         self.t = self.params_time.Tstart + self.iter * self.params_time.dt
         self._u_ctrl_prev = u_ctrl.copy()
         if fs.params_solver.time_scheme != "cn":
             self.order = 2
         self.y_meas = y
-        self._log.append((self.t, self._u_ctrl_prev, y, dE if want_energy else np.full(k, np.nan), (time.time() - t0) / k))
+        self._pending = (self.t, self._u_ctrl_prev, y, want_energy, (time.time() - t0) / k, self.iter)
         if np.any(newly) and fs.params_solver.throw_error:
             raise RuntimeError(f"Failed solving: Inf found in solution (runs {np.flatnonzero(newly).tolist()}; the other runs go on)")
+        breach = self._breach
+        if breach is not None:
+            # the residual monitor's verdict on a step arrives with the next step at the latest (broken factors: all runs share them)
+            self._breach = None
+            msg = f"linear solve residual {breach[0]:.2e} exceeds residual_tol = {self.residual_tol:.1e} at iteration {breach[1]}"
+            logger.critical(msg)
+            if fs.params_solver.throw_error:
+                raise RuntimeError(msg)
+            return None
         return self.y_meas
+
+    _pending = None
+    _breach = None
+    _solve_info = None
+
+    def _flush(self) -> None:
+        """Energy and solve info of the last step (computed on a second stream while the host went on) into the log."""
+        row = self._pending
+        if row is None:
+            return
+        self._pending = None
+        t, u, y, want_energy, runtime, it = row
+        dE, info = self.dev.step_batch_collect()
+        self._solve_info = info
+        if np.any(self.diverged):
+            dE = np.where(self.diverged, np.nan, dE)
+        res = info[~self.diverged, 1]
+        if res.size and np.nanmax(res) > self.residual_tol:
+            self._breach = (float(np.nanmax(res)), it)
+        self._log.append((t, u, y, dE if want_energy else np.full(self.k, np.nan), runtime))
+
+    @property
+    def solve_info(self):
+        """(0, relative residual, |b|, flag) per run of the last step (collected on access)."""
+        self._flush()
+        return self._solve_info
 
     # ── results ──────────────────────────────────────────────────────────────
     def timeseries(self, i: int) -> pd.DataFrame:
         """Log of run ``i``: the columns and rows ``FlowSolver.timeseries`` gives for a single run."""
+        self._flush()
         t0, y0, dE0 = self._log_ic
         ex = FlowExporter(paths=self.fs.paths, fields=self.fs.fields, V=self.fs.V, P=self.fs.P, Tstart=t0, dt=self.params_time.dt, save_every=0)
         ex.log_ic(t=t0, y_meas=y0[i], dE=dE0[i])
@@ -179,6 +210,7 @@ class BatchedFlowSolver:
 
     def close(self) -> None:
         if self._ready:
+            self._flush()
             self.dev.set_batch(0)
             self._ready = False
 

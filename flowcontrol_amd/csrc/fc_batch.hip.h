@@ -73,7 +73,10 @@ __global__ __launch_bounds__(256) void fc_b_repack(const FcBTask* __restrict__ t
 #endif
 template <int KB, bool NT = false>  // NT: the tiled factors exceed the Infinity Cache and are streamed with nontemporal loads (fc_ld in fc_kernels.hip.h)
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FC_B_WPE, FC_B_WPE))) void fc_nd_block_b(
-    const FcBTask* __restrict__ tasks, const int* __restrict__ olist, const double* __restrict__ tiled, double* __restrict__ buf, int CG) {
+    const FcBTask* __restrict__ tasks, const int* __restrict__ olist, const double* __restrict__ tiled, double* __restrict__ buf, int CG,
+    const unsigned char* __restrict__ velrow = nullptr, int N = 0, int* __restrict__ flag = nullptr) {
+  // velrow (overlapped tail): a tile that writes solution rows (buffer rows N .. 2N: the down-sweep) tests what it writes for finiteness,
+  // velocity rows only, and raises flag[simulation] -- the reference's test (flowsolver.py:731,816-819) without a pass of its own
   extern __shared__ double fc_b_red[];
   const FcBTask tk = tasks[blockIdx.x];
   const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
@@ -156,7 +159,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FC_B_WPE, 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int o = lq + 4 * r;
-      if (o < tk.nrows) buf[(size_t)(tk.dst + o) * KB + lr] = acc[r];
+      if (o < tk.nrows) {
+        buf[(size_t)(tk.dst + o) * KB + lr] = acc[r];
+        const int d = tk.dst + o - N;
+        if (velrow && d >= 0 && d < N && velrow[d] && !isfinite(acc[r])) atomicOr(flag + lr, 1);
+      }
     }
   }
 }
@@ -569,6 +576,104 @@ __global__ __launch_bounds__(1024) void fc_final_b(int G, int n_row_blocks, cons
     const int fl = flag[s] & 1;
     flag[s] = 0;
     fc_publish(ysh, n_sens, compute_energy ? 0.5 * r2 : 0.0, r0, r1, (double)fl, r + 64, r + 128, r + 129, r + 136, r + 137, seq_in[0]);
+  }
+}
+
+// Overlapped tail of the batched step (single GPU, cache-resident factors): fc_early_b is what the host waits for -- sensors of every
+// simulation on the new solution, its non-finite flag (raised by the down-sweep tiles as they write; cleared here: per step), one
+// checksummed record per simulation -- and releases the side stream's gate; fc_tail_b and fc_final_late_b (residual norms, energy ->
+// a late record per simulation and step parity) then run on the side stream while the host and the next step go on.
+template <int KB>
+__global__ __launch_bounds__(256) void fc_early_b(int n_sens, const int* __restrict__ s_rowptr, const int* __restrict__ s_idxp,
+                                                  const double* __restrict__ s_w, const double* __restrict__ x, int* __restrict__ flag,
+                                                  double* __restrict__ rec, int rstride, const double* __restrict__ seq_in,
+                                                  unsigned long long* __restrict__ solved) {
+  const int s = blockIdx.x, t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  __shared__ double ysh[64];
+  for (int q = wave; q < n_sens; q += 4) {
+    double acc = 0.0;
+    for (int k = s_rowptr[q] + lane; k < s_rowptr[q + 1]; k += 64) acc += s_w[k] * x[(size_t)s_idxp[k] * KB + s];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) ysh[q] = acc;
+  }
+  __syncthreads();
+  if (t == 0) {
+    const int fl = flag[s] & 1;
+    flag[s] = 0;
+    const double seq = seq_in[0];
+    double* r = rec + (size_t)s * rstride;
+    fc_publish(ysh, n_sens, 0.0, 0.0, 0.0, (double)fl, r + 64, r + 128, r + 129, r + 136, r + 137, seq);
+    if (s == 0) __hip_atomic_store(solved, (unsigned long long)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// gate of the batched side stream: as fc_wait_solved, the sequence number read from the step's slot of the mapped record (graph replay:
+// no per-step kernel argument)
+__global__ void fc_wait_solved_b(const unsigned long long* __restrict__ solved, const double* __restrict__ seq_in, int* __restrict__ gave_up) {
+  const unsigned long long seq = (unsigned long long)seq_in[0];
+  for (long spin = 0; spin < 2000000L; ++spin) {
+    if (__hip_atomic_load(solved, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= seq) return;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  *gave_up = 1;
+}
+// late record of simulation s = blockIdx.x: rec[0] = E, [1] = sum r^2, [2] = sum b^2, [3] = seq, [4], [5] = checksums
+template <int KB>
+__global__ __launch_bounds__(1024) void fc_final_late_b(int G, int n_row_blocks, const double* __restrict__ partial, double* __restrict__ rec, int rstride,
+                                                        int rec_off, const double* __restrict__ seq_in, int compute_energy) {
+  const int s = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+  __shared__ double red[3][16];
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  const double* __restrict__ ps = partial + (size_t)s * 3 * G;
+  for (int base = 0; base < G; base += 8 * nt) {
+    double v0[8], v1[8], v2[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * nt + t;
+      v0[u] = i < n_row_blocks ? ps[i] : 0.0;
+      v1[u] = i < n_row_blocks ? ps[(size_t)G + i] : 0.0;
+      v2[u] = (i >= n_row_blocks && i < G) ? ps[2 * (size_t)G + i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a0 += v0[u];
+      a1 += v1[u];
+      a2 += v2[u];
+    }
+  }
+  const int wave = t >> 6, lane = t & 63, nw = nt >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a0 += __shfl_down(a0, off, 64);
+    a1 += __shfl_down(a1, off, 64);
+    a2 += __shfl_down(a2, off, 64);
+  }
+  if (lane == 0) {
+    red[0][wave] = a0;
+    red[1][wave] = a1;
+    red[2][wave] = a2;
+  }
+  __syncthreads();
+  if (t == 0) {
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+    for (int w = 0; w < nw; ++w) {
+      r0 += red[0][w];
+      r1 += red[1][w];
+      r2 += red[2][w];
+    }
+    typedef unsigned long long u64;
+    const double seq = seq_in[0];
+    const double v[3] = {compute_energy ? 0.5 * r2 : 0.0, r0, r1};
+    double* r = rec + (size_t)s * rstride + rec_off;
+    u64 x = (u64)__double_as_longlong(seq), w = x, k = 3;
+    for (int i = 0; i < 3; ++i, k += 2) {
+      r[i] = v[i];
+      x ^= (u64)__double_as_longlong(v[i]);
+      w += k * (u64)__double_as_longlong(v[i]);
+    }
+    r[4] = __longlong_as_double((long long)x);
+    r[5] = __longlong_as_double((long long)w);
+    r[3] = seq;
   }
 }
 

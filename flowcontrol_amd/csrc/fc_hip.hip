@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <map>
 #include <string>
@@ -257,6 +258,7 @@ struct fc_ctx {
   DevBuf<double> uctrl, ydev, yseq, Eseq, useq;
   DevBuf<int> flag;
   DevBuf<int> flag2;  // the late tail's row workgroups test finiteness too: into a word nobody reads
+  DevBuf<int> flag2x; // ... sixteen of them for the batched late tail
   double* pin = nullptr;    // pinned, device-mapped host record: [0..63] u_ctrl in, [64..] outputs
   double* pin_dev = nullptr;  // device address of the same memory
   uint64_t seq = 0;           // step sequence number published by the last kernel of a step
@@ -348,7 +350,20 @@ struct fc_ctx {
     int cur = 0;
     size_t slot_doubles = 0;
     fc_ctx::BufView buf;
-    DevBuf<double> b, ev, partial;
+    DevBuf<double> bstore;        // two right-hand sides (overlapped tail: the late tail of step n reads b(n) while step n + 1 assembles its own)
+    fc_ctx::BufView b;
+    DevBuf<double> ev, partial;
+    // overlapped tail of the batched step (as fc_ctx::stream2): late records per simulation and step parity
+    struct Late {
+      bool pending = false;
+      double seq = 0.0;
+      int energy = 0;
+    } late[2];
+    int last_par = 0, pend_par = 0;
+    bool pend_overlapped = false, side_busy = false;
+    std::vector<double> last_dE, last_r, last_b;   // per simulation: what fc_step_batch_collect hands out
+    hipGraphExec_t gside[4][2] = {};               // side-stream graph per (ring phase, energy flag)
+    uint64_t gside_sig[4][2] = {};
     DevBuf<int> flag;                                        // [KB] non-finite velocity seen, per simulation
     DevBuf<FcBTask> tasks;
     DevBuf<int> fptr, fsrc;       // up-sweep fold lists: permuted row -> scratch rows (absolute buffer rows) of its descendants
@@ -375,6 +390,9 @@ struct fc_ctx {
     int pre_slot = -1;  // order slot whose element vectors (ev) the LAST launch of the previous step left behind, -1: none
   } bat;
 };
+
+extern "C" int collect_late(fc_ctx* h, int par);        // late records of overlapped steps (defined with the step functions)
+extern "C" int collect_late_batch(fc_ctx* h, int par);
 
 namespace {
 
@@ -713,10 +731,18 @@ inline void ring_advance(fc_ctx* h) {  // the solution in h->buf becomes the sta
 }
 // the second stream (overlapped tail) idle: before anything but a time step touches the buffers its kernels read or write
 int quiesce(fc_ctx* h) {
-  if (h->side_busy) {
+  if (h->side_busy || h->bat.side_busy) {
     HIPCHK(hipStreamSynchronize(h->stream));   // (the side stream's gate waits for the main stream's last solve)
     HIPCHK(hipStreamSynchronize(h->stream2));
     h->side_busy = false;
+    // whatever late records are outstanding are complete now: take them before another call reuses the mapped page
+    FCCHK(collect_late(h, 0));
+    FCCHK(collect_late(h, 1));
+    if (h->bat.side_busy) {
+      FCCHK(collect_late_batch(h, 0));
+      FCCHK(collect_late_batch(h, 1));
+      h->bat.side_busy = false;
+    }
   }
   return FC_OK;
 }
@@ -1641,6 +1667,8 @@ int fc_create(fc_handle* out, int device, int32_t nv, int32_t ne, int32_t nc, co
   TRY(h->flag.alloc(1));
   TRY(h->flag2.alloc(1));
   TRY(h->flag2.zero(h->stream));
+  TRY(h->flag2x.alloc(16));
+  TRY(h->flag2x.zero(h->stream));
   TRY(h->solved.alloc(1));
   TRY(h->solved.zero(h->stream));
   TRY(h->side_err.alloc(1));
@@ -3258,7 +3286,7 @@ void speculate_next_rhs(fc_ctx* h, int order_slot, hipStream_t stream = nullptr)
 // fc_step in two halves: fc_step_begin writes the controls into the mapped record and enqueues the step's launches (the GPU
 // works from here on), fc_step_end waits for the record.  A host program can do its own per-step bookkeeping in between
 // (FlowSolver.step appends the previous step's log row there); fc_step is begin + end.
-constexpr int kLateRec = 160;  // late record of the overlapped tail in the pinned page: [E, sum r^2, sum b^2, seq, checksum, checksum]
+constexpr int kLateRec = 4010;  // late records (two step parities) of the overlapped tail in the pinned page: [E, sum r^2, sum b^2, seq, checksum, checksum, -, -]
 
 // the overlapped form of a step (fc_ctx::stream2): see the comment there
 static bool step_can_overlap(const fc_ctx* h, int order_slot) {
@@ -3268,8 +3296,6 @@ static bool step_can_overlap(const fc_ctx* h, int order_slot) {
   return h->overlap && !h->want_all && !S.nt && !h->partitioned && h->method == FC_METHOD_REFINE && !S.inexact && !S.truncated && S.bits == 64 && use_fused_tail(h) && !h->timing &&
          !h->phase_timing;
 }
-
-static int collect_late(fc_ctx* h, int par);
 
 static int step_enqueue_overlapped(fc_ctx* h) {
   double* dev = h->pin_dev;
@@ -3358,7 +3384,7 @@ int fc_step_begin(fc_handle h, int order_slot, const double* u_ctrl, const doubl
 }
 
 // the late record of an overlapped step (fc_final_late on the side stream): [E, sum r^2, sum b^2, seq, checksum, checksum], one per step parity
-static int collect_late(fc_ctx* h, int par) {
+int collect_late(fc_ctx* h, int par) {
   fc_ctx::Late& L = h->late[par];
   if (!L.pending) return FC_OK;
   volatile double* rec = h->pin + kLateRec + 8 * par;
@@ -4217,8 +4243,9 @@ static int batch_repack(fc_ctx* h, int slot) {
 }
 
 // x (rows N .. 2N of bat.buf) = M^-1 y (rows 0 .. N) for all KB columns
-static int batch_apply(fc_ctx* h, int slot) {
+static int batch_apply(fc_ctx* h, int slot, bool check = false) {
   fc_ctx::Batch& B = h->bat;
+  const unsigned char* vr = check ? h->velrow_p.p : nullptr;  // overlapped tail: the down tiles test what they write for finiteness
   if (!B.ftile_ok[slot]) return fail(FC_ERR_NOT_READY, "batched apply: the slot's factors have no tiled copy (fc_set_batch after fc_setup_solver)");
   double* buf = B.buf.p;
   const double* tiled = B.ftile[slot].p;
@@ -4230,9 +4257,9 @@ static int batch_apply(fc_ctx* h, int slot) {
 #define FC_BLK(K)                                                                                                                                              \
   do {                                                                                                                                                         \
     if (nt)                                                                                                                                                    \
-      hipLaunchKernelGGL((fc_nd_block_b<K, true>), dim3(L.count), dim3(64 * L.cg), L.cg > 1 ? (size_t)L.cg * 2048 : 0, h->stream, tp, B.olist.p, tiled, buf, L.cg); \
+      hipLaunchKernelGGL((fc_nd_block_b<K, true>), dim3(L.count), dim3(64 * L.cg), L.cg > 1 ? (size_t)L.cg * 2048 : 0, h->stream, tp, B.olist.p, tiled, buf, L.cg, vr, h->N, B.flag.p); \
     else                                                                                                                                                       \
-      hipLaunchKernelGGL((fc_nd_block_b<K>), dim3(L.count), dim3(64 * L.cg), L.cg > 1 ? (size_t)L.cg * 2048 : 0, h->stream, tp, B.olist.p, tiled, buf, L.cg);   \
+      hipLaunchKernelGGL((fc_nd_block_b<K>), dim3(L.count), dim3(64 * L.cg), L.cg > 1 ? (size_t)L.cg * 2048 : 0, h->stream, tp, B.olist.p, tiled, buf, L.cg, vr, h->N, B.flag.p);   \
   } while (0)
       FC_KB_DISPATCH(B.KB, FC_BLK(4), FC_BLK(8), FC_BLK(16));
 #undef FC_BLK
@@ -4257,7 +4284,8 @@ int fc_set_batch(fc_handle h, int32_t k) {
   if (k == 0) {
     HIPCHK(hipStreamSynchronize(h->stream));
     batch_drop_graphs(h);
-    B.ring.release(), B.b.release(), B.ev.release(), B.partial.release();
+    B.ring.release(), B.bstore.release(), B.ev.release(), B.partial.release();
+    B.b = fc_ctx::BufView{};
     B.buf = fc_ctx::BufView{};
     B.flag.release();
     // ... and everything fc_set_batch(k > 0) tabulates: the tiled copies of both slots' factors (each >= the factor size), task
@@ -4279,7 +4307,8 @@ int fc_set_batch(fc_handle h, int32_t k) {
     B.slot_doubles = (2 * N + (size_t)B.scratch_rows + 1) * KB;  // + the zero row of the operand lists
     FCCHK(B.ring.alloc(4 * B.slot_doubles));
     B.buf.n = B.slot_doubles;
-    FCCHK(B.b.alloc(N * KB));
+    FCCHK(B.bstore.alloc(2 * N * KB));
+    B.b.n = N * KB;
     FCCHK(B.ev.alloc((size_t)12 * h->nc * KB));
     FCCHK(B.partial.alloc((size_t)3 * ((size_t)B.n_tblocks + (size_t)nblocks(h->nc, 256 / (8 * KB)) + 1) * KB));
     FCCHK(B.flag.alloc(16));
@@ -4288,9 +4317,12 @@ int fc_set_batch(fc_handle h, int32_t k) {
   B.KB = KB;
   for (int o = 0; o < 2; ++o)
     if (h->sys[o].ready && !B.ftile_ok[o]) FCCHK(batch_repack(h, o));
-  for (DevBuf<double>* d : {&B.ring, &B.b, &B.ev, &B.partial}) FCCHK(d->zero(h->stream));
+  for (DevBuf<double>* d : {&B.ring, &B.bstore, &B.ev, &B.partial}) FCCHK(d->zero(h->stream));
   B.cur = 0;
   bat_point(h);
+  B.b.p = B.bstore.p;
+  B.late[0] = B.late[1] = fc_ctx::Batch::Late{};
+  B.last_dE.assign(16, 0.0), B.last_r.assign(16, 0.0), B.last_b.assign(16, 0.0);
   FCCHK(B.flag.zero(h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return FC_OK;
@@ -4403,12 +4435,27 @@ constexpr int kSeqSlot = 4000;
 // lead_elem: the step starts with its element loop; spec_slot >= 0: it ENDS with the element loop of the next step (scheme of
 // that slot) -- the loop depends on the state only, so it runs while the host is between two fc_step_batch calls, as
 // speculate_next_rhs does for the single simulation
-static int batch_launches(fc_ctx* h, int order_slot, int compute_energy, bool lead_elem = true, int spec_slot = -1) {
+constexpr int kLateRecB = 144;  // late record of a simulation inside its record (kRecStride): + 8 x step parity
+static int batch_tail_geometry(fc_ctx* h, int compute_energy, int* n_row_blocks, int* n_cell_blocks) {
+  fc_ctx::Batch& B = h->bat;
+  const int cpb = 256 / (8 * B.KB);
+  *n_row_blocks = B.n_tblocks;
+  *n_cell_blocks = compute_energy ? nblocks(h->nc, cpb) : 0;
+  if ((size_t)3 * (*n_row_blocks + *n_cell_blocks) * B.KB > B.partial.n) return fail(FC_ERR_INVALID, "fc_step_batch: partial buffer too small");
+  return FC_OK;
+}
+
+// overlapped == false: the whole step on the main stream (tail and final behind the apply, one record per simulation).
+// overlapped == true: the main stream ends with fc_early_b (what the host waits for) and the next step's element loop; residual monitor and
+// energy are batch_launches_side's, on the side stream.
+static int batch_launches(fc_ctx* h, int order_slot, int compute_energy, bool lead_elem = true, int spec_slot = -1, bool overlapped = false) {
   fc_ctx::Batch& B = h->bat;
   OrderSys& S = h->sys[order_slot];
   const int KB = B.KB, N = h->N, nc = h->nc;
+  const int par = B.cur & 1;
   const double* uc = h->pin_dev;
   const double* uf = h->pin_dev + 32;
+  const double* seqp = h->pin_dev + kSeqSlot + par;
   const int g_elem = nblocks(nc, 256 / (8 * KB)), g_rows = nblocks((int64_t)N * (KB / 2), 256);
   // the state ring: this step reads (u_n, u_nn) from slots cur, cur - 1 and writes its solution -- the new state -- into the x
   // half of slot cur + 1 (= B.buf); the caller moves `cur` on afterwards
@@ -4427,22 +4474,51 @@ static int batch_launches(fc_ctx* h, int order_slot, int compute_energy, bool le
                                       S.c_val.p, un)
   FC_KB_DISPATCH(KB, FC_GATH(4), FC_GATH(8), FC_GATH(16));
 #undef FC_GATH
-  FCCHK(batch_apply(h, order_slot));
-  // tail: residual monitor, non-finite flags, energy (the solution stays where it is: it is the new state)
+  FCCHK(batch_apply(h, order_slot, overlapped));
   if ((int64_t)B.tlidx.n != S.Ap_nnz && S.Ap_nnz > 0) return fail(FC_ERR_INVALID, "fc_step_batch: tail tables and system pattern disagree");
-  const int cpb = 256 / (8 * KB);
-  const int n_row_blocks = B.n_tblocks, n_cell_blocks = compute_energy ? nblocks(nc, cpb) : 0;
-  const int G = n_row_blocks + n_cell_blocks;
-  if ((size_t)3 * G * KB > B.partial.n) return fail(FC_ERR_INVALID, "fc_step_batch: partial buffer too small");
+  if (overlapped) {
+#define FC_EARLYB(K) hipLaunchKernelGGL((fc_early_b<K>), dim3(B.k), dim3(256), 0, h->stream, h->n_sens, h->s_rowptr.p, h->s_idxp.p, h->s_w.p, xnew, B.flag.p, \
+                                        h->pin_dev, kRecStride, seqp, (unsigned long long*)h->solved.p)
+    FC_KB_DISPATCH(KB, FC_EARLYB(4), FC_EARLYB(8), FC_EARLYB(16));
+#undef FC_EARLYB
+  } else {
+    // tail: residual monitor, non-finite flags, energy (the solution stays where it is: it is the new state)
+    int n_row_blocks = 0, n_cell_blocks = 0;
+    FCCHK(batch_tail_geometry(h, compute_energy, &n_row_blocks, &n_cell_blocks));
+    const int G = n_row_blocks + n_cell_blocks;
 #define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(256), 0, h->stream, N, h->velrow_p.p, xnew, B.b.p, B.tblocks.p, \
                                        B.tcols.p, S.Ap_rowptr.p, B.tlidx.p, S.Ap_val.p, B.flag.p, B.partial.p, G, n_cell_blocks, nc, h->cnp.p, h->geom.p)
-  FC_KB_DISPATCH(KB, FC_TAILB(4), FC_TAILB(8), FC_TAILB(16));
+    FC_KB_DISPATCH(KB, FC_TAILB(4), FC_TAILB(8), FC_TAILB(16));
 #undef FC_TAILB
 #define FC_FINB(K) hipLaunchKernelGGL((fc_final_b<K>), dim3(B.k), dim3(1024), 0, h->stream, G, n_row_blocks, B.partial.p, h->n_sens, h->s_rowptr.p, h->s_idxp.p, \
-                                      h->s_w.p, xnew, B.flag.p, h->pin_dev, kRecStride, h->pin_dev + kSeqSlot, compute_energy)
-  FC_KB_DISPATCH(KB, FC_FINB(4), FC_FINB(8), FC_FINB(16));
+                                      h->s_w.p, xnew, B.flag.p, h->pin_dev, kRecStride, seqp, compute_energy)
+    FC_KB_DISPATCH(KB, FC_FINB(4), FC_FINB(8), FC_FINB(16));
 #undef FC_FINB
+  }
   if (spec_slot >= 0) element_loop(coeffs_for(h, spec_slot), xnew, un);  // the NEXT step's loop: its (u_n, u_nn) = (this solution, this u_n)
+  HIPCHK(hipGetLastError());
+  return FC_OK;
+}
+
+// the side stream's share of an overlapped batched step: [gate] residual monitor + energy of all simulations -> their late records
+static int batch_launches_side(fc_ctx* h, int order_slot, int compute_energy) {
+  fc_ctx::Batch& B = h->bat;
+  OrderSys& S = h->sys[order_slot];
+  const int KB = B.KB, N = h->N, nc = h->nc, par = B.cur & 1;
+  const double* seqp = h->pin_dev + kSeqSlot + par;
+  const double* xnew = B.buf.p + (size_t)N * KB;
+  int n_row_blocks = 0, n_cell_blocks = 0;
+  FCCHK(batch_tail_geometry(h, compute_energy, &n_row_blocks, &n_cell_blocks));
+  const int G = n_row_blocks + n_cell_blocks;
+  hipLaunchKernelGGL(fc_wait_solved_b, dim3(1), dim3(1), 0, h->stream2, (const unsigned long long*)h->solved.p, seqp, h->side_err.p);
+#define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(256), 0, h->stream2, N, h->velrow_p.p, xnew, B.b.p, B.tblocks.p, \
+                                       B.tcols.p, S.Ap_rowptr.p, B.tlidx.p, S.Ap_val.p, h->flag2x.p, B.partial.p, G, n_cell_blocks, nc, h->cnp.p, h->geom.p)
+  FC_KB_DISPATCH(KB, FC_TAILB(4), FC_TAILB(8), FC_TAILB(16));
+#undef FC_TAILB
+#define FC_FINLB(K) hipLaunchKernelGGL((fc_final_late_b<K>), dim3(B.k), dim3(1024), 0, h->stream2, G, n_row_blocks, B.partial.p, h->pin_dev, kRecStride, \
+                                       kLateRecB + 8 * par, seqp, compute_energy)
+  FC_KB_DISPATCH(KB, FC_FINLB(4), FC_FINLB(8), FC_FINLB(16));
+#undef FC_FINLB
   HIPCHK(hipGetLastError());
   return FC_OK;
 }
@@ -4489,10 +4565,34 @@ static void batch_drop_graphs(fc_ctx* h) {
           h->bat.gexec[ph][o][e][l] = nullptr;
           h->bat.gsig[ph][o][e][l] = 0;
         }
+  for (int ph = 0; ph < 4; ++ph)
+    for (int e = 0; e < 2; ++e) {
+      if (h->bat.gside[ph][e]) (void)hipGraphExecDestroy(h->bat.gside[ph][e]);
+      h->bat.gside[ph][e] = nullptr;
+      h->bat.gside_sig[ph][e] = 0;
+    }
   h->bat.pre_slot = -1;
 }
 
-static int batch_enqueue(fc_ctx* h, int order_slot, int compute_energy) {
+static int capture_graph(fc_ctx* h, hipStream_t stream, hipGraphExec_t* gx, const std::function<int()>& launches) {
+  if (*gx) (void)hipGraphExecDestroy(*gx);
+  *gx = nullptr;
+  hipGraph_t graph = nullptr;
+  HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+  const int code = launches();
+  const hipError_t e = hipStreamEndCapture(stream, &graph);
+  if (code != FC_OK) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return code;
+  }
+  if (e != hipSuccess) return fail(FC_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+  const hipError_t e2 = hipGraphInstantiate(gx, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e2 != hipSuccess) return fail(FC_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2));
+  return FC_OK;
+}
+
+static int batch_enqueue(fc_ctx* h, int order_slot, int compute_energy, bool overlapped) {
   static const bool use_graph = [] {
     const char* e = std::getenv("FC_BATCH_GRAPH");  // 0: plain launches
     return !(e && e[0] == '0');
@@ -4511,37 +4611,36 @@ static int batch_enqueue(fc_ctx* h, int order_slot, int compute_energy) {
   }
   const bool lead = B.pre_slot != order_slot || h->have_force;
   B.pre_slot = -1;
+  B.b.p = B.bstore.p + (overlapped ? (size_t)(B.cur & 1) * (size_t)h->N * B.KB : 0);  // (overlapped: b(n) stays intact for step n's late tail)
   auto advance = [&]() {  // the solution this step writes is the state from here on
     B.cur = (B.cur + 1) % 4;
     bat_point(h);
     B.pre_slot = spec_slot;
   };
   if (!use_graph || h->timing) {
-    FCCHK(batch_launches(h, order_slot, compute_energy, lead, spec_slot));
+    FCCHK(batch_launches(h, order_slot, compute_energy, lead, spec_slot, overlapped));
+    if (overlapped) FCCHK(batch_launches_side(h, order_slot, compute_energy));
     advance();
     return FC_OK;
   }
-  const int ph = B.cur, ei = compute_energy ? 1 : 0, li = lead ? 1 : 0;  // one graph per ring phase: the buffers rotate with period four
-  const uint64_t sig = batch_signature(h, order_slot, compute_energy, lead, spec_slot);
+  // one graph per ring phase: the buffers rotate with period four (the overlapped step is two graphs, one per stream)
+  const int ph = B.cur, ei = compute_energy ? 1 : 0, li = lead ? 1 : 0;
+  const uint64_t sig = batch_signature(h, order_slot, compute_energy, lead, spec_slot) ^ (overlapped ? 0x9e3779b97f4a7c15ull : 0ull);
   hipGraphExec_t& gx = B.gexec[ph][order_slot][ei][li];
   if (!gx || B.gsig[ph][order_slot][ei][li] != sig) {
-    if (gx) (void)hipGraphExecDestroy(gx);
-    gx = nullptr;
-    hipGraph_t graph = nullptr;
-    HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    const int code = batch_launches(h, order_slot, compute_energy, lead, spec_slot);
-    const hipError_t e = hipStreamEndCapture(h->stream, &graph);
-    if (code != FC_OK) {
-      if (graph) (void)hipGraphDestroy(graph);
-      return code;
-    }
-    if (e != hipSuccess) return fail(FC_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-    const hipError_t e2 = hipGraphInstantiate(&gx, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (e2 != hipSuccess) return fail(FC_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2));
+    FCCHK(capture_graph(h, h->stream, &gx, [&] { return batch_launches(h, order_slot, compute_energy, lead, spec_slot, overlapped); }));
     B.gsig[ph][order_slot][ei][li] = sig;
   }
   HIPCHK(hipGraphLaunch(gx, h->stream));
+  if (overlapped) {
+    const uint64_t ssig = sig ^ ((uint64_t)order_slot + 1) * 0x100000001b3ull;
+    hipGraphExec_t& gs = B.gside[ph][ei];
+    if (!gs || B.gside_sig[ph][ei] != ssig) {
+      FCCHK(capture_graph(h, h->stream2, &gs, [&] { return batch_launches_side(h, order_slot, compute_energy); }));
+      B.gside_sig[ph][ei] = ssig;
+    }
+    HIPCHK(hipGraphLaunch(gs, h->stream2));
+  }
   advance();
   return FC_OK;
 }
@@ -4559,30 +4658,102 @@ static int batch_ready(fc_ctx* h, int order_slot, int32_t k, const char* who) {
   return FC_OK;
 }
 
-int fc_step_batch_begin(fc_handle h, int order_slot, int32_t k, const double* u_ctrl, const double* u_force, int compute_energy) {
+// late records of an overlapped batched step, parity `par`: all k simulations
+int collect_late_batch(fc_ctx* h, int par) {
+  fc_ctx::Batch& B = h->bat;
+  fc_ctx::Batch::Late& L = B.late[par];
+  if (!L.pending) return FC_OK;
+  const double seq = L.seq;
+  auto bits = [](double v) {
+    unsigned long long u;
+    std::memcpy(&u, &v, sizeof u);
+    return u;
+  };
+  auto ok1 = [&](int s) {
+    volatile double* rec = h->pin + (size_t)s * kRecStride + kLateRecB + 8 * par;
+    if (rec[3] != seq) return false;
+    unsigned long long x = bits(seq), w = x, kk = 3;
+    for (int i = 0; i < 3; ++i, kk += 2) {
+      const unsigned long long v = bits(rec[i]);
+      x ^= v;
+      w += kk * v;
+    }
+    return x == bits(rec[4]) && w == bits(rec[5]);
+  };
+  auto ok = [&]() {
+    for (int s = 0; s < B.k; ++s)
+      if (!ok1(s)) return false;
+    return true;
+  };
+  bool seen = false;
+  for (long spin = 0; spin < 20000000L; ++spin) {
+    if (ok()) {
+      seen = true;
+      break;
+    }
+    __builtin_ia32_pause();
+  }
+  if (!seen) {
+    HIPCHK(hipStreamSynchronize(h->stream2));
+    if (!ok()) return fail(FC_ERR_HIP, "fc_step_batch: a late record (residual monitor, energy) never arrived or failed its checksum");
+  }
+  L.pending = false;
+  if (par == B.last_par)
+    for (int s = 0; s < B.k; ++s) {
+      volatile double* rec = h->pin + (size_t)s * kRecStride + kLateRecB + 8 * par;
+      B.last_dE[(size_t)s] = L.energy ? rec[0] : std::numeric_limits<double>::quiet_NaN();
+      B.last_r[(size_t)s] = rec[1];
+      B.last_b[(size_t)s] = rec[2];
+    }
+  return FC_OK;
+}
+
+static int step_batch_begin(fc_handle h, int order_slot, int32_t k, const double* u_ctrl, const double* u_force, int compute_energy, bool want_all) {
   FCCHK(batch_ready(h, order_slot, k, "fc_step_batch"));
   if (h->n_act > 0 && !u_ctrl) return fail(FC_ERR_INVALID, "fc_step_batch: u_ctrl is null");
   if (h->bat.pending || h->step_pending) return fail(FC_ERR_INVALID, "fc_step_batch_begin: the previous step was not collected");
   HIPCHK(hipSetDevice(h->device));
-  FCCHK(quiesce(h));
+  if (h->side_busy) FCCHK(quiesce(h));  // (a single simulation's late tail on this handle)
   h->pre_slot = -1;
+  fc_ctx::Batch& B = h->bat;
+  const OrderSys& S = h->sys[order_slot];
+  const bool overlapped = h->overlap && !want_all && !S.nt && !h->timing;
+  const int par = B.cur & 1;
+  // the late tail of the step two back read the b buffer / sequence slot this step is about to write: it finished a step ago
+  FCCHK(collect_late_batch(h, par));
+  if (!overlapped && B.side_busy) {
+    FCCHK(collect_late_batch(h, par ^ 1));
+    B.side_busy = false;
+  }
   volatile double* pin = h->pin;
   for (int s = 0; s < h->bat.KB; ++s)
     for (int a = 0; a < h->n_act; ++a) {
       pin[s * kRecStride + a] = s < k ? u_ctrl[(size_t)s * h->n_act + a] : 0.0;
       pin[s * kRecStride + 32 + a] = s < k ? (u_force ? u_force[(size_t)s * h->n_act + a] : u_ctrl[(size_t)s * h->n_act + a]) : 0.0;
     }
-  fc_ctx::Batch& B = h->bat;
   B.pend_slot = order_slot;
   B.pend_energy = compute_energy;
   B.pend_seq = (double)(++h->seq);
-  pin[kSeqSlot] = B.pend_seq;
-  FCCHK(batch_enqueue(h, order_slot, compute_energy));
+  B.pend_par = par;
+  B.pend_overlapped = overlapped;
+  pin[kSeqSlot + par] = B.pend_seq;
+  FCCHK(batch_enqueue(h, order_slot, compute_energy, overlapped));
+  if (overlapped) {
+    B.late[par].pending = true;
+    B.late[par].seq = B.pend_seq;
+    B.late[par].energy = compute_energy;
+    B.side_busy = true;
+  }
   B.pending = true;
   return FC_OK;
 }
 
-int fc_step_batch_end(fc_handle h, int32_t k, double* y_out, double* dE_out, double* info_out) {
+int fc_step_batch_begin(fc_handle h, int order_slot, int32_t k, const double* u_ctrl, const double* u_force, int compute_energy) {
+  return step_batch_begin(h, order_slot, k, u_ctrl, u_force, compute_energy, false);
+}
+
+// flags_out [k] (may be NULL): 1 where a simulation's velocity became non-finite in this step
+static int step_batch_end(fc_handle h, int32_t k, double* y_out, double* dE_out, double* info_out, int32_t* flags_out) {
   FCCHK(batch_check(h, k, "fc_step_batch_end"));
   fc_ctx::Batch& B = h->bat;
   if (!B.pending) return fail(FC_ERR_INVALID, "fc_step_batch_end: no step in flight");
@@ -4631,29 +4802,67 @@ int fc_step_batch_end(fc_handle h, int32_t k, double* y_out, double* dE_out, dou
     FCCHK(time_collect(h));
     if (!all_ok()) return fail(FC_ERR_HIP, "fc_step_batch: a step record failed its checksum after stream synchronisation");
   }
+  B.last_par = B.pend_par;
   int any = 0;
   for (int s = 0; s < k; ++s) {
     volatile double* r = pin + (size_t)s * kRecStride;
     for (int q = 0; q < h->n_sens; ++q)
       if (y_out) y_out[(size_t)s * h->n_sens + q] = r[64 + q];
-    if (dE_out) dE_out[s] = B.pend_energy ? r[128] : std::numeric_limits<double>::quiet_NaN();
     const int flag = ((int)r[136]) % 1024;
     any |= flag;
+    if (flags_out) flags_out[s] = flag;
+    if (info_out) info_out[4 * s + 3] = flag;
+    if (!B.pend_overlapped) {
+      B.last_dE[(size_t)s] = B.pend_energy ? r[128] : std::numeric_limits<double>::quiet_NaN();
+      B.last_r[(size_t)s] = r[129];
+      B.last_b[(size_t)s] = r[130];
+    }
+  }
+  if (B.pend_overlapped && (dE_out || info_out)) FCCHK(collect_late_batch(h, B.last_par));
+  for (int s = 0; s < k; ++s) {
+    if (dE_out) dE_out[s] = B.last_dE[(size_t)s];
     if (info_out) {
-      const double r2 = r[129], b2 = r[130];
+      const double r2 = B.last_r[(size_t)s], b2 = B.last_b[(size_t)s];
       info_out[4 * s + 0] = 0.0;
       info_out[4 * s + 1] = std::sqrt(r2 / (b2 > 0 ? b2 : 1.0));
       info_out[4 * s + 2] = std::sqrt(b2);
-      info_out[4 * s + 3] = flag;
     }
   }
-  if (any) return fail(FC_ERR_DIVERGED, "non-finite velocity after solve (info[s][3] marks the simulations)");
+  if (any) return fail(FC_ERR_DIVERGED, "non-finite velocity after solve (info[s][3] / flags mark the simulations)");
+  return FC_OK;
+}
+
+int fc_step_batch_end(fc_handle h, int32_t k, double* y_out, double* dE_out, double* info_out) {
+  return step_batch_end(h, k, y_out, dE_out, info_out, nullptr);
+}
+
+// fc_step_end / fc_step_collect for k simulations: the early end hands over the measurements and the non-finite flags as soon as the
+// solve is done; energy and solve info of that step follow (fc_step_batch_collect blocks until they exist; info[s][3] repeats the flag)
+int fc_step_batch_end_early(fc_handle h, int32_t k, double* y_out, int32_t* flags_out) {
+  return step_batch_end(h, k, y_out, nullptr, nullptr, flags_out);
+}
+
+int fc_step_batch_collect(fc_handle h, int32_t k, double* dE_out, double* info_out) {
+  FCCHK(batch_check(h, k, "fc_step_batch_collect"));
+  HIPCHK(hipSetDevice(h->device));
+  fc_ctx::Batch& B = h->bat;
+  FCCHK(collect_late_batch(h, B.last_par));
+  for (int s = 0; s < k; ++s) {
+    if (dE_out) dE_out[s] = B.last_dE[(size_t)s];
+    if (info_out) {
+      const double r2 = B.last_r[(size_t)s], b2 = B.last_b[(size_t)s];
+      info_out[4 * s + 0] = 0.0;
+      info_out[4 * s + 1] = std::sqrt(r2 / (b2 > 0 ? b2 : 1.0));
+      info_out[4 * s + 2] = std::sqrt(b2);
+      info_out[4 * s + 3] = std::numeric_limits<double>::quiet_NaN();  // (the flags came with the early end)
+    }
+  }
   return FC_OK;
 }
 
 int fc_step_batch(fc_handle h, int order_slot, int32_t k, const double* u_ctrl, const double* u_force, double* y_out, double* dE_out,
                   int compute_energy, double* info_out) {
-  FCCHK(fc_step_batch_begin(h, order_slot, k, u_ctrl, u_force, compute_energy));
+  FCCHK(step_batch_begin(h, order_slot, k, u_ctrl, u_force, compute_energy, dE_out != nullptr || info_out != nullptr));
   return fc_step_batch_end(h, k, y_out, dE_out, info_out);
 }
 

@@ -685,7 +685,25 @@ class DeviceSolver:
             check(code)
         return y[:, : self.n_sens].copy(), dE.copy(), info
 
+    def step_batch_end_early(self):
+        """(y [k, n_sens], flags [k]) as soon as the batched solve is done; energy and solve info follow (:meth:`step_batch_collect`).
+        Raises :class:`FcDiverged` if any simulation produced a non-finite velocity (``self._batch_flags`` marks which)."""
+        u, uf, y, dE, info, (pu, puf, py, pdE, pinfo) = self._batch_bufs
+        if getattr(self, "_batch_flags", None) is None or self._batch_flags.size != self.batch_k:
+            self._batch_flags = np.zeros(self.batch_k, dtype=np.int32)
+        code = self.lib.fc_step_batch_end_early(self._h, self.batch_k, py, ptr(self._batch_flags))
+        if code:
+            check(code)
+        return y[:, : self.n_sens].copy(), self._batch_flags
+
+    def step_batch_collect(self):
+        """(dE [k], info [k, 4]) of the last batched step that ended early; blocks until they exist."""
+        u, uf, y, dE, info, (pu, puf, py, pdE, pinfo) = self._batch_bufs
+        check(self.lib.fc_step_batch_collect(self._h, self.batch_k, pdE, pinfo))
+        return dE.copy(), info
+
     def step_batch(self, order_slot: int, u_ctrl, compute_energy: bool = True, u_force=None):
+        """One blocking batched step: (y, dE, info), all waited for."""
         self.step_batch_begin(order_slot, u_ctrl, compute_energy, u_force)
         return self.step_batch_end()
 

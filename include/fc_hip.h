@@ -241,6 +241,12 @@ int fc_step_batch(fc_handle h, int order_slot, int32_t k, const double* u_ctrl, 
 int fc_reset_sim_batch(fc_handle h, int32_t s);
 int fc_step_batch_begin(fc_handle h, int order_slot, int32_t k, const double* u_ctrl, const double* u_force, int compute_energy);
 int fc_step_batch_end(fc_handle h, int32_t k, double* y_out, double* dE_out, double* info_out);
+/* fc_step_end(early) / fc_step_collect for k simulations (cache-resident factors: residual monitor and energy of a batched step run on a
+ * second stream while the host and the next step go on): the early end hands over y [k][n_sens] and flags [k] (1: that simulation's
+ * velocity became non-finite; FC_ERR_DIVERGED if any) as soon as the solve is done; fc_step_batch_collect returns (dE [k], info [k][4]) of
+ * that step and blocks until they exist.  fc_step_batch_end with dE_out / info_out, and fc_step_batch, wait for everything as before. */
+int fc_step_batch_end_early(fc_handle h, int32_t k, double* y_out, int32_t* flags_out);
+int fc_step_batch_collect(fc_handle h, int32_t k, double* dE_out, double* info_out);
 /* parity hook: X = A_bc^{-1} B for k right-hand sides through the batched factor apply; b, x: [k][N] */
 int fc_solve_batch(fc_handle h, int slot, int32_t k, const double* b, double* x);
 
