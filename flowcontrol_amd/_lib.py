@@ -123,6 +123,7 @@ SIGNATURES: dict[str, list] = {
     "fc_set_pressure_pin": [_H, C.c_int32, C.c_double],
     "fc_get_local_cells": [_H, _ip],
     "fc_get_refactor_ms": [_H, C.c_int, C.POINTER(C.c_double)],
+    "fc_get_refactor_flops": [_H, C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "fc_sym_build": [C.c_int32, C.c_int32, C.c_int32, _dp, _ip, _ip, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                      C.POINTER(C.c_void_p)],
     "fc_sym_size": [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)],

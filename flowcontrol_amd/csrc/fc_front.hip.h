@@ -53,6 +53,14 @@ struct __attribute__((aligned(16))) FcFront {
 
 typedef double fc_d4 __attribute__((ext_vector_type(4)));
 
+// Multi-GPU root front: of the swept front this handle exports only the pivot rows [keep0, keep1) (its block of the root's D^-1).  A
+// row above the current pivot block (already eliminated) that is not one of them is DEAD: nothing reads it again, so the 64-row tiles
+// made of such rows are skipped by the panel copy and the trailing update -- per rank (1 + 1 / world) n^3 instead of 2 n^3 flops for the
+// replicated root elimination.  keep0 = 0, keep1 = INT_MAX: every row is kept (all other fronts).
+__device__ __forceinline__ bool fc_fe_dead_rows(int i0, int k0, int keep0, int keep1) {
+  return i0 + 64 <= k0 && (i0 + 64 <= keep0 || i0 >= keep1);
+}
+
 // W = A[K,K]^-1 by Gauss-Jordan with partial pivoting among the block's rows (ties -> smallest row: reproducible)
 // (a: KB x (KB + 1) doubles and piv: KB ints of LDS, provided by the caller: the stand-alone kernel below for a front's
 // first step, fc_fe_update for every later one)
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(256) void fc_fe_pivot(const FcFront* __restrict__ n
 // blockIdx.x >= ct: column panel copy, 64 rows per workgroup: Cs[i, c] = A[i, k0 + c]  (zero beyond kb)
 template <int KB>
 __global__ __launch_bounds__(256) void fc_fe_panels(const FcFront* __restrict__ nodes, double* fronts, double* __restrict__ scratch, int step,
-                                                    int ct) {
+                                                    int ct, int keep0 = 0, int keep1 = 0x7fffffff) {
   __shared__ double Ws[KB][KB];  // read as Ws[r][c] with r (nearly) uniform over a wave: broadcast, no padding needed
   __shared__ double Rs[KB][KB == 32 ? 2 * 33 : 32 + 1];
   const FcFront nd = nodes[blockIdx.y];
@@ -312,7 +320,7 @@ __global__ __launch_bounds__(256) void fc_fe_panels(const FcFront* __restrict__ 
   const int t = threadIdx.x;
   if ((int)blockIdx.x >= ct) {
     const int i0 = ((int)blockIdx.x - ct) * 64;
-    if (i0 >= nf) return;
+    if (i0 >= nf || fc_fe_dead_rows(i0, k0, keep0, keep1)) return;
     for (int e = t; e < 64 * KB; e += 256) {
       const int i = i0 + e / KB, c = e % KB;
       if (i < nf) Cs[((size_t)(c >> 2) * nf + i) * 4 + (c & 3)] = c < kb ? A[(size_t)i * nf + k0 + c] : 0.0;  // [k / 4][row][k % 4]: the order the update's MFMA A operands are loaded in
@@ -389,7 +397,7 @@ __global__ __launch_bounds__(256) void fc_fe_panels(const FcFront* __restrict__ 
 //   D[row (l >> 4) + 4 r][col l & 15] in register r.
 template <int KB>
 __global__ __launch_bounds__(256) void fc_fe_update(const FcFront* __restrict__ nodes, double* fronts, double* scratch,
-                                                    int step, int tiles_per_side) {
+                                                    int step, int tiles_per_side, int keep0 = 0, int keep1 = 0x7fffffff) {
   __shared__ double smem[KB * (KB + 1) > KB * 64 ? KB * (KB + 1) : KB * 64];  // the B panel, then (one tile only) the next pivot block
   __shared__ int piv[2 * KB + 2];
   __shared__ double gj[128 + KB];
@@ -447,7 +455,7 @@ __global__ __launch_bounds__(256) void fc_fe_update(const FcFront* __restrict__ 
   const int tile = (int)blockIdx.x - 1;
   const int ti = tile / tiles_per_side, tj = tile % tiles_per_side;
   const int i0 = ti * 64, j0 = tj * 64;
-  if (i0 >= nf || j0 >= nf) return;
+  if (i0 >= nf || j0 >= nf || fc_fe_dead_rows(i0, k0, keep0, keep1)) return;
   // B panel: KB x 64, a row of 64 columns per 64 consecutive threads (coalesced)
   constexpr int BPT = KB * 64 / 256;
   double bq[BPT];
@@ -614,7 +622,8 @@ __global__ __launch_bounds__(256) void fc_fe_pivot_huge(const FcFront* __restric
 //                  rows [32 w, 32 w + 32) (its W rows in registers, the 128 x 64 panel of A staged once in LDS)
 // blockIdx.x >= ct: column panel copy, 64 rows per workgroup: Cs[i, c] = A[i, k0 + c]  (zero beyond kb)
 #define FC_FE_KH_PANEL_LDS_BYTES (FC_FE_KH * 64 * 8)
-__global__ __launch_bounds__(256) void fc_fe_panels_huge(const FcFront* __restrict__ nodes, double* fronts, double* __restrict__ scratch, int step, int ct) {
+__global__ __launch_bounds__(256) void fc_fe_panels_huge(const FcFront* __restrict__ nodes, double* fronts, double* __restrict__ scratch, int step, int ct,
+                                                         int keep0 = 0, int keep1 = 0x7fffffff) {
   extern __shared__ double fc_fe_lds[];
   constexpr int KH = FC_FE_KH;
   const FcFront nd = nodes[blockIdx.y];
@@ -628,7 +637,7 @@ __global__ __launch_bounds__(256) void fc_fe_panels_huge(const FcFront* __restri
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   if ((int)blockIdx.x >= ct) {
     const int i0 = ((int)blockIdx.x - ct) * 64;
-    if (i0 >= nf) return;
+    if (i0 >= nf || fc_fe_dead_rows(i0, k0, keep0, keep1)) return;
     // Cs is stored [k / 4][row][k % 4]: the order fc_fe_update_huge reads it as MFMA A operands (16 rows x 32 B back to back per load)
     for (int e = t; e < 64 * KH; e += 256) {
       const int i = i0 + e / KH, c = e % KH;
@@ -678,7 +687,7 @@ __global__ __launch_bounds__(256) void fc_fe_panels_huge(const FcFront* __restri
 // 64 x 64 tile of the trailing update with 128 pivot columns (fc_fe_update without the look-ahead): the B panel (128 x 64) goes
 // through LDS in two halves of 64 pivot rows, the tile's Cs rows stay in registers.
 __global__ __launch_bounds__(256) void fc_fe_update_huge(const FcFront* __restrict__ nodes, double* fronts, const double* __restrict__ scratch,
-                                                         int step, int tiles_per_side) {
+                                                         int step, int tiles_per_side, int keep0 = 0, int keep1 = 0x7fffffff) {
   __shared__ double Bs[64][64];
   constexpr int KH = FC_FE_KH;
   const FcFront nd = nodes[blockIdx.y];
@@ -688,7 +697,7 @@ __global__ __launch_bounds__(256) void fc_fe_update_huge(const FcFront* __restri
   const int nf = nd.nf;
   const int ti = (int)blockIdx.x / tiles_per_side, tj = (int)blockIdx.x % tiles_per_side;
   const int i0 = ti * 64, j0 = tj * 64;
-  if (i0 >= nf || j0 >= nf) return;
+  if (i0 >= nf || j0 >= nf || fc_fe_dead_rows(i0, k0, keep0, keep1)) return;
   double* A = fronts + nd.front;
   const double* Cs = scratch + nd.scratch + KH * KH;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;

@@ -159,6 +159,7 @@ struct fc_ctx {
   fcsym::Plan sym_plan;
   int64_t sym_total_nnz = 0;  // factor values of the WHOLE tree (all ranks, no truncation)
   double refactor_ms[2] = {0.0, 0.0};  // device time of the last fc_refactor per slot
+  double refactor_flops = 0.0, refactor_flops_full = 0.0;  // trailing-update flops of the last fc_refactor: as run / if no dead rows were skipped
   bool step_pending = false;  // fc_step_begin without its fc_step_end
   int pend_slot = 0, pend_energy = 0;
   bool pend_checked = true;
@@ -2449,6 +2450,7 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
   if ((int64_t)h->pap_src.n != S.Ap_nnz) return fail(FC_ERR_INVALID, "fc_refactor: plan and solver structure disagree (matrix)");
   HIPCHK(hipSetDevice(h->device));
   FCCHK(quiesce(h));
+  h->refactor_flops = h->refactor_flops_full = 0.0;
   for (size_t g = 0; g < h->pnodes.size(); ++g) {
     const fc_ctx::PlanNode& nd = h->pnodes[g];
     const int nb = nd.nf - nd.ni;
@@ -2543,22 +2545,40 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
       const bool wide = !huge && h->plevel_max_nf[li] >= wide_nf;
       const int kbs = huge ? FC_FE_KH : (wide ? FC_FE_KB_WIDE : FC_FE_KB);
       const int steps = (h->plevel_max_ni[li] + kbs - 1) / kbs;
+      // the root front of a multi-GPU layout: this handle exports the pivot rows [keep0, keep1) only; the eliminated rows outside them are dead
+      // (fc_fe_dead_rows).  FC_ROOT_SKIP=0: the whole front is swept, as every rank did up to round 3 (A/B, and the flop count's reference)
+      static const bool root_skip = [] { const char* e = std::getenv("FC_ROOT_SKIP"); return !(e && e[0] == '0'); }();
+      const bool root_level = dist && li == n_levels - 1 && h->root_x0 >= 0;
+      const int keep0 = (root_level && root_skip) ? h->root_x0 : 0, keep1 = (root_level && root_skip) ? h->root_x0 + h->root_xn : INT_MAX;
+      // bookkeeping: flops of the trailing updates (2 kb rows nf per block step and front; the widest front stands for the level) with and
+      // without the dead-row skip -- what a rank pays for the replicated root against what it paid
+      {
+        const int nfm = h->plevel_max_nf[li];
+        for (int k = 0; k < steps; ++k) {
+          const int k0 = k * kbs;
+          int alive = 0;
+          for (int i0 = 0; i0 < nfm; i0 += 64) alive += (i0 + 64 <= k0 && (i0 + 64 <= keep0 || i0 >= keep1)) ? 0 : std::min(64, nfm - i0);
+          const double per_row = 2.0 * (double)std::min(kbs, std::max(0, h->plevel_max_ni[li] - k0)) * (double)nfm * (double)grp.second;
+          h->refactor_flops += per_row * alive;
+          h->refactor_flops_full += per_row * nfm;
+        }
+      }
       for (int k = 0; k < steps; ++k) {
         if (huge) {
           // (a two-stream look-ahead -- the next pivot block's four tiles first, then its inversion beside the rest of the update -- was
           // measured: the streams do not overlap on this runtime, 70.5 -> 69.5 ms on cavity_fine, slower on O1; not kept)
           if (k == 0) hipLaunchKernelGGL(fc_fe_pivot_huge, dim3(grp.second), dim3(256), FC_FE_KH_LDS_BYTES, h->stream, fp, F, h->pscratch.p, k);
-          hipLaunchKernelGGL(fc_fe_panels_huge, dim3(2 * ct, grp.second), dim3(256), FC_FE_KH_PANEL_LDS_BYTES, h->stream, fp, F, h->pscratch.p, k, ct);
-          hipLaunchKernelGGL(fc_fe_update_huge, dim3(ct * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
+          hipLaunchKernelGGL(fc_fe_panels_huge, dim3(2 * ct, grp.second), dim3(256), FC_FE_KH_PANEL_LDS_BYTES, h->stream, fp, F, h->pscratch.p, k, ct, keep0, keep1);
+          hipLaunchKernelGGL(fc_fe_update_huge, dim3(ct * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct, keep0, keep1);
           if (k + 1 < steps) hipLaunchKernelGGL(fc_fe_pivot_huge, dim3(grp.second), dim3(256), FC_FE_KH_LDS_BYTES, h->stream, fp, F, h->pscratch.p, k + 1);
         } else if (wide) {
           if (k == 0) hipLaunchKernelGGL(fc_fe_pivot<FC_FE_KB_WIDE>, dim3(grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k);
-          hipLaunchKernelGGL(fc_fe_panels<FC_FE_KB_WIDE>, dim3(2 * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
-          hipLaunchKernelGGL(fc_fe_update<FC_FE_KB_WIDE>, dim3(ct * ct + 1, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
+          hipLaunchKernelGGL(fc_fe_panels<FC_FE_KB_WIDE>, dim3(2 * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct, keep0, keep1);
+          hipLaunchKernelGGL(fc_fe_update<FC_FE_KB_WIDE>, dim3(ct * ct + 1, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct, keep0, keep1);
         } else {
           if (k == 0) hipLaunchKernelGGL(fc_fe_pivot<FC_FE_KB>, dim3(grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k);
-          hipLaunchKernelGGL(fc_fe_panels<FC_FE_KB>, dim3(2 * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
-          hipLaunchKernelGGL(fc_fe_update<FC_FE_KB>, dim3(ct * ct + 1, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct);
+          hipLaunchKernelGGL(fc_fe_panels<FC_FE_KB>, dim3(2 * ct, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct, keep0, keep1);
+          hipLaunchKernelGGL(fc_fe_update<FC_FE_KB>, dim3(ct * ct + 1, grp.second), dim3(256), 0, h->stream, fp, F, h->pscratch.p, k, ct, keep0, keep1);
         }
       }
       HIPCHK(hipGetLastError());
@@ -2589,6 +2609,15 @@ int fc_refactor(fc_handle h, int slot, double* ms_out) {
   S.ready = true;
   S.inexact = false;  // (decided by the acceptance solve of the caller: fc_setup_solver, fc_accept_factors)
   return batch_repack(h, slot);  // the batched block kernel streams its own (tiled) copy of the values
+}
+
+// trailing-update flops of the handle's last fc_refactor (a level is priced by its widest front): as run, and what they would be with
+// every row of the multi-GPU root front swept (FC_ROOT_SKIP=0, the scheme up to round 3)
+int fc_get_refactor_flops(fc_handle h, double* run, double* full) {
+  if (!h) return fail(FC_ERR_INVALID, "null handle");
+  if (run) *run = h->refactor_flops;
+  if (full) *full = h->refactor_flops_full;
+  return FC_OK;
 }
 
 int fc_get_refactor_ms(fc_handle h, int slot, double* ms) {

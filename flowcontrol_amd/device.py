@@ -481,6 +481,12 @@ class DeviceSolver:
             logger.warning("slot %d: the direct factor apply reaches only %.1e on this operator; its solves run GMRES preconditioned by the factors", slot, res.value)
         return ms.value
 
+    def refactor_flops(self) -> tuple[float, float]:
+        """Trailing-update flops of the last numeric factorisation: (as run, with every row of a multi-GPU root front swept)."""
+        a, b = C.c_double(), C.c_double()
+        check(self.lib.fc_get_refactor_flops(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def factor_values(self, slot: int) -> np.ndarray:
         """Factor values of ``slot`` as they sit on the device (layout of :class:`ndsolver.BlockFactors`)."""
         n = int(self._fac_struct.vals.size) if self._fac_struct is not None else int(self._n_factor_values)

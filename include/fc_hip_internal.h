@@ -121,6 +121,11 @@ int fc_algorithmic_bytes(fc_handle h, int slot, double* sweep_bytes, double* spm
 int fc_set_partition(fc_handle h, int32_t n_local_cells, const int32_t* local_cells,
                      const uint8_t* rowkind /* [N] */, int lead);
 
+/* trailing-update flops of the handle's last fc_refactor (each level priced by its widest front): as run, and what they would be if
+ * every row of a multi-GPU root front were swept on every rank (the scheme up to round 3; FC_ROOT_SKIP=0 runs it): the eliminated
+ * rows of the root front that a rank does not export are dead and skipped -- (1 + 1 / world) n^3 instead of 2 n^3 per rank */
+int fc_get_refactor_flops(fc_handle h, double* run, double* full);
+
 /* Per-phase HIP-event timing of fc_step on the handle's stream (an instrumented replay: the marks cost ~1-2 us each and the
  * host polls less eagerly, so use it for the SPLIT of a step, not for its total).  When on, every fc_step records event marks at
  * its phase boundaries; fc_get_phase_timing returns the accumulated microseconds per phase and the number of steps since the
