@@ -42,6 +42,22 @@ from .steadystate import SteadyStateSolver
 logger = logging.getLogger(__name__)
 
 
+class EnergyField:
+    """u'·u' on the P4 Lagrange nodes of the mesh (:meth:`FlowSolver.compute_energy_field`): a minimal stand-in for the dolfin P4 Function."""
+
+    def __init__(self, coords: np.ndarray, values: np.ndarray):
+        self.coords, self.values = coords, values
+
+    def vector(self):
+        return self
+
+    def get_local(self) -> np.ndarray:
+        return self.values.copy()
+
+    def __call__(self, x):  # nearest node (enough for a look-up at a node; the field is piecewise P4 in between)
+        return float(self.values[np.argmin(np.sum((self.coords - np.asarray(x, dtype=float)) ** 2, axis=1))])
+
+
 class FlowSolver(ABC):
     """Abstract base class for flow simulation and control.
 
@@ -793,6 +809,52 @@ class FlowSolver(ABC):
     def compute_perturbation_energy(self) -> float:
         """½‖u'‖²_L2 of the current perturbation (reference ``:827-829``)."""
         return 0.5 * self._velocity_l2_norm(self.fields.u_.vector().array()) ** 2
+
+    def compute_energy_field(self, export: bool = False, filename=None):
+        """u'·u' as a field on the P4 Lagrange nodes of the mesh (reference ``:831-841``: ``projectm(dot(u_, u_), P4)``).  The product of two
+        P2 fields is piecewise P4 and continuous, so its L2 projection onto the P4 space IS its nodal interpolant: the values below are exact.
+        Returns an :class:`EnergyField` (``coords`` (n, 2), ``values`` (n,), ``vector().get_local()``); nodes: vertices, three per edge (from the
+        lower to the higher vertex id), three per cell.  ``export=True`` writes ``coords`` / ``values`` to ``filename`` (``.npz``)."""
+        th, m = self.th, self.th.mesh
+        u = self.fields.u_.vector().array()
+        nv, ne, nc = th.nv, th.ne, th.nc
+        coords = np.empty((nv + 3 * ne + 3 * nc, 2))
+        values = np.empty(nv + 3 * ne + 3 * nc)
+        # the 15 P4 nodes of the reference cell in barycentric coordinates: vertices, edge k (opposite vertex k) from local vertex k + 1 to k + 2, interior
+        lam = [np.eye(3)[k] for k in range(3)]
+        for k in range(3):
+            a, b = (k + 1) % 3, (k + 2) % 3
+            for j in (1, 2, 3):
+                w = np.zeros(3)
+                w[a], w[b] = 1.0 - j / 4.0, j / 4.0
+                lam.append(w)
+        for k in range(3):
+            w = np.full(3, 0.25)
+            w[k] = 0.5
+            lam.append(w)
+        lam = np.array(lam)  # (15, 3)
+        phi = np.empty((15, 6))  # P2 basis (vertex nodes, then the midpoint of the edge opposite vertex k) at those points
+        for k in range(3):
+            phi[:, k] = lam[:, k] * (2.0 * lam[:, k] - 1.0)
+            phi[:, 3 + k] = 4.0 * lam[:, (k + 1) % 3] * lam[:, (k + 2) % 3]
+        ux, uy = u[: th.nn][th.cell_nodes], u[th.nn :][th.cell_nodes]  # (nc, 6)
+        e = (ux @ phi.T) ** 2 + (uy @ phi.T) ** 2  # (nc, 15)
+        xy = np.einsum("pk,ckd->cpd", lam, m.coords[m.cells])  # (nc, 15, 2)
+        # global ids: an edge's three nodes run from its lower to its higher vertex id
+        ids = np.empty((nc, 15), dtype=np.int64)
+        ids[:, :3] = m.cells
+        for k in range(3):
+            a, b = m.cells[:, (k + 1) % 3], m.cells[:, (k + 2) % 3]
+            fwd = a < b
+            for j in range(3):
+                ids[:, 3 + 3 * k + j] = nv + 3 * m.cell_edges[:, k] + np.where(fwd, j, 2 - j)
+        ids[:, 12:] = nv + 3 * ne + 3 * np.arange(nc)[:, None] + np.arange(3)[None, :]
+        values[ids.reshape(-1)] = e.reshape(-1)
+        coords[ids.reshape(-1)] = xy.reshape(-1, 2)
+        field = EnergyField(coords, values)
+        if export:
+            np.savez(filename, coords=coords, values=values)
+        return field
 
     # ── utilities ────────────────────────────────────────────────────────────
     def merge(self, u: Function, p: Function) -> Function:

@@ -3,8 +3,8 @@
 Run in the build container (``/root/reference`` is not present on the GPU box):
     python tests/golden/make_mesh_fixtures.py
 Inputs (data, not code): src/examples/{cylinder,cavity,pinball,lidcavity}/data_input/*.xdmf + .h5
-Outputs: tests/golden/meshes/<name>.npz with ``coords`` (nv,2) f8 and ``cells`` (nc,3) i4 in the
-file's own numbering, read with flowcontrol_amd's HDF5/XDMF reader.
+Outputs: flowcontrol_amd/examples/<case>/data_input/<name>.npz (``flowcontrol_amd.examples.data.mesh_file``) with ``coords`` (nv,2) f8 and
+``cells`` (nc,3) i4 in the file's own numbering, read with flowcontrol_amd's HDF5/XDMF reader.
 """
 from pathlib import Path
 import sys
@@ -25,9 +25,11 @@ MESHES = {
 }
 
 if __name__ == "__main__":
-    out = Path(__file__).parent / "meshes"
-    out.mkdir(exist_ok=True)
+    from flowcontrol_amd.examples.data import mesh_file
+
     for name, path in MESHES.items():
         m = read_xdmf_mesh(path, reorder=False)
-        np.savez_compressed(out / f"{name}.npz", coords=m.coords, cells=m.cells.astype(np.int32))
-        print(name, m.num_vertices, m.num_cells, (out / f"{name}.npz").stat().st_size)
+        out = mesh_file(name)
+        out.parent.mkdir(parents=True, exist_ok=True)
+        np.savez_compressed(out, coords=m.coords, cells=m.cells.astype(np.int32))
+        print(name, m.num_vertices, m.num_cells, out.stat().st_size)

@@ -634,3 +634,26 @@ def test_signal_helpers():
     assert tuned < plain
     mp_ = sg.multisine_MP(3, 2, unwrap=False, N=64, Fs=16.0, fmin=0.2, fmax=0.8)
     assert mp_.shape == (3, 128) and np.array_equal(mp_[:, :64], mp_[:, 64:]) and sg.multisine_MP(3, 2, N=64, Fs=16.0, fmin=0.2, fmax=0.8).shape == (384,)
+
+
+def test_energy_field_on_the_p4_nodes_is_exact(tmp_path):
+    """FlowSolver.compute_energy_field (reference flowsolver.py:831-841: u'.u' projected onto a P4 space): the product of two P2
+    fields lies in P4, so the nodal values must equal the analytic product at every P4 node — vertices, three per edge, three per cell."""
+    from types import SimpleNamespace
+
+    from flowcontrol_amd.flowsolver import FlowSolver
+    from flowcontrol_amd.fem.mesh import Mesh
+    from flowcontrol_amd.fem.spaces import Function, TaylorHood
+
+    th = TaylorHood(Mesh.unit_square(5, 4))
+    x, y = th.node_coords[:, 0], th.node_coords[:, 1]
+    ux, uy = 1.0 + x * y - 0.5 * y**2, 0.3 * x**2 - x + 2.0 * y  # P2 fields
+    stub = SimpleNamespace(th=th, fields=SimpleNamespace(u_=Function(th.V, np.r_[ux, uy])))
+    f = FlowSolver.compute_energy_field(stub, export=True, filename=tmp_path / "E.npz")
+    X, Y = f.coords[:, 0], f.coords[:, 1]
+    exact = (1.0 + X * Y - 0.5 * Y**2) ** 2 + (0.3 * X**2 - X + 2.0 * Y) ** 2
+    assert f.values.size == th.nv + 3 * th.ne + 3 * th.nc
+    assert np.allclose(f.vector().get_local(), exact, rtol=0, atol=1e-13)
+    assert np.unique(np.round(f.coords, 12), axis=0).shape[0] == f.values.size  # every node once
+    z = np.load(tmp_path / "E.npz")
+    assert np.array_equal(z["values"], f.values)
