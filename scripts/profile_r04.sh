@@ -3,10 +3,12 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/r04
-rm -rf "$OUT" && mkdir -p "$OUT"
+PART=${PART:-AB}  # a gpurun call is limited to 20 minutes: PART=A (steps 1-4), then PART=B (steps 5-7)
+mkdir -p "$OUT"
 (while true; do sleep 60; echo "[$(date +%T)] still profiling"; done) &
 HB=$!
 trap 'kill $HB 2>/dev/null' EXIT
+if [[ $PART == *A* ]]; then
 # 1. the default bench line (what the driver records): headline, roofline, cpu_baseline, replicas, spmv, other_configs (configs 4 / 5 / 3)
 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 echo "bench done"
@@ -25,6 +27,8 @@ rm -rf "$OUT/prof_overlap"
 FC_OVERLAP_TAIL=0 bash scripts/profile_batch.sh "$OUT/batch" > "$OUT/profile_batch.log" 2>&1 || true
 python scripts/batch_probe.py --skip-parity --steps 400 > "$OUT/batch_probe_O1_overlapped.log" 2>&1 || true
 echo "batch profile done"
+fi
+if [[ $PART == *B* ]]; then
 # 5. numeric factorisation times
 python scripts/refactor_time.py O1 mesh_middle_gmsh cavity_coarse cavity_fine > "$OUT/refactor_times.txt" 2>&1 || true
 # 6. long closed-loop runs of configs 5 and 3 + kernel stats / sweep traffic on cavity_fine
@@ -37,5 +41,6 @@ echo "cases done"
 # 7. rehearsals of the N > 1 bench path on this one GPU: 8 thread ranks; 4 process ranks over gloo
 FC_BENCH_THREAD_RANKS=8 python bench.py --gpus 8 --steps 50 --warmup 5 > "$OUT/bench_threads8_rehearsal.json" 2> "$OUT/bench_threads8.err" || true
 FC_BENCH_SAME_DEVICE=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 4 --steps 50 --warmup 5 --no-extras > "$OUT/bench_gloo4_rehearsal.json" 2> "$OUT/bench_gloo4.err" || true
+fi
 echo "all done"
 ls -la "$OUT"
