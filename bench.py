@@ -454,7 +454,9 @@ def run_rank(comm, args, device):
                      "matrix_cells": int(dev.partition_info()["matrix_cells"]),  # cells whose element matrices it assembles
                      "exchanges_per_step": 3,
                      # read back from the communicator inside the library (ncclCommCount / ncclCommUserRank), not from the environment
-                     "rccl_ranks": ci["nranks"] if ci["transport"] == "rccl" else None, "exchange_transport": ci["transport"]}
+                     "rccl_ranks": ci["nranks"] if ci["transport"] == "rccl" else None, "exchange_transport": ci["transport"],
+                     # not None: the in-library RCCL communicator could not be created; the run went on over the host exchange (and is NOT an xGMI figure)
+                     "exchange_fallback": getattr(fs, "exchange_fallback", None)}
         n_rep = max(5, min(args.steps, 50))
         dev.set_phase_timing(True)
         for _ in range(n_rep):

@@ -37,6 +37,19 @@ class FcDiverged(FcError):
     pass
 
 
+class FcCommInitError(FcError):
+    """The RCCL communicator of a partitioned handle could not be created (library not loadable, ``ncclCommInitRank`` refused).
+    Distinct from a communicator that exists and sums wrongly (``fc_comm_selftest``: plain :class:`FcError`, always fatal)."""
+
+    def __init__(self, cause: FcError | str):
+        if isinstance(cause, FcError):
+            RuntimeError.__init__(self, str(cause))
+            self.code = cause.code
+        else:
+            RuntimeError.__init__(self, str(cause))
+            self.code = FC_ERR_HIP
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile ``libfc_hip.so`` for gfx950 in-tree with hipcc (cross-compiles without a GPU)."""
     if LIB_PATH.exists() and not force:

@@ -416,6 +416,8 @@ Rccl g_rccl;
 
 int rccl_load() {
   if (g_rccl.lib) return FC_OK;
+  if (const char* e = std::getenv("FC_RCCL_DISABLE"); e && e[0] == '1')  // test aid: a machine whose RCCL cannot be loaded
+    return fail(FC_ERR_HIP, "cannot load RCCL: disabled by FC_RCCL_DISABLE");
   // first the copy that sits next to the HIP runtime this library is bound to (PyTorch ships its own set and
   // has it loaded already), then by soname, then the system one
   std::string dir;

@@ -135,11 +135,24 @@ class DeviceSolver:
             # one process per GPU: RCCL would see duplicate devices if every rank's handle sat on GPU 0
             raise _lib.FcError(_lib.FC_ERR_INVALID, f"rank {rank}: the solver handle lives on GPU {self.device_index} but this process's "
                                f"current GPU is {torch.cuda.current_device()} (create the solver after torch.cuda.set_device(LOCAL_RANK))")
+        # creating the communicator may fail for reasons of the machine (RCCL not loadable, ncclCommInitRank refused): that is
+        # FcCommInitError, which a caller may answer with the host exchange; rank 0 ships an empty id instead of leaving the
+        # others in the broadcast.  A communicator that exists but does not sum (comm_selftest) is a plain FcError: never retried
         buf = C.create_string_buffer(128)
+        payload, first = None, None
         if rank == 0:
-            check(self.lib.fc_comm_unique_id(buf))
-        uid = broadcast_bytes(buf.raw if rank == 0 else None)
-        check(self.lib.fc_comm_init(self._h, world, rank, C.create_string_buffer(uid, 128)))
+            try:
+                check(self.lib.fc_comm_unique_id(buf))
+                payload = buf.raw
+            except _lib.FcError as err:
+                payload, first = b"", err
+        uid = broadcast_bytes(payload)
+        if not uid:
+            raise _lib.FcCommInitError(first if first is not None else "rank 0 could not create the RCCL unique id")
+        try:
+            check(self.lib.fc_comm_init(self._h, world, rank, C.create_string_buffer(uid, 128)))
+        except _lib.FcError as err:
+            raise _lib.FcCommInitError(err) from err
         self.comm_selftest()
 
     def comm_selftest(self) -> float:

@@ -111,6 +111,8 @@ class FlowSolver(ABC):
         self.krylov_rtol: float = 1e-12
         #: multi-GPU: who the ranks are (flowcontrol_amd.comm.Comm); None = the torch.distributed process group of this process, if any
         self.comm = None
+        #: set when the in-library RCCL communicator could not be created and the exchanges were staged through the host instead
+        self.exchange_fallback: str | None = None
         self._setup()
 
     _pending_log = None        # (iter, t, u_ctrl, y, dE | None, runtime) of the last step, not yet in the exporter
@@ -581,9 +583,36 @@ class FlowSolver(ABC):
         if comm is None or comm.world == 1 or not getattr(self, "distributed", True):
             return
         self.comm = comm
-        # no RCCL process group (CPU collectives, or several ranks sharing one GPU): the exchange steps of a time step are
-        # staged through the host; the arithmetic stays on the GPU
-        dev.join(comm.rank, comm.world, comm.bcast, None if comm.in_stream else comm.allreduce)
+        # no RCCL process group (CPU collectives, or several ranks sharing one GPU; FC_EXCHANGE=host asks for it): the exchange steps
+        # of a time step are staged through the host; the arithmetic stays on the GPU
+        import os
+
+        from ._lib import FcCommInitError
+
+        in_stream = comm.in_stream and os.environ.get("FC_EXCHANGE", "rccl") != "host"
+        if not in_stream:
+            dev.join(comm.rank, comm.world, comm.bcast, comm.allreduce)
+            return
+        failed, why = 0.0, None
+        try:
+            dev.join(comm.rank, comm.world, comm.bcast, None)
+        except FcCommInitError as err:
+            failed, why = 1.0, err
+        # every rank learns whether every rank got its communicator (the process group's own collective, not the library's)
+        if comm.allreduce_max(failed) == 0.0:
+            return
+        if os.environ.get("FC_EXCHANGE_FALLBACK", "1") == "0" or why is None:
+            # (a rank whose communicator DID come up while another's did not cannot go on either way)
+            raise why if why is not None else RuntimeError("another rank could not create its RCCL communicator")
+        # the library's RCCL communicator could not be created although the process group works: same partition, same launch
+        # sequence, exchanges staged through the host over the process group -- slower, and said so (DeviceSolver.comm_info()
+        # reports transport "host", bench.py prints exchange_fallback)
+        import sys
+
+        self.exchange_fallback = str(why)
+        print(f"[flowcontrol_amd] rank {comm.rank}: in-library RCCL communicator failed ({why}); exchanges go through the host "
+              f"over the process group (FC_EXCHANGE_FALLBACK=0 makes this fatal)", file=sys.stderr, flush=True)
+        dev.join(comm.rank, comm.world, comm.bcast, comm.allreduce)
 
     def _upload_state(self) -> None:
         f = self.fields

@@ -210,3 +210,41 @@ def test_exchange_selftest_catches_a_wrong_all_reduce():
     assert run_threaded(2, rank_body, False) == ["ok", "ok"]
     msgs = run_threaded(2, rank_body, True)
     assert all("fc_comm_selftest" in m and "entry 0" in m for m in msgs), msgs
+
+
+def test_a_machine_without_rccl_falls_back_to_the_host_exchange_and_says_so(monkeypatch, capfd):
+    """The in-library RCCL communicator cannot be created (FC_RCCL_DISABLE=1: the library refuses to load RCCL) while the process
+    group itself works: every rank learns of it through the process group, the run goes on over the host exchange with the
+    same partition, ``exchange_fallback`` carries the reason, stderr says so; FC_EXCHANGE_FALLBACK=0 makes it fatal."""
+    from flowcontrol_amd import _lib
+    from flowcontrol_amd.comm import ThreadComm, run_threaded
+
+    monkeypatch.setenv("FC_RCCL_DISABLE", "1")
+    monkeypatch.setattr(ThreadComm, "in_stream", True, raising=False)  # the ranks believe they are an RCCL process group
+    g = np.load(ROOT / "tests" / "golden" / "cylinder_O1.npz")
+
+    def rank_body(comm, nsteps):
+        from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver
+        from flowcontrol_amd.fem.spaces import Function
+        from flowcontrol_amd.flowsolverparameters import ParamIC
+
+        fs = CylinderFlowSolver.make_default(Re=100, path_out=tempfile.mkdtemp(), num_steps=nsteps)
+        fs.comm = comm
+        fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
+        U0, P0 = Function(fs.W, g["UP0"]).split()
+        fs._assign_steady_state(U0, P0)
+        fs.initialize_time_stepping(ic=None)
+        for _ in range(nsteps):
+            fs.step([0.0, 0.0])
+        out = (fs.exchange_fallback, fs.th.device().comm_info()["transport"], fs.timeseries[_ycols(fs.timeseries)].to_numpy())
+        fs.th.release_device()
+        return out
+
+    outs = run_threaded(2, rank_body, 6)
+    for why, transport, y in outs:
+        assert why is not None and "RCCL" in why and transport == "host"
+        assert _rel(y, g["ol_y"][:7]) < 1e-8
+    assert "exchanges go through the host" in capfd.readouterr().err
+    monkeypatch.setenv("FC_EXCHANGE_FALLBACK", "0")
+    with pytest.raises(_lib.FcCommInitError):
+        run_threaded(2, rank_body, 1)
