@@ -354,13 +354,13 @@ __global__ __launch_bounds__(256) void fc_rhs_gather_b(int N, const int* __restr
 // "state ring"); rounds up to 3 scattered it to W-layout arrays and shifted three time levels here, 20 of the kernel's 50 us at
 // KB = 16.  The matrix rows in nested-dissection order come in runs that touch the same few solution
 // rows (a tree node's rows couple to the node and its boundary), so a ROW BLOCK — up to 16 consecutive permuted rows with
-// at most FC_TB_COLS distinct columns, tabulated once per pattern — brings its distinct solution rows [col][KB] to LDS
+// at most tb_cols (128 or 256: build_batch_tables) distinct columns, tabulated once per pattern — brings its distinct solution rows [col][KB] to LDS
 // once (coalesced KB-wide rows, instead of one 8 KB-byte gather per matrix entry and simulation pair) and evaluates the
 // 16 rows from there: 16 lanes per row = (j: 16 / HP) x (simulation pair: HP = KB / 2), each lane walks every
 // (16 / HP)-th entry of its row with the entry's LOCAL column (uint16) and reads two simulations (16 B) from LDS.
 // partial[(s * 3 + w) * G + block], w = 0: sum r^2, 1: sum b^2 (row blocks), 2: sum e (cell blocks)  (fixed order: reproducible).
 #define FC_TB_ROWS 16
-#define FC_TB_COLS 128
+#define FC_TB_COLS 128  // width of a row block's column set when the tail runs alone (fc_ctx::Batch::tb_cols; dynamic LDS: tb_cols * KB doubles)
 typedef double fc_d2u __attribute__((ext_vector_type(2), aligned(8)));
 struct __attribute__((aligned(16))) FcTBlock {
   int row0, nrows;  // permuted rows [row0, row0 + nrows)
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void fc_tail_b(int N, const unsigned char* __r
   constexpr int HP = KB / 2;   // simulation pairs
   constexpr int JL = 16 / HP;  // lanes of a row that split its entries
   const int t = threadIdx.x;
-  __shared__ double xs[FC_TB_COLS * KB];
+  extern __shared__ double xs[];  // [tb_cols][KB] (launch: dynamic LDS)
   __shared__ double red[2][256];
   if ((int)blockIdx.x < n_cell_blocks) {
     fc_energy_b_block<KB>((int)blockIdx.x, nc, cnp, geom, x, partial, G, G - n_cell_blocks, red);

@@ -372,7 +372,8 @@ struct fc_ctx {
     DevBuf<double> ftile[2];      // per slot: the factor values in the tiled layout the batched block kernel streams (fc_b_repack)
     bool ftile_ok[2] = {false, false};
     int64_t tiled_values = 0;
-    DevBuf<FcTBlock> tblocks;     // row blocks of the batched tail (fc_tail_b): <= 16 consecutive permuted rows, <= FC_TB_COLS distinct columns
+    DevBuf<FcTBlock> tblocks;     // row blocks of the batched tail (fc_tail_b): <= 16 consecutive permuted rows, <= tb_cols distinct columns
+    int tb_cols = FC_TB_COLS;     // (FC_TB_COLS in the environment: tuning aid)
     DevBuf<int> tcols;            // their distinct columns
     DevBuf<unsigned short> tlidx; // per matrix entry (order of the permuted CSR): position of its column in its block's list
     int n_tblocks = 0;
@@ -4197,6 +4198,19 @@ static int build_batch_tables(fc_ctx* h) {
   {
     const std::vector<int>& rp = h->sym_plan.Ap_rowptr;
     const std::vector<int>& cl = h->sym_plan.Ap_col;
+    // width of a row block's column set.  Alone on the device the tail is fastest with many small blocks (128 columns: ~8 rows per block on
+    // O1, k = 16: 45.8 us against 53.8 with 256), but the default batched step runs it on the second stream BESIDE the next step's
+    // launches, and there the 256-column blocks (~14.5 rows, half the operand traffic, a third fewer workgroups) leave more of the machine
+    // to the main stream: k = 16 75.0 -> 83.7 k simulated steps/s on O1, k = 8 48.4 -> 50.0 (same box; 192 / 320 / 448: 82.0 / 83.0 / 80.6).
+    // 448 x 16 simulations x 8 B + the static 4 KB stay below the 64 KB a launch gets without opting in.
+    {
+      const char* e = std::getenv("FC_TB_COLS");  // tuning aid
+      bool streams = false;  // any slot whose factors stream from HBM: the batched step stays on one stream there (step_batch_begin)
+      for (int o = 0; o < 2; ++o) streams = streams || (h->sys[o].structured && h->sys[o].nt);
+      const int v = e ? std::atoi(e) : ((h->overlap && !streams) ? 256 : FC_TB_COLS);
+      B.tb_cols = std::min(448, std::max(FC_TB_ROWS, v));
+    }
+    const size_t tb_cols = (size_t)B.tb_cols;
     std::vector<FcTBlock> tb;
     std::vector<int> tcols;
     std::vector<unsigned short> lidx(cl.size(), 0);
@@ -4213,13 +4227,13 @@ static int build_batch_tables(fc_ctx* h) {
             cur.push_back(cl[(size_t)k]);
             ++added;
           }
-        if (cur.size() > FC_TB_COLS && r > r0) {  // this row does not fit any more: it starts the next block
+        if (cur.size() > tb_cols && r > r0) {  // this row does not fit any more: it starts the next block
           for (size_t q = 0; q < added; ++q) mark[(size_t)cur[cur.size() - 1 - q]] = -1;
           cur.resize(cur.size() - added);
           break;
         }
       }
-      if (cur.size() > FC_TB_COLS) return fail(FC_ERR_INVALID, "fc_set_batch: a matrix row has more than FC_TB_COLS entries");
+      if (cur.size() > tb_cols) return fail(FC_ERR_INVALID, "fc_set_batch: a matrix row has more entries than a row block's column set holds");
       std::sort(cur.begin(), cur.end());
       const int c0 = (int)tcols.size();
       for (size_t q = 0; q < cur.size(); ++q) mark[(size_t)cur[q]] = -2 - (int)q;  // local position
@@ -4517,7 +4531,7 @@ static int batch_launches(fc_ctx* h, int order_slot, int compute_energy, bool le
     int n_row_blocks = 0, n_cell_blocks = 0;
     FCCHK(batch_tail_geometry(h, compute_energy, &n_row_blocks, &n_cell_blocks));
     const int G = n_row_blocks + n_cell_blocks;
-#define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(256), 0, h->stream, N, h->velrow_p.p, xnew, B.b.p, B.tblocks.p, \
+#define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(256), (size_t)B.tb_cols * K * sizeof(double), h->stream, N, h->velrow_p.p, xnew, B.b.p, B.tblocks.p, \
                                        B.tcols.p, S.Ap_rowptr.p, B.tlidx.p, S.Ap_val.p, B.flag.p, B.partial.p, G, n_cell_blocks, nc, h->cnp.p, h->geom.p)
     FC_KB_DISPATCH(KB, FC_TAILB(4), FC_TAILB(8), FC_TAILB(16));
 #undef FC_TAILB
@@ -4542,7 +4556,7 @@ static int batch_launches_side(fc_ctx* h, int order_slot, int compute_energy) {
   FCCHK(batch_tail_geometry(h, compute_energy, &n_row_blocks, &n_cell_blocks));
   const int G = n_row_blocks + n_cell_blocks;
   hipLaunchKernelGGL(fc_wait_solved_b, dim3(1), dim3(1), 0, h->stream2, (const unsigned long long*)h->solved.p, seqp, h->side_err.p);
-#define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(256), 0, h->stream2, N, h->velrow_p.p, xnew, B.b.p, B.tblocks.p, \
+#define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(256), (size_t)B.tb_cols * K * sizeof(double), h->stream2, N, h->velrow_p.p, xnew, B.b.p, B.tblocks.p, \
                                        B.tcols.p, S.Ap_rowptr.p, B.tlidx.p, S.Ap_val.p, h->flag2x.p, B.partial.p, G, n_cell_blocks, nc, h->cnp.p, h->geom.p)
   FC_KB_DISPATCH(KB, FC_TAILB(4), FC_TAILB(8), FC_TAILB(16));
 #undef FC_TAILB
