@@ -16,7 +16,7 @@ One JSON line on rank 0 with the driver's keys plus
   cpu_baseline  compiled single-thread restatement of the reference's per-step work (oracle/cpu_step.cpp element
                 loop + SuperLU triangular solves, 1 core) timed on a bounded sample of the same workload; the numpy
                 oracle's figure is reported next to it
-  replicas      shared-operator batched stepping at N = 1: k = 1, 4, 8, 16 lock-step replicas on one handle
+  replicas      shared-operator batched stepping at N = 1: k = 1, 4, 8, 16, 32 lock-step replicas on one handle
                 (replicas_steps_per_s, bytes per simulated step, roofline of the batched factor sweeps)
   spmv          CSR SpMV probe on the assembled BDF2 matrices of the five shipped meshes (O1: the run's own matrix; the
                 others with a synthetic uniform base flow; cavity_fine is the one beyond the Infinity Cache), % of 8 TB/s
@@ -190,7 +190,7 @@ def spmv_probe(fs, include_large: bool) -> dict:
     return out
 
 
-def batched_replicas(fs, steps: int, single_rate: float, ks=(1, 4, 8, 16)) -> dict:
+def batched_replicas(fs, steps: int, single_rate: float, ks=(1, 4, 8, 16, 32)) -> dict:
     """Shared-operator batched stepping (fc_step_batch): k lock-step replicas of the headline workload on ONE handle —
     the reference's IC / controller sweeps run k FlowSolver instances instead (batch_run_lidcavity.py:197-215,
     utils/optim.py:95-102).  Every batched step is one public BatchedFlowSolver.step() (host-synchronised, measurements and

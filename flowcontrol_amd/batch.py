@@ -39,8 +39,8 @@ logger = logging.getLogger(__name__)
 
 class BatchedFlowSolver:
     def __init__(self, fs, k: int) -> None:
-        if not 1 <= int(k) <= 16:
-            raise ValueError(f"k must be in [1, 16], got {k}")
+        if not 1 <= int(k) <= 32:
+            raise ValueError(f"k must be in [1, 32], got {k}")
         if fs.fields.U0 is None:
             raise RuntimeError("no base flow: call compute_steady_state() or load_steady_state() on the FlowSolver first")
         if fs.refine_steps or fs.nd_truncate:

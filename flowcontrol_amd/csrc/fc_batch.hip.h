@@ -77,6 +77,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FC_B_WPE, 
     const unsigned char* __restrict__ velrow = nullptr, int N = 0, int* __restrict__ flag = nullptr) {
   // velrow (overlapped tail): a tile that writes solution rows (buffer rows N .. 2N: the down-sweep) tests what it writes for finiteness,
   // velocity rows only, and raises flag[simulation] -- the reference's test (flowsolver.py:731,816-819) without a pass of its own
+  // KB = 32: the matrix instruction's tile is 16 simulations wide, so a wave keeps TWO accumulators (even / odd simulations) and feeds
+  // every value pair it loaded to both: the factor values -- and the launch floors -- are shared by 32 simulated steps
+  constexpr int NH = KB > 16 ? 2 : 1;
   extern __shared__ double fc_b_red[];
   const FcBTask tk = tasks[blockIdx.x];
   const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
@@ -84,7 +87,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FC_B_WPE, 
   const double* __restrict__ tv = tiled + tk.val + 2 * lane;
   const int* __restrict__ orow = olist + 2 * lq;
   const int ls = lr < KB ? lr : 0;  // lanes beyond the batch width shadow simulation 0 (their output columns are never stored)
-  fc_d4 acc = {0.0, 0.0, 0.0, 0.0};
+  fc_d4 acc[NH];
+#pragma unroll
+  for (int hh = 0; hh < NH; ++hh) acc[hh] = fc_d4{0.0, 0.0, 0.0, 0.0};
   // chunk c of this wave is chunk grp + CG c of the tile.  The pipeline below has NO branch and no per-lane predicate in
   // its body (a branch makes the compiler drain the load queue at every join): the tiled values are zero past the block's
   // edges, a node's operand list is padded to a multiple of 32 with the index of a buffer row that is always zero, and the
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FC_B_WPE, 
 #pragma unroll
     for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const fc_i2*>(orow + (ch < nchunk ? tk.op + 32 * ch + 8 * u : 0));
   };
-  auto L = [&](int c, const fc_i2 (&x)[4], double (&a)[8], double (&b)[8]) {  // values and operand rows of chunk c
+  auto L = [&](int c, const fc_i2 (&x)[4], double (&a)[8], double (&b)[8 * NH]) {  // values and operand rows of chunk c
     const int ch = grp + CG * c;
     const double* __restrict__ p = tv + 512 * (long long)(ch < nchunk ? ch : 0);
 #pragma unroll
@@ -106,63 +111,99 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FC_B_WPE, 
       const fc_d2 v = NT ? __builtin_nontemporal_load(reinterpret_cast<const fc_d2*>(p + 128 * u)) : *reinterpret_cast<const fc_d2*>(p + 128 * u);
       a[2 * u] = v.x;
       a[2 * u + 1] = v.y;
-      b[2 * u] = buf[(size_t)x[u].x * KB + ls];
-      b[2 * u + 1] = buf[(size_t)x[u].y * KB + ls];
+      if constexpr (NH == 1) {
+        b[2 * u] = buf[(size_t)x[u].x * KB + ls];
+        b[2 * u + 1] = buf[(size_t)x[u].y * KB + ls];
+      } else {
+        // accumulator hh of lane column lr stands for simulation 2 lr + hh: both operand values of a row come with ONE 16-byte load
+        const fc_d2 p0 = *reinterpret_cast<const fc_d2*>(buf + (size_t)x[u].x * KB + 2 * lr);
+        const fc_d2 p1 = *reinterpret_cast<const fc_d2*>(buf + (size_t)x[u].y * KB + 2 * lr);
+        b[2 * u] = p0.x;
+        b[8 + 2 * u] = p0.y;
+        b[2 * u + 1] = p1.x;
+        b[8 + 2 * u + 1] = p1.y;
+      }
     }
   };
-  auto M = [&](const double (&a)[8], const double (&b)[8]) {
+  auto M = [&](const double (&a)[8], const double (&b)[8 * NH]) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh) acc[hh] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[8 * hh + u], acc[hh], 0, 0, 0);
   };
-  fc_i2 x0[4], x1[4], x2[4];
-  double a0[8], b0[8], a1[8], b1[8], a2[8], b2[8];
-  if (nw == 1) {  // the small blocks near the leaves: one round trip per stage, nothing to overlap
-    I(0, x0);
-    L(0, x0, a0, b0);
-    M(a0, b0);
-  } else if (nw == 2) {
-    I(0, x0);
-    I(1, x1);
-    L(0, x0, a0, b0);
-    L(1, x1, a1, b1);
-    M(a0, b0);
-    M(a1, b1);
-  } else if (nw > 2) {
-    I(0, x0);
-    I(1, x1);
-    I(2, x2);
-    L(0, x0, a0, b0);
-    L(1, x1, a1, b1);
-    for (int c = 0; c < nw; c += 3) {
-      I(c + 3, x0);
-      L(c + 2, x2, a2, b2);
+  if constexpr (NH == 1) {
+    fc_i2 x0[4], x1[4], x2[4];
+    double a0[8], b0[8], a1[8], b1[8], a2[8], b2[8];
+    if (nw == 1) {  // the small blocks near the leaves: one round trip per stage, nothing to overlap
+      I(0, x0);
+      L(0, x0, a0, b0);
       M(a0, b0);
-      I(c + 4, x1);
-      L(c + 3, x0, a0, b0);
+    } else if (nw == 2) {
+      I(0, x0);
+      I(1, x1);
+      L(0, x0, a0, b0);
+      L(1, x1, a1, b1);
+      M(a0, b0);
       M(a1, b1);
-      I(c + 5, x2);
-      L(c + 4, x1, a1, b1);
-      M(a2, b2);
+    } else if (nw > 2) {
+      I(0, x0);
+      I(1, x1);
+      I(2, x2);
+      L(0, x0, a0, b0);
+      L(1, x1, a1, b1);
+      for (int c = 0; c < nw; c += 3) {
+        I(c + 3, x0);
+        L(c + 2, x2, a2, b2);
+        M(a0, b0);
+        I(c + 4, x1);
+        L(c + 3, x0, a0, b0);
+        M(a1, b1);
+        I(c + 5, x2);
+        L(c + 4, x1, a1, b1);
+        M(a2, b2);
+      }
+    }
+  } else {
+    // two accumulators and twice the operand rows per chunk: ONE chunk of values and operands in registers at a time (the register file of
+    // a 1024-thread workgroup allows 128 per lane), the next chunk's row indices fetched ahead; the other waves of the SIMD cover the round trips
+    fc_i2 x0[4], x1[4];
+    double a0[8], b0[8 * NH];
+    if (nw > 0) I(0, x0);
+    for (int c = 0; c < nw; c += 2) {
+      I(c + 1, x1);
+      L(c, x0, a0, b0);
+      M(a0, b0);
+      I(c + 2, x0);
+      L(c + 1, x1, a0, b0);
+      M(a0, b0);
     }
   }
   if (CG > 1) {
     const int wave = (int)threadIdx.x >> 6;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) fc_b_red[(wave * 4 + r) * 64 + lane] = acc[r];
+    for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) fc_b_red[((wave * NH + hh) * 4 + r) * 64 + lane] = acc[hh][r];
     __syncthreads();
     if (wave != 0) return;
     for (int g = 1; g < CG; ++g)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] += fc_b_red[(g * 4 + r) * 64 + lane];
-  }
-  if (lr < KB) {
+      for (int hh = 0; hh < NH; ++hh)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int o = lq + 4 * r;
-      if (o < tk.nrows) {
-        buf[(size_t)(tk.dst + o) * KB + lr] = acc[r];
-        const int d = tk.dst + o - N;
-        if (velrow && d >= 0 && d < N && velrow[d] && !isfinite(acc[r])) atomicOr(flag + lr, 1);
+        for (int r = 0; r < 4; ++r) acc[hh][r] += fc_b_red[((g * NH + hh) * 4 + r) * 64 + lane];
+  }
+#pragma unroll
+  for (int hh = 0; hh < NH; ++hh) {
+    const int sim = NH == 1 ? lr : 2 * lr + hh;
+    if (sim < KB) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = lq + 4 * r;
+        if (o < tk.nrows) {
+          buf[(size_t)(tk.dst + o) * KB + sim] = acc[hh][r];
+          const int d = tk.dst + o - N;
+          if (velrow && d >= 0 && d < N && velrow[d] && !isfinite(acc[hh][r])) atomicOr(flag + sim, 1);
+        }
       }
     }
   }

@@ -124,7 +124,7 @@ struct OrderSys {
   bool have_c = false;
 };
 
-constexpr int kPinDoubles = 4096;
+constexpr int kPinDoubles = 8192;  // the host-mapped page: 32 simulation records of kRecStride doubles, the sequence slots and the late records behind them
 constexpr int FC_N_PHASES = 9;  // fc_get_phase_timing
 enum { PH_RHS = 0, PH_UP, PH_X1, PH_ROOT, PH_X2, PH_DOWN, PH_TAIL, PH_X3, PH_PUBLISH };
 #ifndef FC_DOWN_DEPTH
@@ -259,7 +259,7 @@ struct fc_ctx {
   DevBuf<double> uctrl, ydev, yseq, Eseq, useq;
   DevBuf<int> flag;
   DevBuf<int> flag2;  // the late tail's row workgroups test finiteness too: into a word nobody reads
-  DevBuf<int> flag2x; // ... sixteen of them for the batched late tail
+  DevBuf<int> flag2x; // ... one per simulation (32) for the batched late tail
   double* pin = nullptr;    // pinned, device-mapped host record: [0..63] u_ctrl in, [64..] outputs
   double* pin_dev = nullptr;  // device address of the same memory
   uint64_t seq = 0;           // step sequence number published by the last kernel of a step
@@ -374,6 +374,7 @@ struct fc_ctx {
     int64_t tiled_values = 0;
     DevBuf<FcTBlock> tblocks;     // row blocks of the batched tail (fc_tail_b): <= 16 consecutive permuted rows, <= tb_cols distinct columns
     int tb_cols = FC_TB_COLS;     // (FC_TB_COLS in the environment: tuning aid)
+    bool tb_built = false;
     DevBuf<int> tcols;            // their distinct columns
     DevBuf<unsigned short> tlidx; // per matrix entry (order of the permuted CSR): position of its column in its block's list
     int n_tblocks = 0;
@@ -1671,7 +1672,7 @@ int fc_create(fc_handle* out, int device, int32_t nv, int32_t ne, int32_t nc, co
   TRY(h->flag.alloc(1));
   TRY(h->flag2.alloc(1));
   TRY(h->flag2.zero(h->stream));
-  TRY(h->flag2x.alloc(16));
+  TRY(h->flag2x.alloc(32));
   TRY(h->flag2x.zero(h->stream));
   TRY(h->solved.alloc(1));
   TRY(h->solved.zero(h->stream));
@@ -1846,7 +1847,7 @@ int fc_set_bc(fc_handle h, int32_t n_bc, const int32_t* bc_dofs, int32_t n_act, 
     if (a != b && h->sym_ready) {
       h->sym_ready = false;
       h->have_plan = false;
-      h->bat.tables = false;  // and the batched launch tables with it (fc_set_batch rebuilds them)
+      h->bat.tables = h->bat.tb_built = false;  // and the batched launch tables with it (fc_set_batch rebuilds them)
       h->bat.k = h->bat.KB = 0;
       for (int o = 0; o < 2; ++o) h->sys[o].structured = false;
     }
@@ -3318,7 +3319,7 @@ void speculate_next_rhs(fc_ctx* h, int order_slot, hipStream_t stream = nullptr)
 // fc_step in two halves: fc_step_begin writes the controls into the mapped record and enqueues the step's launches (the GPU
 // works from here on), fc_step_end waits for the record.  A host program can do its own per-step bookkeeping in between
 // (FlowSolver.step appends the previous step's log row there); fc_step is begin + end.
-constexpr int kLateRec = 4010;  // late records (two step parities) of the overlapped tail in the pinned page: [E, sum r^2, sum b^2, seq, checksum, checksum, -, -]
+constexpr int kLateRec = 8010;  // late records (two step parities) of the overlapped tail in the pinned page: [E, sum r^2, sum b^2, seq, checksum, checksum, -, -]
 
 // the overlapped form of a step (fc_ctx::stream2): see the comment there
 static bool step_can_overlap(const fc_ctx* h, int order_slot) {
@@ -3815,7 +3816,7 @@ int fc_comm_unique_id(char* out128) {
 static void forget_solver_structure(fc_ctx* h) {
   h->sym_ready = false;
   h->have_plan = false;
-  h->bat.tables = false;
+  h->bat.tables = h->bat.tb_built = false;
   h->bat.k = h->bat.KB = 0;
   for (int o = 0; o < 2; ++o) h->sys[o].ready = h->sys[o].structured = false;
 }
@@ -4055,6 +4056,73 @@ static inline double* bat_n(const fc_ctx* h) { return bat_slot(h, h->bat.cur) + 
 static inline double* bat_nn(const fc_ctx* h) { return bat_slot(h, h->bat.cur + 3) + (size_t)h->N * h->bat.KB; }  // u_nn
 static inline void bat_point(fc_ctx* h) { h->bat.buf.p = bat_slot(h, h->bat.cur + 1); }
 
+// row blocks of the batched tail over the permuted pattern (the same for both slots): tabulated per batch width, because a block's
+// solution rows [column][KB] sit in LDS
+static int build_tail_blocks(fc_ctx* h, int KB) {
+  fc_ctx::Batch& B = h->bat;
+  const int N = h->N;
+  const std::vector<int>& rp = h->sym_plan.Ap_rowptr;
+  const std::vector<int>& cl = h->sym_plan.Ap_col;
+  // width of a row block's column set.  Alone on the device the tail is fastest with many small blocks (128 columns: ~8 rows per block on
+  // O1, k = 16: 45.8 us against 53.8 with 256), but the default batched step runs it on the second stream BESIDE the next step's
+  // launches, and there the 256-column blocks (~14.5 rows, half the operand traffic, a third fewer workgroups) leave more of the machine
+  // to the main stream: k = 16 75.0 -> 83.7 k simulated steps/s on O1, k = 8 48.4 -> 50.0 (same box; 192 / 320 / 448: 82.0 / 83.0 / 80.6).
+  // 448 x 16 simulations x 8 B + the static 4 KB stay below the 64 KB a launch gets without opting in.
+  int want;
+  {
+    const char* e = std::getenv("FC_TB_COLS");  // tuning aid
+    bool streams = false;  // any slot whose factors stream from HBM: the batched step stays on one stream there (step_batch_begin)
+    for (int o = 0; o < 2; ++o) streams = streams || (h->sys[o].structured && h->sys[o].nt);
+    const int v = e ? std::atoi(e) : ((h->overlap && !streams) ? 256 : FC_TB_COLS);
+    want = std::min(448 * 16 / std::max(16, KB), std::max(FC_TB_ROWS, v));  // (KB = 32: at most 224 columns)
+  }
+  if (B.tblocks.p && B.tb_cols == want && B.tb_built) return FC_OK;
+  B.tb_cols = want;
+  const size_t tb_cols = (size_t)B.tb_cols;
+  std::vector<FcTBlock> tb;
+  std::vector<int> tcols;
+  std::vector<unsigned short> lidx(cl.size(), 0);
+  std::vector<int> mark((size_t)N, -1), cur;
+  int r0 = 0;
+  while (r0 < N) {
+    cur.clear();
+    int r = r0;
+    for (; r < N && r - r0 < FC_TB_ROWS; ++r) {
+      size_t added = 0;
+      for (int k = rp[(size_t)r]; k < rp[(size_t)r + 1]; ++k)
+        if (mark[(size_t)cl[(size_t)k]] != r0) {
+          mark[(size_t)cl[(size_t)k]] = r0;
+          cur.push_back(cl[(size_t)k]);
+          ++added;
+        }
+      if (cur.size() > tb_cols && r > r0) {  // this row does not fit any more: it starts the next block
+        for (size_t q = 0; q < added; ++q) mark[(size_t)cur[cur.size() - 1 - q]] = -1;
+        cur.resize(cur.size() - added);
+        break;
+      }
+    }
+    if (cur.size() > tb_cols) return fail(FC_ERR_INVALID, "fc_set_batch: a matrix row has more entries than a row block's column set holds");
+    std::sort(cur.begin(), cur.end());
+    const int c0 = (int)tcols.size();
+    for (size_t q = 0; q < cur.size(); ++q) mark[(size_t)cur[q]] = -2 - (int)q;  // local position
+    for (int rr = r0; rr < r; ++rr)
+      for (int k = rp[(size_t)rr]; k < rp[(size_t)rr + 1]; ++k) lidx[(size_t)k] = (unsigned short)(-2 - mark[(size_t)cl[(size_t)k]]);
+    for (int c : cur) mark[(size_t)c] = -1;
+    tcols.insert(tcols.end(), cur.begin(), cur.end());
+    tb.push_back(FcTBlock{r0, r - r0, c0, (int)cur.size()});
+    r0 = r;
+  }
+  if (tcols.empty()) tcols.push_back(0);
+  if (lidx.empty()) lidx.push_back(0);
+  B.n_tblocks = (int)tb.size();
+  FCCHK(B.tblocks.upload(tb, h->stream));
+  FCCHK(B.tcols.upload(tcols, h->stream));
+  FCCHK(B.tlidx.upload(lidx, h->stream));
+  B.tb_built = true;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return FC_OK;
+}
+
 static int build_batch_tables(fc_ctx* h) {
   fc_ctx::Batch& B = h->bat;
   if (B.tables) return FC_OK;
@@ -4071,7 +4139,7 @@ static int build_batch_tables(fc_ctx* h) {
     soff[g] = S;
     S += nd(g, 4);
   }
-  if (2 * (int64_t)N + S > (int64_t)std::numeric_limits<int>::max() / 16) return fail(FC_ERR_INVALID, "fc_set_batch: mesh too large for int32 buffer rows");
+  if (2 * (int64_t)N + S > (int64_t)std::numeric_limits<int>::max() / 32) return fail(FC_ERR_INVALID, "fc_set_batch: mesh too large for int32 buffer rows");
   // fold lists: destination row -> scratch rows, nodes in elimination order (deepest first): the order of the
   // single-simulation segment lists
   std::vector<int> fptr((size_t)N + 1, 0);
@@ -4194,63 +4262,6 @@ static int build_batch_tables(fc_ctx* h) {
   }
   for (int k = 0; k <= t.depth; ++k) emit(k, false);
   if (tasks.empty()) return fail(FC_ERR_INVALID, "fc_set_batch: empty factor structure");
-  // row blocks of the batched tail over the permuted pattern (the same for both slots)
-  {
-    const std::vector<int>& rp = h->sym_plan.Ap_rowptr;
-    const std::vector<int>& cl = h->sym_plan.Ap_col;
-    // width of a row block's column set.  Alone on the device the tail is fastest with many small blocks (128 columns: ~8 rows per block on
-    // O1, k = 16: 45.8 us against 53.8 with 256), but the default batched step runs it on the second stream BESIDE the next step's
-    // launches, and there the 256-column blocks (~14.5 rows, half the operand traffic, a third fewer workgroups) leave more of the machine
-    // to the main stream: k = 16 75.0 -> 83.7 k simulated steps/s on O1, k = 8 48.4 -> 50.0 (same box; 192 / 320 / 448: 82.0 / 83.0 / 80.6).
-    // 448 x 16 simulations x 8 B + the static 4 KB stay below the 64 KB a launch gets without opting in.
-    {
-      const char* e = std::getenv("FC_TB_COLS");  // tuning aid
-      bool streams = false;  // any slot whose factors stream from HBM: the batched step stays on one stream there (step_batch_begin)
-      for (int o = 0; o < 2; ++o) streams = streams || (h->sys[o].structured && h->sys[o].nt);
-      const int v = e ? std::atoi(e) : ((h->overlap && !streams) ? 256 : FC_TB_COLS);
-      B.tb_cols = std::min(448, std::max(FC_TB_ROWS, v));
-    }
-    const size_t tb_cols = (size_t)B.tb_cols;
-    std::vector<FcTBlock> tb;
-    std::vector<int> tcols;
-    std::vector<unsigned short> lidx(cl.size(), 0);
-    std::vector<int> mark((size_t)N, -1), cur;
-    int r0 = 0;
-    while (r0 < N) {
-      cur.clear();
-      int r = r0;
-      for (; r < N && r - r0 < FC_TB_ROWS; ++r) {
-        size_t added = 0;
-        for (int k = rp[(size_t)r]; k < rp[(size_t)r + 1]; ++k)
-          if (mark[(size_t)cl[(size_t)k]] != r0) {
-            mark[(size_t)cl[(size_t)k]] = r0;
-            cur.push_back(cl[(size_t)k]);
-            ++added;
-          }
-        if (cur.size() > tb_cols && r > r0) {  // this row does not fit any more: it starts the next block
-          for (size_t q = 0; q < added; ++q) mark[(size_t)cur[cur.size() - 1 - q]] = -1;
-          cur.resize(cur.size() - added);
-          break;
-        }
-      }
-      if (cur.size() > tb_cols) return fail(FC_ERR_INVALID, "fc_set_batch: a matrix row has more entries than a row block's column set holds");
-      std::sort(cur.begin(), cur.end());
-      const int c0 = (int)tcols.size();
-      for (size_t q = 0; q < cur.size(); ++q) mark[(size_t)cur[q]] = -2 - (int)q;  // local position
-      for (int rr = r0; rr < r; ++rr)
-        for (int k = rp[(size_t)rr]; k < rp[(size_t)rr + 1]; ++k) lidx[(size_t)k] = (unsigned short)(-2 - mark[(size_t)cl[(size_t)k]]);
-      for (int c : cur) mark[(size_t)c] = -1;
-      tcols.insert(tcols.end(), cur.begin(), cur.end());
-      tb.push_back(FcTBlock{r0, r - r0, c0, (int)cur.size()});
-      r0 = r;
-    }
-    if (tcols.empty()) tcols.push_back(0);
-    if (lidx.empty()) lidx.push_back(0);
-    B.n_tblocks = (int)tb.size();
-    FCCHK(B.tblocks.upload(tb, h->stream));
-    FCCHK(B.tcols.upload(tcols, h->stream));
-    FCCHK(B.tlidx.upload(lidx, h->stream));
-  }
   B.scratch_rows = S;
   B.tiled_values = tiled_off;
   B.ftile_ok[0] = B.ftile_ok[1] = false;
@@ -4263,14 +4274,16 @@ static int build_batch_tables(fc_ctx* h) {
   return FC_OK;
 }
 
-#define FC_KB_DISPATCH(KBV, CALL4, CALL8, CALL16) \
+#define FC_KB_DISPATCH(KBV, CALL4, CALL8, CALL16, CALL32) \
   do {                                            \
     if ((KBV) == 4) {                             \
       CALL4;                                      \
     } else if ((KBV) == 8) {                      \
       CALL8;                                      \
-    } else {                                      \
+    } else if ((KBV) == 16) {                     \
       CALL16;                                     \
+    } else {                                      \
+      CALL32;                                     \
     }                                             \
   } while (0)
 
@@ -4302,16 +4315,16 @@ static int batch_apply(fc_ctx* h, int slot, bool check = false) {
 #define FC_BLK(K)                                                                                                                                              \
   do {                                                                                                                                                         \
     if (nt)                                                                                                                                                    \
-      hipLaunchKernelGGL((fc_nd_block_b<K, true>), dim3(L.count), dim3(64 * L.cg), L.cg > 1 ? (size_t)L.cg * 2048 : 0, h->stream, tp, B.olist.p, tiled, buf, L.cg, vr, h->N, B.flag.p); \
+      hipLaunchKernelGGL((fc_nd_block_b<K, true>), dim3(L.count), dim3(64 * L.cg), L.cg > 1 ? (size_t)L.cg * 2048 * (K > 16 ? 2 : 1) : 0, h->stream, tp, B.olist.p, tiled, buf, L.cg, vr, h->N, B.flag.p); \
     else                                                                                                                                                       \
-      hipLaunchKernelGGL((fc_nd_block_b<K>), dim3(L.count), dim3(64 * L.cg), L.cg > 1 ? (size_t)L.cg * 2048 : 0, h->stream, tp, B.olist.p, tiled, buf, L.cg, vr, h->N, B.flag.p);   \
+      hipLaunchKernelGGL((fc_nd_block_b<K>), dim3(L.count), dim3(64 * L.cg), L.cg > 1 ? (size_t)L.cg * 2048 * (K > 16 ? 2 : 1) : 0, h->stream, tp, B.olist.p, tiled, buf, L.cg, vr, h->N, B.flag.p);   \
   } while (0)
-      FC_KB_DISPATCH(B.KB, FC_BLK(4), FC_BLK(8), FC_BLK(16));
+      FC_KB_DISPATCH(B.KB, FC_BLK(4), FC_BLK(8), FC_BLK(16), FC_BLK(32));
 #undef FC_BLK
     } else {
       const int g = nblocks((int64_t)L.nrows * B.KB, 256);
 #define FC_FOLD(K) hipLaunchKernelGGL((fc_nd_fold_b<K>), dim3(g), dim3(256), 0, h->stream, L.nrows, L.row0, B.fptr.p, B.fsrc.p, buf, L.dst_off, L.accumulate)
-      FC_KB_DISPATCH(B.KB, FC_FOLD(4), FC_FOLD(8), FC_FOLD(16));
+      FC_KB_DISPATCH(B.KB, FC_FOLD(4), FC_FOLD(8), FC_FOLD(16), FC_FOLD(32));
 #undef FC_FOLD
     }
   }
@@ -4321,7 +4334,7 @@ static int batch_apply(fc_ctx* h, int slot, bool check = false) {
 }
 
 int fc_set_batch(fc_handle h, int32_t k) {
-  if (!h || k < 0 || k > 16) return fail(FC_ERR_INVALID, "fc_set_batch: k must be in [0, 16]");
+  if (!h || k < 0 || k > 32) return fail(FC_ERR_INVALID, "fc_set_batch: k must be in [0, 32]");
   if (h->bat.pending || h->step_pending) return fail(FC_ERR_INVALID, "fc_set_batch: a step is in flight");
   HIPCHK(hipSetDevice(h->device));
   FCCHK(quiesce(h));
@@ -4340,14 +4353,15 @@ int fc_set_batch(fc_handle h, int32_t k) {
     B.ftile_ok[0] = B.ftile_ok[1] = false;
     B.tasks.release(), B.olist.release(), B.fptr.release(), B.fsrc.release(), B.tblocks.release(), B.tcols.release(), B.tlidx.release();
     B.launches.clear();
-    B.tables = false;
+    B.tables = B.tb_built = false;
     B.k = B.KB = 0;
     return FC_OK;
   }
   FCCHK(build_batch_tables(h));
   h->bat.pre_slot = -1;  // the state below is zeroed
-  const int KB = k <= 4 ? 4 : (k <= 8 ? 8 : 16);
+  const int KB = k <= 4 ? 4 : (k <= 8 ? 8 : (k <= 16 ? 16 : 32));
   const size_t N = (size_t)h->N;
+  FCCHK(build_tail_blocks(h, KB));  // (the width of a row block's column set depends on KB: its rows [column][KB] sit in LDS)
   if (KB != B.KB || !B.ring.p) {
     B.slot_doubles = (2 * N + (size_t)B.scratch_rows + 1) * KB;  // + the zero row of the operand lists
     FCCHK(B.ring.alloc(4 * B.slot_doubles));
@@ -4356,7 +4370,7 @@ int fc_set_batch(fc_handle h, int32_t k) {
     B.b.n = N * KB;
     FCCHK(B.ev.alloc((size_t)12 * h->nc * KB));
     FCCHK(B.partial.alloc((size_t)3 * ((size_t)B.n_tblocks + (size_t)nblocks(h->nc, 256 / (8 * KB)) + 1) * KB));
-    FCCHK(B.flag.alloc(16));
+    FCCHK(B.flag.alloc(32));
   }
   B.k = k;
   B.KB = KB;
@@ -4367,7 +4381,7 @@ int fc_set_batch(fc_handle h, int32_t k) {
   bat_point(h);
   B.b.p = B.bstore.p;
   B.late[0] = B.late[1] = fc_ctx::Batch::Late{};
-  B.last_dE.assign(16, 0.0), B.last_r.assign(16, 0.0), B.last_b.assign(16, 0.0);
+  B.last_dE.assign(32, 0.0), B.last_r.assign(32, 0.0), B.last_b.assign(32, 0.0);
   FCCHK(B.flag.zero(h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return FC_OK;
@@ -4389,7 +4403,7 @@ static int batch_copy(fc_ctx* h, int n, double* host, double* dev, bool to_devic
   const int g = nblocks((int64_t)n * B.KB, 256);
   if (to_device) HIPCHK(hipMemcpyAsync(stage.p, host, (size_t)n * B.k * sizeof(double), hipMemcpyHostToDevice, h->stream));
 #define FC_IL(K) hipLaunchKernelGGL((fc_b_interleave<K>), dim3(g), dim3(256), 0, h->stream, n, B.k, to_device ? stage.p : dev, to_device ? dev : stage.p, to_device ? 1 : 0, perm)
-  FC_KB_DISPATCH(B.KB, FC_IL(4), FC_IL(8), FC_IL(16));
+  FC_KB_DISPATCH(B.KB, FC_IL(4), FC_IL(8), FC_IL(16), FC_IL(32));
 #undef FC_IL
   if (!to_device) HIPCHK(hipMemcpyAsync(host, stage.p, (size_t)n * B.k * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -4465,7 +4479,7 @@ int fc_reset_sim_batch(fc_handle h, int32_t s) {
   const int g = nblocks(h->N, 256);
   for (double* d : {bat_n(h), bat_nn(h)}) {
 #define FC_ZC(K) hipLaunchKernelGGL((fc_b_zero_column<K>), dim3(g), dim3(256), 0, h->stream, h->N, s, d)
-    FC_KB_DISPATCH(B.KB, FC_ZC(4), FC_ZC(8), FC_ZC(16));
+    FC_KB_DISPATCH(B.KB, FC_ZC(4), FC_ZC(8), FC_ZC(16), FC_ZC(32));
 #undef FC_ZC
   }
   const int zero = 0;
@@ -4476,7 +4490,7 @@ int fc_reset_sim_batch(fc_handle h, int32_t s) {
 
 // the launches of one batched step; controls are read from the host-mapped record (uctrl at s * kRecStride, body-force
 // amplitudes at s * kRecStride + 32, the step's sequence number at kSeqSlot), every simulation's outputs go to its own record
-constexpr int kSeqSlot = 4000;
+constexpr int kSeqSlot = 8000;
 // lead_elem: the step starts with its element loop; spec_slot >= 0: it ENDS with the element loop of the next step (scheme of
 // that slot) -- the loop depends on the state only, so it runs while the host is between two fc_step_batch calls, as
 // speculate_next_rhs does for the single simulation
@@ -4510,21 +4524,21 @@ static int batch_launches(fc_ctx* h, int order_slot, int compute_energy, bool le
   auto element_loop = [&](const StepCoeffs& c, const double* u1, const double* u2) {
 #define FC_ELEM(K) hipLaunchKernelGGL((fc_rhs_elem_b<K>), dim3(g_elem), dim3(256), 0, h->stream, nc, h->nn, h->cn.p, h->cnp.p, h->geom.p, u1, u2, \
                                       h->have_force ? h->fprof.p : nullptr, h->have_force ? h->n_act : 0, uf, kRecStride, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, B.ev.p)
-    FC_KB_DISPATCH(KB, FC_ELEM(4), FC_ELEM(8), FC_ELEM(16));
+    FC_KB_DISPATCH(KB, FC_ELEM(4), FC_ELEM(8), FC_ELEM(16), FC_ELEM(32));
 #undef FC_ELEM
   };
   if (lead_elem) element_loop(coeffs_for(h, order_slot), un, unn);
 #define FC_GATH(K) hipLaunchKernelGGL((fc_rhs_gather_b<K>), dim3(g_rows), dim3(256), 0, h->stream, N, h->gptr_p.p, h->gidx_p.p, B.ev.p, h->bcslot_p.p, \
                                       h->bcprof.p, S.lift_p.p, h->n_act, uc, kRecStride, B.b.p, B.buf.p, S.have_c ? S.c_rowptr.p : nullptr, S.c_col.p, \
                                       S.c_val.p, un)
-  FC_KB_DISPATCH(KB, FC_GATH(4), FC_GATH(8), FC_GATH(16));
+  FC_KB_DISPATCH(KB, FC_GATH(4), FC_GATH(8), FC_GATH(16), FC_GATH(32));
 #undef FC_GATH
   FCCHK(batch_apply(h, order_slot, overlapped));
   if ((int64_t)B.tlidx.n != S.Ap_nnz && S.Ap_nnz > 0) return fail(FC_ERR_INVALID, "fc_step_batch: tail tables and system pattern disagree");
   if (overlapped) {
 #define FC_EARLYB(K) hipLaunchKernelGGL((fc_early_b<K>), dim3(B.k), dim3(256), 0, h->stream, h->n_sens, h->s_rowptr.p, h->s_idxp.p, h->s_w.p, xnew, B.flag.p, \
                                         h->pin_dev, kRecStride, seqp, (unsigned long long*)h->solved.p)
-    FC_KB_DISPATCH(KB, FC_EARLYB(4), FC_EARLYB(8), FC_EARLYB(16));
+    FC_KB_DISPATCH(KB, FC_EARLYB(4), FC_EARLYB(8), FC_EARLYB(16), FC_EARLYB(32));
 #undef FC_EARLYB
   } else {
     // tail: residual monitor, non-finite flags, energy (the solution stays where it is: it is the new state)
@@ -4533,11 +4547,11 @@ static int batch_launches(fc_ctx* h, int order_slot, int compute_energy, bool le
     const int G = n_row_blocks + n_cell_blocks;
 #define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(256), (size_t)B.tb_cols * K * sizeof(double), h->stream, N, h->velrow_p.p, xnew, B.b.p, B.tblocks.p, \
                                        B.tcols.p, S.Ap_rowptr.p, B.tlidx.p, S.Ap_val.p, B.flag.p, B.partial.p, G, n_cell_blocks, nc, h->cnp.p, h->geom.p)
-    FC_KB_DISPATCH(KB, FC_TAILB(4), FC_TAILB(8), FC_TAILB(16));
+    FC_KB_DISPATCH(KB, FC_TAILB(4), FC_TAILB(8), FC_TAILB(16), FC_TAILB(32));
 #undef FC_TAILB
 #define FC_FINB(K) hipLaunchKernelGGL((fc_final_b<K>), dim3(B.k), dim3(1024), 0, h->stream, G, n_row_blocks, B.partial.p, h->n_sens, h->s_rowptr.p, h->s_idxp.p, \
                                       h->s_w.p, xnew, B.flag.p, h->pin_dev, kRecStride, seqp, compute_energy)
-    FC_KB_DISPATCH(KB, FC_FINB(4), FC_FINB(8), FC_FINB(16));
+    FC_KB_DISPATCH(KB, FC_FINB(4), FC_FINB(8), FC_FINB(16), FC_FINB(32));
 #undef FC_FINB
   }
   if (spec_slot >= 0) element_loop(coeffs_for(h, spec_slot), xnew, un);  // the NEXT step's loop: its (u_n, u_nn) = (this solution, this u_n)
@@ -4558,11 +4572,11 @@ static int batch_launches_side(fc_ctx* h, int order_slot, int compute_energy) {
   hipLaunchKernelGGL(fc_wait_solved_b, dim3(1), dim3(1), 0, h->stream2, (const unsigned long long*)h->solved.p, seqp, h->side_err.p);
 #define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(256), (size_t)B.tb_cols * K * sizeof(double), h->stream2, N, h->velrow_p.p, xnew, B.b.p, B.tblocks.p, \
                                        B.tcols.p, S.Ap_rowptr.p, B.tlidx.p, S.Ap_val.p, h->flag2x.p, B.partial.p, G, n_cell_blocks, nc, h->cnp.p, h->geom.p)
-  FC_KB_DISPATCH(KB, FC_TAILB(4), FC_TAILB(8), FC_TAILB(16));
+  FC_KB_DISPATCH(KB, FC_TAILB(4), FC_TAILB(8), FC_TAILB(16), FC_TAILB(32));
 #undef FC_TAILB
 #define FC_FINLB(K) hipLaunchKernelGGL((fc_final_late_b<K>), dim3(B.k), dim3(1024), 0, h->stream2, G, n_row_blocks, B.partial.p, h->pin_dev, kRecStride, \
                                        kLateRecB + 8 * par, seqp, compute_energy)
-  FC_KB_DISPATCH(KB, FC_FINLB(4), FC_FINLB(8), FC_FINLB(16));
+  FC_KB_DISPATCH(KB, FC_FINLB(4), FC_FINLB(8), FC_FINLB(16), FC_FINLB(32));
 #undef FC_FINLB
   HIPCHK(hipGetLastError());
   return FC_OK;
@@ -4699,7 +4713,7 @@ static int batch_ready(fc_ctx* h, int order_slot, int32_t k, const char* who) {
   if (h->partitioned || S.truncated) return fail(FC_ERR_INVALID, std::string(who) + ": single-GPU handles with full factors only");
   if (S.inexact) return fail(FC_ERR_INVALID, std::string(who) + ": this slot's factors are inexact (a preconditioner for GMRES): batched stepping applies them directly");
   if (h->n_act > 32 || h->n_sens > 64) return fail(FC_ERR_INVALID, std::string(who) + ": at most 32 actuators and 64 sensors");
-  if (kRecStride * 16 > kPinDoubles) return fail(FC_ERR_INVALID, "record too small");
+  if (kRecStride * 32 > kSeqSlot) return fail(FC_ERR_INVALID, "record too small");
   return FC_OK;
 }
 

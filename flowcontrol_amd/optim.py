@@ -3,7 +3,7 @@ cannot have: the candidates of one optimiser iteration evaluated TOGETHER.
 
 The reference evaluates a cost function point by point (``fun_array``: one closed-loop ``FlowSolver`` simulation per candidate
 controller, ``optim.py:48-68``).  All candidates of an iteration share the flow solver's operators — only the controller differs
-— so here up to 16 of them run as one ``BatchedFlowSolver`` (``closed_loop_costs``): the factors are read once per time step for
+— so here up to 32 of them run as one ``BatchedFlowSolver`` (``closed_loop_costs``): the factors are read once per time step for
 all candidates.  The scalar helpers keep the reference's names, arguments and file formats (``J_costfun.csv``,
 ``J_costfun_cummin.csv``, ``timeseries/timeseries_iter_XXXX[_DIVERGED].csv``).
 """
@@ -99,7 +99,7 @@ def write_optim_csv(timeseries: pd.DataFrame, savedir, diverged: bool, iteration
 # ── the candidates of one iteration, together ────────────────────────────────────────────────────────────────────────
 def closed_loop_costs(fs, controllers: Sequence, num_steps: int, u_penalty: float = 0.0, signal: str = "dE", criterion: str = "integral",
                       feedback: Callable | None = None, ics=None, Tc: float = 0.0, diverged_cost: float = np.inf):
-    """Cost J = xQx + u_penalty · uRu of every controller in ``controllers`` (≤ 16) for ``num_steps`` closed-loop steps of ``fs``'s case,
+    """Cost J = xQx + u_penalty · uRu of every controller in ``controllers`` (≤ 32) for ``num_steps`` closed-loop steps of ``fs``'s case,
     all candidates advanced in lock step on one handle (``BatchedFlowSolver``).
 
     ``controllers[i].step(y=…, dt=…)`` is called once per time step with ``feedback(y_meas_i)`` (default: minus the first
@@ -146,7 +146,7 @@ def closed_loop_costs(fs, controllers: Sequence, num_steps: int, u_penalty: floa
         bfs.close()
 
 
-def fun_array_batched(x: np.ndarray, make_controller: Callable, fs, num_steps: int, batch: int = 16, **kwargs) -> np.ndarray:
+def fun_array_batched(x: np.ndarray, make_controller: Callable, fs, num_steps: int, batch: int = 32, **kwargs) -> np.ndarray:
     """``fun_array`` for closed-loop costs: rows of ``x`` are controller parameters, ``make_controller(row)`` builds the controller;
     the points are evaluated ``batch`` at a time on one handle.  Returns costs (n_points, 1)."""
     x = np.atleast_2d(np.asarray(x, dtype=float))

@@ -214,13 +214,13 @@ int fc_set_baseflow_bc(fc_handle h, int32_t n_bc, const int32_t* bc_dofs, const 
 int fc_picard_step(fc_handle h, double nu, double* up, const double* load, double* rel_change);
 int fc_newton_step(fc_handle h, double nu, double* up, const double* load, double* res_norm, int update);
 
-/* ── shared-operator batched stepping: k <= 16 lock-step simulations on ONE handle ────────────
+/* ── shared-operator batched stepping: k <= 32 lock-step simulations on ONE handle ────────────
  *    Replaces k independent FlowSolver instances that step the SAME operator with different initial
  *    conditions / controls / controllers — the reference's outer workloads: IC sweeps
  *    (examples/lidcavity/batch_run_lidcavity.py:197-215), controller optimisation (utils/optim.py:95-102),
  *    each of which runs FlowSolver.step (flowsolver.py:703-799) once per simulation and time step.
  *    All k simulations share the handle's operators, factors, BC / force / sensor tables and time scheme and are
- *    advanced together: every vector is a matrix [row][KB] on the device (KB = 4, 8 or 16 >= k), every level
+ *    advanced together: every vector is a matrix [row][KB] on the device (KB = 4, 8, 16 or 32 >= k), every level
  *    of the factor sweep a dense block product on the fp64 matrix cores, so the factors are read once per
  *    step for all of them.  Needs fc_setup_solver (full factors, single GPU, no refinement sweeps).
  *    fc_set_batch(h, k) allocates the batched state (all zero; k = 0 frees it).  Host arrays are [k][...]

@@ -1,5 +1,5 @@
 """Development probe of the batched stepping path (prints, asserts nothing): parity of the batched factor apply and of
-batched trajectories against single runs, then throughput for k = 1, 4, 8, 16.
+batched trajectories against single runs, then throughput for k = 1, 4, 8, 16, 32.
 
     python scripts/batch_probe.py [--mesh O1] [--steps 400]
 """
@@ -22,7 +22,7 @@ def rel(a, b):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--ks", default="1,4,8,16")
+    ap.add_argument("--ks", default="1,4,8,16,32")
     ap.add_argument("--refine", type=int, default=0, help="red-refinements of the cylinder mesh (1: BASELINE config 4 mesh)")
     ap.add_argument("--skip-parity", action="store_true")
     a = ap.parse_args()
@@ -44,7 +44,7 @@ def main():
     N = dev.N
     rng = np.random.default_rng(0)
     if not a.skip_parity:
-        for k in (3, 8, 16):
+        for k in (3, 8, 16, 24):
             dev.set_batch(k)
             B = rng.standard_normal((k, N))
             t0 = time.time()

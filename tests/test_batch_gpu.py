@@ -101,7 +101,7 @@ def single_runs(golden_dir):
     fs.th.release_device()
 
 
-@pytest.mark.parametrize("k", [8, 3, 16])
+@pytest.mark.parametrize("k", [8, 3, 16, 20])
 def test_batched_trajectories_equal_their_single_runs_and_the_oracle(k, single_runs, golden_dir):
     """k trajectories with different initial conditions, control inputs and controllers (closed loops through host
     Controllers that see only their own run's measurements), advanced together: each must equal its single run to 1e-12;
@@ -158,7 +158,7 @@ def test_batched_factor_apply_matches_single_solves(single_runs):
     fs, _ = single_runs
     dev = fs.th.device()
     rng = np.random.default_rng(3)
-    for k in (1, 5, 8, 13, 16):
+    for k in (1, 5, 8, 13, 16, 27, 32):
         dev.set_batch(k)
         for slot in (SLOT_BDF1, SLOT_BDF2):
             B = rng.standard_normal((k, dev.N))
@@ -167,7 +167,7 @@ def test_batched_factor_apply_matches_single_solves(single_runs):
                 x1, info = dev.solve(slot, B[s])
                 assert _rel(X[s], x1) < 1e-12
         info = dev.batch_info()
-        assert info["k"] == k and info["KB"] in (4, 8, 16) and info["KB"] >= k
+        assert info["k"] == k and info["KB"] in (4, 8, 16, 32) and info["KB"] >= k
         assert info["factor_bytes"] == 8.0 * dev.factor_nnz[SLOT_BDF2] or info["factor_bytes"] > 0
     dev.set_batch(0)
 
@@ -241,7 +241,7 @@ def test_batch_api_refuses_what_it_cannot_do(single_runs):
     fs, _ = single_runs
     dev = fs.th.device()
     with pytest.raises(_lib.FcError):
-        dev.set_batch(17)
+        dev.set_batch(33)
     dev.set_batch(0)
     with pytest.raises(_lib.FcError):  # no batch allocated
         _lib.check(dev.lib.fc_step_batch(dev._h, SLOT_BDF1, 4, None, None, None, None, 1, None))
