@@ -5,7 +5,7 @@
 // input or controller (IC sweeps examples/lidcavity/batch_run_lidcavity.py:197-215, controller optimisation
 // utils/optim.py:95-102): the factors (O1: 176 MB) are the same for all of them.  A single run re-reads them
 // every step to advance ONE right-hand side; here every vector becomes a row-major matrix [row][KB]
-// (KB = 4, 8 or 16 simulations side by side, simulation index fastest) and every level of the factor sweep a
+// (KB = 4, 8, 16 or 32 simulations side by side, simulation index fastest) and every level of the factor sweep a
 // dense block product  (factor block) x (operand rows x KB)  on the fp64 matrix cores
 // (v_mfma_f64_16x16x4_f64): the factor bytes are streamed once per KB simulated steps.
 //
