@@ -288,6 +288,24 @@ struct fc_ctx {
   // element vectors of the NEXT step's right-hand side, enqueued behind a synchronous step while the host
   // is busy (they depend on the state only): slot whose coefficients they were computed with, or -1
   int pre_slot = -1;
+  // column form of the up-sweep (single GPU, full fp64 factors, in-library symbolic phase): per tree level one LDS-tiled block launch over
+  // the nodes' dense -L blocks (fc_nd_down_block with `out`: the node's y rows staged once per workgroup, whole rows streamed) + one fold
+  // launch (fc_nd_fold1) instead of one segment-row launch.  Two launches per level instead of one, but the blocks stream at the down-sweep's
+  // rate (~5 TB/s) where the segment rows reach 2.7-3.9: it pays where the factors stream from HBM (refined cylinder + 3 %, pinball + 3 %,
+  // cavity_fine + 4.5 % steps/s) and costs 6 % on O1, whose launches sit on their floor.  up_form: 0 = auto (column form for slots with
+  // OrderSys::nt), 1 = row form, 2 = column form (FC_UP_FORM=auto|row|column, read by fc_create)
+  int up_form = 0;
+  struct UpCol {
+    bool ready = false, tried = false;
+    DevBuf<FcBlk> blk;
+    DevBuf<int> fptr, fsrc;
+    DevBuf<double> scratch;
+    struct Lvl {
+      int64_t begin;
+      int count, lpr, rps, fold_row0, fold_nrows;
+    };
+    std::vector<Lvl> lv;  // deepest level first
+  } upc;
   // device-side numeric factorisation (fc_factor_plan / fc_refactor)
   struct PlanNode {
     int64_t front, voff;
@@ -777,19 +795,154 @@ int state_download(fc_ctx* h, double* wn, double* wnn) {
   return FC_OK;
 }
 
+// tables of the column-form up-sweep from the in-library symbolic phase (the values are the ones the row form reads: a node's -L block
+// is stored row-major, nb x ni, behind its [D^-1 | -U] rows)
+int build_up_column(fc_ctx* h) {
+  fc_ctx::UpCol& U = h->upc;
+  U.ready = false;
+  U.tried = true;
+  U.lv.clear();
+  if (!h->sym_ready || h->partitioned || h->sym_truncate > 0) return FC_OK;
+  const fcsym::Factors& fac = h->sym_fac;
+  const fcsym::Tree& t = h->sym_tree;
+  const int N = h->N;
+  const size_t G = fac.nodes.size() / 7;
+  auto nd = [&](size_t g, int f) { return fac.nodes[g * 7 + (size_t)f]; };  // level, n, i0, ni, nb, voff, ioff
+  std::vector<int64_t> soff(G, 0);
+  int64_t S = 0;
+  for (size_t g = 0; g < G; ++g) {
+    soff[g] = S;
+    S += nd(g, 4);
+  }
+  std::vector<int> fptr((size_t)N + 1, 0);
+  for (size_t g = 0; g < G; ++g)
+    for (int64_t j = 0; j < nd(g, 4); ++j) fptr[(size_t)(fac.idx[(size_t)(nd(g, 6) + j)] - N) + 1]++;
+  for (int i = 0; i < N; ++i) fptr[(size_t)i + 1] += fptr[(size_t)i];
+  std::vector<int> fsrc((size_t)std::max(1, fptr[(size_t)N]));
+  {
+    std::vector<int> fill(fptr.begin(), fptr.end() - 1);
+    for (size_t g = 0; g < G; ++g)  // nodes in elimination order (deepest first): the order of the row form's segment lists
+      for (int64_t j = 0; j < nd(g, 4); ++j) fsrc[(size_t)fill[(size_t)(fac.idx[(size_t)(nd(g, 6) + j)] - N)]++] = (int)(soff[g] + j);
+  }
+  std::vector<FcBlk> blk;
+  for (int k = t.depth; k >= 1; --k) {
+    std::vector<size_t> sel;
+    double values = 0.0;
+    int64_t rows = 0;
+    for (size_t g = 0; g < G; ++g)
+      if (nd(g, 0) == k && nd(g, 3) > 0 && nd(g, 4) > 0) {
+        sel.push_back(g);
+        values += (double)nd(g, 3) * (double)nd(g, 4);
+        rows += nd(g, 4);
+      }
+    fc_ctx::UpCol::Lvl L{(int64_t)blk.size(), 0, 16, 1, 0, 0};
+    if (!sel.empty()) {
+      const double wd = values / (double)std::max<int64_t>(rows, 1);
+      static const int lpr_shift = [] { const char* e = std::getenv("FC_UPC_LPR_SHIFT"); return e ? std::atoi(e) : 0; }();  // tuning aids
+      static const int rc_max = [] { const char* e = std::getenv("FC_UPC_RC"); return e ? std::max(8, std::atoi(e)) : 32; }();
+      L.lpr = wd <= 32 ? 8 : (wd <= 64 ? 16 : (wd <= 128 ? 32 : 64));
+      for (int q = 0; q < lpr_shift && L.lpr < 64; ++q) L.lpr *= 2;
+      for (int q = 0; q > lpr_shift && L.lpr > 8; --q) L.lpr /= 2;
+      const int slots = 256 / L.lpr;
+      int rc = rc_max;
+      while (rc > slots && rows / rc < 1024) rc /= 2;
+      rc = std::max(rc, 1);
+      int maxr = 1;
+      for (size_t g : sel) {
+        const int64_t i0 = nd(g, 2), ni = nd(g, 3), nb = nd(g, 4), voff = nd(g, 5), nf = ni + nb;
+        if (ni > FC_BLK_TILE * 64) return fail(FC_ERR_INVALID, "build_up_column: node too large");
+        for (int64_t r0 = 0; r0 < nb; r0 += rc) {
+          const int nr = (int)std::min<int64_t>(rc, nb - r0);
+          blk.push_back(FcBlk{(long long)(voff + ni * nf + r0 * ni), (int)(soff[g] + r0), nr, (int)i0, (int)ni, 0, 0});
+          maxr = std::max(maxr, nr);
+        }
+      }
+      std::stable_sort(blk.begin() + L.begin, blk.end(), [](const FcBlk& a, const FcBlk& b) { return (int64_t)a.nrows * a.ni > (int64_t)b.nrows * b.ni; });
+      L.count = (int)(blk.size() - (size_t)L.begin);
+      int rps = 1;
+      while (rps * slots < maxr) rps *= 2;
+      L.rps = rps;
+    }
+    const int64_t r0 = t.node_ptr[(size_t)k - 1].front(), r1 = t.node_ptr[(size_t)k - 1].back();
+    L.fold_row0 = (int)r0;
+    L.fold_nrows = (int)(r1 - r0);
+    U.lv.push_back(L);
+  }
+  if (blk.empty()) return FC_OK;
+  FCCHK(U.blk.upload(blk, h->stream));
+  FCCHK(U.fptr.upload(fptr, h->stream));
+  FCCHK(U.fsrc.upload(fsrc, h->stream));
+  FCCHK(U.scratch.alloc((size_t)std::max<int64_t>(1, S)));
+  FCCHK(U.scratch.zero(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  U.ready = true;
+  return FC_OK;
+}
+
+static bool up_column_wanted(const fc_ctx* h, const OrderSys& S) { return h->up_form == 2 || (h->up_form == 0 && S.nt); }
+
+// the up-sweep of one apply in column form: per level (deepest first) the nodes' -L blocks times their y rows -> scratch, then the fold
+// of the next level's rows
+int launch_up_column(fc_ctx* h, OrderSys& S) {
+  fc_ctx::UpCol& U = h->upc;
+  for (const fc_ctx::UpCol::Lvl& L : U.lv) {
+    if (L.count > 0) {
+      const FcBlk* bp = U.blk.p + L.begin;
+#define FC_UPB(LP, R)                                                                                                                      \
+  do {                                                                                                                                     \
+    if (S.nt)                                                                                                                              \
+      hipLaunchKernelGGL((fc_nd_down_block<LP, R, double, true>), dim3(L.count), dim3(256), 0, h->stream, bp, S.f_idx.p, S.f_val.p, h->buf.p, \
+                         h->N, (const unsigned char*)nullptr, (int*)nullptr, U.scratch.p);                                                 \
+    else                                                                                                                                   \
+      hipLaunchKernelGGL((fc_nd_down_block<LP, R>), dim3(L.count), dim3(256), 0, h->stream, bp, S.f_idx.p, S.f_val.p, h->buf.p, h->N,     \
+                         (const unsigned char*)nullptr, (int*)nullptr, U.scratch.p);                                                       \
+  } while (0)
+      switch (L.lpr * 100 + L.rps) {
+        case 801: FC_UPB(8, 1); break;
+        case 802: FC_UPB(8, 2); break;
+        case 1604: FC_UPB(16, 4); break;
+        case 1601: FC_UPB(16, 1); break;
+        case 1602: FC_UPB(16, 2); break;
+        case 3201: FC_UPB(32, 1); break;
+        case 3202: FC_UPB(32, 2); break;
+        case 3204: FC_UPB(32, 4); break;
+        case 6401: FC_UPB(64, 1); break;
+        case 6402: FC_UPB(64, 2); break;
+        case 6404: FC_UPB(64, 4); break;
+        case 6408: FC_UPB(64, 8); break;
+        default: return fail(FC_ERR_INVALID, "launch_up_column: unsupported block geometry");
+      }
+#undef FC_UPB
+    }
+    if (L.fold_nrows > 0)
+      hipLaunchKernelGGL(fc_nd_fold1, dim3(nblocks(L.fold_nrows, 256)), dim3(256), 0, h->stream, L.fold_nrows, L.fold_row0, U.fptr.p, U.fsrc.p, U.scratch.p, h->buf.p);
+  }
+  HIPCHK(hipGetLastError());
+  return FC_OK;
+}
+
 int apply_factors(fc_ctx* h, OrderSys& S, int first = 0, int last = -1) {
   if (last < 0) last = (int)S.stages.size() - 1;
+  // column form: all up stages of a whole apply as block + fold launches per level (fc_ctx::upc)
+  bool upc = false;
+  if (up_column_wanted(h, S) && first == 0 && last == (int)S.stages.size() - 1 && !h->partitioned && !S.truncated && S.bits == 64) {
+    if (!h->upc.ready && !h->upc.tried && h->sym_ready) FCCHK(build_up_column(h));
+    upc = h->upc.ready;
+  }
   // timing: ONE event pair around the back-to-back sweep launches of this apply (a pair per launch
   // would serialise the short kernels and read ~2 us high); the launch count is recorded with it
   int nlaunch = 0;
-  for (size_t i = (size_t)first; i < S.stages.size() && (int)i <= last; ++i) nlaunch += S.stages[i].nrows > 0 ? 1 : 0;
+  for (size_t i = (size_t)first; i < S.stages.size() && (int)i <= last; ++i) nlaunch += (S.stages[i].nrows > 0 && !(upc && S.stages[i].kind == 0)) ? 1 : 0;
+  if (upc)
+    for (const fc_ctx::UpCol::Lvl& L : h->upc.lv) nlaunch += (L.count > 0 ? 1 : 0) + (L.fold_nrows > 0 ? 1 : 0);
   FCCHK(time_begin(h, 0, nlaunch));
+  if (upc) FCCHK(launch_up_column(h, S));
   for (size_t i = (size_t)first; i < S.stages.size() && (int)i <= last; ++i) {
     const Stage& st = S.stages[i];
     const bool ex = exchanges(h) && S.ar_n > 0;
     if (ex && (int)i == S.ar2_stage)  // root down-sweep: this rank fills its block of rows, the others' stay zero
       HIPCHK(hipMemsetAsync(h->buf.p + h->N + S.ar_row0, 0, (size_t)S.ar_n * sizeof(double), h->stream));
-    if (st.nrows > 0) FCCHK(launch_sweep(h, S, st));
+    if (st.nrows > 0 && !(upc && st.kind == 0)) FCCHK(launch_sweep(h, S, st));
     // multi-GPU: (1) the root separator's right-hand side is the sum of every rank's element and sub-tree
     // contributions; (2) the root solution is assembled from the ranks' row blocks — the two exchange steps of a solve
     if (ex && (int)i == S.ar_stage) {
@@ -1536,6 +1689,7 @@ int fc_create(fc_handle* out, int device, int32_t nv, int32_t ne, int32_t nc, co
   TRYHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   TRYHIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
   if (const char* e = std::getenv("FC_OVERLAP_TAIL")) h->overlap = e[0] != '0';
+  if (const char* e = std::getenv("FC_UP_FORM")) h->up_form = std::string(e) == "row" ? 1 : (std::string(e) == "column" ? 2 : 0);
   TRYHIP(hipEventCreate(&h->ev0));
   TRYHIP(hipEventCreate(&h->ev1));
   TRYHIP(hipHostMalloc((void**)&h->pin, kPinDoubles * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
@@ -1846,6 +2000,7 @@ int fc_set_bc(fc_handle h, int32_t n_bc, const int32_t* bc_dofs, int32_t n_act, 
     std::sort(b.begin(), b.end());
     if (a != b && h->sym_ready) {
       h->sym_ready = false;
+      h->upc.ready = h->upc.tried = false;
       h->have_plan = false;
       h->bat.tables = h->bat.tb_built = false;  // and the batched launch tables with it (fc_set_batch rebuilds them)
       h->bat.k = h->bat.KB = 0;
@@ -2792,6 +2947,7 @@ int fc_setup_solver(fc_handle h, int slot, int32_t depth, int32_t merge, int32_t
                            pl.ap_src.data(), pl.max_slots));
       h->sym_truncate = truncate;
       h->sym_ready = true;
+      h->upc.ready = h->upc.tried = false;
       FCCHK(apply_pressure_pin(h));
     } else if (truncate != h->sym_truncate) {
       return fail(FC_ERR_INVALID, "fc_setup_solver: both slots of a handle share one tree: same truncate");
@@ -3732,7 +3888,14 @@ int fc_bench_sweeps(fc_handle h, int slot, int reps, double* ms_per_apply, int32
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   *ms_per_apply = (double)ms / reps;
-  if (launches_per_apply) *launches_per_apply = (int32_t)S.stages.size();
+  if (launches_per_apply) {
+    const bool upc = up_column_wanted(h, S) && h->upc.ready && !h->partitioned && !S.truncated && S.bits == 64;
+    int n = 0;
+    for (const Stage& st : S.stages) n += (st.nrows > 0 && !(upc && st.kind == 0)) ? 1 : 0;
+    if (upc)
+      for (const fc_ctx::UpCol::Lvl& L : h->upc.lv) n += (L.count > 0 ? 1 : 0) + (L.fold_nrows > 0 ? 1 : 0);
+    *launches_per_apply = n;
+  }
   return FC_OK;
 }
 
@@ -3815,6 +3978,7 @@ int fc_comm_unique_id(char* out128) {
 // for the old role is void
 static void forget_solver_structure(fc_ctx* h) {
   h->sym_ready = false;
+  h->upc.ready = h->upc.tried = false;
   h->have_plan = false;
   h->bat.tables = h->bat.tb_built = false;
   h->bat.k = h->bat.KB = 0;

@@ -581,8 +581,11 @@ __global__ __launch_bounds__(256) void fc_nd_down_block(const FcBlk* __restrict_
                                                         const int* __restrict__ idxlist,
                                                         const VT* __restrict__ val,
                                                         double* __restrict__ buf, int N,
-                                                        const unsigned char* __restrict__ velrow = nullptr, int* __restrict__ flag = nullptr) {
+                                                        const unsigned char* __restrict__ velrow = nullptr, int* __restrict__ flag = nullptr,
+                                                        double* __restrict__ out = nullptr) {
   // velrow / flag: as in fc_nd_sweep (here the whole mask, indexed by the permuted row)
+  // out (column form of the up-sweep, fc_hip.hip build_up_column): the block is a node's -L block (nb x ni, operand = the node's own y rows,
+  // no index part) and its products go to out[row0 + r] -- a scratch slot per (node, boundary row), folded per level by fc_nd_fold1
   __shared__ double xs[FC_BLK_TILE];
   constexpr int SLOTS = 256 / LPR;  // rows in flight per workgroup
   const FcBlk b = blk[blockIdx.x];
@@ -644,10 +647,36 @@ __global__ __launch_bounds__(256) void fc_nd_down_block(const FcBlk* __restrict_
     for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_down(s, off, LPR);
     const int r = slot + k * SLOTS;
     if (l == 0 && r < b.nrows) {
-      buf[N + b.row0 + r] = s;
-      if (velrow && velrow[b.row0 + r] && !isfinite(s)) atomicOr(flag, 1);
+      if (out) {
+        out[b.row0 + r] = s;
+      } else {
+        buf[N + b.row0 + r] = s;
+        if (velrow && velrow[b.row0 + r] && !isfinite(s)) atomicOr(flag, 1);
+      }
     }
   }
+}
+
+// column form of the up-sweep: y[row0 + i] += the scratch slots of the row's descendants, in list order (deepest node first: reproducible)
+__global__ __launch_bounds__(256) void fc_nd_fold1(int nrows, int row0, const int* __restrict__ fptr, const int* __restrict__ fsrc,
+                                                   const double* __restrict__ scratch, double* __restrict__ y) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= nrows) return;
+  const int i = row0 + t;
+  const int q0 = fptr[i], q1 = fptr[i + 1];
+  double acc = y[i];
+  for (int base = q0; base < q1; base += 8) {
+    int id[8];
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) id[u] = base + u < q1 ? fsrc[base + u] : -1;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = id[u] >= 0 ? scratch[id[u]] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (id[u] >= 0) acc += v[u];
+  }
+  y[i] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -200,3 +200,39 @@ def test_factors_that_miss_the_acceptance_residual_precondition_gmres(golden_dir
     dev.refactor(SLOT_BDF2)
     assert not dev.factors_inexact[SLOT_BDF2]
     dev.close()
+
+
+@pytest.mark.parametrize("mesh", ["O1", "cavity_coarse"])
+def test_the_two_forms_of_the_up_sweep_solve_alike(mesh, monkeypatch):
+    """FC_UP_FORM=row: one segment-row launch per tree level (the default while the factors stay in the Infinity Cache);
+    FC_UP_FORM=column: per level the nodes' dense -L blocks through the LDS-tiled block kernel + one fold launch (the default for
+    factors that stream from HBM).  Same values, same sums in a different association: solutions agree to round-off and both
+    meet the direct solve; the column form runs two launches per level."""
+    from flowcontrol_amd.device import SLOT_BDF2, DeviceSolver
+
+    th = TaylorHood(read_xdmf_mesh(mesh_file(mesh)))
+    x = th.node_coords
+    U0 = np.r_[1.0 + 0.3 * np.sin(x[:, 0]) * np.cos(0.7 * x[:, 1]), 0.2 * np.cos(0.5 * x[:, 0] + 0.1) * np.sin(x[:, 1])]
+    dofs = _bc(th)
+    rng = np.random.default_rng(11)
+    b = rng.standard_normal(th.N)
+    b[dofs] = 0.0
+    sol, launches = {}, {}
+    for form in ("row", "column"):
+        monkeypatch.setenv("FC_UP_FORM", form)  # read when the handle is created
+        dev = DeviceSolver(th)
+        dev.set_bc(dofs, np.zeros((dofs.size, 1)))
+        dev.assemble_matrix(SLOT_BDF2, mass=300.0, nu=0.01, adv=U0, lin=U0)
+        dev.apply_bc(SLOT_BDF2)
+        dev.setup_solver(SLOT_BDF2)
+        xs, info = dev.solve(SLOT_BDF2, b)
+        assert info[1] < 1e-12
+        if form == "row":
+            x0 = spla.splu(dev.matrix(SLOT_BDF2).tocsc()).solve(b)
+            assert np.linalg.norm(xs - x0) <= 1e-10 * np.linalg.norm(x0)
+        sol[form] = xs
+        launches[form] = dev.bench_sweeps(SLOT_BDF2, reps=3)[1]
+        dev.close()
+    assert np.linalg.norm(sol["row"] - sol["column"]) <= 1e-13 * np.linalg.norm(sol["row"])
+    n_up = (launches["row"] - 1) // 2  # row form: depth up launches + root + depth down launches
+    assert launches["column"] == launches["row"] + n_up, launches
