@@ -3512,16 +3512,21 @@ static int step_enqueue_overlapped(fc_ctx* h) {
   ++h->step_count;
   speculate_next_rhs(h, order_slot);  // the next step's element loop, on the main stream behind fc_early as ever
   // ---- side stream: [gate: this step's solve has finished] residual monitor + energy -> this step's late record
-  hipLaunchKernelGGL(fc_wait_solved, dim3(1), dim3(1), 0, h->stream2, h->solved.p, (fc_u64)h->pend_seq, h->side_err.p);
+  // (with factors that stream from HBM a concurrent matrix pass costs more than it hides: step_can_overlap.  The same late tail kept on the
+  //  MAIN stream behind fc_early -- so that the host has y and enqueues the next step while the tail runs -- was measured too: 3-4 % slower
+  //  than the plain one-stream step on the three large meshes, the next step's first launch starts 14 us after fc_final_late although it was
+  //  enqueued 45 us earlier; profiles/EXPERIMENTS.md)
+  hipStream_t ts = h->stream2;
+  hipLaunchKernelGGL(fc_wait_solved, dim3(1), dim3(1), 0, ts, h->solved.p, (fc_u64)h->pend_seq, h->side_err.p);
   const int reps = std::max(1, nblocks(h->N, 32 * 2048));
   const int g_rows = res ? nblocks(h->N, 32 * reps) : 0, g_cells = (compute_energy && h->nc > 0) ? nblocks(h->nc, 32 * reps) : 0;
   const int g = g_rows + g_cells;
   if (g > h->nblk_N) return fail(FC_ERR_INVALID, "step: partial buffer too small");
   if (g > 0)
-    hipLaunchKernelGGL(fc_tail<false>, dim3(g), dim3(256), 0, h->stream2, h->N, h->velrow_p.p, x, b_now, res ? S.Ap_rowptr.p : nullptr, S.Ap_col.p, S.Ap_val.p, g_rows,
+    hipLaunchKernelGGL(fc_tail<false>, dim3(g), dim3(256), 0, ts, h->N, h->velrow_p.p, x, b_now, res ? S.Ap_rowptr.p : nullptr, S.Ap_col.p, S.Ap_val.p, g_rows,
                        0, reps, h->nc, g_cells > 0 ? h->cnp.p : nullptr, h->geom.p, (const unsigned char*)nullptr, (const int*)nullptr, h->nc, h->flag2.p,
                        h->partial.p, FcFin{});
-  hipLaunchKernelGGL(fc_final_late, dim3(1), dim3(256), 0, h->stream2, g_cells > 0 ? g : 0, g_cells > 0 ? h->partial.p + 2 * (size_t)g : nullptr, res ? g : 0,
+  hipLaunchKernelGGL(fc_final_late, dim3(1), dim3(256), 0, ts, g_cells > 0 ? g : 0, g_cells > 0 ? h->partial.p + 2 * (size_t)g : nullptr, res ? g : 0,
                      res ? h->partial.p : nullptr, dev + kLateRec + 8 * par, h->pend_seq);
   HIPCHK(hipGetLastError());
   h->late[par].pending = true;

@@ -113,6 +113,9 @@ class FlowSolver(ABC):
         self.comm = None
         #: set when the in-library RCCL communicator could not be created and the exchanges were staged through the host instead
         self.exchange_fallback: str | None = None
+        #: largest relative residual the monitor has seen on this solver's steps (collected with every step's log row, i.e. without
+        #: making the host wait for the residual of the step that just ended, as reading ``solve_info`` right after ``step`` does)
+        self.residual_max = 0.0
         self._setup()
 
     _pending_log = None        # (iter, t, u_ctrl, y, dE | None, runtime) of the last step, not yet in the exporter
@@ -141,6 +144,8 @@ class FlowSolver(ABC):
             dE, info = self.th.device().step_collect()
             self._last_dE = dE
             self._solve_info = info
+            if info[1] > self.residual_max:  # (NaN compares False)
+                self.residual_max = float(info[1])
             if info[1] > self.residual_tol:  # NaN (monitor off / not this step) compares False
                 self._residual_breach = (float(info[1]), self.iter)
 
