@@ -288,7 +288,7 @@ struct fc_ctx {
   // element vectors of the NEXT step's right-hand side, enqueued behind a synchronous step while the host
   // is busy (they depend on the state only): slot whose coefficients they were computed with, or -1
   int pre_slot = -1;
-  // column form of the up-sweep (single GPU, full fp64 factors, in-library symbolic phase): per tree level one LDS-tiled block launch over
+  // column form of the up-sweep (full fp64 factors, in-library symbolic phase; single-GPU and partitioned handles): per tree level one LDS-tiled block launch over
   // the nodes' dense -L blocks (fc_nd_down_block with `out`: the node's y rows staged once per workgroup, whole rows streamed) + one fold
   // launch (fc_nd_fold1) instead of one segment-row launch.  Two launches per level instead of one, but the blocks stream at the down-sweep's
   // rate (~5 TB/s) where the segment rows reach 2.7-3.9: it pays where the factors stream from HBM (refined cylinder + 3 %, pinball + 3 %,
@@ -435,9 +435,9 @@ struct Rccl {
 Rccl g_rccl;
 
 int rccl_load() {
-  if (g_rccl.lib) return FC_OK;
   if (const char* e = std::getenv("FC_RCCL_DISABLE"); e && e[0] == '1')  // test aid: a machine whose RCCL cannot be loaded
     return fail(FC_ERR_HIP, "cannot load RCCL: disabled by FC_RCCL_DISABLE");
+  if (g_rccl.lib) return FC_OK;
   // first the copy that sits next to the HIP runtime this library is bound to (PyTorch ships its own set and
   // has it loaded already), then by soname, then the system one
   std::string dir;
@@ -796,13 +796,14 @@ int state_download(fc_ctx* h, double* wn, double* wnn) {
 }
 
 // tables of the column-form up-sweep from the in-library symbolic phase (the values are the ones the row form reads: a node's -L block
-// is stored row-major, nb x ni, behind its [D^-1 | -U] rows)
+// is stored row-major, nb x ni, behind its [D^-1 | -U] rows).  Partitioned handles: the rank's own nodes only (that is what its factor
+// layout holds); their slots for root rows fold into this rank's share of the root right-hand side, which the first exchange sums
 int build_up_column(fc_ctx* h) {
   fc_ctx::UpCol& U = h->upc;
   U.ready = false;
   U.tried = true;
   U.lv.clear();
-  if (!h->sym_ready || h->partitioned || h->sym_truncate > 0) return FC_OK;
+  if (!h->sym_ready || h->sym_truncate > 0) return FC_OK;
   const fcsym::Factors& fac = h->sym_fac;
   const fcsym::Tree& t = h->sym_tree;
   const int N = h->N;
@@ -925,7 +926,7 @@ int apply_factors(fc_ctx* h, OrderSys& S, int first = 0, int last = -1) {
   if (last < 0) last = (int)S.stages.size() - 1;
   // column form: all up stages of a whole apply as block + fold launches per level (fc_ctx::upc)
   bool upc = false;
-  if (up_column_wanted(h, S) && first == 0 && last == (int)S.stages.size() - 1 && !h->partitioned && !S.truncated && S.bits == 64) {
+  if (up_column_wanted(h, S) && first == 0 && last == (int)S.stages.size() - 1 && !S.truncated && S.bits == 64) {
     if (!h->upc.ready && !h->upc.tried && h->sym_ready) FCCHK(build_up_column(h));
     upc = h->upc.ready;
   }
@@ -3894,7 +3895,7 @@ int fc_bench_sweeps(fc_handle h, int slot, int reps, double* ms_per_apply, int32
   HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   *ms_per_apply = (double)ms / reps;
   if (launches_per_apply) {
-    const bool upc = up_column_wanted(h, S) && h->upc.ready && !h->partitioned && !S.truncated && S.bits == 64;
+    const bool upc = up_column_wanted(h, S) && h->upc.ready && !S.truncated && S.bits == 64;
     int n = 0;
     for (const Stage& st : S.stages) n += (st.nrows > 0 && !(upc && st.kind == 0)) ? 1 : 0;
     if (upc)

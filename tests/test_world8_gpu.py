@@ -242,7 +242,7 @@ def test_a_machine_without_rccl_falls_back_to_the_host_exchange_and_says_so(monk
 
     outs = run_threaded(2, rank_body, 6)
     for why, transport, y in outs:
-        assert why is not None and "RCCL" in why and transport == "host"
+        assert why is not None and "RCCL" in why and transport == "host", why
         assert _rel(y, g["ol_y"][:7]) < 1e-8
     assert "exchanges go through the host" in capfd.readouterr().err
     monkeypatch.setenv("FC_EXCHANGE_FALLBACK", "0")
