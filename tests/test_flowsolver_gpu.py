@@ -111,6 +111,8 @@ def test_cylinder_open_loop_200_steps_vs_oracle(tmp_path_factory, golden_dir):
     fs.initialize_time_stepping(ic=None)
     for _ in range(100):
         fs.step(u_ctrl=[0.0, 0.0])
+    # the running maximum of the monitored residual: kept with every step's log row (one step behind: nobody waited for the late record)
+    assert 0.0 < fs.residual_max < 1e-12
     y_b, dE_b = fs.run(100, np.zeros(2))  # batched path continues the same trajectory
     g = np.load(golden_dir / "cylinder_O1.npz")
     ts = fs.timeseries
