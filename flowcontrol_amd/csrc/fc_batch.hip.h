@@ -253,12 +253,17 @@ __global__ __launch_bounds__(256) void fc_rhs_elem_b(int nc, int nn, const int* 
                                                      const double* __restrict__ fprof, int n_act, const double* __restrict__ uforce,
                                                      int ustride, double cm_n, double cm_nn, double cc_n, double cc_nn,
                                                      double* __restrict__ ev) {
-  constexpr int CPB = 256 / (8 * KB);  // cells per workgroup
-  __shared__ double nod[6][256];       // fields (ux, uy of u_n; ux, uy of u_nn; fx, fy) x [cell][node 8][s]
-  __shared__ double gs[2][256];
+  // thread = (cell, lane8, simulation PAIR): every nodal load and every store moves 16 B (the loop is bound by the number of vector-memory
+  // instructions); the two simulations of a pair go through the same operations in the same order as a single run's
+  typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));
+  constexpr int HP = KB / 2;            // simulation pairs
+  constexpr int CPB = 256 / (8 * HP);   // cells per workgroup
+  __shared__ d2 nod[6][256];            // fields (ux, uy of u_n; ux, uy of u_nn; fx, fy) x [cell][node 8][pair]
+  __shared__ d2 gs[2][256];
   __shared__ double tph[FC_NQ * 6], tdx[FC_NQ * 6], tde[FC_NQ * 6];
   const int t = threadIdx.x;
-  const int s = t % KB, lane = (t / KB) % 8, cw = t / (8 * KB);
+  const int sp = t % HP, lane = (t / HP) % 8, cw = t / (8 * HP);
+  const int s = 2 * sp;
   const int cl = blockIdx.x * CPB + cw;
   const bool active = cl < nc;
   const int c = active ? cl : 0;
@@ -270,19 +275,19 @@ __global__ __launch_bounds__(256) void fc_rhs_elem_b(int nc, int nn, const int* 
   {
     const int a = lane < 6 ? lane : 0;
     const int ix = cnp[a * nc + c], iy = cnp[(6 + a) * nc + c];
-    double fx = 0.0, fy = 0.0;
+    d2 fx = {0.0, 0.0}, fy = {0.0, 0.0};
     if (n_act > 0) {
       const int n = cn[a * nc + c];
       for (int k = 0; k < n_act; ++k) {
-        const double uk = uforce[s * ustride + k];
+        const d2 uk = {uforce[s * ustride + k], uforce[(s + 1) * ustride + k]};
         fx += uk * fprof[(size_t)k * 2 * nn + n];
         fy += uk * fprof[(size_t)k * 2 * nn + nn + n];
       }
     }
-    nod[0][t] = un[(size_t)ix * KB + s];
-    nod[1][t] = un[(size_t)iy * KB + s];
-    nod[2][t] = unn[(size_t)ix * KB + s];
-    nod[3][t] = unn[(size_t)iy * KB + s];
+    nod[0][t] = *reinterpret_cast<const d2*>(un + (size_t)ix * KB + s);
+    nod[1][t] = *reinterpret_cast<const d2*>(un + (size_t)iy * KB + s);
+    nod[2][t] = *reinterpret_cast<const d2*>(unn + (size_t)ix * KB + s);
+    nod[3][t] = *reinterpret_cast<const d2*>(unn + (size_t)iy * KB + s);
     nod[4][t] = fx;
     nod[5][t] = fy;
   }
@@ -290,13 +295,14 @@ __global__ __launch_bounds__(256) void fc_rhs_elem_b(int nc, int nn, const int* 
   const double j00 = geom[c], j01 = geom[nc + c], j10 = geom[2 * nc + c], j11 = geom[3 * nc + c];
   const double wq = lane < FC_NQ ? c_qw[q] * 0.5 * geom[4 * nc + c] : 0.0;
   __syncthreads();
-  double ux = 0, uy = 0, uxi = 0, uet = 0, vxi = 0, vet = 0;
-  double wx = 0, wy = 0, wxi = 0, wet = 0, zxi = 0, zet = 0;
-  double gx = 0, gy = 0;
-  const int nb = cw * 8 * KB + s;
+  const d2 z = {0.0, 0.0};
+  d2 ux = z, uy = z, uxi = z, uet = z, vxi = z, vet = z;
+  d2 wx = z, wy = z, wxi = z, wet = z, zxi = z, zet = z;
+  d2 gx = z, gy = z;
+  const int nb = cw * 8 * HP + sp;
 #pragma unroll
   for (int a = 0; a < 6; ++a) {
-    const double ax = nod[0][nb + a * KB], ay = nod[1][nb + a * KB], bx = nod[2][nb + a * KB], by = nod[3][nb + a * KB];
+    const d2 ax = nod[0][nb + a * HP], ay = nod[1][nb + a * HP], bx = nod[2][nb + a * HP], by = nod[3][nb + a * HP];
     const double ph = tph[q * 6 + a], dx = tdx[q * 6 + a], de = tde[q * 6 + a];
     ux += ph * ax;
     uy += ph * ay;
@@ -310,28 +316,28 @@ __global__ __launch_bounds__(256) void fc_rhs_elem_b(int nc, int nn, const int* 
     wet += de * bx;
     zxi += dx * by;
     zet += de * by;
-    gx += ph * nod[4][nb + a * KB];
-    gy += ph * nod[5][nb + a * KB];
+    gx += ph * nod[4][nb + a * HP];
+    gy += ph * nod[5][nb + a * HP];
   }
-  const double ux_x = uxi * j00 + uet * j10, ux_y = uxi * j01 + uet * j11;
-  const double uy_x = vxi * j00 + vet * j10, uy_y = vxi * j01 + vet * j11;
-  const double wx_x = wxi * j00 + wet * j10, wx_y = wxi * j01 + wet * j11;
-  const double wy_x = zxi * j00 + zet * j10, wy_y = zxi * j01 + zet * j11;
+  const d2 ux_x = uxi * j00 + uet * j10, ux_y = uxi * j01 + uet * j11;
+  const d2 uy_x = vxi * j00 + vet * j10, uy_y = vxi * j01 + vet * j11;
+  const d2 wx_x = wxi * j00 + wet * j10, wx_y = wxi * j01 + wet * j11;
+  const d2 wy_x = zxi * j00 + zet * j10, wy_y = zxi * j01 + zet * j11;
   gx += cm_n * ux + cm_nn * wx + cc_n * (ux * ux_x + uy * ux_y) + cc_nn * (wx * wx_x + wy * wx_y);
   gy += cm_n * uy + cm_nn * wy + cc_n * (ux * uy_x + uy * uy_y) + cc_nn * (wx * wy_x + wy * wy_y);
   gs[0][t] = gx * wq;
   gs[1][t] = gy * wq;
   __syncthreads();
   if (active && lane < 6) {
-    double accx = 0.0, accy = 0.0;
+    d2 accx = z, accy = z;
 #pragma unroll
     for (int p = 0; p < FC_NQ; ++p) {
       const double pa = tph[p * 6 + lane];
-      accx += pa * gs[0][nb + p * KB];
-      accy += pa * gs[1][nb + p * KB];
+      accx += pa * gs[0][nb + p * HP];
+      accy += pa * gs[1][nb + p * HP];
     }
-    ev[((size_t)lane * nc + c) * KB + s] = accx;
-    ev[((size_t)(6 + lane) * nc + c) * KB + s] = accy;
+    *reinterpret_cast<d2*>(ev + ((size_t)lane * nc + c) * KB + s) = accx;
+    *reinterpret_cast<d2*>(ev + ((size_t)(6 + lane) * nc + c) * KB + s) = accy;
   }
 }
 

@@ -4685,7 +4685,7 @@ static int batch_launches(fc_ctx* h, int order_slot, int compute_energy, bool le
   const double* uc = h->pin_dev;
   const double* uf = h->pin_dev + 32;
   const double* seqp = h->pin_dev + kSeqSlot + par;
-  const int g_elem = nblocks(nc, 256 / (8 * KB)), g_rows = nblocks((int64_t)N * (KB / 2), 256);
+  const int g_elem = nblocks(nc, 256 / (8 * (KB / 2))), g_rows = nblocks((int64_t)N * (KB / 2), 256);  // (element loop: thread = (cell, lane8, simulation pair))
   // the state ring: this step reads (u_n, u_nn) from slots cur, cur - 1 and writes its solution -- the new state -- into the x
   // half of slot cur + 1 (= B.buf); the caller moves `cur` on afterwards
   const double* un = bat_n(h);
