@@ -2889,15 +2889,7 @@ int fc_get_local_cells(fc_handle h, int32_t* cells) {
 
 int fc_accept_factors(fc_handle h, int slot, double* residual_out, int32_t* inexact_out);
 
-// Binary bisections of the default tree: leaves of about 12 cells, i.e. log2(nc / 12) levels, taken to the NEAREST count the
-// fused levels allow (top + a multiple of merge).  Rounding up instead (rounds 1-2) gave the pinball (66 668 cells) and
-// cavity_coarse 16 384 leaves of 3-4 cells: two more launches of blocks too small to fill a workgroup, 7 % slower steps.
-// flowcontrol_amd/device.py::_default_depth is the same rule.
-static int default_depth(int nc, int merge, int top) {
-  const double levels = std::log2(std::max(nc, 1) / 12.0);
-  if (top > 0) return std::max(merge + top, (int)std::ceil(levels));  // partitioned handles: as before (build_tree rounds up)
-  return merge * std::max(1, (int)std::floor(levels / merge + 0.5));
-}
+// (shape of the default elimination tree: fcsym::default_bits, mirrored by flowcontrol_amd/ndsolver.py::default_bits)
 
 int fc_setup_solver(fc_handle h, int slot, int32_t depth, int32_t merge, int32_t truncate, int32_t refine, int32_t check_residual) {
   if (!h || slot < 0 || slot > 1 || merge < 1 || merge > 4 || depth < 0 || truncate < 0 || refine < 0)
@@ -2920,11 +2912,10 @@ int fc_setup_solver(fc_handle h, int slot, int32_t depth, int32_t merge, int32_t
       keep = [truncate](int k, int) { return k >= truncate; };
     }
     if (!h->sym_ready) {
-      int d = depth;
-      if (d == 0) d = default_depth(h->nc, merge, top);
+      const std::vector<int> bits = depth == 0 ? fcsym::default_bits(h->nc, merge, top) : fcsym::uniform_bits(depth, merge, top);
       std::vector<unsigned char> skip((size_t)N, 0);
       for (int k = 0; k < h->n_bc; ++k) skip[(size_t)h->h_bc_dofs[k]] = 1;
-      h->sym_tree = fcsym::build_tree(h->h_cell_dofs, 15, h->h_cent, h->nc, N, d, &skip, merge, top);
+      h->sym_tree = fcsym::build_tree(h->h_cell_dofs, 15, h->h_cent, h->nc, N, bits, &skip, top);
       if (truncate > h->sym_tree.depth) return fail(FC_ERR_INVALID, "fc_setup_solver: truncate exceeds the tree depth");
       FCCHK(fc_set_permutation(h, h->sym_tree.perm.data()));
       FCCHK(upload_energy_matrix(h));
@@ -3138,8 +3129,7 @@ int fc_sym_build(int32_t nv, int32_t ne, int32_t nc, const double* coords, const
     for (int k = 0; k < n_bc; ++k) skip[(size_t)bc_dofs[k]] = 1;
     int top = 0;
     while ((1 << top) < world) ++top;
-    int d = depth;
-    if (d == 0) d = default_depth(nc, merge, top);
+    const std::vector<int> bits = depth == 0 ? fcsym::default_bits(nc, merge, top) : fcsym::uniform_bits(depth, merge, top);
     const bool timing = getenv("FC_SYM_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto lap = [&](const char* what, std::chrono::steady_clock::time_point& t0) {
@@ -3147,7 +3137,7 @@ int fc_sym_build(int32_t nv, int32_t ne, int32_t nc, const double* coords, const
       t0 = now();
     };
     auto t0 = now();
-    fcsym::Tree t = fcsym::build_tree(cd, 15, cent, nc, N, d, &skip, merge, top);
+    fcsym::Tree t = fcsym::build_tree(cd, 15, cent, nc, N, bits, &skip, top);
     lap("build_tree", t0);
     fcsym::Keep keep;
     if (world > 1) keep = [&t, rank, top](int k, int n) { return k == 0 || (n >> (t.cum[k] - top)) == rank; };

@@ -4,6 +4,7 @@
 // mesh the handle already holds, so a caller of the C ABI needs no Python.  flowcontrol_amd/ndsolver.py is the
 // readable specification of every routine here and the tests compare the two (tests/test_symbolic_cabi.py).
 #pragma once
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -104,10 +105,8 @@ inline std::vector<int> bisect_cells(const std::vector<double>& cent /* [nc][2] 
   return leaf;
 }
 
-// element-based nested dissection (ndsolver.build_tree)
-inline Tree build_tree(const std::vector<int>& cell_dofs, int nl, const std::vector<double>& cent, int nc, int N, int depth,
-                       const std::vector<unsigned char>* skip, int merge, int top_bits) {
-  Tree t;
+// bisections fused per tree level, root first (ndsolver.uniform_bits / default_bits)
+inline std::vector<int> uniform_bits(int depth, int merge, int top_bits) {
   std::vector<int> bits;
   if (top_bits > 0) bits.push_back(top_bits);
   int sum = top_bits > 0 ? top_bits : 0;
@@ -115,6 +114,51 @@ inline Tree build_tree(const std::vector<int>& cell_dofs, int nl, const std::vec
     bits.push_back(merge);
     sum += merge;
   }
+  return bits;
+}
+// The default tree: leaves of about 12 cells, i.e. log2(nc / 12) bisections, taken to the NEAREST count the fused levels allow (rounding
+// up instead gave the pinball and cavity_coarse 16 384 leaves of 3-4 cells: two more launches of blocks too small to fill a workgroup).
+// Small meshes (single GPU, <= 20 000 cells: factors that stay in the Infinity Cache, every sweep launch on its ~3.5 us floor) fuse one
+// bisection more into each of the two top levels: O1 [3,3,2,2] instead of [2,2,2,2,2] is 9 launches and 236 MB instead of 11 and 212 MB
+// per apply = 74.9 instead of 77.5 us, + 3.8 % steps/s (launches x 3.5 us + bytes / 5.4 TB/s reproduces both; the other shapes of ten
+// bisections measure worse, profiles/EXPERIMENTS.md).  Where the factors stream from HBM the extra fill costs far more than two launches.
+inline std::vector<int> default_bits(int nc, int merge, int top_bits) {
+  if (const char* e = std::getenv("FC_ND_SHAPE"); e && top_bits == 0) {  // tuning aid: e.g. "2,2,3,3"
+    std::vector<int> bits;
+    for (const char* q = e; *q;) {
+      const int b = std::atoi(q);
+      if (b > 0) bits.push_back(b);
+      while (*q && *q != ',') ++q;
+      if (*q == ',') ++q;
+    }
+    if (!bits.empty()) return bits;
+  }
+  const double levels = std::log2(std::max(nc, 1) / 12.0);
+  if (top_bits > 0) return uniform_bits(std::max(merge + top_bits, (int)std::ceil(levels)), merge, top_bits);  // partitioned handles: rounded up, as ever
+  const int d = merge * std::max(1, (int)std::floor(levels / merge + 0.5));
+  if (merge == 2 && nc <= 20000 && d >= 8) {
+    std::vector<int> bits = {3, 3};
+    for (int sum = 6; sum < d; sum += 2) bits.push_back(2);
+    return bits;
+  }
+  return uniform_bits(d, merge, 0);
+}
+
+inline Tree build_tree(const std::vector<int>& cell_dofs, int nl, const std::vector<double>& cent, int nc, int N, const std::vector<int>& bits,
+                       const std::vector<unsigned char>* skip, int top_bits);
+// ... with `depth` bisections fused `merge` at a time below a 2^top_bits-ary root
+inline Tree build_tree(const std::vector<int>& cell_dofs, int nl, const std::vector<double>& cent, int nc, int N, int depth,
+                       const std::vector<unsigned char>* skip, int merge, int top_bits) {
+  return build_tree(cell_dofs, nl, cent, nc, N, uniform_bits(depth, merge, top_bits), skip, top_bits);
+}
+
+// element-based nested dissection (ndsolver.build_tree); `bits`: bisections fused per tree level, root first (top_bits > 0: bits[0] is the
+// 2^top_bits-ary rank partition of a multi-GPU tree)
+inline Tree build_tree(const std::vector<int>& cell_dofs, int nl, const std::vector<double>& cent, int nc, int N, const std::vector<int>& bits,
+                       const std::vector<unsigned char>* skip, int top_bits) {
+  Tree t;
+  int sum = 0;
+  for (int b : bits) sum += b;
   t.depth_bin = sum;
   t.cum.assign(1, 0);
   for (int b : bits) t.cum.push_back(t.cum.back() + b);

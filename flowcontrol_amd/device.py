@@ -30,12 +30,8 @@ def _i32(a) -> np.ndarray:
 logger = logging.getLogger(__name__)
 
 def _default_depth(nc: int, merge: int, top: int) -> int:
-    """Binary bisections of the default elimination tree: leaves of about 12 cells, to the nearest count the fused levels allow
-    (``csrc/fc_hip.hip::default_depth`` is the same rule)."""
-    levels = float(np.log2(max(nc, 1) / 12.0))
-    if top > 0:  # partitioned handles: as before (build_tree rounds up)
-        return max(merge + top, int(np.ceil(levels)))
-    return merge * max(1, int(np.floor(levels / merge + 0.5)))
+    """Binary bisections of the default elimination tree (``ndsolver.default_bits`` has the shape)."""
+    return int(sum(ndsolver.default_bits(nc, merge, top)))
 
 
 class DeviceSolver:
@@ -282,12 +278,11 @@ class DeviceSolver:
         if self._tree is None:
             th = self.th
             top = int(np.log2(self.world)) if self.world > 1 else 0
-            if depth is None:
-                depth = _default_depth(th.nc, merge, top)
+            bits = ndsolver.default_bits(th.nc, merge, top) if not depth else ndsolver.uniform_bits(depth, merge, top)
             skip = np.zeros(self.N, dtype=bool)
             skip[self.bc_dofs] = True
             self._skip = skip
-            self._tree = ndsolver.build_tree(th.cell_dofs, th.mesh.cell_centroids(), self.N, depth, skip, merge=merge, top_bits=top)
+            self._tree = ndsolver.build_tree(th.cell_dofs, th.mesh.cell_centroids(), self.N, sum(bits), skip, top_bits=top, bits=bits)
             self.perm = self._tree.perm
             self.depth = self._tree.depth
             check(self.lib.fc_set_permutation(self._h, _i32(self.perm)))
@@ -415,11 +410,10 @@ class DeviceSolver:
         if self._tree is None and self.perm is not None:
             depth, merge = self._tree_args
             top = int(np.log2(self.world)) if self.world > 1 else 0
-            if depth == 0:
-                depth = _default_depth(self.th.nc, merge, top)
+            bits = ndsolver.default_bits(self.th.nc, merge, top) if depth == 0 else ndsolver.uniform_bits(depth, merge, top)
             skip = np.zeros(self.N, dtype=bool)
             skip[self.bc_dofs] = True
-            self._tree = ndsolver.build_tree(self.th.cell_dofs, self.th.mesh.cell_centroids(), self.N, depth, skip, merge=merge, top_bits=top)
+            self._tree = ndsolver.build_tree(self.th.cell_dofs, self.th.mesh.cell_centroids(), self.N, sum(bits), skip, top_bits=top, bits=bits)
             assert np.array_equal(self._tree.perm, self.perm)
         return self._tree
 

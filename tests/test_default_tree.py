@@ -1,6 +1,7 @@
 """Default shape of the elimination tree (``fc_setup_solver`` with depth 0): leaves of about 12 cells, to the NEAREST level the
-fused levels allow on single-GPU handles.  The library rule (``csrc/fc_hip.hip::default_depth``, reached through ``fc_sym_build``)
-and the Python one (``device._default_depth``, which rebuilds the tree for the host-side helpers) must agree."""
+fused levels allow on single-GPU handles; small meshes (factors that stay in the Infinity Cache) fuse one bisection more into each of
+the two top levels.  The library rule (``csrc/fc_symbolic.hpp::default_bits``, reached through ``fc_sym_build``) and the Python one
+(``ndsolver.default_bits``, which rebuilds the tree for the host-side helpers) must agree."""
 import numpy as np
 import pytest
 
@@ -15,8 +16,12 @@ def test_default_depth_rule():
     # cells -> bisections (merge 2): O1, O1 refined, pinball, cavity_coarse, cavity_fine, lid cavity 64 x 64
     for nc, want in ((12284, 10), (49136, 12), (66668, 12), (51883, 12), (193916, 14), (8192, 10)):
         assert _default_depth(nc, 2, 0) == want
-    # partitioned handles keep the rule of rounds 1-2 (build_tree rounds up to top + a multiple of merge)
-    assert _default_depth(49136, 2, 3) == 12 and _default_depth(12284, 2, 1) == 10
+    # ... and how they are fused into tree levels, root first: the small meshes (launch-bound sweeps) get two 8-ary top levels
+    assert ndsolver.default_bits(12284, 2, 0) == [3, 3, 2, 2] and ndsolver.default_bits(8192, 2, 0) == [3, 3, 2, 2]
+    assert ndsolver.default_bits(49136, 2, 0) == [2] * 6 and ndsolver.default_bits(193916, 2, 0) == [2] * 7
+    assert ndsolver.default_bits(288, 2, 0) == [2, 2]  # (too shallow for the rule)
+    # partitioned handles keep the rule of rounds 1-2: world-ary root, then merge-ary levels, rounded up
+    assert ndsolver.default_bits(49136, 2, 3) == [3, 2, 2, 2, 2, 2] and ndsolver.default_bits(12284, 2, 1) == [1, 2, 2, 2, 2, 2]
 
 
 @pytest.mark.parametrize("mesh", ["O1", "mesh_middle_gmsh"])
@@ -27,7 +32,8 @@ def test_library_default_tree_is_the_python_default_tree(mesh, golden_dir):
     dofs = _bc(th)
     skip = np.zeros(th.N, bool)
     skip[dofs] = True
-    tree = ndsolver.build_tree(th.cell_dofs, th.mesh.cell_centroids(), th.N, _default_depth(th.nc, 2, 0), skip, merge=2, top_bits=0)
+    bits = ndsolver.default_bits(th.nc, 2, 0)
+    tree = ndsolver.build_tree(th.cell_dofs, th.mesh.cell_centroids(), th.N, sum(bits), skip, bits=bits)
     get, free = _tables(th, dofs, 0, 2, 1, 0, 0)
     try:
         assert np.array_equal(get("perm"), tree.perm)
