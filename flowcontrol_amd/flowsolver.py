@@ -484,19 +484,21 @@ class FlowSolver(ABC):
         return self._find_restart_from_params(Tstart)
 
     def _find_restart_from_json(self, Tstart: float):
-        path_out = Path(self.params_save.path_out)
-        for json_path in sorted(path_out.glob("meta_restart*.json")):
-            meta = json.loads(json_path.read_text())
-            T0 = meta["Tstart"]
-            step = meta["dt"] * meta["save_every"]
-            n = meta["checkpoints_written"]
-            if n == 0:
+        """The run whose checkpoints cover ``Tstart``, from the ``meta_restart*.json`` sidecars an earlier run left in ``path_out``
+        (reference flowsolver.py:564-577): (its metadata, index of the checkpoint written at Tstart, the directory) or None."""
+        out_dir = Path(self.params_save.path_out)
+        tol = 1e-10
+        for sidecar in sorted(out_dir.glob("meta_restart*.json")):
+            meta = json.loads(sidecar.read_text())
+            written = int(meta["checkpoints_written"])
+            if written == 0:
                 continue
-            Tend = T0 + step * n
-            if T0 - 1e-10 <= Tstart <= Tend + 1e-10:
-                counter = round((Tstart - T0) / step)
-                logger.info(f"Restart: found JSON sidecar {json_path.name}, counter={counter}")
-                return meta, counter, path_out
+            first, spacing = meta["Tstart"], meta["dt"] * meta["save_every"]
+            if not (first - tol <= Tstart <= first + spacing * written + tol):
+                continue
+            index = round((Tstart - first) / spacing)
+            logger.info("Restart: found JSON sidecar %s, counter=%d", sidecar.name, index)
+            return meta, index, out_dir
         return None
 
     def _find_restart_from_params(self, Tstart: float):
