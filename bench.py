@@ -533,10 +533,12 @@ def run_rank(comm, args, device):
             "bytes_per_launch": bytes_per_launch, "launches_per_step": tim["sweep_launches"] / args.steps,
             "mean_launch_us": mean_launch_ms * 1e3, "factor_nnz": dev.factor_nnz.get(SLOT_BDF2),
             "applies_per_step": applies / args.steps,
+            # bisections fused per level of the elimination tree, root first (the default shape of this mesh: ndsolver.default_bits; 2 x levels + 1 launches)
+            "tree_bits": __import__("flowcontrol_amd.ndsolver", fromlist=["default_bits"]).default_bits(fs.th.nc, 2, 0) if not REFINE else None,
             "spmv_in_step": ({"bytes": spmv_bytes, "mean_us": 1e3 * tim["spmv_ms"] / tim["spmv_launches"],
                               "GB/s": spmv_bytes / (tim["spmv_ms"] / tim["spmv_launches"]) / 1e6}
                              if tim["spmv_launches"] and tim["spmv_ms"] > 0 else
-                             "fused into fc_tail (residual monitor + state shift + energy, one launch)"),
+                             "fused into fc_tail (residual monitor + energy, one launch)"),
             "note": (f"factors ({sweep_bytes / 1e6:.0f} MB) are re-read every step and largely stay in the 256 MiB Infinity Cache"
                      if sweep_bytes < 256e6 else
                      f"factors ({sweep_bytes / 1e6:.0f} MB) exceed the 256 MiB Infinity Cache: HBM streaming"),
