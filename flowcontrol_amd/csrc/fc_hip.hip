@@ -359,6 +359,7 @@ struct fc_ctx {
     int kind;  // 0: fc_nd_block_b over tasks [first, first + count) with cg column-group waves per row tile; 1: fc_nd_fold_b
     int first, count, cg;
     int row0, nrows, dst_off, accumulate;
+    double mean_chunks = 0.0;  // block launches: 32-column chunks per tile row, weighted by the values behind them (cg is chosen from it per batch width)
   };
   struct Batch {
     int k = 0, KB = 0;
@@ -4411,6 +4412,7 @@ static int build_batch_tables(fc_ctx* h) {
       }
     }
     B.launches.push_back({0, first, (int)tasks.size() - first, cg, 0, 0, 0, 0});
+    B.launches.back().mean_chunks = mean_chunks;
   };
   for (int k = t.depth; k >= 1; --k) {
     emit(k, true);
@@ -4469,8 +4471,18 @@ static int batch_apply(fc_ctx* h, int slot, bool check = false) {
   const double* tiled = B.ftile[slot].p;
   const bool nt = h->sys[slot].nt;
   FCCHK(time_begin(h, 0, (int)B.launches.size()));
-  for (const fc_ctx::BLaunch& L : B.launches) {
+  // column-group waves per tile: about 1.5 chunks of 32 columns per wave, 3 at 32 simulations (two accumulators: a wave does twice the
+  // matrix work per chunk it loads; k = 32 109.7 -> 113.7 k simulated steps/s on O1, k = 16 unchanged or worse with more)
+  static const double cpw_env = [] { const char* e = std::getenv("FC_BATCH_CPW"); return e ? std::max(0.5, std::atof(e)) : 0.0; }();
+  static const int cg_env = [] { const char* e = std::getenv("FC_BATCH_CG"); return e ? std::atoi(e) : 0; }();
+  const double cpw = cpw_env > 0.0 ? cpw_env : (B.KB > 16 ? 3.0 : 1.5);
+  for (fc_ctx::BLaunch L : B.launches) {
     if (L.kind == 0) {
+      if (!(cg_env == 1 || cg_env == 2 || cg_env == 4 || cg_env == 8 || cg_env == 16)) {
+        int cg = 1;
+        while (cg < 16 && L.mean_chunks / cg > cpw) cg *= 2;
+        L.cg = cg;
+      }
       const FcBTask* tp = B.tasks.p + L.first;
 #define FC_BLK(K)                                                                                                                                              \
   do {                                                                                                                                                         \
