@@ -4234,7 +4234,9 @@ static int build_tail_blocks(fc_ctx* h, int KB) {
     const char* e = std::getenv("FC_TB_COLS");  // tuning aid
     bool streams = false;  // any slot whose factors stream from HBM: the batched step stays on one stream there (step_batch_begin)
     for (int o = 0; o < 2; ++o) streams = streams || (h->sys[o].structured && h->sys[o].nt);
-    const int v = e ? std::atoi(e) : ((h->overlap && !streams) ? 256 : FC_TB_COLS);
+    // (32 simulations, [3,3,2,2] tree of O1: 144 columns 118.2 k simulated steps/s, 128: 116.5 k, 224: 113.3 k, 112: 97.5 k -- the LDS a block
+    //  takes decides how many of them sit beside the main stream's workgroups)
+    const int v = e ? std::atoi(e) : ((h->overlap && !streams) ? (KB > 16 ? 144 : 256) : FC_TB_COLS);
     want = std::min(448 * 16 / std::max(16, KB), std::max(FC_TB_ROWS, v));  // (KB = 32: at most 224 columns)
   }
   if (B.tblocks.p && B.tb_cols == want && B.tb_built) return FC_OK;
