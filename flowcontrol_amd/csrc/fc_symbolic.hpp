@@ -123,15 +123,17 @@ inline std::vector<int> uniform_bits(int depth, int merge, int top_bits) {
 // per apply = 74.9 instead of 77.5 us, + 3.8 % steps/s (launches x 3.5 us + bytes / 5.4 TB/s reproduces both; the other shapes of ten
 // bisections measure worse, profiles/EXPERIMENTS.md).  Where the factors stream from HBM the extra fill costs far more than two launches.
 inline std::vector<int> default_bits(int nc, int merge, int top_bits) {
-  if (const char* e = std::getenv("FC_ND_SHAPE"); e && top_bits == 0) {  // tuning aid: e.g. "2,2,3,3"
+  if (const char* e = std::getenv("FC_ND_SHAPE")) {  // tuning aid: e.g. "2,2,3,3" (partitioned handles: the levels BELOW the 2^top_bits-ary rank level)
     std::vector<int> bits;
+    if (top_bits > 0) bits.push_back(top_bits);
+    const size_t fixed = bits.size();
     for (const char* q = e; *q;) {
       const int b = std::atoi(q);
       if (b > 0) bits.push_back(b);
       while (*q && *q != ',') ++q;
       if (*q == ',') ++q;
     }
-    if (!bits.empty()) return bits;
+    if (bits.size() > fixed) return bits;
   }
   const double levels = std::log2(std::max(nc, 1) / 12.0);
   if (top_bits > 0) return uniform_bits(std::max(merge + top_bits, (int)std::ceil(levels)), merge, top_bits);  // partitioned handles: rounded up, as ever
