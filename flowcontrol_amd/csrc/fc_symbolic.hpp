@@ -118,7 +118,7 @@ inline std::vector<int> uniform_bits(int depth, int merge, int top_bits) {
 }
 // The default tree: leaves of about 12 cells, i.e. log2(nc / 12) bisections, taken to the NEAREST count the fused levels allow (rounding
 // up instead gave the pinball and cavity_coarse 16 384 leaves of 3-4 cells: two more launches of blocks too small to fill a workgroup).
-// Small meshes (single GPU, <= 20 000 cells: factors that stay in the Infinity Cache, every sweep launch on its ~3.5 us floor) fuse one
+// Small meshes (single GPU, <= 16 000 cells: factors that stay in the Infinity Cache, every sweep launch on its ~3.5 us floor) fuse one
 // bisection more into each of the two top levels: O1 [3,3,2,2] instead of [2,2,2,2,2] is 9 launches and 236 MB instead of 11 and 212 MB
 // per apply = 74.9 instead of 77.5 us, + 3.8 % steps/s (launches x 3.5 us + bytes / 5.4 TB/s reproduces both; the other shapes of ten
 // bisections measure worse, profiles/EXPERIMENTS.md).  Where the factors stream from HBM the extra fill costs far more than two launches.
@@ -138,7 +138,7 @@ inline std::vector<int> default_bits(int nc, int merge, int top_bits) {
   const double levels = std::log2(std::max(nc, 1) / 12.0);
   if (top_bits > 0) return uniform_bits(std::max(merge + top_bits, (int)std::ceil(levels)), merge, top_bits);  // partitioned handles: rounded up, as ever
   const int d = merge * std::max(1, (int)std::floor(levels / merge + 0.5));
-  if (merge == 2 && nc <= 20000 && d >= 8) {
+  if (merge == 2 && nc <= 16000 && d >= 8) {
     std::vector<int> bits = {3, 3};
     for (int sum = 6; sum < d; sum += 2) bits.push_back(2);
     return bits;

@@ -84,7 +84,7 @@ def uniform_bits(depth: int, merge: int, top_bits: int = 0) -> list[int]:
 
 def default_bits(nc: int, merge: int = 2, top_bits: int = 0) -> list[int]:
     """Shape of the default elimination tree (``csrc/fc_symbolic.hpp::default_bits`` is the same rule): leaves of about 12 cells,
-    i.e. log2(nc / 12) bisections, to the nearest count the fused levels allow.  Small meshes on one GPU (≤ 20 000 cells: factors
+    i.e. log2(nc / 12) bisections, to the nearest count the fused levels allow.  Small meshes on one GPU (≤ 16 000 cells: factors
     that stay in the Infinity Cache, every sweep launch on its ≈ 3.5 µs floor) fuse one bisection more into each of the two top
     levels — O1: [3, 3, 2, 2] instead of [2, 2, 2, 2, 2], two launches fewer for 11 % more factor bytes, + 3.8 % steps/s."""
     import os
@@ -98,7 +98,7 @@ def default_bits(nc: int, merge: int = 2, top_bits: int = 0) -> list[int]:
     if top_bits > 0:  # partitioned handles: rounded up, as ever
         return uniform_bits(max(merge + top_bits, int(np.ceil(levels))), merge, top_bits)
     d = merge * max(1, int(np.floor(levels / merge + 0.5)))
-    if merge == 2 and nc <= 20000 and d >= 8:
+    if merge == 2 and nc <= 16000 and d >= 8:
         return [3, 3] + [2] * ((d - 6) // 2)
     return uniform_bits(d, merge, 0)
 
