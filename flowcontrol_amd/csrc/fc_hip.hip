@@ -25,7 +25,9 @@
 #include "fc_kernels.hip.h"
 #include "fc_front.hip.h"
 #include "fc_batch.hip.h"
+#include "fc_precond.hip.h"
 #include "fc_symbolic.hpp"
+#include "fc_precond.hpp"
 
 namespace {
 
@@ -54,6 +56,18 @@ template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr, o.n = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) {
+      release();
+      p = o.p, n = o.n;
+      o.p = nullptr, o.n = 0;
+    }
+    return *this;
+  }
   int alloc(size_t count) {
     release();
     n = count;
@@ -92,8 +106,66 @@ struct Stage {
   bool nt = false;  // its values are streamed with nontemporal loads (OrderSys::nt, minus the stages kept cache-resident)
 };
 
+// Device copy of the factorisation-free preconditioner of a slot (fc_setup_krylov; fc_precond.hpp / fc_precond.hip.h): the blocks of the
+// saddle-point operator in compact velocity / pressure numberings and the AMG hierarchy of the pressure Schur complement.
+struct PcMat {
+  DevBuf<int> rp, ci;
+  DevBuf<double> v;
+  int nrows = 0, lanes = 8;
+  int64_t nnz = 0;
+  int upload(const fcpc::Csr& M, hipStream_t s) {
+    nrows = M.nrows;
+    nnz = M.nnz();
+    const double mean = nrows ? (double)nnz / nrows : 0.0;
+    lanes = mean <= 6 ? 4 : (mean <= 40 ? 8 : (mean <= 96 ? 16 : 32));
+    FCCHK(rp.upload(M.rp, s));
+    if (nnz == 0) {
+      FCCHK(ci.alloc(1));
+      FCCHK(v.alloc(1));
+      return FC_OK;
+    }
+    FCCHK(ci.upload(M.ci, s));
+    FCCHK(v.upload(M.v, s));
+    return FC_OK;
+  }
+  int64_t bytes() const { return 12 * nnz + 4 * ((int64_t)nrows + 1); }
+};
+struct PcLevel {
+  PcMat A, P, R;
+  DevBuf<double> wdinv, x, r, t;
+  int n = 0;
+};
+struct Precond {
+  bool ready = false;
+  int sweeps = 3;       // damped-Jacobi sweeps on the velocity block
+  double omega = 1.0;   // their damping
+  int nu = 0, np = 0;
+  DevBuf<int> vpos, ppos;  // compact velocity / pressure index -> position in the permuted Krylov vector
+  PcMat F, B, Bt;
+  DevBuf<double> dinvF, wdinvF;  // 1 / diag(F), omega / diag(F)
+  DevBuf<double> u0, u1, rp;     // velocity ping-pong, Schur right-hand side
+  std::vector<PcLevel> lv;
+  int n_coarse = 0;
+  DevBuf<double> cinv, xc, rc;   // dense inverse of the coarsest operator and its vectors
+  int64_t bytes = 0;             // device bytes held by the preconditioner
+  int launches = 0;              // kernel launches per apply
+  void release() {
+    ready = false;
+    for (PcMat* M : {&F, &B, &Bt}) M->rp.release(), M->ci.release(), M->v.release();
+    vpos.release(), ppos.release(), dinvF.release(), wdinvF.release(), u0.release(), u1.release(), rp.release();
+    lv.clear();
+    cinv.release(), xc.release(), rc.release();
+    bytes = 0;
+  }
+  double setup_ms = 0.0;
+  std::vector<int> level_rows;
+};
+
 struct OrderSys {
   bool have_lift = false, ready = false;
+  bool factor_free = false;  // no factors: the slot's Krylov solves are preconditioned by `pc` (fc_setup_krylov)
+  Precond pc;
+  DevBuf<int64_t> ap_src;    // factor-free slots: permuted CSR entry -> entry of the handle's CSR (fc_update_operator)
   bool structured = false;  // segment lists / stage table uploaded (fc_solver_setup); values may be stale
   DevBuf<double> lift;    // [n_act][N] original numbering
   DevBuf<double> lift_p;  // [n_act][N] permuted
@@ -207,6 +279,7 @@ struct fc_ctx {
   DevBuf<double> ks;   // device-resident scalars of the Krylov recurrences (KS_* in fc_kernels.hip.h)
   DevBuf<double> gm, mdot;  // GMRES: Hessenberg / rotations / small vectors; multi-dot partials
   int gmres_m = 30;    // restart length
+  bool pc_warm_start = true;  // factor-free slots: GMRES inside a time step starts from the previous solution (FC_PC_WARM_START=0: from zero)
   int last_krylov_iters = 0;
   double rtol = 1e-10;
   // state + work
@@ -598,6 +671,62 @@ int launch_spmv(fc_ctx* h, int nrows, double mean, const int* rp, const int* col
   FCCHK(time_end(h));
   HIPCHK(hipGetLastError());
   return grid.x;
+}
+
+// one instance of the fused CSR kernel of the factorisation-free preconditioner (fc_precond.hip.h):
+// out[opos(i)] = base[i] + scale * dinv[i] * (rhs[rpos(i)] - (M x)[i])
+int pc_launch(fc_ctx* h, const PcMat* M, int n, const double* x, const double* rhs, const int* rpos, const double* dinv, const double* base,
+              double scale, double* out, const int* opos) {
+  if (n <= 0) return FC_OK;
+  const FcPcArgs a{n, M ? M->rp.p : nullptr, M ? M->ci.p : nullptr, M ? M->v.p : nullptr, x, rhs, rpos, dinv, base, scale, out, opos};
+  const int lanes = M ? M->lanes : 1;
+  const dim3 grid(nblocks(n, 256 / lanes)), block(256);
+  switch (lanes) {
+    case 1: hipLaunchKernelGGL(fc_pc_csr<1>, grid, block, 0, h->stream, a); break;
+    case 4: hipLaunchKernelGGL(fc_pc_csr<4>, grid, block, 0, h->stream, a); break;
+    case 8: hipLaunchKernelGGL(fc_pc_csr<8>, grid, block, 0, h->stream, a); break;
+    case 16: hipLaunchKernelGGL(fc_pc_csr<16>, grid, block, 0, h->stream, a); break;
+    default: hipLaunchKernelGGL(fc_pc_csr<32>, grid, block, 0, h->stream, a); break;
+  }
+  return FC_OK;
+}
+
+// out = M^-1 in with the factorisation-free preconditioner of the slot (fc_setup_krylov), both in the permuted numbering:
+//   u  = k damped-Jacobi sweeps on F u = in_u                    (velocity block: mass dominated)
+//   zp = AMG V(1,1)-cycle on S zp = B u - in_p, S = B diag(F)^-1 Bt  (pressure Schur complement: Poisson-like)
+//   zu = u - diag(F)^-1 Bt zp
+// sweeps + 4 + 5 (AMG levels) launches; `in` is only read, `out` only written (they may not alias).
+int apply_pc(fc_ctx* h, OrderSys& S, const double* in, double* out) {
+  Precond& P = S.pc;
+  if (!P.ready) return fail(FC_ERR_NOT_READY, "fc_setup_krylov not called for this slot");
+  double *u = P.u0.p, *un = P.u1.p;
+  const double* wd = P.sweeps > 1 ? P.wdinvF.p : P.dinvF.p;
+  FCCHK(pc_launch(h, nullptr, P.nu, nullptr, in, P.vpos.p, wd, nullptr, 1.0, u, nullptr));
+  for (int k = 1; k < P.sweeps; ++k) {
+    FCCHK(pc_launch(h, &P.F, P.nu, u, in, P.vpos.p, P.wdinvF.p, u, 1.0, un, nullptr));
+    std::swap(u, un);
+  }
+  const int L = (int)P.lv.size();
+  FCCHK(pc_launch(h, &P.B, P.np, u, in, P.ppos.p, nullptr, nullptr, -1.0, L ? P.lv[0].r.p : P.rc.p, nullptr));
+  for (int l = 0; l < L; ++l) {
+    PcLevel& V = P.lv[(size_t)l];
+    FCCHK(pc_launch(h, nullptr, V.n, nullptr, V.r.p, nullptr, V.wdinv.p, nullptr, 1.0, V.x.p, nullptr));    // x = w D^-1 r
+    FCCHK(pc_launch(h, &V.A, V.n, V.x.p, V.r.p, nullptr, nullptr, nullptr, 1.0, V.t.p, nullptr));              // t = r - A x
+    const int nnext = l + 1 < L ? P.lv[(size_t)l + 1].n : P.n_coarse;
+    FCCHK(pc_launch(h, &V.R, nnext, V.t.p, nullptr, nullptr, nullptr, nullptr, -1.0, l + 1 < L ? P.lv[(size_t)l + 1].r.p : P.rc.p, nullptr));
+  }
+  hipLaunchKernelGGL(fc_pc_dense, dim3(nblocks(P.n_coarse, 4)), dim3(256), 0, h->stream, P.n_coarse, P.cinv.p, P.rc.p, P.xc.p);
+  const double* zc = P.xc.p;
+  for (int l = L - 1; l >= 0; --l) {
+    PcLevel& V = P.lv[(size_t)l];
+    FCCHK(pc_launch(h, &V.P, V.n, zc, nullptr, nullptr, nullptr, V.x.p, -1.0, V.x.p, nullptr));               // x += P x_c (in place)
+    FCCHK(pc_launch(h, &V.A, V.n, V.x.p, V.r.p, nullptr, V.wdinv.p, V.x.p, 1.0, V.t.p, nullptr));              // t = x + w D^-1 (r - A x)
+    zc = V.t.p;
+  }
+  FCCHK(pc_launch(h, &P.Bt, P.nu, zc, nullptr, nullptr, P.dinvF.p, u, 1.0, out, P.vpos.p));
+  FCCHK(pc_launch(h, nullptr, P.np, nullptr, zc, nullptr, nullptr, nullptr, 1.0, out, P.ppos.p));
+  HIPCHK(hipGetLastError());
+  return FC_OK;
 }
 
 int launch_sweep(fc_ctx* h, const OrderSys& S, const Stage& st) {
@@ -1283,6 +1412,7 @@ int bicgstab_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
     hipLaunchKernelGGL(fc_lin3_dev, dim3(g), dim3(256), 0, h->stream, N, out, ks + KS_COEF + 3 * coef, v0, v1, v2, ks);
   };
   auto precond = [&](const double* in, double* out) -> int {  // out = M^-1 in
+    if (S.factor_free) return apply_pc(h, S, in, out);
     hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, in, h->buf.p);
     if (dist) hipLaunchKernelGGL(fc_mask_rows, dim3(g), dim3(256), 0, h->stream, N, kinds, lead, h->buf.p);  // root rows: summed by the apply
     FCCHK(apply_factors(h, S));
@@ -1371,7 +1501,7 @@ int bicgstab_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
 // one re-orthogonalisation (two multi-dot launches per Arnoldi step instead of j sequential dots), Givens rotations and
 // the back substitution in a one-thread kernel, everything on the device; the host reads the state word once per
 // kKrylovCheck Arnoldi steps.  b_p in h->b on entry, x_p in kry[0..N) on exit.
-int gmres_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
+int gmres_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres, const double* x0 = nullptr) {
   const int N = h->N, g = nblocks(N, 256), gd = std::min(g, 256);
   const int m = std::max(1, std::min(h->gmres_m, h->max_iter));
   const size_t need = (size_t)(m + 4) * N;
@@ -1398,6 +1528,7 @@ int gmres_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
   const unsigned char* kinds = dist ? h->rowkind_p.p : nullptr;
   const int lead = h->lead ? 1 : 0;
   auto precond = [&](const double* in, double* out) -> int {
+    if (S.factor_free) return apply_pc(h, S, in, out);
     hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, in, h->buf.p);
     if (dist) hipLaunchKernelGGL(fc_mask_rows, dim3(g), dim3(256), 0, h->stream, N, kinds, lead, h->buf.p);  // root rows: summed by the apply
     FCCHK(apply_factors(h, S));
@@ -1443,8 +1574,14 @@ int gmres_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
   };
   HIPCHK(hipMemsetAsync(ks, 0, KS_SIZE * sizeof(double), h->stream));
   HIPCHK(hipMemsetAsync(gm, 0, gm_n * sizeof(double), h->stream));
-  HIPCHK(hipMemsetAsync(x, 0, (size_t)N * sizeof(double), h->stream));
-  hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, r);
+  if (x0) {  // warm start (time steps of a factor-free slot: the previous solution): r = b - A x0
+    hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, x0, x);
+    FCCHK(matvec(x, w));
+    hipLaunchKernelGGL(fc_lin3, dim3(g), dim3(256), 0, h->stream, N, r, 1.0, h->b.p, -1.0, w, 0.0, (const double*)nullptr);
+  } else {
+    HIPCHK(hipMemsetAsync(x, 0, (size_t)N * sizeof(double), h->stream));
+    hipLaunchKernelGGL(fc_copy, dim3(g), dim3(256), 0, h->stream, N, h->b.p, r);
+  }
   FCCHK(begin_cycle(1));
   double kh[KS_SIZE];
   *iters = 0;
@@ -1558,6 +1695,8 @@ int enqueue_step_launches(fc_ctx* h, int order_slot, const double* d_uctrl, doub
   if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this order");
   if (S.truncated && h->method == FC_METHOD_REFINE)
     return fail(FC_ERR_INVALID, "truncated factors are a preconditioner: set FC_METHOD_GMRES or FC_METHOD_BICGSTAB");
+  if (S.factor_free && h->method == FC_METHOD_REFINE)
+    return fail(FC_ERR_INVALID, "this slot has no factors (fc_setup_krylov): set FC_METHOD_GMRES or FC_METHOD_BICGSTAB");
   if (compute_energy && !h->partitioned && !h->have_mp) return fail(FC_ERR_NOT_READY, "fc_set_energy_matrix not called");
   FCCHK(phase_mark(h, -1));
   FCCHK(enqueue_rhs(h, order_slot, d_uctrl, d_uforce));
@@ -1577,7 +1716,9 @@ int enqueue_step_launches(fc_ctx* h, int order_slot, const double* d_uctrl, doub
     }
     int iters = 0;
     double relres = 0.0;
-    FCCHK(h->method == FC_METHOD_GMRES ? gmres_permuted(h, S, &iters, &relres) : bicgstab_permuted(h, S, &iters, &relres));
+    // factor-free slots start GMRES from the previous solution (u_n, p_n): |b - A x_n| / |b| is O(dt) already
+    const double* x0 = (S.factor_free && h->state_live && h->pc_warm_start) ? st_n(h) : nullptr;
+    FCCHK(h->method == FC_METHOD_GMRES ? gmres_permuted(h, S, &iters, &relres, x0) : bicgstab_permuted(h, S, &iters, &relres));
     h->last_krylov_iters = iters;
     hipLaunchKernelGGL(fc_copy, dim3(nblocks(h->N, 256)), dim3(256), 0, h->stream, h->N, h->kry.p, h->buf.p + h->N);
     return launch_tail(h, S, compute_energy, d_y, d_E, d_r, d_flag_out, d_seq, seq);
@@ -2183,6 +2324,11 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
   const int N = h->N;
   OrderSys& S = h->sys[slot];
   S.ready = false;
+  if (S.factor_free) {
+    S.factor_free = false;
+    S.pc.release();
+    S.ap_src.release();
+  }
   S.Ap_nnz = Ap_rowptr[N];
   for (int64_t k = 0; k < S.Ap_nnz; ++k)
     if (Ap_col[k] < 0 || Ap_col[k] >= N) return fail(FC_ERR_INVALID, "fc_solver_setup: system column out of range");
@@ -2794,8 +2940,9 @@ static int upload_energy_matrix(fc_ctx* h) {
   std::vector<double> mv((size_t)h->nnz);
   HIPCHK(hipMemcpy(mv.data(), h->vals[FC_SLOT_MASS].p, mv.size() * sizeof(double), hipMemcpyDeviceToHost));
   const int N = h->N, nn2 = 2 * h->nn;
-  const std::vector<int>& perm = h->sym_tree.perm;
-  const std::vector<int>& iperm = h->sym_tree.iperm;
+  const std::vector<int>& perm = h->h_perm;  // (the permutation the handle holds: fc_setup_solver's tree or fc_setup_krylov's)
+  std::vector<int> iperm((size_t)N);
+  for (int i = 0; i < N; ++i) iperm[(size_t)perm[(size_t)i]] = i;
   std::vector<int> rp((size_t)N + 1, 0), col;
   std::vector<double> val;
   std::vector<std::pair<int, double>> row;
@@ -3005,6 +3152,147 @@ int fc_setup_solver(fc_handle h, int slot, int32_t depth, int32_t merge, int32_t
     FCCHK(fc_accept_factors(h, slot, nullptr, nullptr));
   }
   return fc_set_solver_options(h, FC_METHOD_REFINE, refine, 1e-10, check_residual);
+}
+
+// Factorisation-free solver setup of a slot (include/fc_hip.h): permutation from the nested-dissection tree alone (no factor layout,
+// no elimination plan, no fronts), permuted system matrix for the Krylov mat-vec, and the SIMPLE / AMG preconditioner of fc_precond.hpp
+// built on the host from the slot's assembled values.  Device memory: the matrix twice (W order + permuted), its velocity block and
+// B / Bt once more in compact numbering, an AMG hierarchy of ~1.3 x nnz(S) -- O(nnz), nothing that grows like the fill.
+int fc_setup_krylov(fc_handle h, int slot, int32_t sweeps, int method, int32_t max_iter, double rtol, int32_t check_residual) {
+  if (!h || slot < 0 || slot > 1 || sweeps < 1 || sweeps > 16) return fail(FC_ERR_INVALID, "fc_setup_krylov: bad argument");
+  if (method != FC_METHOD_GMRES && method != FC_METHOD_BICGSTAB) return fail(FC_ERR_INVALID, "fc_setup_krylov: method must be FC_METHOD_GMRES or FC_METHOD_BICGSTAB");
+  if (!h->slot_ok[slot] || !h->sys[slot].have_lift) return fail(FC_ERR_NOT_READY, "fc_setup_krylov: assemble the slot and call fc_apply_bc first");
+  if (h->partitioned || h->comm || h->host_xchg) return fail(FC_ERR_INVALID, "fc_setup_krylov: the factorisation-free preconditioner runs on a single-GPU handle");
+  HIPCHK(hipSetDevice(h->device));
+  const auto t0 = std::chrono::steady_clock::now();
+  const int N = h->N;
+  OrderSys& S = h->sys[slot];
+  try {
+    if (!h->have_perm) {
+      // the tree is used for its ordering only (sub-domain by sub-domain: rows that share columns sit next to each other)
+      std::vector<unsigned char> skip((size_t)N, 0);
+      for (int k = 0; k < h->n_bc; ++k) skip[(size_t)h->h_bc_dofs[k]] = 1;
+      const fcsym::Tree t = fcsym::build_tree(h->h_cell_dofs, 15, h->h_cent, h->nc, N, fcsym::default_bits(h->nc, 2, 0), &skip, 0);
+      FCCHK(fc_set_permutation(h, t.perm.data()));
+      FCCHK(upload_energy_matrix(h));
+    }
+    FCCHK(quiesce(h));
+    // permuted pattern + where each of its entries comes from
+    if (!S.factor_free || S.ap_src.n != (size_t)h->nnz) {
+      std::vector<int> ip((size_t)N);
+      for (int i = 0; i < N; ++i) ip[(size_t)h->h_perm[(size_t)i]] = i;
+      std::vector<int> rp((size_t)N + 1, 0), ci((size_t)h->nnz);
+      std::vector<int64_t> src((size_t)h->nnz);
+      std::vector<std::pair<int, int>> row;
+      for (int i = 0; i < N; ++i) {
+        const int w = h->h_perm[(size_t)i];
+        row.clear();
+        for (int k = h->h_rowptr[(size_t)w]; k < h->h_rowptr[(size_t)w + 1]; ++k) row.emplace_back(ip[(size_t)h->h_col[(size_t)k]], k);
+        std::sort(row.begin(), row.end());
+        int q = rp[(size_t)i];
+        for (const auto& e : row) ci[(size_t)q] = e.first, src[(size_t)q] = e.second, ++q;
+        rp[(size_t)i + 1] = q;
+      }
+      S.Ap_nnz = h->nnz;
+      FCCHK(S.Ap_rowptr.upload(rp, h->stream));
+      FCCHK(S.Ap_col.upload(ci, h->stream));
+      FCCHK(S.Ap_val.alloc((size_t)h->nnz));
+      FCCHK(S.ap_src.upload(src, h->stream));
+    }
+    hipLaunchKernelGGL(fc_gather64, dim3(nblocks(S.Ap_nnz, 256)), dim3(256), 0, h->stream, S.Ap_nnz, S.ap_src.p, h->vals[slot].p, S.Ap_val.p);
+    std::vector<double> vals((size_t)h->nnz);
+    HIPCHK(hipMemcpyAsync(vals.data(), h->vals[slot].p, (size_t)h->nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    // host: blocks, Schur complement, AMG hierarchy
+    fcpc::Blocks X = fcpc::split_blocks(N, 2 * h->nn, h->h_rowptr, h->h_col, vals.data(), h->h_perm);
+    std::vector<double> dinv((size_t)X.nu), wdinv((size_t)X.nu);
+    for (int i = 0; i < X.nu; ++i) {
+      if (!(std::fabs(X.dF[(size_t)i]) > 0.0)) return fail(FC_ERR_INVALID, "fc_setup_krylov: zero diagonal in the velocity block");
+      dinv[(size_t)i] = 1.0 / X.dF[(size_t)i];
+    }
+    const double rhoF = fcpc::rho_dinv(X.F, X.dF);
+    const double omega = sweeps > 1 ? std::min(1.0, 1.4 / rhoF) : 1.0;
+    for (int i = 0; i < X.nu; ++i) wdinv[(size_t)i] = omega * dinv[(size_t)i];
+    fcpc::Csr Sh = fcpc::spgemm(X.B, X.Bt, dinv.data());
+    if (h->pin_dof >= 0) {  // enclosed flow: the Schur complement has the constant in its kernel; pin it where the factorisation does
+      int ipin = -1;
+      for (int k = 0; k < X.np; ++k)
+        if (h->h_perm[(size_t)X.ppos[(size_t)k]] == h->pin_dof) ipin = k;
+      if (ipin >= 0)
+        for (int q = Sh.rp[(size_t)ipin]; q < Sh.rp[(size_t)ipin + 1]; ++q)
+          if (Sh.ci[(size_t)q] == ipin) Sh.v[(size_t)q] += h->pin_shift;
+    }
+    const int64_t s_nnz = Sh.nnz();
+    fcpc::Amg H = fcpc::build_amg(std::move(Sh));
+    // device copy
+    Precond& P = S.pc;
+    P.release();
+    P.sweeps = sweeps, P.omega = omega, P.nu = X.nu, P.np = X.np;
+    FCCHK(P.vpos.upload(X.vpos, h->stream));
+    FCCHK(P.ppos.upload(X.ppos, h->stream));
+    FCCHK(P.F.upload(X.F, h->stream));
+    FCCHK(P.B.upload(X.B, h->stream));
+    FCCHK(P.Bt.upload(X.Bt, h->stream));
+    FCCHK(P.dinvF.upload(dinv, h->stream));
+    FCCHK(P.wdinvF.upload(wdinv, h->stream));
+    FCCHK(P.u0.alloc((size_t)X.nu));
+    FCCHK(P.u1.alloc((size_t)X.nu));
+    P.bytes = P.F.bytes() + P.B.bytes() + P.Bt.bytes() + 4 * ((int64_t)X.nu + X.np) + 8 * 4 * (int64_t)X.nu;
+    P.level_rows.clear();
+    P.lv.resize(H.levels.size());
+    for (size_t l = 0; l < H.levels.size(); ++l) {
+      PcLevel& V = P.lv[l];
+      const fcpc::Level& G = H.levels[l];
+      V.n = G.A.nrows;
+      FCCHK(V.A.upload(G.A, h->stream));
+      FCCHK(V.P.upload(G.P, h->stream));
+      FCCHK(V.R.upload(G.R, h->stream));
+      FCCHK(V.wdinv.upload(G.wdinv, h->stream));
+      FCCHK(V.x.alloc((size_t)V.n));
+      FCCHK(V.r.alloc((size_t)V.n));
+      FCCHK(V.t.alloc((size_t)V.n));
+      P.bytes += V.A.bytes() + V.P.bytes() + V.R.bytes() + 8 * 4 * (int64_t)V.n;
+      P.level_rows.push_back(V.n);
+    }
+    P.n_coarse = H.n_coarse;
+    P.level_rows.push_back(H.n_coarse);
+    FCCHK(P.cinv.upload(H.coarse_inv, h->stream));
+    FCCHK(P.xc.alloc((size_t)std::max(1, H.n_coarse)));
+    FCCHK(P.rc.alloc((size_t)std::max(1, H.n_coarse)));
+    P.bytes += 8 * ((int64_t)H.n_coarse * H.n_coarse + 2 * H.n_coarse);
+    P.launches = sweeps + 4 + 5 * (int)H.levels.size();
+    HIPCHK(hipStreamSynchronize(h->stream));  // the host vectors above go out of scope
+    (void)s_nnz;
+    P.ready = true;
+  } catch (const std::exception& e) {
+    return fail(FC_ERR_INVALID, std::string("fc_setup_krylov: ") + e.what());
+  }
+  // a slot is either factorised or factor-free: drop what fc_setup_solver may have left
+  S.stages.clear();
+  S.seg_ptr.release(), S.seg.release(), S.blk.release(), S.f_idx.release(), S.f_val.release(), S.f_val32.release(), S.f_val16.release();
+  S.f_nnz = 0, S.sweep_bytes = 0.0, S.bits = 64;
+  S.structured = S.truncated = S.inexact = S.nt = false;
+  S.ar_stage = S.ar2_stage = -1, S.ar_n = 0;
+  S.factor_free = true;
+  S.ready = true;
+  S.pc.setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  h->gmres_m = std::max(30, std::min(60, (int)max_iter));
+  if (const char* e = std::getenv("FC_PC_WARM_START")) h->pc_warm_start = e[0] != '0';
+  return fc_set_solver_options(h, method, max_iter, rtol, check_residual);
+}
+
+// info[8]: device bytes held by the preconditioner, velocity dofs, pressure dofs, AMG levels (sparse + the dense coarsest), rows of the
+// coarsest level, kernel launches per apply, Jacobi sweeps, host milliseconds of the setup; omega_out: the Jacobi damping
+int fc_get_krylov_info(fc_handle h, int slot, int64_t* info, double* omega_out) {
+  if (!h || slot < 0 || slot > 1 || !info) return fail(FC_ERR_INVALID, "fc_get_krylov_info: bad argument");
+  const OrderSys& S = h->sys[slot];
+  if (!S.factor_free || !S.pc.ready) return fail(FC_ERR_NOT_READY, "fc_setup_krylov not called for this slot");
+  const Precond& P = S.pc;
+  info[0] = P.bytes + 12 * S.Ap_nnz + 8 * S.Ap_nnz;  // + the permuted system matrix and its source map
+  info[1] = P.nu, info[2] = P.np, info[3] = (int64_t)P.lv.size() + 1, info[4] = P.n_coarse, info[5] = P.launches, info[6] = P.sweeps;
+  info[7] = (int64_t)std::llround(P.setup_ms);
+  if (omega_out) *omega_out = P.omega;
+  return FC_OK;
 }
 
 static std::string sci(double v) {
@@ -3268,6 +3556,15 @@ int fc_get_rowkind(fc_handle h, uint8_t* rowkind) {
 
 int fc_update_operator(fc_handle h, int slot) {
   if (!h || slot < 0 || slot > 1) return fail(FC_ERR_INVALID, "fc_update_operator: bad argument");
+  if (h->sys[slot].factor_free) {  // the preconditioner of the earlier operator stays (call fc_setup_krylov again for a new one)
+    OrderSys& S = h->sys[slot];
+    HIPCHK(hipSetDevice(h->device));
+    FCCHK(quiesce(h));
+    hipLaunchKernelGGL(fc_gather64, dim3(nblocks(S.Ap_nnz, 256)), dim3(256), 0, h->stream, S.Ap_nnz, S.ap_src.p, h->vals[slot].p, S.Ap_val.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return FC_OK;
+  }
   if (!h->have_plan) return fail(FC_ERR_NOT_READY, "fc_factor_plan not called");
   OrderSys& S = h->sys[slot];
   if (!S.structured) return fail(FC_ERR_NOT_READY, "fc_solver_setup (structure) must be called first");
@@ -3768,6 +4065,8 @@ int fc_solve(fc_handle h, int slot, const double* b, double* x, double* info_out
 static int solve_once(fc_handle h, int slot, const double* b, double* x, double* info_out) {
   OrderSys& S = h->sys[slot];
   if (!S.ready) return fail(FC_ERR_NOT_READY, "fc_solver_setup not called for this slot");
+  if (S.factor_free && h->method == FC_METHOD_REFINE)
+    return fail(FC_ERR_INVALID, "fc_solve: this slot has no factors (fc_setup_krylov): set FC_METHOD_GMRES or FC_METHOD_BICGSTAB");
   HIPCHK(hipSetDevice(h->device));
   FCCHK(quiesce(h));
   h->b.p = h->bstore.p;
@@ -4886,6 +5185,7 @@ static int batch_ready(fc_ctx* h, int order_slot, int32_t k, const char* who) {
   if (h->method != FC_METHOD_REFINE || h->max_iter != 0) return fail(FC_ERR_INVALID, std::string(who) + ": batched steps apply the factors directly (FC_METHOD_REFINE, no refinement sweeps)");
   if (h->partitioned || S.truncated) return fail(FC_ERR_INVALID, std::string(who) + ": single-GPU handles with full factors only");
   if (S.inexact) return fail(FC_ERR_INVALID, std::string(who) + ": this slot's factors are inexact (a preconditioner for GMRES): batched stepping applies them directly");
+  if (S.factor_free) return fail(FC_ERR_INVALID, std::string(who) + ": this slot has no factors (fc_setup_krylov): batched stepping applies factors directly");
   if (h->n_act > 32 || h->n_sens > 64) return fail(FC_ERR_INVALID, std::string(who) + ": at most 32 actuators and 64 sensors");
   if (kRecStride * 32 > kSeqSlot) return fail(FC_ERR_INVALID, "record too small");
   return FC_OK;

@@ -512,10 +512,35 @@ class DeviceSolver:
         m = {"refine": _lib.METHOD_REFINE, "bicgstab": _lib.METHOD_BICGSTAB, "gmres": _lib.METHOD_GMRES}[method]
         check(self.lib.fc_set_solver_options(self._h, m, int(refine), float(rtol), int(check_residual)))
 
+    def setup_krylov(self, slot: int, sweeps: int = 3, method: str = "gmres", max_iter: int = 200, rtol: float = 1e-10,
+                     check_residual: bool | int = True) -> dict:
+        """Factorisation-free solver setup of ``slot`` (``fc_setup_krylov``): nothing is factorised; solves and time steps run
+        the device GMRES / BiCGStab right-preconditioned by the SIMPLE / AMG block preconditioner (``sweeps`` damped-Jacobi
+        sweeps on the velocity block, one smoothed-aggregation V-cycle on the pressure Schur complement ``B diag(F)^-1 Bt``).
+        Memory O(nnz).  Returns the sizes of what was built (``krylov_info``)."""
+        m = {"bicgstab": _lib.METHOD_BICGSTAB, "gmres": _lib.METHOD_GMRES}[method]
+        check(self.lib.fc_setup_krylov(self._h, slot, int(sweeps), m, int(max_iter), float(rtol), int(check_residual)))
+        self._structured.discard(slot)
+        self._krylov_slots = getattr(self, "_krylov_slots", set()) | {slot}
+        self._solver_opts = (int(max_iter), int(check_residual), method, float(rtol))
+        if self.perm is None:
+            self.perm = np.empty(self.N, dtype=np.int32)
+            check(self.lib.fc_get_permutation(self._h, self.perm))
+        self.factor_nnz[slot] = 0
+        return self.krylov_info(slot)
+
+    def krylov_info(self, slot: int) -> dict:
+        """What ``setup_krylov`` holds on the device for ``slot``."""
+        info, om = np.zeros(8, dtype=np.int64), C.c_double()
+        check(self.lib.fc_get_krylov_info(self._h, slot, info, C.byref(om)))
+        return {"bytes": int(info[0]), "velocity_dofs": int(info[1]), "pressure_dofs": int(info[2]), "amg_levels": int(info[3]),
+                "coarsest_rows": int(info[4]), "launches_per_apply": int(info[5]), "jacobi_sweeps": int(info[6]),
+                "setup_ms": int(info[7]), "jacobi_omega": om.value}
+
     def update_operator(self, slot: int) -> None:
         """The slot's matrix changed (assemble + apply_bc) but its factors are kept: refresh the permuted copy
         only.  ``solve`` with ``method="bicgstab"`` then uses the old factors as preconditioner."""
-        if slot not in self._structured:
+        if slot not in self._structured and slot not in getattr(self, "_krylov_slots", ()):
             raise RuntimeError("setup_solver(slot) must run once before update_operator(slot)")
         check(self.lib.fc_update_operator(self._h, slot))
 

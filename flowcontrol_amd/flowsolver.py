@@ -109,6 +109,11 @@ class FlowSolver(ABC):
         self.krylov_method: str = "gmres"
         self.krylov_max_iter: int = 500
         self.krylov_rtol: float = 1e-12
+        #: factorisation-free mode: ``"schur_amg"`` = nothing is factorised; every step is solved by the device GMRES / BiCGStab
+        #: right-preconditioned by the SIMPLE / AMG block preconditioner (``krylov_sweeps`` damped-Jacobi sweeps on the velocity
+        #: block + one algebraic-multigrid V-cycle on the pressure Schur complement); memory O(nnz).  None = factors (default)
+        self.krylov_precond: str | None = None
+        self.krylov_sweeps: int = 3
         #: multi-GPU: who the ranks are (flowcontrol_amd.comm.Comm); None = the torch.distributed process group of this process, if any
         self.comm = None
         #: set when the in-library RCCL communicator could not be created and the exchanges were staged through the host instead
@@ -1006,6 +1011,12 @@ class _DeviceNDSolver:
             vals = np.zeros(dev.nnz)
             vals[pos[~bad]] = M.data[~bad]
             dev.set_matrix_values(self.slot, vals)
+        if fs.krylov_precond is not None:
+            if fs.krylov_precond != "schur_amg":
+                raise ValueError("krylov_precond: None (factors) or 'schur_amg'")
+            dev.setup_krylov(self.slot, sweeps=fs.krylov_sweeps, method=fs.krylov_method, max_iter=fs.krylov_max_iter, rtol=fs.krylov_rtol,
+                             check_residual=fs.check_residual_every)
+            return
         dev.setup_solver(self.slot, depth=fs.nd_depth, refine=fs.refine_steps, truncate=fs.nd_truncate, check_residual=fs.check_residual_every)
         if fs.nd_truncate or fs.factor_bits != 64:
             dev.set_solver_options(refine=fs.krylov_max_iter, check_residual=fs.check_residual_every, method=fs.krylov_method, rtol=fs.krylov_rtol)

@@ -165,6 +165,25 @@ int fc_update_operator(fc_handle h, int slot);
  * pass over the system matrix it costs.  The non-finite test runs on every step regardless. */
 int fc_set_solver_options(fc_handle h, int method, int max_iter, double rtol, int check_residual);
 
+/* FACTORISATION-FREE Krylov mode (reference plug-in point FlowSolver._make_solver, flowsolver.py:812-814: "any object with
+ * set_operator / solve"; BASELINE.json north_star: "HIP BiCGStab/GMRES with CSR SpMV and block-Jacobi/ILU(0) preconditioning").
+ * Instead of fc_setup_solver: NOTHING is factorised.  The slot's solves and time steps run the device GMRES / BiCGStab on the
+ * permuted system matrix, right-preconditioned by a SIMPLE-type block preconditioner built from the assembled values alone:
+ *     u  = `sweeps` damped-Jacobi sweeps on the velocity block F         (the time-step operators are mass dominated)
+ *     zp = one smoothed-aggregation AMG V(1,1)-cycle on S zp = B u - r_p,  S = B diag(F)^-1 Bt  (pressure Schur complement)
+ *     zu = u - diag(F)^-1 Bt zp
+ * Memory is O(nnz) (matrix blocks + an AMG hierarchy of ~1.3 nnz(S)), nothing grows like the fill of a factorisation.
+ * Cylinder O1 BDF2 operator, sweeps = 3: ~20 GMRES iterations to 1e-10 from a zero guess, fewer inside time steps (which start
+ * from the previous solution).  method: FC_METHOD_GMRES or FC_METHOD_BICGSTAB; max_iter / rtol / check_residual as in
+ * fc_set_solver_options.  Needs fc_set_bc, fc_assemble_matrix(slot), fc_apply_bc(slot); single-GPU handles; after the
+ * slot's matrix changed call it again (fc_update_operator alone keeps the old preconditioner for the new operator).
+ * fc_setup_solver on the same slot later replaces the mode.  Batched stepping needs factors. */
+int fc_setup_krylov(fc_handle h, int slot, int32_t sweeps, int method, int32_t max_iter, double rtol, int32_t check_residual);
+/* info[8]: device bytes held for the slot's Krylov mode (permuted matrix + blocks + AMG hierarchy), velocity dofs, pressure dofs, AMG
+ * levels (the dense coarsest one included), rows of the coarsest level, kernel launches per preconditioner apply, Jacobi sweeps, host
+ * milliseconds of the setup; omega_out (optional): the Jacobi damping chosen from the spectral radius of diag(F)^-1 F */
+int fc_get_krylov_info(fc_handle h, int slot, int64_t* info /* [8] */, double* omega_out);
+
 /* ── state: FlowFieldCollection u_n, u_nn, p_n (flowfield.py:67-105; flowsolver.py:487-491) ─ */
 int fc_set_state(fc_handle h, const double* u_n /* [2 nn] */, const double* u_nn /* [2 nn] */,
                  const double* p_n /* [nv] */);
