@@ -131,30 +131,31 @@ struct PcMat {
   int64_t bytes() const { return 12 * nnz + 4 * ((int64_t)nrows + 1); }
 };
 struct PcLevel {
-  PcMat A, P, R;
-  DevBuf<double> wdinv, x, r, t;
-  int n = 0;
+  PcMat G, U;            // folded transfer operators of one AMG level (fc_precond.hpp: fold_down / fold_up)
+  DevBuf<double> cat;    // [r (n) | z_c (n_next)]: the level's right-hand side next to the coarse correction U reads with it
+  int n = 0, n_next = 0;
 };
 struct Precond {
   bool ready = false;
-  int sweeps = 3;       // damped-Jacobi sweeps on the velocity block
+  int sweeps = 2;       // damped-Jacobi sweeps on the velocity block (the first two are one folded product)
   double omega = 1.0;   // their damping
   int nu = 0, np = 0;
   DevBuf<int> vpos, ppos;  // compact velocity / pressure index -> position in the permuted Krylov vector
-  PcMat F, B, Bt;
+  PcMat KF;                // sweeps >= 2: Wd (2 I - F Wd), columns = positions in the Krylov vector
+  PcMat F, B, Bt;          // compact numbering (F only for sweeps >= 3)
   DevBuf<double> dinvF, wdinvF;  // 1 / diag(F), omega / diag(F)
-  DevBuf<double> u0, u1, rp;     // velocity ping-pong, Schur right-hand side
+  DevBuf<double> u0, u1, zp;     // velocity ping-pong, pressure correction
   std::vector<PcLevel> lv;
   int n_coarse = 0;
-  DevBuf<double> cinv, xc, rc;   // dense inverse of the coarsest operator and its vectors
+  DevBuf<double> cinv, rc;       // dense inverse of the coarsest operator, its right-hand side
   int64_t bytes = 0;             // device bytes held by the preconditioner
   int launches = 0;              // kernel launches per apply
   void release() {
     ready = false;
-    for (PcMat* M : {&F, &B, &Bt}) M->rp.release(), M->ci.release(), M->v.release();
-    vpos.release(), ppos.release(), dinvF.release(), wdinvF.release(), u0.release(), u1.release(), rp.release();
+    for (PcMat* M : {&KF, &F, &B, &Bt}) M->rp.release(), M->ci.release(), M->v.release(), M->nnz = 0;
+    vpos.release(), ppos.release(), dinvF.release(), wdinvF.release(), u0.release(), u1.release(), zp.release();
     lv.clear();
-    cinv.release(), xc.release(), rc.release();
+    cinv.release(), rc.release();
     bytes = 0;
   }
   double setup_ms = 0.0;
@@ -279,6 +280,12 @@ struct fc_ctx {
   DevBuf<double> ks;   // device-resident scalars of the Krylov recurrences (KS_* in fc_kernels.hip.h)
   DevBuf<double> gm, mdot;  // GMRES: Hessenberg / rotations / small vectors; multi-dot partials
   int gmres_m = 30;    // restart length
+  // Arnoldi steps of the factorisation-free GMRES as HIP graphs (each is ~30 launch-bound launches: preconditioner apply, mat-vec,
+  // two Gram-Schmidt passes, rotation): one graph per (slot, basis column j), captured on first use; FC_KRYLOV_GRAPH=0: plain launches
+  struct KryGraphs {
+    std::vector<hipGraphExec_t> step;
+    uint64_t sig = 0;
+  } kgraph[2];
   bool pc_warm_start = true;  // factor-free slots: GMRES inside a time step starts from the previous solution (FC_PC_WARM_START=0: from zero)
   int last_krylov_iters = 0;
   double rtol = 1e-10;
@@ -489,6 +496,7 @@ struct fc_ctx {
 extern "C" int collect_late(fc_ctx* h, int par);        // late records of overlapped steps (defined with the step functions)
 extern "C" int collect_late_batch(fc_ctx* h, int par);
 
+
 namespace {
 
 // RCCL is resolved at run time (dlopen): single-GPU use has no dependency on it, and inside a
@@ -692,39 +700,36 @@ int pc_launch(fc_ctx* h, const PcMat* M, int n, const double* x, const double* r
 }
 
 // out = M^-1 in with the factorisation-free preconditioner of the slot (fc_setup_krylov), both in the permuted numbering:
-//   u  = k damped-Jacobi sweeps on F u = in_u                    (velocity block: mass dominated)
-//   zp = AMG V(1,1)-cycle on S zp = B u - in_p, S = B diag(F)^-1 Bt  (pressure Schur complement: Poisson-like)
+//   u  = k damped-Jacobi sweeps on F u = in_u                    (velocity block: mass dominated; the first two are one product)
+//   zp = AMG V(1,1)-cycle on S zp = B u - in_p, S = B diag(F)^-1 Bt  (pressure Schur complement: Poisson-like; 2 launches per level)
 //   zu = u - diag(F)^-1 Bt zp
-// sweeps + 4 + 5 (AMG levels) launches; `in` is only read, `out` only written (they may not alias).
+// max(1, sweeps - 1) + 3 + 2 (sparse AMG levels) launches; `in` is only read, `out` only written (they may not alias).
 int apply_pc(fc_ctx* h, OrderSys& S, const double* in, double* out) {
   Precond& P = S.pc;
   if (!P.ready) return fail(FC_ERR_NOT_READY, "fc_setup_krylov not called for this slot");
   double *u = P.u0.p, *un = P.u1.p;
-  const double* wd = P.sweeps > 1 ? P.wdinvF.p : P.dinvF.p;
-  FCCHK(pc_launch(h, nullptr, P.nu, nullptr, in, P.vpos.p, wd, nullptr, 1.0, u, nullptr));
-  for (int k = 1; k < P.sweeps; ++k) {
+  if (P.sweeps >= 2)
+    FCCHK(pc_launch(h, &P.KF, P.nu, in, nullptr, nullptr, nullptr, nullptr, -1.0, u, nullptr));  // u = K_F in (columns address `in`)
+  else
+    FCCHK(pc_launch(h, nullptr, P.nu, nullptr, in, P.vpos.p, P.dinvF.p, nullptr, 1.0, u, nullptr));
+  for (int k = 2; k < P.sweeps; ++k) {
     FCCHK(pc_launch(h, &P.F, P.nu, u, in, P.vpos.p, P.wdinvF.p, u, 1.0, un, nullptr));
     std::swap(u, un);
   }
   const int L = (int)P.lv.size();
-  FCCHK(pc_launch(h, &P.B, P.np, u, in, P.ppos.p, nullptr, nullptr, -1.0, L ? P.lv[0].r.p : P.rc.p, nullptr));
+  FCCHK(pc_launch(h, &P.B, P.np, u, in, P.ppos.p, nullptr, nullptr, -1.0, L ? P.lv[0].cat.p : P.rc.p, nullptr));  // B u - in_p
   for (int l = 0; l < L; ++l) {
     PcLevel& V = P.lv[(size_t)l];
-    FCCHK(pc_launch(h, nullptr, V.n, nullptr, V.r.p, nullptr, V.wdinv.p, nullptr, 1.0, V.x.p, nullptr));    // x = w D^-1 r
-    FCCHK(pc_launch(h, &V.A, V.n, V.x.p, V.r.p, nullptr, nullptr, nullptr, 1.0, V.t.p, nullptr));              // t = r - A x
-    const int nnext = l + 1 < L ? P.lv[(size_t)l + 1].n : P.n_coarse;
-    FCCHK(pc_launch(h, &V.R, nnext, V.t.p, nullptr, nullptr, nullptr, nullptr, -1.0, l + 1 < L ? P.lv[(size_t)l + 1].r.p : P.rc.p, nullptr));
+    FCCHK(pc_launch(h, &V.G, V.n_next, V.cat.p, nullptr, nullptr, nullptr, nullptr, -1.0, l + 1 < L ? P.lv[(size_t)l + 1].cat.p : P.rc.p, nullptr));
   }
-  hipLaunchKernelGGL(fc_pc_dense, dim3(nblocks(P.n_coarse, 4)), dim3(256), 0, h->stream, P.n_coarse, P.cinv.p, P.rc.p, P.xc.p);
-  const double* zc = P.xc.p;
+  hipLaunchKernelGGL(fc_pc_dense, dim3(nblocks(P.n_coarse, 4)), dim3(256), 0, h->stream, P.n_coarse, P.cinv.p, P.rc.p,
+                     L ? P.lv[(size_t)L - 1].cat.p + P.lv[(size_t)L - 1].n : P.zp.p);
   for (int l = L - 1; l >= 0; --l) {
     PcLevel& V = P.lv[(size_t)l];
-    FCCHK(pc_launch(h, &V.P, V.n, zc, nullptr, nullptr, nullptr, V.x.p, -1.0, V.x.p, nullptr));               // x += P x_c (in place)
-    FCCHK(pc_launch(h, &V.A, V.n, V.x.p, V.r.p, nullptr, V.wdinv.p, V.x.p, 1.0, V.t.p, nullptr));              // t = x + w D^-1 (r - A x)
-    zc = V.t.p;
+    FCCHK(pc_launch(h, &V.U, V.n, V.cat.p, nullptr, nullptr, nullptr, nullptr, -1.0, l > 0 ? P.lv[(size_t)l - 1].cat.p + P.lv[(size_t)l - 1].n : P.zp.p, nullptr));
   }
-  FCCHK(pc_launch(h, &P.Bt, P.nu, zc, nullptr, nullptr, P.dinvF.p, u, 1.0, out, P.vpos.p));
-  FCCHK(pc_launch(h, nullptr, P.np, nullptr, zc, nullptr, nullptr, nullptr, 1.0, out, P.ppos.p));
+  hipLaunchKernelGGL(fc_pc_final, dim3(nblocks(P.nu + P.np, 64)), dim3(256), 0, h->stream, P.nu, P.np, P.Bt.rp.p, P.Bt.ci.p, P.Bt.v.p, P.zp.p,
+                     P.dinvF.p, u, P.vpos.p, P.ppos.p, out);
   HIPCHK(hipGetLastError());
   return FC_OK;
 }
@@ -1497,6 +1502,31 @@ int bicgstab_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres) {
   return FC_OK;
 }
 
+int capture_graph(fc_ctx* h, hipStream_t stream, hipGraphExec_t* gx, const std::function<int()>& launches) {
+  if (*gx) (void)hipGraphExecDestroy(*gx);
+  *gx = nullptr;
+  hipGraph_t graph = nullptr;
+  HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+  const int code = launches();
+  const hipError_t e = hipStreamEndCapture(stream, &graph);
+  if (code != FC_OK) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return code;
+  }
+  if (e != hipSuccess) return fail(FC_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+  const hipError_t e2 = hipGraphInstantiate(gx, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e2 != hipSuccess) return fail(FC_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2));
+  return FC_OK;
+}
+
+void krylov_drop_graphs(fc_ctx* h, int slot) {
+  for (hipGraphExec_t& g : h->kgraph[slot].step)
+    if (g) (void)hipGraphExecDestroy(g);
+  h->kgraph[slot].step.clear();
+  h->kgraph[slot].sig = 0;
+}
+
 // Restarted GMRES(m), right-preconditioned by the slot's factor sweeps: x = M^-1 (V y).  Classical Gram-Schmidt with
 // one re-orthogonalisation (two multi-dot launches per Arnoldi step instead of j sequential dots), Givens rotations and
 // the back substitution in a one-thread kernel, everything on the device; the host reads the state word once per
@@ -1572,6 +1602,41 @@ int gmres_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres, const dou
     hipLaunchKernelGGL(fc_scale_by_norm, dim3(g), dim3(256), 0, h->stream, N, r, norm2, V, ks);
     return FC_OK;
   };
+  // one Arnoldi step: column j of the basis -> column j + 1, Hessenberg column, rotation, convergence state (all on the device)
+  auto arnoldi = [&](int j) -> int {
+    double* vj = V + (size_t)j * N;
+    FCCHK(precond(vj, z));
+    FCCHK(matvec(z, w));
+    // classical Gram-Schmidt, twice: h = V^T w, w -= V h; h2 = V^T w, w -= V h2; Hessenberg column = h + h2
+    FCCHK(multidot(j + 1, V, w, hcol));
+    hipLaunchKernelGGL(fc_gmres_project, dim3(g), dim3(256), 0, h->stream, N, j + 1, V, hcol, w, ks);
+    FCCHK(multidot(j + 1, V, w, hcol2));
+    hipLaunchKernelGGL(fc_small_add, dim3(nblocks(j + 1, 64)), dim3(64), 0, h->stream, j + 1, hcol2, hcol, ks);
+    hipLaunchKernelGGL(fc_gmres_project, dim3(g), dim3(256), 0, h->stream, N, j + 1, V, hcol2, w, ks);
+    FCCHK(multidot(1, w, w, norm2));
+    hipLaunchKernelGGL(fc_gmres_givens, dim3(1), dim3(1), 0, h->stream, j, m, gm, ks, h->rtol);
+    hipLaunchKernelGGL(fc_scale_by_norm, dim3(g), dim3(256), 0, h->stream, N, w, norm2, V + (size_t)(j + 1) * N, ks);
+    return FC_OK;
+  };
+  // factor-free slots: the step is ~30 launches of a few microseconds each -- replayed as one graph per column
+  static const bool graphs_on = [] { const char* e = std::getenv("FC_KRYLOV_GRAPH"); return !(e && e[0] == '0'); }();
+  const bool use_graph = graphs_on && S.factor_free && !dist && !h->timing;
+  const int slot_id = (int)(&S - h->sys);
+  fc_ctx::KryGraphs& KG = h->kgraph[slot_id];
+  if (use_graph) {
+    uint64_t sig = 1469598103934665603ull;
+    auto mix = [&sig](uint64_t v) { sig = (sig ^ v) * 1099511628211ull; };
+    uint64_t rbits;
+    std::memcpy(&rbits, &h->rtol, sizeof rbits);
+    for (uint64_t v : {(uint64_t)(uintptr_t)h->kry.p, (uint64_t)(uintptr_t)gm, (uint64_t)(uintptr_t)h->mdot.p, (uint64_t)(uintptr_t)ks, (uint64_t)(uintptr_t)S.pc.u0.p, (uint64_t)(uintptr_t)S.pc.zp.p,
+                       (uint64_t)(uintptr_t)S.Ap_val.p, (uint64_t)(uintptr_t)S.pc.cinv.p, (uint64_t)m, (uint64_t)N, (uint64_t)S.pc.sweeps, (uint64_t)S.pc.lv.size(), rbits})
+      mix(v);
+    if (KG.sig != sig || KG.step.size() != (size_t)m) {
+      krylov_drop_graphs(h, slot_id);
+      KG.step.assign((size_t)m, nullptr);
+      KG.sig = sig;
+    }
+  }
   HIPCHK(hipMemsetAsync(ks, 0, KS_SIZE * sizeof(double), h->stream));
   HIPCHK(hipMemsetAsync(gm, 0, gm_n * sizeof(double), h->stream));
   if (x0) {  // warm start (time steps of a factor-free slot: the previous solution): r = b - A x0
@@ -1593,18 +1658,13 @@ int gmres_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres, const dou
     int j = 0;
     double state = 0.0;
     for (; j < m && total < h->max_iter; ++j, ++total) {
-      double* vj = V + (size_t)j * N;
-      FCCHK(precond(vj, z));
-      FCCHK(matvec(z, w));
-      // classical Gram-Schmidt, twice: h = V^T w, w -= V h; h2 = V^T w, w -= V h2; Hessenberg column = h + h2
-      FCCHK(multidot(j + 1, V, w, hcol));
-      hipLaunchKernelGGL(fc_gmres_project, dim3(g), dim3(256), 0, h->stream, N, j + 1, V, hcol, w, ks);
-      FCCHK(multidot(j + 1, V, w, hcol2));
-      hipLaunchKernelGGL(fc_small_add, dim3(nblocks(j + 1, 64)), dim3(64), 0, h->stream, j + 1, hcol2, hcol, ks);
-      hipLaunchKernelGGL(fc_gmres_project, dim3(g), dim3(256), 0, h->stream, N, j + 1, V, hcol2, w, ks);
-      FCCHK(multidot(1, w, w, norm2));
-      hipLaunchKernelGGL(fc_gmres_givens, dim3(1), dim3(1), 0, h->stream, j, m, gm, ks, h->rtol);
-      hipLaunchKernelGGL(fc_scale_by_norm, dim3(g), dim3(256), 0, h->stream, N, w, norm2, V + (size_t)(j + 1) * N, ks);
+      if (use_graph) {
+        hipGraphExec_t& gx = KG.step[(size_t)j];
+        if (!gx) FCCHK(capture_graph(h, h->stream, &gx, [&]() { return arnoldi(j); }));
+        HIPCHK(hipGraphLaunch(gx, h->stream));
+      } else {
+        FCCHK(arnoldi(j));
+      }
       if ((j + 1) % kKrylovCheck == 0 || j + 1 == m || total + 1 == h->max_iter) {
         FCCHK(krylov_state(h, kh));
         state = kh[KS_STATE];
@@ -2000,6 +2060,7 @@ int fc_destroy(fc_handle h) {
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   batch_drop_graphs(h);
+  krylov_drop_graphs(h, 0), krylov_drop_graphs(h, 1);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
   if (h->pin) (void)hipHostFree(h->pin);
@@ -3230,37 +3291,40 @@ int fc_setup_krylov(fc_handle h, int slot, int32_t sweeps, int method, int32_t m
     P.sweeps = sweeps, P.omega = omega, P.nu = X.nu, P.np = X.np;
     FCCHK(P.vpos.upload(X.vpos, h->stream));
     FCCHK(P.ppos.upload(X.ppos, h->stream));
-    FCCHK(P.F.upload(X.F, h->stream));
+    if (sweeps >= 2) {
+      fcpc::Csr KF = fcpc::fold_jacobi2(X.F, wdinv);
+      for (int& c : KF.ci) c = X.vpos[(size_t)c];  // the product reads the Krylov vector itself
+      KF.ncols = N;
+      FCCHK(P.KF.upload(KF, h->stream));
+    }
+    if (sweeps >= 3) FCCHK(P.F.upload(X.F, h->stream));
     FCCHK(P.B.upload(X.B, h->stream));
     FCCHK(P.Bt.upload(X.Bt, h->stream));
     FCCHK(P.dinvF.upload(dinv, h->stream));
     FCCHK(P.wdinvF.upload(wdinv, h->stream));
     FCCHK(P.u0.alloc((size_t)X.nu));
     FCCHK(P.u1.alloc((size_t)X.nu));
-    P.bytes = P.F.bytes() + P.B.bytes() + P.Bt.bytes() + 4 * ((int64_t)X.nu + X.np) + 8 * 4 * (int64_t)X.nu;
+    FCCHK(P.zp.alloc((size_t)std::max(1, X.np)));
+    P.bytes = P.KF.bytes() + P.F.bytes() + P.B.bytes() + P.Bt.bytes() + 4 * ((int64_t)X.nu + X.np) + 8 * (4 * (int64_t)X.nu + X.np);
     P.level_rows.clear();
     P.lv.resize(H.levels.size());
     for (size_t l = 0; l < H.levels.size(); ++l) {
       PcLevel& V = P.lv[l];
       const fcpc::Level& G = H.levels[l];
       V.n = G.A.nrows;
-      FCCHK(V.A.upload(G.A, h->stream));
-      FCCHK(V.P.upload(G.P, h->stream));
-      FCCHK(V.R.upload(G.R, h->stream));
-      FCCHK(V.wdinv.upload(G.wdinv, h->stream));
-      FCCHK(V.x.alloc((size_t)V.n));
-      FCCHK(V.r.alloc((size_t)V.n));
-      FCCHK(V.t.alloc((size_t)V.n));
-      P.bytes += V.A.bytes() + V.P.bytes() + V.R.bytes() + 8 * 4 * (int64_t)V.n;
+      V.n_next = G.P.ncols;
+      FCCHK(V.G.upload(fcpc::fold_down(G), h->stream));
+      FCCHK(V.U.upload(fcpc::fold_up(G), h->stream));
+      FCCHK(V.cat.alloc((size_t)V.n + V.n_next));
+      P.bytes += V.G.bytes() + V.U.bytes() + 8 * ((int64_t)V.n + V.n_next);
       P.level_rows.push_back(V.n);
     }
     P.n_coarse = H.n_coarse;
     P.level_rows.push_back(H.n_coarse);
     FCCHK(P.cinv.upload(H.coarse_inv, h->stream));
-    FCCHK(P.xc.alloc((size_t)std::max(1, H.n_coarse)));
     FCCHK(P.rc.alloc((size_t)std::max(1, H.n_coarse)));
-    P.bytes += 8 * ((int64_t)H.n_coarse * H.n_coarse + 2 * H.n_coarse);
-    P.launches = sweeps + 4 + 5 * (int)H.levels.size();
+    P.bytes += 8 * ((int64_t)H.n_coarse * H.n_coarse + H.n_coarse);
+    P.launches = std::max(1, sweeps - 1) + 3 + 2 * (int)H.levels.size();
     HIPCHK(hipStreamSynchronize(h->stream));  // the host vectors above go out of scope
     (void)s_nnz;
     P.ready = true;
@@ -5104,24 +5168,6 @@ static void batch_drop_graphs(fc_ctx* h) {
       h->bat.gside_sig[ph][e] = 0;
     }
   h->bat.pre_slot = -1;
-}
-
-static int capture_graph(fc_ctx* h, hipStream_t stream, hipGraphExec_t* gx, const std::function<int()>& launches) {
-  if (*gx) (void)hipGraphExecDestroy(*gx);
-  *gx = nullptr;
-  hipGraph_t graph = nullptr;
-  HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-  const int code = launches();
-  const hipError_t e = hipStreamEndCapture(stream, &graph);
-  if (code != FC_OK) {
-    if (graph) (void)hipGraphDestroy(graph);
-    return code;
-  }
-  if (e != hipSuccess) return fail(FC_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-  const hipError_t e2 = hipGraphInstantiate(gx, graph, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(graph);
-  if (e2 != hipSuccess) return fail(FC_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2));
-  return FC_OK;
 }
 
 static int batch_enqueue(fc_ctx* h, int order_slot, int compute_energy, bool overlapped) {

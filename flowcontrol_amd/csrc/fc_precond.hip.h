@@ -5,12 +5,13 @@
 //     out[opos(i)] = base[i] + scale * dinv[i] * ( rhs[rpos(i)] - sum_j M[i][j] x[j] )
 //
 // with any of base / dinv / rhs / M absent (0 / 1 / 0 / 0) and optional gather (rpos) and scatter (opos) index lists:
-//   Jacobi first sweep   u  = w D^-1 r_u                       (M absent, rhs gathered from the Krylov vector)
-//   Jacobi sweep         u' = u + w D^-1 (r_u - F u)
+//   velocity sweeps      u  = K_F in                           (two damped-Jacobi sweeps folded into ONE product on the host,
+//                                                               K_F = Wd (2 I - F Wd), its columns address the Krylov vector)
+//   further sweeps       u' = u + w D^-1 (r_u - F u)
 //   Schur right-hand side   = B u - r_p                        (scale = -1)
-//   AMG pre-smoothing    x  = w D^-1 r ; residual t = r - A x ; restriction r_c = R t (scale = -1, rhs absent)
-//   AMG prolongation     x += P x_c (scale = -1, base = x, in place: a row reads x_c only) ; post-smoothing as the Jacobi sweep
-//   velocity update      z_u = u - D^-1 Bt z_p                 (scattered into the Krylov vector)
+//   AMG level, down      r_c = G r,  G = R (I - A Wd)          (pre-smoothing + residual + restriction folded)
+//   AMG level, up        z = U [r ; z_c],  U = [Wd (2 I - A Wd) | (I - Wd A) P]   (prolongation + post-smoothing folded)
+// plus fc_pc_final (velocity update z_u = u - D^-1 Bt z_p and the scatter of (z_u, z_p) into the Krylov vector) and fc_pc_dense.
 // fp64 throughout; LANES lanes per row with the predicated 4-deep issue of fc_spmv_csr.  The matrices are small (the
 // pressure Schur complement has nv rows, its AMG levels shrink by ~8 each) and every launch is latency-bound: what
 // matters is the number of launches, not their bytes -- DESIGN.md section 4.1.
@@ -75,4 +76,23 @@ __global__ __launch_bounds__(256) void fc_pc_dense(int n, const double* __restri
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   if (lane == 0) x[row] = s;
+}
+
+// last launch of an apply: out[vpos[i]] = u[i] - dinv[i] (Bt zp)[i] for the velocity rows, out[ppos[j]] = zp[j] for the pressure rows
+// (4 lanes per row: a row of Bt has 2-4 entries)
+__global__ __launch_bounds__(256) void fc_pc_final(int nu, int np, const int* __restrict__ rp, const int* __restrict__ ci, const double* __restrict__ v,
+                                                   const double* __restrict__ zp, const double* __restrict__ dinv, const double* __restrict__ u,
+                                                   const int* __restrict__ vpos, const int* __restrict__ ppos, double* __restrict__ out) {
+  const int lane = threadIdx.x & 3;
+  const int row = blockIdx.x * 64 + (threadIdx.x >> 2);
+  if (row >= nu + np) return;
+  if (row >= nu) {
+    if (lane == 0) out[ppos[row - nu]] = zp[row - nu];
+    return;
+  }
+  double s = 0.0;
+  for (int k = rp[row] + lane; k < rp[row + 1]; k += 4) s += v[k] * zp[ci[k]];
+  s += __shfl_down(s, 2, 4);
+  s += __shfl_down(s, 1, 4);
+  if (lane == 0) out[vpos[row]] = u[row] - dinv[row] * s;
 }

@@ -250,6 +250,58 @@ inline Amg build_amg(Csr A0, double theta = 0.08, int coarse_max = 256, int max_
   return H;
 }
 
+// One V(1,1)-cycle needs only TWO sparse products per level when the damped-Jacobi smoothers are folded into the transfer
+// operators on the host (every launch of the apply is latency-bound, so launches are what counts):
+//   down:  r_c = R (r - A Wd r)                           = G r,          G = R (I - A Wd)
+//   up:    z   = x2 + Wd (r - A x2),  x2 = Wd r + P z_c   = K r + Q z_c,  K = Wd (2 I - A Wd),  Q = (I - Wd A) P
+// U = [K | Q] acts on the concatenated vector [r ; z_c] (the device keeps the two halves next to each other).
+inline Csr fold_down(const Level& L) {
+  Csr M = L.A;  // I - A Wd
+  for (int i = 0; i < M.nrows; ++i)
+    for (int k = M.rp[(size_t)i]; k < M.rp[(size_t)i + 1]; ++k) {
+      const int j = M.ci[(size_t)k];
+      M.v[(size_t)k] = (i == j ? 1.0 : 0.0) - M.v[(size_t)k] * L.wdinv[(size_t)j];
+    }
+  return spgemm(L.R, M);
+}
+inline Csr fold_up(const Level& L) {
+  const int n = L.A.nrows, nc = L.P.ncols;
+  const Csr AP = spgemm(L.A, L.P);
+  Csr U;
+  U.nrows = n, U.ncols = n + nc;
+  U.rp.assign((size_t)n + 1, 0);
+  for (int i = 0; i < n; ++i) {
+    const double w = L.wdinv[(size_t)i];
+    for (int k = L.A.rp[(size_t)i]; k < L.A.rp[(size_t)i + 1]; ++k) {  // K = Wd (2 I - A Wd)
+      const int j = L.A.ci[(size_t)k];
+      U.ci.push_back(j), U.v.push_back(w * ((i == j ? 2.0 : 0.0) - L.A.v[(size_t)k] * L.wdinv[(size_t)j]));
+    }
+    // Q = P - Wd (A P): the pattern of A P contains the pattern of P (the diagonal of A is not zero)
+    int q = L.P.rp[(size_t)i];
+    const int q1 = L.P.rp[(size_t)i + 1];
+    for (int k = AP.rp[(size_t)i]; k < AP.rp[(size_t)i + 1]; ++k) {
+      const int c = AP.ci[(size_t)k];
+      double val = -w * AP.v[(size_t)k];
+      while (q < q1 && L.P.ci[(size_t)q] < c) U.ci.push_back(n + L.P.ci[(size_t)q]), U.v.push_back(L.P.v[(size_t)q]), ++q;
+      if (q < q1 && L.P.ci[(size_t)q] == c) val += L.P.v[(size_t)q], ++q;
+      U.ci.push_back(n + c), U.v.push_back(val);
+    }
+    for (; q < q1; ++q) U.ci.push_back(n + L.P.ci[(size_t)q]), U.v.push_back(L.P.v[(size_t)q]);
+    U.rp[(size_t)i + 1] = (int)U.ci.size();
+  }
+  return U;
+}
+// two damped-Jacobi sweeps on F u = r from u = 0 as ONE product: u = Wd (2 I - F Wd) r
+inline Csr fold_jacobi2(const Csr& F, const std::vector<double>& wd) {
+  Csr K = F;
+  for (int i = 0; i < K.nrows; ++i)
+    for (int k = K.rp[(size_t)i]; k < K.rp[(size_t)i + 1]; ++k) {
+      const int j = K.ci[(size_t)k];
+      K.v[(size_t)k] = wd[(size_t)i] * ((i == j ? 2.0 : 0.0) - K.v[(size_t)k] * wd[(size_t)j]);
+    }
+  return K;
+}
+
 // The blocks of the saddle-point operator in COMPACT numberings (velocity dofs / pressure dofs, each in the order of their
 // permuted positions), from the handle's CSR in W numbering.  Exact zeros (the rows / columns the symmetric Dirichlet
 // elimination emptied) are dropped.
