@@ -20,6 +20,8 @@ One JSON line on rank 0 with the driver's keys plus
                 (replicas_steps_per_s, bytes per simulated step, roofline of the batched factor sweeps)
   spmv          CSR SpMV probe on the assembled BDF2 matrices of the five shipped meshes (O1: the run's own matrix; the
                 others with a synthetic uniform base flow; cavity_fine is the one beyond the Infinity Cache), % of 8 TB/s
+  krylov_factor_free  N = 1: the same public loop with NO factorisation (fc_setup_krylov: GMRES + SIMPLE / AMG preconditioner):
+                iterations per step, steps/s, device bytes held
   other_configs N = 1: BASELINE configs 4 / 5 / 3 (refined cylinder, pinball closed loop, cavity_fine closed loop) on this GPU —
                 steps/s of the synchronous public loop, the factor sweeps' roofline from their own bytes and HIP-event time (cavity_fine
                 streams 4.7 GB of factors per step from HBM: the true HBM-streaming evidence), phase split, fc_refactor ms
@@ -281,12 +283,10 @@ def _make_pinball(device, shared):
 
 
 def _pinball_controller(fs):
-    """Three sensors → 3-in / 3-out LTI controller → three rotating cylinders (tests/golden/make_config45_fixtures.py's system; its
+    """Three sensors → 3-in / 3-out LTI controller → three rotating cylinders (flowcontrol_amd/examples/pinball/scenarios.py: the system of the golden fixture; its
     output gain, sized for the first 50 steps, is scaled down so that a long run stays a small-amplitude closed loop)."""
-    sys.path.insert(0, str(GOLDEN))
-    from make_config45_fixtures import PINBALL_K
-
     from flowcontrol_amd.controller import Controller
+    from flowcontrol_amd.examples.pinball.scenarios import PINBALL_K
 
     K = Controller(A=PINBALL_K["A"], B=PINBALL_K["B"], C=PINBALL_K["C"] / 2.0e6, D=PINBALL_K["D"])
     y0, dt = fs.y_meas.copy(), fs.params_time.dt
@@ -409,6 +409,41 @@ def run_case(case, comm, device, steps, with_roofline):
     return out
 
 
+def krylov_factor_free(device: int, steps: int, factor_bytes: int | None) -> dict:
+    """The Krylov mode that factorises NOTHING (fc_setup_krylov: device GMRES right-preconditioned by the SIMPLE / AMG block
+    preconditioner) on the headline workload: iterations per step, steps/s of the same public loop, device bytes held."""
+    from flowcontrol_amd._lib import SLOT_BDF2
+    from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver
+    from flowcontrol_amd.fem.spaces import Function
+    from flowcontrol_amd.flowsolverparameters import ParamIC
+
+    fs = CylinderFlowSolver.make_default(Re=100, path_out=tempfile.mkdtemp(prefix="fc_bench_"), num_steps=0, save_every=0)
+    fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
+    fs.krylov_precond, fs.krylov_method, fs.krylov_max_iter, fs.krylov_rtol = "schur_amg", "gmres", 300, 1e-10
+    fs.th.device(device)
+    U0, P0 = Function(fs.W, np.load(GOLDEN / "cylinder_O1.npz")["UP0"]).split()
+    fs._assign_steady_state(U0, P0)
+    fs.initialize_time_stepping(ic=None)
+    u0 = np.zeros(2)
+    for _ in range(5):
+        fs.step(u0)
+    its, res = [], []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fs.step(u0)
+        its.append(int(fs.solve_info[0])), res.append(float(fs.solve_info[1]))
+    dt = time.perf_counter() - t0
+    info = fs.th.device().krylov_info(SLOT_BDF2)
+    out = {"preconditioner": f"SIMPLE: {info['jacobi_sweeps']} damped-Jacobi sweeps on the velocity block + one smoothed-aggregation AMG V(1,1)-cycle on "
+                             f"B diag(F)^-1 Bt ({info['amg_levels']} levels, coarsest {info['coarsest_rows']} rows), right-preconditioned GMRES, warm start; nothing is factorised",
+           "rtol": fs.krylov_rtol, "steps": steps, "iterations_per_step": float(np.mean(its)), "iterations_max": int(np.max(its)),
+           "steps_per_s": steps / dt, "ms_per_step": 1e3 * dt / steps, "rel_residual_max": float(np.max(res)),
+           "bytes_held": info["bytes"], "launches_per_precond_apply": info["launches_per_apply"], "setup_ms": info["setup_ms"],
+           "factor_bytes_of_the_direct_mode": factor_bytes, "y_last": fs.y_meas.tolist()}
+    fs.th.release_device()
+    return out
+
+
 def headline(comm, device, args):
     """The driver's contract: W untimed warm-up steps, EXACTLY K timed steps between barrier + synchronize, max over ranks."""
     import torch
@@ -494,7 +529,7 @@ def run_rank(comm, args, device):
         comm.barrier()
 
     result = None
-    roofline = phases = spmv = cpu = replicas = other = None
+    roofline = phases = spmv = cpu = replicas = other = kff = None
     t_batched = None
     depth_str = None
     if rank == 0 and not args.no_extras:
@@ -517,6 +552,8 @@ def run_rank(comm, args, device):
         mean_launch_ms = tim["sweep_ms"] / max(tim["sweep_launches"], 1)
         bytes_per_launch = sweep_bytes / n_stage
         achieved = bytes_per_launch / mean_launch_ms / 1e6  # GB/s
+        apply_us = 1e3 * tim["sweep_ms"] / max(applies, 1)
+        tree = dev.tree_info(min_tree=True)
         traffic, traffic_commit = None, None
         tfile = ROOT / "profiles" / "traffic.json"  # PMC passes of the DEFAULT workload (scripts/profile_gpu.sh)
         if tfile.exists() and REFINE == 0 and not partitioned:
@@ -534,7 +571,14 @@ def run_rank(comm, args, device):
             "mean_launch_us": mean_launch_ms * 1e3, "factor_nnz": dev.factor_nnz.get(SLOT_BDF2),
             "applies_per_step": applies / args.steps,
             # bisections fused per level of the elimination tree, root first (the default shape of this mesh: ndsolver.default_bits; 2 x levels + 1 launches)
-            "tree_bits": __import__("flowcontrol_amd.ndsolver", fromlist=["default_bits"]).default_bits(fs.th.nc, 2, 0) if not REFINE else None,
+            "tree_bits": tree["bits"],
+            # fractions that stay comparable across rounds (the design's own byte count grows with the fill of the tree it picks): the
+            # apply's wall time per call, the same time priced at 8 B per stored factor value only, and at the bytes of the
+            # all-binary-pairs tree [2,2,...] of the same depth (the shape with the least fill; bytes scaled by the ratio of factor values)
+            "apply_us": apply_us,
+            "frac_values_only": 8.0 * dev.factor_nnz.get(SLOT_BDF2) / (apply_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "frac_min_tree": (sweep_bytes * tree["nnz_min_tree"] / dev.factor_nnz.get(SLOT_BDF2)) / (apply_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "factor_nnz_min_tree": tree["nnz_min_tree"],
             "spmv_in_step": ({"bytes": spmv_bytes, "mean_us": 1e3 * tim["spmv_ms"] / tim["spmv_launches"],
                               "GB/s": spmv_bytes / (tim["spmv_ms"] / tim["spmv_launches"]) / 1e6}
                              if tim["spmv_launches"] and tim["spmv_ms"] > 0 else
@@ -555,7 +599,14 @@ def run_rank(comm, args, device):
             cpu = cpu_baseline(fs)
             cpu.pop("_y_last"), cpu.pop("_dE_last")
         depth_str = f"ND selected-inverse depth {dev.depth}, {fs.refine_steps} refinement"
+        factor_bytes = 8 * int(dev.factor_nnz.get(SLOT_BDF2) or 0)
         fs.th.release_device()
+        if world == 1 and not args.no_krylov:
+            try:
+                kff = krylov_factor_free(device, min(args.steps, 200), factor_bytes)
+            except Exception as err:
+                kff = {"error": repr(err)}
+                log(f"krylov_factor_free failed: {err!r}")
         if world == 1 and not args.no_other_configs and REFINE == 0:
             # BASELINE configs 3 / 4 / 5 on this GPU, in the driver-timed run: closed-loop steps/s, the factor sweeps' roofline from
             # their own bytes and HIP-event time, the step's phase split (tail = fc_tail + fc_final), fc_refactor milliseconds
@@ -610,8 +661,12 @@ def run_rank(comm, args, device):
             "spmv": spmv,
             "cpu_baseline": cpu,
             "speedup_vs_cpu_baseline": (value / cpu["value"]) if cpu else None,
+            "krylov_factor_free": kff,
             "solve_rel_residual_pre_refine": resid_last,
             "y_last": y_last.tolist(),
+            # compact copy of other_configs at the END of the line (a log tail that cuts the long line still shows it): [steps/s, sweep roofline fraction]
+            "other_configs_summary": ({k: ([round(v["steps_per_s"], 1), round(v["roofline"]["frac"], 3)] if "error" not in v else "error")
+                                       for k, v in other.items()} if other else None),
         }
     comm.barrier()
     return result
@@ -634,6 +689,7 @@ def main() -> None:
     ap.add_argument("--no-replicas", action="store_true", help="skip the batched-replicas section (profiling passes of the single-simulation step)")
     ap.add_argument("--no-extras", action="store_true", help="skip rank 0's single-GPU extras (roofline replay, SpMV probe, batched replicas, CPU baseline)")
     ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the BASELINE config 3 / 4 / 5 section")
+    ap.add_argument("--no-krylov", action="store_true", help="N = 1: skip the factorisation-free Krylov leg")
     ap.add_argument("--skip", default="", help="comma-separated legs to leave out: config3,config4,config5")
     ap.add_argument("--no-config4", action="store_true", help="N > 1: skip the strong-scaling leg on the BASELINE config-4 mesh (same as --skip config4)")
     ap.add_argument("--refine", type=int, default=0, help="red-refine the O1 mesh K times (BASELINE config 4: K=1); not the headline workload")

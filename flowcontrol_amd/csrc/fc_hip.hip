@@ -227,6 +227,7 @@ struct fc_ctx {
   // symbolic phase done inside the library (fc_setup_solver): kept for the second slot and for the getters
   bool sym_ready = false;
   int sym_truncate = 0;
+  std::vector<int> sym_bits;  // bisections fused per level of sym_tree, root first
   fcsym::Tree sym_tree;
   fcsym::Factors sym_fac;
   fcsym::Plan sym_plan;
@@ -3122,6 +3123,7 @@ int fc_setup_solver(fc_handle h, int slot, int32_t depth, int32_t merge, int32_t
     }
     if (!h->sym_ready) {
       const std::vector<int> bits = depth == 0 ? fcsym::default_bits(h->nc, merge, top) : fcsym::uniform_bits(depth, merge, top);
+      h->sym_bits = bits;
       std::vector<unsigned char> skip((size_t)N, 0);
       for (int k = 0; k < h->n_bc; ++k) skip[(size_t)h->h_bc_dofs[k]] = 1;
       h->sym_tree = fcsym::build_tree(h->h_cell_dofs, 15, h->h_cent, h->nc, N, bits, &skip, top);
@@ -3606,6 +3608,31 @@ int fc_get_solver_info(fc_handle h, int slot, int64_t* info) {
   info[7] = S.ar2_stage;
   info[8] = h->partitioned ? h->ncl : h->nc;
   info[9] = h->sym_ready ? h->sym_truncate : 0;
+  return FC_OK;
+}
+
+// Shape of the handle's elimination tree (bench / documentation): bits_out[<= 16] = bisections fused per level, root first (the tree of
+// fc_setup_solver if it ran, else the default shape for this mesh); nnz_min_tree (optional) = factor values of the all-binary-pairs
+// tree [2, 2, ...] with the same number of bisections -- the layout with the least fill among the shapes fc_setup_solver chooses from,
+// the fixed denominator of bench.py's roofline.frac_min_tree (one symbolic pass on the host, ~0.1 s on O1).
+int fc_get_tree_info(fc_handle h, int32_t* bits_out, int32_t* n_bits, int64_t* nnz_min_tree) {
+  if (!h || !bits_out || !n_bits) return fail(FC_ERR_INVALID, "fc_get_tree_info: bad argument");
+  const std::vector<int> bits = h->sym_ready && !h->sym_bits.empty() ? h->sym_bits : fcsym::default_bits(h->nc, 2, 0);
+  if (bits.size() > 16) return fail(FC_ERR_INVALID, "fc_get_tree_info: more than 16 tree levels");
+  *n_bits = (int32_t)bits.size();
+  for (size_t i = 0; i < bits.size(); ++i) bits_out[i] = bits[i];
+  if (nnz_min_tree) {
+    try {
+      int sum = 0;
+      for (int b : bits) sum += b;
+      std::vector<unsigned char> skip((size_t)h->N, 0);
+      for (int k = 0; k < h->n_bc; ++k) skip[(size_t)h->h_bc_dofs[k]] = 1;
+      const fcsym::Tree t = fcsym::build_tree(h->h_cell_dofs, 15, h->h_cent, h->nc, h->N, fcsym::uniform_bits(sum, 2, 0), &skip, 0);
+      *nnz_min_tree = fcsym::layout_factors(t, nullptr).nnz;
+    } catch (const std::exception& e) {
+      return fail(FC_ERR_INVALID, std::string("fc_get_tree_info: ") + e.what());
+    }
+  }
   return FC_OK;
 }
 

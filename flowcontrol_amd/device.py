@@ -512,7 +512,7 @@ class DeviceSolver:
         m = {"refine": _lib.METHOD_REFINE, "bicgstab": _lib.METHOD_BICGSTAB, "gmres": _lib.METHOD_GMRES}[method]
         check(self.lib.fc_set_solver_options(self._h, m, int(refine), float(rtol), int(check_residual)))
 
-    def setup_krylov(self, slot: int, sweeps: int = 3, method: str = "gmres", max_iter: int = 200, rtol: float = 1e-10,
+    def setup_krylov(self, slot: int, sweeps: int = 2, method: str = "gmres", max_iter: int = 200, rtol: float = 1e-10,
                      check_residual: bool | int = True) -> dict:
         """Factorisation-free solver setup of ``slot`` (``fc_setup_krylov``): nothing is factorised; solves and time steps run
         the device GMRES / BiCGStab right-preconditioned by the SIMPLE / AMG block preconditioner (``sweeps`` damped-Jacobi
@@ -528,6 +528,14 @@ class DeviceSolver:
             check(self.lib.fc_get_permutation(self._h, self.perm))
         self.factor_nnz[slot] = 0
         return self.krylov_info(slot)
+
+    def tree_info(self, min_tree: bool = False) -> dict:
+        """Bisections fused per level of the elimination tree (root first) and, on request, the factor values of the
+        all-binary-pairs tree of the same depth (``fc_get_tree_info``)."""
+        bits, n = np.zeros(16, dtype=np.int32), C.c_int32()
+        nnz = C.c_int64(-1)
+        check(self.lib.fc_get_tree_info(self._h, bits, C.byref(n), C.cast(C.byref(nnz), C.c_void_p) if min_tree else None))
+        return {"bits": [int(b) for b in bits[: n.value]], "nnz_min_tree": int(nnz.value) if min_tree else None}
 
     def krylov_info(self, slot: int) -> dict:
         """What ``setup_krylov`` holds on the device for ``slot``."""

@@ -113,7 +113,7 @@ class FlowSolver(ABC):
         #: right-preconditioned by the SIMPLE / AMG block preconditioner (``krylov_sweeps`` damped-Jacobi sweeps on the velocity
         #: block + one algebraic-multigrid V-cycle on the pressure Schur complement); memory O(nnz).  None = factors (default)
         self.krylov_precond: str | None = None
-        self.krylov_sweeps: int = 3
+        self.krylov_sweeps: int = 2
         #: multi-GPU: who the ranks are (flowcontrol_amd.comm.Comm); None = the torch.distributed process group of this process, if any
         self.comm = None
         #: set when the in-library RCCL communicator could not be created and the exchanges were staged through the host instead

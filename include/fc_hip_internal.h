@@ -116,6 +116,11 @@ int fc_get_timing(fc_handle h, double* sweep_ms, int64_t* sweep_launches, double
 /* algorithmic bytes of one factor apply (sum over sweep launches) and of one CSR SpMV */
 int fc_algorithmic_bytes(fc_handle h, int slot, double* sweep_bytes, double* spmv_bytes);
 
+/* shape of the handle's elimination tree: bits_out[<= 16] = bisections fused per tree level, root first (fc_setup_solver's tree, or the
+ * default shape of this mesh before it ran); nnz_min_tree (optional, one host symbolic pass): factor values of the all-binary-pairs tree
+ * [2, 2, ...] of the same depth -- the fixed denominator of bench.py's roofline.frac_min_tree */
+int fc_get_tree_info(fc_handle h, int32_t* bits_out /* [16] */, int32_t* n_bits, int64_t* nnz_min_tree);
+
 /* the multi-GPU partition as arrays (fc_setup_solver derives and applies it itself on a handle with an exchange): this rank's
  * cells and rowkind[N] (W numbering): 0 = other rank's dof, 1 = owned, 2 = root separator (replicated) */
 int fc_set_partition(fc_handle h, int32_t n_local_cells, const int32_t* local_cells,

@@ -262,7 +262,7 @@ def test_batched_cavity_force_actuation_closed_loop(golden_dir):
     import sys
 
     sys.path.insert(0, str(golden_dir))
-    from make_config3_fixture import CAVITY_K
+    from flowcontrol_amd.examples.cavity.scenarios import CAVITY_K
 
     from flowcontrol_amd.batch import BatchedFlowSolver
     from flowcontrol_amd.examples.cavity.cavityflowsolver import CavityFlowSolver

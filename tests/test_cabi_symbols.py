@@ -70,6 +70,30 @@ def test_product_never_imports_the_oracle():
         assert "import oracle" not in src and "from oracle" not in src, f"{py} imports the oracle"
 
 
+def test_bench_touches_the_oracle_only_in_its_cpu_baseline_leg():
+    """bench.py may import the oracle inside cpu_baseline / _cpu_baseline_1core only, and nothing from the fixture generators
+    under tests/golden (they import the oracle at module level): every other leg measures the product alone."""
+    import ast
+
+    tree = ast.parse((ROOT / "bench.py").read_text())
+    allowed = {"cpu_baseline", "_cpu_baseline_1core"}
+
+    def imports(node):
+        for sub in ast.walk(node):
+            if isinstance(sub, ast.Import):
+                yield from (a.name for a in sub.names)
+            elif isinstance(sub, ast.ImportFrom) and sub.module:
+                yield sub.module
+
+    for node in tree.body:
+        names = list(imports(node))
+        where = getattr(node, "name", "<module level>")
+        for mod in names:
+            assert not mod.startswith("make_"), f"bench.py ({where}) imports the fixture generator {mod}"
+            if mod == "oracle" or mod.startswith("oracle."):
+                assert isinstance(node, ast.FunctionDef) and node.name in allowed, f"bench.py ({where}) imports {mod} outside the cpu_baseline leg"
+
+
 def test_a_stale_library_is_never_loaded_silently(monkeypatch, tmp_path):
     """_lib.load(): when the rebuild fails, an existing libfc_hip.so may only be used if it is not older than any of its
     sources (a stale binary under test would void every parity claim); without a library the first call raises."""

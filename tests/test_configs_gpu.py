@@ -46,7 +46,7 @@ def _config4_solver(path_out, num_steps=50):
 
 
 def test_config4_refined_cylinder_base_flow_and_actuated_steps(tmp_path_factory, golden_dir):
-    from make_config45_fixtures import config4_actuation
+    from flowcontrol_amd.examples.cylinder.scenarios import config4_actuation
 
     g = np.load(golden_dir / "cylinder_O1_refined1.npz")
     fs = _config4_solver(tmp_path_factory.mktemp("config4"))
@@ -82,7 +82,7 @@ def _config4_worker(rank, world, port, out, nsteps):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from flowcontrol_amd.fem.spaces import Function
-        from make_config45_fixtures import config4_actuation
+        from flowcontrol_amd.examples.cylinder.scenarios import config4_actuation
 
         g = np.load(ROOT / "tests" / "golden" / "cylinder_O1_refined1.npz")
         fs = _config4_solver(tempfile.mkdtemp(), nsteps)
@@ -141,7 +141,7 @@ def _pinball(path_out):
 
 
 def test_config5_pinball_rotation_open_loop_bumps(tmp_path_factory):
-    from make_config45_fixtures import pinball_bumps
+    from flowcontrol_amd.examples.pinball.scenarios import pinball_bumps
 
     fs, g = _pinball(tmp_path_factory.mktemp("config5_ol"))
     us = []
@@ -163,7 +163,7 @@ def test_config5_pinball_rotation_open_loop_bumps(tmp_path_factory):
 def test_config5_pinball_rotation_closed_loop(tmp_path_factory):
     """Sensors → Controller (ZOH-discretised 3-in / 3-out LTI system) → three rotating cylinders, 50 steps."""
     from flowcontrol_amd.controller import Controller
-    from make_config45_fixtures import PINBALL_K
+    from flowcontrol_amd.examples.pinball.scenarios import PINBALL_K
 
     fs, g = _pinball(tmp_path_factory.mktemp("config5_cl"))
     K = Controller(A=PINBALL_K["A"], B=PINBALL_K["B"], C=PINBALL_K["C"], D=PINBALL_K["D"])
@@ -205,7 +205,8 @@ def test_config3_cavity_fine_closed_loop_vs_oracle(tmp_path_factory, golden_dir)
     from flowcontrol_amd._lib import SLOT_BDF2
     from flowcontrol_amd.controller import Controller
     from flowcontrol_amd.examples.cavity.cavityflowsolver import CavityFlowSolver
-    from make_config3_fixture import CAVITY_K, N_STEPS, SAMPLE_STRIDE
+    from flowcontrol_amd.examples.cavity.scenarios import CAVITY_K
+    from make_config3_fixture import N_STEPS, SAMPLE_STRIDE
     from oracle import ns_oracle as O
 
     g = np.load(golden_dir / "cavity_fine_re7500.npz")

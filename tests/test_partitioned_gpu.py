@@ -250,7 +250,7 @@ def test_rccl_plumbing_on_the_refined_mesh(monkeypatch):
     import sys
 
     sys.path.insert(0, str(ROOT / "tests" / "golden"))
-    from make_config45_fixtures import config4_actuation
+    from flowcontrol_amd.examples.cylinder.scenarios import config4_actuation
 
     from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver, refined_cylinder_mesh
     from flowcontrol_amd.fem.spaces import Function

@@ -60,7 +60,7 @@ def _check_bookkeeping(outs, nc):
 
 
 def _config4_rank(comm, nsteps):
-    from make_config45_fixtures import config4_actuation
+    from flowcontrol_amd.examples.cylinder.scenarios import config4_actuation
 
     from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver, refined_cylinder_mesh
     from flowcontrol_amd.fem.spaces import Function
@@ -96,7 +96,7 @@ def test_config4_refined_cylinder_on_eight_ranks():
 
 
 def _pinball_rank(comm, nsteps):
-    from make_config45_fixtures import PINBALL_K
+    from flowcontrol_amd.examples.pinball.scenarios import PINBALL_K
 
     from flowcontrol_amd.actuator import CYLINDER_ACTUATION_MODE
     from flowcontrol_amd.controller import Controller
@@ -140,7 +140,7 @@ def test_config5_pinball_closed_loop_on_eight_ranks():
 
 
 def _cavity_rank(comm, nsteps):
-    from make_config3_fixture import CAVITY_K
+    from flowcontrol_amd.examples.cavity.scenarios import CAVITY_K
 
     from flowcontrol_amd.controller import Controller
     from flowcontrol_amd.examples.cavity.cavityflowsolver import CavityFlowSolver
