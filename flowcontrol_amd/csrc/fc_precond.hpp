@@ -12,11 +12,12 @@
 // hierarchy built from the assembled values alone (no mesh knowledge, no boundary-condition guesswork: S is formed
 // algebraically from the eliminated operator).  Nothing here factorises anything but the coarsest AMG level (<= 256 dofs,
 // dense inverse).  Everything in this file is index / setup work on the host; the applies are device kernels
-// (fc_pc_csr / fc_pc_dense in fc_kernels.hip.h).
+// (fc_pc_csr / fc_pc_dense / fc_pc_final in fc_precond.hip.h).
 //
-// Measured on the cylinder O1 BDF2 operator (56 203 dofs), GMRES to 1e-10 from a zero guess (profiles/EXPERIMENTS.md III):
-// additive Vanka patches alone stall (1000 iterations -> 4e-9), block-triangular with one Jacobi sweep 47, SIMPLE with one
-// sweep 33, SIMPLE with three sweeps 18 (exact S^-1) / ~21 (one V-cycle).
+// Measured on the cylinder O1 BDF2 operator (56 203 dofs), GMRES to 1e-10 from a zero guess (tests/support/precond_study.py,
+// profiles/r05_precond_study.txt): additive Vanka patches alone need ~750 iterations, block-triangular with one Jacobi sweep 47,
+// SIMPLE with one sweep 33 / two sweeps 20 (exact S^-1), SIMPLE with two sweeps and one V-cycle 31; on the device, inside time
+// steps (warm start) 18.6 per step.
 #pragma once
 #include <algorithm>
 #include <cmath>
