@@ -107,6 +107,8 @@ SIGNATURES: dict[str, list] = {
     "fc_solver_set_blocks": [_H, C.c_int, C.c_int32, _lp, _ip, _ip, C.c_int64, _lp, _ip, _ip, _ip, _ip, _ip, _ip, C.c_int64, C.c_int64],
     "fc_set_solver_options": [_H, C.c_int, C.c_int, C.c_double, C.c_int],
     "fc_get_tree_info": [_H, _ip, C.POINTER(C.c_int32), C.c_void_p],
+    "fc_comm_probe": [C.c_int],
+    "fc_comm_destroy": [_H],
     "fc_setup_krylov": [_H, C.c_int, C.c_int32, C.c_int, C.c_int32, C.c_double, C.c_int32],
     "fc_get_krylov_info": [_H, C.c_int, _lp, C.POINTER(C.c_double)],
     "fc_set_state": [_H, _dp, _dp, C.c_void_p],

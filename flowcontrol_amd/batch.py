@@ -151,16 +151,26 @@ class BatchedFlowSolver:
         self._pending = (self.t, self._u_ctrl_prev, y, want_energy, (time.time() - t0) / k, self.iter)
         if np.any(newly) and fs.params_solver.throw_error:
             raise RuntimeError(f"Failed solving: Inf found in solution (runs {np.flatnonzero(newly).tolist()}; the other runs go on)")
-        breach = self._breach
-        if breach is not None:
-            # the residual monitor's verdict on a step arrives with the next step at the latest (broken factors: all runs share them)
-            self._breach = None
-            msg = f"linear solve residual {breach[0]:.2e} exceeds residual_tol = {self.residual_tol:.1e} at iteration {breach[1]}"
-            logger.critical(msg)
-            if fs.params_solver.throw_error:
-                raise RuntimeError(msg)
+        # the residual monitor's verdict on a step arrives with the next step at the latest (broken factors: all runs share them)
+        if self._report_breach():
             return None
         return self.y_meas
+
+    def _report_breach(self) -> bool:
+        """A pending verdict of the residual monitor: logged, raised when ``throw_error`` is set; ``self.breached`` remembers it (a breach
+        on the LAST step of a run surfaces through ``timeseries`` / ``close``, which call this)."""
+        breach = self._breach
+        if breach is None:
+            return False
+        self._breach = None
+        self.breached = True
+        msg = f"linear solve residual {breach[0]:.2e} exceeds residual_tol = {self.residual_tol:.1e} at iteration {breach[1]}"
+        logger.critical(msg)
+        if self.fs.params_solver.throw_error:
+            raise RuntimeError(msg)
+        return True
+
+    breached = False  # the residual monitor has rejected a step of this batch (broken factors: no run's results are to be trusted)
 
     _pending = None
     _breach = None
@@ -192,6 +202,7 @@ class BatchedFlowSolver:
     def timeseries(self, i: int) -> pd.DataFrame:
         """Log of run ``i``: the columns and rows ``FlowSolver.timeseries`` gives for a single run."""
         self._flush()
+        self._report_breach()
         t0, y0, dE0 = self._log_ic
         ex = FlowExporter(paths=self.fs.paths, fields=self.fs.fields, V=self.fs.V, P=self.fs.P, Tstart=t0, dt=self.params_time.dt, save_every=0)
         ex.log_ic(t=t0, y_meas=y0[i], dE=dE0[i])
@@ -210,9 +221,12 @@ class BatchedFlowSolver:
 
     def close(self) -> None:
         if self._ready:
-            self._flush()
-            self.dev.set_batch(0)
-            self._ready = False
+            try:
+                self._flush()
+                self._report_breach()
+            finally:
+                self.dev.set_batch(0)
+                self._ready = False
 
 
 __all__ = ["BatchedFlowSolver"]

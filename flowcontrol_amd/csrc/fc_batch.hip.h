@@ -656,18 +656,21 @@ __global__ __launch_bounds__(256) void fc_early_b(int n_sens, const int* __restr
 }
 // gate of the batched side stream: as fc_wait_solved, the sequence number read from the step's slot of the mapped record (graph replay:
 // no per-step kernel argument)
-__global__ void fc_wait_solved_b(const unsigned long long* __restrict__ solved, const double* __restrict__ seq_in, int* __restrict__ gave_up) {
+__global__ void fc_wait_solved_b(const unsigned long long* __restrict__ solved, const double* __restrict__ seq_in, int* __restrict__ gave_up, long max_spin) {
   const unsigned long long seq = (unsigned long long)seq_in[0];
-  for (long spin = 0; spin < 2000000L; ++spin) {
-    if (__hip_atomic_load(solved, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= seq) return;
+  for (long spin = 0; spin < max_spin; ++spin) {
+    if (__hip_atomic_load(solved, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= seq) {
+      *gave_up = 0;
+      return;
+    }
     __builtin_amdgcn_s_sleep(8);
   }
   *gave_up = 1;
 }
-// late record of simulation s = blockIdx.x: rec[0] = E, [1] = sum r^2, [2] = sum b^2, [3] = seq, [4], [5] = checksums
+// late record of simulation s = blockIdx.x: rec[0] = E, [1] = sum r^2, [2] = sum b^2, [3] = seq, [4], [5] = checksums, [6] = the gate gave up
 template <int KB>
 __global__ __launch_bounds__(1024) void fc_final_late_b(int G, int n_row_blocks, const double* __restrict__ partial, double* __restrict__ rec, int rstride,
-                                                        int rec_off, const double* __restrict__ seq_in, int compute_energy) {
+                                                        int rec_off, const double* __restrict__ seq_in, int compute_energy, const int* __restrict__ gave_up) {
   const int s = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
   __shared__ double red[3][16];
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
@@ -710,11 +713,11 @@ __global__ __launch_bounds__(1024) void fc_final_late_b(int G, int n_row_blocks,
     }
     typedef unsigned long long u64;
     const double seq = seq_in[0];
-    const double v[3] = {compute_energy ? 0.5 * r2 : 0.0, r0, r1};
+    const double v[4] = {compute_energy ? 0.5 * r2 : 0.0, r0, r1, (gave_up && *gave_up) ? 1.0 : 0.0};
     double* r = rec + (size_t)s * rstride + rec_off;
     u64 x = (u64)__double_as_longlong(seq), w = x, k = 3;
-    for (int i = 0; i < 3; ++i, k += 2) {
-      r[i] = v[i];
+    for (int i = 0; i < 4; ++i, k += 2) {
+      r[i < 3 ? i : 6] = v[i];
       x ^= (u64)__double_as_longlong(v[i]);
       w += k * (u64)__double_as_longlong(v[i]);
     }

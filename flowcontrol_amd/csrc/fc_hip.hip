@@ -310,7 +310,8 @@ struct fc_ctx {
   // a late record that fc_step_end collects only if the caller asks for them, else fc_step_collect / the next step does.
   hipStream_t stream2 = nullptr;
   DevBuf<fc_u64> solved;    // sequence number of the last step whose solve has finished (fc_early -> fc_wait_solved)
-  DevBuf<int> side_err;     // fc_wait_solved gave up
+  DevBuf<int> side_err;     // fc_wait_solved gave up (rewritten by every gate; fc_final_late publishes it inside the late record)
+  long gate_spin = 2000000L;  // polls of the side stream's gate before it gives up (~50 ms; FC_GATE_SPIN: test aid, 0 = give up at once)
   bool side_busy = false;   // stream2 has work that has not been synchronised with
   bool overlap = true;      // FC_OVERLAP_TAIL=0: everything on one stream, one record
   bool sweep_check = false; // the down-sweep launches of the apply being enqueued test the solution for finiteness
@@ -1893,6 +1894,7 @@ int fc_create(fc_handle* out, int device, int32_t nv, int32_t ne, int32_t nc, co
   TRYHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   TRYHIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
   if (const char* e = std::getenv("FC_OVERLAP_TAIL")) h->overlap = e[0] != '0';
+  if (const char* e = std::getenv("FC_GATE_SPIN")) h->gate_spin = std::max(0L, std::atol(e));
   if (const char* e = std::getenv("FC_UP_FORM")) h->up_form = std::string(e) == "row" ? 1 : (std::string(e) == "column" ? 2 : 0);
   TRYHIP(hipEventCreate(&h->ev0));
   TRYHIP(hipEventCreate(&h->ev1));
@@ -3897,7 +3899,7 @@ static int step_enqueue_overlapped(fc_ctx* h) {
   //  than the plain one-stream step on the three large meshes, the next step's first launch starts 14 us after fc_final_late although it was
   //  enqueued 45 us earlier; profiles/EXPERIMENTS.md)
   hipStream_t ts = h->stream2;
-  hipLaunchKernelGGL(fc_wait_solved, dim3(1), dim3(1), 0, ts, h->solved.p, (fc_u64)h->pend_seq, h->side_err.p);
+  hipLaunchKernelGGL(fc_wait_solved, dim3(1), dim3(1), 0, ts, h->solved.p, (fc_u64)h->pend_seq, h->side_err.p, h->gate_spin);
   const int reps = std::max(1, nblocks(h->N, 32 * 2048));
   const int g_rows = res ? nblocks(h->N, 32 * reps) : 0, g_cells = (compute_energy && h->nc > 0) ? nblocks(h->nc, 32 * reps) : 0;
   const int g = g_rows + g_cells;
@@ -3907,7 +3909,7 @@ static int step_enqueue_overlapped(fc_ctx* h) {
                        0, reps, h->nc, g_cells > 0 ? h->cnp.p : nullptr, h->geom.p, (const unsigned char*)nullptr, (const int*)nullptr, h->nc, h->flag2.p,
                        h->partial.p, FcFin{});
   hipLaunchKernelGGL(fc_final_late, dim3(1), dim3(256), 0, ts, g_cells > 0 ? g : 0, g_cells > 0 ? h->partial.p + 2 * (size_t)g : nullptr, res ? g : 0,
-                     res ? h->partial.p : nullptr, dev + kLateRec + 8 * par, h->pend_seq);
+                     res ? h->partial.p : nullptr, dev + kLateRec + 8 * par, h->pend_seq, (const int*)h->side_err.p);
   HIPCHK(hipGetLastError());
   h->late[par].pending = true;
   h->late[par].seq = h->pend_seq;
@@ -3971,8 +3973,8 @@ int collect_late(fc_ctx* h, int par) {
   auto ok = [&]() {
     if (rec[3] != seq) return false;
     unsigned long long x = bits(seq), w = x, k = 3;
-    for (int i = 0; i < 3; ++i, k += 2) {
-      const unsigned long long v = bits(rec[i]);
+    for (int i = 0; i < 4; ++i, k += 2) {
+      const unsigned long long v = bits(rec[i < 3 ? i : 6]);
       x ^= v;
       w += k * v;
     }
@@ -3991,6 +3993,9 @@ int collect_late(fc_ctx* h, int par) {
     if (!ok()) return fail(FC_ERR_HIP, "fc_step: the late record (residual monitor, energy) never arrived or failed its checksum");
   }
   L.pending = false;
+  if (rec[6] != 0.0)  // the side stream's gate gave up: its tail may have read buffers the main stream was still writing
+    return fail(FC_ERR_HIP, "fc_step: the side stream stopped waiting for the step's solve (main stream delayed or a launch failed): "
+                            "residual monitor and energy of that step are not valid");
   if (par == h->last_par) {  // the values fc_step_collect hands out are those of the LAST step that ended
     const double nan = std::numeric_limits<double>::quiet_NaN();
     const double r2 = rec[1], b2 = rec[2];
@@ -4384,6 +4389,32 @@ int fc_comm_init(fc_handle h, int nranks, int rank, const char* id128) {
   h->nranks = nranks;
   h->rank = rank;
   forget_solver_structure(h);
+  return FC_OK;
+}
+
+// Can THIS rank create an RCCL communicator at all (library loadable, symbols there)?  Called by every rank before fc_comm_init so
+// that the ranks can agree, over their own process group, to fall back to the host exchange TOGETHER: ncclCommInitRank is a
+// collective, a rank that cannot even load RCCL would leave the others waiting inside it.  FC_RCCL_FAIL_RANK=<r> (test aid): rank r
+// reports failure.
+int fc_comm_probe(int rank) {
+  if (const char* e = std::getenv("FC_RCCL_FAIL_RANK"); e && std::atoi(e) == rank)
+    return fail(FC_ERR_HIP, "cannot load RCCL: disabled for this rank by FC_RCCL_FAIL_RANK");
+  return rccl_load();
+}
+
+// drop the handle's RCCL communicator (a mixed outcome of fc_comm_init over the ranks: the ranks that did get one give it back and
+// everybody goes on over the host exchange)
+int fc_comm_destroy(fc_handle h) {
+  if (!h) return fail(FC_ERR_INVALID, "null handle");
+  if (h->comm) {
+    HIPCHK(hipSetDevice(h->device));
+    FCCHK(quiesce(h));
+    if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
+    h->comm = nullptr;
+    h->nranks = 1;
+    h->rank = 0;
+    forget_solver_structure(h);
+  }
   return FC_OK;
 }
 
@@ -5040,6 +5071,12 @@ int fc_reset_sim_batch(fc_handle h, int32_t s) {
   HIPCHK(hipSetDevice(h->device));
   fc_ctx::Batch& B = h->bat;
   B.pre_slot = -1;
+  // the late tail of the step that just ended (side stream) may still be reading the state columns zeroed below: let it finish
+  // (its late record stays collectable -- fc_step_batch_collect -- with the values of the step as it ran)
+  if (B.side_busy) {
+    HIPCHK(hipStreamSynchronize(h->stream2));
+    B.side_busy = false;
+  }
   const int g = nblocks(h->N, 256);
   for (double* d : {bat_n(h), bat_nn(h)}) {
 #define FC_ZC(K) hipLaunchKernelGGL((fc_b_zero_column<K>), dim3(g), dim3(256), 0, h->stream, h->N, s, d)
@@ -5133,13 +5170,13 @@ static int batch_launches_side(fc_ctx* h, int order_slot, int compute_energy) {
   int n_row_blocks = 0, n_cell_blocks = 0;
   FCCHK(batch_tail_geometry(h, compute_energy, &n_row_blocks, &n_cell_blocks));
   const int G = n_row_blocks + n_cell_blocks;
-  hipLaunchKernelGGL(fc_wait_solved_b, dim3(1), dim3(1), 0, h->stream2, (const unsigned long long*)h->solved.p, seqp, h->side_err.p);
+  hipLaunchKernelGGL(fc_wait_solved_b, dim3(1), dim3(1), 0, h->stream2, (const unsigned long long*)h->solved.p, seqp, h->side_err.p, h->gate_spin);
 #define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(256), (size_t)B.tb_cols * K * sizeof(double), h->stream2, N, h->velrow_p.p, xnew, B.b.p, B.tblocks.p, \
                                        B.tcols.p, S.Ap_rowptr.p, B.tlidx.p, S.Ap_val.p, h->flag2x.p, B.partial.p, G, n_cell_blocks, nc, h->cnp.p, h->geom.p)
   FC_KB_DISPATCH(KB, FC_TAILB(4), FC_TAILB(8), FC_TAILB(16), FC_TAILB(32));
 #undef FC_TAILB
 #define FC_FINLB(K) hipLaunchKernelGGL((fc_final_late_b<K>), dim3(B.k), dim3(1024), 0, h->stream2, G, n_row_blocks, B.partial.p, h->pin_dev, kRecStride, \
-                                       kLateRecB + 8 * par, seqp, compute_energy)
+                                       kLateRecB + 8 * par, seqp, compute_energy, (const int*)h->side_err.p)
   FC_KB_DISPATCH(KB, FC_FINLB(4), FC_FINLB(8), FC_FINLB(16), FC_FINLB(32));
 #undef FC_FINLB
   HIPCHK(hipGetLastError());
@@ -5279,8 +5316,8 @@ int collect_late_batch(fc_ctx* h, int par) {
     volatile double* rec = h->pin + (size_t)s * kRecStride + kLateRecB + 8 * par;
     if (rec[3] != seq) return false;
     unsigned long long x = bits(seq), w = x, kk = 3;
-    for (int i = 0; i < 3; ++i, kk += 2) {
-      const unsigned long long v = bits(rec[i]);
+    for (int i = 0; i < 4; ++i, kk += 2) {
+      const unsigned long long v = bits(rec[i < 3 ? i : 6]);
       x ^= v;
       w += kk * v;
     }
@@ -5304,6 +5341,9 @@ int collect_late_batch(fc_ctx* h, int par) {
     if (!ok()) return fail(FC_ERR_HIP, "fc_step_batch: a late record (residual monitor, energy) never arrived or failed its checksum");
   }
   L.pending = false;
+  if (B.k > 0 && h->pin[kLateRecB + 8 * par + 6] != 0.0)
+    return fail(FC_ERR_HIP, "fc_step_batch: the side stream stopped waiting for the step's solve (main stream delayed or a launch failed): "
+                            "residual monitor and energy of that step are not valid");
   if (par == B.last_par)
     for (int s = 0; s < B.k; ++s) {
       volatile double* rec = h->pin + (size_t)s * kRecStride + kLateRecB + 8 * par;

@@ -1046,18 +1046,24 @@ __global__ __launch_bounds__(256) void fc_early(int n_sens, const int* __restric
   }
 }
 // first kernel of a step's side-stream batch: one thread waits until the main stream's fc_early of step `seq` has run (bounded: a solve
-// that never arrives -- a failed launch -- ends the wait after ~50 ms and leaves *gave_up = 1; the late record then never matches and the
-// host reports it).  HIP events would do the same across streams, but cost the host ~7 us per record / wait pair on this runtime.
-__global__ void fc_wait_solved(const fc_u64* __restrict__ solved, fc_u64 seq, int* __restrict__ gave_up) {
-  for (long spin = 0; spin < 2000000L; ++spin) {
-    if (__hip_atomic_load(solved, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= seq) return;
+// that never arrives -- a failed launch, a main stream held up for longer than ~50 ms -- ends the wait and leaves *gave_up = 1;
+// fc_final_late then publishes the flag INSIDE the checksummed late record and the host reports FC_ERR_HIP for that step instead of
+// accepting a residual / energy computed on buffers the main stream may still be writing).  The word is rewritten by every gate (0 or 1).
+// HIP events would do the same across streams, but cost the host ~7 us per record / wait pair on this runtime.
+__global__ void fc_wait_solved(const fc_u64* __restrict__ solved, fc_u64 seq, int* __restrict__ gave_up, long max_spin) {
+  for (long spin = 0; spin < max_spin; ++spin) {
+    if (__hip_atomic_load(solved, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= seq) {
+      *gave_up = 0;
+      return;
+    }
     __builtin_amdgcn_s_sleep(8);
   }
   *gave_up = 1;
 }
-// the late record: rec[0] = E, rec[1] = sum r^2, rec[2] = sum b^2, rec[3] = seq, rec[4], rec[5] = checksums (as fc_publish)
+// the late record: rec[0] = E, rec[1] = sum r^2, rec[2] = sum b^2, rec[3] = seq, rec[4], rec[5] = checksums (as fc_publish) over the three
+// values, the gate's give-up flag rec[6] and seq
 __global__ __launch_bounds__(256) void fc_final_late(int n_e, const double* __restrict__ e_partial, int n_r, const double* __restrict__ r_partial,
-                                                     double* __restrict__ rec, double seq) {
+                                                     double* __restrict__ rec, double seq, const int* __restrict__ gave_up) {
   __shared__ double red[3][256];
   const int t = threadIdx.x;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
@@ -1097,10 +1103,10 @@ __global__ __launch_bounds__(256) void fc_final_late(int n_e, const double* __re
   }
   if (t == 0) {
     typedef unsigned long long u64;
-    const double v[3] = {e_partial ? 0.5 * red[0][0] : 0.0, r_partial ? red[1][0] : 0.0, r_partial ? red[2][0] : 0.0};
+    const double v[4] = {e_partial ? 0.5 * red[0][0] : 0.0, r_partial ? red[1][0] : 0.0, r_partial ? red[2][0] : 0.0, (gave_up && *gave_up) ? 1.0 : 0.0};
     u64 x = (u64)__double_as_longlong(seq), w = x, k = 3;
-    for (int i = 0; i < 3; ++i, k += 2) {
-      rec[i] = v[i];
+    for (int i = 0; i < 4; ++i, k += 2) {
+      rec[i < 3 ? i : 6] = v[i];
       x ^= (u64)__double_as_longlong(v[i]);
       w += k * (u64)__double_as_longlong(v[i]);
     }

@@ -85,12 +85,18 @@ class DeviceSolver:
         self._xchg_error: BaseException | None = None
 
     # ── multi-GPU ────────────────────────────────────────────────────────────
-    def join(self, rank: int, world: int, broadcast_bytes, host_allreduce=None) -> None:
+    def join(self, rank: int, world: int, broadcast_bytes, host_allreduce=None, agree=None) -> None:
         """Make this handle rank ``rank`` of a ``world``-GPU run (one process per GPU).
 
         ``broadcast_bytes(b | None) -> bytes`` ships the 128-byte RCCL unique id from rank 0 to every
         rank (e.g. ``torch.distributed.broadcast_object_list``); the communicator then lives inside
         the library and its all-reduces run on the solver's own HIP stream.
+
+        ``agree(flag: float) -> float`` (the max of ``flag`` over the ranks, through the caller's own process group): with it the
+        ranks settle TOGETHER whether the RCCL communicator exists — every rank probes RCCL before the collective
+        ``ncclCommInitRank`` and reports after it; on any failure every rank raises :class:`FcCommInitError` (a rank that did get a
+        communicator gives it back first), so that all of them can take the host exchange instead of some waiting in a collective
+        for a rank that never comes.
         """
         if world & (world - 1):
             raise ValueError("world size must be a power of two (one elimination sub-tree per GPU)")
@@ -134,6 +140,15 @@ class DeviceSolver:
         # creating the communicator may fail for reasons of the machine (RCCL not loadable, ncclCommInitRank refused): that is
         # FcCommInitError, which a caller may answer with the host exchange; rank 0 ships an empty id instead of leaving the
         # others in the broadcast.  A communicator that exists but does not sum (comm_selftest) is a plain FcError: never retried
+        if agree is not None:
+            # before anything of RCCL is started (ncclGetUniqueId opens rank 0's bootstrap listener): can EVERY rank load RCCL?
+            mine = None
+            try:
+                check(self.lib.fc_comm_probe(rank))
+            except _lib.FcError as err:
+                mine = err
+            if agree(0.0 if mine is None else 1.0) != 0.0:
+                raise _lib.FcCommInitError(mine if mine is not None else "another rank cannot load RCCL")
         buf = C.create_string_buffer(128)
         payload, first = None, None
         if rank == 0:
@@ -145,10 +160,17 @@ class DeviceSolver:
         uid = broadcast_bytes(payload)
         if not uid:
             raise _lib.FcCommInitError(first if first is not None else "rank 0 could not create the RCCL unique id")
+        mine = None
         try:
             check(self.lib.fc_comm_init(self._h, world, rank, C.create_string_buffer(uid, 128)))
         except _lib.FcError as err:
-            raise _lib.FcCommInitError(err) from err
+            mine = err
+        if agree is not None and agree(0.0 if mine is None else 1.0) != 0.0:
+            if mine is None:
+                check(self.lib.fc_comm_destroy(self._h))  # mixed outcome: give the communicator back, everybody falls back
+            raise _lib.FcCommInitError(mine if mine is not None else "another rank could not create its RCCL communicator")
+        if mine is not None:
+            raise _lib.FcCommInitError(mine) from mine
         self.comm_selftest()
 
     def comm_selftest(self) -> float:

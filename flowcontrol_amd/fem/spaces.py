@@ -353,6 +353,9 @@ def _th_device(self, device_index: int | None = None):
 def _th_release(self) -> None:
     dev = getattr(self, "_device", None)
     if dev is not None:
+        # whoever still waits for results of the handle's last step (a FlowSolver's deferred log row: energy, residual) fetches them now
+        for hook in list(getattr(self, "_release_hooks", ())):
+            hook()
         dev.close()
     self._device = None
 

@@ -136,6 +136,30 @@ class FlowSolver(ABC):
         self._flush_log()
         return self._exporter
 
+    def _report_breach(self) -> bool:
+        """The residual monitor's verdict on the last step(s), if one is pending: logged, and raised when ``throw_error`` is set.
+        ``step()`` consumes it itself; the readers of a finished run (``timeseries``, ``write_timeseries``, a checkpoint) call this so
+        that a breach on the LAST step of a run is not lost (returns True when there was one)."""
+        breach = getattr(self, "_residual_breach", None)
+        if breach is None:
+            return False
+        self._residual_breach = None
+        msg = f"linear solve residual {breach[0]:.2e} exceeds residual_tol = {self.residual_tol:.1e} at iteration {breach[1]}"
+        logger.critical(msg)
+        if self.params_solver.throw_error:
+            raise RuntimeError(msg)
+        return True
+
+    def _before_release(self) -> None:
+        """The device handle is about to go (``th.release_device()``): book the deferred log row while its energy / residual can
+        still be fetched."""
+        try:
+            self._flush_log()
+            self._collect()
+        except Exception as err:  # the handle may be broken already: the row keeps NaN
+            logger.warning("could not collect the last step's energy / residual before the device was released: %s", err)
+            self._late_pending = False
+
     @exporter.setter
     def exporter(self, value) -> None:
         self._pending_log = None
@@ -146,6 +170,8 @@ class FlowSolver(ABC):
         (``fc_step_collect``): fetched once, when somebody needs them — the log row, ``solve_info``, the residual check."""
         if getattr(self, "_late_pending", False):
             self._late_pending = False
+            if getattr(self.th, "_device", None) is None:  # the handle was released without the hook (th._device = None by hand)
+                return
             dE, info = self.th.device().step_collect()
             self._last_dE = dE
             self._solve_info = info
@@ -237,6 +263,10 @@ class FlowSolver(ABC):
         )
         self.first_step = True
         self._systems_ready = False
+        hooks = getattr(self.th, "_release_hooks", None)
+        if hooks is None:
+            hooks = self.th._release_hooks = []
+        hooks.append(self._before_release)
 
     def _define_paths(self) -> SimPaths:
         def ext(T: float) -> str:
@@ -605,17 +635,17 @@ class FlowSolver(ABC):
         if not in_stream:
             dev.join(comm.rank, comm.world, comm.bcast, comm.allreduce)
             return
-        failed, why = 0.0, None
+        why = None
         try:
-            dev.join(comm.rank, comm.world, comm.bcast, None)
-        except FcCommInitError as err:
-            failed, why = 1.0, err
-        # every rank learns whether every rank got its communicator (the process group's own collective, not the library's)
-        if comm.allreduce_max(failed) == 0.0:
+            # the ranks settle inside join() -- over the process group's own collective, before and after the collective
+            # ncclCommInitRank -- whether ALL of them have a communicator: either every rank returns, or every rank raises
+            # FcCommInitError (a rank that did get one has given it back)
+            dev.join(comm.rank, comm.world, comm.bcast, None, agree=comm.allreduce_max)
             return
-        if os.environ.get("FC_EXCHANGE_FALLBACK", "1") == "0" or why is None:
-            # (a rank whose communicator DID come up while another's did not cannot go on either way)
-            raise why if why is not None else RuntimeError("another rank could not create its RCCL communicator")
+        except FcCommInitError as err:
+            why = err
+        if os.environ.get("FC_EXCHANGE_FALLBACK", "1") == "0":
+            raise why
         # the library's RCCL communicator could not be created although the process group works: same partition, same launch
         # sequence, exchanges staged through the host over the process group -- slower, and said so (DeviceSolver.comm_info()
         # reports transport "host", bench.py prints exchange_fallback)
@@ -694,8 +724,18 @@ class FlowSolver(ABC):
                 dev.step_begin(slot, u_ctrl, compute_energy=want_energy, u_force=u_force)  # the GPU works from here on ...
                 # ... while the host does what does not depend on this step's result: the previous step's log row and progress
                 # line, the actuators' bookkeeping (the reference does all of it inside the step, flowsolver.py:721-799)
-                self._flush_log()
-                self.set_actuators_u_ctrl(u_ctrl)
+                try:
+                    self._flush_log()
+                    self.set_actuators_u_ctrl(u_ctrl)
+                except BaseException:
+                    # the host's bookkeeping failed (exporter I/O ...) with a step in flight: end it and take it back, so that
+                    # the handle is not left refusing every later fc_step_begin and the device state matches self.iter
+                    try:
+                        dev.step_end(early=True)
+                        dev.undo_step()
+                    except Exception:  # noqa: BLE001 -- the original error is the one to report
+                        pass
+                    raise
                 # back as soon as the measurements are: energy and residual of this step follow (self._collect)
                 y, dE, info = dev.step_end(early=True)
                 self._late_pending = True
@@ -725,18 +765,15 @@ class FlowSolver(ABC):
         self.y_meas = y
         # this step's log row is booked while the next step runs (or as soon as anybody looks at the exporter); dE = None: to be collected
         self._pending_log = (self.iter, self.t, self._u_ctrl_prev, y, dE if want_energy else np.nan, time.time() - t0)
-        if self._niter_multiple_of(self.iter, self.params_save.save_every):
-            self._checkpoint()
-        breach = getattr(self, "_residual_breach", None)
-        if breach is not None:
-            # the residual monitor is this solver's own check (the reference makes none): its verdict on a step arrives with the NEXT step
-            # at the latest -- the factors (or the system) are broken, do not keep stepping silently
-            self._residual_breach = None
-            msg = f"linear solve residual {breach[0]:.2e} exceeds residual_tol = {self.residual_tol:.1e} at iteration {breach[1]}"
-            logger.critical(msg)
-            if self.params_solver.throw_error:
-                raise RuntimeError(msg)
+        checkpoint = self._niter_multiple_of(self.iter, self.params_save.save_every)
+        if checkpoint:
+            self._collect()  # a checkpoint is written only once THIS step's residual verdict exists
+        # the residual monitor is this solver's own check (the reference makes none): its verdict on a step arrives with the NEXT step
+        # at the latest (with the step itself before a checkpoint) -- the factors (or the system) are broken, do not keep stepping silently
+        if self._report_breach():
             return None
+        if checkpoint:
+            self._checkpoint()
         return self.y_meas
 
     def _step_with_plugin_solver(self, solver, slot: int, u_ctrl, want_energy: bool):
@@ -827,11 +864,15 @@ class FlowSolver(ABC):
         return np.vstack(ys), np.concatenate(dEs)
 
     def write_timeseries(self) -> None:
+        self._flush_log()
+        self._report_breach()  # a breach on the last step of a run surfaces here at the latest
         if self._is_writer():
             self.exporter.write_timeseries()
 
     @property
     def timeseries(self) -> pd.DataFrame:
+        self._flush_log()
+        self._report_breach()
         return self.exporter.to_dataframe()
 
     # ── solver plug-in point (reference :812-819; docs/numerical-details.md:44-48) ──

@@ -129,6 +129,8 @@ def closed_loop_costs(fs, controllers: Sequence, num_steps: int, u_penalty: floa
                 alive = False
                 break
         series = [bfs.timeseries(i) for i in range(k)]
+        if bfs.breached:  # the monitor's verdict on the LAST step arrives with the log: costs of a broken last step are not ranked
+            alive = False
         J = np.empty(k)
         for i, ts in enumerate(series):
             if bool(bfs.diverged[i]):  # a diverging candidate ends there; the others run to the end

@@ -289,6 +289,11 @@ int fc_measure(fc_handle h, const double* up /* [N] */, double* y /* [n_sens] */
  *    tail (sensor partials, energy, residual norms, divergence flag). */
 int fc_comm_unique_id(char* out128 /* ncclUniqueId bytes, made on rank 0 and broadcast by the host */);
 int fc_comm_init(fc_handle h, int nranks, int rank, const char* id128);
+/* fc_comm_probe: can this rank load RCCL at all?  Every rank calls it BEFORE fc_comm_init and the ranks agree on the outcome over
+ * their own process group: ncclCommInitRank is a collective, so a rank that cannot load RCCL must not leave the others waiting in it.
+ * fc_comm_destroy: give the communicator back (mixed outcome of fc_comm_init: everybody then uses fc_set_host_exchange). */
+int fc_comm_probe(int rank);
+int fc_comm_destroy(fc_handle h);
 /* Exchange through the host for a partitioned handle that has NO RCCL communicator (several ranks on one GPU,
  * CPU-only collectives such as gloo): `fn(buf, n, user)` must sum the n doubles of `buf` over the ranks, in place.
  * The launch sequence of a step is the one of the RCCL path; only the exchange itself differs (device -> pinned
