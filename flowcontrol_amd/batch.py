@@ -63,6 +63,8 @@ class BatchedFlowSolver:
         if self.dev.world > 1:
             raise RuntimeError("batched stepping runs on single-GPU handles (replicas scale across GPUs by themselves)")
         self.dev.set_batch(self.k)
+        # the residual monitor's cadence of the single run applies to the batch (fs.check_residual_every: every n-th batched step)
+        self.dev.set_solver_options(refine=0, check_residual=fs.check_residual_every)
         self._ready = True
 
     def initialize_time_stepping(self, ics: Sequence[ParamIC | Function | None] | None = None, Tstart: float = 0.0) -> None:
@@ -188,7 +190,7 @@ class BatchedFlowSolver:
         if np.any(self.diverged):
             dE = np.where(self.diverged, np.nan, dE)
         res = info[~self.diverged, 1]
-        if res.size and np.nanmax(res) > self.residual_tol:
+        if res.size and not np.all(np.isnan(res)) and np.nanmax(res) > self.residual_tol:  # (NaN: a step off the monitor's cadence)
             self._breach = (float(np.nanmax(res)), it)
         self._log.append((t, u, y, dE if want_energy else np.full(self.k, np.nan), runtime))
 

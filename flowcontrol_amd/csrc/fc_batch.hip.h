@@ -349,7 +349,15 @@ __global__ __launch_bounds__(256) void fc_rhs_gather_b(int N, const int* __restr
                                                        const double* __restrict__ uctrl, int ustride, double* __restrict__ b,
                                                        double* __restrict__ y, const int* __restrict__ c_rowptr,
                                                        const int* __restrict__ c_col, const double* __restrict__ c_val,
-                                                       const double* __restrict__ un) {
+                                                       const double* __restrict__ un, int with_ctrl,
+                                                       unsigned long long* __restrict__ solved = nullptr, const double* __restrict__ seq_in = nullptr) {
+  // solved (the gather that runs AHEAD for the next step, behind fc_early_b and the element loop): this launch opens the side stream's
+  // gate instead of fc_early_b -- the late tail then runs beside this gather and the next step's first (latency-bound) sweep launches
+  // rather than beside the element loop, which is compute-bound and was slowed from 16.5 to 30 us by it (k = 16, O1).  Correctness
+  // needs the gate no earlier than fc_early_b; when it opens afterwards is a matter of speed only.
+  if (solved && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(solved, (unsigned long long)seq_in[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  // with_ctrl = 0: the part of the right-hand side that does not depend on the controls -- what the previous step's launches can
+  // already assemble for this one while the host still computes u_ctrl (fc_rhs_ctrl_b adds the rest on the few rows it touches)
   typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));
   constexpr int HP = KB / 2;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -357,7 +365,8 @@ __global__ __launch_bounds__(256) void fc_rhs_gather_b(int N, const int* __restr
   if (i >= N) return;
   double a0 = 0.0, a1 = 0.0;
   const int bs = bcslot[i];
-  if (bs >= 0) {
+  if (bs >= 0 && !with_ctrl) {
+  } else if (bs >= 0) {
     for (int k = 0; k < n_act; ++k) {
       const double p = bcprof[(size_t)bs * n_act + k];
       a0 += uctrl[s * ustride + k] * p;
@@ -379,17 +388,53 @@ __global__ __launch_bounds__(256) void fc_rhs_gather_b(int N, const int* __restr
           a1 += v[u].y;
         }
     }
-    for (int k = 0; k < n_act; ++k) {
-      const double l = lift[(size_t)k * N + i];
-      a0 -= uctrl[s * ustride + k] * l;
-      a1 -= uctrl[(s + 1) * ustride + k] * l;
-    }
+    if (with_ctrl)
+      for (int k = 0; k < n_act; ++k) {
+        const double l = lift[(size_t)k * N + i];
+        a0 -= uctrl[s * ustride + k] * l;
+        a1 -= uctrl[(s + 1) * ustride + k] * l;
+      }
     if (c_rowptr)
       for (int k = c_rowptr[i]; k < c_rowptr[i + 1]; ++k) {
         const d2 u2 = *reinterpret_cast<const d2*>(un + (size_t)c_col[k] * KB + s);
         a0 -= c_val[k] * u2.x;
         a1 -= c_val[k] * u2.y;
       }
+  }
+  const d2 out = {a0, a1};
+  *reinterpret_cast<d2*>(b + (size_t)i * KB + s) = out;
+  *reinterpret_cast<d2*>(y + (size_t)i * KB + s) = out;
+}
+
+// the control-dependent rest of a right-hand side that fc_rhs_gather_b assembled with_ctrl = 0: the Dirichlet rows (value = profile . u_ctrl)
+// and the rows next to them (- lifting vector . u_ctrl), listed once per slot (rows[]); same operations in the same order as the
+// full gather, so the result is bit-identical.  thread = (listed row, simulation pair)
+template <int KB>
+__global__ __launch_bounds__(256) void fc_rhs_ctrl_b(int n_rows, const int* __restrict__ rows, int N, const int* __restrict__ bcslot,
+                                                     const double* __restrict__ bcprof, const double* __restrict__ lift, int n_act,
+                                                     const double* __restrict__ uctrl, int ustride, double* __restrict__ b, double* __restrict__ y) {
+  typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));
+  constexpr int HP = KB / 2;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = t / HP, s = 2 * (t % HP);
+  if (q >= n_rows) return;
+  const int i = rows[q];
+  const int bs = bcslot[i];
+  double a0 = 0.0, a1 = 0.0;
+  if (bs >= 0) {
+    for (int k = 0; k < n_act; ++k) {
+      const double p = bcprof[(size_t)bs * n_act + k];
+      a0 += uctrl[s * ustride + k] * p;
+      a1 += uctrl[(s + 1) * ustride + k] * p;
+    }
+  } else {
+    const d2 v = *reinterpret_cast<const d2*>(b + (size_t)i * KB + s);
+    a0 = v.x, a1 = v.y;
+    for (int k = 0; k < n_act; ++k) {
+      const double l = lift[(size_t)k * N + i];
+      a0 -= uctrl[s * ustride + k] * l;
+      a1 -= uctrl[(s + 1) * ustride + k] * l;
+    }
   }
   const d2 out = {a0, a1};
   *reinterpret_cast<d2*>(b + (size_t)i * KB + s) = out;
@@ -408,50 +453,59 @@ __global__ __launch_bounds__(256) void fc_rhs_gather_b(int N, const int* __restr
 // partial[(s * 3 + w) * G + block], w = 0: sum r^2, 1: sum b^2 (row blocks), 2: sum e (cell blocks)  (fixed order: reproducible).
 #define FC_TB_ROWS 16
 #define FC_TB_COLS 128  // width of a row block's column set when the tail runs alone (fc_ctx::Batch::tb_cols; dynamic LDS: tb_cols * KB doubles)
+#define FC_TB_NNZ 768   // matrix entries of a row block at most (staged in LDS: 10 B each); build_tail_blocks cuts the blocks accordingly
+inline size_t fc_tail_b_lds(int tb_cols, int KB) { return (size_t)tb_cols * KB * sizeof(double) + (size_t)FC_TB_NNZ * (sizeof(double) + sizeof(unsigned short)); }
 typedef double fc_d2u __attribute__((ext_vector_type(2), aligned(8)));
 struct __attribute__((aligned(16))) FcTBlock {
-  int row0, nrows;  // permuted rows [row0, row0 + nrows)
+  int row0, nrows;  // its rows: trowd[row0 .. row0 + nrows) = (permuted row, first matrix entry, length | velocity row << 16, offset in the staged range)
   int col0, ncols;  // its distinct columns: bcols[col0 .. col0 + ncols)
 };
-// energy of the new velocity, 1/2 int |u|^2 element by element (flowsolver.py:827-829), for KB simulations: a workgroup brings
-// its cells' nodal velocities to LDS once (thread = (cell, node, simulation)) and evaluates the integrand from there
-// (thread = (cell, Radon point, simulation)).  The cell workgroups are the FIRST n_cell_blocks of fc_tail_b's grid (their
-// chain of dependent gathers overlaps with the row blocks' streaming; as a launch of their own they cost its ~5 us floor).
-// partial[(s * 3 + 2) * G + first + block]
+// energy of the new velocity, 1/2 int |u|^2 element by element (flowsolver.py:827-829), for KB simulations.  thread = (cell, simulation):
+// 256 / KB cells side by side, FC_EB_TRIPS of them one after the other per workgroup; a thread reads the twelve nodal velocities of
+// its cell for its simulation (a KB-wide row of x per node: coalesced over the simulations) and evaluates the seven Radon points
+// itself -- no LDS staging, no barrier but the final fold.  (Rounds 3-4 spread a cell over 8 lanes, one Radon point each: at KB = 32
+// that was ONE cell per 256-thread workgroup, 12 284 workgroups with three barriers each on O1 -- most of the 114 us of fc_tail_b<32>.)
+// The cell workgroups are the FIRST n_cell_blocks of fc_tail_b's grid.  partial[(s * 3 + 2) * G + first + block]
+#define FC_EB_TRIPS 4
 template <int KB>
 __device__ __forceinline__ void fc_energy_b_block(int cb, int nc, const int* __restrict__ cnp, const double* __restrict__ geom,
                                                   const double* __restrict__ x, double* __restrict__ partial,
                                                   int G, int first, double (&red)[2][256]) {
-  constexpr int CPB = 256 / (8 * KB);  // cells per workgroup
+  constexpr int CW = 256 / KB;  // cells side by side
   const int t = threadIdx.x;
-  const int s = t % KB, lane = (t / KB) % 8, cw = t / (8 * KB);
+  const int s = t % KB, cw = t / KB;
   double e = 0.0;
-  const int c = cb * CPB + cw;
-  const int cc = c < nc ? c : 0;
-  {
-    const int a = lane < 6 ? lane : 0;
-    red[0][t] = x[(size_t)cnp[(size_t)a * nc + cc] * KB + s];
-    red[1][t] = x[(size_t)cnp[(size_t)(6 + a) * nc + cc] * KB + s];
-  }
-  __syncthreads();
-  if (c < nc && lane < FC_NQ) {
-    double ux = 0.0, uy = 0.0;
-    const int nb = cw * 8 * KB + s;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      const double ph = c_phi2[lane * 6 + a];
-      ux += ph * red[0][nb + a * KB];
-      uy += ph * red[1][nb + a * KB];
+  for (int trip = 0; trip < FC_EB_TRIPS; ++trip) {
+    const int c = (cb * FC_EB_TRIPS + trip) * CW + cw;
+    if (c < nc) {
+      double ux[6], uy[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        ux[a] = x[(size_t)cnp[(size_t)a * nc + c] * KB + s];
+        uy[a] = x[(size_t)cnp[(size_t)(6 + a) * nc + c] * KB + s];
+      }
+      double acc = 0.0;
+#pragma unroll
+      for (int q = 0; q < FC_NQ; ++q) {
+        double vx = 0.0, vy = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          const double ph = c_phi2[q * 6 + a];
+          vx += ph * ux[a];
+          vy += ph * uy[a];
+        }
+        acc += c_qw[q] * (vx * vx + vy * vy);
+      }
+      e += 0.5 * geom[4 * (size_t)nc + c] * acc;
     }
-    e = c_qw[lane] * 0.5 * geom[4 * (size_t)nc + cc] * (ux * ux + uy * uy);
   }
-  __syncthreads();
   red[0][t] = e;
   __syncthreads();
   if (t < KB) {
     double se = 0.0;
 #pragma unroll
-    for (int g = 0; g < 8 * CPB; ++g) se += red[0][g * KB + t];
+    for (int g = 0; g < CW; ++g) se += red[0][g * KB + t];
     partial[((size_t)t * 3 + 2) * G + first + cb] = se;
   }
 }
@@ -459,14 +513,14 @@ __device__ __forceinline__ void fc_energy_b_block(int cb, int nc, const int* __r
 template <int KB>
 __global__ __launch_bounds__(256) void fc_tail_b(int N, const unsigned char* __restrict__ velrow, const double* __restrict__ x,
                                                  const double* __restrict__ b, const FcTBlock* __restrict__ blocks,
-                                                 const int* __restrict__ bcols, const int* __restrict__ a_rowptr,
+                                                 const int* __restrict__ bcols, const int4* __restrict__ trowd,
                                                  const unsigned short* __restrict__ a_lidx, const double* __restrict__ a_val,
                                                  int* __restrict__ flag, double* __restrict__ partial, int G,
-                                                 int n_cell_blocks, int nc, const int* __restrict__ cnp, const double* __restrict__ geom) {
+                                                 int n_cell_blocks, int nc, const int* __restrict__ cnp, const double* __restrict__ geom, int tb_cols) {
   constexpr int HP = KB / 2;   // simulation pairs
   constexpr int JL = 16 / HP;  // lanes of a row that split its entries
   const int t = threadIdx.x;
-  extern __shared__ double xs[];  // [tb_cols][KB] (launch: dynamic LDS)
+  extern __shared__ double xs[];  // [tb_cols][KB] | values [FC_TB_NNZ] | local columns [FC_TB_NNZ] (launch: dynamic LDS, fc_tail_b_lds)
   __shared__ double red[2][256];
   if ((int)blockIdx.x < n_cell_blocks) {
     fc_energy_b_block<KB>((int)blockIdx.x, nc, cnp, geom, x, partial, G, G - n_cell_blocks, red);
@@ -474,50 +528,80 @@ __global__ __launch_bounds__(256) void fc_tail_b(int N, const unsigned char* __r
   }
   const int rbk = (int)blockIdx.x - n_cell_blocks;  // row block of this workgroup
   {
+    // A row block is a short chain of dependent memory round trips and little else, so the chain is what is laid out here:
+    //   trip 1 (scalar)  the block descriptor
+    //   trip 2           row descriptors (row, first entry, length, offset in the staged range -- one int4 each, tabulated on the host:
+    //                    no row -> row pointer -> entries chain) and the column list
+    //   trip 3           everything else at once: solution rows -> LDS, the block's matrix entries -> LDS, the x / b values of the
+    //                    finishing pass -> registers
+    // then LDS only.  (Rounds 3-4 walked ~8 dependent trips per block: 114 us for fc_tail_b<32> on O1.)
     const FcTBlock bk = blocks[rbk];
-    // the block's solution rows -> LDS, two simulations per lane
-    for (int e = t; e < bk.ncols * HP; e += 256) {
-      const int c = e / HP, sp = e % HP;
-      *reinterpret_cast<fc_d2u*>(xs + c * KB + 2 * sp) = *reinterpret_cast<const fc_d2u*>(x + (size_t)bcols[bk.col0 + c] * KB + 2 * sp);
-    }
-    const int rl = t / 16, j = (t % 16) / HP, sp = t % HP;
-    const int i = bk.row0 + rl;
+    double* vs = xs + (size_t)tb_cols * KB;
+    unsigned short* ls = reinterpret_cast<unsigned short*>(vs + FC_TB_NNZ);
+    const int rl = t / 16, q16 = t % 16, j = q16 / HP, sp = t % HP;
     const bool live = rl < bk.nrows;
-    const int k0 = live ? a_rowptr[i] : 0, k1 = live ? a_rowptr[i + 1] : 0;
-    // eight entries per lane and trip, every load of a trip issued before the first use (addresses clamped into the row,
-    // values past its end replaced by zero: no branch in the body); the first trip is in flight while the block's
-    // solution rows are staged
-    int la[8];
-    double va[8];
-    auto fetch = [&](int base) {
+    constexpr int NT = (16 * KB + 255) / 256;  // trips of the finishing pass (thread = (row, simulation))
+    constexpr int CT = 12;                     // trips of the staging loop at most (tb_cols * KB / 2 <= 3072 lanes' worth)
+    // every load below is UNCONDITIONAL at a clamped (always valid) address and lands in a register; what is conditional is the use.
+    // (Written as predicated loads straight into LDS the compiler emitted load - s_waitcnt vmcnt(0) - ds_write per element: nine
+    // dependent round trips for the solution rows alone.)
+    const int rlc = rl < bk.nrows ? rl : bk.nrows - 1;
+    const int4 rd = trowd[bk.row0 + rlc];
+    int fi[NT], fvel[NT], cid[CT];
+    bool fok[NT];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int kk = base + u * JL;
-        const int kc = kk < k1 ? kk : (k1 > k0 ? k1 - 1 : 0);
-        const int l = a_lidx[kc];
-        const double v = a_val[kc];
-        la[u] = l;
-        va[u] = kk < k1 ? v : 0.0;
-      }
-    };
-    fetch(k0 + j);
+    for (int u = 0; u < NT; ++u) {
+      const int r_l = (t + 256 * u) / KB;
+      fok[u] = r_l < bk.nrows;
+      const int4 d = trowd[bk.row0 + (fok[u] ? r_l : bk.nrows - 1)];
+      fi[u] = d.x, fvel[u] = d.z >> 16;
+    }
+#pragma unroll
+    for (int u = 0; u < CT; ++u) {
+      const int c = t / HP + u * (256 / HP);
+      cid[u] = bcols[bk.col0 + (c < bk.ncols ? c : bk.ncols - 1)];
+    }
+    const int g0 = rd.y, len = live ? (rd.z & 0xFFFF) : 0, k0 = rd.w, k1 = k0 + len;
+    // trip 3: solution rows, the block's matrix entries, the finishing pass's x / b
+    fc_d2u stage[CT];
+#pragma unroll
+    for (int u = 0; u < CT; ++u) stage[u] = *reinterpret_cast<const fc_d2u*>(x + (size_t)cid[u] * KB + 2 * sp);
+    constexpr int ET = 4;  // 16 lanes per row, four 128-byte pieces: rows of up to 64 entries in one go
+    double ev[ET];
+    unsigned short el[ET];
+    const int lenc = (rd.z & 0xFFFF) > 0 ? (rd.z & 0xFFFF) : 1;
+#pragma unroll
+    for (int u = 0; u < ET; ++u) {
+      const int e = q16 + 16 * u;
+      const int ec = e < lenc ? e : lenc - 1;
+      ev[u] = a_val[g0 + ec];
+      el[u] = a_lidx[g0 + ec];
+    }
+    double xv[NT], bv[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const int s = (t + 256 * u) % KB;
+      xv[u] = x[(size_t)fi[u] * KB + s];
+      bv[u] = b[(size_t)fi[u] * KB + s];
+    }
+#pragma unroll
+    for (int u = 0; u < CT; ++u)
+      if (t / HP + u * (256 / HP) < bk.ncols) *reinterpret_cast<fc_d2u*>(xs + (t / HP + u * (256 / HP)) * KB + 2 * sp) = stage[u];
+#pragma unroll
+    for (int u = 0; u < ET; ++u)
+      if (q16 + 16 * u < len) vs[k0 + q16 + 16 * u] = ev[u], ls[k0 + q16 + 16 * u] = el[u];
+    for (int e = q16 + 16 * ET; e < len; e += 16) {  // (longer rows: the rest, piece by piece)
+      vs[k0 + e] = a_val[g0 + e];
+      ls[k0 + e] = a_lidx[g0 + e];
+    }
     __syncthreads();
     double s0 = 0.0, s1 = 0.0;
-    for (int base = k0 + j; base < k1; base += 8 * JL) {
-      int lc[8];
-      double vc[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        lc[u] = la[u];
-        vc[u] = va[u];
-      }
-      if (base + 8 * JL < k1) fetch(base + 8 * JL);  // rows longer than 8 JL entries: the next trip streams in behind this one
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const fc_d2u xa = *reinterpret_cast<const fc_d2u*>(xs + lc[u] * KB + 2 * sp);
-        s0 += vc[u] * xa.x;
-        s1 += vc[u] * xa.y;
-      }
+#pragma unroll 4
+    for (int k = k0 + j; k < k1; k += JL) {
+      const double v = vs[k];
+      const fc_d2u xa = *reinterpret_cast<const fc_d2u*>(xs + (int)ls[k] * KB + 2 * sp);
+      s0 += v * xa.x;
+      s1 += v * xa.y;
     }
 #pragma unroll
     for (int off = (JL / 2) * HP; off >= HP; off >>= 1) {
@@ -532,14 +616,14 @@ __global__ __launch_bounds__(256) void fc_tail_b(int N, const unsigned char* __r
     }
     __syncthreads();
     double r2 = 0.0, b2 = 0.0;
-    for (int e = t; e < bk.nrows * KB; e += 256) {  // one trip for KB = 16, fewer threads for smaller KB
-      const int r_l = e / KB, s = e % KB;
-      const int ii = bk.row0 + r_l;
-      const double v = x[(size_t)ii * KB + s], bb = b[(size_t)ii * KB + s];
-      const double res = bb - xs[r_l * KB + s];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      if (!fok[u]) continue;
+      const int e = t + 256 * u, r_l = e / KB, s = e % KB;
+      const double res = bv[u] - xs[r_l * KB + s];
       r2 += res * res;
-      b2 += bb * bb;
-      if (velrow[ii] && !isfinite(v)) atomicOr(flag + s, 1);  // (reference flowsolver.py:731,816-819: the velocity is tested)
+      b2 += bv[u] * bv[u];
+      if (fvel[u] && !isfinite(xv[u])) atomicOr(flag + s, 1);  // (reference flowsolver.py:731,816-819: the velocity is tested)
     }
     // threads e = r_l * KB + s: simulation = t % KB for every trip (256 is a multiple of KB)
     red[0][t] = r2;
@@ -634,7 +718,7 @@ template <int KB>
 __global__ __launch_bounds__(256) void fc_early_b(int n_sens, const int* __restrict__ s_rowptr, const int* __restrict__ s_idxp,
                                                   const double* __restrict__ s_w, const double* __restrict__ x, int* __restrict__ flag,
                                                   double* __restrict__ rec, int rstride, const double* __restrict__ seq_in,
-                                                  unsigned long long* __restrict__ solved) {
+                                                  unsigned long long* __restrict__ solved /* null: a later launch opens the gate */) {
   const int s = blockIdx.x, t = threadIdx.x, wave = t >> 6, lane = t & 63;
   __shared__ double ysh[64];
   for (int q = wave; q < n_sens; q += 4) {
@@ -651,7 +735,7 @@ __global__ __launch_bounds__(256) void fc_early_b(int n_sens, const int* __restr
     const double seq = seq_in[0];
     double* r = rec + (size_t)s * rstride;
     fc_publish(ysh, n_sens, 0.0, 0.0, 0.0, (double)fl, r + 64, r + 128, r + 129, r + 136, r + 137, seq);
-    if (s == 0) __hip_atomic_store(solved, (unsigned long long)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (s == 0 && solved) __hip_atomic_store(solved, (unsigned long long)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 // gate of the batched side stream: as fc_wait_solved, the sequence number read from the step's slot of the mapped record (graph replay:

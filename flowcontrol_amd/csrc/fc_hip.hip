@@ -460,14 +460,16 @@ struct fc_ctx {
       bool pending = false;
       double seq = 0.0;
       int energy = 0;
+      bool checked = true;
     } late[2];
     int last_par = 0, pend_par = 0;
     bool pend_overlapped = false, side_busy = false;
     std::vector<double> last_dE, last_r, last_b;   // per simulation: what fc_step_batch_collect hands out
-    hipGraphExec_t gside[4][2] = {};               // side-stream graph per (ring phase, energy flag)
-    uint64_t gside_sig[4][2] = {};
+    hipGraphExec_t gside[4][4] = {};               // side-stream graph per (ring phase, energy flag + 2 x residual monitor)
+    uint64_t gside_sig[4][4] = {};
     DevBuf<int> flag;                                        // [KB] non-finite velocity seen, per simulation
     DevBuf<FcBTask> tasks;
+    DevBuf<int> trowd;            // tail row blocks: one int4 per row, in the cell order of build_tail_blocks (FcTBlock)
     DevBuf<int> fptr, fsrc;       // up-sweep fold lists: permuted row -> scratch rows (absolute buffer rows) of its descendants
     DevBuf<int> olist;            // per tree node: the buffer row of every operand column ([y rows of the node | x rows of its boundary])
     DevBuf<double> ftile[2];      // per slot: the factor values in the tiled layout the batched block kernel streams (fc_b_repack)
@@ -487,11 +489,20 @@ struct fc_ctx {
     double pend_seq = 0.0;
     // the launches of one batched step as a HIP graph per (order slot, energy flag): captured on first use, replayed as long as
     // no buffer or parameter that a kernel argument was taken from has changed (gsig: hash of all of them)
-    // (third index: 1 = the graph starts with the element loop, 0 = the previous step's graph already ran it -- pre_slot)
+    // (last index: 2 = the graph starts with the element loop, 1 = with the full gather (the previous step's graph ran the element loop:
+    //  pre_slot), 0 = with the control rows only (it gathered the control-independent right-hand side too: pre_gather))
     // (first index: the ring phase `cur` the step starts from -- the buffers a step reads and writes rotate with period four)
-    hipGraphExec_t gexec[4][2][2][2] = {};
-    uint64_t gsig[4][2][2][2] = {};
+    hipGraphExec_t gexec[4][2][4][3] = {};   // [ring phase][slot][energy + 2 x residual monitor][lead]
+    uint64_t gsig[4][2][4][3] = {};
     int pre_slot = -1;  // order slot whose element vectors (ev) the LAST launch of the previous step left behind, -1: none
+    uint64_t step_count = 0;   // batched steps enqueued (the residual monitor's cadence counts them: fc_set_solver_options check_residual = n)
+    bool pend_checked = true;  // the step in flight forms its residual
+    bool pre_gather = false;  // ... and whose control-independent right-hand side it has gathered as well -- into pre_b / pre_y
+    const double* pre_b = nullptr;
+    const double* pre_y = nullptr;
+    DevBuf<int> ctrl_rows[2];  // per slot: the rows whose right-hand side depends on u_ctrl (Dirichlet rows + rows with a lifting entry)
+    int n_ctrl_rows[2] = {0, 0};
+    bool ctrl_ok[2] = {false, false};
   } bat;
 };
 
@@ -2216,6 +2227,8 @@ int fc_set_bc(fc_handle h, int32_t n_bc, const int32_t* bc_dofs, int32_t n_act, 
   }
   h->n_bc = n_bc;
   h->n_act = n_act;
+  h->bat.ctrl_ok[0] = h->bat.ctrl_ok[1] = false;
+  h->bat.pre_slot = -1;
   h->h_bc_dofs.assign(bc_dofs, bc_dofs + n_bc);
   h->h_bcprof.assign(profiles, profiles + (size_t)n_bc * n_act);
   FCCHK(h->isbc.upload(isbc.data(), isbc.size(), h->stream));
@@ -2328,6 +2341,8 @@ int fc_apply_bc(fc_handle h, int slot) {
     }
     S.have_lift = true;
     S.ready = false;
+    if (slot < 2) h->bat.ctrl_ok[slot] = false;  // the rows with a lifting entry are listed from these vectors (build_ctrl_rows)
+    h->bat.pre_slot = -1;
   }
   hipLaunchKernelGGL(fc_apply_bc_rows, dim3(nblocks(N, 256)), dim3(256), 0, h->stream, N, h->rowptr.p, h->col.p,
                      h->isbc.p, h->vals[slot].p);
@@ -2364,6 +2379,7 @@ int fc_set_permutation(fc_handle h, const int32_t* perm) {
   h->have_perm = true;
   h->have_mp = false;
   h->pre_slot = -1;
+  h->bat.ctrl_ok[0] = h->bat.ctrl_ok[1] = false;
   h->undo_ok = false;
   for (int o = 0; o < 2; ++o) h->sys[o].ready = h->sys[o].structured = false;
   FCCHK(upload_sensors(h));  // sensor positions in the permuted numbering
@@ -4649,7 +4665,7 @@ static int build_tail_blocks(fc_ctx* h, int KB) {
   // O1, k = 16: 45.8 us against 53.8 with 256), but the default batched step runs it on the second stream BESIDE the next step's
   // launches, and there the 256-column blocks (~14.5 rows, half the operand traffic, a third fewer workgroups) leave more of the machine
   // to the main stream: k = 16 75.0 -> 83.7 k simulated steps/s on O1, k = 8 48.4 -> 50.0 (same box; 192 / 320 / 448: 82.0 / 83.0 / 80.6).
-  // 448 x 16 simulations x 8 B + the static 4 KB stay below the 64 KB a launch gets without opting in.
+  // 384 x 16 simulations x 8 B + the staged matrix entries (FC_TB_NNZ x 10 B) + the static 4 KB stay below the 64 KB a launch gets without opting in.
   int want;
   {
     const char* e = std::getenv("FC_TB_COLS");  // tuning aid
@@ -4658,43 +4674,74 @@ static int build_tail_blocks(fc_ctx* h, int KB) {
     // (32 simulations, [3,3,2,2] tree of O1: 144 columns 118.2 k simulated steps/s, 128: 116.5 k, 224: 113.3 k, 112: 97.5 k -- the LDS a block
     //  takes decides how many of them sit beside the main stream's workgroups)
     const int v = e ? std::atoi(e) : ((h->overlap && !streams) ? (KB > 16 ? 144 : 256) : FC_TB_COLS);
-    want = std::min(448 * 16 / std::max(16, KB), std::max(FC_TB_ROWS, v));  // (KB = 32: at most 224 columns)
+    want = std::min(384 * 16 / std::max(16, KB), std::max(FC_TB_ROWS, v));  // (KB = 32: at most 192 columns)
   }
   if (B.tblocks.p && B.tb_cols == want && B.tb_built) return FC_OK;
   B.tb_cols = want;
   const size_t tb_cols = (size_t)B.tb_cols;
+  // The residual only needs sums over ALL rows, so the tail is free to visit them in an order of its own: cell by cell (the cells are
+  // Morton-ordered), a node's two velocity rows next to each other.  Rows that are neighbours in the solver's permuted numbering share
+  // few columns (inside a tree node the dofs are in index order: all x-velocities, then all y-velocities, then the pressures --
+  // 16 such rows touch ~280 distinct columns, i.e. every staged solution row served 1.7 matrix rows); 16 rows of two or three
+  // neighbouring cells touch ~90.
+  std::vector<int> ip((size_t)N), rorder;
+  rorder.reserve((size_t)N);
+  for (int i = 0; i < N; ++i) ip[(size_t)h->h_perm[(size_t)i]] = i;
+  {
+    std::vector<unsigned char> seen((size_t)N, 0);
+    auto take = [&](int w) {
+      if (!seen[(size_t)w]) seen[(size_t)w] = 1, rorder.push_back(ip[(size_t)w]);
+    };
+    for (int c = 0; c < h->nc; ++c) {
+      const int* cd = h->h_cell_dofs.data() + (size_t)c * 15;
+      for (int a = 0; a < 6; ++a) take(cd[a]), take(cd[6 + a]);
+      for (int a = 12; a < 15; ++a) take(cd[a]);
+    }
+    for (int w = 0; w < N; ++w) take(w);  // (dofs of no cell: none on a conforming mesh)
+  }
   std::vector<FcTBlock> tb;
-  std::vector<int> tcols;
+  std::vector<int> tcols, trowd;  // trowd: one int4 per row (FcTBlock)
   std::vector<unsigned short> lidx(cl.size(), 0);
   std::vector<int> mark((size_t)N, -1), cur;
-  int r0 = 0;
-  while (r0 < N) {
+  trowd.reserve(4 * (size_t)N);
+  size_t q0 = 0;
+  while (q0 < (size_t)N) {
     cur.clear();
-    int r = r0;
-    for (; r < N && r - r0 < FC_TB_ROWS; ++r) {
+    size_t q = q0;
+    int nnz = 0;
+    for (; q < (size_t)N && q - q0 < FC_TB_ROWS; ++q) {
+      const int r = rorder[q];
+      const int len = rp[(size_t)r + 1] - rp[(size_t)r];
+      if (q > q0 && nnz + len > FC_TB_NNZ) break;  // the block's entries are staged in LDS
       size_t added = 0;
       for (int k = rp[(size_t)r]; k < rp[(size_t)r + 1]; ++k)
-        if (mark[(size_t)cl[(size_t)k]] != r0) {
-          mark[(size_t)cl[(size_t)k]] = r0;
+        if (mark[(size_t)cl[(size_t)k]] != (int)q0) {
+          mark[(size_t)cl[(size_t)k]] = (int)q0;
           cur.push_back(cl[(size_t)k]);
           ++added;
         }
-      if (cur.size() > tb_cols && r > r0) {  // this row does not fit any more: it starts the next block
-        for (size_t q = 0; q < added; ++q) mark[(size_t)cur[cur.size() - 1 - q]] = -1;
+      if (cur.size() > tb_cols && q > q0) {  // this row does not fit any more: it starts the next block
+        for (size_t u = 0; u < added; ++u) mark[(size_t)cur[cur.size() - 1 - u]] = -1;
         cur.resize(cur.size() - added);
         break;
       }
+      nnz += len;
     }
-    if (cur.size() > tb_cols) return fail(FC_ERR_INVALID, "fc_set_batch: a matrix row has more entries than a row block's column set holds");
+    if (cur.size() > tb_cols || nnz > FC_TB_NNZ) return fail(FC_ERR_INVALID, "fc_set_batch: a matrix row has more entries than a row block holds");
     std::sort(cur.begin(), cur.end());
     const int c0 = (int)tcols.size();
-    for (size_t q = 0; q < cur.size(); ++q) mark[(size_t)cur[q]] = -2 - (int)q;  // local position
-    for (int rr = r0; rr < r; ++rr)
-      for (int k = rp[(size_t)rr]; k < rp[(size_t)rr + 1]; ++k) lidx[(size_t)k] = (unsigned short)(-2 - mark[(size_t)cl[(size_t)k]]);
+    for (size_t u = 0; u < cur.size(); ++u) mark[(size_t)cur[u]] = -2 - (int)u;  // local position
+    int off = 0;
+    for (size_t u = q0; u < q; ++u) {
+      const int r = rorder[u];
+      trowd.push_back(r), trowd.push_back(rp[(size_t)r]), trowd.push_back((rp[(size_t)r + 1] - rp[(size_t)r]) | ((h->h_perm[(size_t)r] < 2 * h->nn ? 1 : 0) << 16)), trowd.push_back(off);
+      off += rp[(size_t)r + 1] - rp[(size_t)r];
+      for (int k = rp[(size_t)r]; k < rp[(size_t)r + 1]; ++k) lidx[(size_t)k] = (unsigned short)(-2 - mark[(size_t)cl[(size_t)k]]);
+    }
     for (int c : cur) mark[(size_t)c] = -1;
     tcols.insert(tcols.end(), cur.begin(), cur.end());
-    tb.push_back(FcTBlock{r0, r - r0, c0, (int)cur.size()});
-    r0 = r;
+    tb.push_back(FcTBlock{(int)q0, (int)(q - q0), c0, (int)cur.size()});
+    q0 = q;
   }
   if (tcols.empty()) tcols.push_back(0);
   if (lidx.empty()) lidx.push_back(0);
@@ -4702,6 +4749,7 @@ static int build_tail_blocks(fc_ctx* h, int KB) {
   FCCHK(B.tblocks.upload(tb, h->stream));
   FCCHK(B.tcols.upload(tcols, h->stream));
   FCCHK(B.tlidx.upload(lidx, h->stream));
+  FCCHK(B.trowd.upload(trowd, h->stream));
   B.tb_built = true;
   HIPCHK(hipStreamSynchronize(h->stream));
   return FC_OK;
@@ -4946,7 +4994,8 @@ int fc_set_batch(fc_handle h, int32_t k) {
     // repack per fc_refactor
     B.ftile[0].release(), B.ftile[1].release();
     B.ftile_ok[0] = B.ftile_ok[1] = false;
-    B.tasks.release(), B.olist.release(), B.fptr.release(), B.fsrc.release(), B.tblocks.release(), B.tcols.release(), B.tlidx.release();
+    B.tasks.release(), B.olist.release(), B.fptr.release(), B.fsrc.release(), B.tblocks.release(), B.tcols.release(), B.tlidx.release(), B.trowd.release(), B.ctrl_rows[0].release(), B.ctrl_rows[1].release();
+    B.ctrl_ok[0] = B.ctrl_ok[1] = false;
     B.launches.clear();
     B.tables = B.tb_built = false;
     B.k = B.KB = 0;
@@ -4961,10 +5010,10 @@ int fc_set_batch(fc_handle h, int32_t k) {
     B.slot_doubles = (2 * N + (size_t)B.scratch_rows + 1) * KB;  // + the zero row of the operand lists
     FCCHK(B.ring.alloc(4 * B.slot_doubles));
     B.buf.n = B.slot_doubles;
-    FCCHK(B.bstore.alloc(2 * N * KB));
+    FCCHK(B.bstore.alloc(4 * N * KB));  // one right-hand side per ring phase: b(n) for step n's late tail, b(n + 1) being gathered ahead
     B.b.n = N * KB;
     FCCHK(B.ev.alloc((size_t)12 * h->nc * KB));
-    FCCHK(B.partial.alloc((size_t)3 * ((size_t)B.n_tblocks + (size_t)nblocks(h->nc, 256 / (8 * KB)) + 1) * KB));
+    FCCHK(B.partial.alloc((size_t)3 * ((size_t)B.n_tblocks + (size_t)nblocks(h->nc, FC_EB_TRIPS * (256 / KB)) + 1) * KB));
     FCCHK(B.flag.alloc(32));
   }
   B.k = k;
@@ -5098,8 +5147,9 @@ constexpr int kSeqSlot = 8000;
 constexpr int kLateRecB = 144;  // late record of a simulation inside its record (kRecStride): + 8 x step parity
 static int batch_tail_geometry(fc_ctx* h, int compute_energy, int* n_row_blocks, int* n_cell_blocks) {
   fc_ctx::Batch& B = h->bat;
-  const int cpb = 256 / (8 * B.KB);
-  *n_row_blocks = B.n_tblocks;
+  // (a step off the residual monitor's cadence has no row blocks: B.pend_checked, set by step_batch_begin before the launches)
+  const int cpb = FC_EB_TRIPS * (256 / B.KB);  // cells per cell workgroup of fc_tail_b (fc_energy_b_block)
+  *n_row_blocks = B.pend_checked ? B.n_tblocks : 0;
   *n_cell_blocks = compute_energy ? nblocks(h->nc, cpb) : 0;
   if ((size_t)3 * (*n_row_blocks + *n_cell_blocks) * B.KB > B.partial.n) return fail(FC_ERR_INVALID, "fc_step_batch: partial buffer too small");
   return FC_OK;
@@ -5108,7 +5158,10 @@ static int batch_tail_geometry(fc_ctx* h, int compute_energy, int* n_row_blocks,
 // overlapped == false: the whole step on the main stream (tail and final behind the apply, one record per simulation).
 // overlapped == true: the main stream ends with fc_early_b (what the host waits for) and the next step's element loop; residual monitor and
 // energy are batch_launches_side's, on the side stream.
-static int batch_launches(fc_ctx* h, int order_slot, int compute_energy, bool lead_elem = true, int spec_slot = -1, bool overlapped = false) {
+// lead: 2 = element loop + full gather, 1 = full gather (element vectors left by the previous step), 0 = control rows only (the
+// previous step gathered the control-independent right-hand side as well); spec_gather: gather the NEXT step's control-independent
+// right-hand side behind its element loop (into the b / y buffers that step will use)
+static int batch_launches(fc_ctx* h, int order_slot, int compute_energy, int lead = 2, int spec_slot = -1, bool overlapped = false, bool spec_gather = false) {
   fc_ctx::Batch& B = h->bat;
   OrderSys& S = h->sys[order_slot];
   const int KB = B.KB, N = h->N, nc = h->nc;
@@ -5128,17 +5181,30 @@ static int batch_launches(fc_ctx* h, int order_slot, int compute_energy, bool le
     FC_KB_DISPATCH(KB, FC_ELEM(4), FC_ELEM(8), FC_ELEM(16), FC_ELEM(32));
 #undef FC_ELEM
   };
-  if (lead_elem) element_loop(coeffs_for(h, order_slot), un, unn);
+  // the side stream's gate opens behind the gather that runs ahead for the next step, if there is one (FC_LATE_GATE=0: behind fc_early_b)
+  static const bool late_gate_on = [] { const char* e = std::getenv("FC_LATE_GATE"); return !(e && e[0] == '0'); }();
+  const bool late_gate = late_gate_on && overlapped && spec_slot >= 0 && spec_gather;
+  if (lead == 2) element_loop(coeffs_for(h, order_slot), un, unn);
+  if (lead >= 1) {
 #define FC_GATH(K) hipLaunchKernelGGL((fc_rhs_gather_b<K>), dim3(g_rows), dim3(256), 0, h->stream, N, h->gptr_p.p, h->gidx_p.p, B.ev.p, h->bcslot_p.p, \
                                       h->bcprof.p, S.lift_p.p, h->n_act, uc, kRecStride, B.b.p, B.buf.p, S.have_c ? S.c_rowptr.p : nullptr, S.c_col.p, \
-                                      S.c_val.p, un)
-  FC_KB_DISPATCH(KB, FC_GATH(4), FC_GATH(8), FC_GATH(16), FC_GATH(32));
+                                      S.c_val.p, un, 1)
+    FC_KB_DISPATCH(KB, FC_GATH(4), FC_GATH(8), FC_GATH(16), FC_GATH(32));
 #undef FC_GATH
-  FCCHK(batch_apply(h, order_slot, overlapped));
+  } else if (B.n_ctrl_rows[order_slot] > 0) {
+    const int nr = B.n_ctrl_rows[order_slot];
+#define FC_CTRL(K) hipLaunchKernelGGL((fc_rhs_ctrl_b<K>), dim3(nblocks((int64_t)nr * (K / 2), 256)), dim3(256), 0, h->stream, nr, B.ctrl_rows[order_slot].p, N, \
+                                      h->bcslot_p.p, h->bcprof.p, S.lift_p.p, h->n_act, uc, kRecStride, B.b.p, B.buf.p)
+    FC_KB_DISPATCH(KB, FC_CTRL(4), FC_CTRL(8), FC_CTRL(16), FC_CTRL(32));
+#undef FC_CTRL
+  }
+  // (the down-sweep tiles test what they write for finiteness whenever no tail pass of this stream does it: the overlapped step,
+  //  and a step off the residual monitor's cadence)
+  FCCHK(batch_apply(h, order_slot, overlapped || !B.pend_checked));
   if ((int64_t)B.tlidx.n != S.Ap_nnz && S.Ap_nnz > 0) return fail(FC_ERR_INVALID, "fc_step_batch: tail tables and system pattern disagree");
   if (overlapped) {
 #define FC_EARLYB(K) hipLaunchKernelGGL((fc_early_b<K>), dim3(B.k), dim3(256), 0, h->stream, h->n_sens, h->s_rowptr.p, h->s_idxp.p, h->s_w.p, xnew, B.flag.p, \
-                                        h->pin_dev, kRecStride, seqp, (unsigned long long*)h->solved.p)
+                                        h->pin_dev, kRecStride, seqp, late_gate ? (unsigned long long*)nullptr : (unsigned long long*)h->solved.p)
     FC_KB_DISPATCH(KB, FC_EARLYB(4), FC_EARLYB(8), FC_EARLYB(16), FC_EARLYB(32));
 #undef FC_EARLYB
   } else {
@@ -5146,9 +5212,9 @@ static int batch_launches(fc_ctx* h, int order_slot, int compute_energy, bool le
     int n_row_blocks = 0, n_cell_blocks = 0;
     FCCHK(batch_tail_geometry(h, compute_energy, &n_row_blocks, &n_cell_blocks));
     const int G = n_row_blocks + n_cell_blocks;
-#define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(256), (size_t)B.tb_cols * K * sizeof(double), h->stream, N, h->velrow_p.p, xnew, B.b.p, B.tblocks.p, \
-                                       B.tcols.p, S.Ap_rowptr.p, B.tlidx.p, S.Ap_val.p, B.flag.p, B.partial.p, G, n_cell_blocks, nc, h->cnp.p, h->geom.p)
-    FC_KB_DISPATCH(KB, FC_TAILB(4), FC_TAILB(8), FC_TAILB(16), FC_TAILB(32));
+#define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(256), fc_tail_b_lds(B.tb_cols, K), h->stream, N, h->velrow_p.p, xnew, B.b.p, B.tblocks.p, \
+                                       B.tcols.p, (const int4*)B.trowd.p, B.tlidx.p, S.Ap_val.p, B.flag.p, B.partial.p, G, n_cell_blocks, nc, h->cnp.p, h->geom.p, B.tb_cols)
+    if (G > 0) FC_KB_DISPATCH(KB, FC_TAILB(4), FC_TAILB(8), FC_TAILB(16), FC_TAILB(32));
 #undef FC_TAILB
 #define FC_FINB(K) hipLaunchKernelGGL((fc_final_b<K>), dim3(B.k), dim3(1024), 0, h->stream, G, n_row_blocks, B.partial.p, h->n_sens, h->s_rowptr.p, h->s_idxp.p, \
                                       h->s_w.p, xnew, B.flag.p, h->pin_dev, kRecStride, seqp, compute_energy)
@@ -5156,7 +5222,46 @@ static int batch_launches(fc_ctx* h, int order_slot, int compute_energy, bool le
 #undef FC_FINB
   }
   if (spec_slot >= 0) element_loop(coeffs_for(h, spec_slot), xnew, un);  // the NEXT step's loop: its (u_n, u_nn) = (this solution, this u_n)
+  if (spec_slot >= 0 && spec_gather) {
+    // ... and the control-independent part of its right-hand side, into the buffers that step will use: b of the next ring phase (none of
+    // the two late tails that may still run reads it) and the y half of its work buffer
+    OrderSys& Sn = h->sys[spec_slot];
+    double* bnext = B.bstore.p + (overlapped ? (size_t)((B.cur + 1) % 4) * (size_t)N * KB : 0);
+    double* ynext = bat_slot(h, B.cur + 2);
+#define FC_GATH(K) hipLaunchKernelGGL((fc_rhs_gather_b<K>), dim3(g_rows), dim3(256), 0, h->stream, N, h->gptr_p.p, h->gidx_p.p, B.ev.p, h->bcslot_p.p, \
+                                      h->bcprof.p, Sn.lift_p.p, h->n_act, uc, kRecStride, bnext, ynext, (const int*)nullptr, Sn.c_col.p, Sn.c_val.p, xnew, 0, \
+                                      late_gate ? (unsigned long long*)h->solved.p : (unsigned long long*)nullptr, seqp)
+    FC_KB_DISPATCH(KB, FC_GATH(4), FC_GATH(8), FC_GATH(16), FC_GATH(32));
+#undef FC_GATH
+  }
   HIPCHK(hipGetLastError());
+  return FC_OK;
+}
+
+// rows of `slot` whose right-hand side depends on u_ctrl: Dirichlet rows and rows with an entry in a lifting vector (permuted numbering)
+static int build_ctrl_rows(fc_ctx* h, int slot) {
+  fc_ctx::Batch& B = h->bat;
+  OrderSys& S = h->sys[slot];
+  const int N = h->N;
+  std::vector<double> lift((size_t)std::max(1, h->n_act) * N, 0.0);
+  if (h->n_act > 0 && S.lift_p.n >= (size_t)h->n_act * N) {
+    HIPCHK(hipMemcpyAsync(lift.data(), S.lift_p.p, (size_t)h->n_act * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  std::vector<int> ip((size_t)N), rows;
+  for (int i = 0; i < N; ++i) ip[(size_t)h->h_perm[(size_t)i]] = i;
+  std::vector<unsigned char> isbc((size_t)N, 0);
+  for (int k = 0; k < h->n_bc; ++k) isbc[(size_t)ip[(size_t)h->h_bc_dofs[(size_t)k]]] = 1;
+  for (int i = 0; i < N; ++i) {
+    bool dep = isbc[(size_t)i] != 0;
+    for (int k = 0; k < h->n_act && !dep; ++k) dep = lift[(size_t)k * N + i] != 0.0;
+    if (dep) rows.push_back(i);
+  }
+  B.n_ctrl_rows[slot] = (int)rows.size();
+  if (rows.empty()) rows.push_back(0);
+  FCCHK(B.ctrl_rows[slot].upload(rows, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  B.ctrl_ok[slot] = true;
   return FC_OK;
 }
 
@@ -5171,9 +5276,9 @@ static int batch_launches_side(fc_ctx* h, int order_slot, int compute_energy) {
   FCCHK(batch_tail_geometry(h, compute_energy, &n_row_blocks, &n_cell_blocks));
   const int G = n_row_blocks + n_cell_blocks;
   hipLaunchKernelGGL(fc_wait_solved_b, dim3(1), dim3(1), 0, h->stream2, (const unsigned long long*)h->solved.p, seqp, h->side_err.p, h->gate_spin);
-#define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(256), (size_t)B.tb_cols * K * sizeof(double), h->stream2, N, h->velrow_p.p, xnew, B.b.p, B.tblocks.p, \
-                                       B.tcols.p, S.Ap_rowptr.p, B.tlidx.p, S.Ap_val.p, h->flag2x.p, B.partial.p, G, n_cell_blocks, nc, h->cnp.p, h->geom.p)
-  FC_KB_DISPATCH(KB, FC_TAILB(4), FC_TAILB(8), FC_TAILB(16), FC_TAILB(32));
+#define FC_TAILB(K) hipLaunchKernelGGL((fc_tail_b<K>), dim3(G), dim3(256), fc_tail_b_lds(B.tb_cols, K), h->stream2, N, h->velrow_p.p, xnew, B.b.p, B.tblocks.p, \
+                                       B.tcols.p, (const int4*)B.trowd.p, B.tlidx.p, S.Ap_val.p, h->flag2x.p, B.partial.p, G, n_cell_blocks, nc, h->cnp.p, h->geom.p, B.tb_cols)
+  if (G > 0) FC_KB_DISPATCH(KB, FC_TAILB(4), FC_TAILB(8), FC_TAILB(16), FC_TAILB(32));
 #undef FC_TAILB
 #define FC_FINLB(K) hipLaunchKernelGGL((fc_final_late_b<K>), dim3(B.k), dim3(1024), 0, h->stream2, G, n_row_blocks, B.partial.p, h->pin_dev, kRecStride, \
                                        kLateRecB + 8 * par, seqp, compute_energy, (const int*)h->side_err.p)
@@ -5185,7 +5290,7 @@ static int batch_launches_side(fc_ctx* h, int order_slot, int compute_energy) {
 
 // everything a kernel argument of batch_launches is taken from, hashed (FNV-1a): a captured graph is replayed only while
 // this is unchanged
-static uint64_t batch_signature(fc_ctx* h, int order_slot, int compute_energy, bool lead_elem, int spec_slot) {
+static uint64_t batch_signature(fc_ctx* h, int order_slot, int compute_energy, int lead_elem, int spec_slot, bool spec_gather) {
   fc_ctx::Batch& B = h->bat;
   OrderSys& S = h->sys[order_slot];
   const StepCoeffs c = coeffs_for(h, order_slot);
@@ -5204,7 +5309,8 @@ static uint64_t batch_signature(fc_ctx* h, int order_slot, int compute_energy, b
       (uint64_t)(uintptr_t)B.partial.p, (uint64_t)(uintptr_t)h->s_rowptr.p, (uint64_t)(uintptr_t)h->s_idx.p, (uint64_t)(uintptr_t)h->s_w.p,
       (uint64_t)(uintptr_t)h->pin_dev, (uint64_t)(uintptr_t)B.tblocks.p, (uint64_t)(uintptr_t)B.tcols.p, (uint64_t)(uintptr_t)B.tlidx.p, (uint64_t)B.n_tblocks, (uint64_t)B.k, (uint64_t)B.KB, (uint64_t)h->n_act, (uint64_t)h->n_sens, (uint64_t)(h->have_force ? 1 : 0),
       (uint64_t)(S.have_c ? 1 : 0), (uint64_t)compute_energy, (uint64_t)B.launches.size(), (uint64_t)B.tasks.n, bits(c.cm_n), bits(c.cm_nn), bits(c.cc_n),
-      bits(c.cc_nn), (uint64_t)(lead_elem ? 1 : 0), (uint64_t)(spec_slot + 1), spec_slot >= 0 ? bits(coeffs_for(h, spec_slot).cm_n) : 0,
+      bits(c.cc_nn), (uint64_t)lead_elem, (uint64_t)(spec_gather ? 1 : 0), (uint64_t)(B.pend_checked ? 1 : 0), (uint64_t)(uintptr_t)B.ctrl_rows[order_slot].p, (uint64_t)B.n_ctrl_rows[order_slot],
+      (uint64_t)(uintptr_t)B.bstore.p, (uint64_t)(spec_slot + 1), spec_slot >= 0 ? bits(coeffs_for(h, spec_slot).cm_n) : 0,
       spec_slot >= 0 ? bits(coeffs_for(h, spec_slot).cm_nn) : 0, spec_slot >= 0 ? bits(coeffs_for(h, spec_slot).cc_n) : 0,
       spec_slot >= 0 ? bits(coeffs_for(h, spec_slot).cc_nn) : 0};
   uint64_t hsh = 1469598103934665603ull;
@@ -5219,14 +5325,14 @@ static uint64_t batch_signature(fc_ctx* h, int order_slot, int compute_energy, b
 static void batch_drop_graphs(fc_ctx* h) {
   for (int ph = 0; ph < 4; ++ph)
     for (int o = 0; o < 2; ++o)
-      for (int e = 0; e < 2; ++e)
-        for (int l = 0; l < 2; ++l) {
+      for (int e = 0; e < 4; ++e)
+        for (int l = 0; l < 3; ++l) {
           if (h->bat.gexec[ph][o][e][l]) (void)hipGraphExecDestroy(h->bat.gexec[ph][o][e][l]);
           h->bat.gexec[ph][o][e][l] = nullptr;
           h->bat.gsig[ph][o][e][l] = 0;
         }
   for (int ph = 0; ph < 4; ++ph)
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < 4; ++e) {
       if (h->bat.gside[ph][e]) (void)hipGraphExecDestroy(h->bat.gside[ph][e]);
       h->bat.gside[ph][e] = nullptr;
       h->bat.gside_sig[ph][e] = 0;
@@ -5235,9 +5341,13 @@ static void batch_drop_graphs(fc_ctx* h) {
 }
 
 static int batch_enqueue(fc_ctx* h, int order_slot, int compute_energy, bool overlapped) {
+  // FC_BATCH_GRAPH=1: replay the step as a HIP graph per (ring phase, slot, flags).  Default since round 5: plain launches -- the first
+  // kernel of a step starts ~10 us sooner than behind hipGraphLaunch and the other ~16 launches are enqueued while the GPU works
+  // (k = 8 / 16 / 32 on O1: 49.2 / 90.3 / 139.0 k simulated steps/s against 50.3 / 87.9 / 135.6 k with graphs; the host spends
+  // ~60 us per step launching, a third of the step)
   static const bool use_graph = [] {
-    const char* e = std::getenv("FC_BATCH_GRAPH");  // 0: plain launches
-    return !(e && e[0] == '0');
+    const char* e = std::getenv("FC_BATCH_GRAPH");
+    return e && e[0] == '1';
   }();
   fc_ctx::Batch& B = h->bat;
   // element loop of the NEXT step behind this one (same prediction as speculate_next_rhs: BDF2 follows, or the same CN slot);
@@ -5251,26 +5361,46 @@ static int batch_enqueue(fc_ctx* h, int order_slot, int compute_energy, bool ove
     const int next = h->sys[order_slot].have_c ? order_slot : FC_SLOT_BDF2;
     if (h->sys[next].ready && h->sys[next].have_lift) spec_slot = next;
   }
-  const bool lead = B.pre_slot != order_slot || h->have_force;
+  // ... and the control-independent part of its right-hand side behind it (FC_SPECULATE_GATHER=0: not): what is left for the next step
+  // before its factor sweeps is the handful of rows that see u_ctrl.  Not for Crank-Nicolson slots (their explicit operator would be
+  // subtracted in another order than the full gather does it: the batched and the single run are kept bit-identical)
+  static const bool speculate_gather = [] {
+    const char* e = std::getenv("FC_SPECULATE_GATHER");
+    return !(e && e[0] == '0');
+  }();
+  bool spec_gather = false;
+  if (spec_slot >= 0 && speculate_gather && !h->sys[spec_slot].have_c) {
+    if (!B.ctrl_ok[spec_slot]) FCCHK(build_ctrl_rows(h, spec_slot));
+    spec_gather = true;
+  }
+  const bool have_ev = B.pre_slot == order_slot && !h->have_force;
+  B.b.p = B.bstore.p + (overlapped ? (size_t)(B.cur % 4) * (size_t)h->N * B.KB : 0);  // (overlapped: b(n) stays intact for step n's late tail)
+  // (the gathered right-hand side counts only if it sits where this step reads it: a step that switches between the overlapped and the
+  //  one-stream form -- fc_step_batch after fc_step_batch_begin / _end_early -- gathers again)
+  const int lead = !have_ev ? 2 : ((B.pre_gather && B.ctrl_ok[order_slot] && B.pre_b == B.b.p && B.pre_y == B.buf.p) ? 0 : 1);
   B.pre_slot = -1;
-  B.b.p = B.bstore.p + (overlapped ? (size_t)(B.cur & 1) * (size_t)h->N * B.KB : 0);  // (overlapped: b(n) stays intact for step n's late tail)
+  B.pre_gather = false;
+  const double* spec_b = B.bstore.p + (overlapped ? (size_t)((B.cur + 1) % 4) * (size_t)h->N * B.KB : 0);
+  const double* spec_y = bat_slot(h, B.cur + 2);
   auto advance = [&]() {  // the solution this step writes is the state from here on
     B.cur = (B.cur + 1) % 4;
     bat_point(h);
     B.pre_slot = spec_slot;
+    B.pre_gather = spec_gather;
+    B.pre_b = spec_b, B.pre_y = spec_y;
   };
   if (!use_graph || h->timing) {
-    FCCHK(batch_launches(h, order_slot, compute_energy, lead, spec_slot, overlapped));
+    FCCHK(batch_launches(h, order_slot, compute_energy, lead, spec_slot, overlapped, spec_gather));
     if (overlapped) FCCHK(batch_launches_side(h, order_slot, compute_energy));
     advance();
     return FC_OK;
   }
   // one graph per ring phase: the buffers rotate with period four (the overlapped step is two graphs, one per stream)
-  const int ph = B.cur, ei = compute_energy ? 1 : 0, li = lead ? 1 : 0;
-  const uint64_t sig = batch_signature(h, order_slot, compute_energy, lead, spec_slot) ^ (overlapped ? 0x9e3779b97f4a7c15ull : 0ull);
+  const int ph = B.cur, ei = (compute_energy ? 1 : 0) + (B.pend_checked ? 2 : 0), li = lead;
+  const uint64_t sig = batch_signature(h, order_slot, compute_energy, lead, spec_slot, spec_gather) ^ (overlapped ? 0x9e3779b97f4a7c15ull : 0ull);
   hipGraphExec_t& gx = B.gexec[ph][order_slot][ei][li];
   if (!gx || B.gsig[ph][order_slot][ei][li] != sig) {
-    FCCHK(capture_graph(h, h->stream, &gx, [&] { return batch_launches(h, order_slot, compute_energy, lead, spec_slot, overlapped); }));
+    FCCHK(capture_graph(h, h->stream, &gx, [&] { return batch_launches(h, order_slot, compute_energy, lead, spec_slot, overlapped, spec_gather); }));
     B.gsig[ph][order_slot][ei][li] = sig;
   }
   HIPCHK(hipGraphLaunch(gx, h->stream));
@@ -5348,8 +5478,8 @@ int collect_late_batch(fc_ctx* h, int par) {
     for (int s = 0; s < B.k; ++s) {
       volatile double* rec = h->pin + (size_t)s * kRecStride + kLateRecB + 8 * par;
       B.last_dE[(size_t)s] = L.energy ? rec[0] : std::numeric_limits<double>::quiet_NaN();
-      B.last_r[(size_t)s] = rec[1];
-      B.last_b[(size_t)s] = rec[2];
+      B.last_r[(size_t)s] = L.checked ? (double)rec[1] : std::numeric_limits<double>::quiet_NaN();  // (off the monitor's cadence: NaN)
+      B.last_b[(size_t)s] = L.checked ? (double)rec[2] : std::numeric_limits<double>::quiet_NaN();
     }
   return FC_OK;
 }
@@ -5377,6 +5507,10 @@ static int step_batch_begin(fc_handle h, int order_slot, int32_t k, const double
       pin[s * kRecStride + a] = s < k ? u_ctrl[(size_t)s * h->n_act + a] : 0.0;
       pin[s * kRecStride + 32 + a] = s < k ? (u_force ? u_force[(size_t)s * h->n_act + a] : u_ctrl[(size_t)s * h->n_act + a]) : 0.0;
     }
+  // the residual monitor's cadence (fc_set_solver_options check_residual = n: every n-th batched step; the reference forms no residual at
+  // all, flowsolver.py:728-737); the non-finite test runs on every step
+  B.pend_checked = h->check_residual != 0 && (B.step_count % (uint64_t)h->check_residual) == 0;
+  ++B.step_count;
   B.pend_slot = order_slot;
   B.pend_energy = compute_energy;
   B.pend_seq = (double)(++h->seq);
@@ -5388,6 +5522,7 @@ static int step_batch_begin(fc_handle h, int order_slot, int32_t k, const double
     B.late[par].pending = true;
     B.late[par].seq = B.pend_seq;
     B.late[par].energy = compute_energy;
+    B.late[par].checked = B.pend_checked;
     B.side_busy = true;
   }
   B.pending = true;
@@ -5460,8 +5595,8 @@ static int step_batch_end(fc_handle h, int32_t k, double* y_out, double* dE_out,
     if (info_out) info_out[4 * s + 3] = flag;
     if (!B.pend_overlapped) {
       B.last_dE[(size_t)s] = B.pend_energy ? r[128] : std::numeric_limits<double>::quiet_NaN();
-      B.last_r[(size_t)s] = r[129];
-      B.last_b[(size_t)s] = r[130];
+      B.last_r[(size_t)s] = B.pend_checked ? (double)r[129] : std::numeric_limits<double>::quiet_NaN();
+      B.last_b[(size_t)s] = B.pend_checked ? (double)r[130] : std::numeric_limits<double>::quiet_NaN();
     }
   }
   if (B.pend_overlapped && (dE_out || info_out)) FCCHK(collect_late_batch(h, B.last_par));

@@ -244,6 +244,8 @@ int fc_newton_step(fc_handle h, double nu, double* up, const double* load, doubl
  *    step for all of them.  Needs fc_setup_solver (full factors, single GPU, no refinement sweeps).
  *    fc_set_batch(h, k) allocates the batched state (all zero; k = 0 frees it).  Host arrays are [k][...]
  *    (simulation-major).  The single-simulation state of the handle is independent of the batched one. */
+/*    (fc_set_solver_options' check_residual = n applies to the batched steps too: the residual monitor runs on every n-th batched step of
+ *    the handle, info_out[s][1], [2] are NaN in between; the non-finite test runs on every step.) */
 int fc_set_batch(fc_handle h, int32_t k);
 int fc_set_state_batch(fc_handle h, int32_t k, const double* u_n /* [k][2 nn] */, const double* u_nn /* [k][2 nn] */,
                        const double* p_n /* [k][nv] or NULL */);

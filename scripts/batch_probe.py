@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--ks", default="1,4,8,16,32")
     ap.add_argument("--refine", type=int, default=0, help="red-refinements of the cylinder mesh (1: BASELINE config 4 mesh)")
     ap.add_argument("--skip-parity", action="store_true")
+    ap.add_argument("--energy-every", type=int, default=1, help="params_save.energy_every of the throughput runs (0: the tail has no cell workgroups)")
+    ap.add_argument("--reps", type=int, default=1, help="repeat every throughput measurement (box noise)")
     a = ap.parse_args()
     from flowcontrol_amd._lib import SLOT_BDF2
     from flowcontrol_amd.batch import BatchedFlowSolver
@@ -34,6 +36,7 @@ def main():
 
     kw = {"meshpath": refined_cylinder_mesh(a.refine)} if a.refine else {}
     fs = CylinderFlowSolver.make_default(Re=100, path_out=tempfile.mkdtemp(), num_steps=10, **kw)
+    fs.params_save.energy_every = a.energy_every
     g = np.load(ROOT / "tests" / "golden" / ("cylinder_O1_refined1.npz" if a.refine else "cylinder_O1.npz"))
     U0, P0 = Function(fs.W, g["UP0"]).split()
     fs._assign_steady_state(U0, P0)
@@ -88,10 +91,15 @@ def main():
         u = np.zeros((k, 2))
         for _ in range(20):
             bfs.step(u)
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            bfs.step(u)
-        dt = (time.perf_counter() - t0) / a.steps
+        dts = []
+        for _ in range(a.reps):
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                bfs.step(u)
+            dts.append((time.perf_counter() - t0) / a.steps)
+        dt = min(dts)
+        if a.reps > 1:
+            print("   reps [sim-steps/s]:", " ".join(f"{k / d:.0f}" for d in dts), flush=True)
         ms = dev.bench_batch_apply(SLOT_BDF2, 100)
         info = dev.batch_info()
         gb = (info["factor_bytes"] + info["vector_bytes"]) / 1e9

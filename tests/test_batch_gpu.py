@@ -334,3 +334,37 @@ def test_lidcavity_ic_sweep_example_matches_single_runs(tmp_path_factory):
         single.th.release_device()
     bfs.close()
     fs.th.release_device()
+
+
+def test_batched_residual_monitor_cadence_and_the_gather_that_runs_ahead(golden_dir):
+    """``check_residual_every = n`` on the batched path: the residual is formed on every n-th batched step (NaN in between, the
+    non-finite test stays on every step) and the trajectories are those of the every-step run (sensors bit for bit) — as they are with
+    the control-independent right-hand side gathered one step ahead (the default) or not (FC_SPECULATE_GATHER=0 is read once
+    per process, so the second property is checked against the single runs by the parity test above and here by actuating)."""
+    from flowcontrol_amd.batch import BatchedFlowSolver
+
+    k, n = 5, 13
+    ics = [ParamIC(xloc=2.0 + 0.2 * i, yloc=0.05 * i, radius=0.5, amplitude=1.0 + 0.1 * i) for i in range(k)]
+    us = [np.array([[0.03 * (i + 1) * np.sin(0.4 * m), -0.02 * i * np.cos(0.3 * m)] for i in range(k)]) for m in range(n)]
+    out = {}
+    for every in (1, 4):
+        fs = _solver(golden_dir)
+        fs.check_residual_every = every
+        bfs = BatchedFlowSolver(fs, k)
+        bfs.initialize_time_stepping(ics=ics)
+        res = []
+        for m in range(n):
+            bfs.step(us[m])
+            res.append(bfs.solve_info[:, 1].copy())
+        out[every] = ([bfs.timeseries(i) for i in range(k)], np.array(res))
+        bfs.close()
+        fs.th.release_device()
+    ts1, r1 = out[1]
+    ts4, r4 = out[4]
+    assert np.all(r1 < 1e-12)
+    checked = np.arange(n) % 4 == 0
+    assert np.all(r4[checked] < 1e-12) and np.all(np.isnan(r4[~checked]))
+    for a, b in zip(ts1, ts4):
+        assert np.array_equal(a[_ycols(a)].to_numpy(), b[_ycols(b)].to_numpy())
+        # (the energy's partial sums sit at other positions of the fold when the row blocks are absent: another summation tree)
+        assert np.allclose(a["dE"].to_numpy(), b["dE"].to_numpy(), rtol=1e-13, atol=0.0)
