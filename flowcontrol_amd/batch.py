@@ -64,7 +64,7 @@ class BatchedFlowSolver:
             raise RuntimeError("batched stepping runs on single-GPU handles (replicas scale across GPUs by themselves)")
         self.dev.set_batch(self.k)
         # the residual monitor's cadence of the single run applies to the batch (fs.check_residual_every: every n-th batched step)
-        self.dev.set_solver_options(refine=0, check_residual=fs.check_residual_every)
+        self.dev.set_solver_options(refine=0, check_residual=-1 if fs.check_residual_every is None else fs.check_residual_every)
         self._ready = True
 
     def initialize_time_stepping(self, ics: Sequence[ParamIC | Function | None] | None = None, Tstart: float = 0.0) -> None:

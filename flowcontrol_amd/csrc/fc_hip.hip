@@ -598,6 +598,13 @@ void tabulate(double* phi2, double* dphi2, double* phi1, double* qw) {
 
 inline int nblocks(int64_t n, int per) { return (int)((n + per - 1) / per); }
 
+// cadence of the residual monitor for a slot: fc_set_solver_options' check_residual, -1 = auto -- every step while the factors stay in the
+// Infinity Cache (the pass over the system matrix hides beside the next step), every 8th step where they stream from HBM (there the
+// pass costs ~10 % of the step: cavity_fine 150 of 1 098 us).  The reference forms no residual at all (flowsolver.py:728-737).
+// (partitioned handles keep every step: their residual rides in the tail record's all-reduce at no extra exchange)
+inline int residual_every(const fc_ctx* h, const OrderSys& S) { return h->check_residual < 0 ? ((S.nt && !h->partitioned) ? 8 : 1) : h->check_residual; }
+
+
 int pick_lanes(double mean_nnz) {
   if (const char* e = std::getenv("FC_SPMV_LANES")) {  // tuning aid
     const int v = std::atoi(e);
@@ -1325,7 +1332,8 @@ int launch_tail(fc_ctx* h, OrderSys& S, int compute_energy, double* d_y, double*
                 double* d_seq, double seq) {
   // check_residual = n >= 1: the monitor runs on every n-th step of the handle (the reference never forms this residual,
   // flowsolver.py:728-737 tests finiteness only; n > 1 amortises the matrix pass); the steps in between report NaN
-  const bool res = h->check_residual != 0 && (h->step_count % (uint64_t)h->check_residual) == 0;
+  const int every = residual_every(h, S);
+  const bool res = every != 0 && (h->step_count % (uint64_t)every) == 0;
   h->last_checked = res;
   const bool part = h->partitioned;
   const int ncl = part ? h->ncl : h->nc;
@@ -3120,7 +3128,7 @@ int fc_accept_factors(fc_handle h, int slot, double* residual_out, int32_t* inex
 // (shape of the default elimination tree: fcsym::default_bits, mirrored by flowcontrol_amd/ndsolver.py::default_bits)
 
 int fc_setup_solver(fc_handle h, int slot, int32_t depth, int32_t merge, int32_t truncate, int32_t refine, int32_t check_residual) {
-  if (!h || slot < 0 || slot > 1 || merge < 1 || merge > 4 || depth < 0 || truncate < 0 || refine < 0)
+  if (!h || slot < 0 || slot > 1 || merge < 1 || merge > 4 || depth < 0 || truncate < 0 || refine < 0 || check_residual < -1)
     return fail(FC_ERR_INVALID, "fc_setup_solver: bad argument");
   if (!h->slot_ok[slot] || !h->sys[slot].have_lift) return fail(FC_ERR_NOT_READY, "fc_setup_solver: assemble the slot and call fc_apply_bc first");
   HIPCHK(hipSetDevice(h->device));
@@ -3766,7 +3774,7 @@ int fc_set_energy_matrix(fc_handle h, const int32_t* rowptr, const int32_t* col,
 }
 
 int fc_set_solver_options(fc_handle h, int method, int max_iter, double rtol, int check_residual) {
-  if (!h || max_iter < 0 || max_iter > 1000 || check_residual < 0) return fail(FC_ERR_INVALID, "fc_set_solver_options: bad argument");
+  if (!h || max_iter < 0 || max_iter > 1000 || check_residual < -1) return fail(FC_ERR_INVALID, "fc_set_solver_options: bad argument");
   if (method != FC_METHOD_REFINE && method != FC_METHOD_BICGSTAB && method != FC_METHOD_GMRES)
     return fail(FC_ERR_INVALID, "fc_set_solver_options: unknown method (REFINE, BICGSTAB, GMRES)");
   if (method != FC_METHOD_REFINE && (max_iter < 1 || !(rtol > 0.0)))
@@ -3880,7 +3888,8 @@ static bool step_can_overlap(const fc_ctx* h, int order_slot) {
   const OrderSys& S = h->sys[order_slot];
   // (factors that stream from HBM -- S.nt -- leave no slack for a concurrent matrix pass: measured on the refined cylinder, the pinball and
   //  cavity_fine the overlapped tail costs 6-8 % of the step rate where the cache-resident O1 gains 10 %; profiles/r04_overlap.txt)
-  return h->overlap && !h->want_all && !S.nt && !h->partitioned && h->method == FC_METHOD_REFINE && !S.inexact && !S.truncated && S.bits == 64 && use_fused_tail(h) && !h->timing &&
+  static const bool overlap_nt = [] { const char* e = std::getenv("FC_OVERLAP_NT"); return e && e[0] == '1'; }();  // experiment: overlap on streaming meshes too
+  return h->overlap && !h->want_all && (!S.nt || overlap_nt) && !h->partitioned && h->method == FC_METHOD_REFINE && !S.inexact && !S.truncated && S.bits == 64 && use_fused_tail(h) && !h->timing &&
          !h->phase_timing;
 }
 
@@ -3905,7 +3914,8 @@ static int step_enqueue_overlapped(fc_ctx* h) {
                      h->pend_seq, h->solved.p);
   ring_advance(h);  // the solution just written is the state from here on
   h->state_live = true;
-  const bool res = h->check_residual != 0 && (h->step_count % (uint64_t)h->check_residual) == 0;
+  const int every = residual_every(h, S);
+  const bool res = every != 0 && (h->step_count % (uint64_t)every) == 0;
   h->last_checked = res;
   ++h->step_count;
   speculate_next_rhs(h, order_slot);  // the next step's element loop, on the main stream behind fc_early as ever
@@ -5509,7 +5519,8 @@ static int step_batch_begin(fc_handle h, int order_slot, int32_t k, const double
     }
   // the residual monitor's cadence (fc_set_solver_options check_residual = n: every n-th batched step; the reference forms no residual at
   // all, flowsolver.py:728-737); the non-finite test runs on every step
-  B.pend_checked = h->check_residual != 0 && (B.step_count % (uint64_t)h->check_residual) == 0;
+  const int every = residual_every(h, S);
+  B.pend_checked = every != 0 && (B.step_count % (uint64_t)every) == 0;
   ++B.step_count;
   B.pend_slot = order_slot;
   B.pend_energy = compute_energy;

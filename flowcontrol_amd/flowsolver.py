@@ -98,7 +98,9 @@ class FlowSolver(ABC):
         #: ... on every n-th step (1: every step; 0: never).  The reference forms no such residual (flowsolver.py:728-737 tests finiteness
         #: only): the monitor is this solver's own check and costs one pass over the system matrix per monitored step.  On the steps
         #: in between ``solve_info[1]`` is NaN; the non-finite test runs on every step regardless.
-        self.check_residual_every: int = 1
+        #: None = auto: every step while the factors stay in the Infinity Cache (the pass hides beside the next step), every 8th step on
+        #: meshes whose factors stream from HBM (refined cylinder, pinball, cavity meshes: there it costs ~10 % of a step)
+        self.check_residual_every: int | None = None
         #: memory-lean mode: factorise only the tree levels >= nd_truncate and solve every step with a Krylov method
         #: preconditioned by those truncated factors (0 = full selected inverse, applied directly)
         self.nd_truncate: int = 0
@@ -1056,11 +1058,12 @@ class _DeviceNDSolver:
             if fs.krylov_precond != "schur_amg":
                 raise ValueError("krylov_precond: None (factors) or 'schur_amg'")
             dev.setup_krylov(self.slot, sweeps=fs.krylov_sweeps, method=fs.krylov_method, max_iter=fs.krylov_max_iter, rtol=fs.krylov_rtol,
-                             check_residual=fs.check_residual_every)
+                             check_residual=-1 if fs.check_residual_every is None else fs.check_residual_every)
             return
-        dev.setup_solver(self.slot, depth=fs.nd_depth, refine=fs.refine_steps, truncate=fs.nd_truncate, check_residual=fs.check_residual_every)
+        dev.setup_solver(self.slot, depth=fs.nd_depth, refine=fs.refine_steps, truncate=fs.nd_truncate, check_residual=-1 if fs.check_residual_every is None else fs.check_residual_every)
         if fs.nd_truncate or fs.factor_bits != 64:
-            dev.set_solver_options(refine=fs.krylov_max_iter, check_residual=fs.check_residual_every, method=fs.krylov_method, rtol=fs.krylov_rtol)
+            dev.set_solver_options(refine=fs.krylov_max_iter, check_residual=-1 if fs.check_residual_every is None else fs.check_residual_every,
+                                   method=fs.krylov_method, rtol=fs.krylov_rtol)
 
     def solve(self, x: np.ndarray, b: np.ndarray) -> None:
         sol, _ = self.fs.th.device().solve(self.slot, b)

@@ -162,7 +162,9 @@ int fc_update_operator(fc_handle h, int slot);
 /* method: FC_METHOD_*; max_iter: refinement sweeps (REFINE) or the Krylov iteration cap; rtol: Krylov target;
  * check_residual: 0 = no residual monitor, n >= 1 = fc_step / fc_run form |b - A x| / |b| on every n-th step of the handle (info[1];
  * NaN on the steps in between) -- the reference never forms it (flowsolver.py:728-737 tests finiteness only), n > 1 amortises the
- * pass over the system matrix it costs.  The non-finite test runs on every step regardless. */
+ * pass over the system matrix it costs; -1 = auto: every step while the slot's factors stay in the 256 MiB Infinity Cache (the pass
+ * hides beside the next step), every 8th step where they stream from HBM (there it costs ~10 % of a step).  The non-finite test
+ * runs on every step regardless. */
 int fc_set_solver_options(fc_handle h, int method, int max_iter, double rtol, int check_residual);
 
 /* FACTORISATION-FREE Krylov mode (reference plug-in point FlowSolver._make_solver, flowsolver.py:812-814: "any object with

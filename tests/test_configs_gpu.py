@@ -41,6 +41,7 @@ def _config4_solver(path_out, num_steps=50):
     from flowcontrol_amd.flowsolverparameters import ParamIC
 
     fs = CylinderFlowSolver.make_default(Re=100, path_out=path_out, num_steps=num_steps, meshpath=refined_cylinder_mesh(1))
+    fs.check_residual_every = 1  # these tests assert every step's residual (the default cadence is 8 where the factors stream from HBM)
     fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
     return fs
 
@@ -132,6 +133,7 @@ def _pinball(path_out):
 
     g = np.load(ROOT / "tests" / "golden" / "pinball_re100_rotation.npz")
     fs = PinballFlowSolver.make_default(Re=100, mode_actuation=CYLINDER_ACTUATION_MODE.ROTATION, path_out=path_out, num_steps=50)
+    fs.check_residual_every = 1  # (see _config4_solver)
     fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
     assert fs.th.N == int(g["ndofs"]) == 302035
     U0, P0 = Function(fs.W, g["UP0"]).split()
@@ -213,6 +215,7 @@ def test_config3_cavity_fine_closed_loop_vs_oracle(tmp_path_factory, golden_dir)
     fs = CavityFlowSolver.make_default(Re=7500, path_out=tmp_path_factory.mktemp("config3"), num_steps=N_STEPS,
                                        meshpath=mesh_file("cavity_fine"))
     assert fs.th.N == int(g["ndofs"]) == 876645 and fs.th.nc == int(g["ncells"])
+    fs.check_residual_every = 1  # every step's residual is asserted below (default where the factors stream from HBM: every 8th step)
     fs.compute_steady_state(method="picard", max_iter=10, tol=1e-7, u_ctrl=[0.0])
     fs.compute_steady_state(method="newton", max_iter=10, u_ctrl=[0.0], initial_guess=fs.fields.UP0)
     up0 = fs.fields.UP0.vector().get_local()
@@ -269,6 +272,6 @@ def test_example_scripts_run_end_to_end(tmp_path_factory):
     assert any(p.suffix == ".csv" for p in Path(fs.params_save.path_out).rglob("*"))
     fs.th.release_device()
     fs = run_pinball_suction_example.main(num_steps=4, path_out=tmp_path_factory.mktemp("ex_pinball"))
-    assert np.all(np.isfinite(fs.y_meas)) and fs.solve_info[1] < 1e-10
+    assert np.all(np.isfinite(fs.y_meas)) and 0.0 < fs.residual_max < 1e-10  # (the monitor ran on the first step at least: default cadence)
     assert np.abs(fs.timeseries[["u_ctrl_1", "u_ctrl_2", "u_ctrl_3"]].to_numpy()[1:]).max() > 0  # the bumps were applied
     fs.th.release_device()
