@@ -373,7 +373,7 @@ def run_case(case, comm, device, steps, with_roofline):
            "worst_relative_residual": worst,
            # cadence of the residual monitor in the timed loop (the solver's default: every step while the factors stay in the Infinity Cache,
            # every 8th step where they stream from HBM; the reference forms no residual at all) -- finiteness, sensors and energy: every step
-           "residual_monitor_every": (fs.check_residual_every if fs.check_residual_every is not None
+           "residual_monitor_every": (getattr(fs, "check_residual_every", None) if getattr(fs, "check_residual_every", None) is not None
                                       else (8 if (comm.world == 1 and dev.factor_storage(1)[1] > 268435456) else 1)),
            "y_last": np.asarray(fs.y_meas).tolist(), "setup_s": setup_s,
            "refactor_ms": {str(k): float(v) for k, v in dev.refactor_ms.items()}}
