@@ -21,17 +21,25 @@ ks["Name"] = ks["Name"].str.slice(0, 70)
 ks.head(16).to_csv(out + "/kernel_stats.csv", index=False)
 print(ks[["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"]].head(16).to_string(index=False))
 res = {}
+per_kernel = {}
 for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     c = pd.read_csv(glob.glob(f"{out}/{sub}/**/*_counter_collection.csv", recursive=True)[0])
     c = c[c["Counter_Name"] == name]
-    sw = c[c["Kernel_Name"].str.contains("fc_nd_sweep|fc_nd_down_block")]
+    # every launch of a factor apply (segment sweeps, LDS-tiled blocks, the column form's fold launches); applies of the run (time steps,
+    # base-flow iterations, acceptance solves alike) = those launches / launches per apply as the library reports them
+    sw = c[c["Kernel_Name"].str.contains("fc_nd_sweep|fc_nd_down_block|fc_nd_fold1")]
     d = json.loads(open(f"{out}/bench_{'fetch' if name == 'FETCH_SIZE' else 'write'}.json").read().strip().splitlines()[-1])
-    launches = d["roofline"]["launches_per_apply"]
-    n_apply = len(sw.groupby("Dispatch_Id")) / launches
+    res["launches_per_apply"] = d["roofline"]["launches_per_apply"]
+    n_apply = len(sw.groupby("Dispatch_Id")) / res["launches_per_apply"]
     res[name + "_KB_per_apply_raw"] = float(sw["Counter_Value"].sum() / n_apply)
     res["bytes_per_apply_algorithmic"] = d["roofline"]["bytes_per_apply"]
-res["bytes_per_apply_counters"] = (2.0 * res["FETCH_SIZE_KB_per_apply_raw"] + res["WRITE_SIZE_KB_per_apply_raw"]) * 1024.0  # gfx950: FETCH_SIZE counts 128-B requests at 64 B
-res["bytes_per_apply_counters_uncorrected"] = (res["FETCH_SIZE_KB_per_apply_raw"] + res["WRITE_SIZE_KB_per_apply_raw"]) * 1024.0
+    for kname, g in sw.groupby(sw["Kernel_Name"].str.replace(r"^void ", "", regex=True).str.slice(0, 40)):
+        per_kernel.setdefault(kname, {})[name + "_KB_per_apply_raw"] = float(g["Counter_Value"].sum() / n_apply)
+# gfx950: FETCH_SIZE tallies the 128-B requests at 64 B -- a factor 2.00 for every access width these kernels use (8 B and 16 B per lane,
+# 8- and 16-lane rows, nontemporal or not: scripts/fetch_calib.sh, profiles/r05_fetch_calib.csv); WRITE_SIZE reads true
+res["bytes_per_apply_counters"] = (2.0 * res["FETCH_SIZE_KB_per_apply_raw"] + res["WRITE_SIZE_KB_per_apply_raw"]) * 1024.0
+res["counters_over_algorithmic"] = res["bytes_per_apply_counters"] / res["bytes_per_apply_algorithmic"]
+res["per_kernel"] = per_kernel
 json.dump(res, open(out + "/traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
