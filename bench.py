@@ -575,7 +575,7 @@ def run_rank(comm, args, device):
             "bytes_per_launch": bytes_per_launch, "launches_per_step": tim["sweep_launches"] / args.steps,
             "mean_launch_us": mean_launch_ms * 1e3, "factor_nnz": dev.factor_nnz.get(SLOT_BDF2),
             "applies_per_step": applies / args.steps,
-            # bisections fused per level of the elimination tree, root first (the default shape of this mesh: ndsolver.default_bits; 2 x levels + 1 launches)
+            # bisections fused per level of the elimination tree, root first (fc_get_tree_info; 2 x levels + 1 launches)
             "tree_bits": tree["bits"],
             # fractions that stay comparable across rounds (the design's own byte count grows with the fill of the tree it picks): the
             # apply's wall time per call, the same time priced at 8 B per stored factor value only, and at the bytes of the

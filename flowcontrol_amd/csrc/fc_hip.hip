@@ -602,7 +602,11 @@ inline int nblocks(int64_t n, int per) { return (int)((n + per - 1) / per); }
 // Infinity Cache (the pass over the system matrix hides beside the next step), every 8th step where they stream from HBM (there the
 // pass costs ~10 % of the step: cavity_fine 150 of 1 098 us).  The reference forms no residual at all (flowsolver.py:728-737).
 // (partitioned handles keep every step: their residual rides in the tail record's all-reduce at no extra exchange)
-inline int residual_every(const fc_ctx* h, const OrderSys& S) { return h->check_residual < 0 ? ((S.nt && !h->partitioned) ? 8 : 1) : h->check_residual; }
+// ... and so do Krylov solves (the monitor is what checks their result against the fp64 operator, at a fraction of their cost)
+inline int residual_every(const fc_ctx* h, const OrderSys& S) {
+  if (h->check_residual >= 0) return h->check_residual;
+  return (S.nt && !h->partitioned && h->method == FC_METHOD_REFINE && !S.inexact) ? 8 : 1;
+}
 
 
 int pick_lanes(double mean_nnz) {
@@ -3185,8 +3189,17 @@ int fc_setup_solver(fc_handle h, int slot, int32_t depth, int32_t merge, int32_t
     if (!S.structured) {
       const fcsym::Tree& t = h->sym_tree;
       const fcsym::Factors& fac = h->sym_fac;
-      const fcsym::Partition part = fcsym::partition(t, fac, rank, world);
-      if (world > 1 && !h->partitioned)
+      fcsym::Partition part = fcsym::partition(t, fac, rank, world);
+      // a ONE-rank communicator (test aid, FC_FORCE_COMM=1 on the Python side: fc_comm_init with nranks = 1): everything is owned and the
+      // root's rows are "shared" with nobody, but the partitioned code path -- cell list, row kinds, both in-stream all-reduces of the
+      // apply, the tail record's -- runs as it does on several GPUs
+      const bool one_rank_comm = world == 1 && h->comm != nullptr && truncate == 0;
+      if (one_rank_comm) {
+        const int64_t root0 = t.node_ptr[0].front(), root1 = t.node_ptr[0].back();
+        for (int64_t i = root0; i < root1; ++i) part.rowkind[(size_t)t.perm[(size_t)i]] = 2;
+        part.ar_stage = t.depth - 1, part.ar_row0 = (int)root0, part.ar_n = (int)(root1 - root0), part.ar2_stage = t.depth;
+      }
+      if ((world > 1 || one_rank_comm) && !h->partitioned)
         FCCHK(fc_set_partition(h, (int)part.local_cells.size(), part.local_cells.data(), part.rowkind.data(), rank == 0 ? 1 : 0));
       const int zero32 = 0;
       const int64_t zero64 = 0;
@@ -3199,7 +3212,13 @@ int fc_setup_solver(fc_handle h, int slot, int32_t depth, int32_t merge, int32_t
       int64_t local = 0;
       for (int v : part.seg_len) local += v;
       h->sym_local_values[slot] = local;
-      const fcsym::Blocks B = fcsym::down_blocks(t, fac, rank, world);
+      // (tuning / test aids: FC_BLOCK_KERNEL=0 keeps every down stage on the segment kernel, FC_BLOCK_TARGET / FC_BLOCK_MIN move the
+      //  rows-per-workgroup choice of the LDS-tiled block kernel through all of its instantiations)
+      const char* eb = std::getenv("FC_BLOCK_KERNEL");
+      const char* et = std::getenv("FC_BLOCK_TARGET");
+      const char* em = std::getenv("FC_BLOCK_MIN");
+      fcsym::Blocks B = fcsym::down_blocks(t, fac, rank, world, 32, et ? std::max(1, std::atoi(et)) : 1024, em ? std::max(1, std::atoi(em)) : 512);
+      if (eb && eb[0] == '0') std::fill(B.count.begin(), B.count.end(), 0);
       FCCHK(fc_solver_set_blocks(h, slot, (int)B.begin.size(), B.begin.data(), B.count.data(), B.lpr.data(), (int64_t)B.val.size(),
                                  B.val.empty() ? &zero64 : B.val.data(), B.row0.empty() ? &zero32 : B.row0.data(),
                                  B.nrows.empty() ? &zero32 : B.nrows.data(), B.i0.empty() ? &zero32 : B.i0.data(),
@@ -3229,7 +3248,7 @@ int fc_setup_solver(fc_handle h, int slot, int32_t depth, int32_t merge, int32_t
       return fail(FC_ERR_HIP, "fc_setup_solver: GMRES on the compressed factors needed " + std::to_string((int)info[0]) + " iterations (residual " + std::to_string(info[1]) + ")");
     return FC_OK;  // the caller chooses the Krylov method and its tolerances (fc_set_solver_options)
   }
-  if (truncate == 0 && (world == 1 ? !h->partitioned : exchanges(h))) {
+  if (truncate == 0 && (world == 1 ? (!h->partitioned || h->comm != nullptr) : exchanges(h))) {  // (a one-rank communicator probes like a single GPU)
     std::vector<double> b((size_t)N), x((size_t)N);
     for (int i = 0; i < N; ++i) b[i] = std::cos(0.37 * i + 0.1);
     // enclosed flow: a right-hand side compatible with the constant-pressure null space.  Decided by the GLOBAL pin

@@ -14,7 +14,6 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import _lib
-from . import ndsolver
 from ._lib import SLOT_BDF1, SLOT_BDF2, SLOT_MASS, SLOT_SCRATCH, check, ptr
 from .fem.spaces import TaylorHood
 
@@ -28,10 +27,6 @@ def _i32(a) -> np.ndarray:
 
 
 logger = logging.getLogger(__name__)
-
-def _default_depth(nc: int, merge: int, top: int) -> int:
-    """Binary bisections of the default elimination tree (``ndsolver.default_bits`` has the shape)."""
-    return int(sum(ndsolver.default_bits(nc, merge, top)))
 
 
 class DeviceSolver:
@@ -56,20 +51,15 @@ class DeviceSolver:
         check(self.lib.fc_get_pattern(self._h, self.rowptr, self.colidx))
         self.n_act = 0
         self.n_sens = 0
-        self._tree: ndsolver.NDTree | None = None
         self.perm: np.ndarray | None = None  # elimination ordering (new position -> W dof)
         self.factor_nnz: dict[int, int] = {}
         self.rank, self.world = 0, 1
-        self.use_block_kernel = os.environ.get("FC_BLOCK_KERNEL", "1") != "0"  # LDS-tiled down-sweeps
-        self.part: ndsolver.RankPartition | None = None
+        self.part = None  # multi-GPU: this rank's share (rowkind, local cells, exchange stages) as the library laid it out
         self._sensor_rows: list | None = None
-        # the numeric factorisation always runs on the device (fc_refactor); the symbolic phase (tree, factor layout,
-        # elimination plan, sweep tables) runs inside the library (fc_setup_solver); FC_PY_SYMBOLIC=1 keeps the numpy one of
-        # :mod:`ndsolver` that it mirrors
-        self.py_symbolic = os.environ.get("FC_PY_SYMBOLIC", "0") == "1"
+        # the whole solver setup -- symbolic phase (tree, factor layout, elimination plan, sweep tables: csrc/fc_symbolic.hpp) and numeric
+        # factorisation -- runs inside the library (fc_setup_solver).  The numpy specification the symbolic phase is compared with lives
+        # with the tests (tests/support/ndsolver.py, tests/test_symbolic_cabi.py).
         self._tree_args = None
-        self._fac_struct: ndsolver.BlockFactors | None = None
-        self._plan: ndsolver.FactorPlan | None = None
         self._structured: set[int] = set()
         self.refactor_ms: dict[int, float] = {}
         #: slot -> the factors missed the acceptance residual by the direct apply and serve as GMRES preconditioner (fc_accept_factors)
@@ -105,12 +95,10 @@ class DeviceSolver:
         # FC_FORCE_COMM=1 (test aid): build a 1-rank RCCL communicator and run the partitioned code
         # path (cell list, row kinds, in-stream all-reduces) on a single GPU
         self._force_comm = world == 1 and os.environ.get("FC_FORCE_COMM", "0") == "1"
-        if self._force_comm:
-            self.py_symbolic = True  # the one-rank partition is patched together on the host
         if world == 1 and not self._force_comm:
             return
         # another root for the elimination tree: whatever was set up for the single-GPU role is void
-        self._tree, self.perm, self._fac_struct, self._plan, self.part = None, None, None, None, None
+        self.perm, self.part = None, None
         self._structured.clear()
         if host_allreduce is not None:
             # exchange through the host (fc_set_host_exchange): no RCCL communicator; ``host_allreduce(array)`` sums a
@@ -237,7 +225,7 @@ class DeviceSolver:
         self.n_act = profiles.shape[1]
         if self.perm is not None and not np.array_equal(np.sort(bc_dofs), np.sort(getattr(self, "bc_dofs", bc_dofs))):
             # the elimination tree parks the Dirichlet dofs in the leaves: a different set needs a new tree
-            self._tree, self.perm, self._fac_struct, self._plan = None, None, None, None
+            self.perm = None
             self._structured.clear()
         self.bc_dofs = bc_dofs
         check(self.lib.fc_set_bc(self._h, len(bc_dofs), ptr(bc_dofs), self.n_act, ptr(np.ascontiguousarray(profiles))))
@@ -250,13 +238,7 @@ class DeviceSolver:
         check(self.lib.fc_set_force(self._h, self.n_act, ptr(profiles)))
 
     def set_sensors(self, rows: list[tuple[np.ndarray, np.ndarray]]) -> None:
-        self._sensor_rows = rows
-        if self.part is not None and self.py_symbolic:
-            # partitioned (the library does this itself on the fc_setup_solver path): every rank evaluates the part of each sensor row that lives on dofs it owns
-            # (root dofs: lead rank only); the partial readings are summed by the step's all-reduce
-            k = self.part.rowkind
-            keep = [(k[np.asarray(i)] == 1) | ((k[np.asarray(i)] == 2) & (self.rank == 0)) for i, _ in rows]
-            rows = [(np.asarray(i)[m], np.asarray(w)[m]) for (i, w), m in zip(rows, keep)]
+        self._sensor_rows = rows  # (partitioned handles: the library restricts every row to the dofs this rank accounts for)
         self.n_sens = len(rows)
         rp = np.zeros(len(rows) + 1, dtype=np.int32)
         for i, (idx, _) in enumerate(rows):
@@ -271,20 +253,19 @@ class DeviceSolver:
     def apply_bc(self, slot) -> None:
         check(self.lib.fc_apply_bc(self._h, slot))
 
-    # ── solver setup (host analysis + factorisation, device upload) ──────────
+    # ── solver setup (analysis + factorisation inside the library) ───────────
     def setup_solver(self, slot: int, depth: int | None = None, refine: int = 0, check_residual: bool | int = True, merge: int = 2,
                      restructure: bool = False, truncate: int = 0) -> None:
-        """Factorise the (BC-eliminated) matrix of ``slot`` and hand the factors to the device.
+        """Factorise the (BC-eliminated) matrix of ``slot`` on the device (``fc_setup_solver``).
 
         ``depth`` binary bisections (default: leaves of ≈ 12 cells), fused ``merge`` at a time into a
         2**merge-ary elimination tree (on ``world`` GPUs the root is ``world``-ary first: one sub-tree
         per rank); ``refine`` iterative-refinement sweeps per solve (the fp64 selected inverse is
         accurate to round-off on its own, so 0 + residual monitoring is the default).
 
-        The host only lays out the structure (once per tree); the numbers are computed on the device
-        (``fc_refactor``; on a partitioned handle every rank repeats it for the whole tree), and a later call
-        for the same slot is just that numeric phase (``restructure=True`` uploads the launch geometry
-        again).
+        Tree, permutation, factor layout, elimination plan and sweep tables are laid out once per tree by the library's own
+        symbolic phase (``csrc/fc_symbolic.hpp``); a later call for the same slot is just the numeric phase on the device
+        (on a partitioned handle every rank factorises its own sub-tree and the root).
 
         ``truncate = d > 0`` (memory-lean preconditioner): only the tree levels ≥ d are factorised and stored (the
         sub-domain solves and their couplings to the separators above — memory shrinks towards O(nnz) as d grows); the
@@ -294,101 +275,7 @@ class DeviceSolver:
             depth = int(os.environ["FC_ND_DEPTH"])
         if os.environ.get("FC_ND_MERGE"):
             merge = int(os.environ["FC_ND_MERGE"])
-        if not self.py_symbolic:
-            self._setup_solver_native(slot, depth, refine, check_residual, merge, truncate)
-            return
-        if self._tree is None:
-            th = self.th
-            top = int(np.log2(self.world)) if self.world > 1 else 0
-            bits = ndsolver.default_bits(th.nc, merge, top) if not depth else ndsolver.uniform_bits(depth, merge, top)
-            skip = np.zeros(self.N, dtype=bool)
-            skip[self.bc_dofs] = True
-            self._skip = skip
-            self._tree = ndsolver.build_tree(th.cell_dofs, th.mesh.cell_centroids(), self.N, sum(bits), skip, top_bits=top, bits=bits)
-            self.perm = self._tree.perm
-            self.depth = self._tree.depth
-            check(self.lib.fc_set_permutation(self._h, _i32(self.perm)))
-            self._upload_energy_matrix()
-        t = self._tree
-        # partitioned handles: every rank holds the whole (small) matrix but lays out and factorises its own sub-tree
-        # and the root only; the root front is summed over the ranks inside fc_refactor
-        up_split = int(os.environ.get("FC_UP_SPLIT", "0"))
-        # structure on the host (index work only, once per tree), numbers on the device
-        if self._fac_struct is None:
-            # a rank of a multi-GPU run lays out, stores and factorises its own sub-tree and the root only
-            keep = ndsolver.rank_keeps(t, self.rank, self.world) if self.world > 1 else None
-            self._truncate = int(truncate)
-            if truncate:
-                if self.world > 1 or truncate > t.depth:
-                    raise ValueError("truncate needs a single-GPU handle and 0 < truncate <= tree depth")
-                keep = lambda k, n: k >= truncate  # noqa: E731
-            self._fac_struct = ndsolver.factorize_blocks(None, t, numeric=False, keep=keep)
-            pl = ndsolver.factor_plan(self._fac_struct, self.rowptr, self.colidx, self._skip, keep=keep)
-            check(self.lib.fc_factor_plan(
-                self._h, int(pl.nodes.shape[0]), pl.nodes, int(pl.level_ptr.size - 1), pl.level_ptr, int(pl.front_size),
-                int(pl.a_src.size), pl.a_src if pl.a_src.size else np.zeros(1, np.int64), pl.a_dst if pl.a_dst.size else np.zeros(1, np.int64),
-                pl.a_ptr, pl.ext_off, int(pl.ext_p.size), pl.ext_p, int(pl.ap_src.size), pl.ap_src, int(pl.max_slots)))
-            rr = pl.root_rows  # a rank stores only the rows of the root's pivot-block inverse that it applies
-            check(self.lib.fc_set_root_rows(self._h, -1 if rr is None else rr[0] - int(t.node_ptr[0][0]), 0 if rr is None else rr[1] - rr[0]))
-            self._plan = pl
-            if truncate:  # the top levels' down stages become diagonal stages
-                self._fac_struct.stage_kind[t.depth : t.depth + truncate] = 2
-            if self._pin is not None:
-                self._upload_pin()
-            tag = sp.csr_matrix((np.ones(self.nnz), self.colidx, self.rowptr), shape=(self.N, self.N))
-            Ap = tag[t.perm][:, t.perm].tocsr()
-            Ap.sort_indices()
-            self._Ap_struct = Ap
-        if slot in self._structured and not restructure:
-            self.refactor(slot)
-            self.set_solver_options(refine, check_residual)
-            return
-        fac, Ap = ndsolver.split_up_segments(self._fac_struct, up_split), self._Ap_struct
-        part = ndsolver.partition(fac, self.rank, self.world)
-        if getattr(self, "_force_comm", False):
-            # single-rank communicator: everything is owned, the root rows are "shared" with nobody
-            root0, root1 = int(t.node_ptr[0][0]), int(t.node_ptr[0][-1])
-            part.rowkind[t.perm[root0:root1]] = 2
-            part.ar_stage, part.ar_row0, part.ar_n, part.ar2_stage = t.depth - 1, root0, root1 - root0, t.depth
-        if (self.world > 1 or getattr(self, "_force_comm", False)) and self.part is None:
-            check(self.lib.fc_set_partition(self._h, int(part.local_cells.size), ptr(_i32(part.local_cells)),
-                                            ptr(np.ascontiguousarray(part.rowkind, dtype=np.uint8)), int(self.rank == 0)))
-            self.part = part
-            if self._sensor_rows is not None:
-                self.set_sensors(self._sensor_rows)
-        idx = fac.idx if fac.idx.size else np.zeros(1, dtype=np.int32)
-        seg_val = part.seg_val if part.seg_val.size else np.zeros(1, dtype=np.int64)
-        seg_col = part.seg_col if part.seg_col.size else np.zeros(1, dtype=np.int32)
-        seg_len = part.seg_len if part.seg_len.size else np.zeros(1, dtype=np.int32)
-        check(
-            self.lib.fc_solver_setup(
-                self._h, slot, _i32(Ap.indptr), _i32(Ap.indices), _f64(Ap.data), len(part.stage_kind), part.stage_begin,
-                part.stage_row0, part.stage_nrows, part.stage_kind, part.seg_ptr, int(part.seg_val.size), seg_val,
-                seg_col, seg_len, int(fac.idx.size), _i32(idx), int(fac.vals.size), fac.vals,
-                int(part.ar_stage), int(part.ar_row0), int(part.ar_n), int(part.ar2_stage),
-            )
-        )
-        if self.use_block_kernel:
-            bb, bc, bl, bval, brow0, bnr, bi0, bni, bidx, bnb = ndsolver.down_blocks(
-                fac, self.rank, self.world, target_blocks=int(os.environ.get("FC_BLOCK_TARGET", "1024")),
-                min_blocks=int(os.environ.get("FC_BLOCK_MIN", "512")))
-            z64, z32 = np.zeros(1, np.int64), np.zeros(1, np.int32)
-            pick = lambda a, z: a if a.size else z  # noqa: E731
-            check(
-                self.lib.fc_solver_set_blocks(
-                    self._h, slot, len(bb), bb, bc, bl, int(bval.size), pick(bval, z64), pick(brow0, z32), pick(bnr, z32),
-                    pick(bi0, z32), pick(bni, z32), pick(bidx, z32), pick(bnb, z32), int(fac.idx.size), int(fac.vals.size),
-                )
-            )
-        if getattr(self, "_truncate", 0):
-            check(self.lib.fc_set_stage_diag(self._h, slot, _f64(ndsolver.schur_diagonal_scaling(self.matrix(slot), self.nn)[t.perm])))
-        self._structured.add(slot)
-        self.refactor(slot)
-        self.factor_nnz[slot] = int(fac.nnz)
-        self._n_factor_values = int(fac.vals.size)
-        self.local_factor_nnz = int(part.seg_len.sum())
-        self.n_stages = len(part.stage_kind)
-        self.set_solver_options(refine, check_residual)
+        self._setup_solver_native(slot, depth, refine, check_residual, merge, truncate)
 
     def _setup_solver_native(self, slot, depth, refine, check_residual, merge, truncate) -> None:
         """``fc_setup_solver``: tree, factor layout, elimination plan, sweep tables, numeric factorisation and its
@@ -406,7 +293,7 @@ class DeviceSolver:
             self.perm = np.empty(self.N, dtype=np.int32)
             check(self.lib.fc_get_permutation(self._h, self.perm))
             self._tree_args = (int(depth or 0), int(merge))
-        if self.world > 1 and self.part is None:
+        if (self.world > 1 or getattr(self, "_force_comm", False)) and self.part is None:
             from types import SimpleNamespace
 
             kind = np.empty(self.N, dtype=np.uint8)
@@ -425,25 +312,9 @@ class DeviceSolver:
         self._structured.add(slot)
         self._solver_opts = (int(refine), int(check_residual), "refine", 1e-10)
 
-    @property
-    def tree(self) -> "ndsolver.NDTree | None":
-        """The elimination tree as :mod:`ndsolver` builds it (tests and tools only: on the default path the library owns
-        the tree and this rebuilds the identical one on the host on first use)."""
-        if self._tree is None and self.perm is not None:
-            depth, merge = self._tree_args
-            top = int(np.log2(self.world)) if self.world > 1 else 0
-            bits = ndsolver.default_bits(self.th.nc, merge, top) if depth == 0 else ndsolver.uniform_bits(depth, merge, top)
-            skip = np.zeros(self.N, dtype=bool)
-            skip[self.bc_dofs] = True
-            self._tree = ndsolver.build_tree(self.th.cell_dofs, self.th.mesh.cell_centroids(), self.N, sum(bits), skip, top_bits=top, bits=bits)
-            assert np.array_equal(self._tree.perm, self.perm)
-        return self._tree
-
     def set_factor_precision(self, bits: int) -> None:
         """Storage width of the factor values of every slot set up from now on: 64 = exact selected inverse (default), 32 / 16
         = compressed factors (fp32 / bfloat16, 50 % / 25 % of the memory; a preconditioner for ``method="gmres" | "bicgstab"``)."""
-        if int(bits) != 64 and self.py_symbolic:
-            raise ValueError("compressed factors are laid out by the in-library analysis (unset FC_PY_SYMBOLIC)")
         if int(bits) != getattr(self, "_factor_bits", 64):
             self._structured.clear()
         check(self.lib.fc_set_factor_precision(self._h, int(bits)))
@@ -466,26 +337,21 @@ class DeviceSolver:
         if dof != self._pin:
             self._pin, self._pin_shift = dof, float(shift)
             self._probe = None
-            if not self.py_symbolic:
-                check(self.lib.fc_set_pressure_pin(self._h, -1 if dof is None else dof, float(shift)))
-            elif self._plan is not None:
-                self._upload_pin()
-
-    def _upload_pin(self) -> None:
-        if self._pin is None:
-            check(self.lib.fc_set_front_shifts(self._h, 0, np.zeros(1, np.int64), np.zeros(1)))
-        else:
-            slot = ndsolver.front_diagonal_slot(self._plan, self._tree, self._pin)
-            if slot < 0:  # the pinned dof is eliminated by another rank
-                check(self.lib.fc_set_front_shifts(self._h, 0, np.zeros(1, np.int64), np.zeros(1)))
-            else:
-                check(self.lib.fc_set_front_shifts(self._h, 1, np.array([slot], dtype=np.int64), np.array([self._pin_shift])))
+            check(self.lib.fc_set_pressure_pin(self._h, -1 if dof is None else dof, float(shift)))
 
     def refactor(self, slot: int) -> float:
         """Numeric factorisation of the slot's current matrix on the device (the structure of the first
         ``setup_solver`` is reused): what ``solver.set_operator(A)`` costs.  Returns device milliseconds."""
         if slot not in self._structured:
             raise RuntimeError("setup_solver(slot) must run once before refactor(slot)")
+        if getattr(self, "_truncate", 0):
+            # truncated factors (a preconditioner): the library redoes the numeric phase AND the diagonal stand-in of the dropped
+            # levels' Schur complement in one call; the caller's Krylov options stay
+            opts = self._solver_opts
+            depth, merge = self._tree_args
+            self._setup_solver_native(slot, depth, 0, opts[1], merge, self._truncate)
+            self.set_solver_options(*opts)
+            return self.refactor_ms[slot]
         ms = C.c_double()
         code = self.lib.fc_refactor(self._h, slot, C.byref(ms))
         self._raise_exchange_error()
@@ -497,9 +363,6 @@ class DeviceSolver:
             self._probe = np.cos(0.37 * np.arange(self.N) + 0.1)
             if self._pin is not None:
                 self._probe[2 * self.nn :] = 0.0  # compatible with the constant-pressure null space
-        if getattr(self, "_truncate", 0):
-            check(self.lib.fc_set_stage_diag(self._h, slot, _f64(ndsolver.schur_diagonal_scaling(self.matrix(slot), self.nn)[self.perm])))
-            return ms.value  # a preconditioner: nothing to probe
         # (on a partitioned handle the probe is a collective: every rank refactorises, every rank probes)
         res, inexact = C.c_double(), C.c_int32()
         code = self.lib.fc_accept_factors(self._h, slot, C.byref(res), C.byref(inexact))
@@ -517,8 +380,8 @@ class DeviceSolver:
         return a.value, b.value
 
     def factor_values(self, slot: int) -> np.ndarray:
-        """Factor values of ``slot`` as they sit on the device (layout of :class:`ndsolver.BlockFactors`)."""
-        n = int(self._fac_struct.vals.size) if self._fac_struct is not None else int(self._n_factor_values)
+        """Factor values of ``slot`` as they sit on the device (the layout ``fcsym::layout_factors`` / ``tests/support/ndsolver.BlockFactors`` describe)."""
+        n = int(self._n_factor_values)
         out = np.empty(n)
         check(self.lib.fc_get_factor_values(self._h, slot, n, out))
         return out

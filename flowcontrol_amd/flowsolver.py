@@ -5,7 +5,7 @@ case files and closed-loop scripts port unchanged; what differs is where the wor
 
 * ``_prepare_systems`` (reference ``:665-701``): both LHS matrices are assembled by the HIP
   element loop, Dirichlet rows/columns are eliminated on the device, and the time-invariant
-  operator is factorised once (``ndsolver``) into level-wise sparse factors that live in HBM.
+  operator is factorised once (``fc_setup_solver``) into level-wise sparse factors that live in HBM.
 * ``step`` (reference ``:703-799``) crosses the C ABI **once** (``fc_step``): RHS element loop with
   BC lifting → factor sweeps + refinement → split/shift → sensors → energy, all on one HIP stream;
   only ``u_ctrl`` goes in and ``(y_meas, dE, info)`` comes out.

@@ -27,9 +27,9 @@ for name in sys.argv[1:] or ["O1", "cavity_fine"]:
     ms = [dev.refactor(SLOT_BDF2) for _ in range(5)]
     b = np.random.default_rng(0).standard_normal(dev.N)
     _, info = dev.solve(SLOT_BDF2, b)
-    from flowcontrol_amd import ndsolver  # noqa: E402
+    from tests.support import ndsolver  # noqa: E402
 
-    nodes = ndsolver.factorize_blocks(None, dev.tree, numeric=False).nodes  # (level, index, i0, ni, nb, value offset, ...)
+    nodes = ndsolver.factorize_blocks(None, ndsolver.tree_of(dev), numeric=False).nodes  # (level, index, i0, ni, nb, value offset, ...)
     ni, nf = nodes[:, 3].astype(float), (nodes[:, 3] + nodes[:, 4]).astype(float)
     flops = float((2.0 * ni * nf * nf).sum())  # Gauss-Jordan: ni pivot steps, each a rank-1 update of the nf x nf front
     print(f"{name}: {nodes.shape[0]} fronts, {flops / 1e9:.2f} GFLOP per factorisation -> {flops / (min(ms) * 1e-3) / 1e12:.2f} TFLOP/s "

@@ -2,7 +2,7 @@
 Frobenius norm of the steady Jacobian A = -dF/dUP0 with bc.apply (reference test_operatorgetter.py:23-26,133-144)."""
 import sys, tempfile, numpy as np, time
 sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[2]))
-from flowcontrol_amd import ndsolver
+from tests.support import ndsolver
 from flowcontrol_amd.fem.boundary import combine_bcs
 from flowcontrol_amd.examples.cavity.cavityflowsolver import CavityFlowSolver
 from oracle import ns_oracle as O

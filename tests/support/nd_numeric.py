@@ -16,8 +16,8 @@ from dataclasses import dataclass
 import numpy as np
 import scipy.sparse as sp
 
-from flowcontrol_amd import ndsolver
-from flowcontrol_amd.ndsolver import BlockFactors, FactorPlan, NDTree, RankPartition
+from tests.support import ndsolver
+from tests.support.ndsolver import BlockFactors, FactorPlan, NDTree, RankPartition
 
 
 @dataclass

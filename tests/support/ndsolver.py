@@ -18,10 +18,11 @@ a level), which is what the HIP kernels in ``csrc/fc_hip.hip`` execute:
 The Krylov / iterative-refinement wrapper on the device uses this as its preconditioner; with
 fp64 factors it is exact to round-off, so one or two refinement steps reach LU-grade residuals.
 
-This module is the readable specification of the SYMBOLIC analysis (tree, factor layout, elimination plan, partition,
-tiles, dependencies) that the library performs natively (``csrc/fc_symbolic.hpp``; ``FC_PY_SYMBOLIC=1`` routes the setup
-through this module, ``tests/test_symbolic_cabi.py`` compares the two table by table).  The numbers are always computed on
-the device (``fc_refactor``); the numeric host multifrontal used by the tests is ``tests/support/nd_numeric.py``.
+TEST INFRASTRUCTURE (moved out of the package in round 5): this module is the readable numpy specification of the SYMBOLIC
+analysis (tree, factor layout, elimination plan, partition, tiles, dependencies).  The product has exactly one implementation
+of it, the library's ``csrc/fc_symbolic.hpp`` behind ``fc_setup_solver``; ``tests/test_symbolic_cabi.py`` compares the two
+table by table, the golden-fixture generators use the tree's permutation as a fill-reducing ordering for SuperLU, and the
+numeric host multifrontal the device factorisation is checked against is ``tests/support/nd_numeric.py``.
 """
 
 from __future__ import annotations
@@ -731,3 +732,15 @@ def partition(fac: BlockFactors, rank: int, world: int) -> RankPartition:
 
 
 __all__ += ["RankPartition", "partition"]
+
+
+def tree_of(dev) -> "NDTree":
+    """The elimination tree of a :class:`flowcontrol_amd.device.DeviceSolver` whose solver has been set up, rebuilt here from the
+    shape the library reports (``fc_get_tree_info``); its permutation must be the handle's."""
+    bits = dev.tree_info()["bits"]
+    top = int(np.log2(dev.world)) if dev.world > 1 else 0
+    skip = np.zeros(dev.N, dtype=bool)
+    skip[dev.bc_dofs] = True
+    t = build_tree(dev.th.cell_dofs, dev.th.mesh.cell_centroids(), dev.N, sum(bits), skip, top_bits=top, bits=bits)
+    assert np.array_equal(t.perm, dev.perm), "the numpy specification and the library disagree on the permutation"
+    return t

@@ -30,7 +30,7 @@ class _FakeSolver:
     """FlowSolver-shaped stand-in: step() = one partitioned solve of a fixed Oseen-like system through gloo."""
 
     def __init__(self, n, distributed):
-        from flowcontrol_amd import ndsolver
+        from tests.support import ndsolver
         from flowcontrol_amd.fem.mesh import Mesh
         from flowcontrol_amd.fem.spaces import TaylorHood
         from oracle import ns_oracle as O

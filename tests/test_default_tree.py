@@ -1,12 +1,11 @@
 """Default shape of the elimination tree (``fc_setup_solver`` with depth 0): leaves of about 12 cells, to the NEAREST level the
 fused levels allow on single-GPU handles; small meshes (factors that stay in the Infinity Cache) fuse one bisection more into each of
-the two top levels.  The library rule (``csrc/fc_symbolic.hpp::default_bits``, reached through ``fc_sym_build``) and the Python one
-(``ndsolver.default_bits``, which rebuilds the tree for the host-side helpers) must agree."""
+the two top levels.  The library rule (``csrc/fc_symbolic.hpp::default_bits``, reached through ``fc_sym_build``) and the numpy
+specification (``tests/support/ndsolver.default_bits``) must agree."""
 import numpy as np
 import pytest
 
-from flowcontrol_amd import ndsolver
-from flowcontrol_amd.device import _default_depth
+from tests.support import ndsolver
 from flowcontrol_amd.fem.mesh import read_xdmf_mesh
 from flowcontrol_amd.fem.spaces import TaylorHood
 from flowcontrol_amd.examples.data import mesh_file  # noqa: E402
@@ -15,7 +14,7 @@ from flowcontrol_amd.examples.data import mesh_file  # noqa: E402
 def test_default_depth_rule():
     # cells -> bisections (merge 2): O1, O1 refined, pinball, cavity_coarse, cavity_fine, lid cavity 64 x 64
     for nc, want in ((12284, 10), (49136, 12), (66668, 12), (51883, 12), (193916, 14), (8192, 10)):
-        assert _default_depth(nc, 2, 0) == want
+        assert sum(ndsolver.default_bits(nc, 2, 0)) == want
     # ... and how they are fused into tree levels, root first: the small meshes (launch-bound sweeps) get two 8-ary top levels
     assert ndsolver.default_bits(12284, 2, 0) == [3, 3, 2, 2] and ndsolver.default_bits(8192, 2, 0) == [3, 3, 2, 2]
     assert ndsolver.default_bits(49136, 2, 0) == [2] * 6 and ndsolver.default_bits(193916, 2, 0) == [2] * 7

@@ -16,7 +16,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from flowcontrol_amd import ndsolver
+from tests.support import ndsolver
 from flowcontrol_amd.fem.mesh import Mesh
 from flowcontrol_amd.fem.spaces import TaylorHood
 from oracle import ns_oracle as O

@@ -271,7 +271,7 @@ def test_pinball_regression_open_loop(tmp_path_factory, golden_dir):
 def test_cylinder_crank_nicolson_vs_oracle(tmp_path_factory, golden_dir):
     """time_scheme="cn" through the public API (ParamSolver.time_scheme, flowsolverparameters.py) against
     the oracle's CN stepper: 10 actuated steps; and CN ≈ BDF2 to O(dt²) on the same trajectory."""
-    from flowcontrol_amd import ndsolver
+    from tests.support import ndsolver
     from oracle import ns_oracle as O
 
     g = np.load(golden_dir / "cylinder_O1.npz")
@@ -314,7 +314,7 @@ def test_cavity_closed_loop_force_actuation_vs_oracle(tmp_path_factory, golden_d
     an LTI Controller fed with the wall-shear sensor (no cavity controller ships with the reference: a
     documented synthetic stable first-order low-pass, K(s) = 0.5 / (0.01 s + 1)), 6 steps; the device
     trajectory must follow the oracle's with the same control sequence."""
-    from flowcontrol_amd import ndsolver
+    from tests.support import ndsolver
     from flowcontrol_amd.examples.cavity.cavityflowsolver import CavityFlowSolver
     from oracle import ns_oracle as O
 

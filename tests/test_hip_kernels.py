@@ -185,38 +185,38 @@ def test_crank_nicolson_step(setup):
     dev.set_force(None)
 
 
-def test_block_and_segment_down_sweeps_agree(setup):
-    """The LDS-tiled block kernel (forced on for every down stage) and the segment kernel produce the
-    same solve to round-off."""
-    th, dev, d, O = setup
-    from flowcontrol_amd import ndsolver
-    from flowcontrol_amd.device import SLOT_BDF2
+def test_block_and_segment_down_sweeps_agree(setup, monkeypatch):
+    """The LDS-tiled block kernel (forced on for every down stage, through all of its (lanes per row, rows per slot)
+    instantiations: FC_BLOCK_TARGET 1 / 64 / huge = 32 / intermediate / fewest rows per workgroup) and the segment kernel
+    (FC_BLOCK_KERNEL=0) produce the same solve to round-off.  The knobs are read when a handle lays out its sweep tables, so
+    every variant gets a handle of its own."""
+    th, dev0, d, O = setup
+    from flowcontrol_amd.device import SLOT_BDF2, DeviceSolver
 
     dt, Re = 0.005, 100.0
     U0 = _smooth_velocity(th)
     dofs, prof = _bc_setup(th)
-    dev.set_bc(dofs, prof)
-    dev.set_time_scheme(dt, True)
-    dev.assemble_matrix(SLOT_BDF2, mass=1.5 / dt, nu=1.0 / Re, adv=U0, lin=U0)
-    dev.apply_bc(SLOT_BDF2)
-    b = np.random.default_rng(3).standard_normal(dev.N)
-    orig = ndsolver.down_blocks
-    results = []
-    try:
-        dev.use_block_kernel = False
-        dev.setup_solver(SLOT_BDF2, restructure=True)
-        x_seg, _ = dev.solve(SLOT_BDF2, b)
-        dev.use_block_kernel = True
-        # target_blocks 1 / 64 / huge: 32 / intermediate / fewest rows per workgroup, i.e. every
-        # (lanes per row, rows per slot) instantiation of the kernel
-        for target in (1, 64, 1 << 30):
-            ndsolver.down_blocks = lambda fac, rank=0, world=1, **kw: orig(fac, rank, world, target_blocks=target, min_blocks=1)  # noqa: B023
-            dev.setup_solver(SLOT_BDF2, restructure=True)
-            results.append(dev.solve(SLOT_BDF2, b))
-    finally:
-        ndsolver.down_blocks = orig
-        dev.use_block_kernel = True
-    for x_blk, info in results:
+    b = np.random.default_rng(3).standard_normal(dev0.N)
+
+    def solve():
+        dev = DeviceSolver(th, dev0.device_index)
+        try:
+            dev.set_bc(dofs, prof)
+            dev.set_time_scheme(dt, True)
+            dev.assemble_matrix(SLOT_BDF2, mass=1.5 / dt, nu=1.0 / Re, adv=U0, lin=U0)
+            dev.apply_bc(SLOT_BDF2)
+            dev.setup_solver(SLOT_BDF2)
+            return dev.solve(SLOT_BDF2, b)
+        finally:
+            dev.close()
+
+    monkeypatch.setenv("FC_BLOCK_KERNEL", "0")
+    x_seg, _ = solve()
+    monkeypatch.delenv("FC_BLOCK_KERNEL")
+    monkeypatch.setenv("FC_BLOCK_MIN", "1")
+    for target in (1, 64, 1 << 30):
+        monkeypatch.setenv("FC_BLOCK_TARGET", str(target))
+        x_blk, info = solve()
         assert _rel(x_blk, x_seg) < 1e-12
         assert info[1] < 1e-9
 
@@ -233,7 +233,7 @@ def test_device_factorisation_matches_host_multifrontal(setup, wide, monkeypatch
     values to round-off, then again after the matrix changed (numeric phase only)."""
     th, dev, d, O = setup
     from flowcontrol_amd.device import SLOT_BDF2
-    from tests.support import nd_numeric
+    from tests.support import nd_numeric, ndsolver
 
     if wide == "huge":
         monkeypatch.setenv("FC_FE_HUGE_NF", "256")
@@ -252,7 +252,7 @@ def test_device_factorisation_matches_host_multifrontal(setup, wide, monkeypatch
         dev.setup_solver(SLOT_BDF2)  # second round: numeric phase only
         assert SLOT_BDF2 in dev._structured and dev.refactor_ms[SLOT_BDF2] > 0
         A = dev.matrix(SLOT_BDF2)
-        host = nd_numeric.factorize_blocks(A, dev.tree)
+        host = nd_numeric.factorize_blocks(A, ndsolver.tree_of(dev))
         got = dev.factor_values(SLOT_BDF2)
         assert got.shape == host.vals.shape
         assert np.abs(got - host.vals).max() <= 1e-10 * np.abs(host.vals).max()
@@ -281,7 +281,9 @@ def test_pivoting_inside_the_pivot_block(setup):
     dev.apply_bc(SLOT_BDF2)
     dev.setup_solver(SLOT_BDF2)
     A = dev.matrix(SLOT_BDF2).tocsr()
-    t = dev.tree
+    from tests.support import ndsolver
+
+    t = ndsolver.tree_of(dev)
     is_bc = np.zeros(dev.N, dtype=bool)
     is_bc[dofs] = True
     K = t.depth

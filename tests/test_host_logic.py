@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import scipy.signal
 
-from flowcontrol_amd import ndsolver
+from tests.support import ndsolver
 from flowcontrol_amd.actuator import ActuatorBCParabolicV, ActuatorBCRotation
 from flowcontrol_amd.controller import Controller
 from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver
@@ -430,7 +430,7 @@ def test_factor_plan_replays_the_multifrontal_factorisation():
     multifrontal factors bit for bit, and the structure-only layout equals the numeric one."""
     import scipy.sparse as sp
 
-    from flowcontrol_amd import ndsolver as nd
+    from tests.support import ndsolver as nd
     from flowcontrol_amd.fem.mesh import Mesh
     from flowcontrol_amd.fem.spaces import TaylorHood
     from oracle import ns_oracle as O

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import scipy.io as sio
 
-from flowcontrol_amd import ndsolver
+from tests.support import ndsolver
 from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver
 from flowcontrol_amd.fem.boundary import combine_bcs
 from oracle import ns_oracle as O

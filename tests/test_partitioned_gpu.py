@@ -64,7 +64,7 @@ def _worker(rank, world, port, out, nsteps, backend="gloo", refine=0, scheme="bd
             out["krylov_its"] = int(fs.solve_info[0]) if bits != 64 else 0
         from flowcontrol_amd._lib import SLOT_BDF2
 
-        from flowcontrol_amd import ndsolver
+        from tests.support import ndsolver
 
         dev = fs.th.device()
         slot = next(iter(dev.factor_nnz))  # Crank-Nicolson keeps its one operator in the first slot
@@ -73,7 +73,7 @@ def _worker(rank, world, port, out, nsteps, backend="gloo", refine=0, scheme="bd
         out[f"values{rank}"] = int(dev.local_factor_nnz)  # factor values this rank sweeps per solve
         out[f"stored{rank}"] = int(dev.factor_nnz[slot])  # ... and stores (its sub-tree + the root's pivot block)
         if rank == 0:
-            out["total_values"] = int(ndsolver.factorize_blocks(None, dev.tree, numeric=False).nnz)  # the whole tree
+            out["total_values"] = int(ndsolver.factorize_blocks(None, ndsolver.tree_of(dev), numeric=False).nnz)  # the whole tree
         fs.th.release_device()
     finally:
         dist.destroy_process_group()

@@ -6,7 +6,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from flowcontrol_amd import _lib, ndsolver
+from flowcontrol_amd import _lib
+from tests.support import ndsolver
 from flowcontrol_amd.fem.mesh import Mesh, read_xdmf_mesh
 from flowcontrol_amd.fem.spaces import TaylorHood
 from flowcontrol_amd.examples.data import mesh_file  # noqa: E402
