@@ -954,6 +954,16 @@ int state_download(fc_ctx* h, double* wn, double* wnn) {
   return FC_OK;
 }
 
+// Workgroups a level of the LDS-tiled block kernel should at least have (rows per workgroup are halved from 32 until it does): enough to
+// keep every CU busy through the tail of the launch, and more of them -- shorter tiles -- the more rows a level has.  Measured on the
+// three streaming meshes (steps/s with 1024 / 2048 / 4096 / 8192 for the down stages, profiles/r05_block_target.txt): refined O1
+// (223 k dofs) 3 534 / 3 627 / 3 612 / 3 444, pinball (302 k) 2 830 / 2 899 / 2 885 / 2 797, cavity_fine (877 k) 1 037 / 1 059 / 1 088 / 1 102.
+inline int block_target(int N) {
+  int t = 1024;
+  while (t < 8192 && (double)N / 128.0 > 1.4142 * t) t *= 2;  // nearest power of two to N / 128, within [1024, 8192]
+  return t;
+}
+
 // tables of the column-form up-sweep from the in-library symbolic phase (the values are the ones the row form reads: a node's -L block
 // is stored row-major, nb x ni, behind its [D^-1 | -U] rows).  Partitioned handles: the rank's own nodes only (that is what its factor
 // layout holds); their slots for root rows fold into this rank's share of the root right-hand side, which the first exchange sums
@@ -1005,7 +1015,9 @@ int build_up_column(fc_ctx* h) {
       for (int q = 0; q > lpr_shift && L.lpr > 8; --q) L.lpr /= 2;
       const int slots = 256 / L.lpr;
       int rc = rc_max;
-      while (rc > slots && rows / rc < 1024) rc /= 2;
+      static const int upc_env = [] { const char* e = std::getenv("FC_UPC_TARGET"); return e ? std::max(1, std::atoi(e)) : 0; }();
+      const int upc_target = upc_env ? upc_env : std::max(2048, block_target(N) / 2);
+      while (rc > slots && rows / rc < upc_target) rc /= 2;
       rc = std::max(rc, 1);
       int maxr = 1;
       for (size_t g : sel) {
@@ -3217,7 +3229,7 @@ int fc_setup_solver(fc_handle h, int slot, int32_t depth, int32_t merge, int32_t
       const char* eb = std::getenv("FC_BLOCK_KERNEL");
       const char* et = std::getenv("FC_BLOCK_TARGET");
       const char* em = std::getenv("FC_BLOCK_MIN");
-      fcsym::Blocks B = fcsym::down_blocks(t, fac, rank, world, 32, et ? std::max(1, std::atoi(et)) : 1024, em ? std::max(1, std::atoi(em)) : 512);
+      fcsym::Blocks B = fcsym::down_blocks(t, fac, rank, world, 32, et ? std::max(1, std::atoi(et)) : block_target(N), em ? std::max(1, std::atoi(em)) : 512);
       if (eb && eb[0] == '0') std::fill(B.count.begin(), B.count.end(), 0);
       FCCHK(fc_solver_set_blocks(h, slot, (int)B.begin.size(), B.begin.data(), B.count.data(), B.lpr.data(), (int64_t)B.val.size(),
                                  B.val.empty() ? &zero64 : B.val.data(), B.row0.empty() ? &zero32 : B.row0.data(),

@@ -37,6 +37,23 @@ for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         per_kernel.setdefault(kname, {})[name + "_KB_per_apply_raw"] = float(g["Counter_Value"].sum() / n_apply)
 # gfx950: FETCH_SIZE tallies the 128-B requests at 64 B -- a factor 2.00 for every access width these kernels use (8 B and 16 B per lane,
 # 8- and 16-lane rows, nontemporal or not: scripts/fetch_calib.sh, profiles/r05_fetch_calib.csv); WRITE_SIZE reads true
+# per launch position of an apply (kernel, grid): median duration and median bytes read (FETCH_SIZE x 2) -> TB/s of every sweep launch
+try:
+    cf = pd.read_csv(glob.glob(f"{out}/pmc_fetch/**/*_counter_collection.csv", recursive=True)[0])
+    cf = cf[cf["Counter_Name"] == "FETCH_SIZE"]
+    tf = pd.read_csv(glob.glob(f"{out}/pmc_fetch/**/*_kernel_trace.csv", recursive=True)[0])
+    tf["dur"] = tf["End_Timestamp"] - tf["Start_Timestamp"]
+    j = cf.groupby("Dispatch_Id")["Counter_Value"].sum().rename("fetch_kb").to_frame().join(tf.set_index("Dispatch_Id")[["Kernel_Name", "Grid_Size_X", "dur"]], how="inner")
+    j = j[j["Kernel_Name"].str.contains("fc_nd_sweep|fc_nd_down_block|fc_nd_fold1|fc_tail|fc_rhs")]
+    j["kernel"] = j["Kernel_Name"].str.replace(r"^void ", "", regex=True).str.slice(0, 34)
+    pos = j.groupby(["kernel", "Grid_Size_X"]).agg(n=("dur", "size"), us=("dur", lambda v: v.median() / 1e3), MB=("fetch_kb", lambda v: 2.0 * v.median() * 1024 / 1e6)).reset_index()
+    pos["TB/s"] = pos["MB"] / pos["us"]
+    pos = pos[pos["n"] >= 5].sort_values("us", ascending=False)
+    pos.to_csv(out + "/launch_positions.csv", index=False)
+    print(pos.to_string(index=False))
+    print("sum of medians [us]:", pos[pos["kernel"].str.contains("fc_nd")]["us"].sum(), " MB:", pos[pos["kernel"].str.contains("fc_nd")]["MB"].sum())
+except Exception as err:
+    print("launch positions failed:", err)
 res["bytes_per_apply_counters"] = (2.0 * res["FETCH_SIZE_KB_per_apply_raw"] + res["WRITE_SIZE_KB_per_apply_raw"]) * 1024.0
 res["counters_over_algorithmic"] = res["bytes_per_apply_counters"] / res["bytes_per_apply_algorithmic"]
 res["per_kernel"] = per_kernel
