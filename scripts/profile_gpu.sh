@@ -11,7 +11,7 @@ HB=$!
 trap 'kill $HB 2>/dev/null' EXIT
 # one stream, one record (FC_OVERLAP_TAIL=0): a clean launch sequence per step for the per-position medians; the kernels are the same
 export FC_OVERLAP_TAIL=0
-ARGS="--warmup 20 --no-cpu-baseline --no-large-spmv --no-replicas --no-other-configs"
+ARGS="--warmup 20 --no-cpu-baseline --no-large-spmv --no-replicas --no-other-configs --no-krylov"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python bench.py --steps ${STEPS:-1000} $ARGS > "$OUT/bench_stats.json" 2> "$OUT/stats.err"
 echo "stats pass done"
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python bench.py --steps 100 $ARGS > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err"
