@@ -44,7 +44,11 @@ def _check(lib, rc):
     assert rc == 0, lib.fc_last_error().decode()
 
 
-def test_setup_and_step_through_the_c_abi_only():
+@pytest.mark.parametrize("mode", ["factors", "krylov"])
+def test_setup_and_step_through_the_c_abi_only(mode):
+    """mode "krylov": ``fc_setup_krylov`` in place of ``fc_setup_solver`` — nothing is factorised, the same ``fc_step`` calls run
+    the device GMRES with the SIMPLE / AMG preconditioner (on this 12 x 12 mesh the pressure Schur complement has 169 rows: the
+    hierarchy is its dense inverse alone)."""
     lib = _lib.load()
     n = 12
     coords, cells, cell_edges, edges = _square_mesh(n)
@@ -81,10 +85,18 @@ def test_setup_and_step_through_the_c_abi_only():
         for slot, alpha in ((_lib.SLOT_BDF1, 1.0 / dt), (_lib.SLOT_BDF2, 1.5 / dt)):
             _check(lib, lib.fc_assemble_matrix(h, slot, alpha, 1.0 / Re, U0.ctypes.data_as(C.c_void_p), 1.0, U0.ctypes.data_as(C.c_void_p), 1.0, -1.0, -1.0))
             _check(lib, lib.fc_apply_bc(h, slot))
-            _check(lib, lib.fc_setup_solver(h, slot, 0, 2, 0, 0, 1))
+            if mode == "factors":
+                _check(lib, lib.fc_setup_solver(h, slot, 0, 2, 0, 0, 1))
+            else:
+                _check(lib, lib.fc_setup_krylov(h, slot, 2, _lib.METHOD_GMRES, 300, 1e-12, 1))
         info = np.zeros(10, dtype=np.int64)
         _check(lib, lib.fc_get_solver_info(h, _lib.SLOT_BDF2, info))
-        assert info[0] > 0 and info[3] == 2 * info[4] + 1  # factor values; stages = up-sweeps + down-sweeps of the tree
+        if mode == "factors":
+            assert info[0] > 0 and info[3] == 2 * info[4] + 1  # factor values; stages = up-sweeps + down-sweeps of the tree
+        else:
+            kinfo = np.zeros(8, dtype=np.int64)
+            _check(lib, lib.fc_get_krylov_info(h, _lib.SLOT_BDF2, kinfo, None))
+            assert info[0] == 0 and info[3] == 0 and kinfo[0] > 0 and kinfo[2] == nv  # no factor values, no sweep stages; pressure dofs
         perm = np.empty(N, dtype=np.int32)
         _check(lib, lib.fc_get_permutation(h, perm))
         assert np.array_equal(np.sort(perm), np.arange(N))
@@ -114,6 +126,7 @@ def test_setup_and_step_through_the_c_abi_only():
             assert np.allclose(y_out, y_ref, rtol=1e-9, atol=1e-12)
             assert abs(dE.value - 0.5 * u_n @ (M @ u_n)) < 1e-10 * abs(dE.value)
             assert inf[1] < 1e-10  # residual monitor of the step's solve
+            assert (inf[0] > 1) == (mode == "krylov")  # Krylov iterations of the step / refinement sweeps (none)
         sol = np.empty(N)
         _check(lib, lib.fc_get_solution(h, sol))
         assert np.linalg.norm(sol - up) < 1e-10 * np.linalg.norm(up)

@@ -60,6 +60,32 @@ def test_factor_free_solve_matches_the_direct_solve(mesh, dt, Re):
     dev.close()
 
 
+def test_factor_free_cavity_with_body_force_follows_the_oracle(tmp_path_factory, golden_dir):
+    """The cavity case (Re = 7500, dt = 4e-4, FORCE actuator: the body force enters the element loop, wall-shear integral sensor) with
+    no factorisation: 10 steps of the reference's regression scenario against the oracle's series."""
+    from flowcontrol_amd.examples.cavity.cavityflowsolver import CavityFlowSolver
+    from flowcontrol_amd.fem.spaces import Function
+
+    g = np.load(golden_dir / "cavity_coarse.npz")
+    fs = CavityFlowSolver.make_default(Re=7500, path_out=tmp_path_factory.mktemp("free_cavity"), num_steps=10)
+    fs.krylov_precond, fs.krylov_method, fs.krylov_max_iter, fs.krylov_rtol = "schur_amg", "gmres", 300, 1e-11
+    U0, P0 = Function(fs.W, g["UP0"]).split()
+    fs._assign_steady_state(U0, P0)
+    fs.initialize_time_stepping(ic=None)
+    its = []
+    for _ in range(10):
+        fs.step([0.0])
+        assert fs.solve_info[1] < 1e-9
+        its.append(int(fs.solve_info[0]))
+    assert 1 <= max(its) <= 100
+    ts = fs.timeseries
+    y = ts[[c for c in ts.columns if c.startswith("y_meas")]].to_numpy()
+    assert np.linalg.norm(y - g["y"][:11]) <= 1e-8 * np.linalg.norm(g["y"][:11])
+    assert np.linalg.norm(ts["dE"].to_numpy() - g["dE"][:11]) <= 1e-8 * np.linalg.norm(g["dE"][:11])
+    print(f"[factorisation-free, cavity_coarse] iterations per step {its}; held {fs.th.device().krylov_info(1)['bytes'] / 1e6:.1f} MB")
+    fs.th.release_device()
+
+
 @pytest.mark.parametrize("method", ["gmres", "bicgstab"])
 def test_factor_free_time_steps_follow_the_oracle(method, tmp_path_factory, golden_dir):
     """50 open-loop steps of the cylinder case (O1, BDF1 then BDF2) with NO factorisation: sensors and energy within 1e-8 of
