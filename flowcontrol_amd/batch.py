@@ -130,7 +130,16 @@ class BatchedFlowSolver:
             u_force = 0.5 * (u_ctrl + prev)
         dev = self.dev
         dev.step_batch_begin(SLOT_BDF2 if self.order == 2 else SLOT_BDF1, u_ctrl, compute_energy=want_energy, u_force=u_force)
-        self._flush()  # the previous step's energies / residuals arrive behind the host's back: book its log row while this step runs
+        try:
+            self._flush()  # the previous step's energies / residuals arrive behind the host's back: book its log row while this step runs
+        except BaseException:
+            # the host's bookkeeping failed with a batched step in flight: end it, so that the handle does not refuse every later
+            # fc_step_batch_begin (its result is dropped: the batch's state has advanced, the caller sees the error)
+            try:
+                dev.step_batch_end_early()
+            except Exception:  # noqa: BLE001 -- the original error is the one to report
+                pass
+            raise
         newly = np.zeros(k, dtype=bool)
         try:
             y, flags = dev.step_batch_end_early()
