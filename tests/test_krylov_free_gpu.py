@@ -117,3 +117,40 @@ def test_factor_free_time_steps_follow_the_oracle(method, tmp_path_factory, gold
     print(f"[factorisation-free, {method}] iterations per step: first {its[:3]} mean {np.mean(its):.1f} max {max(its)}; "
           f"held {dev.krylov_info(1)['bytes'] / 1e6:.1f} MB")
     fs.th.release_device()
+
+
+def test_factor_free_crank_nicolson_steps_follow_the_oracle(tmp_path_factory, golden_dir):
+    """time_scheme="cn" (NSForms._cn, nsforms.py:191-236: half of the linear terms explicit, an extra operator in the right-hand side)
+    with no factorisation: 8 actuated steps against the oracle's Crank-Nicolson stepper."""
+    from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver
+    from flowcontrol_amd.fem.spaces import Function
+    from flowcontrol_amd.flowsolverparameters import ParamIC
+    from oracle import ns_oracle as O
+
+    g = np.load(golden_dir / "cylinder_O1.npz")
+    fs = CylinderFlowSolver.make_default(Re=100, path_out=tmp_path_factory.mktemp("free_cn"), num_steps=8)
+    fs.params_solver.time_scheme = "cn"
+    fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
+    fs.krylov_precond, fs.krylov_method, fs.krylov_max_iter, fs.krylov_rtol = "schur_amg", "gmres", 300, 1e-11
+    U0, P0 = Function(fs.W, g["UP0"]).split()
+    fs._assign_steady_state(U0, P0)
+    fs.initialize_time_stepping(ic=None)
+    th = fs.th
+    dofs, prof = fs._bc_tables()
+    ts = O.TimeStepperCN(O.Disc.from_taylor_hood(th), 100.0, 0.005, g["UP0"][: 2 * th.nn], dofs, prof)
+    rows = [s.row(fs) for s in fs.params_control.sensor_list]
+    u_n = fs.fields.ic.u.vector().get_local()
+    ys, its = [], []
+    for k in range(8):
+        uc = np.array([0.05 * np.sin(0.4 * k), -0.03])
+        fs.step(uc)
+        its.append(int(fs.solve_info[0]))
+        up = ts.step(u_n, uc)
+        u_n = up[: 2 * th.nn]
+        ys.append([w @ up[i] for i, w in rows])
+    y_dev = fs.timeseries[["y_meas_1", "y_meas_2", "y_meas_3"]].to_numpy()[1:]
+    assert np.linalg.norm(y_dev - np.array(ys)) <= 1e-8 * np.linalg.norm(ys)
+    assert np.linalg.norm(fs.fields.u_.vector().get_local() - u_n) <= 1e-8 * np.linalg.norm(u_n)
+    assert 1 <= max(its) <= 100
+    print(f"[factorisation-free, Crank-Nicolson] iterations per step {its}")
+    fs.th.release_device()
