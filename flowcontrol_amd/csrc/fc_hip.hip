@@ -3344,6 +3344,13 @@ int fc_setup_krylov(fc_handle h, int slot, int32_t sweeps, int method, int32_t m
     }
     const int64_t s_nnz = Sh.nnz();
     fcpc::Amg H = fcpc::build_amg(std::move(Sh));
+    // smoothing sweeps of the V-cycle before and after the coarse correction (folded into the transfer operators either way: the launch
+    // count does not change, the products get denser): FC_PC_AMG_SWEEPS=1|2
+    // (O1, time steps: 18.6 -> 15.6 iterations per step, 520 -> 583 steps/s with two sweeps; cavity_fine: 39 -> 35 iterations but 453 ->
+    //  510 us per iteration and twice the setup time, pinball 41 -> 36 at 237 -> 269 us: a wash -- the denser products stop being free once
+    //  they leave the caches: one sweep beyond 16 384 pressure dofs)
+    static const int amg_env = [] { const char* e = std::getenv("FC_PC_AMG_SWEEPS"); return e ? std::max(1, std::min(2, std::atoi(e))) : 0; }();
+    const int amg_sweeps = amg_env ? amg_env : (X.np <= 16384 ? 2 : 1);
     // device copy
     Precond& P = S.pc;
     P.release();
@@ -3372,8 +3379,15 @@ int fc_setup_krylov(fc_handle h, int slot, int32_t sweeps, int method, int32_t m
       const fcpc::Level& G = H.levels[l];
       V.n = G.A.nrows;
       V.n_next = G.P.ncols;
-      FCCHK(V.G.upload(fcpc::fold_down(G), h->stream));
-      FCCHK(V.U.upload(fcpc::fold_up(G), h->stream));
+      if (amg_sweeps >= 2) {  // V(2,2): still two products per level, denser ones
+        fcpc::Csr Gd, Uu;
+        fcpc::fold_v22(G, Gd, Uu);
+        FCCHK(V.G.upload(Gd, h->stream));
+        FCCHK(V.U.upload(Uu, h->stream));
+      } else {
+        FCCHK(V.G.upload(fcpc::fold_down(G), h->stream));
+        FCCHK(V.U.upload(fcpc::fold_up(G), h->stream));
+      }
       FCCHK(V.cat.alloc((size_t)V.n + V.n_next));
       P.bytes += V.G.bytes() + V.U.bytes() + 8 * ((int64_t)V.n + V.n_next);
       P.level_rows.push_back(V.n);

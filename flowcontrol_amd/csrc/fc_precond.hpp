@@ -21,6 +21,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <climits>
 #include <cstdint>
 #include <stdexcept>
 #include <vector>
@@ -292,6 +293,64 @@ inline Csr fold_up(const Level& L) {
   }
   return U;
 }
+// C = alpha A + beta B (same shape; columns of every row sorted)
+inline Csr add(const Csr& A, double alpha, const Csr& B, double beta) {
+  if (A.nrows != B.nrows || A.ncols != B.ncols) throw std::runtime_error("fcpc::add: shapes disagree");
+  Csr C;
+  C.nrows = A.nrows, C.ncols = A.ncols;
+  C.rp.assign((size_t)A.nrows + 1, 0);
+  for (int i = 0; i < A.nrows; ++i) {
+    int p = A.rp[(size_t)i], q = B.rp[(size_t)i];
+    const int p1 = A.rp[(size_t)i + 1], q1 = B.rp[(size_t)i + 1];
+    while (p < p1 || q < q1) {
+      const int ca = p < p1 ? A.ci[(size_t)p] : INT32_MAX, cb = q < q1 ? B.ci[(size_t)q] : INT32_MAX;
+      double v = 0.0;
+      const int c = ca < cb ? ca : cb;
+      if (ca == c) v += alpha * A.v[(size_t)p++];
+      if (cb == c) v += beta * B.v[(size_t)q++];
+      C.ci.push_back(c), C.v.push_back(v);
+    }
+    C.rp[(size_t)i + 1] = (int)C.ci.size();
+  }
+  return C;
+}
+inline Csr identity(int n) {
+  Csr I;
+  I.nrows = I.ncols = n;
+  I.rp.resize((size_t)n + 1), I.ci.resize((size_t)n), I.v.assign((size_t)n, 1.0);
+  for (int i = 0; i < n; ++i) I.rp[(size_t)i] = i, I.ci[(size_t)i] = i;
+  I.rp[(size_t)n] = n;
+  return I;
+}
+inline Csr scale_rows(Csr A, const std::vector<double>& d) {
+  for (int i = 0; i < A.nrows; ++i)
+    for (int k = A.rp[(size_t)i]; k < A.rp[(size_t)i + 1]; ++k) A.v[(size_t)k] *= d[(size_t)i];
+  return A;
+}
+// The same folding for a V(2,2)-cycle (two damped-Jacobi sweeps before and after the coarse correction) -- still two products per
+// level, only denser ones (patterns of A^2 / A^3 instead of A): with E = I - Wd A (one sweep's error propagator), W2 = (I + E) Wd,
+//   down:  r_c = R (I - A W2) r                   up:  z = (I + E^2) W2 r + E^2 P z_c
+inline void fold_v22(const Level& L, Csr& G, Csr& U) {
+  const int n = L.A.nrows, nc = L.P.ncols;
+  const Csr I = identity(n);
+  const Csr E = add(I, 1.0, scale_rows(L.A, L.wdinv), -1.0);          // I - Wd A
+  Csr Wd = I;
+  Wd.v = L.wdinv;
+  const Csr W2 = spgemm(add(I, 1.0, E, 1.0), Wd);                      // (I + E) Wd
+  G = spgemm(L.R, add(I, 1.0, spgemm(L.A, W2), -1.0));                 // R (I - A W2)
+  const Csr E2 = spgemm(E, E);
+  const Csr K = spgemm(add(I, 1.0, E2, 1.0), W2);                      // (I + E^2) W2
+  const Csr Q = spgemm(E2, L.P);                                       // E^2 P
+  U.nrows = n, U.ncols = n + nc;
+  U.rp.assign((size_t)n + 1, 0);
+  U.ci.clear(), U.v.clear();
+  for (int i = 0; i < n; ++i) {
+    for (int k = K.rp[(size_t)i]; k < K.rp[(size_t)i + 1]; ++k) U.ci.push_back(K.ci[(size_t)k]), U.v.push_back(K.v[(size_t)k]);
+    for (int k = Q.rp[(size_t)i]; k < Q.rp[(size_t)i + 1]; ++k) U.ci.push_back(n + Q.ci[(size_t)k]), U.v.push_back(Q.v[(size_t)k]);
+    U.rp[(size_t)i + 1] = (int)U.ci.size();
+  }
+}
+
 // two damped-Jacobi sweeps on F u = r from u = 0 as ONE product: u = Wd (2 I - F Wd) r
 inline Csr fold_jacobi2(const Csr& F, const std::vector<double>& wd) {
   Csr K = F;
