@@ -1648,10 +1648,17 @@ int gmres_permuted(fc_ctx* h, OrderSys& S, int* iters, double* relres, const dou
     FCCHK(multidot(j + 1, V, w, hcol));
     hipLaunchKernelGGL(fc_gmres_project, dim3(g), dim3(256), 0, h->stream, N, j + 1, V, hcol, w, ks);
     FCCHK(multidot(j + 1, V, w, hcol2));
-    hipLaunchKernelGGL(fc_small_add, dim3(nblocks(j + 1, 64)), dim3(64), 0, h->stream, j + 1, hcol2, hcol, ks);
-    hipLaunchKernelGGL(fc_gmres_project, dim3(g), dim3(256), 0, h->stream, N, j + 1, V, hcol2, w, ks);
-    FCCHK(multidot(1, w, w, norm2));
-    hipLaunchKernelGGL(fc_gmres_givens, dim3(1), dim3(1), 0, h->stream, j, m, gm, ks, h->rtol);
+    if (dist) {
+      hipLaunchKernelGGL(fc_small_add, dim3(nblocks(j + 1, 64)), dim3(64), 0, h->stream, j + 1, hcol2, hcol, ks);
+      hipLaunchKernelGGL(fc_gmres_project, dim3(g), dim3(256), 0, h->stream, N, j + 1, V, hcol2, w, ks);
+      FCCHK(multidot(1, w, w, norm2));
+      hipLaunchKernelGGL(fc_gmres_givens, dim3(1), dim3(1), 0, h->stream, j, m, gm, ks, h->rtol, (const double*)nullptr, (const double*)nullptr, 0);
+    } else {
+      // single GPU: the column's second-pass coefficients and the fold of |w|^2 ride in the rotation kernel (same sums, same order)
+      hipLaunchKernelGGL(fc_gmres_project, dim3(g), dim3(256), 0, h->stream, N, j + 1, V, hcol2, w, ks);
+      hipLaunchKernelGGL(fc_multidot, dim3(gd, 1), dim3(256), 0, h->stream, N, 1, w, w, h->mdot.p, ks, kinds, lead);
+      hipLaunchKernelGGL(fc_gmres_givens, dim3(1), dim3(64), 0, h->stream, j, m, gm, ks, h->rtol, (const double*)hcol2, (const double*)h->mdot.p, gd);
+    }
     hipLaunchKernelGGL(fc_scale_by_norm, dim3(g), dim3(256), 0, h->stream, N, w, norm2, V + (size_t)(j + 1) * N, ks);
     return FC_OK;
   };

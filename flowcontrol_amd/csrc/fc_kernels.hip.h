@@ -1581,8 +1581,20 @@ __global__ void fc_gmres_combine(int n, int nv, const double* __restrict__ V, co
 // One thread: column j of the Hessenberg matrix (h[0..j] from the projections, h[j+1] = |w| from norm2) through the
 // stored Givens rotations, new rotation, residual estimate |g[j+1]|; when converged or at j + 1 == m: back substitution
 // y = R^-1 g.  gm layout: H (m+1) x m column-major | cs[m] | sn[m] | g[m+1] | y[m] | hcol[m+2] | norm2 | used
-__global__ void fc_gmres_givens(int j, int m, double* gm, double* ks, double rtol) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// (hcol2 != nullptr: the second Gram-Schmidt pass's coefficients are added to the column here instead of by a launch of their own;
+//  npart != nullptr: |w|^2 is folded here from the gx partial sums of fc_multidot -- 64 threads, the order of fc_multidot_reduce --
+//  instead of by a launch of its own: two launches less per Arnoldi step on single-GPU handles)
+__global__ void fc_gmres_givens(int j, int m, double* gm, double* ks, double rtol, const double* __restrict__ hcol2 = nullptr,
+                                const double* __restrict__ npart = nullptr, int gx = 0) {
+  if (blockIdx.x != 0) return;
+  double nsum = 0.0;
+  if (npart) {
+    if (ks[KS_STATE] == 0.0)
+      for (int k = threadIdx.x; k < gx; k += 64) nsum += npart[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nsum += __shfl_down(nsum, off, 64);
+  }
+  if (threadIdx.x != 0) return;
   double* H = gm;
   double* cs = H + (size_t)(m + 1) * m;
   double* sn = cs + m;
@@ -1592,8 +1604,9 @@ __global__ void fc_gmres_givens(int j, int m, double* gm, double* ks, double rto
   double* norm2 = hcol + m + 2;
   double* used = norm2 + 1;
   if (ks[KS_STATE] != 0.0) return;
+  if (npart) norm2[0] = nsum;
   double* Hj = H + (size_t)j * (m + 1);
-  for (int i = 0; i <= j; ++i) Hj[i] = hcol[i];
+  for (int i = 0; i <= j; ++i) Hj[i] = hcol2 ? hcol[i] + hcol2[i] : hcol[i];
   Hj[j + 1] = sqrt(norm2[0]);
   for (int i = 0; i < j; ++i) {
     const double a = cs[i] * Hj[i] + sn[i] * Hj[i + 1], b = -sn[i] * Hj[i] + cs[i] * Hj[i + 1];
