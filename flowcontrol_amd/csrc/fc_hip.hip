@@ -2437,6 +2437,7 @@ int fc_solver_setup(fc_handle h, int slot, const int32_t* Ap_rowptr, const int32
   S.ready = false;
   if (S.factor_free) {
     S.factor_free = false;
+    krylov_drop_graphs(h, slot);
     S.pc.release();
     S.ap_src.release();
   }
@@ -3358,7 +3359,8 @@ int fc_setup_krylov(fc_handle h, int slot, int32_t sweeps, int method, int32_t m
     //  they leave the caches: one sweep beyond 16 384 pressure dofs)
     static const int amg_env = [] { const char* e = std::getenv("FC_PC_AMG_SWEEPS"); return e ? std::max(1, std::min(2, std::atoi(e))) : 0; }();
     const int amg_sweeps = amg_env ? amg_env : (X.np <= 16384 ? 2 : 1);
-    // device copy
+    // device copy (graphs captured over the old one hold its sizes and pointers: gone with it)
+    krylov_drop_graphs(h, slot);
     Precond& P = S.pc;
     P.release();
     P.sweeps = sweeps, P.omega = omega, P.nu = X.nu, P.np = X.np;
