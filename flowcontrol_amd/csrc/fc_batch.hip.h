@@ -30,6 +30,9 @@ struct __attribute__((aligned(16))) FcBTask {
   int ncols;      // columns of the block = operand rows of the node
   int op;         // offset of the node's operand row list (buffer row of every column; multiple of 8)
   int dst;        // first destination buffer row
+  int split;      // 0: the task is a whole tile.  Else part | parts << 8: the task covers a run of the tile's 32-column chunks (src / val / op / ncols
+                  // describe that run), its products are a PARTIAL sum: the tile's last-arriving part adds the parts up in part order
+  int pslot;      // first of the tile's `parts` partial slots (16 x KB doubles each); its arrival counter is ticket[pslot]
   int pad;
 };
 
@@ -74,7 +77,10 @@ __global__ __launch_bounds__(256) void fc_b_repack(const FcBTask* __restrict__ t
 template <int KB, bool NT = false>  // NT: the tiled factors exceed the Infinity Cache and are streamed with nontemporal loads (fc_ld in fc_kernels.hip.h)
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FC_B_WPE, FC_B_WPE))) void fc_nd_block_b(
     const FcBTask* __restrict__ tasks, const int* __restrict__ olist, const double* __restrict__ tiled, double* __restrict__ buf, int CG,
-    const unsigned char* __restrict__ velrow = nullptr, int N = 0, int* __restrict__ flag = nullptr) {
+    const unsigned char* __restrict__ velrow = nullptr, int N = 0, int* __restrict__ flag = nullptr, double* __restrict__ part = nullptr,
+    unsigned* __restrict__ ticket = nullptr) {
+  // part / ticket (split tiles, FcBTask::split): the few wide tiles of the levels near the root are cut into runs of chunks, one workgroup
+  // each, so that those launches fill all compute units instead of one per tile (O1 root: 143 tiles of 72 chunks)
   // velrow (overlapped tail): a tile that writes solution rows (buffer rows N .. 2N: the down-sweep) tests what it writes for finiteness,
   // velocity rows only, and raises flag[simulation] -- the reference's test (flowsolver.py:731,816-819) without a pass of its own
   // KB = 32: the matrix instruction's tile is 16 simulations wide, so a wave keeps TWO accumulators (even / odd simulations) and feeds
@@ -191,6 +197,42 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(FC_B_WPE, 
       for (int hh = 0; hh < NH; ++hh)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[hh][r] += fc_b_red[((g * NH + hh) * 4 + r) * 64 + lane];
+  }
+  if (tk.split) {
+    // (wave 0 only from here.)  The partial goes to the coherence point (sc1 stores, drained), then the part arrives on the tile's counter;
+    // the last arriver reads all parts back -- its own too -- and adds them in part order: the sum does not depend on who arrives when
+    const int me = tk.split & 255, np = tk.split >> 8;
+    double* __restrict__ mine = part + (size_t)(tk.pslot + me) * (NH * 256);
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) fc_st_sc1(mine + (hh * 4 + r) * 64 + lane, acc[hh][r]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int last = 0;
+    if (lane == 0) {
+      last = __hip_atomic_fetch_add(ticket + tk.pslot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)np - 1u ? 1 : 0;
+      if (last) __hip_atomic_store(ticket + tk.pslot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!__shfl(last, 0)) return;
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) acc[hh] = fc_d4{0.0, 0.0, 0.0, 0.0};
+    for (int g0 = 0; g0 < np; g0 += 4) {  // four parts' loads in flight at a time (a part per round trip would cost np round trips)
+      double v[4][NH * 4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double* __restrict__ src = part + (size_t)(tk.pslot + (g0 + u < np ? g0 + u : np - 1)) * (NH * 256);
+#pragma unroll
+        for (int q = 0; q < NH * 4; ++q) v[u][q] = fc_ld_sc1(src + q * 64 + lane);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (g0 + u < np) {
+#pragma unroll
+          for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[hh][r] += v[u][hh * 4 + r];
+        }
+    }
   }
 #pragma unroll
   for (int hh = 0; hh < NH; ++hh) {

@@ -469,6 +469,9 @@ struct fc_ctx {
     uint64_t gside_sig[4][4] = {};
     DevBuf<int> flag;                                        // [KB] non-finite velocity seen, per simulation
     DevBuf<FcBTask> tasks;
+    DevBuf<double> part;          // split tiles (FcBTask::split): a partial slot of 16 x 32 doubles per part ...
+    DevBuf<unsigned> ticket;      // ... and the arrival counter of every split tile (at its first slot; self-resetting)
+    int64_t pslots = 0;
     DevBuf<int> trowd;            // tail row blocks: one int4 per row, in the cell order of build_tail_blocks (FcTBlock)
     DevBuf<int> fptr, fsrc;       // up-sweep fold lists: permuted row -> scratch rows (absolute buffer rows) of its descendants
     DevBuf<int> olist;            // per tree node: the buffer row of every operand column ([y rows of the node | x rows of its boundary])
@@ -4869,6 +4872,7 @@ static int build_batch_tables(fc_ctx* h) {
   }
   std::vector<FcBTask> tasks;
   int64_t tiled_off = 0;
+  B.pslots = 0;
   B.launches.clear();
   B.factor_values = 0;
   B.vec_rows = 0.0;
@@ -4898,6 +4902,31 @@ static int build_batch_tables(fc_ctx* h) {
     // crosses the fabric once per XCD that hosts it instead of once per tile.  FC_BATCH_XCD=0: node-major order.
     static const bool xcd_order = [] { const char* e = std::getenv("FC_BATCH_XCD"); return !(e && e[0] == '0'); }();
     std::vector<FcBTask> cls[8];
+    // Wide tiles are cut into parts of about `split_chunks` 32-column chunks, one workgroup each (the kernel's last arriver adds a tile's
+    // parts in part order): a launch with fewer 16-row tiles than compute units -- O1's root is ONE node of 143 tiles x 72 chunks -- or with
+    // a few more than a whole number of rounds of 1024-thread workgroups otherwise streams at half the rate of the others.
+    // FC_BATCH_SPLIT=<chunks> (0: never split)
+    static const int split_chunks = [] { const char* e = std::getenv("FC_BATCH_SPLIT"); return e ? std::max(0, std::atoi(e)) : 16; }();
+    auto push_parts = [&](const FcBTask& whole, std::vector<FcBTask>& out) {
+      const int nchunk = (whole.ncols + 31) / 32;
+      const int parts = split_chunks > 0 && 2 * nchunk >= 3 * split_chunks ? std::min(255, (nchunk + split_chunks / 2) / split_chunks) : 1;
+      if (parts <= 1) {
+        out.push_back(whole);
+        return;
+      }
+      for (int q = 0; q < parts; ++q) {
+        const int c0 = (int)((int64_t)nchunk * q / parts), c1 = (int)((int64_t)nchunk * (q + 1) / parts);
+        FcBTask tk = whole;
+        tk.src += 32 * (int64_t)c0;
+        tk.val += 512 * (int64_t)c0;
+        tk.op += 32 * c0;
+        tk.ncols = std::min(whole.ncols, 32 * c1) - 32 * c0;
+        tk.split = q | (parts << 8);
+        tk.pslot = (int)B.pslots;
+        out.push_back(tk);
+      }
+      B.pslots += parts;
+    };
     int64_t tiles_total = 0;
     for (size_t g : sel) tiles_total += ((up ? nd(g, 4) : nd(g, 3)) + 15) / 16;
     const int64_t run_max = std::max<int64_t>(1, (tiles_total + 7) / 8);  // a node with more tiles is cut into runs of this many
@@ -4917,7 +4946,7 @@ static int build_batch_tables(fc_ctx* h) {
         tk.op = up ? ooff_up[g] : ooff[g];
         tk.dst = up ? (int)(2 * (int64_t)N + soff[g] + r0) : (int)(N + i0 + r0);
         if (!xcd_order) {
-          tasks.push_back(tk);
+          push_parts(tk, tasks);
           continue;
         }
         if (in_run == 0) {  // a new run: the class with the fewest tasks so far
@@ -4925,7 +4954,7 @@ static int build_batch_tables(fc_ctx* h) {
           for (int q = 1; q < 8; ++q)
             if (cls[q].size() < cls[c].size()) c = q;
         }
-        cls[c].push_back(tk);
+        push_parts(tk, cls[c]);
         if (++in_run == run_max) in_run = 0;
       }
       B.factor_values += rows * ld;
@@ -4946,8 +4975,17 @@ static int build_batch_tables(fc_ctx* h) {
         --left;
       }
     }
-    B.launches.push_back({0, first, (int)tasks.size() - first, cg, 0, 0, 0, 0});
-    B.launches.back().mean_chunks = mean_chunks;
+    // (column-group waves of the launch: from the chunks of its TASKS -- a part of a split tile is a task)
+    double tcols = 0.0, trows = 0.0;
+    for (size_t q = (size_t)first; q < tasks.size(); ++q) tcols += (double)tasks[q].nrows * tasks[q].ncols, trows += (double)tasks[q].nrows;
+    const double task_chunks = tcols / std::max(trows, 1.0) / 32.0;
+    cg = 1;
+    while (cg < 16 && task_chunks / cg > chunks_per_wave) cg *= 2;
+    if (force_cg == 1 || force_cg == 2 || force_cg == 4 || force_cg == 8 || force_cg == 16) cg = force_cg;
+    bool any_split = false;
+    for (size_t q = (size_t)first; q < tasks.size(); ++q) any_split = any_split || tasks[q].split != 0;
+    B.launches.push_back({0, first, (int)tasks.size() - first, cg, any_split ? 1 : 0, 0, 0, 0});  // (row0 of a block launch: it has split tiles)
+    B.launches.back().mean_chunks = task_chunks;
   };
   for (int k = t.depth; k >= 1; --k) {
     emit(k, true);
@@ -4963,6 +5001,9 @@ static int build_batch_tables(fc_ctx* h) {
   B.tiled_values = tiled_off;
   B.ftile_ok[0] = B.ftile_ok[1] = false;
   FCCHK(B.tasks.upload(tasks, h->stream));
+  FCCHK(B.part.alloc((size_t)std::max<int64_t>(1, B.pslots) * 512));
+  FCCHK(B.ticket.alloc((size_t)std::max<int64_t>(1, B.pslots)));
+  FCCHK(B.ticket.zero(h->stream));
   FCCHK(B.fptr.upload(fptr, h->stream));
   FCCHK(B.fsrc.upload(fsrc, h->stream));
   FCCHK(B.olist.upload(olist, h->stream));
@@ -5014,17 +5055,21 @@ static int batch_apply(fc_ctx* h, int slot, bool check = false) {
   for (fc_ctx::BLaunch L : B.launches) {
     if (L.kind == 0) {
       if (!(cg_env == 1 || cg_env == 2 || cg_env == 4 || cg_env == 8 || cg_env == 16)) {
+        // (launches with split tiles: 3-4 chunks per wave -- their parts are long enough for the register pipeline to reach its steady state)
+        static const double split_cpw = [] { const char* e = std::getenv("FC_BATCH_SPLIT_CPW"); return e ? std::max(0.5, std::atof(e)) : 0.0; }();
+        const double want = !L.row0 ? cpw : (split_cpw > 0.0 ? split_cpw : (B.KB > 16 ? 4.0 : 3.0));
         int cg = 1;
-        while (cg < 16 && L.mean_chunks / cg > cpw) cg *= 2;
+        while (cg < 16 && L.mean_chunks / cg > want) cg *= 2;
         L.cg = cg;
       }
       const FcBTask* tp = B.tasks.p + L.first;
-#define FC_BLK(K)                                                                                                                                              \
-  do {                                                                                                                                                         \
-    if (nt)                                                                                                                                                    \
-      hipLaunchKernelGGL((fc_nd_block_b<K, true>), dim3(L.count), dim3(64 * L.cg), L.cg > 1 ? (size_t)L.cg * 2048 * (K > 16 ? 2 : 1) : 0, h->stream, tp, B.olist.p, tiled, buf, L.cg, vr, h->N, B.flag.p); \
-    else                                                                                                                                                       \
-      hipLaunchKernelGGL((fc_nd_block_b<K>), dim3(L.count), dim3(64 * L.cg), L.cg > 1 ? (size_t)L.cg * 2048 * (K > 16 ? 2 : 1) : 0, h->stream, tp, B.olist.p, tiled, buf, L.cg, vr, h->N, B.flag.p);   \
+#define FC_BLK(K) \
+  do { \
+    const size_t lds = L.cg > 1 ? (size_t)L.cg * 2048 * (K > 16 ? 2 : 1) : 0; \
+    if (nt) \
+      hipLaunchKernelGGL((fc_nd_block_b<K, true>), dim3(L.count), dim3(64 * L.cg), lds, h->stream, tp, B.olist.p, tiled, buf, L.cg, vr, h->N, B.flag.p, B.part.p, B.ticket.p); \
+    else \
+      hipLaunchKernelGGL((fc_nd_block_b<K>), dim3(L.count), dim3(64 * L.cg), lds, h->stream, tp, B.olist.p, tiled, buf, L.cg, vr, h->N, B.flag.p, B.part.p, B.ticket.p); \
   } while (0)
       FC_KB_DISPATCH(B.KB, FC_BLK(4), FC_BLK(8), FC_BLK(16), FC_BLK(32));
 #undef FC_BLK
@@ -5058,7 +5103,7 @@ int fc_set_batch(fc_handle h, int32_t k) {
     // repack per fc_refactor
     B.ftile[0].release(), B.ftile[1].release();
     B.ftile_ok[0] = B.ftile_ok[1] = false;
-    B.tasks.release(), B.olist.release(), B.fptr.release(), B.fsrc.release(), B.tblocks.release(), B.tcols.release(), B.tlidx.release(), B.trowd.release(), B.ctrl_rows[0].release(), B.ctrl_rows[1].release();
+    B.tasks.release(), B.part.release(), B.ticket.release(), B.olist.release(), B.fptr.release(), B.fsrc.release(), B.tblocks.release(), B.tcols.release(), B.tlidx.release(), B.trowd.release(), B.ctrl_rows[0].release(), B.ctrl_rows[1].release();
     B.ctrl_ok[0] = B.ctrl_ok[1] = false;
     B.launches.clear();
     B.tables = B.tb_built = false;
@@ -5374,7 +5419,7 @@ static uint64_t batch_signature(fc_ctx* h, int order_slot, int compute_energy, i
       (uint64_t)(uintptr_t)h->pin_dev, (uint64_t)(uintptr_t)B.tblocks.p, (uint64_t)(uintptr_t)B.tcols.p, (uint64_t)(uintptr_t)B.tlidx.p, (uint64_t)B.n_tblocks, (uint64_t)B.k, (uint64_t)B.KB, (uint64_t)h->n_act, (uint64_t)h->n_sens, (uint64_t)(h->have_force ? 1 : 0),
       (uint64_t)(S.have_c ? 1 : 0), (uint64_t)compute_energy, (uint64_t)B.launches.size(), (uint64_t)B.tasks.n, bits(c.cm_n), bits(c.cm_nn), bits(c.cc_n),
       bits(c.cc_nn), (uint64_t)lead_elem, (uint64_t)(spec_gather ? 1 : 0), (uint64_t)(B.pend_checked ? 1 : 0), (uint64_t)(uintptr_t)B.ctrl_rows[order_slot].p, (uint64_t)B.n_ctrl_rows[order_slot],
-      (uint64_t)(uintptr_t)B.bstore.p, (uint64_t)(spec_slot + 1), spec_slot >= 0 ? bits(coeffs_for(h, spec_slot).cm_n) : 0,
+      (uint64_t)(uintptr_t)B.bstore.p, (uint64_t)(uintptr_t)B.part.p, (uint64_t)(uintptr_t)B.ticket.p, (uint64_t)(spec_slot + 1), spec_slot >= 0 ? bits(coeffs_for(h, spec_slot).cm_n) : 0,
       spec_slot >= 0 ? bits(coeffs_for(h, spec_slot).cm_nn) : 0, spec_slot >= 0 ? bits(coeffs_for(h, spec_slot).cc_n) : 0,
       spec_slot >= 0 ? bits(coeffs_for(h, spec_slot).cc_nn) : 0};
   uint64_t hsh = 1469598103934665603ull;

@@ -368,3 +368,48 @@ def test_batched_residual_monitor_cadence_and_the_gather_that_runs_ahead(golden_
         assert np.array_equal(a[_ycols(a)].to_numpy(), b[_ycols(b)].to_numpy())
         # (the energy's partial sums sit at other positions of the fold when the row blocks are absent: another summation tree)
         assert np.allclose(a["dE"].to_numpy(), b["dE"].to_numpy(), rtol=1e-13, atol=0.0)
+
+
+_SPLIT_SCRIPT = r"""
+import sys, tempfile, numpy as np
+from flowcontrol_amd._lib import SLOT_BDF2
+from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver
+from flowcontrol_amd.fem.spaces import Function
+fs = CylinderFlowSolver.make_default(Re=100, path_out=tempfile.mkdtemp(), num_steps=4)
+U0, P0 = Function(fs.W, np.load(sys.argv[1])["UP0"]).split()
+fs._assign_steady_state(U0, P0)
+fs.initialize_time_stepping(ic=None)
+fs.step(u_ctrl=[0.0, 0.0])
+dev = fs.th.device()
+rng = np.random.default_rng(11)
+worst = 0.0
+for k in (7, 16, 32):
+    dev.set_batch(k)
+    B = rng.standard_normal((k, dev.N))
+    X = dev.solve_batch(SLOT_BDF2, B)
+    for _ in range(3):
+        assert np.array_equal(dev.solve_batch(SLOT_BDF2, B), X), "a split tile's sum depends on the arrival order of its parts"
+    for s in range(k):
+        x1, _ = dev.solve(SLOT_BDF2, B[s])
+        worst = max(worst, np.linalg.norm(X[s] - x1) / np.linalg.norm(x1))
+print("WORST", worst)
+"""
+
+
+@pytest.mark.parametrize("split", ["2", "0"])
+def test_split_tiles_add_their_parts_in_a_fixed_order(split, golden_dir):
+    """Wide tiles of the batched block sweeps are cut into parts (one workgroup each, ``FcBTask::split``); the tile's last-arriving
+    part adds the partial products in part order.  FC_BATCH_SPLIT=2 cuts every tile of three or more 32-column chunks (the default, 16,
+    only the levels near the root), 0 none: the batched apply must equal the single solves either way and be bit-reproducible from
+    call to call.  (The knob is read once per process: a child process.)"""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, FC_BATCH_SPLIT=split, PYTHONPATH=str(root))
+    out = subprocess.run([sys.executable, "-c", _SPLIT_SCRIPT, str(golden_dir / "cylinder_O1.npz")], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    worst = float([ln for ln in out.stdout.splitlines() if ln.startswith("WORST")][0].split()[1])
+    assert worst < 1e-12
