@@ -383,6 +383,90 @@ __global__ __launch_bounds__(256) void fc_rhs_elem_b(int nc, int nn, const int* 
   }
 }
 
+// The same element loop with ALL of a cell's work on one thread = (cell, simulation): the 24 nodal values of the thread's simulation sit in
+// registers, the basis tables come through the scalar unit (compile-time indices into constant memory), there is no LDS and no barrier.
+// fc_rhs_elem_b above shares the nodal values of a cell between its 7 point threads through LDS -- every thread reads all of them back
+// (75 LDS instructions per thread, 8 clocks each at 16 B per lane): at KB = 32 that is ~20 us of LDS issue alone.  Here the cost is the
+// ~870 fp64 FMAs per (cell, simulation), i.e. 8.7 us at KB = 32 on full-rate vector units.  Same sums in the same order (a = 0..5 inside a
+// point, points 0..6 into the test functions).  FORCE: body-force profiles present (their nodal values take 12 more registers).
+template <int KB, bool FORCE>
+__global__ __launch_bounds__(256) void fc_rhs_elem_breg(int nc, int nn, const int* __restrict__ cn, const int* __restrict__ cnp,
+                                                        const double* __restrict__ geom,
+                                                        const double* __restrict__ un, const double* __restrict__ unn,
+                                                        const double* __restrict__ fprof, int n_act, const double* __restrict__ uforce,
+                                                        int ustride, double cm_n, double cm_nn, double cc_n, double cc_nn,
+                                                        double* __restrict__ ev) {
+  constexpr int CPB = 256 / KB;
+  const int s = (int)threadIdx.x % KB, c = blockIdx.x * CPB + (int)threadIdx.x / KB;
+  if (c >= nc) return;
+  double ax[6], ay[6], bx[6], by[6], fx[FORCE ? 6 : 1], fy[FORCE ? 6 : 1];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    const int ix = cnp[a * nc + c], iy = cnp[(6 + a) * nc + c];
+    ax[a] = un[(size_t)ix * KB + s];
+    ay[a] = un[(size_t)iy * KB + s];
+    bx[a] = unn[(size_t)ix * KB + s];
+    by[a] = unn[(size_t)iy * KB + s];
+    if constexpr (FORCE) {
+      const int n = cn[a * nc + c];
+      double f0 = 0.0, f1 = 0.0;
+      for (int k = 0; k < n_act; ++k) {
+        const double uk = uforce[s * ustride + k];
+        f0 += uk * fprof[(size_t)k * 2 * nn + n];
+        f1 += uk * fprof[(size_t)k * 2 * nn + nn + n];
+      }
+      fx[a] = f0, fy[a] = f1;
+    }
+  }
+  const double j00 = geom[c], j01 = geom[nc + c], j10 = geom[2 * nc + c], j11 = geom[3 * nc + c], hdet = 0.5 * geom[4 * nc + c];
+  double accx[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, accy[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int q = 0; q < FC_NQ; ++q) {
+    double ux = 0.0, uy = 0.0, uxi = 0.0, uet = 0.0, vxi = 0.0, vet = 0.0;
+    double wx = 0.0, wy = 0.0, wxi = 0.0, wet = 0.0, zxi = 0.0, zet = 0.0;
+    double gx = 0.0, gy = 0.0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const double ph = c_phi2[q * 6 + a], dx = c_dphi2[2 * (q * 6 + a)], de = c_dphi2[2 * (q * 6 + a) + 1];
+      ux += ph * ax[a];
+      uy += ph * ay[a];
+      uxi += dx * ax[a];
+      uet += de * ax[a];
+      vxi += dx * ay[a];
+      vet += de * ay[a];
+      wx += ph * bx[a];
+      wy += ph * by[a];
+      wxi += dx * bx[a];
+      wet += de * bx[a];
+      zxi += dx * by[a];
+      zet += de * by[a];
+      if constexpr (FORCE) {
+        gx += ph * fx[a];
+        gy += ph * fy[a];
+      }
+    }
+    const double ux_x = uxi * j00 + uet * j10, ux_y = uxi * j01 + uet * j11;
+    const double uy_x = vxi * j00 + vet * j10, uy_y = vxi * j01 + vet * j11;
+    const double wx_x = wxi * j00 + wet * j10, wx_y = wxi * j01 + wet * j11;
+    const double wy_x = zxi * j00 + zet * j10, wy_y = zxi * j01 + zet * j11;
+    gx += cm_n * ux + cm_nn * wx + cc_n * (ux * ux_x + uy * ux_y) + cc_nn * (wx * wx_x + wy * wx_y);
+    gy += cm_n * uy + cm_nn * wy + cc_n * (ux * uy_x + uy * uy_y) + cc_nn * (wx * wy_x + wy * wy_y);
+    const double wq = c_qw[q] * hdet;
+    gx *= wq;
+    gy *= wq;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      accx[a] += c_phi2[q * 6 + a] * gx;
+      accy[a] += c_phi2[q * 6 + a] * gy;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    ev[((size_t)a * nc + c) * KB + s] = accx[a];
+    ev[((size_t)(6 + a) * nc + c) * KB + s] = accy[a];
+  }
+}
+
 // fc_rhs_gather, one thread per (permuted row, simulation PAIR): every load moves 16 B
 template <int KB>
 __global__ __launch_bounds__(256) void fc_rhs_gather_b(int N, const int* __restrict__ gptr, const int* __restrict__ gidx,

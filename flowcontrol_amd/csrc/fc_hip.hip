@@ -5284,7 +5284,25 @@ static int batch_launches(fc_ctx* h, int order_slot, int compute_energy, int lea
   const double* un = bat_n(h);
   const double* unn = bat_nn(h);
   double* xnew = B.buf.p + (size_t)N * KB;
+  // element loop: one thread per (cell, simulation), everything in registers (fc_rhs_elem_breg); FC_BATCH_ELEM=lds: the LDS-shared form
+  // (thread = (cell, lane8, simulation pair), fc_rhs_elem_b)
+  static const bool elem_reg = [] { const char* e = std::getenv("FC_BATCH_ELEM"); return !(e && std::string(e) == "lds"); }();
   auto element_loop = [&](const StepCoeffs& c, const double* u1, const double* u2) {
+    if (elem_reg) {
+      const int g_reg = nblocks(nc, 256 / KB);
+#define FC_ELEMR(K)                                                                                                                                \
+  do {                                                                                                                                             \
+    if (h->have_force)                                                                                                                             \
+      hipLaunchKernelGGL((fc_rhs_elem_breg<K, true>), dim3(g_reg), dim3(256), 0, h->stream, nc, h->nn, h->cn.p, h->cnp.p, h->geom.p, u1, u2,       \
+                         h->fprof.p, h->n_act, uf, kRecStride, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, B.ev.p);                                          \
+    else                                                                                                                                           \
+      hipLaunchKernelGGL((fc_rhs_elem_breg<K, false>), dim3(g_reg), dim3(256), 0, h->stream, nc, h->nn, h->cn.p, h->cnp.p, h->geom.p, u1, u2,      \
+                         (const double*)nullptr, 0, uf, kRecStride, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, B.ev.p);                                     \
+  } while (0)
+      FC_KB_DISPATCH(KB, FC_ELEMR(4), FC_ELEMR(8), FC_ELEMR(16), FC_ELEMR(32));
+#undef FC_ELEMR
+      return;
+    }
 #define FC_ELEM(K) hipLaunchKernelGGL((fc_rhs_elem_b<K>), dim3(g_elem), dim3(256), 0, h->stream, nc, h->nn, h->cn.p, h->cnp.p, h->geom.p, u1, u2, \
                                       h->have_force ? h->fprof.p : nullptr, h->have_force ? h->n_act : 0, uf, kRecStride, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, B.ev.p)
     FC_KB_DISPATCH(KB, FC_ELEM(4), FC_ELEM(8), FC_ELEM(16), FC_ELEM(32));

@@ -373,13 +373,17 @@ def test_batched_residual_monitor_cadence_and_the_gather_that_runs_ahead(golden_
 _SPLIT_SCRIPT = r"""
 import sys, tempfile, numpy as np
 from flowcontrol_amd._lib import SLOT_BDF2
+from flowcontrol_amd.batch import BatchedFlowSolver
 from flowcontrol_amd.examples.cylinder.cylinderflowsolver import CylinderFlowSolver
 from flowcontrol_amd.fem.spaces import Function
-fs = CylinderFlowSolver.make_default(Re=100, path_out=tempfile.mkdtemp(), num_steps=4)
+from flowcontrol_amd.flowsolverparameters import ParamIC
+fs = CylinderFlowSolver.make_default(Re=100, path_out=tempfile.mkdtemp(), num_steps=8)
 U0, P0 = Function(fs.W, np.load(sys.argv[1])["UP0"]).split()
 fs._assign_steady_state(U0, P0)
+fs.params_ic = ParamIC(xloc=2.0, yloc=0.0, radius=0.5, amplitude=1.0)
 fs.initialize_time_stepping(ic=None)
-fs.step(u_ctrl=[0.0, 0.0])
+u = lambda n: np.array([0.3 * np.sin(0.4 * n), -0.2 * np.cos(0.3 * n)])
+y1 = np.array([fs.step(u_ctrl=u(n)).copy() for n in range(8)])
 dev = fs.th.device()
 rng = np.random.default_rng(11)
 worst = 0.0
@@ -392,23 +396,33 @@ for k in (7, 16, 32):
     for s in range(k):
         x1, _ = dev.solve(SLOT_BDF2, B[s])
         worst = max(worst, np.linalg.norm(X[s] - x1) / np.linalg.norm(x1))
+dev.set_batch(0)
+# the batched STEP (element loop, gather, sweeps, tail) against the single run above
+for k in (3, 32):
+    bfs = BatchedFlowSolver(fs, k)
+    bfs.initialize_time_stepping(ics=[fs.params_ic] * k)
+    yb = np.array([bfs.step(np.tile(u(n), (k, 1))).copy() for n in range(8)])
+    for j in range(k):
+        worst = max(worst, np.linalg.norm(yb[:, j] - y1) / np.linalg.norm(y1))
+    bfs.close()
 print("WORST", worst)
 """
 
 
-@pytest.mark.parametrize("split", ["2", "0"])
-def test_split_tiles_add_their_parts_in_a_fixed_order(split, golden_dir):
+@pytest.mark.parametrize("knobs", [{"FC_BATCH_SPLIT": "2"}, {"FC_BATCH_SPLIT": "0", "FC_BATCH_ELEM": "lds"}], ids=["split2", "nosplit_ldselem"])
+def test_split_tiles_add_their_parts_in_a_fixed_order(knobs, golden_dir):
     """Wide tiles of the batched block sweeps are cut into parts (one workgroup each, ``FcBTask::split``); the tile's last-arriving
     part adds the partial products in part order.  FC_BATCH_SPLIT=2 cuts every tile of three or more 32-column chunks (the default, 16,
     only the levels near the root), 0 none: the batched apply must equal the single solves either way and be bit-reproducible from
-    call to call.  (The knob is read once per process: a child process.)"""
+    call to call.  The second case also runs the LDS-shared element loop (``fc_rhs_elem_b``; the default is the all-register
+    ``fc_rhs_elem_breg``): batched steps must equal the single run with either.  (The knobs are read once per process: a child process.)"""
     import os
     import subprocess
     import sys
     from pathlib import Path
 
     root = Path(__file__).resolve().parents[1]
-    env = dict(os.environ, FC_BATCH_SPLIT=split, PYTHONPATH=str(root))
+    env = dict(os.environ, PYTHONPATH=str(root), **knobs)
     out = subprocess.run([sys.executable, "-c", _SPLIT_SCRIPT, str(golden_dir / "cylinder_O1.npz")], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     worst = float([ln for ln in out.stdout.splitlines() if ln.startswith("WORST")][0].split()[1])
