@@ -1305,6 +1305,19 @@ int build_force_vectors(fc_ctx* h) {
   return FC_OK;
 }
 
+// the element loop of a time step (no body-force profiles: pre-assembled load vectors): eight lanes per cell with the nodal values shared
+// through LDS on small meshes, a thread per cell (fc_rhs_elem_reg) where the cells alone fill the SIMDs (FC_ELEM_REG_MIN cells; 0: never)
+void launch_step_elem(fc_ctx* h, hipStream_t stream, const StepCoeffs& c, const double* ucoef, int ncl) {
+  static const int reg_min = [] { const char* e = std::getenv("FC_ELEM_REG_MIN"); return e ? std::atoi(e) : 40000; }();
+  const int* cells = h->partitioned ? h->cell_list.p : nullptr;
+  if (reg_min > 0 && ncl >= reg_min)
+    hipLaunchKernelGGL(fc_rhs_elem_reg, dim3(nblocks(ncl, 256)), dim3(256), 0, stream, h->nc, h->cnp.p, h->geom.p, st_n(h), st_nn(h), c.cm_n, c.cm_nn,
+                       c.cc_n, c.cc_nn, h->ev.p, cells, ncl);
+  else
+    hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks((int64_t)ncl * 8, 256)), dim3(256), 0, stream, h->nc, h->nn, h->cn.p, h->cnp.p, h->geom.p, st_n(h),
+                       st_nn(h), (const double*)nullptr, 0, ucoef, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p, cells, ncl);
+}
+
 int enqueue_rhs(fc_ctx* h, int order_slot, const double* d_uctrl, const double* d_uforce = nullptr) {
   const StepCoeffs c = coeffs_for(h, order_slot);
   OrderSys& S = h->sys[order_slot];
@@ -1313,10 +1326,7 @@ int enqueue_rhs(fc_ctx* h, int order_slot, const double* d_uctrl, const double* 
   if (h->have_force && !h->fvec_ok) return fail(FC_ERR_NOT_READY, "enqueue_rhs: force vectors not built");
   const bool have_ev = h->pre_slot == order_slot;
   h->pre_slot = -1;
-  if (ncl > 0 && !have_ev)
-    hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks((int64_t)ncl * 8, 256)), dim3(256), 0, h->stream, h->nc, h->nn, h->cn.p, h->cnp.p, h->geom.p,
-                       st_n(h), st_nn(h), (const double*)nullptr, 0, d_uforce, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p,
-                       h->partitioned ? h->cell_list.p : nullptr, ncl);
+  if (ncl > 0 && !have_ev) launch_step_elem(h, h->stream, c, d_uforce, ncl);
   hipLaunchKernelGGL(fc_rhs_gather, dim3(nblocks(h->N, 256)), dim3(256), 0, h->stream, h->N, h->gptr_p.p, h->gidx_p.p,
                      h->ev.p, h->bcslot_p.p, h->bcprof.p, S.lift_p.p, h->n_act, d_uctrl, h->b.p, h->buf.p,
                      h->partitioned ? h->rowkind_p.p : nullptr, h->lead ? 1 : 0, S.have_c ? S.c_rowptr.p : nullptr,
@@ -3929,9 +3939,7 @@ void speculate_next_rhs(fc_ctx* h, int order_slot, hipStream_t stream = nullptr)
   const int next = h->sys[order_slot].have_c ? order_slot : FC_SLOT_BDF2;
   if (!h->sys[next].ready || !h->sys[next].have_lift) return;
   const StepCoeffs c = coeffs_for(h, next);
-  hipLaunchKernelGGL(fc_rhs_elem, dim3(nblocks((int64_t)ncl * 8, 256)), dim3(256), 0, stream, h->nc, h->nn, h->cn.p, h->cnp.p, h->geom.p,
-                     st_n(h), st_nn(h), (const double*)nullptr, 0, h->pin_dev, c.cm_n, c.cm_nn, c.cc_n, c.cc_nn, h->ev.p,
-                     h->partitioned ? h->cell_list.p : nullptr, ncl);
+  launch_step_elem(h, stream, c, h->pin_dev, ncl);
   if (hipGetLastError() == hipSuccess) h->pre_slot = next;
 }
 

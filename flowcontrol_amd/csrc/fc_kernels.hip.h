@@ -118,6 +118,71 @@ __global__ __launch_bounds__(256) void fc_rhs_elem(int nc, int nn, const int* __
   }
 }
 
+// The same loop with a cell's whole work on ONE thread (nodal values in registers, basis tables through the scalar unit, no LDS, no
+// shuffles; the sums run in the same order).  ~870 dependent-ish FMAs per thread: a loss on O1 (12 k cells = less than a wave per SIMD,
+// see above), a gain once the mesh brings >= ~1 wave per SIMD -- the eight-lane form then pays 8 x the threads for the LDS round trip
+// (pinball, 66.7 k cells: 14 us).  No body-force profiles (the time steps use pre-assembled load vectors).
+__global__ __launch_bounds__(256) void fc_rhs_elem_reg(int nc, const int* __restrict__ cnp, const double* __restrict__ geom,
+                                                       const double* __restrict__ un, const double* __restrict__ unn, double cm_n,
+                                                       double cm_nn, double cc_n, double cc_nn, double* __restrict__ ev,
+                                                       const int* __restrict__ cell_list, int ncl) {
+  const int cl = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cl >= ncl) return;
+  const int c = cell_list ? cell_list[cl] : cl;
+  double ax[6], ay[6], bx[6], by[6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    const int ix = cnp[a * nc + c], iy = cnp[(6 + a) * nc + c];
+    ax[a] = un[ix];
+    ay[a] = un[iy];
+    bx[a] = unn[ix];
+    by[a] = unn[iy];
+  }
+  const double j00 = geom[c], j01 = geom[nc + c], j10 = geom[2 * nc + c], j11 = geom[3 * nc + c], hdet = 0.5 * geom[4 * nc + c];
+  double accx[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, accy[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int q = 0; q < FC_NQ; ++q) {
+    double ux = 0, uy = 0, uxi = 0, uet = 0, vxi = 0, vet = 0;
+    double wx = 0, wy = 0, wxi = 0, wet = 0, zxi = 0, zet = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const double ph = c_phi2[q * 6 + a], dx = c_dphi2[(q * 6 + a) * 2], de = c_dphi2[(q * 6 + a) * 2 + 1];
+      ux += ph * ax[a];
+      uy += ph * ay[a];
+      uxi += dx * ax[a];
+      uet += de * ax[a];
+      vxi += dx * ay[a];
+      vet += de * ay[a];
+      wx += ph * bx[a];
+      wy += ph * by[a];
+      wxi += dx * bx[a];
+      wet += de * bx[a];
+      zxi += dx * by[a];
+      zet += de * by[a];
+    }
+    const double ux_x = uxi * j00 + uet * j10, ux_y = uxi * j01 + uet * j11;
+    const double uy_x = vxi * j00 + vet * j10, uy_y = vxi * j01 + vet * j11;
+    const double wx_x = wxi * j00 + wet * j10, wx_y = wxi * j01 + wet * j11;
+    const double wy_x = zxi * j00 + zet * j10, wy_y = zxi * j01 + zet * j11;
+    double gx = 0.0, gy = 0.0;
+    gx += cm_n * ux + cm_nn * wx + cc_n * (ux * ux_x + uy * ux_y) + cc_nn * (wx * wx_x + wy * wx_y);
+    gy += cm_n * uy + cm_nn * wy + cc_n * (ux * uy_x + uy * uy_y) + cc_nn * (wx * wy_x + wy * wy_y);
+    const double wq = c_qw[q] * hdet;
+    gx *= wq;
+    gy *= wq;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      accx[a] += c_phi2[q * 6 + a] * gx;
+      accy[a] += c_phi2[q * 6 + a] * gy;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    ev[(size_t)a * nc + c] = accx[a];
+    ev[(size_t)(6 + a) * nc + c] = accy[a];
+  }
+}
+
 // per (permuted) row: sum the element contributions, lift and impose the Dirichlet data.
 __global__ __launch_bounds__(256) void fc_rhs_gather(int N, const int* __restrict__ gptr,
                                                      const int* __restrict__ gidx,
