@@ -101,6 +101,7 @@ struct Stage {
   int lanes, sub;  // lanes per row, lanes per segment slot
   int64_t blk_begin = 0;  // down stages: LDS-tiled block kernel (fc_nd_down_block) when blk_count > 0
   int blk_count = 0, blk_lpr = 64, blk_rps = 1;
+  int blk_flat = 0;  // > 0: small nodes -- the stage runs fc_nd_flat_block with this many loads per thread (tiles of <= 256 x blk_flat values)
   double bytes;  // algorithmic bytes of this launch
   int64_t wg_begin = -1;  // offset of this launch's workgroup order (OrderSys::wg_order), -1: launch order = row order
   bool nt = false;  // its values are streamed with nontemporal loads (OrderSys::nt, minus the stages kept cache-resident)
@@ -385,6 +386,7 @@ struct fc_ctx {
     struct Lvl {
       int64_t begin;
       int count, lpr, rps, fold_row0, fold_nrows;
+      int flat = 0;  // as Stage::blk_flat
     };
     std::vector<Lvl> lv;  // deepest level first
   } upc;
@@ -761,6 +763,75 @@ int apply_pc(fc_ctx* h, OrderSys& S, const double* in, double* out) {
   return FC_OK;
 }
 
+// levels of small nodes go through the flat block kernel (fc_nd_flat_block): rows up to FC_FLAT_ROW values wide (environment, default 256;
+// 0: never), tiles of at most FC_FLAT_CAP values.  Returns the loads per thread (4, 8, 12, 16) or 0.
+int flat_loads(int max_row, int64_t max_tile) {
+  static const int flat_row = [] { const char* e = std::getenv("FC_FLAT_ROW"); return e ? std::atoi(e) : 256; }();
+  if (flat_row <= 0 || max_row > flat_row || max_row > FC_FLAT_WD || max_tile > FC_FLAT_CAP || max_tile <= 0) return 0;
+  return (int)(4 * ((max_tile + 1023) / 1024));
+}
+
+// values per tile the flat levels aim at (FC_FLAT_TILE; 2048 = 8 loads per thread measured best: refined O1 apply 241.9 -> 234.1 us,
+// pinball 308.3 -> 302.8, cavity_fine 813 -> 806; 4096: 238.2 / 307.8 / 825; 1024: 240.8 / 306.6 / 823)
+int flat_tile_values() {
+  static const int v = [] { const char* e = std::getenv("FC_FLAT_TILE"); return e ? std::min(FC_FLAT_CAP, std::max(256, std::atoi(e))) : 2048; }();
+  return v;
+}
+
+// down stages that will run the flat kernel: their tiles (<= 32 rows of a node, fcsym::down_blocks) are cut into equal runs of rows of at
+// most flat_tile_values() values
+void retile_flat(fcsym::Blocks& B) {
+  fcsym::Blocks R;
+  const size_t nst = B.begin.size();
+  R.begin.assign(nst, 0), R.count.assign(nst, 0), R.lpr = B.lpr;
+  for (size_t s = 0; s < nst; ++s) {
+    R.begin[s] = (int64_t)R.val.size();
+    int max_row = 0;
+    for (int64_t q = B.begin[s]; q < B.begin[s] + B.count[s]; ++q) max_row = std::max(max_row, B.ni[(size_t)q] + B.nb[(size_t)q]);
+    const bool flat = B.count[s] > 0 && flat_loads(max_row, 1) > 0;
+    for (int64_t q = B.begin[s]; q < B.begin[s] + B.count[s]; ++q) {
+      const size_t u = (size_t)q;
+      const int64_t wd = (int64_t)B.ni[u] + B.nb[u];
+      int parts = 1;
+      if (flat && (int64_t)B.nrows[u] * wd > flat_tile_values()) {
+        const int64_t fit = std::max<int64_t>(1, flat_tile_values() / wd);
+        parts = (int)((B.nrows[u] + fit - 1) / fit);
+      }
+      const int rc = (B.nrows[u] + parts - 1) / parts;
+      for (int r0 = 0; r0 < B.nrows[u]; r0 += rc) {
+        R.val.push_back(B.val[u] + (int64_t)r0 * wd);
+        R.row0.push_back(B.row0[u] + r0);
+        R.nrows.push_back(std::min(rc, B.nrows[u] - r0));
+        R.i0.push_back(B.i0[u]), R.ni.push_back(B.ni[u]), R.idx.push_back(B.idx[u]), R.nb.push_back(B.nb[u]);
+      }
+    }
+    R.count[s] = (int)((int64_t)R.val.size() - R.begin[s]);
+  }
+  B = std::move(R);
+}
+
+int launch_flat(fc_ctx* h, const OrderSys& S, const FcBlk* bp, int count, int loads, bool nt, const unsigned char* vr, double* out) {
+#define FC_FLAT(UU)                                                                                                                          \
+  do {                                                                                                                                       \
+    if (nt)                                                                                                                                  \
+      hipLaunchKernelGGL((fc_nd_flat_block<UU, true>), dim3(count), dim3(256), 0, h->stream, bp, S.f_idx.p, S.f_val.p, h->buf.p, h->N, vr,  \
+                         h->flag.p, out);                                                                                                    \
+    else                                                                                                                                     \
+      hipLaunchKernelGGL((fc_nd_flat_block<UU, false>), dim3(count), dim3(256), 0, h->stream, bp, S.f_idx.p, S.f_val.p, h->buf.p, h->N, vr, \
+                         h->flag.p, out);                                                                                                    \
+  } while (0)
+  switch (loads) {
+    case 4: FC_FLAT(4); break;
+    case 8: FC_FLAT(8); break;
+    case 12: FC_FLAT(12); break;
+    case 16: FC_FLAT(16); break;
+    default: return fail(FC_ERR_INVALID, "launch_flat: unsupported tile size");
+  }
+#undef FC_FLAT
+  HIPCHK(hipGetLastError());
+  return FC_OK;
+}
+
 int launch_sweep(fc_ctx* h, const OrderSys& S, const Stage& st) {
   if (st.kind == 2) {
     if (S.dscale.n != (size_t)h->N) return fail(FC_ERR_NOT_READY, "fc_set_stage_diag not called for a truncated factorisation");
@@ -808,6 +879,8 @@ int launch_sweep(fc_ctx* h, const OrderSys& S, const Stage& st) {
     HIPCHK(hipGetLastError());
     return FC_OK;
   }
+  if (st.kind == 1 && st.blk_count > 0 && st.blk_flat > 0)
+    return launch_flat(h, S, S.blk.p + st.blk_begin, st.blk_count, st.blk_flat, st.nt, h->sweep_check ? h->velrow_p.p : nullptr, nullptr);
   if (st.kind == 1 && st.blk_count > 0) {
     const FcBlk* bp = S.blk.p + st.blk_begin;
     const unsigned char* vr = h->sweep_check ? h->velrow_p.p : nullptr;  // (overlapped tail: finiteness tested as the solution is written)
@@ -1022,12 +1095,22 @@ int build_up_column(fc_ctx* h) {
       const int upc_target = upc_env ? upc_env : std::max(2048, block_target(N) / 2);
       while (rc > slots && rows / rc < upc_target) rc /= 2;
       rc = std::max(rc, 1);
+      // small nodes (rows of a few dozen values): the flat kernel, on tiles of as many whole rows as FC_FLAT_CAP values hold
+      int max_ni = 0;
+      for (size_t g : sel) max_ni = std::max(max_ni, (int)nd(g, 3));
+      const bool flat = flat_loads(max_ni, 1) > 0;
+      int64_t max_tile = 0;
       int maxr = 1;
       for (size_t g : sel) {
         const int64_t i0 = nd(g, 2), ni = nd(g, 3), nb = nd(g, 4), voff = nd(g, 5), nf = ni + nb;
         if (ni > FC_BLK_TILE * 64) return fail(FC_ERR_INVALID, "build_up_column: node too large");
+        if (flat) {  // (the node's rows in equal tiles)
+          const int64_t fit = std::max<int64_t>(1, flat_tile_values() / ni), parts = (nb + fit - 1) / fit;
+          rc = (int)((nb + parts - 1) / parts);
+        }
         for (int64_t r0 = 0; r0 < nb; r0 += rc) {
           const int nr = (int)std::min<int64_t>(rc, nb - r0);
+          max_tile = std::max(max_tile, (int64_t)nr * ni);
           blk.push_back(FcBlk{(long long)(voff + ni * nf + r0 * ni), (int)(soff[g] + r0), nr, (int)i0, (int)ni, 0, 0});
           maxr = std::max(maxr, nr);
         }
@@ -1037,6 +1120,7 @@ int build_up_column(fc_ctx* h) {
       int rps = 1;
       while (rps * slots < maxr) rps *= 2;
       L.rps = rps;
+      L.flat = flat ? flat_loads(max_ni, max_tile) : 0;
     }
     const int64_t r0 = t.node_ptr[(size_t)k - 1].front(), r1 = t.node_ptr[(size_t)k - 1].back();
     L.fold_row0 = (int)r0;
@@ -1061,7 +1145,9 @@ static bool up_column_wanted(const fc_ctx* h, const OrderSys& S) { return h->up_
 int launch_up_column(fc_ctx* h, OrderSys& S) {
   fc_ctx::UpCol& U = h->upc;
   for (const fc_ctx::UpCol::Lvl& L : U.lv) {
-    if (L.count > 0) {
+    if (L.count > 0 && L.flat > 0) {
+      FCCHK(launch_flat(h, S, U.blk.p + L.begin, L.count, L.flat, S.nt, nullptr, U.scratch.p));
+    } else if (L.count > 0) {
       const FcBlk* bp = U.blk.p + L.begin;
 #define FC_UPB(LP, R)                                                                                                                      \
   do {                                                                                                                                     \
@@ -2705,6 +2791,13 @@ int fc_solver_set_blocks(fc_handle h, int slot, int32_t n_stages, const int64_t*
     int rps = 1;
     while (rps * slots < maxr) rps *= 2;
     st.blk_rps = rps;
+    int max_row = 0;
+    int64_t max_tile = 0;
+    for (int64_t q = stage_blk_begin[s]; q < stage_blk_begin[s] + stage_blk_count[s]; ++q) {
+      max_row = std::max(max_row, blk_ni[q] + blk_nb[q]);
+      max_tile = std::max(max_tile, (int64_t)blk_nrows[q] * (blk_ni[q] + blk_nb[q]));
+    }
+    st.blk_flat = (stage_blk_count[s] > 0 && S.bits == 64) ? flat_loads(max_row, max_tile) : 0;
   }
   FCCHK(S.blk.upload(packed, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -3252,6 +3345,7 @@ int fc_setup_solver(fc_handle h, int slot, int32_t depth, int32_t merge, int32_t
       const char* em = std::getenv("FC_BLOCK_MIN");
       fcsym::Blocks B = fcsym::down_blocks(t, fac, rank, world, 32, et ? std::max(1, std::atoi(et)) : block_target(N), em ? std::max(1, std::atoi(em)) : 512);
       if (eb && eb[0] == '0') std::fill(B.count.begin(), B.count.end(), 0);
+      retile_flat(B);
       FCCHK(fc_solver_set_blocks(h, slot, (int)B.begin.size(), B.begin.data(), B.count.data(), B.lpr.data(), (int64_t)B.val.size(),
                                  B.val.empty() ? &zero64 : B.val.data(), B.row0.empty() ? &zero32 : B.row0.data(),
                                  B.nrows.empty() ? &zero32 : B.nrows.data(), B.i0.empty() ? &zero32 : B.i0.data(),

@@ -722,6 +722,60 @@ __global__ __launch_bounds__(256) void fc_nd_down_block(const FcBlk* __restrict_
   }
 }
 
+// The same block product for the levels of SMALL nodes (rows of a few dozen values: the leaves and their parents).  A tile (FcBlk: nrows
+// whole rows, row-major, contiguous) is read as ONE flat stream -- thread t takes values t, t + 256, ...: every wave instruction is 512
+// consecutive bytes, all of a thread's U loads are issued back to back, whatever the row width -- into LDS, next to the operand; then 8 lanes
+// per row form the row sums from LDS in a fixed order.  fc_nd_down_block puts LPR lanes on a row: with rows of 30-90 values a wave
+// instruction there touches 8 separate 64-byte pieces and most of a row is a single trip (3.3-4.2 TB/s on the leaf levels of the
+// HBM-streaming meshes where the wide levels reach 4.6-5.4).  Tiles hold <= FC_FLAT_CAP values, rows <= FC_FLAT_WD wide.
+#define FC_FLAT_CAP 4096
+#define FC_FLAT_WD 512
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void fc_nd_flat_block(const FcBlk* __restrict__ blk, const int* __restrict__ idxlist,
+                                                        const double* __restrict__ val, double* __restrict__ buf, int N,
+                                                        const unsigned char* __restrict__ velrow, int* __restrict__ flag,
+                                                        double* __restrict__ out) {
+  __shared__ double xs[FC_FLAT_WD];
+  __shared__ double vs[256 * U];
+  const FcBlk b = blk[blockIdx.x];
+  const int wd = b.ni + b.nb, n = b.nrows * wd, t = threadIdx.x;
+  const double* __restrict__ v = val + b.val;
+  double pv[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {  // unconditional, clamped: a predicated load makes the compiler wait for each one in turn
+    const int e = t + 256 * u;
+    pv[u] = fc_ld<NT>(v + (e < n ? e : 0));
+  }
+  for (int j = t; j < wd; j += 256) xs[j] = j < b.ni ? buf[b.i0 + j] : buf[idxlist[b.idx + (j - b.ni)]];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int e = t + 256 * u;
+    if (e < n) vs[e] = pv[u];
+  }
+  __syncthreads();
+  const int l = t & 7;
+  for (int r = t >> 3; r < b.nrows; r += 32) {
+    const double* __restrict__ row = vs + r * wd;
+    double s0 = 0.0, s1 = 0.0;
+    for (int j = l; j < wd; j += 16) {
+      s0 += row[j] * xs[j];
+      if (j + 8 < wd) s1 += row[j + 8] * xs[j + 8];
+    }
+    double s = s0 + s1;
+    s += __shfl_down(s, 4, 8);
+    s += __shfl_down(s, 2, 8);
+    s += __shfl_down(s, 1, 8);
+    if (l == 0) {
+      if (out) {
+        out[b.row0 + r] = s;
+      } else {
+        buf[N + b.row0 + r] = s;
+        if (velrow && velrow[b.row0 + r] && !isfinite(s)) atomicOr(flag, 1);
+      }
+    }
+  }
+}
+
 // column form of the up-sweep: y[row0 + i] += the scratch slots of the row's descendants, in list order (deepest node first: reproducible)
 __global__ __launch_bounds__(256) void fc_nd_fold1(int nrows, int row0, const int* __restrict__ fptr, const int* __restrict__ fsrc,
                                                    const double* __restrict__ scratch, double* __restrict__ y) {

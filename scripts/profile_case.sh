@@ -27,7 +27,7 @@ for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     c = c[c["Counter_Name"] == name]
     # every launch of a factor apply (segment sweeps, LDS-tiled blocks, the column form's fold launches); applies of the run (time steps,
     # base-flow iterations, acceptance solves alike) = those launches / launches per apply as the library reports them
-    sw = c[c["Kernel_Name"].str.contains("fc_nd_sweep|fc_nd_down_block|fc_nd_fold1")]
+    sw = c[c["Kernel_Name"].str.contains("fc_nd_sweep|fc_nd_down_block|fc_nd_flat_block|fc_nd_fold1")]
     d = json.loads(open(f"{out}/bench_{'fetch' if name == 'FETCH_SIZE' else 'write'}.json").read().strip().splitlines()[-1])
     res["launches_per_apply"] = d["roofline"]["launches_per_apply"]
     n_apply = len(sw.groupby("Dispatch_Id")) / res["launches_per_apply"]
@@ -44,7 +44,7 @@ try:
     tf = pd.read_csv(glob.glob(f"{out}/pmc_fetch/**/*_kernel_trace.csv", recursive=True)[0])
     tf["dur"] = tf["End_Timestamp"] - tf["Start_Timestamp"]
     j = cf.groupby("Dispatch_Id")["Counter_Value"].sum().rename("fetch_kb").to_frame().join(tf.set_index("Dispatch_Id")[["Kernel_Name", "Grid_Size_X", "dur"]], how="inner")
-    j = j[j["Kernel_Name"].str.contains("fc_nd_sweep|fc_nd_down_block|fc_nd_fold1|fc_tail|fc_rhs")]
+    j = j[j["Kernel_Name"].str.contains("fc_nd_sweep|fc_nd_down_block|fc_nd_flat_block|fc_nd_fold1|fc_tail|fc_rhs")]
     j["kernel"] = j["Kernel_Name"].str.replace(r"^void ", "", regex=True).str.slice(0, 34)
     pos = j.groupby(["kernel", "Grid_Size_X"]).agg(n=("dur", "size"), us=("dur", lambda v: v.median() / 1e3), MB=("fetch_kb", lambda v: 2.0 * v.median() * 1024 / 1e6)).reset_index()
     pos["TB/s"] = pos["MB"] / pos["us"]

@@ -58,7 +58,7 @@ for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         d[name + "_launches"] = int(len(grp))
 if traffic:
     # the factor sweeps of one apply: segment kernel (up levels, root) + tiled block kernel (down levels)
-    sweeps = {k: v for k, v in traffic.items() if "fc_nd_sweep" in k or "fc_nd_down_block" in k}
+    sweeps = {k: v for k, v in traffic.items() if "fc_nd_sweep" in k or "fc_nd_down_block" in k or "fc_nd_flat_block" in k}
     tot_f = sum(v.get("FETCH_SIZE_KB_per_launch", 0) * v.get("FETCH_SIZE_launches", 0) for v in sweeps.values())
     n_f = sum(v.get("FETCH_SIZE_launches", 0) for v in sweeps.values())
     tot_w = sum(v.get("WRITE_SIZE_KB_per_launch", 0) * v.get("WRITE_SIZE_launches", 0) for v in sweeps.values())
