@@ -766,7 +766,8 @@ int apply_pc(fc_ctx* h, OrderSys& S, const double* in, double* out) {
 // levels of small nodes go through the flat block kernel (fc_nd_flat_block): rows up to FC_FLAT_ROW values wide (environment, default 256;
 // 0: never), tiles of at most FC_FLAT_CAP values.  Returns the loads per thread (4, 8, 12, 16) or 0.
 int flat_loads(int max_row, int64_t max_tile) {
-  static const int flat_row = [] { const char* e = std::getenv("FC_FLAT_ROW"); return e ? std::atoi(e) : 256; }();
+  const char* e = std::getenv("FC_FLAT_ROW");  // (read per setup, not cached: tests lay out handles with different settings in one process)
+  const int flat_row = e ? std::atoi(e) : 256;
   if (flat_row <= 0 || max_row > flat_row || max_row > FC_FLAT_WD || max_tile > FC_FLAT_CAP || max_tile <= 0) return 0;
   return (int)(4 * ((max_tile + 1023) / 1024));
 }
@@ -774,8 +775,8 @@ int flat_loads(int max_row, int64_t max_tile) {
 // values per tile the flat levels aim at (FC_FLAT_TILE; 2048 = 8 loads per thread measured best: refined O1 apply 241.9 -> 234.1 us,
 // pinball 308.3 -> 302.8, cavity_fine 813 -> 806; 4096: 238.2 / 307.8 / 825; 1024: 240.8 / 306.6 / 823)
 int flat_tile_values() {
-  static const int v = [] { const char* e = std::getenv("FC_FLAT_TILE"); return e ? std::min(FC_FLAT_CAP, std::max(256, std::atoi(e))) : 2048; }();
-  return v;
+  const char* e = std::getenv("FC_FLAT_TILE");
+  return e ? std::min(FC_FLAT_CAP, std::max(256, std::atoi(e))) : 2048;
 }
 
 // down stages that will run the flat kernel: their tiles (<= 32 rows of a node, fcsym::down_blocks) are cut into equal runs of rows of at

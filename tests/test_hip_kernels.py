@@ -214,11 +214,22 @@ def test_block_and_segment_down_sweeps_agree(setup, monkeypatch):
     x_seg, _ = solve()
     monkeypatch.delenv("FC_BLOCK_KERNEL")
     monkeypatch.setenv("FC_BLOCK_MIN", "1")
+    monkeypatch.setenv("FC_FLAT_ROW", "0")  # the row-lane block kernel on every level ...
     for target in (1, 64, 1 << 30):
         monkeypatch.setenv("FC_BLOCK_TARGET", str(target))
         x_blk, info = solve()
         assert _rel(x_blk, x_seg) < 1e-12
         assert info[1] < 1e-9
+    # ... and the flat kernel (fc_nd_flat_block: tiles read as one contiguous stream, row sums from LDS) on the levels of small nodes, through
+    # its four loads-per-thread instantiations (tiles of <= 1024 / 2048 / 3072 / 4096 values), row form and column form of the up-sweep
+    for up_form in ("row", "column"):
+        monkeypatch.setenv("FC_UP_FORM", up_form)
+        for flat_row, tile in ((256, 2048), (512, 1024), (512, 3072), (160, 4096)):
+            monkeypatch.setenv("FC_FLAT_ROW", str(flat_row))
+            monkeypatch.setenv("FC_FLAT_TILE", str(tile))
+            x_flat, info = solve()
+            assert _rel(x_flat, x_seg) < 1e-12, (up_form, flat_row, tile)
+            assert info[1] < 1e-9
 
 
 @pytest.mark.parametrize("wide", [False, True, "huge"])
