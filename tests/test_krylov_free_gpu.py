@@ -60,6 +60,37 @@ def test_factor_free_solve_matches_the_direct_solve(mesh, dt, Re):
     dev.close()
 
 
+def test_factor_free_solve_at_full_size_uses_a_fraction_of_the_factor_memory():
+    """BASELINE config 3's mesh (cavity_fine, 877 k dofs): the factorisation-free solve against the SAME device's direct solve (the
+    oracle's SuperLU needs minutes here; the direct path is pinned to the oracle on this mesh by tests/test_configs_gpu.py), the
+    iteration bar of the small meshes (mesh-independent: ~40 from a zero guess), and the point of the mode: what it holds is O(nnz) —
+    a quarter of the 3.9 GB of factor values the direct mode streams."""
+    from flowcontrol_amd.device import SLOT_BDF2, DeviceSolver
+
+    th = TaylorHood(read_xdmf_mesh(mesh_file("cavity_fine")))
+    dev = DeviceSolver(th)
+    x = th.node_coords
+    dt, Re = 4e-4, 7500.0
+    U0 = np.r_[0.5 * np.sin(2.0 * x[:, 0]) * np.cos(1.3 * x[:, 1]), 0.3 * np.cos(1.1 * x[:, 0] + 0.2) * np.sin(2.0 * x[:, 1])]
+    dofs = _bc(th)
+    dev.set_bc(dofs, np.zeros((dofs.size, 1)))
+    dev.assemble_matrix(SLOT_BDF2, mass=1.5 / dt, nu=1.0 / Re, adv=U0, lin=U0)
+    dev.apply_bc(SLOT_BDF2)
+    b = np.random.default_rng(5).standard_normal(dev.N)
+    b[dofs] = 0.0
+    info = dev.setup_krylov(SLOT_BDF2, sweeps=2, method="gmres", max_iter=300, rtol=1e-12)
+    xs, si = dev.solve(SLOT_BDF2, b)
+    assert si[1] < 1e-11 and 1 < si[0] <= 100, si
+    dev.setup_solver(SLOT_BDF2)  # the same slot, factorised now
+    xd, sd = dev.solve(SLOT_BDF2, b)
+    assert sd[1] < 1e-11
+    assert np.linalg.norm(xs - xd) <= 1e-9 * np.linalg.norm(xd)
+    factor_bytes = 8.0 * dev.factor_nnz[SLOT_BDF2]
+    assert info["bytes"] < 0.3 * factor_bytes, (info["bytes"], factor_bytes)
+    print(f"[cavity_fine] factorisation-free: {int(si[0])} GMRES iterations, {info['bytes'] / 1e6:.0f} MB held against {factor_bytes / 1e6:.0f} MB of factor values")
+    dev.close()
+
+
 def test_factor_free_cavity_with_body_force_follows_the_oracle(tmp_path_factory, golden_dir):
     """The cavity case (Re = 7500, dt = 4e-4, FORCE actuator: the body force enters the element loop, wall-shear integral sensor) with
     no factorisation: 10 steps of the reference's regression scenario against the oracle's series."""
