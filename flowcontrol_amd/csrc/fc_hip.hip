@@ -378,6 +378,7 @@ struct fc_ctx {
   // cavity_fine + 4.5 % steps/s) and costs 6 % on O1, whose launches sit on their floor.  up_form: 0 = auto (column form for slots with
   // OrderSys::nt), 1 = row form, 2 = column form (FC_UP_FORM=auto|row|column, read by fc_create)
   int up_form = 0;
+  int elem_reg_min = 40000;  // FC_ELEM_REG_MIN (read by fc_create): meshes / cell lists of at least this many cells run the element loop on a thread per cell
   struct UpCol {
     bool ready = false, tried = false;
     DevBuf<FcBlk> blk;
@@ -1393,9 +1394,9 @@ int build_force_vectors(fc_ctx* h) {
 }
 
 // the element loop of a time step (no body-force profiles: pre-assembled load vectors): eight lanes per cell with the nodal values shared
-// through LDS on small meshes, a thread per cell (fc_rhs_elem_reg) where the cells alone fill the SIMDs (FC_ELEM_REG_MIN cells; 0: never)
+// through LDS on small meshes, a thread per cell (fc_rhs_elem_reg) where the cells alone fill the SIMDs (fc_ctx::elem_reg_min cells; 0: never)
 void launch_step_elem(fc_ctx* h, hipStream_t stream, const StepCoeffs& c, const double* ucoef, int ncl) {
-  static const int reg_min = [] { const char* e = std::getenv("FC_ELEM_REG_MIN"); return e ? std::atoi(e) : 40000; }();
+  const int reg_min = h->elem_reg_min;
   const int* cells = h->partitioned ? h->cell_list.p : nullptr;
   if (reg_min > 0 && ncl >= reg_min)
     hipLaunchKernelGGL(fc_rhs_elem_reg, dim3(nblocks(ncl, 256)), dim3(256), 0, stream, h->nc, h->cnp.p, h->geom.p, st_n(h), st_nn(h), c.cm_n, c.cm_nn,
@@ -2037,6 +2038,7 @@ int fc_create(fc_handle* out, int device, int32_t nv, int32_t ne, int32_t nc, co
   TRYHIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
   if (const char* e = std::getenv("FC_OVERLAP_TAIL")) h->overlap = e[0] != '0';
   if (const char* e = std::getenv("FC_GATE_SPIN")) h->gate_spin = std::max(0L, std::atol(e));
+  if (const char* e = std::getenv("FC_ELEM_REG_MIN")) h->elem_reg_min = std::atoi(e);
   if (const char* e = std::getenv("FC_UP_FORM")) h->up_form = std::string(e) == "row" ? 1 : (std::string(e) == "column" ? 2 : 0);
   TRYHIP(hipEventCreate(&h->ev0));
   TRYHIP(hipEventCreate(&h->ev1));
