@@ -593,8 +593,8 @@ def run_rank(comm, args, device):
         tim = dev.get_timing()
         dev.set_timing(False)
         sweep_bytes, spmv_bytes = dev.algorithmic_bytes(SLOT_BDF2)
-        n_stage = 2 * dev.depth + 1
-        applies = tim["sweep_launches"] / max(n_stage, 1)
+        applies = args.steps  # one factor apply per step (direct mode, no refinement sweeps)
+        n_stage = tim["sweep_launches"] / max(applies, 1)  # launches per apply: 2 depth + 1 in the row form of the up-sweep (+ depth folds in the column form)
         mean_launch_ms = tim["sweep_ms"] / max(tim["sweep_launches"], 1)
         bytes_per_launch = sweep_bytes / n_stage
         achieved = bytes_per_launch / mean_launch_ms / 1e6  # GB/s
